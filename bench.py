@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/sec of the MI355X-native vectorised env stepper.
+
+Metric (BASELINE.json): env steps/sec (whole node), 4096 envs per GPU,
+synthetic random-action rollouts (rl_baselines/random_agent.py:35-42).
+
+One bench "step" = one srlhip_rollout() pass: every env of this rank's shard
+advances `inner_steps` VecEnv steps (auto-reset inside, random-agent actions
+drawn on the device, observation / reward / done planes streamed to HBM).
+value = total env-steps of all ranks / max-over-ranks wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kuka|mobile]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "robotics-rl-srl_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec)
+# algorithmic bytes per env-step
+ALG_BYTES = {"mobile": 73, "kuka": 213}
+PUBLISHED_REFERENCE_FPS = 250.0   # /root/reference/README.md:9 (8 cores, with 224x224 rendering)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="auto", choices=["auto", "kuka", "mobile"])
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--inner-steps", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
+    return ap.parse_args()
+
+
+def kuka_available():
+    from srlhip import _lib
+    try:
+        cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+        cfg.num_envs = 1
+        _lib.Handle(cfg).close()
+        return True
+    except _lib.SrlHipError:
+        return False
+
+
+def cpu_baseline(workload, n_envs, budget_s=12.0):
+    """Oracle ('port') timed on this box's host cores, rank 0, N=1 only."""
+    from oracle import clib
+    cores = 1
+    if workload == "mobile":
+        T = 1024
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < min(budget_s, 4.0):
+            clib.mobile_rollout(0, np.arange(n_envs), T, actions=None, rng_mode=clib.RNG_PHILOX)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": reps * T * n_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                "sample": "oracle/mobile_oracle.c, {} envs x {} steps x {} passes, 1 thread, physics only "
+                          "(no rendering)".format(n_envs, T, reps)}
+    from oracle import kuka_clib
+    return kuka_clib.cpu_baseline(budget_s)
+
+
+def main():
+    args = parse()
+    from srlhip import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "kuka" if kuka_available() else "mobile"
+    n = args.envs_per_gpu
+    inner = args.inner_steps or (256 if workload == "mobile" else 32)
+    K = args.steps if args.steps is not None else (40 if workload == "mobile" else 20)
+    W = args.warmup if args.warmup is not None else (5 if workload == "mobile" else 3)
+
+    kind = _lib.ENV_MOBILE if workload == "mobile" else _lib.ENV_KUKA_BUTTON
+    cfg = _lib.default_config(kind)
+    cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, local_rank, rank * n, 0
+    cfg.rng_mode = _lib.RNG_PHILOX if args.rng == "philox" else _lib.RNG_MT19937
+    cfg.auto_reset, cfg.io_device = 1, 1
+    h = _lib.Handle(cfg)
+    od = h.obs_dim
+    obs0 = torch.zeros((n, od), dtype=torch.float32, device=dev)
+    obs = torch.zeros((inner, n, od), dtype=torch.float32, device=dev)
+    rew = torch.zeros((inner, n), dtype=torch.float32, device=dev)
+    done = torch.zeros((inner, n), dtype=torch.uint8, device=dev)
+    act = torch.zeros((inner, n), dtype=torch.int32, device=dev)
+    out = (obs.data_ptr(), rew.data_ptr(), done.data_ptr(), act.data_ptr())
+    h.reset(obs_out=obs0.data_ptr())
+    h.sync()
+
+    ep_ret_ptr = h.device_ptr(_lib.F_EP_RETURN)
+    gathered = None
+    if world > 1:
+        import torch.distributed as dist
+        gathered = torch.zeros((world * n,), dtype=torch.float32, device=dev)
+
+    def one_step():
+        h.rollout(inner, out=out)
+        if world > 1:
+            # the path's only exchange: episode returns, once per rollout, RCCL over xGMI
+            h.sync()
+            local = rew.sum(dim=0)
+            dist.all_gather_into_tensor(gathered, local)
+
+    def fence():
+        h.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(W):
+        one_step()
+    fence()
+    h.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one_step()
+    kernel_ms = h.timing_end()          # HIP events on the stepper's own stream
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_env_steps = world * n * inner * K
+    value = total_env_steps / dt
+    steps_per_launch = n * inner
+    avg_launch_s = kernel_ms * 1e-3 / K
+    achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "mobile_rollout_k" if workload == "mobile" else "kuka_step_k",
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
+    if workload == "kuka":
+        from srlhip import kuka_model
+        flops = kuka_model.FLOPS_PER_ENV_STEP
+        tf = flops * steps_per_launch / avg_launch_s / 1e12
+        roofline.update({"note": "Kuka stepper is FP64-VALU / dependency-latency bound, not HBM bound "
+                                 "(SURVEY §7 hard parts); HBM fraction reported because the north star asks for it",
+                         "valu_fp64_tflops": tf, "valu_fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "valu_frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_env_step": flops})
+    line = {
+        "metric": "env steps/sec (whole node), {} {} envs/GPU".format(
+            "KukaButtonGymEnv" if workload == "kuka" else "MobileRobotGymEnv", n),
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "{}-v0 ground_truth obs, {} envs per GPU, random-agent discrete actions".format(
+            "KukaButtonGymEnv" if workload == "kuka" else "MobileRobotGymEnv", n),
+            "envs_per_gpu": n, "inner_steps": inner, "env_steps_per_bench_step": world * n * inner,
+            "rng_mode": args.rng, "auto_reset": True, "parallelism": "env-shard x{}".format(world),
+            "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(workload, n)
+            line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
+        except Exception as exc:      # the checker must never sink the measurement
+            line["cpu_baseline"] = {"value": None, "error": repr(exc)}
+    h.close()
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+/*
+ * srlhip.h — C-ABI of libsrlhip, the MI355X (gfx950) vectorised env stepper.
+ *
+ * Drop-in boundary for the env-step hot path of araffin/robotics-rl-srl.
+ * The reference has no native ABI of its own (pure Python over the
+ * third-party pybullet wheel); the seam it exposes is Python-level:
+ *   - per-env gym surface      environments/srl_env.py:5-102
+ *   - vec-env assembly         rl_baselines/utils.py:194-229 (createEnvs)
+ *   - dataset generator loop   environments/dataset_generator.py:38-117
+ * Each entry point below names the reference interface it replaces.
+ * The Python host side (robotics-rl-srl_amd/srlhip) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SRLHIP_E* code otherwise;
+ *     srlhip_last_error() gives the message (per handle; NULL handle ->
+ *     thread-local message of the last failed srlhip_create).
+ *   - the library owns all device memory (structure-of-arrays, one array per
+ *     field, env index fastest).  Pointer arguments are borrowed for the call.
+ *     cfg.io_device = 0: they are HOST pointers (the call copies and
+ *     synchronises);  cfg.io_device = 1: they are DEVICE pointers on
+ *     cfg.device_id and the call only enqueues work on the handle's stream
+ *     (srlhip_sync() or the returned stream to order against it).
+ *   - one HIP stream per handle; a handle is not thread-safe; distinct handles
+ *     are independent (no global mutable state) -> one handle per GPU.
+ *   - "env id" i of a handle is GLOBAL env cfg.first_env_id + i; every random
+ *     stream is derived from the global id so results are invariant to how
+ *     envs are sharded across GPUs (environments/utils.py:52 seeds seed+rank).
+ */
+#ifndef SRLHIP_H
+#define SRLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRLHIP_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define SRLHIP_OK            0
+#define SRLHIP_EINVAL      (-22)  /* bad argument / unsupported combination     */
+#define SRLHIP_ENOMEM      (-12)
+#define SRLHIP_EHIP        (-5)   /* HIP runtime error (no device, launch fail) */
+#define SRLHIP_ENOTSUP     (-95)  /* e.g. continuous actions on Mobile2Target   */
+
+/* ---- env kinds: environments/registry.py:41-53 -------------------------- */
+#define SRLHIP_ENV_MOBILE          0  /* MobileRobotGymEnv-v0            */
+#define SRLHIP_ENV_MOBILE_1D       1  /* MobileRobot1DGymEnv-v0          */
+#define SRLHIP_ENV_MOBILE_2TARGET  2  /* MobileRobot2TargetGymEnv-v0     */
+#define SRLHIP_ENV_MOBILE_LINE     3  /* MobileRobotLineTargetGymEnv-v0  */
+#define SRLHIP_ENV_KUKA_BUTTON     4  /* KukaButtonGymEnv-v0             */
+
+/* ---- observation modes: kuka_button_gym_env.py:162-173 ------------------ */
+#define SRLHIP_OBS_GROUND_TRUTH     0  /* f32[obs_dim] relative position        */
+#define SRLHIP_OBS_JOINTS           1  /* Kuka only: 14 constant joint values   */
+#define SRLHIP_OBS_JOINTS_POSITION  2  /* Kuka only: 3 + 14                      */
+#define SRLHIP_OBS_RAW_PIXELS       3  /* u8[H,W,3(6)] from the tile rasteriser  */
+
+/* ---- random-number modes ------------------------------------------------- */
+#define SRLHIP_RNG_HOST     0  /* caller supplies every random draw (parity harness)        */
+#define SRLHIP_RNG_PHILOX   1  /* device Philox4x32-10 keyed (seed, global env id): throughput */
+#define SRLHIP_RNG_MT19937  2  /* device-resident numpy RandomState per env: reproduces the
+                                  reference's env.np_random stream (srl_env.py:71-78)       */
+
+typedef struct srlhip_env *srlhip_handle;
+
+typedef struct srlhip_config {
+    int32_t struct_size;      /* = sizeof(srlhip_config), ABI check                        */
+    int32_t env_kind;         /* SRLHIP_ENV_*                                              */
+    int32_t num_envs;         /* envs owned by this handle (this GPU's shard)              */
+    int32_t device_id;        /* HIP device ordinal                                        */
+    int32_t first_env_id;     /* global id of env 0 (sharding offset)                      */
+    int32_t is_discrete;      /* ctor kwarg is_discrete   (mobile_robot_env.py:61)         */
+    int32_t random_target;    /* ctor kwarg random_target                                  */
+    int32_t force_down;       /* ctor kwarg force_down    (Kuka)                           */
+    int32_t shape_reward;     /* ctor kwarg shape_reward                                   */
+    int32_t action_repeat;    /* ctor kwarg action_repeat (Kuka, >=1)                      */
+    int32_t action_joints;    /* ctor kwarg action_joints (Kuka)                           */
+    int32_t obs_mode;         /* SRLHIP_OBS_*  (ctor kwarg srl_model)                      */
+    int32_t img_h, img_w;     /* raw_pixels size (reference: 224x224)                      */
+    int32_t multi_view;       /* ctor kwarg multi_view (Kuka, 6-channel image)             */
+    int32_t rng_mode;         /* SRLHIP_RNG_*                                              */
+    int32_t auto_reset;       /* 1: step() resets finished envs itself and returns the first
+                                 observation of the next episode (SB VecEnv semantics,
+                                 rl_baselines/utils.py:216-220); needs rng_mode != HOST     */
+    int32_t io_device;        /* 0 host pointers, 1 device pointers (see Conventions)      */
+    int64_t seed0;            /* base seed: env i is seeded seed0 + first_env_id + i       */
+    double  max_distance;     /* ctor kwarg max_distance                                   */
+} srlhip_config;
+
+/* Fill *cfg with the reference's ctor defaults for env_kind
+ * (kuka_button_gym_env.py:78-81, mobile_robot_env.py:61-64). */
+int srlhip_default_config(int32_t env_kind, srlhip_config *cfg);
+
+/* Replaces: env construction in makeEnv/_make (environments/utils.py:36-95),
+ * one call for the whole batch instead of one process per env. Seeds every env
+ * with seed0 + global id, but does not reset. */
+int srlhip_create(const srlhip_config *cfg, srlhip_handle *out);
+int srlhip_destroy(srlhip_handle h);
+
+/* Shapes implied by the config (observation_space / action_space of the env). */
+int srlhip_obs_dim(srlhip_handle h);          /* floats per env (ground truth modes)   */
+int srlhip_obs_bytes(srlhip_handle h);        /* bytes per env of one observation      */
+int srlhip_action_dim(srlhip_handle h);       /* 1 (discrete) | 2 | 3 | 7              */
+int srlhip_num_actions(srlhip_handle h);      /* Discrete(n): n ; 0 if continuous      */
+
+/* Replaces SRLGymEnv.seed (srl_env.py:71-78) for the envs selected by mask
+ * (NULL = all).  seeds[i] is the integer the reference would pass to
+ * env.seed(); MT19937 mode hashes it exactly like gym (sha512 -> init_by_array).
+ * mask/seeds are always HOST pointers. */
+int srlhip_seed(srlhip_handle h, const uint8_t *mask, const int64_t *seeds);
+
+/* Replaces <Env>.reset() (mobile_robot_env.py:159-222, kuka_button_gym_env.py:214-281)
+ * for the envs selected by mask (NULL = all; HOST pointer).
+ * host_rand: RNG_HOST only — [num_envs][srlhip_reset_rand_count()] doubles, the
+ *            values the reference's np_random calls would return, in draw order.
+ * obs_out:   [num_envs][obs] — rows of unselected envs are left untouched. */
+int srlhip_reset(srlhip_handle h, const uint8_t *mask, const double *host_rand, void *obs_out);
+int srlhip_reset_rand_count(srlhip_handle h);
+
+/* Replaces VecEnv.step / <Env>.step (mobile_robot_env.py:235-280,
+ * kuka_button_gym_env.py:293-368) for the whole batch.
+ * actions: discrete -> int32[num_envs], value -1 == the reference's `None`
+ *          action (kuka_button_gym_env.py:295-299);  continuous -> float[num_envs][adim].
+ * host_noise: RNG_HOST only — double[num_envs], value of np_random.normal(...) per env.
+ * obs_out [num_envs][obs], reward_out float[num_envs], done_out uint8[num_envs].
+ * With cfg.auto_reset the observation of a finished env is the first one of its
+ * next episode. */
+int srlhip_step(srlhip_handle h, const void *actions, const double *host_noise,
+                void *obs_out, float *reward_out, uint8_t *done_out);
+
+/* Fused rollout: T consecutive steps with auto-reset, outputs streamed as
+ * [T][num_envs] planes.  Replaces the random-agent hot loop
+ * (rl_baselines/random_agent.py:35-42, dataset_generator.py:91-105).
+ * actions_TN: int32/float [T][num_envs]([adim]) or NULL -> uniform random
+ * actions drawn on the device (returned in act_out_TN if not NULL).
+ * Requires cfg.auto_reset and rng_mode != HOST.  Any output may be NULL. */
+int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
+                   void *obs_TN, float *reward_TN, uint8_t *done_TN, void *act_out_TN);
+
+/* Raw state access (checkpoint / parity): field ids below; arrays are
+ * [num_envs] (or [k][num_envs] for vector fields) of the field's own type.
+ * Always HOST pointers. */
+#define SRLHIP_F_POS_X          0   /* f64 */
+#define SRLHIP_F_POS_Y          1   /* f64 */
+#define SRLHIP_F_TARGET_X       2   /* f64 (current target for 2Target)      */
+#define SRLHIP_F_TARGET_Y       3   /* f64 */
+#define SRLHIP_F_STEP_COUNT     4   /* i32 _env_step_counter                 */
+#define SRLHIP_F_CUR_TARGET     5   /* i32 current_target (2Target)          */
+#define SRLHIP_F_LAST_REWARD    6   /* f64 reward of the last step, uncast   */
+#define SRLHIP_F_EP_RETURN      7   /* f64 running episode return            */
+#define SRLHIP_F_EP_LENGTH      8   /* i32 running episode length            */
+#define SRLHIP_F_KUKA_Q         16  /* f64[7]  arm joint positions           */
+#define SRLHIP_F_KUKA_QD        17  /* f64[7]  arm joint velocities          */
+#define SRLHIP_F_KUKA_EE_TARGET 18  /* f64[3]  Kuka.end_effector_pos         */
+#define SRLHIP_F_KUKA_BUTTON_Q  19  /* f64[2]  glider position, velocity     */
+#define SRLHIP_F_KUKA_BUTTON_POS 20 /* f64[3]  button_pos (target)           */
+#define SRLHIP_F_KUKA_GRIPPER   21  /* f64[3]  getArmPos()                   */
+#define SRLHIP_F_KUKA_COUNTERS  22  /* i32[3]  n_contacts, n_steps_outside, terminated */
+int srlhip_get_state(srlhip_handle h, int32_t field, void *out);
+int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
+/* Zero-copy hand-off of a field's device array (e.g. to torch via
+ * __cuda_array_interface__). */
+int srlhip_device_ptr(srlhip_handle h, int32_t field, void **dptr);
+
+/* Per-env statistics of the most recently FINISHED episode and the number of
+ * finished episodes: what stable_baselines.bench.Monitor records
+ * (environments/utils.py:54).  HOST pointers, any may be NULL. */
+int srlhip_episode_stats(srlhip_handle h, double *last_return, int32_t *last_length,
+                         int32_t *n_finished);
+
+/* Stream ordering and live kernel timing (HIP events on the handle's stream). */
+int srlhip_sync(srlhip_handle h);
+int srlhip_stream(srlhip_handle h, void **hip_stream);
+int srlhip_timing_begin(srlhip_handle h);
+int srlhip_timing_end(srlhip_handle h, float *elapsed_ms);   /* synchronises */
+
+const char *srlhip_last_error(srlhip_handle h);
+int srlhip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRLHIP_H */

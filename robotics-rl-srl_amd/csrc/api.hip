@@ -1,0 +1,425 @@
+// api.hip — C-ABI front end of libsrlhip (include/srlhip.h): handle lifetime,
+// seeding, host<->device staging, state access, timing.  The env kernels live
+// in mobile.hip / kuka.hip.
+#include <string.h>
+
+#include <new>
+
+#include "internal.hpp"
+
+using namespace srl;
+
+namespace {
+
+thread_local std::string g_create_error;
+constexpr int kBlock = 256;
+
+bool is_mobile(int kind) { return kind >= SRLHIP_ENV_MOBILE && kind <= SRLHIP_ENV_MOBILE_LINE; }
+
+// RandomState.seed(digits) for the selected envs, one lane per env.
+__global__ void mt_seed_k(Mt19937View v, int n, const uint8_t *mask, const uint32_t *digits, const int32_t *len) {
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n || (mask && !mask[e])) return;
+    uint32_t key[2] = {digits[e], digits[n + e]};
+    Mt19937 m;
+    m.load(v, e);
+    m.seed_by_array(key, len[e]);
+    m.store(v, e);
+}
+
+__global__ void key_seed_k(RngState r, int n, const uint8_t *mask, const uint32_t *lohi) {
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n || (mask && !mask[e])) return;
+    r.key[e] = lohi[e]; r.key[n + e] = lohi[n + e];
+    r.ctr[e] = 0; r.act_ctr[e] = 0;
+}
+
+int ensure(Handle *h, void **buf, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    SRL_HIP_CHECK(h, hipMalloc(buf, bytes));
+    *cap = bytes;
+    return 0;
+}
+int stage_in(Handle *h, void **buf, size_t *cap, const void *host, size_t bytes) {
+    int rc = ensure(h, buf, cap, bytes);
+    if (rc) return rc;
+    SRL_HIP_CHECK(h, hipMemcpyAsync(*buf, host, bytes, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+size_t action_bytes(const Handle *h) {
+    return (size_t)h->n * (h->cfg.is_discrete ? sizeof(int32_t) : sizeof(float) * action_dim_of(h->cfg));
+}
+size_t obs_bytes_per_env(const Handle *h) {
+    if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
+        return (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.multi_view ? 6 : 3);
+    return sizeof(float) * obs_dim_of(h->cfg);
+}
+
+int set_device(Handle *h) {
+    SRL_HIP_CHECK(h, hipSetDevice(h->cfg.device_id));
+    return 0;
+}
+
+int seed_impl(Handle *h, const uint8_t *mask, const int64_t *seeds) {
+    const int n = h->n;
+    std::vector<uint32_t> lohi(2 * (size_t)n), digits(2 * (size_t)n);
+    std::vector<int32_t> len(n);
+    for (int i = 0; i < n; i++) {
+        uint64_t s = (uint64_t)seeds[i];
+        lohi[i] = (uint32_t)s; lohi[n + i] = (uint32_t)(s >> 32);
+        if (h->cfg.rng_mode == SRLHIP_RNG_MT19937 && (!mask || mask[i])) {
+            if (seeds[i] < 0) return h->fail(SRLHIP_EINVAL, "seed must be a non-negative integer (gym seeding)");
+            uint32_t d[2];
+            len[i] = gym_hash_seed(s, d);
+            if (len[i] == 0) return h->fail(SRLHIP_EINVAL, "seed hashes to an empty key");
+            digits[i] = d[0]; digits[n + i] = d[1];
+        }
+    }
+    int rc;
+    const uint8_t *d_mask = nullptr;
+    if (mask) {
+        if ((rc = stage_in(h, &h->st_mask, &h->st_mask_sz, mask, n))) return rc;
+        d_mask = static_cast<const uint8_t *>(h->st_mask);
+    }
+    dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    if ((rc = stage_in(h, &h->st_rand, &h->st_rand_sz, lohi.data(), lohi.size() * 4))) return rc;
+    hipLaunchKernelGGL(key_seed_k, grid, block, 0, h->stream, h->rng, n, d_mask,
+                       static_cast<const uint32_t *>(h->st_rand));
+    SRL_HIP_CHECK(h, hipGetLastError());
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // host vectors die at return
+    if (h->cfg.rng_mode == SRLHIP_RNG_MT19937) {
+        if ((rc = stage_in(h, &h->st_rand, &h->st_rand_sz, digits.data(), digits.size() * 4))) return rc;
+        if ((rc = stage_in(h, &h->st_noise, &h->st_noise_sz, len.data(), len.size() * 4))) return rc;
+        hipLaunchKernelGGL(mt_seed_k, grid, block, 0, h->stream, h->rng.mt, n, d_mask,
+                           static_cast<const uint32_t *>(h->st_rand), static_cast<const int32_t *>(h->st_noise));
+        SRL_HIP_CHECK(h, hipGetLastError());
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int field_lookup(Handle *h, int field, void **dptr, size_t *elem, int *count) {
+    *count = 1;
+    switch (field) {
+        case SRLHIP_F_LAST_REWARD: *dptr = h->stats.last_reward; *elem = 8; return 0;
+        case SRLHIP_F_EP_RETURN: *dptr = h->stats.ep_return; *elem = 8; return 0;
+        case SRLHIP_F_EP_LENGTH: *dptr = h->stats.ep_length; *elem = 4; return 0;
+    }
+    if (is_mobile(h->cfg.env_kind)) return mobile_field(h, field, dptr, elem, count);
+    return kuka_field(h, field, dptr, elem, count);
+}
+
+}  // namespace
+
+extern "C" {
+
+int srlhip_abi_version(void) { return SRLHIP_ABI_VERSION; }
+
+int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
+    if (!cfg || env_kind < SRLHIP_ENV_MOBILE || env_kind > SRLHIP_ENV_KUKA_BUTTON) return SRLHIP_EINVAL;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = (int32_t)sizeof *cfg;
+    cfg->env_kind = env_kind;
+    cfg->num_envs = 1;
+    cfg->is_discrete = 1;
+    cfg->force_down = 1;
+    cfg->action_repeat = 1;
+    cfg->obs_mode = SRLHIP_OBS_GROUND_TRUTH;
+    cfg->img_h = cfg->img_w = 224;                                  // RENDER_HEIGHT/WIDTH
+    cfg->rng_mode = SRLHIP_RNG_MT19937;
+    cfg->auto_reset = 1;
+    cfg->max_distance = env_kind == SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
+    return 0;
+}
+
+const char *srlhip_last_error(srlhip_handle hh) {
+    if (!hh) return g_create_error.c_str();
+    return reinterpret_cast<Handle *>(hh)->err.c_str();
+}
+
+int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
+    if (!cfg || !out) { g_create_error = "create: null argument"; return SRLHIP_EINVAL; }
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(srlhip_config)) {
+        g_create_error = "create: srlhip_config.struct_size mismatch (ABI)"; return SRLHIP_EINVAL;
+    }
+    if (cfg->num_envs <= 0) { g_create_error = "create: num_envs must be positive"; return SRLHIP_EINVAL; }
+    if (cfg->env_kind < SRLHIP_ENV_MOBILE || cfg->env_kind > SRLHIP_ENV_KUKA_BUTTON) {
+        g_create_error = "create: unknown env_kind"; return SRLHIP_EINVAL;
+    }
+    if (cfg->rng_mode < SRLHIP_RNG_HOST || cfg->rng_mode > SRLHIP_RNG_MT19937) {
+        g_create_error = "create: unknown rng_mode"; return SRLHIP_EINVAL;
+    }
+    if (cfg->auto_reset && cfg->rng_mode == SRLHIP_RNG_HOST) {
+        g_create_error = "create: auto_reset needs a device RNG mode"; return SRLHIP_EINVAL;
+    }
+    if (!cfg->is_discrete &&
+        (cfg->env_kind == SRLHIP_ENV_MOBILE_1D || cfg->env_kind == SRLHIP_ENV_MOBILE_2TARGET)) {
+        // mobile_robot_1D_env.py:44, mobile_robot_2target_env.py:128-129 raise ValueError
+        g_create_error = "Only discrete actions is supported"; return SRLHIP_ENOTSUP;
+    }
+    if (is_mobile(cfg->env_kind) && cfg->obs_mode != SRLHIP_OBS_GROUND_TRUTH &&
+        cfg->obs_mode != SRLHIP_OBS_RAW_PIXELS) {
+        g_create_error = "create: MobileRobot envs support ground_truth / raw_pixels only"; return SRLHIP_EINVAL;
+    }
+    if (cfg->env_kind == SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
+        g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;
+    }
+    hipError_t e = hipSetDevice(cfg->device_id);
+    if (e != hipSuccess) {
+        g_create_error = std::string("create: hipSetDevice failed (no MI355X visible?): ") + hipGetErrorString(e);
+        return SRLHIP_EHIP;
+    }
+    Handle *h = new (std::nothrow) Handle();
+    if (!h) { g_create_error = "create: out of host memory"; return SRLHIP_ENOMEM; }
+    h->cfg = *cfg; h->n = cfg->num_envs; h->kuka = nullptr;
+    h->st_actions = h->st_noise = h->st_obs = h->st_rew = h->st_done = h->st_mask = h->st_rand = nullptr;
+    h->st_actions_sz = h->st_noise_sz = h->st_obs_sz = h->st_rew_sz = h->st_done_sz = h->st_mask_sz = h->st_rand_sz = 0;
+    memset(&h->rng, 0, sizeof h->rng); memset(&h->stats, 0, sizeof h->stats); memset(&h->mobile, 0, sizeof h->mobile);
+    int rc = 0;
+    auto bail = [&](int code) { g_create_error = h->err; srlhip_destroy(reinterpret_cast<srlhip_handle>(h)); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        h->stream = nullptr; h->ev_begin = h->ev_end = nullptr; h->err = "create: hipStreamCreate failed";
+        return bail(SRLHIP_EHIP);
+    }
+    (void)hipEventCreate(&h->ev_begin); (void)hipEventCreate(&h->ev_end);
+    const size_t n = (size_t)h->n;
+    if ((rc = h->dalloc(&h->rng.key, 2 * n)) || (rc = h->dalloc(&h->rng.ctr, n)) || (rc = h->dalloc(&h->rng.act_ctr, n)))
+        return bail(rc);
+    if (cfg->rng_mode == SRLHIP_RNG_MT19937) {
+        h->rng.mt.stride = (int64_t)n;
+        if ((rc = h->dalloc(&h->rng.mt.mt, (size_t)MT_N * n)) || (rc = h->dalloc(&h->rng.mt.mti, n)) ||
+            (rc = h->dalloc(&h->rng.mt.has_gauss, n)) || (rc = h->dalloc(&h->rng.mt.gauss, n)))
+            return bail(rc);
+    }
+    EpisodeStats &st = h->stats;
+    if ((rc = h->dalloc(&st.ep_return, n)) || (rc = h->dalloc(&st.ep_length, n)) || (rc = h->dalloc(&st.last_return, n)) ||
+        (rc = h->dalloc(&st.last_length, n)) || (rc = h->dalloc(&st.n_finished, n)) || (rc = h->dalloc(&st.last_reward, n)))
+        return bail(rc);
+    rc = is_mobile(cfg->env_kind) ? mobile_alloc(h) : kuka_alloc(h);
+    if (rc) return bail(rc);
+    std::vector<int64_t> seeds(n);
+    for (size_t i = 0; i < n; i++) seeds[i] = cfg->seed0 + cfg->first_env_id + (int64_t)i;   // environments/utils.py:52
+    if ((rc = seed_impl(h, nullptr, seeds.data()))) return bail(rc);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "create: device initialisation failed"; return bail(SRLHIP_EHIP); }
+    *out = reinterpret_cast<srlhip_handle>(h);
+    return 0;
+}
+
+int srlhip_destroy(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->kuka) kuka_free(h);
+    for (void *p : h->allocs) (void)hipFree(p);
+    void *st[] = {h->st_actions, h->st_noise, h->st_obs, h->st_rew, h->st_done, h->st_mask, h->st_rand};
+    for (void *p : st) if (p) (void)hipFree(p);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int srlhip_obs_dim(srlhip_handle hh) { return hh ? obs_dim_of(reinterpret_cast<Handle *>(hh)->cfg) : SRLHIP_EINVAL; }
+int srlhip_obs_bytes(srlhip_handle hh) { return hh ? (int)obs_bytes_per_env(reinterpret_cast<Handle *>(hh)) : SRLHIP_EINVAL; }
+int srlhip_action_dim(srlhip_handle hh) { return hh ? action_dim_of(reinterpret_cast<Handle *>(hh)->cfg) : SRLHIP_EINVAL; }
+int srlhip_num_actions(srlhip_handle hh) { return hh ? num_actions_of(reinterpret_cast<Handle *>(hh)->cfg) : SRLHIP_EINVAL; }
+
+int srlhip_reset_rand_count(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    return is_mobile(h->cfg.env_kind) ? mobile_reset_rand_count(h->cfg) : kuka_reset_rand_count(h->cfg);
+}
+
+int srlhip_seed(srlhip_handle hh, const uint8_t *mask, const int64_t *seeds) {
+    if (!hh || !seeds) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    return rc ? rc : seed_impl(h, mask, seeds);
+}
+
+int srlhip_reset(srlhip_handle hh, const uint8_t *mask, const double *host_rand, void *obs_out) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int n = h->n;
+    const uint8_t *d_mask = nullptr;
+    if (mask) {
+        if ((rc = stage_in(h, &h->st_mask, &h->st_mask_sz, mask, n))) return rc;
+        d_mask = static_cast<const uint8_t *>(h->st_mask);
+    }
+    const double *d_rand = host_rand;
+    void *d_obs = obs_out;
+    const size_t ob = obs_bytes_per_env(h) * n;
+    if (!h->cfg.io_device) {
+        if (host_rand) {
+            size_t bytes = sizeof(double) * (size_t)srlhip_reset_rand_count(hh) * n;
+            if ((rc = stage_in(h, &h->st_rand, &h->st_rand_sz, host_rand, bytes))) return rc;
+            d_rand = static_cast<const double *>(h->st_rand);
+        }
+        if (obs_out) {
+            // unselected rows must keep the caller's contents
+            if ((rc = stage_in(h, &h->st_obs, &h->st_obs_sz, obs_out, ob))) return rc;
+            d_obs = h->st_obs;
+        }
+    }
+    rc = is_mobile(h->cfg.env_kind) ? mobile_reset(h, d_mask, d_rand, static_cast<float *>(d_obs))
+                                    : kuka_reset(h, d_mask, d_rand, d_obs);
+    if (rc) return rc;
+    if (!h->cfg.io_device) {
+        if (obs_out) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_out, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    } else if (mask) {
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // staged mask must stay valid
+    }
+    return 0;
+}
+
+int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise, void *obs_out, float *reward_out,
+                uint8_t *done_out) {
+    if (!hh || !actions) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int n = h->n;
+    if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !host_noise)
+        return h->fail(SRLHIP_EINVAL, "step: RNG_HOST needs host_noise");
+    const void *d_act = actions; const double *d_noise = host_noise;
+    void *d_obs = obs_out; float *d_rew = reward_out; uint8_t *d_done = done_out;
+    const size_t ob = obs_bytes_per_env(h) * n;
+    if (!h->cfg.io_device) {
+        if ((rc = stage_in(h, &h->st_actions, &h->st_actions_sz, actions, action_bytes(h)))) return rc;
+        d_act = h->st_actions;
+        if (host_noise) {
+            if ((rc = stage_in(h, &h->st_noise, &h->st_noise_sz, host_noise, sizeof(double) * n))) return rc;
+            d_noise = static_cast<const double *>(h->st_noise);
+        }
+        if (obs_out) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, ob))) return rc; d_obs = h->st_obs; }
+        if (reward_out) { if ((rc = ensure(h, &h->st_rew, &h->st_rew_sz, 4 * (size_t)n))) return rc; d_rew = static_cast<float *>(h->st_rew); }
+        if (done_out) { if ((rc = ensure(h, &h->st_done, &h->st_done_sz, n))) return rc; d_done = static_cast<uint8_t *>(h->st_done); }
+    }
+    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, d_act, d_noise, static_cast<float *>(d_obs), d_rew, d_done)
+                                    : kuka_step(h, d_act, d_noise, d_obs, d_rew, d_done);
+    if (rc) return rc;
+    if (!h->cfg.io_device) {
+        if (obs_out) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_out, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
+        if (reward_out) SRL_HIP_CHECK(h, hipMemcpyAsync(reward_out, d_rew, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        if (done_out) SRL_HIP_CHECK(h, hipMemcpyAsync(done_out, d_done, n, hipMemcpyDeviceToHost, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int srlhip_rollout(srlhip_handle hh, int32_t T, const void *actions_TN, void *obs_TN, float *reward_TN,
+                   uint8_t *done_TN, void *act_out_TN) {
+    if (!hh || T <= 0) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!h->cfg.auto_reset || h->cfg.rng_mode == SRLHIP_RNG_HOST)
+        return h->fail(SRLHIP_EINVAL, "rollout: needs auto_reset and a device RNG mode");
+    const size_t n = (size_t)h->n, tn = n * (size_t)T;
+    const void *d_act = actions_TN; void *d_obs = obs_TN; float *d_rew = reward_TN; uint8_t *d_done = done_TN;
+    void *d_act_out = act_out_TN;
+    const size_t ob = obs_bytes_per_env(h) * tn, ab = action_bytes(h) * (size_t)T;
+    if (!h->cfg.io_device) {
+        if (actions_TN) { if ((rc = stage_in(h, &h->st_actions, &h->st_actions_sz, actions_TN, ab))) return rc; d_act = h->st_actions; }
+        else if (act_out_TN) { if ((rc = ensure(h, &h->st_actions, &h->st_actions_sz, ab))) return rc; d_act_out = h->st_actions; }
+        if (obs_TN) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, ob))) return rc; d_obs = h->st_obs; }
+        if (reward_TN) { if ((rc = ensure(h, &h->st_rew, &h->st_rew_sz, 4 * tn))) return rc; d_rew = static_cast<float *>(h->st_rew); }
+        if (done_TN) { if ((rc = ensure(h, &h->st_done, &h->st_done_sz, tn))) return rc; d_done = static_cast<uint8_t *>(h->st_done); }
+    }
+    rc = is_mobile(h->cfg.env_kind)
+             ? mobile_rollout(h, T, d_act, static_cast<float *>(d_obs), d_rew, d_done, actions_TN ? nullptr : d_act_out)
+             : kuka_rollout(h, T, d_act, d_obs, d_rew, d_done, actions_TN ? nullptr : d_act_out);
+    if (rc) return rc;
+    if (!h->cfg.io_device) {
+        if (obs_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_TN, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
+        if (reward_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(reward_TN, d_rew, 4 * tn, hipMemcpyDeviceToHost, h->stream));
+        if (done_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(done_TN, d_done, tn, hipMemcpyDeviceToHost, h->stream));
+        if (act_out_TN && !actions_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(act_out_TN, d_act_out, ab, hipMemcpyDeviceToHost, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int srlhip_get_state(srlhip_handle hh, int32_t field, void *out) {
+    if (!hh || !out) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    void *d; size_t elem; int count;
+    if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    SRL_HIP_CHECK(h, hipMemcpy(out, d, elem * count * (size_t)h->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int srlhip_set_state(srlhip_handle hh, int32_t field, const void *in) {
+    if (!hh || !in) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    void *d; size_t elem; int count;
+    if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    SRL_HIP_CHECK(h, hipMemcpy(d, in, elem * count * (size_t)h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int srlhip_device_ptr(srlhip_handle hh, int32_t field, void **dptr) {
+    if (!hh || !dptr) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    size_t elem; int count;
+    return field_lookup(h, field, dptr, &elem, &count);
+}
+
+int srlhip_episode_stats(srlhip_handle hh, double *last_return, int32_t *last_length, int32_t *n_finished) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->n;
+    if (last_return) SRL_HIP_CHECK(h, hipMemcpy(last_return, h->stats.last_return, 8 * n, hipMemcpyDeviceToHost));
+    if (last_length) SRL_HIP_CHECK(h, hipMemcpy(last_length, h->stats.last_length, 4 * n, hipMemcpyDeviceToHost));
+    if (n_finished) SRL_HIP_CHECK(h, hipMemcpy(n_finished, h->stats.n_finished, 4 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int srlhip_sync(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int srlhip_stream(srlhip_handle hh, void **hip_stream) {
+    if (!hh || !hip_stream) return SRLHIP_EINVAL;
+    *hip_stream = reinterpret_cast<Handle *>(hh)->stream;
+    return 0;
+}
+
+int srlhip_timing_begin(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    SRL_HIP_CHECK(h, hipEventRecord(h->ev_begin, h->stream));
+    return 0;
+}
+
+int srlhip_timing_end(srlhip_handle hh, float *elapsed_ms) {
+    if (!hh || !elapsed_ms) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    SRL_HIP_CHECK(h, hipEventRecord(h->ev_end, h->stream));
+    SRL_HIP_CHECK(h, hipEventSynchronize(h->ev_end));
+    SRL_HIP_CHECK(h, hipEventElapsedTime(elapsed_ms, h->ev_begin, h->ev_end));
+    return 0;
+}
+
+}  // extern "C"

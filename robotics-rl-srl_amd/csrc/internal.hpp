@@ -1,0 +1,132 @@
+// internal.hpp — handle layout shared by the C-ABI front end (api.hip) and the
+// kernel translation units (mobile.hip, kuka.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/srlhip.h"
+#include "rng.hpp"
+
+namespace srl {
+
+// ---- per-env random-stream state (all modes allocated lazily) --------------
+struct RngState {
+    Mt19937View mt;        // RNG_MT19937
+    uint32_t *key;         // [2][N] Philox key (seed lo, hi) — also the action stream in every mode
+    uint64_t *ctr;         // [N] Philox block counter, env stream
+    uint64_t *act_ctr;     // [N] Philox block counter, synthetic-agent action stream
+};
+
+// ---- episode accounting (bench.Monitor equivalent, environments/utils.py:54)
+struct EpisodeStats {
+    double *ep_return;       // running
+    int32_t *ep_length;      // running
+    double *last_return;     // of the most recently finished episode
+    int32_t *last_length;
+    int32_t *n_finished;
+    double *last_reward;     // reward of the last step, uncast (f64)
+};
+
+// ---- MobileRobot family: SoA state, f64 exactly as the reference's numpy ---
+struct MobileState {
+    double *pos_x, *pos_y;       // robot_pos[:2]            (mobile_robot_env.py:97)
+    double *tgt_x, *tgt_y;       // target_pos / button_pos[0]
+    double *tgt2_x, *tgt2_y;     // button_pos[1]            (2Target only)
+    int32_t *counter;            // _env_step_counter
+    int32_t *cur_target;         // current_target           (2Target only)
+};
+
+struct MobileParams {
+    int32_t kind, is_discrete, random_target, shape_reward, auto_reset;
+    int32_t n;
+};
+
+struct Handle;
+
+// mobile.hip
+int mobile_alloc(Handle *h);
+void mobile_free(Handle *h);
+int mobile_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, float *d_obs);
+int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *d_obs, float *d_rew,
+                uint8_t *d_done);
+int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done,
+                   void *d_act_out);
+int mobile_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
+int mobile_reset_rand_count(const srlhip_config &c);
+
+// kuka.hip
+int kuka_alloc(Handle *h);
+void kuka_free(Handle *h);
+int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void *d_obs);
+int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_obs, float *d_rew,
+              uint8_t *d_done);
+int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_rew, uint8_t *d_done,
+                 void *d_act_out);
+int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
+int kuka_reset_rand_count(const srlhip_config &c);
+
+struct KukaState;   // defined in kuka.hip
+
+struct Handle {
+    srlhip_config cfg;
+    int n;
+    hipStream_t stream;
+    hipEvent_t ev_begin, ev_end;
+    std::string err;
+    RngState rng;
+    EpisodeStats stats;
+    MobileState mobile;
+    KukaState *kuka;
+    std::vector<void *> allocs;      // everything hipMalloc'ed for this handle
+    // staging buffers for io_device == 0
+    void *st_actions, *st_noise, *st_obs, *st_rew, *st_done, *st_mask, *st_rand;
+    size_t st_actions_sz, st_noise_sz, st_obs_sz, st_rew_sz, st_done_sz, st_mask_sz, st_rand_sz;
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+    template <class T>
+    int dalloc(T **p, size_t count) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+        if (e != hipSuccess) return fail(SRLHIP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        e = hipMemsetAsync(q, 0, count * sizeof(T), stream);
+        if (e != hipSuccess) return fail(SRLHIP_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
+        allocs.push_back(q);
+        *p = static_cast<T *>(q);
+        return 0;
+    }
+};
+
+#define SRL_HIP_CHECK(h, expr)                                                                     \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return (h)->fail(SRLHIP_EHIP, std::string(#expr ": ") + hipGetErrorString(e__));       \
+    } while (0)
+
+inline int obs_dim_of(const srlhip_config &c) {
+    switch (c.env_kind) {
+        case SRLHIP_ENV_MOBILE_1D: return 1;
+        case SRLHIP_ENV_MOBILE: case SRLHIP_ENV_MOBILE_2TARGET: case SRLHIP_ENV_MOBILE_LINE: return 2;
+        case SRLHIP_ENV_KUKA_BUTTON:
+            return c.obs_mode == SRLHIP_OBS_JOINTS ? 14 : c.obs_mode == SRLHIP_OBS_JOINTS_POSITION ? 17 : 3;
+    }
+    return 0;
+}
+inline int num_actions_of(const srlhip_config &c) {
+    if (!c.is_discrete) return 0;
+    switch (c.env_kind) {
+        case SRLHIP_ENV_MOBILE_1D: return 2;
+        case SRLHIP_ENV_KUKA_BUTTON: return 6;
+        default: return 4;
+    }
+}
+inline int action_dim_of(const srlhip_config &c) {
+    if (c.is_discrete) return 1;
+    if (c.env_kind == SRLHIP_ENV_KUKA_BUTTON) return c.action_joints ? 7 : 3;
+    return 2;
+}
+
+}  // namespace srl

@@ -1,0 +1,383 @@
+// mobile.hip — MobileRobot family stepper for gfx950 (MI355X).
+//
+// Replaces, for a whole batch of envs per launch:
+//   reset   mobile_robot_env.py:159-222 (+ variants: 1D :58-74, 2Target :35-67,
+//           LineTarget :56-64) — only the RNG draws and state init; every
+//           pybullet call on this path is scene loading / rendering.
+//   step    mobile_robot_env.py:235-280, _reward :345-363, _termination :336-343
+//           (2Target reward :162-181, LineTarget reward :108-125, 1D step :108-147)
+//
+// Mapping: one lane per env, structure-of-arrays state (env index fastest) so
+// a wavefront's 64 loads/stores of a field are one coalesced 512-byte row.
+// Arithmetic is float64 with -ffp-contract=off, the reference's numpy f64; the
+// only fused op is the explicit fma chain of np.linalg.norm's ddot (see
+// norm2()).  ~40 flops per env-step: the path is HBM/launch bound, no LDS, no
+// MFMA.  mobile_rollout_k keeps the state in VGPRs for T steps and streams the
+// [T][N] observation / reward / done planes with non-temporal stores.
+#include "internal.hpp"
+
+namespace srl {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// np.linalg.norm(v, 2) == sqrt(ddot(v, v)); OpenBLAS accumulates with FMA.
+__device__ __forceinline__ double norm2(double a) { return sqrt(fma(a, a, 0.0)); }
+__device__ __forceinline__ double norm2(double a, double b) { return sqrt(fma(b, b, fma(a, a, 0.0))); }
+
+struct MobileEnv {
+    double x, y, tx, ty, t2x, t2y;
+    int32_t counter, cur;
+};
+
+__device__ __forceinline__ void load_env(const MobileState &s, int e, MobileEnv &m) {
+    m.x = s.pos_x[e]; m.y = s.pos_y[e]; m.tx = s.tgt_x[e]; m.ty = s.tgt_y[e];
+    m.t2x = s.tgt2_x[e]; m.t2y = s.tgt2_y[e]; m.counter = s.counter[e]; m.cur = s.cur_target[e];
+}
+__device__ __forceinline__ void store_env(const MobileState &s, int e, const MobileEnv &m) {
+    s.pos_x[e] = m.x; s.pos_y[e] = m.y; s.tgt_x[e] = m.tx; s.tgt_y[e] = m.ty;
+    s.tgt2_x[e] = m.t2x; s.tgt2_y[e] = m.t2y; s.counter[e] = m.counter; s.cur_target[e] = m.cur;
+}
+
+// Random sources ---------------------------------------------------------------
+struct HostRng {                 // SRLHIP_RNG_HOST: caller pre-drew everything
+    const double *rand; int i; double noise;
+    __device__ double uniform(double, double) { return rand[i++]; }
+    __device__ double normal(double, double) { return noise; }
+};
+struct PhiloxRng {               // SRLHIP_RNG_PHILOX
+    Philox p;
+    __device__ double uniform(double lo, double hi) { return p.uniform(lo, hi); }
+    // scale == 0 draws nothing: counter streams need no alignment with numpy
+    __device__ double normal(double loc, double scale) { return scale == 0.0 ? loc : p.normal(loc, scale); }
+};
+struct MtRng {                   // SRLHIP_RNG_MT19937: np_random itself
+    Mt19937 m;
+    __device__ double uniform(double lo, double hi) { return m.uniform(lo, hi); }
+    __device__ double normal(double loc, double scale) { return m.normal(loc, scale); }
+};
+
+template <int MODE> struct RngSel;
+template <> struct RngSel<SRLHIP_RNG_HOST> { using type = HostRng; };
+template <> struct RngSel<SRLHIP_RNG_PHILOX> { using type = PhiloxRng; };
+template <> struct RngSel<SRLHIP_RNG_MT19937> { using type = MtRng; };
+
+template <int MODE>
+__device__ __forceinline__ void rng_load(typename RngSel<MODE>::type &r, const RngState &rs, int e, int n,
+                                         const double *host_rand, int rand_stride, const double *noise) {
+    if constexpr (MODE == SRLHIP_RNG_HOST) {
+        r.rand = host_rand ? host_rand + (int64_t)e * rand_stride : nullptr;
+        r.i = 0;
+        r.noise = noise ? noise[e] : 0.0;
+    } else if constexpr (MODE == SRLHIP_RNG_PHILOX) {
+        r.p.k0 = rs.key[e]; r.p.k1 = rs.key[n + e]; r.p.ctr = rs.ctr[e]; r.p.stream = 0;
+    } else {
+        r.m.load(rs.mt, e);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void rng_store(const typename RngSel<MODE>::type &r, const RngState &rs, int e) {
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = r.p.ctr;
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) r.m.store(rs.mt, e);
+}
+
+// reset: mobile_robot_env.py:166-181 and the variant overrides -------------------
+template <class R>
+__device__ __forceinline__ void reset_env(const MobileParams &p, R &rng, MobileEnv &m) {
+    const double max_x = 4.0, max_y = 4.0;
+    m.cur = 0;
+    m.x = max_x / 2 + rng.uniform(-max_x / 3, max_x / 3);
+    m.y = 0.0;
+    if (p.kind != SRLHIP_ENV_MOBILE_1D) m.y = max_y / 2 + rng.uniform(-max_y / 3, max_y / 3);
+    const double margin = 0.1 * max_x;
+    m.tx = 0.9 * max_x; m.ty = 0.0; m.t2x = 0.0; m.t2y = 0.0;
+    if (p.kind == SRLHIP_ENV_MOBILE_1D) {
+        if (p.random_target) m.tx = rng.uniform(0 + margin, max_x - margin);
+    } else if (p.kind == SRLHIP_ENV_MOBILE_LINE) {
+        if (p.random_target) m.tx = rng.uniform(0 + margin, max_x - margin);
+        m.ty = max_x;
+    } else {
+        m.ty = max_y * 3 / 4;
+        if (p.random_target) {
+            m.tx = rng.uniform(0 + margin, max_x - margin);
+            m.ty = rng.uniform(0 + margin, max_y - margin);
+        }
+        if (p.kind == SRLHIP_ENV_MOBILE_2TARGET) {
+            m.t2x = 0.1 * max_x; m.t2y = max_y * 3 / 4;
+            if (p.random_target) {
+                m.t2x = rng.uniform(0 + margin, max_x - margin);
+                m.t2y = rng.uniform(0 + margin, max_y - margin);
+            }
+        }
+    }
+    m.counter = 0;
+}
+
+// getSRLState for ground_truth: getGroundTruth() - getTargetPos() (srl_env.py:39-42)
+__device__ __forceinline__ void observe(const MobileParams &p, const MobileEnv &m, float &o0, float &o1) {
+    double tx = m.cur ? m.t2x : m.tx, ty = m.cur ? m.t2y : m.ty;
+    if (p.kind == SRLHIP_ENV_MOBILE_LINE) {          // 1-vector target broadcast over (x, y)
+        double t = tx - 0.2;
+        o0 = (float)(m.x - t); o1 = (float)(m.y - t);
+    } else {
+        o0 = (float)(m.x - tx); o1 = (float)(m.y - ty);
+    }
+}
+
+// step: mobile_robot_env.py:235-280 --------------------------------------------
+__device__ __forceinline__ void step_env(const MobileParams &p, MobileEnv &m, int a, float a0, float a1, double dv,
+                                         double &reward, bool &done) {
+    double dx = 0.0, dy = 0.0;
+    if (p.is_discrete) {
+        if (p.kind == SRLHIP_ENV_MOBILE_1D) {
+            dx = a == 0 ? -dv : a == 1 ? dv : 0.0;
+        } else {
+            dx = a == 0 ? -dv : a == 1 ? dv : 0.0;
+            dy = a == 2 ? -dv : a == 3 ? dv : 0.0;
+        }
+    } else {
+        // float32 Box action * python-float dv: numpy keeps float32 (value-based casting)
+        float fdv = (float)dv;
+        dx = (double)(fmaxf(fminf(a0, 1.0f), -1.0f) * fdv);
+        dy = (double)(fmaxf(fminf(a1, 1.0f), -1.0f) * fdv);
+    }
+    const double px = m.x, py = m.y;
+    m.x = m.x + dx;
+    if (p.kind != SRLHIP_ENV_MOBILE_1D) m.y = m.y + dy;
+    // collision with the arena walls: x first, `break` on the first violation
+    const double margin_x = 0.1 + (0.325 * 2) / 2, margin_y = 0.1 + 0.2 / 2;
+    bool bumped = false;
+    if (m.x < margin_x || m.x > 4 - margin_x) {
+        bumped = true;
+    } else if (p.kind != SRLHIP_ENV_MOBILE_1D && (m.y < margin_y || m.y > 4 - margin_y)) {
+        bumped = true;
+    }
+    if (bumped) { m.x = px; m.y = py; }
+    m.counter += 1;
+    // _reward
+    double tx = m.cur ? m.t2x : m.tx, ty = m.cur ? m.t2y : m.ty;
+    double distance, threshold = 0.4;
+    if (p.kind == SRLHIP_ENV_MOBILE_LINE) {
+        distance = fabs((tx - 0.2) - m.x);
+        threshold = 0.1;
+    } else if (p.kind == SRLHIP_ENV_MOBILE_1D) {
+        distance = norm2(tx - m.x);
+    } else {
+        distance = norm2(tx - m.x, ty - m.y);
+    }
+    reward = 0.0;
+    if (distance <= threshold) {
+        reward = 1.0;
+        if (p.kind == SRLHIP_ENV_MOBILE_2TARGET && m.cur < 1) m.cur += 1;
+    }
+    if (bumped) reward = -1.0;
+    if (p.shape_reward) reward = -distance;
+    done = m.counter > 250;                           // terminated is never set (:336-343)
+}
+
+__device__ __forceinline__ void account(const EpisodeStats &st, int e, double reward, bool done) {
+    double r = st.ep_return[e] + reward;
+    int32_t l = st.ep_length[e] + 1;
+    st.last_reward[e] = reward;
+    if (done) {
+        st.last_return[e] = r; st.last_length[e] = l; st.n_finished[e] += 1;
+        r = 0.0; l = 0;
+    }
+    st.ep_return[e] = r; st.ep_length[e] = l;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+mobile_reset_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, const uint8_t *mask,
+               const double *host_rand, int rand_stride, float *obs) {
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.n) return;
+    if (mask && !mask[e]) return;
+    typename RngSel<MODE>::type rng;
+    rng_load<MODE>(rng, rs, e, p.n, host_rand, rand_stride, nullptr);
+    MobileEnv m;
+    load_env(s, e, m);
+    reset_env(p, rng, m);
+    store_env(s, e, m);
+    rng_store<MODE>(rng, rs, e);
+    st.ep_return[e] = 0.0; st.ep_length[e] = 0;
+    if (obs) {
+        float o0, o1;
+        observe(p, m, o0, o1);
+        if (p.kind == SRLHIP_ENV_MOBILE_1D) obs[e] = o0;
+        else reinterpret_cast<float2 *>(obs)[e] = make_float2(o0, o1);
+    }
+}
+
+// Synthetic random-agent action (rl_baselines/random_agent.py:36): Philox stream 1.
+__device__ __forceinline__ void sample_action(const MobileParams &p, const RngState &rs, int e, uint64_t &actr,
+                                              int &a, float &a0, float &a1) {
+    Philox ph; ph.k0 = rs.key[e]; ph.k1 = rs.key[p.n + e]; ph.ctr = actr; ph.stream = 1;
+    if (p.is_discrete) {
+        a = (int)ph.bounded(p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u);
+    } else {
+        uint32_t o[4]; ph.block(o);
+        a0 = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+        a1 = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+    }
+    actr = ph.ctr;
+}
+
+// One launch == T consecutive VecEnv steps; T == 1 with plain stores is the
+// per-step entry point, T > 1 the fused rollout.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, const void *actions,
+                 const double *noise, float *obs, float *rew, uint8_t *done_out, void *act_out) {
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.n) return;
+    typename RngSel<MODE>::type rng;
+    rng_load<MODE>(rng, rs, e, p.n, nullptr, 0, noise);
+    MobileEnv m;
+    load_env(s, e, m);
+    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    uint64_t actr = actions ? 0 : rs.act_ctr[e];
+    const int adim = p.is_discrete ? 1 : 2;
+    for (int t = 0; t < T; t++) {
+        const int64_t row = (int64_t)t * p.n + e;
+        int a = 0; float a0 = 0.f, a1 = 0.f;
+        if (actions) {
+            if (p.is_discrete) a = static_cast<const int32_t *>(actions)[row];
+            else { float2 v = static_cast<const float2 *>(actions)[row]; a0 = v.x; a1 = v.y; }
+        } else {
+            sample_action(p, rs, e, actr, a, a0, a1);
+            if (act_out) {
+                if (p.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
+                else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+            }
+        }
+        double dv = 0.1 + rng.normal(0.0, 0.0);       // DELTA_POS + N(0, NOISE_STD = 0): drawn, value 0
+        double reward; bool done;
+        step_env(p, m, a, a0, a1, dv, reward, done);
+        ep_ret += reward; ep_len += 1; last_reward = reward;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+            if (p.auto_reset) reset_env(p, rng, m);
+        }
+        float o0, o1;
+        observe(p, m, o0, o1);
+        if (obs) {
+            if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
+            else {
+                __builtin_nontemporal_store(o0, obs + 2 * row);
+                __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+            }
+        }
+        if (rew) __builtin_nontemporal_store((float)reward, rew + row);
+        if (done_out) __builtin_nontemporal_store((uint8_t)done, done_out + row);
+    }
+    (void)adim;
+    store_env(s, e, m);
+    rng_store<MODE>(rng, rs, e);
+    if (!actions) rs.act_ctr[e] = actr;
+    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret;
+    st.last_length[e] = last_len; st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
+}
+
+MobileParams params_of(const Handle *h) {
+    MobileParams p;
+    p.kind = h->cfg.env_kind; p.is_discrete = h->cfg.is_discrete; p.random_target = h->cfg.random_target;
+    p.shape_reward = h->cfg.shape_reward; p.auto_reset = h->cfg.auto_reset; p.n = h->n;
+    return p;
+}
+
+}  // namespace
+
+int mobile_reset_rand_count(const srlhip_config &c) {
+    int base = c.env_kind == SRLHIP_ENV_MOBILE_1D ? 1 : 2;
+    if (!c.random_target) return base;
+    switch (c.env_kind) {
+        case SRLHIP_ENV_MOBILE_1D: case SRLHIP_ENV_MOBILE_LINE: return base + 1;
+        case SRLHIP_ENV_MOBILE_2TARGET: return base + 4;
+        default: return base + 2;
+    }
+}
+
+int mobile_alloc(Handle *h) {
+    MobileState &s = h->mobile;
+    size_t n = (size_t)h->n;
+    int rc = 0;
+    if ((rc = h->dalloc(&s.pos_x, n)) || (rc = h->dalloc(&s.pos_y, n)) || (rc = h->dalloc(&s.tgt_x, n)) ||
+        (rc = h->dalloc(&s.tgt_y, n)) || (rc = h->dalloc(&s.tgt2_x, n)) || (rc = h->dalloc(&s.tgt2_y, n)) ||
+        (rc = h->dalloc(&s.counter, n)) || (rc = h->dalloc(&s.cur_target, n)))
+        return rc;
+    return 0;
+}
+
+void mobile_free(Handle *) {}
+
+int mobile_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, float *d_obs) {
+    MobileParams p = params_of(h);
+    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+    int stride = mobile_reset_rand_count(h->cfg);
+    switch (h->cfg.rng_mode) {
+        case SRLHIP_RNG_HOST:
+            if (!d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
+            hipLaunchKernelGGL(mobile_reset_k<SRLHIP_RNG_HOST>, grid, block, 0, h->stream, p, h->mobile, h->rng,
+                               h->stats, d_mask, d_host_rand, stride, d_obs);
+            break;
+        case SRLHIP_RNG_PHILOX:
+            hipLaunchKernelGGL(mobile_reset_k<SRLHIP_RNG_PHILOX>, grid, block, 0, h->stream, p, h->mobile, h->rng,
+                               h->stats, d_mask, d_host_rand, stride, d_obs);
+            break;
+        default:
+            hipLaunchKernelGGL(mobile_reset_k<SRLHIP_RNG_MT19937>, grid, block, 0, h->stream, p, h->mobile, h->rng,
+                               h->stats, d_mask, d_host_rand, stride, d_obs);
+    }
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done,
+                   void *d_act_out) {
+    MobileParams p = params_of(h);
+    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+    switch (h->cfg.rng_mode) {
+        case SRLHIP_RNG_PHILOX:
+            hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_PHILOX>, grid, block, 0, h->stream, p, h->mobile, h->rng,
+                               h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            break;
+        case SRLHIP_RNG_MT19937:
+            hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_MT19937>, grid, block, 0, h->stream, p, h->mobile, h->rng,
+                               h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            break;
+        default:
+            return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
+    }
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *d_obs, float *d_rew,
+                uint8_t *d_done) {
+    if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return mobile_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
+    MobileParams p = params_of(h);
+    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_HOST>, grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
+                       1, d_actions, d_noise, d_obs, d_rew, d_done, (void *)nullptr);
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int mobile_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
+    MobileState &s = h->mobile;
+    *count = 1;
+    switch (field) {
+        case SRLHIP_F_POS_X: *dptr = s.pos_x; *elem = 8; return 0;
+        case SRLHIP_F_POS_Y: *dptr = s.pos_y; *elem = 8; return 0;
+        case SRLHIP_F_TARGET_X: *dptr = s.tgt_x; *elem = 8; return 0;
+        case SRLHIP_F_TARGET_Y: *dptr = s.tgt_y; *elem = 8; return 0;
+        case SRLHIP_F_STEP_COUNT: *dptr = s.counter; *elem = 4; return 0;
+        case SRLHIP_F_CUR_TARGET: *dptr = s.cur_target; *elem = 4; return 0;
+    }
+    return h->fail(SRLHIP_EINVAL, "unknown field for the MobileRobot family");
+}
+
+}  // namespace srl

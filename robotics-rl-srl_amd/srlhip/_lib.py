@@ -1,0 +1,251 @@
+"""ctypes binding of libsrlhip.so (include/srlhip.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared
+object is missing or no MI355X is visible, the errors raised here say so.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrlhip.so")
+
+# ---- constants mirrored from include/srlhip.h --------------------------------
+ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON = range(5)
+OBS_GROUND_TRUTH, OBS_JOINTS, OBS_JOINTS_POSITION, OBS_RAW_PIXELS = range(4)
+RNG_HOST, RNG_PHILOX, RNG_MT19937 = range(3)
+F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REWARD, F_EP_RETURN, F_EP_LENGTH = range(9)
+F_KUKA_Q, F_KUKA_QD, F_KUKA_EE_TARGET, F_KUKA_BUTTON_Q, F_KUKA_BUTTON_POS, F_KUKA_GRIPPER, F_KUKA_COUNTERS = range(16, 23)
+
+_FIELD_SHAPES = {
+    F_POS_X: (np.float64, 1), F_POS_Y: (np.float64, 1), F_TARGET_X: (np.float64, 1), F_TARGET_Y: (np.float64, 1),
+    F_STEP_COUNT: (np.int32, 1), F_CUR_TARGET: (np.int32, 1), F_LAST_REWARD: (np.float64, 1),
+    F_EP_RETURN: (np.float64, 1), F_EP_LENGTH: (np.int32, 1),
+    F_KUKA_Q: (np.float64, 7), F_KUKA_QD: (np.float64, 7), F_KUKA_EE_TARGET: (np.float64, 3),
+    F_KUKA_BUTTON_Q: (np.float64, 2), F_KUKA_BUTTON_POS: (np.float64, 3), F_KUKA_GRIPPER: (np.float64, 3),
+    F_KUKA_COUNTERS: (np.int32, 3),
+}
+
+EXPORTS = [
+    "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
+    "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
+    "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
+    "srlhip_device_ptr", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
+    "srlhip_timing_end", "srlhip_last_error",
+]
+
+
+class Config(ctypes.Structure):
+    """struct srlhip_config"""
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("env_kind", ctypes.c_int32), ("num_envs", ctypes.c_int32),
+        ("device_id", ctypes.c_int32), ("first_env_id", ctypes.c_int32), ("is_discrete", ctypes.c_int32),
+        ("random_target", ctypes.c_int32), ("force_down", ctypes.c_int32), ("shape_reward", ctypes.c_int32),
+        ("action_repeat", ctypes.c_int32), ("action_joints", ctypes.c_int32), ("obs_mode", ctypes.c_int32),
+        ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32), ("multi_view", ctypes.c_int32),
+        ("rng_mode", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("io_device", ctypes.c_int32),
+        ("seed0", ctypes.c_int64), ("max_distance", ctypes.c_double),
+    ]
+
+
+class SrlHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libsrlhip.so; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrlHipError(
+            "libsrlhip.so is not built ({}). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C robotics-rl-srl_amd/csrc`. There is no CPU fallback for the env stepper.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    lib.srlhip_last_error.restype = ctypes.c_char_p
+    lib.srlhip_last_error.argtypes = [vp]
+    lib.srlhip_default_config.argtypes = [i32, ctypes.POINTER(Config)]
+    lib.srlhip_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    for name in ("srlhip_destroy", "srlhip_obs_dim", "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions",
+                 "srlhip_reset_rand_count", "srlhip_sync", "srlhip_timing_begin"):
+        getattr(lib, name).argtypes = [vp]
+    lib.srlhip_seed.argtypes = [vp, vp, vp]
+    lib.srlhip_reset.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.srlhip_rollout.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.srlhip_get_state.argtypes = [vp, i32, vp]
+    lib.srlhip_set_state.argtypes = [vp, i32, vp]
+    lib.srlhip_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    _lib = lib
+    return lib
+
+
+def default_config(env_kind):
+    cfg = Config()
+    rc = load().srlhip_default_config(env_kind, ctypes.byref(cfg))
+    if rc:
+        raise SrlHipError("srlhip_default_config({}) -> {}".format(env_kind, rc))
+    return cfg
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):          # raw device pointer (io_device = 1)
+        return ctypes.c_void_p(a)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Handle(object):
+    """Thin object wrapper over srlhip_handle; numpy arrays in host-io mode,
+    integer device pointers (e.g. torch.Tensor.data_ptr()) in device-io mode."""
+
+    def __init__(self, cfg):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self.cfg = cfg
+        rc = self._lib.srlhip_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            msg = self._lib.srlhip_last_error(None).decode()
+            raise SrlHipError("srlhip_create failed ({}): {}".format(rc, msg))
+        self.num_envs = cfg.num_envs
+        self.obs_dim = self._lib.srlhip_obs_dim(self._h)
+        self.obs_bytes = self._lib.srlhip_obs_bytes(self._h)
+        self.action_dim = self._lib.srlhip_action_dim(self._h)
+        self.num_actions = self._lib.srlhip_num_actions(self._h)
+        self.reset_rand_count = self._lib.srlhip_reset_rand_count(self._h)
+
+    def _check(self, rc, what):
+        if rc:
+            raise SrlHipError("{} failed ({}): {}".format(what, rc, self._lib.srlhip_last_error(self._h).decode()))
+
+    def close(self):
+        if self._h:
+            self._lib.srlhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- allocation helpers (host io) -----------------------------------------
+    def new_obs(self, T=None):
+        n = self.num_envs
+        lead = (n,) if T is None else (T, n)
+        if self.cfg.obs_mode == OBS_RAW_PIXELS:
+            ch = 6 if self.cfg.multi_view else 3
+            return np.zeros(lead + (self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
+        return np.zeros(lead + (self.obs_dim,), np.float32)
+
+    def action_array(self, actions, T=None):
+        n = self.num_envs
+        lead = (n,) if T is None else (T, n)
+        if self.cfg.is_discrete:
+            a = np.ascontiguousarray(actions, dtype=np.int32)
+            assert a.shape == lead, (a.shape, lead)
+        else:
+            a = np.ascontiguousarray(actions, dtype=np.float32)
+            assert a.shape == lead + (self.action_dim,), (a.shape, lead)
+        return a
+
+    # ---- ABI calls -------------------------------------------------------------
+    def seed(self, seeds, mask=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        assert seeds.shape == (self.num_envs,)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self._lib.srlhip_seed(self._h, _ptr(m), _ptr(seeds)), "srlhip_seed")
+
+    def reset(self, mask=None, host_rand=None, obs_out=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if host_rand is not None and not isinstance(host_rand, int):
+            host_rand = np.ascontiguousarray(host_rand, dtype=np.float64)
+            assert host_rand.shape == (self.num_envs, self.reset_rand_count)
+        if obs_out is None and not self.cfg.io_device:
+            obs_out = self.new_obs()
+        self._check(self._lib.srlhip_reset(self._h, _ptr(m), _ptr(host_rand), _ptr(obs_out)), "srlhip_reset")
+        return obs_out
+
+    def step(self, actions, host_noise=None, out=None):
+        if self.cfg.io_device:
+            obs, rew, done = out
+            self._check(self._lib.srlhip_step(self._h, _ptr(actions), _ptr(host_noise), _ptr(obs), _ptr(rew),
+                                              _ptr(done)), "srlhip_step")
+            return out
+        a = self.action_array(actions)
+        if host_noise is not None:
+            host_noise = np.ascontiguousarray(host_noise, dtype=np.float64)
+        if out is None:
+            out = (self.new_obs(), np.zeros(self.num_envs, np.float32), np.zeros(self.num_envs, np.uint8))
+        obs, rew, done = out
+        self._check(self._lib.srlhip_step(self._h, _ptr(a), _ptr(host_noise), _ptr(obs), _ptr(rew), _ptr(done)),
+                    "srlhip_step")
+        return out
+
+    def rollout(self, T, actions=None, want=("obs", "reward", "done", "actions"), out=None):
+        n = self.num_envs
+        if self.cfg.io_device:
+            obs, rew, done, act = out
+            self._check(self._lib.srlhip_rollout(self._h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done),
+                                                 _ptr(act)), "srlhip_rollout")
+            return out
+        a = None if actions is None else self.action_array(actions, T)
+        obs = self.new_obs(T) if "obs" in want else None
+        rew = np.zeros((T, n), np.float32) if "reward" in want else None
+        done = np.zeros((T, n), np.uint8) if "done" in want else None
+        act = None
+        if a is None and "actions" in want:
+            act = np.zeros((T, n), np.int32) if self.cfg.is_discrete else np.zeros((T, n, self.action_dim), np.float32)
+        self._check(self._lib.srlhip_rollout(self._h, T, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(act)),
+                    "srlhip_rollout")
+        return {"obs": obs, "reward": rew, "done": done, "actions": a if a is not None else act}
+
+    def get_state(self, field):
+        dtype, k = _FIELD_SHAPES[field]
+        out = np.zeros((k, self.num_envs) if k > 1 else (self.num_envs,), dtype)
+        self._check(self._lib.srlhip_get_state(self._h, field, _ptr(out)), "srlhip_get_state")
+        return out
+
+    def set_state(self, field, value):
+        dtype, k = _FIELD_SHAPES[field]
+        v = np.ascontiguousarray(value, dtype=dtype)
+        assert v.shape == ((k, self.num_envs) if k > 1 else (self.num_envs,))
+        self._check(self._lib.srlhip_set_state(self._h, field, _ptr(v)), "srlhip_set_state")
+
+    def device_ptr(self, field):
+        p = ctypes.c_void_p()
+        self._check(self._lib.srlhip_device_ptr(self._h, field, ctypes.byref(p)), "srlhip_device_ptr")
+        return p.value
+
+    def episode_stats(self):
+        n = self.num_envs
+        ret, length, fin = np.zeros(n, np.float64), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._check(self._lib.srlhip_episode_stats(self._h, _ptr(ret), _ptr(length), _ptr(fin)),
+                    "srlhip_episode_stats")
+        return ret, length, fin
+
+    def sync(self):
+        self._check(self._lib.srlhip_sync(self._h), "srlhip_sync")
+
+    def stream(self):
+        p = ctypes.c_void_p()
+        self._check(self._lib.srlhip_stream(self._h, ctypes.byref(p)), "srlhip_stream")
+        return p.value
+
+    def timing_begin(self):
+        self._check(self._lib.srlhip_timing_begin(self._h), "srlhip_timing_begin")
+
+    def timing_end(self):
+        ms = ctypes.c_float()
+        self._check(self._lib.srlhip_timing_end(self._h, ctypes.byref(ms)), "srlhip_timing_end")
+        return ms.value

@@ -1,0 +1,184 @@
+"""GPU parity, MobileRobot family: HIP path (through the C-ABI) vs the CPU
+oracle on the same seeds/actions.  Integer/flag outputs and the f64 internal
+state are compared BIT-EXACT; observations bit-exact after the f32 cast."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import clib, mobile_oracle
+from srlhip import _lib
+
+pytestmark = pytest.mark.gpu
+
+N_ACT = {0: 4, 1: 2, 2: 4, 3: 4}
+
+
+def make(kind, n, rng_mode, auto_reset=1, seed0=0, first=0, **kw):
+    cfg = _lib.default_config(kind)
+    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0, cfg.first_env_id = n, rng_mode, auto_reset, seed0, first
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return _lib.Handle(cfg)
+
+
+def assert_same(oracle, obs0, obs, rew, done, tag=""):
+    assert np.array_equal(oracle["obs0"], obs0), tag + " obs0"
+    assert np.array_equal(oracle["obs"], obs), tag + " obs"
+    assert np.array_equal(oracle["reward"], rew), tag + " reward"
+    assert np.array_equal(oracle["done"], done), tag + " done"
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("random_target", [0, 1])
+def test_mt19937_step_by_step_matches_oracle(kind, random_target):
+    """Reference-exact mode: env i seeded seed0+i like makeEnv (environments/utils.py:52);
+    np_random lives on the device.  2+ episodes, per-step launches."""
+    n, T, seed0 = 256, 2 * 251 + 9, 11
+    rs = np.random.RandomState(1234)
+    actions = rs.randint(N_ACT[kind], size=(T, n)).astype(np.int32)
+    h = make(kind, n, _lib.RNG_MT19937, seed0=seed0, random_target=random_target)
+    obs0 = h.reset()
+    obs, rew, done = [], [], []
+    for t in range(T):
+        o, r, d = h.step(actions[t])
+        obs.append(o.copy()); rew.append(r.copy()); done.append(d.copy())
+    ora = clib.mobile_rollout(kind, seed0 + np.arange(n), T, actions=actions, random_target=bool(random_target))
+    assert_same(ora, obs0, np.array(obs), np.array(rew), np.array(done), "kind%d" % kind)
+    # internal float64 state, bit-exact
+    fs = ora["final_state"]
+    assert np.array_equal(h.get_state(_lib.F_POS_X), fs[:, 0])
+    assert np.array_equal(h.get_state(_lib.F_POS_Y), fs[:, 1])
+    assert np.array_equal(h.get_state(_lib.F_STEP_COUNT), fs[:, 6].astype(np.int32))
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(ret, ora["ep_stats"][:, 0])
+    assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32))
+    assert np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32))
+    assert fin.min() == 2
+    h.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_fused_rollout_4096_envs_matches_oracle(kind):
+    """BASELINE config 2 size: 4096 envs, fused T-step kernel, host actions, MT19937 streams."""
+    n, T = 4096, 2 * 251 + 3
+    rs = np.random.RandomState(99)
+    actions = rs.randint(N_ACT[kind], size=(T, n)).astype(np.int32)
+    h = make(kind, n, _lib.RNG_MT19937, seed0=0, shape_reward=1 if kind == 0 else 0)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    ora = clib.mobile_rollout(kind, np.arange(n), T, actions=actions, shape_reward=(kind == 0))
+    assert_same(ora, obs0, out["obs"], out["reward"], out["done"])
+    if kind == 0:   # shaped reward: uncast float64 of the last step
+        assert np.array_equal(h.get_state(_lib.F_LAST_REWARD), ora["reward64"][-1])
+    h.close()
+
+
+@pytest.mark.parametrize("discrete", [1, 0])
+def test_philox_random_agent_rollout_matches_oracle(discrete):
+    """Throughput mode: Philox env stream + device-sampled random-agent actions,
+    replayed bit-exactly by the oracle's Philox restatement."""
+    n, T = 4096, 600
+    h = make(0, n, _lib.RNG_PHILOX, seed0=5, is_discrete=discrete, random_target=1)
+    obs0 = h.reset()
+    out = h.rollout(T)
+    ora = clib.mobile_rollout(0, 5 + np.arange(n), T, actions=None, is_discrete=bool(discrete), random_target=True,
+                              rng_mode=clib.RNG_PHILOX)
+    assert np.array_equal(ora["actions"], out["actions"])
+    assert_same(ora, obs0, out["obs"], out["reward"], out["done"])
+    # chunked rollouts continue the same streams
+    h2 = make(0, n, _lib.RNG_PHILOX, seed0=5, is_discrete=discrete, random_target=1)
+    h2.reset()
+    a = h2.rollout(250)
+    b = h2.rollout(T - 250)
+    assert np.array_equal(np.concatenate([a["obs"], b["obs"]]), out["obs"])
+    h.close(); h2.close()
+
+
+def test_host_rng_mode_and_manual_reset():
+    """RNG_HOST harness: every draw supplied by the caller (numpy RandomState per env),
+    no auto-reset: finished envs are reset with srlhip_reset(mask) like a VecEnv worker."""
+    from oracle import gym_seeding
+    n, T = 64, 300
+    rngs = [gym_seeding.np_random(100 + i)[0] for i in range(n)]
+    envs = []
+    for i in range(n):
+        e = mobile_oracle.MobileOracleEnv(mobile_oracle.MOBILE, random_target=True)
+        e.seed(100 + i)
+        envs.append(e)
+    h = make(0, n, _lib.RNG_HOST, auto_reset=0, random_target=1)
+
+    def draw_reset(rng):
+        return [rng.uniform(-4 / 3, 4 / 3), rng.uniform(-4 / 3, 4 / 3), rng.uniform(0.4, 3.6), rng.uniform(0.4, 3.6)]
+
+    obs = h.reset(host_rand=np.array([draw_reset(r) for r in rngs]))
+    ref = np.array([e.reset() for e in envs], dtype=np.float32)
+    assert np.array_equal(obs, ref)
+    arng = np.random.RandomState(3)
+    for t in range(T):
+        a = arng.randint(4, size=n).astype(np.int32)
+        noise = np.array([r.normal(0.0, scale=0.0) for r in rngs])
+        o, r_, d = h.step(a, host_noise=noise)
+        exp = [e.step(int(a[i])) for i, e in enumerate(envs)]
+        assert np.array_equal(o, np.array([x[0] for x in exp], dtype=np.float32))
+        assert np.array_equal(r_, np.array([x[1] for x in exp], dtype=np.float32))
+        assert np.array_equal(d.astype(bool), np.array([x[2] for x in exp]))
+        if d.any():
+            rand = np.zeros((n, 4))
+            for i in np.nonzero(d)[0]:
+                rand[i] = draw_reset(rngs[i])
+            o2 = h.reset(mask=d, host_rand=rand, obs_out=o.copy())
+            for i in np.nonzero(d)[0]:
+                assert np.array_equal(o2[i], envs[i].reset().astype(np.float32))
+            assert np.array_equal(o2[d == 0], o[d == 0])
+    h.close()
+
+
+def test_sharding_invariance_and_reseed():
+    """Env streams depend on the GLOBAL env id only: 2 shards == 1 handle;
+    srlhip_seed(mask) reseeds like dataset_generator.py:82-86."""
+    n, T = 512, 300
+    rs = np.random.RandomState(5)
+    actions = rs.randint(4, size=(T, n)).astype(np.int32)
+    full = make(0, n, _lib.RNG_MT19937, seed0=7, random_target=1)
+    o_full = full.reset()
+    r_full = full.rollout(T, actions=actions)
+    parts = []
+    for g in range(2):
+        hs = make(0, n // 2, _lib.RNG_MT19937, seed0=7, first=g * n // 2, random_target=1)
+        o = hs.reset()
+        r = hs.rollout(T, actions=np.ascontiguousarray(actions[:, g * n // 2:(g + 1) * n // 2]))
+        parts.append((o, r))
+        hs.close()
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), o_full)
+    for k in ("obs", "reward", "done"):
+        assert np.array_equal(np.concatenate([p[1][k] for p in parts], axis=1), r_full[k])
+    # reseed half of the envs with new seeds and reset only those
+    mask = (np.arange(n) % 2).astype(np.uint8)
+    full.seed(1000 + np.arange(n), mask=mask)
+    o2 = full.reset(mask=mask, obs_out=np.zeros((n, 2), np.float32))
+    ora = clib.mobile_rollout(0, 1000 + np.arange(n), 1, actions=np.zeros((1, n), np.int32), random_target=True)
+    assert np.array_equal(o2[mask == 1], ora["obs0"][mask == 1])
+    full.close()
+
+
+def test_device_io_mode_with_torch_buffers():
+    """io_device=1: torch owns the I/O buffers (plumbing only), zero host copies."""
+    import torch
+    n, T = 4096, 64
+    h = make(0, n, _lib.RNG_PHILOX, seed0=1, io_device=1)
+    dev = torch.device("cuda:0")
+    obs0 = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    h.reset(obs_out=obs0.data_ptr())
+    obs = torch.zeros((T, n, 2), dtype=torch.float32, device=dev)
+    rew = torch.zeros((T, n), dtype=torch.float32, device=dev)
+    done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    act = torch.zeros((T, n), dtype=torch.int32, device=dev)
+    h.rollout(T, out=(obs.data_ptr(), rew.data_ptr(), done.data_ptr(), act.data_ptr()))
+    h.sync()
+    ora = clib.mobile_rollout(0, 1 + np.arange(n), T, actions=None, rng_mode=clib.RNG_PHILOX)
+    assert np.array_equal(obs0.cpu().numpy(), ora["obs0"])
+    assert np.array_equal(obs.cpu().numpy(), ora["obs"])
+    assert np.array_equal(act.cpu().numpy(), ora["actions"])
+    assert np.array_equal(rew.cpu().numpy(), ora["reward"])
+    h.close()
