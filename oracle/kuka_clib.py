@@ -1,0 +1,120 @@
+"""ctypes front end of the plain-C Kuka oracle (oracle/kuka_oracle.c).
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py."""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+from . import clib
+
+RNG_PHILOX, RNG_MT19937 = 1, 2
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _lib():
+    lib = clib.lib()
+    lib.kuka_oracle_rollout.argtypes = (
+        [ctypes.c_int] * 6 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 14)
+    lib.kuka_oracle_aba.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_double, ctypes.c_void_p]
+    lib.kuka_oracle_wrapper_step.argtypes = ([ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_double] +
+                                             [ctypes.c_void_p] * 2)
+    return lib
+
+
+def aba(q, qd, tau, gz=-10.0):
+    q, qd, tau = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau))
+    out = np.zeros(7)
+    _lib().kuka_oracle_aba(_p(q), _p(qd), _p(tau), gz, _p(out))
+    return out
+
+
+def minv(q):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    out = np.zeros((7, 7))
+    _lib().kuka_oracle_minv(_p(q), _p(out))
+    return out
+
+
+def fk(q):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    R, p = np.zeros((7, 3, 3)), np.zeros((7, 3))
+    _lib().kuka_oracle_fk(_p(q), _p(R), _p(p))
+    return R, p
+
+
+def ik(q, target):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    target = np.ascontiguousarray(target, dtype=np.float64)
+    out = np.zeros(7)
+    _lib().kuka_oracle_ik(_p(q), _p(target), _p(out))
+    return out
+
+
+def settled(random_target=False, action_joints=False):
+    out = np.zeros(22)
+    _lib().kuka_oracle_settled(int(random_target), int(action_joints), _p(out))
+    return {"q": out[:7], "qd": out[7:14], "ee_target": out[14:17], "button": out[17:19], "gripper": out[19:22]}
+
+
+def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, random_target=False, force_down=True,
+            shape_reward=False, action_repeat=1, max_distance=0.8, obs_mode=0, rng_mode=RNG_MT19937, auto_reset=True,
+            trace=True):
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    n = len(seeds)
+    od = {0: 3, 1: 14, 2: 17}[obs_mode]
+    adim = 1 if is_discrete else (7 if action_joints else 3)
+    keys, lens = clib.mt_keys(seeds) if rng_mode == RNG_MT19937 else (np.zeros((n, 2), np.uint32), np.zeros(n, np.int32))
+    out = {
+        "obs0": np.zeros((n, od), np.float32), "obs": np.zeros((T, n, od), np.float32),
+        "reward": np.zeros((T, n), np.float32), "reward64": np.zeros((T, n)), "done": np.zeros((T, n), np.uint8),
+        "q": np.zeros((T, n, 7)) if trace else None, "gripper": np.zeros((T, n, 3)) if trace else None,
+        "final_state": np.zeros((n, 24)), "ep_stats": np.zeros((n, 3)),
+    }
+    act_out = None
+    if actions is None:
+        act_out = np.zeros((T, n), np.int32) if is_discrete else np.zeros((T, n, adim), np.float32)
+    else:
+        actions = np.ascontiguousarray(actions, dtype=np.int32 if is_discrete else np.float32)
+        assert actions.shape == ((T, n) if is_discrete else (T, n, adim)), actions.shape
+    rc = _lib().kuka_oracle_rollout(
+        int(is_discrete), int(action_joints), int(random_target), int(force_down), int(shape_reward),
+        int(action_repeat), float(max_distance), int(obs_mode), int(rng_mode), int(auto_reset), n, int(T),
+        _p(seeds), _p(keys), _p(lens), _p(actions), _p(out["obs0"]), _p(out["obs"]), _p(out["reward"]),
+        _p(out["reward64"]), _p(out["done"]), _p(act_out), _p(out["q"]), _p(out["gripper"]),
+        _p(out["final_state"]), _p(out["ep_stats"]))
+    assert rc == 0
+    out["actions"] = actions if actions is not None else act_out
+    return out
+
+
+def wrapper_step(state, gripper, button_pos, contact_button, contact_table, shape_reward=False, is_discrete=True,
+                 max_distance=0.8):
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    st = np.concatenate([st, np.zeros(8 - len(st))])
+    g = np.ascontiguousarray(gripper, dtype=np.float64)
+    b = np.ascontiguousarray(button_pos, dtype=np.float64)
+    reward, done = ctypes.c_double(), ctypes.c_int()
+    _lib().kuka_oracle_wrapper_step(_p(st), _p(g), _p(b), int(contact_button), int(contact_table), int(shape_reward),
+                                    int(is_discrete), float(max_distance), ctypes.byref(reward), ctypes.byref(done))
+    return st[:4].copy(), reward.value, bool(done.value)
+
+
+def cpu_baseline(budget_s=12.0, n_envs=None):
+    """Time the oracle on the host cores (OpenMP over envs): bench.py's cpu_baseline leg."""
+    threads = os.cpu_count() or 1
+    n = n_envs or max(64, min(4096, 4 * threads))
+    T = 8
+    rollout(np.arange(n), 2, actions=None, rng_mode=RNG_PHILOX, trace=False)      # warm-up / settle
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s:
+        rollout(np.arange(n), T, actions=None, rng_mode=RNG_PHILOX, trace=False)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": reps * T * n / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "oracle/kuka_oracle.c (OpenMP over envs), {} envs x {} steps x {} passes incl. a 505-step "
+                      "settle per pass, physics only (no rendering)".format(n, T, reps)}

@@ -1,0 +1,584 @@
+/* kuka_oracle.c — plain-C float64 restatement of KukaButtonGymEnv stepping.
+ * TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+ *
+ * In-tree logic restated (verified line by line against the reference source, and
+ * pinned by tests/golden/kuka_wrapper_reference.npz — the reference's own wrapper
+ * code driven by a scripted fake pybullet):
+ *   Kuka.applyAction            /root/reference/environments/kuka_gym/kuka.py:118-187
+ *   KukaButtonGymEnv.reset      .../kuka_button_gym_env.py:214-281
+ *   KukaButtonGymEnv.step       :293-340      step2 :342-368
+ *   _termination :422-426       _reward :428-463     getSRLState :175-189
+ * Out-of-tree arithmetic restated from the dependency's PUBLISHED algorithm
+ * (pybullet==1.8.6 / Bullet 2.87, absent here -> PARITY UNPINNED for this part):
+ *   p.calculateInverseKinematics  one damped-least-squares step (BussIK DLS)
+ *   p.stepSimulation              btMultiBodyDynamicsWorld: Featherstone ABA + joint
+ *                                 motor / limit / contact rows + 150-iteration
+ *                                 projected Gauss-Seidel + semi-implicit Euler
+ *   p.getContactPoints            analytic sphere/cylinder/plane predicate
+ * Written for readability, not speed: dense 6x6 spatial algebra, no structure exploited,
+ * M^-1 obtained by seven extra ABA calls.  Compile with -ffp-contract=off. */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kuka_model.h"
+#include "np_random.h"
+#include "philox.h"
+
+#define N KM_NDOF
+#define MAX_ROWS 40
+
+/* ------------------------------------------------------------------ small algebra */
+typedef double mat3[3][3];
+typedef double vec6[6];
+typedef double mat6[6][6];
+
+static void rpy_to_mat(const double rpy[3], mat3 R) {
+    double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
+    R[0][0] = cy * cp; R[0][1] = cy * sp * sr - sy * cr; R[0][2] = cy * sp * cr + sy * sr;
+    R[1][0] = sy * cp; R[1][1] = sy * sp * sr + cy * cr; R[1][2] = sy * sp * cr - cy * sr;
+    R[2][0] = -sp;     R[2][1] = cp * sr;                R[2][2] = cp * cr;
+}
+static void mat3_mul(const mat3 A, const mat3 B, mat3 C) {
+    int i, j, k;
+    for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) { double s = 0; for (k = 0; k < 3; k++) s += A[i][k] * B[k][j]; C[i][j] = s; }
+}
+static void mat3_vec(const mat3 A, const double v[3], double o[3]) {
+    int i; for (i = 0; i < 3; i++) o[i] = A[i][0] * v[0] + A[i][1] * v[1] + A[i][2] * v[2];
+}
+static void cross(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void skew(const double v[3], mat3 S) {
+    S[0][0] = 0; S[0][1] = -v[2]; S[0][2] = v[1]; S[1][0] = v[2]; S[1][1] = 0; S[1][2] = -v[0];
+    S[2][0] = -v[1]; S[2][1] = v[0]; S[2][2] = 0;
+}
+static void mat6_vec(const mat6 A, const vec6 v, vec6 o) {
+    int i, k; for (i = 0; i < 6; i++) { double s = 0; for (k = 0; k < 6; k++) s += A[i][k] * v[k]; o[i] = s; }
+}
+static void mat6T_vec(const mat6 A, const vec6 v, vec6 o) {
+    int i, k; for (i = 0; i < 6; i++) { double s = 0; for (k = 0; k < 6; k++) s += A[k][i] * v[k]; o[i] = s; }
+}
+/* spatial cross products: crm(v) m  and  crf(v) f = -crm(v)^T f */
+static void crm_vec(const vec6 v, const vec6 m, vec6 o) {
+    double a[3], b[3], c[3];
+    cross(v, m, a); o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+    cross(v + 3, m, b); cross(v, m + 3, c);
+    o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+static void crf_vec(const vec6 v, const vec6 f, vec6 o) {
+    double a[3], b[3], c[3];
+    cross(v, f, a); cross(v + 3, f + 3, b);
+    o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2];
+    cross(v, f + 3, c); o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+
+/* ------------------------------------------------------------------ kinematics */
+/* rotation of link i's frame in its parent's frame, and the motion transform X_i (parent -> link) */
+static void joint_rotation(int i, double q, mat3 Rpc) {
+    mat3 Rfix, Rz; double rz[3] = {0, 0, q};
+    rpy_to_mat(KM_JOINT_RPY[i], Rfix); rpy_to_mat(rz, Rz);
+    mat3_mul(Rfix, Rz, Rpc);
+}
+static void motion_transform(int i, double q, mat6 X) {
+    mat3 Rpc, E, rx, Erx; int a, b;
+    joint_rotation(i, q, Rpc);
+    for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) E[a][b] = Rpc[b][a];
+    skew(KM_JOINT_XYZ[i], rx);
+    mat3_mul(E, rx, Erx);
+    memset(X, 0, sizeof(mat6));
+    for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) { X[a][b] = E[a][b]; X[a + 3][b + 3] = E[a][b]; X[a + 3][b] = -Erx[a][b]; }
+}
+/* world pose of every link frame */
+static void forward_kinematics(const double q[N], mat3 R[N], double p[N][3]) {
+    mat3 Rw = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, Rpc, Rn; double pw[3], t[3]; int i;
+    memcpy(pw, KM_BASE_POS, sizeof pw);
+    for (i = 0; i < N; i++) {
+        mat3_vec(Rw, KM_JOINT_XYZ[i], t);
+        pw[0] += t[0]; pw[1] += t[1]; pw[2] += t[2];
+        joint_rotation(i, q[i], Rpc);
+        mat3_mul(Rw, Rpc, Rn);
+        memcpy(Rw, Rn, sizeof(mat3));
+        memcpy(R[i], Rw, sizeof(mat3)); memcpy(p[i], pw, sizeof pw);
+    }
+}
+static void link7_point(const mat3 R[N], const double p[N][3], const double local[3], double world[3]) {
+    double t[3]; mat3_vec(R[N - 1], local, t);
+    world[0] = p[N - 1][0] + t[0]; world[1] = p[N - 1][1] + t[1]; world[2] = p[N - 1][2] + t[2];
+}
+/* geometric Jacobian of a world point rigidly attached to link_7 */
+static void point_jacobian(const mat3 R[N], const double p[N][3], const double pt[3], double Jv[3][N], double Jw[3][N]) {
+    int j;
+    for (j = 0; j < N; j++) {
+        double z[3] = {R[j][0][2], R[j][1][2], R[j][2][2]}, d[3] = {pt[0] - p[j][0], pt[1] - p[j][1], pt[2] - p[j][2]}, c[3];
+        cross(z, d, c);
+        Jv[0][j] = c[0]; Jv[1][j] = c[1]; Jv[2][j] = c[2];
+        Jw[0][j] = z[0]; Jw[1][j] = z[1]; Jw[2][j] = z[2];
+    }
+}
+
+/* ------------------------------------------------------------------ Featherstone ABA */
+static void spatial_inertia(int i, mat6 I) {
+    const double *c = KM_COM[i]; double m = KM_MASS[i]; mat3 cx; int a, b;
+    double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    skew(c, cx);
+    memset(I, 0, sizeof(mat6));
+    for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) {
+        I[a][b] = (a == b ? KM_INERTIA[i][a] + m * cc : 0.0) - m * c[a] * c[b];
+        I[a][b + 3] = m * cx[a][b];
+        I[a + 3][b] = -m * cx[a][b];
+        I[a + 3][b + 3] = a == b ? m : 0.0;
+    }
+}
+/* qdd = FD(q, qd, tau) with gravity (0, 0, gz) — RBDA Table 7.1, joint axis S = e_z(angular) */
+static void aba(const double q[N], const double qd[N], const double tau[N], double gz, double qdd[N]) {
+    static const vec6 S = {0, 0, 1, 0, 0, 0};
+    mat6 X[N], IA[N]; vec6 v[N], c[N], pA[N], U[N], a[N]; double d[N], u[N];
+    int i, r, s, k;
+    for (i = 0; i < N; i++) {
+        vec6 vJ, Iv;
+        motion_transform(i, q[i], X[i]);
+        for (k = 0; k < 6; k++) vJ[k] = S[k] * qd[i];
+        if (i == 0) memcpy(v[i], vJ, sizeof(vec6));
+        else { mat6_vec(X[i], v[i - 1], v[i]); for (k = 0; k < 6; k++) v[i][k] += vJ[k]; }
+        crm_vec(v[i], vJ, c[i]);
+        spatial_inertia(i, IA[i]);
+        mat6_vec(IA[i], v[i], Iv);
+        crf_vec(v[i], Iv, pA[i]);
+    }
+    for (i = N - 1; i >= 0; i--) {
+        mat6_vec(IA[i], S, U[i]);
+        d[i] = U[i][2];
+        u[i] = tau[i] - pA[i][2];
+        if (i > 0) {
+            mat6 Ia, T; vec6 pa, Iac, t;
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) Ia[r][s] = IA[i][r][s] - U[i][r] * U[i][s] / d[i];
+            mat6_vec(Ia, c[i], Iac);
+            for (k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + U[i][k] * u[i] / d[i];
+            /* IA[parent] += X^T Ia X ;  pA[parent] += X^T pa */
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += Ia[r][k] * X[i][k][s]; T[r][s] = acc; }
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += X[i][k][r] * T[k][s]; IA[i - 1][r][s] += acc; }
+            mat6T_vec(X[i], pa, t);
+            for (k = 0; k < 6; k++) pA[i - 1][k] += t[k];
+        }
+    }
+    for (i = 0; i < N; i++) {
+        vec6 ap; double Ua = 0;
+        if (i == 0) { vec6 a0 = {0, 0, 0, 0, 0, 0}; a0[5] = -gz; mat6_vec(X[i], a0, ap); }
+        else mat6_vec(X[i], a[i - 1], ap);
+        for (k = 0; k < 6; k++) ap[k] += c[i][k];
+        for (k = 0; k < 6; k++) Ua += U[i][k] * ap[k];
+        qdd[i] = (u[i] - Ua) / d[i];
+        for (k = 0; k < 6; k++) a[i][k] = ap[k] + S[k] * qdd[i];
+    }
+}
+/* W = M(q)^-1, column j = response to a unit torque on joint j (no velocity, no gravity) */
+static void mass_matrix_inverse(const double q[N], double W[N][N]) {
+    double zero[N] = {0}, e[N], col[N]; int i, j;
+    for (j = 0; j < N; j++) {
+        memset(e, 0, sizeof e); e[j] = 1.0;
+        aba(q, zero, e, 0.0, col);
+        for (i = 0; i < N; i++) W[i][j] = col[i];
+    }
+}
+
+/* ------------------------------------------------------------------ inverse kinematics */
+/* one damped-least-squares step towards (target position, orientation = quat(euler(0,-pi,0))) */
+static void quat_from_mat(const mat3 R, double qt[4]) {       /* (x, y, z, w), Shepperd */
+    double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qt[3] = 0.25 * s; qt[0] = (R[2][1] - R[1][2]) / s; qt[1] = (R[0][2] - R[2][0]) / s; qt[2] = (R[1][0] - R[0][1]) / s; }
+    else if (R[0][0] > R[1][1] && R[0][0] > R[2][2]) { double s = sqrt(1.0 + R[0][0] - R[1][1] - R[2][2]) * 2; qt[3] = (R[2][1] - R[1][2]) / s; qt[0] = 0.25 * s; qt[1] = (R[0][1] + R[1][0]) / s; qt[2] = (R[0][2] + R[2][0]) / s; }
+    else if (R[1][1] > R[2][2]) { double s = sqrt(1.0 + R[1][1] - R[0][0] - R[2][2]) * 2; qt[3] = (R[0][2] - R[2][0]) / s; qt[0] = (R[0][1] + R[1][0]) / s; qt[1] = 0.25 * s; qt[2] = (R[1][2] + R[2][1]) / s; }
+    else { double s = sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2; qt[3] = (R[1][0] - R[0][1]) / s; qt[0] = (R[0][2] + R[2][0]) / s; qt[1] = (R[1][2] + R[2][1]) / s; qt[2] = 0.25 * s; }
+}
+static void quat_mul(const double a[4], const double b[4], double o[4]) {
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+}
+static int solve_linear(double A[N][N], double b[N], double x[N]) {   /* Gaussian elimination, partial pivoting */
+    int i, j, k;
+    for (k = 0; k < N; k++) {
+        int best = k; double bv = fabs(A[k][k]);
+        for (i = k + 1; i < N; i++) if (fabs(A[i][k]) > bv) { bv = fabs(A[i][k]); best = i; }
+        if (bv == 0.0) return -1;
+        if (best != k) { double t; for (j = 0; j < N; j++) { t = A[k][j]; A[k][j] = A[best][j]; A[best][j] = t; } t = b[k]; b[k] = b[best]; b[best] = t; }
+        for (i = k + 1; i < N; i++) {
+            double f = A[i][k] / A[k][k];
+            for (j = k; j < N; j++) A[i][j] -= f * A[k][j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (i = N - 1; i >= 0; i--) { double s = b[i]; for (j = i + 1; j < N; j++) s -= A[i][j] * x[j]; x[i] = s / A[i][i]; }
+    return 0;
+}
+static void inverse_kinematics(const double q[N], const mat3 R[N], const double p[N][3], const double target[3], double q_des[N]) {
+    /* target orientation p.getQuaternionFromEuler([0, -pi, 0]) = (0, sin(-pi/2), 0, cos(-pi/2)) */
+    const double tq[4] = {0.0, sin(-KM_PI / 2), 0.0, cos(-KM_PI / 2)};
+    double ee[3], Jv[3][N], Jw[3][N], J[6][N], dS[6], cq[4], cinv[4], dq[4], A[N][N], b[N], dth[N];
+    double angle, s2, axis[3], maxabs = 0; int i, j, k;
+    link7_point(R, p, KM_EE_POINT, ee);
+    point_jacobian(R, p, ee, Jv, Jw);
+    for (j = 0; j < N; j++) for (k = 0; k < 3; k++) { J[k][j] = Jv[k][j]; J[k + 3][j] = Jw[k][j]; }
+    for (k = 0; k < 3; k++) dS[k] = target[k] - ee[k];
+    quat_from_mat(R[N - 1], cq);
+    cinv[0] = -cq[0]; cinv[1] = -cq[1]; cinv[2] = -cq[2]; cinv[3] = cq[3];
+    quat_mul(tq, cinv, dq);                                   /* deltaQ = endQ * startQ^-1 */
+    { double w = dq[3]; if (w > 1) w = 1; if (w < -1) w = -1; angle = 2.0 * acos(w); }
+    s2 = 1.0 - dq[3] * dq[3];
+    if (s2 < 10.0 * 2.2204460492503131e-16) { axis[0] = 1; axis[1] = 0; axis[2] = 0; }
+    else { double s = 1.0 / sqrt(s2); axis[0] = dq[0] * s; axis[1] = dq[1] * s; axis[2] = dq[2] * s; }
+    if (angle > KM_PI) angle -= 2 * KM_PI;
+    { double nrm = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+      for (k = 0; k < 3; k++) dS[3 + k] = angle * (axis[k] / nrm); }
+    /* (J^T J + diag(damping)) dtheta = J^T dS */
+    for (i = 0; i < N; i++) {
+        for (j = 0; j < N; j++) { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * J[k][j]; A[i][j] = s; }
+        A[i][i] += KM_IK_DAMPING;
+        { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * dS[k]; b[i] = s; }
+    }
+    if (solve_linear(A, b, dth) != 0) memset(dth, 0, sizeof dth);
+    for (i = 0; i < N; i++) if (fabs(dth[i]) > maxabs) maxabs = fabs(dth[i]);
+    if (maxabs > KM_IK_MAX_ANGLE) for (i = 0; i < N; i++) dth[i] *= KM_IK_MAX_ANGLE / maxabs;
+    for (i = 0; i < N; i++) q_des[i] = q[i] + dth[i];
+}
+
+/* ------------------------------------------------------------------ env state */
+typedef struct {
+    double q[N], qd[N];            /* arm joints                                   */
+    double ee_target[3];           /* Kuka.end_effector_pos                        */
+    double bq, bqd;                /* button glider position / velocity            */
+    int button_motor_on;           /* 0: pybullet default velocity motor, 1: step2's position target */
+    double button_xy[2];           /* button base position on the table            */
+    double button_pos[3];          /* target: cap position at reset + 0.28 in z    */
+    double gripper[3];             /* getArmPos() after the last physics step      */
+    int contact_button, contact_table;   /* manifolds of the last stepSimulation  */
+    int counter, n_contacts, n_outside, terminated;
+} kenv;
+
+typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints; double max_distance; } kcfg;
+
+/* ------------------------------------------------------------------ collision */
+/* signed distance between a sphere and an upright solid cylinder (axis z, centre xy, z in [z0, z1]);
+ * n = unit normal from the cylinder towards the sphere */
+static double sphere_cylinder(const double c[3], double rad, const double xy[2], double R, double z0, double z1, double n[3]) {
+    double dx = c[0] - xy[0], dy = c[1] - xy[1], rho = sqrt(dx * dx + dy * dy);
+    double er = rho - R, ez_top = c[2] - z1, ez_bot = z0 - c[2], ez = ez_top > ez_bot ? ez_top : ez_bot;
+    double rx = rho > 1e-12 ? dx / rho : 1.0, ry = rho > 1e-12 ? dy / rho : 0.0, sz = ez_top > ez_bot ? 1.0 : -1.0;
+    if (er <= 0 && ez <= 0) {                 /* centre inside the solid: exit through the nearest face */
+        if (er > ez) { n[0] = rx; n[1] = ry; n[2] = 0; return er - rad; }
+        n[0] = 0; n[1] = 0; n[2] = sz; return ez - rad;
+    }
+    if (er <= 0) { n[0] = 0; n[1] = 0; n[2] = sz; return ez - rad; }
+    if (ez <= 0) { n[0] = rx; n[1] = ry; n[2] = 0; return er - rad; }
+    { double dist = sqrt(er * er + ez * ez); n[0] = rx * er / dist; n[1] = ry * er / dist; n[2] = sz * ez / dist; return dist - rad; }
+}
+
+/* ------------------------------------------------------------------ one physics step */
+typedef struct { double J[N]; double Jb; double WJ[N]; double WJb; double Dinv, rhs, lo, hi, applied; } row_t;
+
+static void add_row(row_t *rows, int *nrows, const double J[N], double Jb, const double W[N][N], double Wb,
+                    double desired_vel, double pos_error_vel, const double qd[N], double bqd, double lo, double hi) {
+    row_t *r = &rows[(*nrows)++]; int i, j; double D = 0, rel = 0;
+    for (i = 0; i < N; i++) { double s = 0; for (j = 0; j < N; j++) s += W[i][j] * J[j]; r->WJ[i] = s; r->J[i] = J[i]; }
+    r->Jb = Jb; r->WJb = Wb * Jb;
+    for (i = 0; i < N; i++) { D += J[i] * r->WJ[i]; rel += J[i] * qd[i]; }
+    D += Jb * r->WJb; rel += Jb * bqd;
+    r->Dinv = 1.0 / D;
+    r->rhs = (desired_vel - rel) * r->Dinv + pos_error_vel * r->Dinv;   /* velocityImpulse + penetrationImpulse */
+    r->lo = lo; r->hi = hi; r->applied = 0.0;
+}
+
+/* Kuka.applyAction (kuka.py:118-187) followed by p.stepSimulation() */
+static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets) {
+    mat3 R[N]; double p[N][3], q_des[N], tau[N], qdd[N], W[N][N], dv[N], dvb = 0.0;
+    const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
+    row_t rows[MAX_ROWS]; int nrows = 0, i, k, it, s;
+    const double (*box)[3] = KM_EE_BOX[cfg->random_target ? 0 : 1];
+    double zeroJ[N] = {0};
+
+    forward_kinematics(e->q, R, p);
+    if (!joint_targets) {
+        for (k = 0; k < 3; k++) {                                   /* kuka.py:134-139 */
+            e->ee_target[k] += motor[k];
+            if (e->ee_target[k] < box[0][k]) e->ee_target[k] = box[0][k];
+            if (e->ee_target[k] > box[1][k]) e->ee_target[k] = box[1][k];
+        }
+        inverse_kinematics(e->q, R, p, e->ee_target, q_des);      /* kuka.py:155-156 */
+    } else memcpy(q_des, joint_targets, sizeof q_des);           /* kuka.py:160-163 */
+
+    /* -- collision detection at the current poses (start of stepSimulation) -- */
+    e->contact_button = 0; e->contact_table = 0;
+    {
+        double cap_z0 = KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + e->bq;
+        /* -- unconstrained velocities: ABA with joint damping torques and gravity -- */
+        for (i = 0; i < N; i++) tau[i] = -KM_JOINT_DAMPING * e->qd[i];
+        aba(e->q, e->qd, tau, KM_GRAVITY_Z, qdd);
+        for (i = 0; i < N; i++) e->qd[i] += dt * qdd[i];
+        e->bqd += dt * KM_GRAVITY_Z;
+        mass_matrix_inverse(e->q, W);
+
+        /* -- constraint rows: motors, then violated joint limits, then contacts -- */
+        for (i = 0; i < N; i++) {                                   /* arm motors, kuka.py:167-170 */
+            double J[N] = {0}, target = KM_ARM_KP * (q_des[i] - e->q[i]) / dt;
+            if (target > KM_ARM_MAX_VEL) target = KM_ARM_MAX_VEL;
+            if (target < -KM_ARM_MAX_VEL) target = -KM_ARM_MAX_VEL;
+            J[i] = 1.0;
+            add_row(rows, &nrows, J, 0.0, W, Wb, target, 0.0, e->qd, e->bqd, -KM_ARM_MAX_FORCE * dt, KM_ARM_MAX_FORCE * dt);
+        }
+        if (e->button_motor_on)                                    /* kuka_button_gym_env.py:347 */
+            add_row(rows, &nrows, zeroJ, 1.0, W, Wb, KM_BUTTON_KP * (KM_BUTTON_TARGET - e->bq) / dt, 0.0, e->qd, e->bqd,
+                    -KM_BUTTON_MAX_FORCE * dt, KM_BUTTON_MAX_FORCE * dt);
+        else
+            add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, 0.0, e->qd, e->bqd, -KM_DEFAULT_MOTOR_IMPULSE, KM_DEFAULT_MOTOR_IMPULSE);
+        for (i = 0; i < N; i++) {                                   /* joint limits (only when violated) */
+            double J[N] = {0}, pen_lo = e->q[i] - KM_JOINT_LOWER[i], pen_hi = KM_JOINT_UPPER[i] - e->q[i];
+            if (pen_lo <= 0) { J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, 0.0, -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_hi <= 0) { J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, 0.0, -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+        }
+        { double pen_lo = e->bq - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - e->bq;
+          if (pen_lo <= 0) add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE);
+          if (pen_hi <= 0) add_row(rows, &nrows, zeroJ, -1.0, W, Wb, 0.0, -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+        for (s = 0; s < KM_NSPHERE; s++) {                          /* gripper spheres vs cap, base, table */
+            double c[3], n[3], dist, pt[3], Jv[3][N], Jw[3][N], J[N]; int shape;
+            link7_point(R, p, KM_SPHERE[s], c);
+            if (c[2] - KM_SPHERE[s][3] - KM_TABLE_TOP_Z < KM_CONTACT_THRESHOLD) e->contact_table = 1;
+            for (shape = 0; shape < 2; shape++) {
+                double pos_err_vel, allow;
+                if (shape == 0) dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, n);
+                else dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_BASE_RADIUS, KM_BUTTON_BASE_Z, KM_BUTTON_BASE_Z + KM_BASE_HEIGHT, n);
+                if (!(dist < KM_CONTACT_THRESHOLD)) continue;
+                if (shape == 0) e->contact_button = 1;
+                for (k = 0; k < 3; k++) pt[k] = c[k] - KM_SPHERE[s][3] * n[k];      /* contact point on the sphere */
+                point_jacobian(R, p, pt, Jv, Jw);
+                for (i = 0; i < N; i++) J[i] = n[0] * Jv[0][i] + n[1] * Jv[1][i] + n[2] * Jv[2][i];
+                /* separated: allow approach up to dist/dt; penetrating: push out with erp */
+                allow = dist > 0 ? -dist / dt : 0.0;
+                pos_err_vel = dist > 0 ? 0.0 : -dist * KM_ERP / dt;
+                add_row(rows, &nrows, J, shape == 0 ? -n[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, e->bqd, 0.0, 1e10);
+            }
+        }
+    }
+    /* -- projected Gauss-Seidel, numSolverIterations = 150 -- */
+    memset(dv, 0, sizeof dv);
+    for (it = 0; it < KM_SOLVER_ITERS; it++) {
+        for (k = 0; k < nrows; k++) {
+            row_t *r = &rows[k]; double jdv = r->Jb * dvb, delta, sum;
+            for (i = 0; i < N; i++) jdv += r->J[i] * dv[i];
+            delta = r->rhs - jdv * r->Dinv;
+            sum = r->applied + delta;
+            if (sum < r->lo) { delta = r->lo - r->applied; r->applied = r->lo; }
+            else if (sum > r->hi) { delta = r->hi - r->applied; r->applied = r->hi; }
+            else r->applied = sum;
+            for (i = 0; i < N; i++) dv[i] += delta * r->WJ[i];
+            dvb += delta * r->WJb;
+        }
+    }
+    /* -- semi-implicit Euler -- */
+    for (i = 0; i < N; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
+    e->bqd += dvb; e->bq += dt * e->bqd;
+    forward_kinematics(e->q, R, p);
+    link7_point(R, p, KM_GRIPPER_POINT, e->gripper);
+}
+
+/* ------------------------------------------------------------------ env wrapper */
+static double norm3(const double a[3], const double b[3]) {      /* np.linalg.norm(a - b, 2): ddot with fma */
+    double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
+}
+static int termination(const kenv *e) { return e->terminated || e->counter > KM_MAX_STEPS; }   /* :422-426 */
+
+static double reward_fn(kenv *e, const kcfg *cfg) {              /* :428-463 */
+    double distance = norm3(e->button_pos, e->gripper);
+    int reward = e->contact_button ? 1 : 0;
+    e->n_contacts += reward;
+    if (distance > cfg->max_distance || e->contact_table) { reward = -1; e->n_outside += 1; }
+    else e->n_outside = 0;
+    if (e->contact_table || e->n_contacts >= KM_N_CONTACTS_BEFORE_TERMINATION || e->n_outside >= KM_N_STEPS_OUTSIDE_SAFETY_SPHERE)
+        e->terminated = 1;
+    if (cfg->shape_reward) {
+        if (cfg->is_discrete) return -distance;
+        if (e->terminated && reward > 0) return 50;
+        if (e->terminated && reward < 0) return -250;
+        return -distance;
+    }
+    return reward;
+}
+
+typedef struct { int mode; np_rng mt; philox_t ph; } krng;
+static double k_double(krng *r) { return r->mode == 2 ? np_rng_double(&r->mt) : philox_double(&r->ph); }
+static double k_uniform(krng *r, double lo, double hi) { return r->mode == 2 ? np_rng_uniform(&r->mt, lo, hi) : philox_uniform(&r->ph, lo, hi); }
+static double k_normal(krng *r, double loc, double scale) { return r->mode == 2 ? np_rng_normal(&r->mt, loc, scale) : loc + scale * philox_std_normal(&r->ph); }
+static uint32_t k_randint3(krng *r) { return r->mode == 2 ? np_rng_randint(&r->mt, 3) : philox_bounded(&r->ph, 2); }
+
+/* arm/button state after the 500 settle steps (kuka_button_gym_env.py:242-247); the arm never
+ * touches anything while settling, so it is the same for every button position. */
+static void settle(kenv *e, const kcfg *cfg) {
+    const double zero[5] = {0, 0, 0, 0, 0}; int i;
+    memset(e, 0, sizeof *e);
+    for (i = 0; i < N; i++) e->q[i] = KM_JOINT_POSITIONS[i];
+    memcpy(e->ee_target, KM_EE_INIT, sizeof e->ee_target);
+    e->button_xy[0] = KM_BUTTON_X; e->button_xy[1] = KM_BUTTON_Y;
+    for (i = 0; i < KM_N_SETTLE_STEPS; i++) physics_step(e, cfg, zero, cfg->action_joints ? KM_JOINT_POSITIONS : NULL);
+}
+
+static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) {   /* :214-281 */
+    double bx = KM_BUTTON_X, by = KM_BUTTON_Y; int i;
+    if (cfg->random_target) { bx += 0.15 * k_uniform(r, -1, 1); by += 0.3 * k_uniform(r, -1, 1); }
+    *e = *settled;
+    e->button_xy[0] = bx; e->button_xy[1] = by;
+    for (i = 0; i < KM_N_RANDOM_ACTIONS_AT_INIT; i++) {
+        double action[5] = {0, 0, 0, 0, 0};
+        if (cfg->is_discrete) {
+            double sign = k_double(r) > 0.5 ? 1.0 : -1.0;
+            uint32_t idx = k_randint3(r);
+            action[idx] += sign * KM_DELTA_V;
+            physics_step(e, cfg, action, NULL);
+        } else if (cfg->action_joints) {
+            /* np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1), broadcast */
+            double joints[N], g = k_normal(r, 7.0, 1.0);
+            int j; for (j = 0; j < N; j++) joints[j] = KM_JOINT_POSITIONS[j] + KM_DELTA_THETA * g;
+            physics_step(e, cfg, action, joints);
+        } else {
+            /* np_random.normal((3,)) -> one draw 3 + N(0,1); L2-normalised 1-vector = +-1, broadcast */
+            double g = k_normal(r, 3.0, 1.0), dir = g / sqrt(fma(g, g, 0.0));
+            action[0] += KM_DELTA_V_CONTINUOUS * dir; action[1] += KM_DELTA_V_CONTINUOUS * dir; action[2] += KM_DELTA_V_CONTINUOUS * dir;
+            physics_step(e, cfg, action, NULL);
+        }
+    }
+    e->button_pos[0] = bx; e->button_pos[1] = by;
+    e->button_pos[2] = KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + e->bq + KM_BUTTON_DISTANCE_HEIGHT;   /* :273-274 */
+    e->counter = 0; e->n_contacts = 0; e->n_outside = 0; e->terminated = 0;
+}
+
+static void observe(const kenv *e, int obs_mode, float *o) {     /* getSRLState :175-189 */
+    int k = 0, j;
+    if (obs_mode == 0 || obs_mode == 2) for (j = 0; j < 3; j++) o[k++] = (float)(e->gripper[j] - e->button_pos[j]);
+    if (obs_mode == 1 || obs_mode == 2) for (j = 0; j < 14; j++) o[k++] = (float)KM_JOINT_POSITIONS[j];
+}
+
+/* KukaButtonGymEnv.step (:293-340) + step2 (:342-368).  action < 0 == None. */
+static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const float *caction, int *done) {
+    double motor[5] = {0, 0, 0, 0, 0}, joints[N]; const double *jt = NULL; int rep;
+    if (action < 0) { if (cfg->action_joints) jt = KM_JOINT_POSITIONS; }      /* None: :295-299, no RNG draw */
+    else if (cfg->is_discrete) {
+        double dv = KM_DELTA_V + k_normal(r, 0.0, KM_NOISE_STD);
+        if (action == 0) motor[0] = -dv; else if (action == 1) motor[0] = dv;
+        else if (action == 2) motor[1] = -dv; else if (action == 3) motor[1] = dv;
+        else if (action == 4) motor[2] = -dv; else if (action == 5) motor[2] = cfg->force_down ? -dv : dv;
+    } else if (cfg->action_joints) {
+        double dth = KM_DELTA_THETA + k_normal(r, 0.0, KM_NOISE_STD_JOINTS); int j;
+        /* float32 action * python float stays float32, + float64 list -> float64 */
+        for (j = 0; j < N; j++) joints[j] = (double)(caction[j] * (float)dth) + KM_JOINT_POSITIONS[j];
+        jt = joints;
+    } else {
+        double dv = KM_DELTA_V_CONTINUOUS + k_normal(r, 0.0, KM_NOISE_STD_CONTINUOUS);
+        /* action[i] is a numpy float32 scalar: float32 * python float -> float64 product */
+        motor[0] = (double)caction[0] * dv; motor[1] = (double)caction[1] * dv;
+        motor[2] = cfg->force_down ? -fabs((double)caction[2] * dv) : (double)caction[2] * dv;
+    }
+    e->button_motor_on = 1;                                        /* step2 :347 */
+    for (rep = 0; rep < cfg->action_repeat; rep++) {
+        physics_step(e, cfg, motor, jt);
+        if (termination(e)) break;
+        e->counter += 1;
+    }
+    { double reward = reward_fn(e, cfg); *done = termination(e); return reward; }
+}
+
+/* ------------------------------------------------------------------ batch entry points */
+/* Rollout of n envs, T steps each, auto-reset (VecEnv worker semantics).
+ * actions: int32 [T][n] (discrete, -1 = None) or float [T][n][adim]; NULL -> Philox random agent.
+ * Outputs (any may be NULL): obs0 [n][od], obs [T][n][od] f32, rew f32 / rew64 f64 [T][n], done u8 [T][n],
+ * q_trace [T][n][7] f64 (joint positions after each step, BEFORE a possible auto-reset),
+ * grip_trace [T][n][3], final [n][24]: q7 qd7 ee3 bq bqd counter n_contacts n_outside terminated button_z. */
+int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, int force_down, int shape_reward,
+                        int action_repeat, double max_distance, int obs_mode, int rng_mode, int auto_reset, int n, int T,
+                        const int64_t *seeds, const uint32_t *mt_keys, const int32_t *mt_key_len, const void *actions,
+                        float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out, void *act_out,
+                        double *q_trace, double *grip_trace, double *final_state, double *ep_stats) {
+    kcfg cfg; kenv settled; int e;
+    const int od = obs_mode == 1 ? 14 : obs_mode == 2 ? 17 : 3, adim = is_discrete ? 1 : action_joints ? 7 : 3;
+    cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
+    cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
+    cfg.max_distance = max_distance;
+    settle(&settled, &cfg);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (e = 0; e < n; e++) {
+        kenv env; krng *r = (krng *)malloc(sizeof(krng)); philox_t act; int t;
+        double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
+        r->mode = rng_mode;
+        if (rng_mode == 2) np_rng_seed_array(&r->mt, mt_keys + 2 * (size_t)e, mt_key_len[e]);
+        r->ph.k0 = (uint32_t)(uint64_t)seeds[e]; r->ph.k1 = (uint32_t)((uint64_t)seeds[e] >> 32); r->ph.ctr = 0; r->ph.stream = 0;
+        act = r->ph; act.stream = 1;
+        env_reset(&env, &cfg, r, &settled);
+        if (obs0) observe(&env, obs_mode, obs0 + (size_t)e * od);
+        for (t = 0; t < T; t++) {
+            size_t row = (size_t)t * n + e; int a = 0, done; float ca[7] = {0}; double reward;
+            if (actions) {
+                if (is_discrete) a = ((const int32_t *)actions)[row];
+                else memcpy(ca, (const float *)actions + row * adim, sizeof(float) * adim);
+            } else {
+                if (is_discrete) a = (int)philox_bounded(&act, 5);
+                else { int j; for (j = 0; j < adim; j += 2) { uint32_t o[4]; philox_block(&act, o); ca[j] = (float)(-1.0 + 2.0 * philox_to_double(o[0], o[1])); if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * philox_to_double(o[2], o[3])); } }
+                if (act_out) { if (is_discrete) ((int32_t *)act_out)[row] = a; else memcpy((float *)act_out + row * adim, ca, sizeof(float) * adim); }
+            }
+            reward = env_step(&env, &cfg, r, a, ca, &done);
+            if (q_trace) memcpy(q_trace + row * N, env.q, sizeof(double) * N);
+            if (grip_trace) memcpy(grip_trace + row * 3, env.gripper, sizeof(double) * 3);
+            ep_ret += reward; ep_len += 1;
+            if (done) {
+                last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
+                if (auto_reset) env_reset(&env, &cfg, r, &settled);
+            }
+            if (obs) observe(&env, obs_mode, obs + row * od);
+            if (rew) rew[row] = (float)reward;
+            if (rew64) rew64[row] = reward;
+            if (done_out) done_out[row] = (uint8_t)done;
+        }
+        if (final_state) {
+            double *f = final_state + 24 * (size_t)e; int j;
+            for (j = 0; j < N; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
+            f[14] = env.ee_target[0]; f[15] = env.ee_target[1]; f[16] = env.ee_target[2]; f[17] = env.bq; f[18] = env.bqd;
+            f[19] = env.counter; f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.button_pos[2];
+        }
+        if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
+        free(r);
+    }
+    return 0;
+}
+
+/* The settled state itself (q7 qd7 ee3 bq bqd gripper3) and raw dynamics probes for the
+ * independent numpy cross-check (tests/test_kuka_dynamics.py). */
+void kuka_oracle_settled(int random_target, int action_joints, double *out22) {
+    kcfg cfg; kenv s; int j;
+    memset(&cfg, 0, sizeof cfg); cfg.random_target = random_target; cfg.action_joints = action_joints; cfg.action_repeat = 1; cfg.is_discrete = 1;
+    settle(&s, &cfg);
+    for (j = 0; j < N; j++) { out22[j] = s.q[j]; out22[7 + j] = s.qd[j]; }
+    out22[14] = s.ee_target[0]; out22[15] = s.ee_target[1]; out22[16] = s.ee_target[2]; out22[17] = s.bq; out22[18] = s.bqd;
+    out22[19] = s.gripper[0]; out22[20] = s.gripper[1]; out22[21] = s.gripper[2];
+}
+void kuka_oracle_aba(const double *q, const double *qd, const double *tau, double gz, double *qdd) { aba(q, qd, tau, gz, qdd); }
+void kuka_oracle_minv(const double *q, double *W49) { double W[N][N]; int i, j; mass_matrix_inverse(q, W); for (i = 0; i < N; i++) for (j = 0; j < N; j++) W49[i * N + j] = W[i][j]; }
+void kuka_oracle_fk(const double *q, double *R63, double *p21) {
+    mat3 R[N]; double p[N][3]; int i, a, b;
+    forward_kinematics(q, R, p);
+    for (i = 0; i < N; i++) { for (a = 0; a < 3; a++) { for (b = 0; b < 3; b++) R63[i * 9 + a * 3 + b] = R[i][a][b]; p21[i * 3 + a] = p[i][a]; } }
+}
+void kuka_oracle_ik(const double *q, const double *target, double *q_des) {
+    mat3 R[N]; double p[N][3]; forward_kinematics(q, R, p); inverse_kinematics(q, R, p, target, q_des);
+}
+/* scripted-wrapper probe: reward/termination logic on caller-supplied physics outputs */
+void kuka_oracle_wrapper_step(double *state8, const double *gripper, const double *button_pos, int contact_button, int contact_table,
+                              int shape_reward, int is_discrete, double max_distance, double *reward, int *done) {
+    kenv e; kcfg cfg; memset(&e, 0, sizeof e); memset(&cfg, 0, sizeof cfg);
+    e.counter = (int)state8[0]; e.n_contacts = (int)state8[1]; e.n_outside = (int)state8[2]; e.terminated = (int)state8[3];
+    memcpy(e.gripper, gripper, sizeof e.gripper); memcpy(e.button_pos, button_pos, sizeof e.button_pos);
+    e.contact_button = contact_button; e.contact_table = contact_table;
+    cfg.shape_reward = shape_reward; cfg.is_discrete = is_discrete; cfg.max_distance = max_distance;
+    if (!termination(&e)) e.counter += 1;                         /* step2 loop with action_repeat = 1 */
+    *reward = reward_fn(&e, &cfg); *done = termination(&e);
+    state8[0] = e.counter; state8[1] = e.n_contacts; state8[2] = e.n_outside; state8[3] = e.terminated;
+}
