@@ -226,13 +226,15 @@ static void inverse_kinematics(const double q[N], const mat3 R[N], const double 
     quat_from_mat(R[N - 1], cq);
     cinv[0] = -cq[0]; cinv[1] = -cq[1]; cinv[2] = -cq[2]; cinv[3] = cq[3];
     quat_mul(tq, cinv, dq);                                   /* deltaQ = endQ * startQ^-1 */
-    { double w = dq[3]; if (w > 1) w = 1; if (w < -1) w = -1; angle = 2.0 * acos(w); }
-    s2 = 1.0 - dq[3] * dq[3];
-    if (s2 < 10.0 * 2.2204460492503131e-16) { axis[0] = 1; axis[1] = 0; axis[2] = 0; }
-    else { double s = 1.0 / sqrt(s2); axis[0] = dq[0] * s; axis[1] = dq[1] * s; axis[2] = dq[2] * s; }
+    /* btQuaternion::getAngle()/getAxis(): angle = 2 acos(w), axis = xyz / sqrt(1 - w^2).  Evaluated in the
+     * equivalent, well-conditioned form angle = 2 atan2(|xyz|, w), axis = xyz / |xyz| (acos loses half the
+     * digits as w -> 1, i.e. exactly where the controller converges). */
+    s2 = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
+    angle = 2.0 * atan2(s2, dq[3]);
+    if (s2 * s2 < 10.0 * 2.2204460492503131e-16) { axis[0] = 1; axis[1] = 0; axis[2] = 0; }
+    else { axis[0] = dq[0] / s2; axis[1] = dq[1] / s2; axis[2] = dq[2] / s2; }
     if (angle > KM_PI) angle -= 2 * KM_PI;
-    { double nrm = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-      for (k = 0; k < 3; k++) dS[3 + k] = angle * (axis[k] / nrm); }
+    for (k = 0; k < 3; k++) dS[3 + k] = angle * axis[k];
     /* (J^T J + diag(damping)) dtheta = J^T dS */
     for (i = 0; i < N; i++) {
         for (j = 0; j < N; j++) { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * J[k][j]; A[i][j] = s; }

@@ -1,12 +1,322 @@
-// kuka.hip — placeholder until the Kuka stepper lands (next milestone).
+// kuka.hip — KukaButtonGymEnv stepper kernels for gfx950 (MI355X) and their host plumbing.
+//
+// Launch geometry: one lane per env, 64-lane workgroups (one wavefront), per-link
+// ABA staging in LDS ([slot][lane], 49 KiB per workgroup -> 3 workgroups per CU),
+// state structure-of-arrays in HBM (env index fastest: a wavefront's loads and
+// stores of a field are one coalesced 512-byte row).  kuka_rollout_k keeps the
+// whole env state in VGPRs for T steps and streams the [T][N] observation /
+// reward / done planes.  The path is FP64-VALU / dependency-latency bound (150
+// sequential Gauss-Seidel sweeps per physics step), not HBM bound and not
+// MFMA-shaped; see DESIGN.md §Kuka kernel for the roofline accounting.
 #include "internal.hpp"
+#include "kuka_env.hpp"
+
 namespace srl {
-struct KukaState {};
-int kuka_alloc(Handle *h) { return h->fail(SRLHIP_ENOTSUP, "KukaButtonGymEnv kernels not built yet"); }
-void kuka_free(Handle *) {}
-int kuka_reset(Handle *h, const uint8_t *, const double *, void *) { return h->fail(SRLHIP_ENOTSUP, "kuka"); }
-int kuka_step(Handle *h, const void *, const double *, void *, float *, uint8_t *) { return h->fail(SRLHIP_ENOTSUP, "kuka"); }
-int kuka_rollout(Handle *h, int, const void *, void *, float *, uint8_t *, void *) { return h->fail(SRLHIP_ENOTSUP, "kuka"); }
-int kuka_field(Handle *h, int, void **, size_t *, int *) { return h->fail(SRLHIP_EINVAL, "unknown field"); }
-int kuka_reset_rand_count(const srlhip_config &) { return 0; }
+
+using namespace kuka;
+
+constexpr int kWave = 64;
+constexpr int NDBL = 41, NINT = 7;
+
+// SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
+enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38 };
+// SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
+enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6 };
+
+struct KukaState {
+    double *d;          // [NDBL][n]
+    int32_t *i;         // [NINT][n]
+    double *rows;       // [SC_ROWS_TOTAL][n]  generic constraint rows (global scratch)
+    double *settled;    // [kStartDoubles]
+    double *starts;     // [nstarts][kStartDoubles]
+    int32_t nstarts;
+};
+
+namespace {
+
+struct KukaParams { Cfg cfg; int32_t n; };
+
+__device__ __forceinline__ void load_env(const KukaState &s, int64_t n, int64_t e, Env &v) {
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        v.q[k] = s.d[(D_Q + k) * n + e]; v.qd[k] = s.d[(D_QD + k) * n + e];
+        v.sq[k] = s.d[(D_SQ + k) * n + e]; v.cq[k] = s.d[(D_CQ + k) * n + e];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
+    v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
+    v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
+    v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
+    v.terminated = s.i[I_TERM * n + e];
+}
+__device__ __forceinline__ void store_env(const KukaState &s, int64_t n, int64_t e, const Env &v) {
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        s.d[(D_Q + k) * n + e] = v.q[k]; s.d[(D_QD + k) * n + e] = v.qd[k];
+        s.d[(D_SQ + k) * n + e] = v.sq[k]; s.d[(D_CQ + k) * n + e] = v.cq[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
+    s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
+    s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
+    s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
+    s.i[I_TERM * n + e] = v.terminated;
+}
+
+struct DevMt { Mt19937 m;
+    __device__ double double01() { return m.double01(); } __device__ double uniform(double a, double b) { return m.uniform(a, b); }
+    __device__ double normal(double a, double b) { return m.normal(a, b); } __device__ uint32_t bounded(uint32_t r) { return m.bounded(r); } };
+struct DevPhilox { Philox p;
+    __device__ double double01() { return p.double01(); } __device__ double uniform(double a, double b) { return p.uniform(a, b); }
+    __device__ double normal(double a, double b) { return p.normal(a, b); } __device__ uint32_t bounded(uint32_t r) { return p.bounded(r); } };
+template <int MODE> struct KRng;
+template <> struct KRng<SRLHIP_RNG_HOST> { using type = HostDraws; };
+template <> struct KRng<SRLHIP_RNG_PHILOX> { using type = DevPhilox; };
+template <> struct KRng<SRLHIP_RNG_MT19937> { using type = DevMt; };
+
+template <int MODE>
+__device__ __forceinline__ void krng_load(typename KRng<MODE>::type &r, const RngState &rs, int e, int n, const double *draws) {
+    if constexpr (MODE == SRLHIP_RNG_HOST) { r.v = draws; r.i = 0; }
+    else if constexpr (MODE == SRLHIP_RNG_PHILOX) { r.p.k0 = rs.key[e]; r.p.k1 = rs.key[n + e]; r.p.ctr = rs.ctr[e]; r.p.stream = 0; }
+    else r.m.load(rs.mt, e);
+}
+template <int MODE>
+__device__ __forceinline__ void krng_store(const typename KRng<MODE>::type &r, const RngState &rs, int e) {
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = r.p.ctr;
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) r.m.store(rs.mt, e);
+}
+
+extern __shared__ double kuka_lds[];
+
+__device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, int64_t e) {
+    Scratch sc;
+    sc.b = kuka_lds + threadIdx.x; sc.st = kWave; sc.g = s.rows + e; sc.gst = n;
+    return sc;
+}
+
+// 500 settle steps (kuka_button_gym_env.py:242-247).  Every lane integrates the same env so that
+// wave-level votes stay uniform; lane 0 publishes.
+__global__ void __launch_bounds__(kWave) kuka_settle_k(KukaParams p, KukaState s) {
+    Scratch sc = make_scratch(s, p.n, 0);
+    sc.g = s.rows + threadIdx.x % p.n;
+    Env e;
+    initial_env(e);
+    const double zero[3] = {0, 0, 0};
+    double jt[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
+    for (int i = 0; i < kNSettleSteps; i++) physics_step(e, p.cfg, sc, zero, p.cfg.action_joints != 0, jt);
+    if (threadIdx.x == 0) pack_start(e, s.settled);
+}
+
+// table of the 6^5 (2^5) possible episode start states
+__global__ void __launch_bounds__(kWave) kuka_starts_k(KukaParams p, KukaState s) {
+    const int idx = blockIdx.x * kWave + threadIdx.x;
+    if (idx >= s.nstarts) return;
+    Scratch sc = make_scratch(s, p.n, 0);
+    sc.g = s.rows + idx % p.n;            // start states are contact-free: the rows are never touched
+    Env e;
+    unpack_start(e, s.settled);
+    e.bx = kButtonX; e.by = kButtonY; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    e.bpos[0] = e.bpos[1] = e.bpos[2] = 0.0;
+    const int base = p.cfg.is_discrete ? 6 : 2;
+    int rem = idx;
+    for (int k = 0; k < kNInitActions; k++) { init_action_step(e, p.cfg, sc, rem % base); rem /= base; }
+    pack_start(e, s.starts + (int64_t)idx * kStartDoubles);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kWave)
+kuka_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand,
+             int rand_stride, float *obs) {
+    const int e = blockIdx.x * kWave + threadIdx.x;
+    if (e >= p.n) return;
+    if (mask && !mask[e]) return;
+    const int64_t n = p.n;
+    Scratch sc = make_scratch(s, n, e);
+    typename KRng<MODE>::type rng;
+    krng_load<MODE>(rng, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
+    Env v;
+    reset_env(v, p.cfg, sc, rng, s.starts, s.settled);
+    store_env(s, n, e, v);
+    krng_store<MODE>(rng, rs, e);
+    st.ep_return[e] = 0.0; st.ep_length[e] = 0;
+    if (obs) {
+        const int od = p.cfg.obs_mode == 1 ? 14 : p.cfg.obs_mode == 2 ? 17 : 3;
+        observe(v, p.cfg, obs + (int64_t)e * od, 1);
+    }
+}
+
+// T consecutive VecEnv steps per launch (T == 1: the per-step entry point).
+template <int MODE>
+__global__ void __launch_bounds__(kWave)
+kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
+               float *obs, float *rew, uint8_t *done_out, void *act_out) {
+    const int e = blockIdx.x * kWave + threadIdx.x;
+    if (e >= p.n) return;
+    const int64_t n = p.n;
+    const Cfg &cfg = p.cfg;
+    Scratch sc = make_scratch(s, n, e);
+    typename KRng<MODE>::type rng;
+    krng_load<MODE>(rng, rs, e, p.n, noise ? noise + e : nullptr);
+    Env v;
+    load_env(s, n, e, v);
+    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    Philox act; act.k0 = rs.key[e]; act.k1 = rs.key[n + e]; act.ctr = rs.act_ctr[e]; act.stream = 1;
+    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
+    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    for (int t = 0; t < T; t++) {
+        const int64_t row = (int64_t)t * n + e;
+        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (actions) {
+            if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
+            else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
+        } else {
+            if (cfg.is_discrete) a = (int)act.bounded(5);
+            else for (int j = 0; j < adim; j += 2) {
+                uint32_t o[4]; act.block(o);
+                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+            }
+            if (act_out) {
+                if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
+                else for (int j = 0; j < adim; j++) static_cast<float *>(act_out)[row * adim + j] = ca[j];
+            }
+        }
+        bool done;
+        const double reward = env_step(v, cfg, sc, rng, a, ca, &done);
+        ep_ret += reward; ep_len += 1; last_reward = reward;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+            if (cfg.auto_reset) reset_env(v, cfg, sc, rng, s.starts, s.settled);
+        }
+        if (obs) observe(v, cfg, obs + row * od, 1);
+        if (rew) rew[row] = (float)reward;
+        if (done_out) done_out[row] = (uint8_t)done;
+    }
+    store_env(s, n, e, v);
+    krng_store<MODE>(rng, rs, e);
+    if (!actions) rs.act_ctr[e] = act.ctr;
+    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
+    st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
+}
+
+KukaParams params_of(const Handle *h) {
+    KukaParams p;
+    const srlhip_config &c = h->cfg;
+    p.cfg.random_target = c.random_target; p.cfg.force_down = c.force_down; p.cfg.shape_reward = c.shape_reward;
+    p.cfg.action_repeat = c.action_repeat; p.cfg.is_discrete = c.is_discrete; p.cfg.action_joints = c.action_joints;
+    p.cfg.obs_mode = c.obs_mode; p.cfg.auto_reset = c.auto_reset; p.cfg.max_distance = c.max_distance;
+    p.n = h->n;
+    return p;
+}
+
+constexpr size_t kLdsBytes = (size_t)SC_TOTAL * kWave * sizeof(double);
+
+template <class K>
+int allow_lds(Handle *h, K kernel) {
+    SRL_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kLdsBytes));
+    return 0;
+}
+
+}  // namespace
+
+int kuka_reset_rand_count(const srlhip_config &c) { return (c.random_target ? 2 : 0) + (c.is_discrete ? 10 : 5); }
+
+int kuka_alloc(Handle *h) {
+    if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
+        return h->fail(SRLHIP_ENOTSUP, "KukaButtonGymEnv raw_pixels: tile rasteriser not built yet");
+    KukaState *s = new KukaState();
+    h->kuka = s;
+    const size_t n = (size_t)h->n;
+    int rc;
+    s->nstarts = (!h->cfg.is_discrete && h->cfg.action_joints) ? 0 : h->cfg.is_discrete ? kNumStartsDiscrete : kNumStartsContinuous;
+    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) ||
+        (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
+        return rc;
+    if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k)) ||
+        (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_HOST>)) || (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_PHILOX>)) ||
+        (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_MT19937>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_HOST>)) ||
+        (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_PHILOX>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_MT19937>)))
+        return rc;
+    KukaParams p = params_of(h);
+    hipLaunchKernelGGL(kuka_settle_k, dim3(1), dim3(kWave), kLdsBytes, h->stream, p, *s);
+    SRL_HIP_CHECK(h, hipGetLastError());
+    if (s->nstarts > 0) {
+        hipLaunchKernelGGL(kuka_starts_k, dim3((s->nstarts + kWave - 1) / kWave), dim3(kWave), kLdsBytes, h->stream, p, *s);
+        SRL_HIP_CHECK(h, hipGetLastError());
+    }
+    return 0;
+}
+
+void kuka_free(Handle *h) { delete h->kuka; h->kuka = nullptr; }
+
+int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void *d_obs) {
+    KukaParams p = params_of(h);
+    dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
+    const int stride = kuka_reset_rand_count(h->cfg);
+    float *obs = static_cast<float *>(d_obs);
+    switch (h->cfg.rng_mode) {
+        case SRLHIP_RNG_HOST:
+            if (!d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
+            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_HOST>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+            break;
+        case SRLHIP_RNG_PHILOX:
+            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_PHILOX>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+            break;
+        default:
+            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_MT19937>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+    }
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_rew, uint8_t *d_done, void *d_act_out) {
+    KukaParams p = params_of(h);
+    dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
+    float *obs = static_cast<float *>(d_obs);
+    switch (h->cfg.rng_mode) {
+        case SRLHIP_RNG_PHILOX:
+            hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_PHILOX>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
+            break;
+        case SRLHIP_RNG_MT19937:
+            hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_MT19937>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
+            break;
+        default:
+            return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
+    }
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_obs, float *d_rew, uint8_t *d_done) {
+    if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return kuka_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
+    KukaParams p = params_of(h);
+    dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
+    hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_HOST>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, 1,
+                       d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, (void *)nullptr);
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
+    KukaState *s = h->kuka;
+    const size_t n = (size_t)h->n;
+    *elem = 8; *count = 1;
+    switch (field) {
+        case SRLHIP_F_KUKA_Q: *dptr = s->d + D_Q * n; *count = 7; return 0;
+        case SRLHIP_F_KUKA_QD: *dptr = s->d + D_QD * n; *count = 7; return 0;
+        case SRLHIP_F_KUKA_EE_TARGET: *dptr = s->d + D_EE * n; *count = 3; return 0;
+        case SRLHIP_F_KUKA_BUTTON_Q: *dptr = s->d + D_BQ * n; *count = 2; return 0;
+        case SRLHIP_F_KUKA_BUTTON_POS: *dptr = s->d + D_BPOS * n; *count = 3; return 0;
+        case SRLHIP_F_KUKA_GRIPPER: *dptr = s->d + D_GRIP * n; *count = 3; return 0;
+        case SRLHIP_F_STEP_COUNT: *dptr = s->i + I_COUNTER * n; *elem = 4; return 0;
+        case SRLHIP_F_KUKA_COUNTERS: *dptr = s->i + I_NCONTACT * n; *elem = 4; *count = 3; return 0;
+    }
+    return h->fail(SRLHIP_EINVAL, "unknown field for KukaButtonGymEnv");
+}
+
 }  // namespace srl

@@ -1,0 +1,180 @@
+// kuka_env.hpp — env-level logic of KukaButtonGymEnv on top of kuka_core.hpp:
+//   reset   kuka_button_gym_env.py:214-281   (settled state + 5 random init actions)
+//   step    :293-340, step2 :342-368, _termination :422-426, _reward :428-463, getSRLState :175-189
+//
+// Reset is O(1) on the device.  The 500 settle steps are RNG- and contact-free,
+// and each of the 5 init actions is one of only six (sign, axis) moves of 0.03 m
+// applied without noise, so an episode can only start from one of 6^5 = 7776
+// arm states (32 for continuous actions).  Those are integrated once per handle
+// with the same physics_step() and kept as a table in HBM; reset draws the RNG
+// exactly like the reference, turns the draws into a table index and gathers
+// 288 bytes.  (action_joints mode has a continuous init distribution and
+// integrates its 5 steps in the kernel.)
+#pragma once
+#include "kuka_core.hpp"
+
+namespace srl {
+namespace kuka {
+
+constexpr int kStartDoubles = 36;          // q7 qd7 sq7 cq7 ee3 bq bqd grip3
+constexpr int kNumStartsDiscrete = 7776;   // 6^5
+constexpr int kNumStartsContinuous = 32;   // 2^5
+
+SRL_HD void pack_start(const Env &e, double *o) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) { o[i] = e.q[i]; o[7 + i] = e.qd[i]; o[14 + i] = e.sq[i]; o[21 + i] = e.cq[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[28 + k] = e.ee[k]; o[33 + k] = e.grip[k]; }
+    o[31] = e.bq; o[32] = e.bqd;
+}
+SRL_HD void unpack_start(Env &e, const double *o) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) { e.q[i] = o[i]; e.qd[i] = o[7 + i]; e.sq[i] = o[14 + i]; e.cq[i] = o[21 + i]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = o[28 + k]; e.grip[k] = o[33 + k]; }
+    e.bq = o[31]; e.bqd = o[32];
+}
+
+// state right after loadSDF/resetJointState (kuka.py:56-73), before the settle steps
+SRL_HD void initial_env(Env &e) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) { e.q[i] = kJointPositions[i]; e.qd[i] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
+    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY;
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    update_trig_and_gripper(e);
+}
+
+// one init action of reset(): code = sign_bit * 3 + axis (discrete) or sign_bit (continuous)
+SRL_HD void init_action_step(Env &e, const Cfg &cfg, const Scratch &sc, int code) {
+    double motor[3] = {0, 0, 0};
+    if (cfg.is_discrete) {
+        const double sign = code >= 3 ? 1.0 : -1.0;
+        const int axis = code % 3;
+        motor[axis] += sign * kDeltaV;
+    } else {
+        const double dir = code ? 1.0 : -1.0;
+        motor[0] += kDeltaVContinuous * dir; motor[1] += kDeltaVContinuous * dir; motor[2] += kDeltaVContinuous * dir;
+    }
+    physics_step(e, cfg, sc, motor, false, motor);
+}
+
+SRL_HD double norm3(const double a[3], const double b[3]) {      // np.linalg.norm(a - b, 2): ddot with fma
+    const double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
+}
+SRL_HD bool termination(const Env &e) { return e.terminated || e.counter > kMaxSteps; }
+
+SRL_HD double reward_fn(Env &e, const Cfg &cfg) {
+    const double distance = norm3(e.bpos, e.grip);
+    int reward = e.contact_button ? 1 : 0;
+    e.n_contacts += reward;
+    if (distance > cfg.max_distance || e.contact_table) { reward = -1; e.n_outside += 1; }
+    else e.n_outside = 0;
+    if (e.contact_table || e.n_contacts >= kNContactsBeforeTermination || e.n_outside >= kNStepsOutside) e.terminated = 1;
+    if (cfg.shape_reward) {
+        if (cfg.is_discrete) return -distance;
+        if (e.terminated && reward > 0) return 50.0;
+        if (e.terminated && reward < 0) return -250.0;
+        return -distance;
+    }
+    return (double)reward;
+}
+
+// RNG adaptor over caller-supplied draws (SRLHIP_RNG_HOST)
+struct HostDraws {
+    const double *v; int i;
+    SRL_HD double double01() { return v[i++]; }
+    SRL_HD double uniform(double, double) { return v[i++]; }
+    SRL_HD double normal(double, double) { return v[i++]; }
+    SRL_HD uint32_t bounded(uint32_t) { return (uint32_t)v[i++]; }
+};
+
+// KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.
+template <class R>
+SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const double *starts, const double *settled) {
+    double bx = kButtonX, by = kButtonY;
+    if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    if (!cfg.is_discrete && cfg.action_joints) {
+        unpack_start(e, settled);
+        e.bx = bx; e.by = by;
+        for (int k = 0; k < kNInitActions; k++) {
+            // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1), broadcast
+            const double g = rng.normal(7.0, 1.0);
+            double joints[ND], motor[3] = {0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * g;
+            physics_step(e, cfg, sc, motor, true, joints);
+        }
+    } else {
+        int idx = 0, mul = 1;
+        for (int k = 0; k < kNInitActions; k++) {
+            int code;
+            if (cfg.is_discrete) {
+                const int sign_bit = rng.double01() > 0.5 ? 1 : 0;
+                const int axis = (int)rng.bounded(2);
+                code = sign_bit * 3 + axis;
+                idx += code * mul; mul *= 6;
+            } else {
+                // np_random.normal((3,)) -> one draw 3 + N(0,1); L2-normalised 1-vector = +-1, broadcast
+                const double g = rng.normal(3.0, 1.0);
+                code = (g / sqrt(fma(g, g, 0.0))) > 0 ? 1 : 0;
+                idx += code * mul; mul *= 2;
+            }
+        }
+        unpack_start(e, starts + (int64_t)idx * kStartDoubles);
+        e.bx = bx; e.by = by;
+    }
+    e.bpos[0] = bx; e.bpos[1] = by;
+    e.bpos[2] = kButtonBaseZ + kGliderOriginZ + e.bq + kButtonDistanceHeight;
+    e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+}
+
+SRL_HD void observe(const Env &e, const Cfg &cfg, float *o, int64_t stride) {   // getSRLState
+    int k = 0;
+    if (cfg.obs_mode == 0 || cfg.obs_mode == 2)
+        for (int j = 0; j < 3; j++) o[(k++) * stride] = (float)(e.grip[j] - e.bpos[j]);
+    if (cfg.obs_mode == 1 || cfg.obs_mode == 2)
+        for (int j = 0; j < 14; j++) o[(k++) * stride] = (float)kJointPositions[j];
+}
+
+// KukaButtonGymEnv.step + step2.  action < 0 == None.  Returns the reward; *done = _termination().
+template <class R>
+SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int action, const float *ca, bool *done) {
+    double motor[3] = {0, 0, 0}, joints[ND];
+    bool joint_mode = false;
+#pragma unroll
+    for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j];
+    if (action < 0) {
+        joint_mode = cfg.action_joints != 0;
+    } else if (cfg.is_discrete) {
+        const double dv = kDeltaV + rng.normal(0.0, kNoiseStd);
+        if (action == 0) motor[0] = -dv; else if (action == 1) motor[0] = dv;
+        else if (action == 2) motor[1] = -dv; else if (action == 3) motor[1] = dv;
+        else if (action == 4) motor[2] = -dv; else if (action == 5) motor[2] = cfg.force_down ? -dv : dv;
+    } else if (cfg.action_joints) {
+        const double dth = kDeltaTheta + rng.normal(0.0, kNoiseStdJoints);
+        joint_mode = true;
+#pragma unroll
+        for (int j = 0; j < ND; j++) joints[j] = (double)(ca[j] * (float)dth) + kJointPositions[j];
+    } else {
+        const double dv = kDeltaVContinuous + rng.normal(0.0, kNoiseStdContinuous);
+        motor[0] = (double)ca[0] * dv; motor[1] = (double)ca[1] * dv;
+        motor[2] = cfg.force_down ? -fabs((double)ca[2] * dv) : (double)ca[2] * dv;
+    }
+    e.motor_on = 1;
+    for (int rep = 0; rep < cfg.action_repeat; rep++) {
+        physics_step(e, cfg, sc, motor, joint_mode, joints);
+        if (termination(e)) break;
+        e.counter += 1;
+    }
+    const double reward = reward_fn(e, cfg);
+    *done = termination(e);
+    return reward;
+}
+
+}  // namespace kuka
+}  // namespace srl

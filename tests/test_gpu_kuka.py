@@ -1,0 +1,168 @@
+"""GPU parity, KukaButtonGymEnv: HIP stepper (through the C-ABI) vs the plain-C
+oracle on identical seeds/actions.  North-star bar: joint positions within 1e-4,
+discrete reward / done flags bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import clib, kuka_clib
+from srlhip import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def make(n, rng_mode=_lib.RNG_MT19937, auto_reset=1, seed0=0, first=0, **kw):
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0, cfg.first_env_id = n, rng_mode, auto_reset, seed0, first
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return _lib.Handle(cfg)
+
+
+def check_planes(ora, obs0, out, flags_exact=True):
+    assert np.abs(ora["obs0"] - obs0).max() <= TOL
+    assert np.abs(ora["obs"] - out["obs"]).max() <= TOL
+    assert np.array_equal(ora["done"], out["done"])
+    if flags_exact:
+        assert np.array_equal(ora["reward"], out["reward"])
+    else:
+        assert np.abs(ora["reward"] - out["reward"]).max() <= TOL
+
+
+def test_step_by_step_trajectories_256_envs():
+    """Per-step launches over 1001+ steps; joint positions checked after EVERY step."""
+    n, T, seed0 = 256, 1010, 3
+    actions = np.random.RandomState(5).randint(6, size=(T, n)).astype(np.int32)
+    h = make(n, seed0=seed0)
+    obs0 = h.reset()
+    ora = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions)
+    assert np.abs(ora["obs0"] - obs0).max() <= TOL
+    worst = 0.0
+    for t in range(T):
+        o, r, d = h.step(actions[t])
+        assert np.array_equal(d, ora["done"][t]), t
+        assert np.array_equal(r, ora["reward"][t]), t
+        assert np.abs(o - ora["obs"][t]).max() <= TOL, t
+        if not d.any():                       # q of a just-reset env belongs to the next episode
+            worst = max(worst, np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["q"][t]).max())
+    assert worst <= TOL
+    print("max |q_gpu - q_oracle| =", worst)
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32))
+    assert np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32))
+    assert np.array_equal(ret, ora["ep_stats"][:, 0])
+    assert fin.min() >= 1
+    h.close()
+
+
+def test_fused_rollout_4096_envs():
+    """BASELINE config 3 size: 4096 envs, one fused launch, every env crosses >= 1 auto-reset."""
+    n, T = 4096, 1001
+    actions = np.random.RandomState(6).randint(6, size=(T, n)).astype(np.int32)
+    # bias towards 'down' so that most episodes end by button/table contact well before 1001 steps
+    down = np.random.RandomState(7).rand(T, n) < 0.25
+    actions[down] = 4
+    h = make(n)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    ora = kuka_clib.rollout(np.arange(n), T, actions=actions, trace=False)
+    check_planes(ora, obs0, out)
+    f = ora["final_state"]
+    assert np.abs(h.get_state(_lib.F_KUKA_Q).T - f[:, 0:7]).max() <= TOL
+    assert np.abs(h.get_state(_lib.F_KUKA_QD).T - f[:, 7:14]).max() <= 1e-3
+    assert np.array_equal(h.get_state(_lib.F_STEP_COUNT), f[:, 19].astype(np.int32))
+    assert np.array_equal(h.get_state(_lib.F_KUKA_COUNTERS).T, f[:, 20:23].astype(np.int32))
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32)) and fin.min() >= 1
+    assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32))
+    h.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(random_target=1, shape_reward=1),
+    dict(action_repeat=3, force_down=0, max_distance=0.28),
+    dict(obs_mode=_lib.OBS_JOINTS_POSITION),
+    dict(obs_mode=_lib.OBS_JOINTS),
+])
+def test_env_options(kw):
+    n, T = 128, 600
+    actions = np.random.RandomState(8).randint(-1, 6, size=(T, n)).astype(np.int32)      # -1 == None action
+    h = make(n, seed0=40, **kw)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    okw = {k: v for k, v in kw.items()}
+    ora = kuka_clib.rollout(40 + np.arange(n), T, actions=actions, trace=False, **okw)
+    check_planes(ora, obs0, out, flags_exact=not kw.get("shape_reward"))
+    h.close()
+
+
+@pytest.mark.parametrize("joints", [0, 1])
+def test_continuous_actions(joints):
+    n, T, adim = 64, 400, 7 if joints else 3
+    actions = np.random.RandomState(9).uniform(-1, 1, size=(T, n, adim)).astype(np.float32)
+    h = make(n, seed0=9, is_discrete=0, action_joints=joints)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    ora = kuka_clib.rollout(9 + np.arange(n), T, actions=actions, is_discrete=False, action_joints=bool(joints), trace=False)
+    check_planes(ora, obs0, out)
+    h.close()
+
+
+def test_philox_random_agent_rollout():
+    """Throughput mode (what bench.py times): Philox env stream + device-sampled actions."""
+    n, T = 1024, 500
+    h = make(n, rng_mode=_lib.RNG_PHILOX, seed0=2)
+    obs0 = h.reset()
+    out = h.rollout(T)
+    ora = kuka_clib.rollout(2 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False)
+    assert np.array_equal(ora["actions"], out["actions"])
+    check_planes(ora, obs0, out)
+    h.close()
+
+
+def test_host_rng_mode_no_auto_reset():
+    """RNG_HOST harness: caller supplies np_random's draws; finished envs reset via srlhip_reset(mask)."""
+    from oracle import gym_seeding
+    n, T = 32, 700
+    rngs = [gym_seeding.np_random(500 + i)[0] for i in range(n)]
+    actions = np.random.RandomState(11).randint(6, size=(T, n)).astype(np.int32)
+    actions[np.random.RandomState(12).rand(T, n) < 0.3] = 4
+    h = make(n, rng_mode=_lib.RNG_HOST, auto_reset=0)
+
+    def reset_draws(r):
+        out = []
+        for _ in range(5):
+            out += [r.rand(), float(r.randint(3))]
+        return out
+
+    obs = h.reset(host_rand=np.array([reset_draws(r) for r in rngs]))
+    ora = kuka_clib.rollout(500 + np.arange(n), T, actions=actions)
+    assert np.abs(obs - ora["obs0"]).max() <= TOL
+    for t in range(T):
+        noise = np.array([r.normal(0.0, scale=0.01) for r in rngs])
+        o, r_, d = h.step(actions[t], host_noise=noise)
+        assert np.array_equal(d, ora["done"][t]) and np.array_equal(r_, ora["reward"][t])
+        if d.any():
+            rand = np.zeros((n, 10))
+            for i in np.nonzero(d)[0]:
+                rand[i] = reset_draws(rngs[i])
+            o = h.reset(mask=d, host_rand=rand, obs_out=o.copy())
+        assert np.abs(o - ora["obs"][t]).max() <= TOL
+    h.close()
+
+
+def test_sharding_invariance():
+    n, T = 256, 300
+    actions = np.random.RandomState(13).randint(6, size=(T, n)).astype(np.int32)
+    full = make(n, seed0=21, random_target=1)
+    o_full = full.reset()
+    r_full = full.rollout(T, actions=actions)
+    for g in range(2):
+        hs = make(n // 2, seed0=21, first=g * n // 2, random_target=1)
+        sl = slice(g * n // 2, (g + 1) * n // 2)
+        assert np.array_equal(hs.reset(), o_full[sl])
+        r = hs.rollout(T, actions=np.ascontiguousarray(actions[:, sl]))
+        for k in ("obs", "reward", "done"):
+            assert np.array_equal(r[k], r_full[k][:, sl])
+        hs.close()
+    full.close()
