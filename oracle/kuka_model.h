@@ -81,6 +81,7 @@ static const double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, rad
 #define KM_BUTTON_MAX_FORCE 100000.0     /* pybullet default force (recalled) */
 #define KM_DEFAULT_MOTOR_IMPULSE 1.0     /* pybullet createJointMotors default velocity motor (recalled) */
 #define KM_LIMIT_MAX_IMPULSE 100.0       /* btMultiBodyConstraint default m_maxAppliedImpulse */
+#define KM_LIMIT_ACTIVATION_VEL 10.0    /* limit rows exist when stop distance / dt <= this (rad/s) */
 #define KM_ERP 0.2                       /* btContactSolverInfo m_erp / m_erp2 defaults */
 #define KM_CONTACT_THRESHOLD 0.002       /* manifold points live below this separation */
 

@@ -322,7 +322,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         e->bqd += dt * KM_GRAVITY_Z;
         mass_matrix_inverse(e->q, W);
 
-        /* -- constraint rows: motors, then violated joint limits, then contacts -- */
+        /* -- constraint rows: motors, then joint limits, then contacts -- */
         for (i = 0; i < N; i++) {                                   /* arm motors, kuka.py:167-170 */
             double J[N] = {0}, target = KM_ARM_KP * (q_des[i] - e->q[i]) / dt;
             if (target > KM_ARM_MAX_VEL) target = KM_ARM_MAX_VEL;
@@ -335,14 +335,17 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                     -KM_BUTTON_MAX_FORCE * dt, KM_BUTTON_MAX_FORCE * dt);
         else
             add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, 0.0, e->qd, e->bqd, -KM_DEFAULT_MOTOR_IMPULSE, KM_DEFAULT_MOTOR_IMPULSE);
-        for (i = 0; i < N; i++) {                                   /* joint limits (only when violated) */
+        /* joint limits (btMultiBodyJointLimitConstraint): unilateral rows.  A row whose stop is still `pen`
+         * away only forbids approaching faster than pen/dt, so it is created when pen/dt is within reach
+         * (arm: KM_LIMIT_ACTIVATION_VEL, far above the 0.35 rad/s motor clamp; button: always). */
+        for (i = 0; i < N; i++) {
             double J[N] = {0}, pen_lo = e->q[i] - KM_JOINT_LOWER[i], pen_hi = KM_JOINT_UPPER[i] - e->q[i];
-            if (pen_lo <= 0) { J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, 0.0, -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
-            if (pen_hi <= 0) { J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, 0.0, -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt) { J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt) { J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
         }
         { double pen_lo = e->bq - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - e->bq;
-          if (pen_lo <= 0) add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE);
-          if (pen_hi <= 0) add_row(rows, &nrows, zeroJ, -1.0, W, Wb, 0.0, -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+          add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE);
+          add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
         for (s = 0; s < KM_NSPHERE; s++) {                          /* gripper spheres vs cap, base, table */
             double c[3], n[3], dist, pt[3], Jv[3][N], Jw[3][N], J[N]; int shape;
             link7_point(R, p, KM_SPHERE[s], c);

@@ -75,6 +75,7 @@ constexpr double kGliderOriginZ = 0.005, kGliderLower = 0.0, kGliderUpper = 0.01
 constexpr double kCapRadius = 0.09, kCapHeight = 0.03, kBaseRadius = 0.10, kBaseHeight = 0.03;
 constexpr double kButtonDistanceHeight = 0.28, kButtonTarget = 0.1, kButtonKp = 0.1, kButtonMaxForce = 100000.0;
 constexpr double kDefaultMotorImpulse = 1.0, kLimitMaxImpulse = 100.0, kErp = 0.2, kContactThreshold = 0.002;
+constexpr double kLimitActivationVel = 10.0;   // limit rows exist when stop distance / dt <= this
 constexpr int kMaxSteps = 1000, kNContactsBeforeTermination = 5, kNStepsOutside = 5000;
 constexpr double kDeltaV = 0.03, kDeltaVContinuous = 0.0035, kDeltaTheta = 0.1;
 constexpr double kNoiseStd = 0.01, kNoiseStdContinuous = 0.0001, kNoiseStdJoints = 0.002;
@@ -104,7 +105,9 @@ constexpr int ROW_J = 0, ROW_WJ = 7, ROW_JB = 14, ROW_WJB = 15, ROW_DINV = 16, R
               ROW_HI = 19, ROW_APP = 20, ROW_STRIDE = 21;
 constexpr int SC_ROWS_TOTAL = kMaxGenRows * ROW_STRIDE;      // 168 doubles of global scratch per env
 
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(SRL_NO_WAVE_VOTE)
+#define SRL_ANY(pred) (k < kMaxGenRows)
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define SRL_ANY(pred) (__any(pred))
 #else
 #define SRL_ANY(pred) (pred)
@@ -617,21 +620,28 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
 #pragma unroll
     for (int i = 0; i < ND; i++) {
         const double pen_lo = e.q[i] - kJointLower[i], pen_hi = kJointUpper[i] - e.q[i];
-        if (pen_lo <= 0 || pen_hi <= 0) {
+        if (pen_lo <= kLimitActivationVel * dt || pen_hi <= kLimitActivationVel * dt) {
             double J[ND];
 #pragma unroll
             for (int j = 0; j < ND; j++) J[j] = 0.0;
-            if (pen_lo <= 0) { J[i] = 1.0; add_generic_row(sc, ngen, J, 0.0, W, 0.0, -pen_lo * kErp / dt, e, 0.0, kLimitMaxImpulse); }
-            if (pen_hi <= 0) { J[i] = -1.0; add_generic_row(sc, ngen, J, 0.0, W, 0.0, -pen_hi * kErp / dt, e, 0.0, kLimitMaxImpulse); }
+            if (pen_lo <= kLimitActivationVel * dt) {
+                J[i] = 1.0;
+                add_generic_row(sc, ngen, J, 0.0, W, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt, e, 0.0, kLimitMaxImpulse);
+            }
+            if (pen_hi <= kLimitActivationVel * dt) {
+                J[i] = -1.0;
+                add_generic_row(sc, ngen, J, 0.0, W, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt, e, 0.0, kLimitMaxImpulse);
+            }
         }
     }
     const int nlim = ngen;
-    // button limit rows (scalar): lower J = +1, upper J = -1; both exist only when violated
-    double jb_lo = 0.0, rhs_blo = 0.0, app_blo = 0.0, jb_hi = 0.0, rhs_bhi = 0.0, app_bhi = 0.0;
+    // button limit rows (scalar, always present): lower J = +1, upper J = -1.  A stop that is still `pen`
+    // away only forbids approaching it faster than pen/dt; a violated stop pushes back with erp.
+    double rhs_blo, app_blo = 0.0, rhs_bhi, app_bhi = 0.0;
     {
         const double pen_lo = e.bq - kGliderLower, pen_hi = kGliderUpper - e.bq;
-        if (pen_lo <= 0) { jb_lo = 1.0; rhs_blo = (0.0 - e.bqd) * dinvb + (-pen_lo * kErp / dt) * dinvb; }
-        if (pen_hi <= 0) { jb_hi = -1.0; rhs_bhi = (0.0 + e.bqd) * dinvb + (-pen_hi * kErp / dt) * dinvb; }
+        rhs_blo = ((pen_lo > 0 ? -pen_lo / dt : 0.0) - e.bqd) * dinvb + (pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt) * dinvb;
+        rhs_bhi = ((pen_hi > 0 ? -pen_hi / dt : 0.0) + e.bqd) * dinvb + (pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt) * dinvb;
     }
     e.contact_button = 0; e.contact_table = 0;
     // walk the kinematics again for contact Jacobians only when some sphere is close
@@ -681,13 +691,10 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
         }
         for (int k = 0; SRL_ANY(k < nlim); k++)
             if (k < nlim) pgs_generic_row(sc, k, dv, dvb);
-        if (jb_lo != 0.0) {
+        {
             double delta;
             SRL_PGS_ROW(app_blo, rhs_blo, dinvb, 0.0, kLimitMaxImpulse, dvb, delta);
             dvb += delta * wb;
-        }
-        if (jb_hi != 0.0) {
-            double delta;
             SRL_PGS_ROW(app_bhi, rhs_bhi, dinvb, 0.0, kLimitMaxImpulse, -dvb, delta);
             dvb -= delta * wb;
         }

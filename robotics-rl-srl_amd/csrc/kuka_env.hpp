@@ -101,12 +101,14 @@ SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const d
     if (!cfg.is_discrete && cfg.action_joints) {
         unpack_start(e, settled);
         e.bx = bx; e.by = by;
+        // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1) per init action,
+        // broadcast over the joints.  All five are drawn before the physics steps.
+        double g[kNInitActions];
+        for (int k = 0; k < kNInitActions; k++) g[k] = rng.normal(7.0, 1.0);
         for (int k = 0; k < kNInitActions; k++) {
-            // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1), broadcast
-            const double g = rng.normal(7.0, 1.0);
             double joints[ND], motor[3] = {0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * g;
+            for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * g[k];
             physics_step(e, cfg, sc, motor, true, joints);
         }
     } else {
