@@ -28,6 +28,7 @@
 
 #define N KM_NDOF
 #define MAX_ROWS 40
+#define MAX_GENERIC_ROWS 6   /* arm-limit + contact rows kept per step, first come first kept (solver row budget) */
 
 /* ------------------------------------------------------------------ small algebra */
 typedef double mat3[3][3];
@@ -297,7 +298,7 @@ static void add_row(row_t *rows, int *nrows, const double J[N], double Jb, const
 static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets) {
     mat3 R[N]; double p[N][3], q_des[N], tau[N], qdd[N], W[N][N], dv[N], dvb = 0.0;
     const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
-    row_t rows[MAX_ROWS]; int nrows = 0, i, k, it, s;
+    row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s;
     const double (*box)[3] = KM_EE_BOX[cfg->random_target ? 0 : 1];
     double zeroJ[N] = {0};
 
@@ -340,8 +341,8 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
          * (arm: KM_LIMIT_ACTIVATION_VEL, far above the 0.35 rad/s motor clamp; button: always). */
         for (i = 0; i < N; i++) {
             double J[N] = {0}, pen_lo = e->q[i] - KM_JOINT_LOWER[i], pen_hi = KM_JOINT_UPPER[i] - e->q[i];
-            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt) { J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
-            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt) { J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
         }
         { double pen_lo = e->bq - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - e->bq;
           add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE);
@@ -356,6 +357,8 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                 else dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_BASE_RADIUS, KM_BUTTON_BASE_Z, KM_BUTTON_BASE_Z + KM_BASE_HEIGHT, n);
                 if (!(dist < KM_CONTACT_THRESHOLD)) continue;
                 if (shape == 0) e->contact_button = 1;
+                if (ngeneric >= MAX_GENERIC_ROWS) continue;
+                ngeneric++;
                 for (k = 0; k < 3; k++) pt[k] = c[k] - KM_SPHERE[s][3] * n[k];      /* contact point on the sphere */
                 point_jacobian(R, p, pt, Jv, Jw);
                 for (i = 0; i < N; i++) J[i] = n[0] * Jv[0][i] + n[1] * Jv[1][i] + n[2] * Jv[2][i];

@@ -1,7 +1,7 @@
 // kuka.hip — KukaButtonGymEnv stepper kernels for gfx950 (MI355X) and their host plumbing.
 //
-// Launch geometry: one lane per env, 64-lane workgroups (one wavefront), per-link
-// ABA staging in LDS ([slot][lane], 49 KiB per workgroup -> 3 workgroups per CU),
+// Launch geometry: one lane per env, 64-lane workgroups (one wavefront), per-link ABA
+// staging and the generic constraint rows in LDS ([slot][lane], 112 KiB per workgroup),
 // state structure-of-arrays in HBM (env index fastest: a wavefront's loads and
 // stores of a field are one coalesced 512-byte row).  kuka_rollout_k keeps the
 // whole env state in VGPRs for T steps and streams the [T][N] observation /
@@ -26,7 +26,6 @@ enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 
 struct KukaState {
     double *d;          // [NDBL][n]
     int32_t *i;         // [NINT][n]
-    double *rows;       // [SC_ROWS_TOTAL][n]  generic constraint rows (global scratch)
     double *settled;    // [kStartDoubles]
     double *starts;     // [nstarts][kStartDoubles]
     int32_t nstarts;
@@ -90,7 +89,7 @@ extern __shared__ double kuka_lds[];
 
 __device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, int64_t e) {
     Scratch sc;
-    sc.b = kuka_lds + threadIdx.x; sc.st = kWave; sc.g = s.rows + e; sc.gst = n;
+    sc.b = kuka_lds + threadIdx.x; sc.st = kWave;
     return sc;
 }
 
@@ -98,7 +97,6 @@ __device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, i
 // wave-level votes stay uniform; lane 0 publishes.
 __global__ void __launch_bounds__(kWave) kuka_settle_k(KukaParams p, KukaState s) {
     Scratch sc = make_scratch(s, p.n, 0);
-    sc.g = s.rows + threadIdx.x % p.n;
     Env e;
     initial_env(e);
     const double zero[3] = {0, 0, 0};
@@ -114,7 +112,6 @@ __global__ void __launch_bounds__(kWave) kuka_starts_k(KukaParams p, KukaState s
     const int idx = blockIdx.x * kWave + threadIdx.x;
     if (idx >= s.nstarts) return;
     Scratch sc = make_scratch(s, p.n, 0);
-    sc.g = s.rows + idx % p.n;            // start states are contact-free: the rows are never touched
     Env e;
     unpack_start(e, s.settled);
     e.bx = kButtonX; e.by = kButtonY; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
@@ -234,7 +231,7 @@ int kuka_alloc(Handle *h) {
     const size_t n = (size_t)h->n;
     int rc;
     s->nstarts = (!h->cfg.is_discrete && h->cfg.action_joints) ? 0 : h->cfg.is_discrete ? kNumStartsDiscrete : kNumStartsContinuous;
-    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) ||
+    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
     if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k)) ||

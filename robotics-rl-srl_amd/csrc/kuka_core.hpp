@@ -85,29 +85,25 @@ constexpr double kFlopsPerPhysicsStep = 5.6e4;
 
 // ---------------------------------------------------------------- LDS scratch
 // [slot][lane] doubles; `st` = lanes per workgroup (64 on the device, 1 on the host).
-struct Scratch {
-    double *b;       // LDS: per-link staging, [slot][lane]
-    int st;
-    double *g;       // HBM (L2-resident): the rarely used generic constraint rows, [slot][env]
-    int64_t gst;
-    SRL_HD double &at(int i) const { return b[(int64_t)i * st]; }
-    SRL_HD double &row(int i) const { return g[(int64_t)i * gst]; }
-};
-constexpr int kMaxGenRows = 8;       // violated arm-limit rows + contact rows kept per step
+constexpr int kMaxGenRows = 6;       // arm-limit rows + contact rows kept per step (first come, first kept)
 constexpr int SC_Z = 0;              // z_i      [7][3]
 constexpr int SC_P = 21;             // p_i      [7][3]
 constexpr int SC_U = 42;             // U_i      [7][6]
 constexpr int SC_DINV = 84;          // 1/d_i    [7]
 constexpr int SC_UU = 91;            // u_i      [7]
-constexpr int SC_TOTAL = 98;         // 98 doubles = 784 B of LDS per env (49 KiB per 64-lane workgroup)
-// generic rows [kMaxGenRows][21]: J7 WJ7 Jb WJb Dinv rhs lo hi applied
+constexpr int SC_ROW = 98;           // generic rows [kMaxGenRows][21]: J7 WJ7 Jb WJb Dinv rhs lo hi applied
 constexpr int ROW_J = 0, ROW_WJ = 7, ROW_JB = 14, ROW_WJB = 15, ROW_DINV = 16, ROW_RHS = 17, ROW_LO = 18,
               ROW_HI = 19, ROW_APP = 20, ROW_STRIDE = 21;
-constexpr int SC_ROWS_TOTAL = kMaxGenRows * ROW_STRIDE;      // 168 doubles of global scratch per env
+constexpr int SC_TOTAL = SC_ROW + kMaxGenRows * ROW_STRIDE;   // 224 doubles = 1792 B of LDS per env (112 KiB / workgroup)
 
-#if defined(SRL_NO_WAVE_VOTE)
-#define SRL_ANY(pred) (k < kMaxGenRows)
-#elif defined(__HIP_DEVICE_COMPILE__)
+struct Scratch {
+    double *b;       // LDS base of this lane, [slot][lane]
+    int st;
+    SRL_HD double &at(int i) const { return b[(int64_t)i * st]; }
+    SRL_HD double &row(int i) const { return b[(int64_t)(SC_ROW + i) * st]; }
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
 #define SRL_ANY(pred) (__any(pred))
 #else
 #define SRL_ANY(pred) (pred)
