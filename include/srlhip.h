@@ -152,6 +152,8 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_LAST_REWARD    6   /* f64 reward of the last step, uncast   */
 #define SRLHIP_F_EP_RETURN      7   /* f64 running episode return            */
 #define SRLHIP_F_EP_LENGTH      8   /* i32 running episode length            */
+#define SRLHIP_F_TARGET2_X      9   /* f64 second target (2Target)           */
+#define SRLHIP_F_TARGET2_Y      10  /* f64 */
 #define SRLHIP_F_KUKA_Q         16  /* f64[7]  arm joint positions           */
 #define SRLHIP_F_KUKA_QD        17  /* f64[7]  arm joint velocities          */
 #define SRLHIP_F_KUKA_EE_TARGET 18  /* f64[3]  Kuka.end_effector_pos         */

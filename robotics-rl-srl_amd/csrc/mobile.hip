@@ -374,6 +374,8 @@ int mobile_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_POS_Y: *dptr = s.pos_y; *elem = 8; return 0;
         case SRLHIP_F_TARGET_X: *dptr = s.tgt_x; *elem = 8; return 0;
         case SRLHIP_F_TARGET_Y: *dptr = s.tgt_y; *elem = 8; return 0;
+        case SRLHIP_F_TARGET2_X: *dptr = s.tgt2_x; *elem = 8; return 0;
+        case SRLHIP_F_TARGET2_Y: *dptr = s.tgt2_y; *elem = 8; return 0;
         case SRLHIP_F_STEP_COUNT: *dptr = s.counter; *elem = 4; return 0;
         case SRLHIP_F_CUR_TARGET: *dptr = s.cur_target; *elem = 4; return 0;
     }
