@@ -103,6 +103,20 @@ def wrapper_step(state, gripper, button_pos, contact_button, contact_table, shap
     return st[:4].copy(), reward.value, bool(done.value)
 
 
+def command_trace(seed, T, actions, is_discrete=True, action_joints=False, random_target=False, force_down=True):
+    """IK targets / joint targets issued during reset() (5 init actions) and each step of one env."""
+    keys, lens = clib.mt_keys([seed])
+    actions = np.ascontiguousarray(actions, dtype=np.int32 if is_discrete else np.float32)
+    ee, jt = np.zeros((T + 5, 3)), np.zeros((T + 5, 7))
+    n_reset = ctypes.c_int()
+    lib = _lib()
+    lib.kuka_oracle_command_trace.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    n = lib.kuka_oracle_command_trace(int(is_discrete), int(action_joints), int(random_target), int(force_down),
+                                      _p(keys), int(lens[0]), int(T), _p(actions), _p(ee), _p(jt), ctypes.byref(n_reset))
+    return {"reset_ee": ee[:n_reset.value], "reset_jt": jt[:n_reset.value], "ee": ee[n_reset.value:n_reset.value + n],
+            "jt": jt[n_reset.value:n_reset.value + n], "n_steps": n}
+
+
 def cpu_baseline(budget_s=12.0, n_envs=None):
     """Time the oracle on the host cores (OpenMP over envs): bench.py's cpu_baseline leg."""
     threads = os.cpu_count() or 1

@@ -30,6 +30,11 @@
 #define MAX_ROWS 40
 #define MAX_GENERIC_ROWS 6   /* arm-limit + contact rows kept per step, first come first kept (solver row budget) */
 
+/* optional trace of the commands handed to the arm (wrapper pinning tests) */
+static double *g_trace_ee = NULL, *g_trace_jt = NULL;
+static int g_trace_n = 0;
+#pragma omp threadprivate(g_trace_ee, g_trace_jt, g_trace_n)
+
 /* ------------------------------------------------------------------ small algebra */
 typedef double mat3[3][3];
 typedef double vec6[6];
@@ -311,6 +316,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         }
         inverse_kinematics(e->q, R, p, e->ee_target, q_des);      /* kuka.py:155-156 */
     } else memcpy(q_des, joint_targets, sizeof q_des);           /* kuka.py:160-163 */
+    if (g_trace_ee) { memcpy(g_trace_ee + 3 * g_trace_n, e->ee_target, 3 * sizeof(double)); if (joint_targets) memcpy(g_trace_jt + N * g_trace_n, joint_targets, N * sizeof(double)); g_trace_n++; }
 
     /* -- collision detection at the current poses (start of stepSimulation) -- */
     e->contact_button = 0; e->contact_table = 0;
@@ -589,4 +595,28 @@ void kuka_oracle_wrapper_step(double *state8, const double *gripper, const doubl
     if (!termination(&e)) e.counter += 1;                         /* step2 loop with action_repeat = 1 */
     *reward = reward_fn(&e, &cfg); *done = termination(&e);
     state8[0] = e.counter; state8[1] = e.n_contacts; state8[2] = e.n_outside; state8[3] = e.terminated;
+}
+
+/* Commands issued by reset() (5 init actions) and by every step of one env: Cartesian IK targets
+ * (Kuka.end_effector_pos after the clip) and, in joint mode, the motor target list.  Returns the number of
+ * env steps executed (stops at done). */
+int kuka_oracle_command_trace(int is_discrete, int action_joints, int random_target, int force_down, const uint32_t *mt_key,
+                              int mt_key_len, int T, const void *actions, double *ee_trace, double *jt_trace, int *n_reset_cmds) {
+    kcfg cfg; kenv settled, env; krng *r = (krng *)malloc(sizeof(krng)); int t, done = 0;
+    cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = 0; cfg.action_repeat = 1;
+    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = 0.8;
+    settle(&settled, &cfg);
+    r->mode = 2; np_rng_seed_array(&r->mt, mt_key, mt_key_len);
+    g_trace_ee = ee_trace; g_trace_jt = jt_trace; g_trace_n = 0;
+    env_reset(&env, &cfg, r, &settled);
+    *n_reset_cmds = g_trace_n;
+    for (t = 0; t < T && !done; t++) {
+        int a = 0; float ca[7] = {0};
+        if (is_discrete) a = ((const int32_t *)actions)[t];
+        else memcpy(ca, (const float *)actions + (size_t)t * (action_joints ? 7 : 3), sizeof(float) * (action_joints ? 7 : 3));
+        env_step(&env, &cfg, r, a, ca, &done);
+    }
+    g_trace_ee = NULL; g_trace_jt = NULL;
+    free(r);
+    return t;
 }

@@ -135,7 +135,9 @@ def action_case(seed, mode, random_target, force_down):
     if mode == "discrete":
         actions = arng.randint(-1, 6, size=T)            # -1 stands for None
     elif mode == "continuous":
-        actions = arng.uniform(-1, 1, (T, 3)).astype(np.float32)
+        # float64 copies of float32 values: `action[0] * dv` on a float32 *scalar* promotes differently in
+        # numpy 1.14 (reference pin, -> float64) and numpy 2.x (-> float32); float64 inputs are unambiguous
+        actions = arng.uniform(-1, 1, (T, 3)).astype(np.float32).astype(np.float64)
     else:
         actions = arng.uniform(-1, 1, (T, 7)).astype(np.float32)
     ik, motor, rewards, dones = [], [], [], []
