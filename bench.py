@@ -80,13 +80,11 @@ def main():
     args = parse()
     from srlhip import _lib
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from srlhip import sharding
+    rank, local_rank, world = sharding.dist_env()
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        sharding.init_process_group("nccl", local_rank)       # "nccl" == RCCL over xGMI on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -100,7 +98,8 @@ def main():
 
     kind = _lib.ENV_MOBILE if workload == "mobile" else _lib.ENV_KUKA_BUTTON
     cfg = _lib.default_config(kind)
-    cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, local_rank, rank * n, 0
+    first_env_id, _ = sharding.shard_range(world * n, world, rank)
+    cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, local_rank, first_env_id, 0
     cfg.rng_mode = _lib.RNG_PHILOX if args.rng == "philox" else _lib.RNG_MT19937
     cfg.auto_reset, cfg.io_device = 1, 1
     h = _lib.Handle(cfg)
@@ -125,8 +124,7 @@ def main():
         if world > 1:
             # the path's only exchange: episode returns, once per rollout, RCCL over xGMI
             h.sync()
-            local = rew.sum(dim=0)
-            dist.all_gather_into_tensor(gathered, local)
+            sharding.gather_episode_returns(rew.sum(dim=0), out=gathered)
 
     def fence():
         h.sync()
@@ -145,10 +143,7 @@ def main():
     kernel_ms = h.timing_end()          # HIP events on the stepper's own stream
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, device=dev)
 
     total_env_steps = world * n * inner * K
     value = total_env_steps / dt
