@@ -113,7 +113,6 @@ def main():
     h.reset(obs_out=obs0.data_ptr())
     h.sync()
 
-    ep_ret_ptr = h.device_ptr(_lib.F_EP_RETURN)
     gathered = None
     if world > 1:
         import torch.distributed as dist
@@ -152,7 +151,7 @@ def main():
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
     roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "mobile_rollout_k" if workload == "mobile" else "kuka_step_k",
+                "kernel": "mobile_rollout_k" if workload == "mobile" else "kuka_rollout_k",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
     if workload == "kuka":

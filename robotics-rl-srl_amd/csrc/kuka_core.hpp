@@ -38,7 +38,11 @@ namespace kuka {
 constexpr int ND = 7;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kDt = 1.0 / 240.0;
+#ifndef SRL_EXPERIMENT_SOLVER_ITERS
 constexpr int kSolverIters = 150;
+#else   // timing experiments only (never shipped): see DESIGN.md §Kuka kernel, phase split
+constexpr int kSolverIters = SRL_EXPERIMENT_SOLVER_ITERS;
+#endif
 constexpr double kGravityZ = -10.0;
 constexpr double kBasePos[3] = {-0.1, 0.0, -0.15};
 // joint frame in the parent link: translation along one parent axis, then a fixed
@@ -527,25 +531,20 @@ SRL_HD void add_generic_row(const Scratch &sc, int &ngen, const double J[ND], do
     sc.row(base + ROW_LO) = lo; sc.row(base + ROW_HI) = hi; sc.row(base + ROW_APP) = 0.0;
 }
 
-#define SRL_PGS_ROW(app, rhs, dinv, lo, hi, jdv, delta)            \
-    {                                                              \
-        delta = (rhs) - (jdv) * (dinv);                            \
-        double sum__ = (app) + delta;                              \
-        double cl__ = fmin(fmax(sum__, (lo)), (hi));               \
-        delta = cl__ == sum__ ? delta : cl__ - (app);              \
-        (app) = cl__;                                              \
-    }
-
-SRL_HD void pgs_generic_row(const Scratch &sc, int k, double dv[ND], double &dvb) {
+// One Gauss-Seidel update of LDS row k in impulse space: the arm velocity change so far is
+// W lam + g with g = sum_l WJ_l mu_l, so J_k . dv = WJ_k . lam + J_k . g (+ the button part).
+SRL_HD void pgs_generic_row(const Scratch &sc, int k, const double lam[ND], double g[ND], double &dvb) {
     const int base = k * ROW_STRIDE;
     double jdv = sc.row(base + ROW_JB) * dvb;
 #pragma unroll
-    for (int i = 0; i < ND; i++) jdv += sc.row(base + ROW_J + i) * dv[i];
-    double app = sc.row(base + ROW_APP), delta;
-    SRL_PGS_ROW(app, sc.row(base + ROW_RHS), sc.row(base + ROW_DINV), sc.row(base + ROW_LO), sc.row(base + ROW_HI), jdv, delta);
-    sc.row(base + ROW_APP) = app;
+    for (int i = 0; i < ND; i++) jdv += sc.row(base + ROW_WJ + i) * lam[i] + sc.row(base + ROW_J + i) * g[i];
+    const double mu = sc.row(base + ROW_APP);
+    const double sum = mu + (sc.row(base + ROW_RHS) - jdv * sc.row(base + ROW_DINV));
+    const double cl = fmin(fmax(sum, sc.row(base + ROW_LO)), sc.row(base + ROW_HI));
+    const double delta = cl - mu;
+    sc.row(base + ROW_APP) = cl;
 #pragma unroll
-    for (int i = 0; i < ND; i++) dv[i] += delta * sc.row(base + ROW_WJ + i);
+    for (int i = 0; i < ND; i++) g[i] += delta * sc.row(base + ROW_WJ + i);
     dvb += delta * sc.row(base + ROW_WJB);
 }
 
@@ -604,10 +603,10 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     e.bqd += dt * kGravityZ;
 
     // -- rows.  Register rows: 7 arm motors, button motor, button limit.  LDS rows: arm limits, contacts.
-    double rhs[ND], dinv[ND], app[ND];
+    double dinv[ND];
     const double arm_bound = kArmMaxForce * dt;
 #pragma unroll
-    for (int i = 0; i < ND; i++) { dinv[i] = 1.0 / W[i][i]; rhs[i] = (target[i] - e.qd[i]) * dinv[i]; app[i] = 0.0; }
+    for (int i = 0; i < ND; i++) dinv[i] = 1.0 / W[i][i];
     const double wb = 1.0 / kCapMass, dinvb = 1.0 / wb;
     double rhs_bm, bound_bm, app_bm = 0.0;
     if (e.motor_on) { rhs_bm = (kButtonKp * (kButtonTarget - e.bq) / dt - e.bqd) * dinvb; bound_bm = kButtonMaxForce * dt; }
@@ -667,36 +666,62 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             add_generic_row(sc, ngen, J, shape == 0 ? -n[2] : 0.0, W, allow, pos_err, e, 0.0, 1e10);
         }
     }
-    // -- projected Gauss-Seidel, 150 sweeps.  Row order: arm motors, button motor, violated arm limits,
-    //    violated button limits, contacts (generic rows [0, nlim) are the arm limits, [nlim, ngen) contacts).
-    double dv[ND], dvb = 0.0;
+    // -- projected Gauss-Seidel, 150 sweeps.  Row order: arm motors, button motor, arm limits, button
+    //    limits, contacts (LDS rows [0, nlim) are the arm limits, [nlim, ngen) the contacts).
+    //    The arm motor block is iterated in impulse space: lam_i <- clamp((c_i - g_i - sum_{j!=i} W_ij lam_j) / W_ii),
+    //    which is the same Gauss-Seidel update as accumulating dv = W lam row by row, with a 4-deep
+    //    dependent chain per row and 6 FMAs instead of 7 + bookkeeping; the velocity change is formed once
+    //    at the end.  The button DoF stays in velocity space (scalar dvb).
+#define SRL_W(i, j) ((i) <= (j) ? W[i][j] : W[j][i])
+    double lam[ND], g[ND], cg[ND], dvb = 0.0;
 #pragma unroll
-    for (int i = 0; i < ND; i++) dv[i] = 0.0;
+    for (int i = 0; i < ND; i++) { lam[i] = 0.0; g[i] = 0.0; cg[i] = target[i] - e.qd[i]; }
+    const double c_bm = rhs_bm, blim = kLimitMaxImpulse;
     for (int it = 0; it < kSolverIters; it++) {
 #pragma unroll
         for (int i = 0; i < ND; i++) {
-            double delta;
-            SRL_PGS_ROW(app[i], rhs[i], dinv[i], -arm_bound, arm_bound, dv[i], delta);
+            double r = cg[i];
 #pragma unroll
-            for (int j = 0; j < ND; j++) dv[j] += delta * W[j][i];
+            for (int j = 0; j < ND; j++)
+                if (j != i) r -= SRL_W(i, j) * lam[j];
+            lam[i] = fmin(fmax(r * dinv[i], -arm_bound), arm_bound);
         }
         {
-            double delta;
-            SRL_PGS_ROW(app_bm, rhs_bm, dinvb, -bound_bm, bound_bm, dvb, delta);
-            dvb += delta * wb;
+            const double sum = app_bm + (c_bm - dvb * dinvb);
+            const double cl = fmin(fmax(sum, -bound_bm), bound_bm);
+            dvb += (cl - app_bm) * wb;
+            app_bm = cl;
         }
-        for (int k = 0; SRL_ANY(k < nlim); k++)
-            if (k < nlim) pgs_generic_row(sc, k, dv, dvb);
+        if (SRL_ANY(ngen > 0)) {
+            for (int k = 0; SRL_ANY(k < nlim); k++)
+                if (k < nlim) pgs_generic_row(sc, k, lam, g, dvb);
+        }
         {
-            double delta;
-            SRL_PGS_ROW(app_blo, rhs_blo, dinvb, 0.0, kLimitMaxImpulse, dvb, delta);
-            dvb += delta * wb;
-            SRL_PGS_ROW(app_bhi, rhs_bhi, dinvb, 0.0, kLimitMaxImpulse, -dvb, delta);
-            dvb -= delta * wb;
+            double sum = app_blo + (rhs_blo - dvb * dinvb);
+            double cl = fmin(fmax(sum, 0.0), blim);
+            dvb += (cl - app_blo) * wb;
+            app_blo = cl;
+            sum = app_bhi + (rhs_bhi + dvb * dinvb);
+            cl = fmin(fmax(sum, 0.0), blim);
+            dvb -= (cl - app_bhi) * wb;
+            app_bhi = cl;
         }
-        for (int k = nlim; SRL_ANY(k < ngen); k++)
-            if (k < ngen) pgs_generic_row(sc, k, dv, dvb);
+        if (SRL_ANY(ngen > 0)) {
+            for (int k = nlim; SRL_ANY(k < ngen); k++)
+                if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
+#pragma unroll
+            for (int i = 0; i < ND; i++) cg[i] = (target[i] - e.qd[i]) - g[i];
+        }
     }
+    double dv[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+        double a = g[i];
+#pragma unroll
+        for (int j = 0; j < ND; j++) a += SRL_W(i, j) * lam[j];
+        dv[i] = a;
+    }
+#undef SRL_W
     // -- semi-implicit Euler, then refresh sin/cos and the gripper position
 #pragma unroll
     for (int i = 0; i < ND; i++) { e.qd[i] += dv[i]; e.q[i] += dt * e.qd[i]; }
