@@ -673,46 +673,53 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     //    dependent chain per row and 6 FMAs instead of 7 + bookkeeping; the velocity change is formed once
     //    at the end.  The button DoF stays in velocity space (scalar dvb).
 #define SRL_W(i, j) ((i) <= (j) ? W[i][j] : W[j][i])
-    double lam[ND], g[ND], cg[ND], dvb = 0.0;
+    double lam[ND], g[ND], cg[ND], cur[ND], nxt[ND], dvb = 0.0;
 #pragma unroll
-    for (int i = 0; i < ND; i++) { lam[i] = 0.0; g[i] = 0.0; cg[i] = target[i] - e.qd[i]; }
-    const double c_bm = rhs_bm, blim = kLimitMaxImpulse;
-    for (int it = 0; it < kSolverIters; it++) {
+    for (int i = 0; i < ND; i++) { lam[i] = 0.0; g[i] = 0.0; cg[i] = target[i] - e.qd[i]; cur[i] = cg[i]; nxt[i] = 0.0; }
+    const double blim = kLimitMaxImpulse;
+    // cur_i = cg_i - sum_{j<i} W_ij lam_j(this sweep) - sum_{j>i} W_ij lam_j(previous sweep).  Each new lam_j is
+    // scattered into the rows that still need it (cur) and into next sweep's partial sums (nxt), so the only
+    // dependent chain per arm row is fma -> mul -> max -> min.  The three scalar button rows clamp the impulse
+    // increment against (lo - applied, hi - applied), which are known one sweep ahead: fma -> max -> min -> fma.
+#define SRL_ARM_ROWS()                                                                   \
+    _Pragma("unroll") for (int j = 0; j < ND; j++) {                                     \
+        const double l = fmin(fmax(cur[j] * dinv[j], -arm_bound), arm_bound);            \
+        lam[j] = l;                                                                      \
+        _Pragma("unroll") for (int i = j + 1; i < ND; i++) cur[i] -= SRL_W(i, j) * l;    \
+        _Pragma("unroll") for (int i = 0; i < j; i++) nxt[i] -= SRL_W(i, j) * l;         \
+    }
+#define SRL_BUTTON_ROW(app, rhs, jsign, lo, hi)                                          \
+    {                                                                                    \
+        const double d__ = fmin(fmax((rhs) - (jsign) * dvb * dinvb, (lo) - (app)), (hi) - (app)); \
+        dvb += (jsign) * d__ * wb;                                                       \
+        (app) += d__;                                                                    \
+    }
+    if (!SRL_ANY(ngen > 0)) {
+        // whole wavefront free of limit / contact rows: one straight-line block per sweep
+        for (int it = 0; it < kSolverIters; it++) {
+            SRL_ARM_ROWS()
+            SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
+            SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
+            SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
 #pragma unroll
-        for (int i = 0; i < ND; i++) {
-            double r = cg[i];
-#pragma unroll
-            for (int j = 0; j < ND; j++)
-                if (j != i) r -= SRL_W(i, j) * lam[j];
-            lam[i] = fmin(fmax(r * dinv[i], -arm_bound), arm_bound);
+            for (int i = 0; i < ND; i++) { cur[i] = cg[i] + nxt[i]; nxt[i] = 0.0; }
         }
-        {
-            const double sum = app_bm + (c_bm - dvb * dinvb);
-            const double cl = fmin(fmax(sum, -bound_bm), bound_bm);
-            dvb += (cl - app_bm) * wb;
-            app_bm = cl;
-        }
-        if (SRL_ANY(ngen > 0)) {
+    } else {
+        for (int it = 0; it < kSolverIters; it++) {
+            SRL_ARM_ROWS()
+            SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
             for (int k = 0; SRL_ANY(k < nlim); k++)
                 if (k < nlim) pgs_generic_row(sc, k, lam, g, dvb);
-        }
-        {
-            double sum = app_blo + (rhs_blo - dvb * dinvb);
-            double cl = fmin(fmax(sum, 0.0), blim);
-            dvb += (cl - app_blo) * wb;
-            app_blo = cl;
-            sum = app_bhi + (rhs_bhi + dvb * dinvb);
-            cl = fmin(fmax(sum, 0.0), blim);
-            dvb -= (cl - app_bhi) * wb;
-            app_bhi = cl;
-        }
-        if (SRL_ANY(ngen > 0)) {
+            SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
+            SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
             for (int k = nlim; SRL_ANY(k < ngen); k++)
                 if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
 #pragma unroll
-            for (int i = 0; i < ND; i++) cg[i] = (target[i] - e.qd[i]) - g[i];
+            for (int i = 0; i < ND; i++) { cur[i] = ((target[i] - e.qd[i]) - g[i]) + nxt[i]; nxt[i] = 0.0; }
         }
     }
+#undef SRL_ARM_ROWS
+#undef SRL_BUTTON_ROW
     double dv[ND];
 #pragma unroll
     for (int i = 0; i < ND; i++) {
