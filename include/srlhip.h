@@ -167,6 +167,12 @@ int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
  * __cuda_array_interface__). */
 int srlhip_device_ptr(srlhip_handle h, int32_t field, void **dptr);
 
+/* Replaces <Env>.render("rgb_array") (kuka_button_gym_env.py:370-420, mobile_robot_env.py:282-334)
+ * for the whole batch: uint8 [num_envs][img_h][img_w][3 (6 with multi_view)] of the CURRENT state,
+ * produced by the tile rasteriser.  Also what step()/reset()/rollout() write to obs_out when
+ * cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS.  img_out follows cfg.io_device. */
+int srlhip_render(srlhip_handle h, void *img_out);
+
 /* Per-env statistics of the most recently FINISHED episode and the number of
  * finished episodes: what stable_baselines.bench.Monitor records
  * (environments/utils.py:54).  HOST pointers, any may be NULL. */

@@ -54,7 +54,7 @@ size_t action_bytes(const Handle *h) {
 }
 size_t obs_bytes_per_env(const Handle *h) {
     if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
-        return (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.multi_view ? 6 : 3);
+        return (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3);
     return sizeof(float) * obs_dim_of(h->cfg);
 }
 
@@ -165,6 +165,9 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
         cfg->obs_mode != SRLHIP_OBS_RAW_PIXELS) {
         g_create_error = "create: MobileRobot envs support ground_truth / raw_pixels only"; return SRLHIP_EINVAL;
     }
+    if (cfg->obs_mode == SRLHIP_OBS_RAW_PIXELS && (cfg->img_h < 8 || cfg->img_w < 8 || cfg->img_h > 1024 || cfg->img_w > 1024)) {
+        g_create_error = "create: img_h / img_w must be in [8, 1024]"; return SRLHIP_EINVAL;
+    }
     if (cfg->env_kind == SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
         g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;
     }
@@ -269,9 +272,11 @@ int srlhip_reset(srlhip_handle hh, const uint8_t *mask, const double *host_rand,
             d_obs = h->st_obs;
         }
     }
-    rc = is_mobile(h->cfg.env_kind) ? mobile_reset(h, d_mask, d_rand, static_cast<float *>(d_obs))
-                                    : kuka_reset(h, d_mask, d_rand, d_obs);
+    const bool pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
+    rc = is_mobile(h->cfg.env_kind) ? mobile_reset(h, d_mask, d_rand, pixels ? nullptr : static_cast<float *>(d_obs))
+                                    : kuka_reset(h, d_mask, d_rand, pixels ? nullptr : d_obs);
     if (rc) return rc;
+    if (pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;     // every env is (re)drawn: rows of unselected envs too
     if (!h->cfg.io_device) {
         if (obs_out) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_out, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
         SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -304,9 +309,11 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
         if (reward_out) { if ((rc = ensure(h, &h->st_rew, &h->st_rew_sz, 4 * (size_t)n))) return rc; d_rew = static_cast<float *>(h->st_rew); }
         if (done_out) { if ((rc = ensure(h, &h->st_done, &h->st_done_sz, n))) return rc; d_done = static_cast<uint8_t *>(h->st_done); }
     }
-    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, d_act, d_noise, static_cast<float *>(d_obs), d_rew, d_done)
-                                    : kuka_step(h, d_act, d_noise, d_obs, d_rew, d_done);
+    const bool pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
+    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, d_act, d_noise, pixels ? nullptr : static_cast<float *>(d_obs), d_rew, d_done)
+                                    : kuka_step(h, d_act, d_noise, pixels ? nullptr : d_obs, d_rew, d_done);
     if (rc) return rc;
+    if (pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;
     if (!h->cfg.io_device) {
         if (obs_out) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_out, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
         if (reward_out) SRL_HIP_CHECK(h, hipMemcpyAsync(reward_out, d_rew, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
@@ -335,10 +342,25 @@ int srlhip_rollout(srlhip_handle hh, int32_t T, const void *actions_TN, void *ob
         if (reward_TN) { if ((rc = ensure(h, &h->st_rew, &h->st_rew_sz, 4 * tn))) return rc; d_rew = static_cast<float *>(h->st_rew); }
         if (done_TN) { if ((rc = ensure(h, &h->st_done, &h->st_done_sz, tn))) return rc; d_done = static_cast<uint8_t *>(h->st_done); }
     }
-    rc = is_mobile(h->cfg.env_kind)
-             ? mobile_rollout(h, T, d_act, static_cast<float *>(d_obs), d_rew, d_done, actions_TN ? nullptr : d_act_out)
-             : kuka_rollout(h, T, d_act, d_obs, d_rew, d_done, actions_TN ? nullptr : d_act_out);
-    if (rc) return rc;
+    if (h->cfg.obs_mode != SRLHIP_OBS_RAW_PIXELS) {
+        rc = is_mobile(h->cfg.env_kind)
+                 ? mobile_rollout(h, T, d_act, static_cast<float *>(d_obs), d_rew, d_done, actions_TN ? nullptr : d_act_out)
+                 : kuka_rollout(h, T, d_act, d_obs, d_rew, d_done, actions_TN ? nullptr : d_act_out);
+        if (rc) return rc;
+    } else {
+        // images are drawn between steps: one stepper launch + one rasteriser launch per step, same stream
+        const size_t a_step = action_bytes(h), o_step = obs_bytes_per_env(h) * n;
+        for (int32_t t = 0; t < T; t++) {
+            const void *a_t = d_act ? static_cast<const uint8_t *>(d_act) + (size_t)t * a_step : nullptr;
+            void *ao_t = (!actions_TN && d_act_out) ? static_cast<uint8_t *>(d_act_out) + (size_t)t * a_step : nullptr;
+            float *r_t = d_rew ? d_rew + (size_t)t * n : nullptr;
+            uint8_t *dn_t = d_done ? d_done + (size_t)t * n : nullptr;
+            rc = is_mobile(h->cfg.env_kind) ? mobile_rollout(h, 1, a_t, nullptr, r_t, dn_t, ao_t)
+                                            : kuka_rollout(h, 1, a_t, nullptr, r_t, dn_t, ao_t);
+            if (rc) return rc;
+            if (d_obs && (rc = raster_render(h, static_cast<uint8_t *>(d_obs) + (size_t)t * o_step))) return rc;
+        }
+    }
     if (!h->cfg.io_device) {
         if (obs_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_TN, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
         if (reward_TN) SRL_HIP_CHECK(h, hipMemcpyAsync(reward_TN, d_rew, 4 * tn, hipMemcpyDeviceToHost, h->stream));
@@ -378,6 +400,22 @@ int srlhip_device_ptr(srlhip_handle hh, int32_t field, void **dptr) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     size_t elem; int count;
     return field_lookup(h, field, dptr, &elem, &count);
+}
+
+int srlhip_render(srlhip_handle hh, void *img_out) {
+    if (!hh || !img_out) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t bytes = (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3) * h->n;
+    void *d_img = img_out;
+    if (!h->cfg.io_device) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, bytes))) return rc; d_img = h->st_obs; }
+    if ((rc = raster_render(h, d_img))) return rc;
+    if (!h->cfg.io_device) {
+        SRL_HIP_CHECK(h, hipMemcpyAsync(img_out, d_img, bytes, hipMemcpyDeviceToHost, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
 }
 
 int srlhip_episode_stats(srlhip_handle hh, double *last_return, int32_t *last_length, int32_t *n_finished) {

@@ -68,6 +68,9 @@ int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_
 int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
 int kuka_reset_rand_count(const srlhip_config &c);
 
+// raster.hip
+int raster_render(Handle *h, void *d_img);
+
 struct KukaState;   // defined in kuka.hip
 
 struct Handle {

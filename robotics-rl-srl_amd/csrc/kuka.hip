@@ -224,8 +224,6 @@ int allow_lds(Handle *h, K kernel) {
 int kuka_reset_rand_count(const srlhip_config &c) { return (c.random_target ? 2 : 0) + (c.is_discrete ? 10 : 5); }
 
 int kuka_alloc(Handle *h) {
-    if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
-        return h->fail(SRLHIP_ENOTSUP, "KukaButtonGymEnv raw_pixels: tile rasteriser not built yet");
     KukaState *s = new KukaState();
     h->kuka = s;
     const size_t n = (size_t)h->n;
@@ -297,6 +295,14 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
                        d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, (void *)nullptr);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
+}
+
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by; int64_t n; };
+void kuka_raster_view(Handle *h, RasterKukaView *v) {
+    const KukaState *s = h->kuka;
+    const size_t n = (size_t)h->n;
+    v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n;
+    v->n = (int64_t)n;
 }
 
 int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {

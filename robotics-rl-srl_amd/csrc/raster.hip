@@ -1,0 +1,341 @@
+// raster.hip — batched tile rasteriser for the raw_pixels observation (gfx950).
+//
+// Replaces KukaButtonGymEnv.render / MobileRobotGymEnv.render
+// (kuka_button_gym_env.py:370-420, mobile_robot_env.py:282-334): pybullet's
+// computeViewMatrixFromYawPitchRoll + computeProjectionMatrixFOV(60, 1, 0.1, 100) +
+// getCameraImage(ER_TINY_RENDERER) -> RGB u8.  TinyRenderer's mesh visuals, texture
+// and shadows are not reproducible without pybullet_data; the contract kept is the
+// camera model, object poses and colours, z-buffered, Lambert + ambient shading
+// (DESIGN.md §Rasteriser).
+//
+// Mapping: one 256-lane workgroup per (env, camera).  The env's scene — at most 16
+// analytic primitives (plane, z-rotated box, upright cylinder, capsule) — is built
+// once per workgroup into LDS from the SoA state (for the Kuka: float64 forward
+// kinematics from the cached joint sin/cos), then every lane ray-casts its pixels
+// against the LDS list (nearest hit = z-buffer in registers) and parks 3 bytes per
+// pixel in an LDS tile of 4096 pixels that is flushed with coalesced 16-byte stores:
+// the path's HBM traffic is the 12 288-byte image per env and nothing else.
+// float32 throughout, -ffp-contract=off so that the C oracle (oracle/raster_oracle.c)
+// reproduces the bytes.
+#include "internal.hpp"
+#include "kuka_core.hpp"
+
+namespace srl {
+
+// KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by; int64_t n; };     // sq/cq: [7][n]
+struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
+
+namespace {
+
+constexpr int kRasterBlock = 256;
+constexpr int kMaxPrims = 16;
+constexpr int kTilePixels = 4096;
+
+enum { PRIM_PLANE = 0, PRIM_BOX = 1, PRIM_CYL = 2, PRIM_CAPSULE = 3 };
+
+struct Prim {
+    int type;
+    float r, g, b;
+    float ax, ay, az;      // plane: (., ., z0)  box: centre  cylinder: base centre  capsule: end a
+    float bx, by, bz;      // box: half extents             cylinder: (radius, ., height)  capsule: end b
+    float rad;             // capsule radius
+    float cs, sn;          // box: cos/sin of the yaw about z
+};
+
+struct Camera {
+    float ex, ey, ez;      // eye
+    float fx, fy, fz;      // forward (unit)
+    float rx, ry, rz;      // right   (unit)
+    float ux, uy, uz;      // up      (unit)
+    float tan_half_fov;
+};
+
+struct RasterParams {
+    int32_t kind, n, h, w, channels, ncam;
+    Camera cam[2];
+};
+
+__device__ __forceinline__ void set_prim(Prim &p, int type, float r, float g, float b, float ax, float ay, float az,
+                                         float bx, float by, float bz, float rad, float cs, float sn) {
+    p.type = type; p.r = r; p.g = g; p.b = b; p.ax = ax; p.ay = ay; p.az = az; p.bx = bx; p.by = by; p.bz = bz;
+    p.rad = rad; p.cs = cs; p.sn = sn;
+}
+
+// ---- ray / primitive intersection: returns t (> 0) or -1, and the surface normal ----------------------
+__device__ __forceinline__ float hit_plane(const Prim &p, float oz, float dz, float &nx, float &ny, float &nz) {
+    if (dz == 0.0f) return -1.0f;
+    const float t = (p.az - oz) / dz;
+    nx = 0.0f; ny = 0.0f; nz = 1.0f;
+    return t > 0.0f ? t : -1.0f;
+}
+
+__device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float &nx, float &ny, float &nz) {
+    // into the box frame (rotation about z by -yaw)
+    const float px = ox - p.ax, py = oy - p.ay, pz = oz - p.az;
+    const float lox = p.cs * px + p.sn * py, loy = p.cs * py - p.sn * px;
+    const float ldx = p.cs * dx + p.sn * dy, ldy = p.cs * dy - p.sn * dx;
+    float tmin = -3.0e38f, tmax = 3.0e38f;
+    int axis = 0; float sign = 0.0f;
+    const float o[3] = {lox, loy, pz}, d[3] = {ldx, ldy, dz}, h[3] = {p.bx, p.by, p.bz};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (d[k] == 0.0f) {
+            if (o[k] < -h[k] || o[k] > h[k]) return -1.0f;
+        } else {
+            const float inv = 1.0f / d[k];
+            float t0 = (-h[k] - o[k]) * inv, t1 = (h[k] - o[k]) * inv;
+            float s = -1.0f;
+            if (t0 > t1) { const float tt = t0; t0 = t1; t1 = tt; s = 1.0f; }
+            if (t0 > tmin) { tmin = t0; axis = k; sign = s; }
+            if (t1 < tmax) tmax = t1;
+        }
+    }
+    if (tmin > tmax || tmin <= 0.0f) return -1.0f;
+    const float lnx = axis == 0 ? sign : 0.0f, lny = axis == 1 ? sign : 0.0f;
+    nx = p.cs * lnx - p.sn * lny; ny = p.sn * lnx + p.cs * lny; nz = axis == 2 ? sign : 0.0f;
+    return tmin;
+}
+
+__device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                              float &nx, float &ny, float &nz) {
+    const float R = p.bx, z0 = p.az, z1 = p.az + p.bz;
+    const float px = ox - p.ax, py = oy - p.ay;
+    float best = -1.0f;
+    const float a = dx * dx + dy * dy;
+    if (a > 0.0f) {
+        const float b = px * dx + py * dy, c = px * px + py * py - R * R;
+        const float disc = b * b - a * c;
+        if (disc >= 0.0f) {
+            const float t = (-b - sqrtf(disc)) / a;
+            const float z = oz + t * dz;
+            if (t > 0.0f && z >= z0 && z <= z1) {
+                best = t;
+                nx = (px + t * dx) / R; ny = (py + t * dy) / R; nz = 0.0f;
+            }
+        }
+    }
+    if (dz != 0.0f) {       // caps (the top one is what a camera above ever sees)
+        const float zc = dz < 0.0f ? z1 : z0;
+        const float t = (zc - oz) / dz;
+        if (t > 0.0f && (best < 0.0f || t < best)) {
+            const float hx = px + t * dx, hy = py + t * dy;
+            if (hx * hx + hy * hy <= R * R) { best = t; nx = 0.0f; ny = 0.0f; nz = dz < 0.0f ? 1.0f : -1.0f; }
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             float &nx, float &ny, float &nz) {
+    const float bax = p.bx - p.ax, bay = p.by - p.ay, baz = p.bz - p.az;
+    const float oax = ox - p.ax, oay = oy - p.ay, oaz = oz - p.az;
+    const float baba = bax * bax + bay * bay + baz * baz;
+    const float bard = bax * dx + bay * dy + baz * dz;
+    const float baoa = bax * oax + bay * oay + baz * oaz;
+    const float rdoa = dx * oax + dy * oay + dz * oaz;
+    const float oaoa = oax * oax + oay * oay + oaz * oaz;
+    const float a = baba - bard * bard;
+    float b = baba * rdoa - baoa * bard;
+    float c = baba * oaoa - baoa * baoa - p.rad * p.rad * baba;
+    float h = b * b - a * c;
+    if (h < 0.0f || baba == 0.0f) return -1.0f;
+    float t = -1.0f, y = 0.0f;
+    bool body = false;
+    if (a > 0.0f) {
+        t = (-b - sqrtf(h)) / a;
+        y = baoa + t * bard;
+        body = y > 0.0f && y < baba;
+    }
+    if (!body) {            // one of the two end spheres
+        const float ocx = y <= 0.0f ? oax : ox - p.bx, ocy = y <= 0.0f ? oay : oy - p.by, ocz = y <= 0.0f ? oaz : oz - p.bz;
+        b = dx * ocx + dy * ocy + dz * ocz;
+        c = ocx * ocx + ocy * ocy + ocz * ocz - p.rad * p.rad;
+        h = b * b - c;
+        if (h < 0.0f) return -1.0f;
+        t = -b - sqrtf(h);
+        y = y <= 0.0f ? 0.0f : baba;
+    }
+    if (t <= 0.0f) return -1.0f;
+    const float k = y / baba;
+    nx = (oax + t * dx - bax * k) / p.rad; ny = (oay + t * dy - bay * k) / p.rad; nz = (oaz + t * dz - baz * k) / p.rad;
+    return t;
+}
+
+// ---- scenes ----------------------------------------------------------------------------------------------
+__device__ int build_mobile_scene(const RasterParams &rp, const RasterMobileView &v, int e, Prim *prims) {
+    const float x = (float)v.x[e], y = (float)v.y[e];
+    const float tx = (float)v.tx[e], ty = (float)v.ty[e], t2x = (float)v.t2x[e], t2y = (float)v.t2y[e];
+    int n = 0;
+    set_prim(prims[n++], PRIM_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, 0.0f, 0, 0, 0, 0, 1, 0);
+    set_prim(prims[n++], PRIM_BOX, 0.8f, 0.0f, 0.0f, 2.0f, 0.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);           // wall_left
+    if (rp.kind != SRLHIP_ENV_MOBILE_1D) {
+        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.0f, 0.0f, 4.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);       // wall_bottom
+        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.8f, 0.0f, 2.0f, 4.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);       // wall_right
+        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.0f, 0.8f, 0.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);       // wall_top
+    }
+    if (rp.kind == SRLHIP_ENV_MOBILE_LINE)
+        set_prim(prims[n++], PRIM_BOX, 1.0f, 1.0f, 0.0f, tx, 2.0f, -0.045f, 2.0f, 0.25f, 0.05f, 0, 0.0f, 1.0f);      // line target
+    else
+        set_prim(prims[n++], PRIM_CYL, 1.0f, 1.0f, 0.0f, tx, ty, 0.0f, 0.18f, 0, 0.03f, 0, 1, 0);
+    if (rp.kind == SRLHIP_ENV_MOBILE_2TARGET)
+        set_prim(prims[n++], PRIM_CYL, 0.8f, 0.0f, 0.0f, t2x, t2y, 0.0f, 0.18f, 0, 0.03f, 0, 1, 0);
+    set_prim(prims[n++], PRIM_BOX, 0.15f, 0.15f, 0.60f, x, y, 0.075f, 0.325f, 0.1f, 0.075f, 0, 1.0f, 0.0f);          // robot
+    return n;
+}
+
+__device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
+    using namespace kuka;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {kBasePos[0], kBasePos[1], kBasePos[2]};
+    float jp[ND][3];
+    const int64_t n = v.n;
+#define SRL_FK(I) { fk_forward<I>(R, p, v.sq[(I) * n + e], v.cq[(I) * n + e]); jp[I][0] = (float)p[0]; jp[I][1] = (float)p[1]; jp[I][2] = (float)p[2]; }
+    SRL_FK(0) SRL_FK(1) SRL_FK(2) SRL_FK(3) SRL_FK(4) SRL_FK(5) SRL_FK(6)
+#undef SRL_FK
+    const float bx = (float)v.bx[e], by = (float)v.by[e], cap_z = (float)(kButtonBaseZ + kGliderOriginZ + v.bq[e]);
+    int k = 0;
+    set_prim(prims[k++], PRIM_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
+    set_prim(prims[k++], PRIM_BOX, 0.55f, 0.35f, 0.20f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);     // table top
+    set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, bx, by, (float)kButtonBaseZ, 0.10f, 0, 0.03f, 0, 1, 0);         // button base
+    set_prim(prims[k++], PRIM_CYL, 1.0f, 1.0f, 0.0f, bx, by, cap_z, 0.09f, 0, 0.03f, 0, 1, 0);                       // button cap
+    set_prim(prims[k++], PRIM_CAPSULE, 0.35f, 0.35f, 0.38f, (float)kBasePos[0], (float)kBasePos[1], (float)kBasePos[2],
+             jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
+    for (int i = 0; i < ND - 1; i++)
+        set_prim(prims[k++], PRIM_CAPSULE, 1.0f, 0.45f, 0.05f, jp[i][0], jp[i][1], jp[i][2], jp[i + 1][0], jp[i + 1][1],
+                 jp[i + 1][2], 0.06f, 1, 0);
+    const double body[3] = {0, 0, 0.10}, fa0[3] = {0, 0.030, 0.10}, fa1[3] = {0, 0.020, 0.255}, fb0[3] = {0, -0.030, 0.10},
+                 fb1[3] = {0, -0.020, 0.255};
+    double a[3], b[3];
+    tip_point(R, p, body, a);
+    set_prim(prims[k++], PRIM_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], (float)a[0], (float)a[1], (float)a[2], 0.045f, 1, 0);
+    tip_point(R, p, fa0, a); tip_point(R, p, fa1, b);
+    set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+    tip_point(R, p, fb0, a); tip_point(R, p, fb1, b);
+    set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+    return k;
+}
+
+__device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, int nprims, const Camera &c, float sx, float sy) {
+    float dx = c.fx + sx * c.rx + sy * c.ux, dy = c.fy + sx * c.ry + sy * c.uy, dz = c.fz + sx * c.rz + sy * c.uz;
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;     // background
+    bool hit = false;
+    for (int k = 0; k < nprims; k++) {
+        const Prim &p = prims[k];
+        float nx, ny, nz, t;
+        if (p.type == PRIM_PLANE) t = hit_plane(p, c.ez, dz, nx, ny, nz);
+        else if (p.type == PRIM_BOX) t = hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
+        else if (p.type == PRIM_CYL) t = hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
+        else t = hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
+        if (t > 0.0f && t < best) { best = t; bnx = nx; bny = ny; bnz = nz; cr = p.r; cg = p.g; cb = p.b; hit = true; }
+    }
+    float shade = 1.0f;
+    if (hit) {
+        // one directional light, ambient 0.6 + diffuse 0.4 (TinyRenderer-like proportions), no shadows
+        const float lx = -0.40824829f, ly = 0.40824829f, lz = 0.81649658f;
+        const float ndl = fmaxf(bnx * lx + bny * ly + bnz * lz, 0.0f);
+        shade = 0.6f + 0.4f * ndl;
+    }
+    const uint32_t r8 = (uint32_t)(fminf(cr * shade, 1.0f) * 255.0f + 0.5f);
+    const uint32_t g8 = (uint32_t)(fminf(cg * shade, 1.0f) * 255.0f + 0.5f);
+    const uint32_t b8 = (uint32_t)(fminf(cb * shade, 1.0f) * 255.0f + 0.5f);
+    return r8 | (g8 << 8) | (b8 << 16);
+}
+
+__global__ void __launch_bounds__(kRasterBlock)
+raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) {
+    __shared__ Prim prims[kMaxPrims];
+    __shared__ int nprims;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
+    const int e = blockIdx.x, cam = blockIdx.y;
+    if (threadIdx.x == 0)
+        nprims = rp.kind == SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
+    __syncthreads();
+    const Camera c = rp.cam[cam];
+    const int npix = rp.h * rp.w;
+    uint8_t *out = img + (int64_t)e * npix * rp.channels;
+    for (int base = 0; base < npix; base += kTilePixels) {
+        const int count = min(kTilePixels, npix - base);
+        for (int i = threadIdx.x; i < count; i += kRasterBlock) {
+            const int pix = base + i, row = pix / rp.w, col = pix - row * rp.w;
+            const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+            const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
+            const uint32_t rgb = shade_pixel(prims, nprims, c, sx, sy);
+            tile[3 * i] = (uint8_t)rgb; tile[3 * i + 1] = (uint8_t)(rgb >> 8); tile[3 * i + 2] = (uint8_t)(rgb >> 16);
+        }
+        __syncthreads();
+        if (rp.channels == 3 && ((count * 3) & 15) == 0 && (((int64_t)base * 3) & 15) == 0 && ((reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(tile);
+            u32x4 *dst = reinterpret_cast<u32x4 *>(out + (int64_t)base * 3);
+            for (int i = threadIdx.x; i < count * 3 / 16; i += kRasterBlock) __builtin_nontemporal_store(src[i], dst + i);
+        } else {
+            for (int i = threadIdx.x; i < count; i += kRasterBlock) {
+                uint8_t *d = out + (int64_t)(base + i) * rp.channels + 3 * cam;
+                d[0] = tile[3 * i]; d[1] = tile[3 * i + 1]; d[2] = tile[3 * i + 2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pybullet computeViewMatrixFromYawPitchRoll (upAxisIndex = 2): eye = target + Rz(yaw) Ry(roll) Rx(pitch) (0,-d,0),
+// up = R (0,0,1); negative pitch looks down from above.
+Camera make_camera(const double target[3], double dist, double yaw_deg, double pitch_deg, double roll_deg, double fov_deg) {
+    const double d2r = 3.14159265358979323846 / 180.0;
+    const double cy = cos(yaw_deg * d2r), sy = sin(yaw_deg * d2r), cp = cos(pitch_deg * d2r), sp = sin(pitch_deg * d2r);
+    const double cr = cos(roll_deg * d2r), sr = sin(roll_deg * d2r);
+    // R = Rz(yaw) * Ry(roll) * Rx(pitch)
+    const double Rm[3][3] = {{cy * cr, cy * sr * sp - sy * cp, cy * sr * cp + sy * sp},
+                             {sy * cr, sy * sr * sp + cy * cp, sy * sr * cp - cy * sp},
+                             {-sr, cr * sp, cr * cp}};
+    double eye[3], up[3], f[3], r[3], u[3];
+    for (int k = 0; k < 3; k++) { eye[k] = target[k] + Rm[k][1] * (-dist); up[k] = Rm[k][2]; f[k] = target[k] - eye[k]; }
+    double nf = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    for (int k = 0; k < 3; k++) f[k] /= nf;
+    r[0] = f[1] * up[2] - f[2] * up[1]; r[1] = f[2] * up[0] - f[0] * up[2]; r[2] = f[0] * up[1] - f[1] * up[0];
+    double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    for (int k = 0; k < 3; k++) r[k] /= nr;
+    u[0] = r[1] * f[2] - r[2] * f[1]; u[1] = r[2] * f[0] - r[0] * f[2]; u[2] = r[0] * f[1] - r[1] * f[0];
+    Camera c;
+    c.ex = (float)eye[0]; c.ey = (float)eye[1]; c.ez = (float)eye[2];
+    c.fx = (float)f[0]; c.fy = (float)f[1]; c.fz = (float)f[2];
+    c.rx = (float)r[0]; c.ry = (float)r[1]; c.rz = (float)r[2];
+    c.ux = (float)u[0]; c.uy = (float)u[1]; c.uz = (float)u[2];
+    c.tan_half_fov = (float)tan(fov_deg * d2r / 2);
+    return c;
+}
+
+}  // namespace
+
+// views of the env state, provided by mobile.hip / kuka.hip
+void kuka_raster_view(Handle *h, RasterKukaView *v);
+
+int raster_render(Handle *h, void *d_img) {
+    RasterParams rp;
+    const srlhip_config &c = h->cfg;
+    rp.kind = c.env_kind; rp.n = h->n; rp.h = c.img_h; rp.w = c.img_w;
+    rp.ncam = (c.env_kind == SRLHIP_ENV_KUKA_BUTTON && c.multi_view) ? 2 : 1;
+    rp.channels = 3 * rp.ncam;
+    RasterKukaView kv = {};
+    RasterMobileView mv = {};
+    if (c.env_kind == SRLHIP_ENV_KUKA_BUTTON) {
+        const double t1[3] = {0.316, -0.2, -0.1}, t2[3] = {0.316, 0.316, -0.105};
+        rp.cam[0] = make_camera(t1, 1.1, 145, -36, 0, 60);        // kuka_button_gym_env.py:94-102
+        rp.cam[1] = make_camera(t2, 1.05, 32, -13, 0, 60);        // :403-409 (multi_view)
+        kuka_raster_view(h, &kv);
+    } else {
+        const double t[3] = {2, c.env_kind == SRLHIP_ENV_MOBILE_1D ? 0.0 : 2.0, 0};
+        rp.cam[0] = make_camera(t, 4.4, 90, -90, 0, 60);          // mobile_robot_env.py:76-84, 1D :33
+        rp.cam[1] = rp.cam[0];
+        const MobileState &s = h->mobile;
+        mv.x = s.pos_x; mv.y = s.pos_y; mv.tx = s.tgt_x; mv.ty = s.tgt_y; mv.t2x = s.tgt2_x; mv.t2y = s.tgt2_y; mv.cur = s.cur_target;
+    }
+    hipLaunchKernelGGL(raster_k, dim3(h->n, rp.ncam), dim3(kRasterBlock), 0, h->stream, rp, kv, mv, static_cast<uint8_t *>(d_img));
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+}  // namespace srl

@@ -32,7 +32,7 @@ EXPORTS = [
     "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
-    "srlhip_device_ptr", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
+    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error",
 ]
 
@@ -83,6 +83,7 @@ def load():
     lib.srlhip_set_state.argtypes = [vp, i32, vp]
     lib.srlhip_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
     lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     _lib = lib
@@ -145,7 +146,7 @@ class Handle(object):
         n = self.num_envs
         lead = (n,) if T is None else (T, n)
         if self.cfg.obs_mode == OBS_RAW_PIXELS:
-            ch = 6 if self.cfg.multi_view else 3
+            ch = 6 if (self.cfg.multi_view and self.cfg.env_kind == ENV_KUKA_BUTTON) else 3
             return np.zeros(lead + (self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         return np.zeros(lead + (self.obs_dim,), np.float32)
 
@@ -227,6 +228,17 @@ class Handle(object):
         p = ctypes.c_void_p()
         self._check(self._lib.srlhip_device_ptr(self._h, field, ctypes.byref(p)), "srlhip_device_ptr")
         return p.value
+
+    def render(self, out=None):
+        """uint8 [N][H][W][C] image of the current state of every env (tile rasteriser)."""
+        if self.cfg.io_device:
+            self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
+            return out
+        ch = 6 if (self.cfg.multi_view and self.cfg.env_kind == ENV_KUKA_BUTTON) else 3
+        if out is None:
+            out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
+        self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
+        return out
 
     def episode_stats(self):
         n = self.num_envs

@@ -123,7 +123,7 @@ class _HipEnv(SRLGymEnv):
     def render(self, mode='human', close=False):
         if mode != "rgb_array":
             return np.array([])
-        raise NotImplementedError("raw_pixels rendering needs the tile rasteriser (not built in this round)")
+        return self._h.render()[0]          # HIP tile rasteriser, uint8 [H][W][3 (6 with multi_view)]
 
 
 # ---------------------------------------------------------------------------- MobileRobot

@@ -46,6 +46,8 @@ class HipVecEnv(object):
         if self.srl_model not in OBS_MODES:
             raise NotImplementedError("srl_model={!r}: learned SRL encoders plug in on top of raw_pixels".format(self.srl_model))
         cfg.obs_mode = OBS_MODES[self.srl_model]
+        if "img_shape" in kw:                       # (H, W); the reference renders 224 x 224
+            cfg.img_h, cfg.img_w = kw["img_shape"]
         cfg.rng_mode, cfg.auto_reset, cfg.io_device = RNG_MODES[rng_mode], 1, 0
         self.cfg = cfg
         self._h = _lib.Handle(cfg)
@@ -108,7 +110,7 @@ class HipVecEnv(object):
         return self._h.rollout(n_steps, actions=actions)
 
     def get_images(self):
-        raise NotImplementedError("rendering needs the tile rasteriser")
+        return list(self._h.render())
 
     def render(self, mode="human"):
         return np.array([])

@@ -1,0 +1,83 @@
+"""GPU parity of the tile rasteriser (raw_pixels observation) against oracle/raster_oracle.c:
+uint8 images bit-exact (float32, no contraction on either side)."""
+import numpy as np
+import pytest
+
+from oracle import raster_clib
+from srlhip import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def kuka_state(h):
+    q = h.get_state(_lib.F_KUKA_Q).T
+    b = h.get_state(_lib.F_KUKA_BUTTON_Q)[0]
+    bp = h.get_state(_lib.F_KUKA_BUTTON_POS).T
+    return np.concatenate([q, b[:, None], bp[:, :2]], axis=1)
+
+
+def mobile_state(h):
+    f = lambda k: h.get_state(k)
+    return np.stack([f(_lib.F_POS_X), f(_lib.F_POS_Y), f(_lib.F_TARGET_X), f(_lib.F_TARGET_Y), f(_lib.F_TARGET2_X), f(_lib.F_TARGET2_Y)], 1)
+
+
+def assert_images_equal(gpu, ora):
+    assert gpu.shape == ora.shape and gpu.dtype == np.uint8
+    diff = np.abs(gpu.astype(np.int16) - ora.astype(np.int16))
+    frac = (diff.max(axis=-1) > 0).mean()
+    assert frac == 0.0, "differing pixels: {:.5f}, max diff {}".format(frac, diff.max())
+
+
+@pytest.mark.parametrize("hw,multi_view", [((64, 64), 0), ((224, 224), 0), ((64, 64), 1), ((48, 80), 0)])
+def test_kuka_images_match_oracle(hw, multi_view):
+    n = 64
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg.num_envs, cfg.seed0, cfg.random_target, cfg.multi_view = n, 2, 1, multi_view
+    cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, hw[0], hw[1]
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    assert obs.shape == (n, hw[0], hw[1], 6 if multi_view else 3) and obs.dtype == np.uint8
+    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view))
+    actions = np.random.RandomState(0).randint(6, size=(40, n)).astype(np.int32)
+    for t in range(40):
+        obs, r, d = h.step(actions[t])
+    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view))
+    assert_images_equal(h.render(), obs)
+    assert len(np.unique(obs.reshape(-1, obs.shape[-1])[:, :3], axis=0)) > 50      # a real shaded scene, not a flat fill
+    h.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_mobile_images_match_oracle(kind):
+    n = 32
+    cfg = _lib.default_config(kind)
+    cfg.num_envs, cfg.seed0, cfg.random_target = n, 4, 1
+    cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, 64, 64
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    assert_images_equal(obs, raster_clib.render(kind, mobile_state(h)))
+    out = h.rollout(30, actions=np.random.RandomState(1).randint(2, size=(30, n)).astype(np.int32))
+    assert out["obs"].shape == (30, n, 64, 64, 3)
+    assert_images_equal(out["obs"][-1], raster_clib.render(kind, mobile_state(h)))
+    # the robot (blue box) moves between frames
+    assert (out["obs"][0] != out["obs"][-1]).any()
+    h.close()
+
+
+def test_facade_render_and_raw_pixel_vec_env():
+    from environments.kuka_gym.kuka_button_gym_env import KukaButtonGymEnv
+    from srlhip.vec_env import HipVecEnv
+    env = KukaButtonGymEnv()                      # default srl_model = raw_pixels, 224 x 224 like the reference
+    assert env.observation_space.shape == (224, 224, 3)
+    env.seed(0)
+    obs = env.reset()
+    assert obs.shape == (224, 224, 3) and obs.dtype == np.uint8 and env.render().size == 0
+    obs2, r, d, _ = env.step(4)
+    assert obs2.shape == (224, 224, 3)
+    env.close()
+    venv = HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "raw_pixels", "img_shape": (64, 64)})
+    o = venv.reset()
+    assert o.shape == (16, 64, 64, 3) and o.dtype == np.uint8
+    o, r, d, info = venv.step([0] * 16)
+    assert len(venv.get_images()) == 16
+    venv.close()
