@@ -29,7 +29,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec)
 # algorithmic bytes per env-step
-ALG_BYTES = {"mobile": 73, "kuka": 213}
+ALG_BYTES = {"mobile": 73, "kuka": 213, "kuka_pixels": 24900}
 PUBLISHED_REFERENCE_FPS = 250.0   # /root/reference/README.md:9 (8 cores, with 224x224 rendering)
 
 
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="auto", choices=["auto", "kuka", "mobile"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "kuka", "mobile", "kuka_pixels"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--inner-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +76,74 @@ def cpu_baseline(workload, n_envs, budget_s=12.0):
     return kuka_clib.cpu_baseline(budget_s)
 
 
+def bench_pixels(args, rank, local_rank, world, dev):
+    """BASELINE config 4/5: KukaButtonGymEnv raw_pixels 64x64 -> tile rasteriser -> SRL encoder forward
+    (PyTorch-ROCm) on the same device.  One bench step = `inner` VecEnv steps of this rank's shard."""
+    from srlhip import _lib, sharding
+    from srlhip.pixel_env import PixelStateVecEnv
+    from state_representation.models import SRLNeuralNetwork
+    n, inner = args.envs_per_gpu, args.inner_steps or 8
+    K = args.steps if args.steps is not None else 10
+    W = args.warmup if args.warmup is not None else 2
+    torch.manual_seed(0)
+    enc = SRLNeuralNetwork(3, cuda=True, img_shape=(64, 64), device=dev)
+    first, _ = sharding.shard_range(world * n, world, rank)
+    env = PixelStateVecEnv("KukaButtonGymEnv-v0", n, enc, seed=0, img_shape=(64, 64), device_id=local_rank, first_env_id=first)
+    env.reset()
+    gathered = torch.zeros((world * n,), dtype=torch.float32, device=dev) if world > 1 else None
+    ret = torch.zeros((n,), dtype=torch.float32, device=dev)
+
+    def one_step():
+        ret.zero_()
+        for _ in range(inner):
+            states, rew, done = env.step()
+            ret.add_(rew)
+        if world > 1:
+            sharding.gather_episode_returns(ret, out=gathered)
+
+    def fence():
+        env.h.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(W):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one_step()
+    fence()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, device=dev)
+    # dominant HBM kernel of this path: the rasteriser; time it alone with HIP events on its own stream
+    env.h.sync()
+    reps = 50
+    env.h.timing_begin()
+    for _ in range(reps):
+        env.h.render(out=env.images.data_ptr())
+    raster_ms = env.h.timing_end() / reps
+    value = world * n * inner * K / dt
+    raster_gbs = n * 64 * 64 * 3 / (raster_ms * 1e-3) / 1e9
+    line = {"metric": "env steps/sec (whole node), KukaButtonGymEnv {} envs/GPU".format(n), "value": value,
+            "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 dynamics, f32 raster/encoder",
+            "data": "synthetic",
+            "config": {"workload": "KukaButtonGymEnv-v0 raw_pixels 64x64, {} envs per GPU, tile rasteriser + srl_zoo CustomCNN "
+                                   "forward (random init) on the same device, random-agent actions".format(n),
+                       "envs_per_gpu": n, "inner_steps": inner, "parallelism": "env-shard x{}".format(world),
+                       "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
+            "roofline": {"bound": "hbm", "kernel": "raster_k", "achieved": raster_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": raster_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": raster_ms,
+                         "alg_bytes_per_env_step": 12288, "env_steps_per_launch": n,
+                         "note": "image write only (12 288 B per env); the rasteriser is ray-cast ALU bound at 64x64"}}
+    env.close()
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     from srlhip import _lib
@@ -91,6 +159,8 @@ def main():
     workload = args.workload
     if workload == "auto":
         workload = "kuka" if kuka_available() else "mobile"
+    if workload == "kuka_pixels":
+        return bench_pixels(args, rank, local_rank, world, dev)
     n = args.envs_per_gpu
     inner = args.inner_steps or (256 if workload == "mobile" else 32)
     K = args.steps if args.steps is not None else (40 if workload == "mobile" else 20)

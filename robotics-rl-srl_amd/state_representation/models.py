@@ -1,0 +1,98 @@
+"""SRL encoder forward pass for the raw_pixels path (state_representation/models.py:38-193,
+rl_baselines/utils.py:162-191), batched and device-resident.
+
+The reference runs ONE encoder process that serves every env serially at batch size 1 through
+multiprocessing queues (150 KB pickled per observation).  Here the rasteriser's uint8 NHWC batch stays
+in HBM and goes through one batched forward under PyTorch-ROCm (MIOpen / rocBLAS do the convolutions).
+
+srl_zoo is an empty submodule in the reference checkout, so the architecture is restated from its
+published description: CustomCNN = conv7x7/2(3->64)+BN+ReLU+maxpool3/2,
+conv3x3(64->64)+BN+ReLU+maxpool3/2, conv3x3/2(64->64)+BN+ReLU+maxpool3/2, FC(flat -> state_dim); the
+flattened size follows the input size (6*6*64 at 224x224, 1*1*64 at 64x64).  Weights are random-initialised
+unless a state_dict is given: there are no checkpoints in this environment."""
+import numpy as np
+import torch as th
+import torch.nn as nn
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess(images_u8):
+    """srl_zoo preprocessImage + the reference's layout: uint8 [N][H][W][C] -> float32 [N][C][W][H]
+    (state_representation/models.py:185-188 transposes (0, 3, 2, 1): width and height swapped), scaled to
+    [0, 1] and ImageNet mean/std normalised per 3-channel group.  Runs on the tensor's device."""
+    x = images_u8.to(th.float32) / 255.0
+    c = x.shape[-1]
+    mean = th.tensor(IMAGENET_MEAN * (c // 3), dtype=th.float32, device=x.device)
+    std = th.tensor(IMAGENET_STD * (c // 3), dtype=th.float32, device=x.device)
+    x = (x - mean) / std
+    return x.permute(0, 3, 2, 1).contiguous()
+
+
+class CustomCNN(nn.Module):
+    def __init__(self, state_dim=2, n_channels=3, img_shape=(224, 224)):
+        super(CustomCNN, self).__init__()
+        self.conv_layers = nn.Sequential(
+            nn.Conv2d(n_channels, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+            nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=1, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.Conv2d(64, 64, kernel_size=3, stride=2, padding=1, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+        )
+        with th.no_grad():
+            flat = self.conv_layers(th.zeros(1, n_channels, img_shape[1], img_shape[0])).numel()
+        self.flat_dim = flat
+        self.fc = nn.Linear(flat, state_dim)
+
+    def forward(self, x):
+        x = self.conv_layers(x)
+        return self.fc(x.reshape(x.size(0), -1))
+
+    def getStates(self, x):
+        return self.forward(x)
+
+
+class SRLNeuralNetwork(object):
+    """state_representation/models.py:SRLNeuralNetwork — getState(observation) for one image (reference
+    surface) and getStates(images) for a whole device-resident batch."""
+
+    def __init__(self, state_dim, cuda=False, model_type="custom_cnn", n_channels=3, img_shape=(224, 224),
+                 state_dict=None, device=None):
+        assert model_type == "custom_cnn", "only the srl_zoo CustomCNN encoder is restated"
+        self.state_dim = state_dim
+        self.device = th.device(device if device is not None else ("cuda" if cuda else "cpu"))
+        self.model = CustomCNN(state_dim, n_channels, img_shape)
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        self.model = self.model.eval().to(self.device)
+
+    @th.no_grad()
+    def getStates(self, images_u8):
+        """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim]."""
+        if isinstance(images_u8, np.ndarray):
+            images_u8 = th.from_numpy(images_u8)
+        return self.model.getStates(preprocess(images_u8.to(self.device)))
+
+    def getState(self, observation, env_id=0):
+        return self.getStates(np.asarray(observation)[None])[0].to("cpu").numpy()
+
+
+def getSRLDim(path=None, env_object=None):
+    if path is not None:
+        import json
+        with open(path.rsplit("/", 1)[0] + "/exp_config.json") as f:
+            return json.load(f).get("state-dim", 2)
+    return env_object.getGroundTruthDim()
+
+
+def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_shape=(224, 224), n_channels=3):
+    """Factory with the reference's signature (models.py:38-107).  With a checkpoint path the state_dict is
+    loaded into the restated CustomCNN; without one the encoder is random-initialised."""
+    state_dict = None
+    if path is not None:
+        state_dim = getSRLDim(path) if state_dim is None else state_dim
+        state_dict = th.load(path, map_location="cpu")
+    assert state_dim is not None and state_dim > 0
+    return SRLNeuralNetwork(state_dim, cuda, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict)
