@@ -673,40 +673,89 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     //    dependent chain per row and 6 FMAs instead of 7 + bookkeeping; the velocity change is formed once
     //    at the end.  The button DoF stays in velocity space (scalar dvb).
 #define SRL_W(i, j) ((i) <= (j) ? W[i][j] : W[j][i])
-    double lam[ND], g[ND], cg[ND], cur[ND], nxt[ND], dvb = 0.0;
+    // Rows are pre-scaled by 1 / W_ii (Ws_ij = W_ij / W_ii, cs_i = (c_i - g_i) / W_ii) so that an arm-row update is
+    //   lam_j = clamp(cur_j);  cur_i -= Ws_ij lam_j (i > j: rows still to come);  nxt_i -= Ws_ij lam_j (i < j: next sweep)
+    // with cur_i = cs_i - sum_{j<i} Ws_ij lam_j(this sweep) - sum_{j>i} Ws_ij lam_j(previous sweep): the only
+    // dependent chain per row is fma -> max -> min.  The three scalar button rows clamp the impulse increment
+    // against (lo - applied, hi - applied), known one sweep ahead: fma -> max -> min -> fma.
+    double Ws[ND][ND], lam[ND], g[ND], cs[ND], cur[ND], nxt[ND], dvb = 0.0;
 #pragma unroll
-    for (int i = 0; i < ND; i++) { lam[i] = 0.0; g[i] = 0.0; cg[i] = target[i] - e.qd[i]; cur[i] = cg[i]; nxt[i] = 0.0; }
-    const double blim = kLimitMaxImpulse;
-    // cur_i = cg_i - sum_{j<i} W_ij lam_j(this sweep) - sum_{j>i} W_ij lam_j(previous sweep).  Each new lam_j is
-    // scattered into the rows that still need it (cur) and into next sweep's partial sums (nxt), so the only
-    // dependent chain per arm row is fma -> mul -> max -> min.  The three scalar button rows clamp the impulse
-    // increment against (lo - applied, hi - applied), which are known one sweep ahead: fma -> max -> min -> fma.
-#define SRL_ARM_ROWS()                                                                   \
-    _Pragma("unroll") for (int j = 0; j < ND; j++) {                                     \
-        const double l = fmin(fmax(cur[j] * dinv[j], -arm_bound), arm_bound);            \
-        lam[j] = l;                                                                      \
-        _Pragma("unroll") for (int i = j + 1; i < ND; i++) cur[i] -= SRL_W(i, j) * l;    \
-        _Pragma("unroll") for (int i = 0; i < j; i++) nxt[i] -= SRL_W(i, j) * l;         \
+    for (int i = 0; i < ND; i++) {
+        lam[i] = 0.0; g[i] = 0.0; cs[i] = (target[i] - e.qd[i]) * dinv[i]; cur[i] = cs[i]; nxt[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < ND; j++) Ws[i][j] = j == i ? 0.0 : SRL_W(i, j) * dinv[i];
     }
+    const double blim = kLimitMaxImpulse;
 #define SRL_BUTTON_ROW(app, rhs, jsign, lo, hi)                                          \
     {                                                                                    \
         const double d__ = fmin(fmax((rhs) - (jsign) * dvb * dinvb, (lo) - (app)), (hi) - (app)); \
         dvb += (jsign) * d__ * wb;                                                       \
         (app) += d__;                                                                    \
     }
+    // FUSED = 1: cs is constant over the solve, so next sweep's partial sum starts from cs at its first term
+#define SRL_ARM_ROWS(FUSED)                                                              \
+    _Pragma("unroll") for (int j = 0; j < ND; j++) {                                     \
+        const double l = fmin(fmax(cur[j], -arm_bound), arm_bound);                      \
+        lam[j] = l;                                                                      \
+        _Pragma("unroll") for (int i = j + 1; i < ND; i++) cur[i] -= Ws[i][j] * l;       \
+        _Pragma("unroll") for (int i = 0; i < j; i++) {                                  \
+            if ((FUSED) && i == j - 1) nxt[i] = cs[i] - Ws[i][j] * l;                    \
+            else nxt[i] -= Ws[i][j] * l;                                                 \
+        }                                                                                \
+    }
     if (!SRL_ANY(ngen > 0)) {
-        // whole wavefront free of limit / contact rows: one straight-line block per sweep
+        // -- path 1: the whole wavefront is free of limit / contact rows: one straight-line block per sweep
         for (int it = 0; it < kSolverIters; it++) {
-            SRL_ARM_ROWS()
+            SRL_ARM_ROWS(1)
             SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
             SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
             SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
 #pragma unroll
-            for (int i = 0; i < ND; i++) { cur[i] = cg[i] + nxt[i]; nxt[i] = 0.0; }
+            for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
+            cur[ND - 1] = cs[ND - 1];
+        }
+    } else if (!SRL_ANY(nlim > 0)) {
+        // -- path 2: contact rows only (no arm joint near its stop).  The first two contact rows of every lane are
+        //    held in VGPRs for all 150 sweeps (lanes without one carry an all-zero row, which is a no-op), the
+        //    rest stay in LDS.  Arm velocity change so far = W lam + g with g = sum_k WJ_k mu_k.
+        double rJ[2][ND], rWJ[2][ND], rJb[2], rWJb[2], rDinv[2], rRhs[2], rLo[2], rHi[2], rMu[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const bool has = k < ngen;
+            const int base = k * ROW_STRIDE;
+#pragma unroll
+            for (int i = 0; i < ND; i++) { rJ[k][i] = has ? sc.row(base + ROW_J + i) : 0.0; rWJ[k][i] = has ? sc.row(base + ROW_WJ + i) : 0.0; }
+            rJb[k] = has ? sc.row(base + ROW_JB) : 0.0; rWJb[k] = has ? sc.row(base + ROW_WJB) : 0.0;
+            rDinv[k] = has ? sc.row(base + ROW_DINV) : 0.0; rRhs[k] = has ? sc.row(base + ROW_RHS) : 0.0;
+            rLo[k] = has ? sc.row(base + ROW_LO) : 0.0; rHi[k] = has ? sc.row(base + ROW_HI) : 0.0; rMu[k] = 0.0;
+        }
+        const bool second = SRL_ANY(ngen > 1);
+        for (int it = 0; it < kSolverIters; it++) {
+            SRL_ARM_ROWS(0)
+            SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
+            SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
+            SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (k == 1 && !second) break;
+                double jdv = rJb[k] * dvb;
+#pragma unroll
+                for (int i = 0; i < ND; i++) jdv += rWJ[k][i] * lam[i] + rJ[k][i] * g[i];
+                const double d = fmin(fmax(rRhs[k] - jdv * rDinv[k], rLo[k] - rMu[k]), rHi[k] - rMu[k]);
+                rMu[k] += d;
+#pragma unroll
+                for (int i = 0; i < ND; i++) g[i] += d * rWJ[k][i];
+                dvb += d * rWJb[k];
+            }
+            for (int k = 2; SRL_ANY(k < ngen); k++)
+                if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
+#pragma unroll
+            for (int i = 0; i < ND; i++) { cs[i] = ((target[i] - e.qd[i]) - g[i]) * dinv[i]; cur[i] = cs[i] + nxt[i]; nxt[i] = 0.0; }
         }
     } else {
+        // -- path 3 (rare): arm-limit rows present; every generic row through LDS, in the general row order
         for (int it = 0; it < kSolverIters; it++) {
-            SRL_ARM_ROWS()
+            SRL_ARM_ROWS(0)
             SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
             for (int k = 0; SRL_ANY(k < nlim); k++)
                 if (k < nlim) pgs_generic_row(sc, k, lam, g, dvb);
@@ -715,7 +764,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             for (int k = nlim; SRL_ANY(k < ngen); k++)
                 if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
 #pragma unroll
-            for (int i = 0; i < ND; i++) { cur[i] = ((target[i] - e.qd[i]) - g[i]) + nxt[i]; nxt[i] = 0.0; }
+            for (int i = 0; i < ND; i++) { cs[i] = ((target[i] - e.qd[i]) - g[i]) * dinv[i]; cur[i] = cs[i] + nxt[i]; nxt[i] = 0.0; }
         }
     }
 #undef SRL_ARM_ROWS
