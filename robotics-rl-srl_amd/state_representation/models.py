@@ -54,6 +54,28 @@ class CustomCNN(nn.Module):
         return self.forward(x)
 
 
+def fold_batchnorm(seq):
+    """Inference-time fusion of every Conv2d + BatchNorm2d(eval) pair into one Conv2d with bias
+    (w' = w * gamma / sigma, b' = beta - mu * gamma / sigma): removes three memory-bound BN passes per forward."""
+    out, layers = [], list(seq)
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Conv2d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d):
+            bn = layers[i + 1]
+            scale = bn.weight / th.sqrt(bn.running_var + bn.eps)
+            conv = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=True)
+            conv.weight.data = (m.weight * scale.view(-1, 1, 1, 1)).detach().clone()
+            bias = m.bias if m.bias is not None else th.zeros_like(bn.running_mean)
+            conv.bias.data = ((bias - bn.running_mean) * scale + bn.bias).detach().clone()
+            out.append(conv)
+            i += 2
+        else:
+            out.append(m)
+            i += 1
+    return nn.Sequential(*out)
+
+
 class SRLNeuralNetwork(object):
     """state_representation/models.py:SRLNeuralNetwork — getState(observation) for one image (reference
     surface) and getStates(images) for a whole device-resident batch."""
@@ -66,14 +88,18 @@ class SRLNeuralNetwork(object):
         self.model = CustomCNN(state_dim, n_channels, img_shape)
         if state_dict is not None:
             self.model.load_state_dict(state_dict)
-        self.model = self.model.eval().to(self.device)
+        self.model = self.model.eval()
+        with th.no_grad():
+            self.fused_conv = fold_batchnorm(self.model.conv_layers).eval().to(self.device)
+        self.model = self.model.to(self.device)
 
     @th.no_grad()
     def getStates(self, images_u8):
         """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim]."""
         if isinstance(images_u8, np.ndarray):
             images_u8 = th.from_numpy(images_u8)
-        return self.model.getStates(preprocess(images_u8.to(self.device)))
+        x = self.fused_conv(preprocess(images_u8.to(self.device)))
+        return self.model.fc(x.reshape(x.size(0), -1))
 
     def getState(self, observation, env_id=0):
         return self.getStates(np.asarray(observation)[None])[0].to("cpu").numpy()

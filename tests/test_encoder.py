@@ -43,3 +43,16 @@ def test_device_resident_pixels_to_state_pipeline():
     ref = cpu.getStates(env.images.cpu().numpy())
     assert np.abs(states.cpu().numpy() - ref.numpy()).max() < 2e-3
     env.close()
+
+
+def test_batchnorm_folding_is_equivalent():
+    torch.manual_seed(1)
+    net = SRLNeuralNetwork(4, img_shape=(64, 64))
+    for m in net.model.modules():                       # non-trivial BN statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    net = SRLNeuralNetwork(4, img_shape=(64, 64), state_dict=net.model.state_dict())
+    img = np.random.RandomState(0).randint(0, 256, size=(5, 64, 64, 3)).astype(np.uint8)
+    with torch.no_grad():
+        ref = net.model.getStates(preprocess(torch.from_numpy(img)))
+    assert np.abs(net.getStates(img).numpy() - ref.numpy()).max() < 1e-4
