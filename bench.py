@@ -46,6 +46,28 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, env_steps_per_launch):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summaries (profiles/rNN_*_pmc_{FETCH,WRITE}_SIZE.csv,
+    collected by profiles/collect.sh in separate --pmc passes of this same command).  FETCH_SIZE / WRITE_SIZE are in KiB;
+    FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 tallies 128-B requests at 64 B).  None if no summary
+    matches this launch geometry."""
+    import csv
+    import glob
+    import re
+    wl = "kuka" if kernel.startswith("kuka") else "mobile"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_{}_pmc_{}.csv".format(wl, counter))))
+        if not files:
+            return None
+        for row in csv.DictReader(open(files[-1])):
+            if row["kernel"] == kernel and row["counter"] == counter:
+                out[counter] = float(row["avg_per_dispatch"])
+    if len(out) != 2:
+        return None
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+
+
 def kuka_available():
     from srlhip import _lib
     try:
@@ -224,6 +246,9 @@ def main():
                 "kernel": "mobile_rollout_k" if workload == "mobile" else "kuka_rollout_k",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
+    if n == 4096 and inner == (256 if workload == "mobile" else 32):       # geometry the PMC passes were taken at
+        roofline["traffic"] = measured_traffic(roofline["kernel"], steps_per_launch)
+        roofline["traffic_source"] = "profiles/ PMC summaries (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
     if workload == "kuka":
         from srlhip import kuka_model
         flops = kuka_model.FLOPS_PER_ENV_STEP

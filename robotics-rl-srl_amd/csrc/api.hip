@@ -392,6 +392,7 @@ int srlhip_set_state(srlhip_handle hh, int32_t field, const void *in) {
     if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     SRL_HIP_CHECK(h, hipMemcpy(d, in, elem * count * (size_t)h->n, hipMemcpyHostToDevice));
+    if (field == SRLHIP_F_KUKA_Q) return kuka_refresh(h);        // derived planes: sin/cos of q, gripper position
     return 0;
 }
 

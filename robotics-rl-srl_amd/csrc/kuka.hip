@@ -200,6 +200,16 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
     st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 
+// after srlhip_set_state(KUKA_Q): refresh the cached sin/cos and the gripper position
+__global__ void kuka_refresh_k(KukaState s, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Env v;
+    load_env(s, n, e, v);
+    update_trig_and_gripper(v);
+    store_env(s, n, e, v);
+}
+
 KukaParams params_of(const Handle *h) {
     KukaParams p;
     const srlhip_config &c = h->cfg;
@@ -303,6 +313,13 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const size_t n = (size_t)h->n;
     v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n;
     v->n = (int64_t)n;
+}
+
+int kuka_refresh(Handle *h) {
+    hipLaunchKernelGGL(kuka_refresh_k, dim3((h->n + 63) / 64), dim3(64), 0, h->stream, *h->kuka, h->n);
+    SRL_HIP_CHECK(h, hipGetLastError());
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {

@@ -166,3 +166,31 @@ def test_sharding_invariance():
             assert np.array_equal(r[k], r_full[k][:, sl])
         hs.close()
     full.close()
+
+
+def test_state_checkpoint_restore_and_error_paths():
+    """get_state/set_state round trip (env-state snapshot), and misuse that must fail loudly."""
+    n, T = 64, 60
+    actions = np.random.RandomState(21).randint(6, size=(2 * T, n)).astype(np.int32)
+    a = make(n, rng_mode=_lib.RNG_PHILOX, seed0=5)
+    a.reset()
+    a.rollout(T, actions=actions[:T])
+    snap = {f: a.get_state(f) for f in (_lib.F_KUKA_Q, _lib.F_KUKA_QD, _lib.F_KUKA_EE_TARGET, _lib.F_KUKA_BUTTON_Q)}
+    ref = a.rollout(T, actions=actions[T:])
+    b = make(n, rng_mode=_lib.RNG_PHILOX, seed0=5)
+    b.reset()
+    b.rollout(T, actions=actions[:T])                        # same RNG/counter state as `a` at the snapshot
+    b.set_state(_lib.F_KUKA_QD, np.zeros((7, n)))            # perturb, then restore from the snapshot
+    b.set_state(_lib.F_KUKA_Q, snap[_lib.F_KUKA_Q] + 0.01)
+    for f, v in snap.items():
+        b.set_state(f, v)
+    out = b.rollout(T, actions=actions[T:])
+    assert np.array_equal(out["obs"], ref["obs"]) and np.array_equal(out["reward"], ref["reward"])
+    with pytest.raises(_lib.SrlHipError):
+        b.get_state(_lib.F_POS_X)                             # a MobileRobot field on a Kuka handle
+    hst = make(4, rng_mode=_lib.RNG_HOST, auto_reset=0)
+    with pytest.raises(_lib.SrlHipError):
+        hst.rollout(4)                                        # fused rollout needs a device RNG
+    with pytest.raises(_lib.SrlHipError):
+        hst.reset()                                           # RNG_HOST reset without the draws
+    a.close(); b.close(); hst.close()
