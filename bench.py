@@ -82,18 +82,18 @@ def kuka_available():
 def cpu_baseline(workload, n_envs, budget_s=12.0):
     """Oracle ('port') timed on this box's host cores, rank 0, N=1 only."""
     from oracle import clib
-    cores = 1
     if workload == "mobile":
+        # BASELINE config 1: 4 envs behind a SubprocVecEnv-protocol emulation (the way the reference runs N envs)
+        from oracle import subproc_baseline
+        base = subproc_baseline.mobile_subproc_fps(num_cpu=4, n_steps=2048, warmup=256)
         T = 1024
         t0 = time.perf_counter()
         reps = 0
-        while time.perf_counter() - t0 < min(budget_s, 4.0):
+        while time.perf_counter() - t0 < 3.0:
             clib.mobile_rollout(0, np.arange(n_envs), T, actions=None, rng_mode=clib.RNG_PHILOX)
             reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": reps * T * n_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                "sample": "oracle/mobile_oracle.c, {} envs x {} steps x {} passes, 1 thread, physics only "
-                          "(no rendering)".format(n_envs, T, reps)}
+        base["c_port_1_thread_env_steps_per_s"] = reps * T * n_envs / (time.perf_counter() - t0)
+        return base
     from oracle import kuka_clib
     return kuka_clib.cpu_baseline(budget_s)
 
