@@ -51,6 +51,7 @@ extern "C" {
 #define SRLHIP_ENV_MOBILE_2TARGET  2  /* MobileRobot2TargetGymEnv-v0     */
 #define SRLHIP_ENV_MOBILE_LINE     3  /* MobileRobotLineTargetGymEnv-v0  */
 #define SRLHIP_ENV_KUKA_BUTTON     4  /* KukaButtonGymEnv-v0             */
+#define SRLHIP_ENV_KUKA_MOVING     5  /* KukaMovingButtonGymEnv-v0 (kuka_moving_button_gym_env.py) */
 
 /* ---- observation modes: kuka_button_gym_env.py:162-173 ------------------ */
 #define SRLHIP_OBS_GROUND_TRUTH     0  /* f32[obs_dim] relative position        */

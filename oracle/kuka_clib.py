@@ -25,6 +25,11 @@ def _lib():
     return lib
 
 
+def set_moving(flag):
+    """Select KukaMovingButtonGymEnv semantics for the following rollout / trace / wrapper calls."""
+    _lib().kuka_oracle_set_moving(int(bool(flag)))
+
+
 def aba(q, qd, tau, gz=-10.0):
     q, qd, tau = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau))
     out = np.zeros(7)

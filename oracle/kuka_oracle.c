@@ -260,13 +260,15 @@ typedef struct {
     double bq, bqd;                /* button glider position / velocity            */
     int button_motor_on;           /* 0: pybullet default velocity motor, 1: step2's position target */
     double button_xy[2];           /* button base position on the table            */
+    double button_z;               /* button base height (MovingButton re-places the base every step) */
+    double button_speed;           /* MovingButton: signed y increment per step (kuka_moving_button_gym_env.py:40) */
     double button_pos[3];          /* target: cap position at reset + 0.28 in z    */
     double gripper[3];             /* getArmPos() after the last physics step      */
     int contact_button, contact_table;   /* manifolds of the last stepSimulation  */
     int counter, n_contacts, n_outside, terminated;
 } kenv;
 
-typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints; double max_distance; } kcfg;
+typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving; double max_distance; } kcfg;
 
 /* ------------------------------------------------------------------ collision */
 /* signed distance between a sphere and an upright solid cylinder (axis z, centre xy, z in [z0, z1]);
@@ -321,7 +323,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     /* -- collision detection at the current poses (start of stepSimulation) -- */
     e->contact_button = 0; e->contact_table = 0;
     {
-        double cap_z0 = KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + e->bq;
+        double cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + e->bq;
         /* -- unconstrained velocities: ABA with joint damping torques and gravity -- */
         for (i = 0; i < N; i++) tau[i] = -KM_JOINT_DAMPING * e->qd[i];
         aba(e->q, e->qd, tau, KM_GRAVITY_Z, qdd);
@@ -360,7 +362,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             for (shape = 0; shape < 2; shape++) {
                 double pos_err_vel, allow;
                 if (shape == 0) dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, n);
-                else dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_BASE_RADIUS, KM_BUTTON_BASE_Z, KM_BUTTON_BASE_Z + KM_BASE_HEIGHT, n);
+                else dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, n);
                 if (!(dist < KM_CONTACT_THRESHOLD)) continue;
                 if (shape == 0) e->contact_button = 1;
                 if (ngeneric >= MAX_GENERIC_ROWS) continue;
@@ -402,7 +404,8 @@ static double norm3(const double a[3], const double b[3]) {      /* np.linalg.no
     double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
     return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
 }
-static int termination(const kenv *e) { return e->terminated || e->counter > KM_MAX_STEPS; }   /* :422-426 */
+static int g_max_steps_moving = 1500;   /* kuka_moving_button_gym_env.py:3,34 */
+static int termination_cfg(const kenv *e, const kcfg *cfg) { return e->terminated || e->counter > (cfg->moving ? g_max_steps_moving : KM_MAX_STEPS); }   /* :422-426 */
 
 static double reward_fn(kenv *e, const kcfg *cfg) {              /* :428-463 */
     double distance = norm3(e->button_pos, e->gripper);
@@ -413,7 +416,7 @@ static double reward_fn(kenv *e, const kcfg *cfg) {              /* :428-463 */
     if (e->contact_table || e->n_contacts >= KM_N_CONTACTS_BEFORE_TERMINATION || e->n_outside >= KM_N_STEPS_OUTSIDE_SAFETY_SPHERE)
         e->terminated = 1;
     if (cfg->shape_reward) {
-        if (cfg->is_discrete) return -distance;
+        if (cfg->is_discrete && !cfg->moving) return -distance;      /* MovingButton uses the 50 / -250 / -d branch for every action type (:143-151) */
         if (e->terminated && reward > 0) return 50;
         if (e->terminated && reward < 0) return -250;
         return -distance;
@@ -426,6 +429,7 @@ static double k_double(krng *r) { return r->mode == 2 ? np_rng_double(&r->mt) : 
 static double k_uniform(krng *r, double lo, double hi) { return r->mode == 2 ? np_rng_uniform(&r->mt, lo, hi) : philox_uniform(&r->ph, lo, hi); }
 static double k_normal(krng *r, double loc, double scale) { return r->mode == 2 ? np_rng_normal(&r->mt, loc, scale) : loc + scale * philox_std_normal(&r->ph); }
 static uint32_t k_randint3(krng *r) { return r->mode == 2 ? np_rng_randint(&r->mt, 3) : philox_bounded(&r->ph, 2); }
+static uint32_t k_randint2(krng *r) { return r->mode == 2 ? np_rng_randint(&r->mt, 2) : philox_bounded(&r->ph, 1); }
 
 /* arm/button state after the 500 settle steps (kuka_button_gym_env.py:242-247); the arm never
  * touches anything while settling, so it is the same for every button position. */
@@ -434,15 +438,16 @@ static void settle(kenv *e, const kcfg *cfg) {
     memset(e, 0, sizeof *e);
     for (i = 0; i < N; i++) e->q[i] = KM_JOINT_POSITIONS[i];
     memcpy(e->ee_target, KM_EE_INIT, sizeof e->ee_target);
-    e->button_xy[0] = KM_BUTTON_X; e->button_xy[1] = KM_BUTTON_Y;
+    e->button_xy[0] = KM_BUTTON_X; e->button_xy[1] = KM_BUTTON_Y; e->button_z = KM_BUTTON_BASE_Z;
     for (i = 0; i < KM_N_SETTLE_STEPS; i++) physics_step(e, cfg, zero, cfg->action_joints ? KM_JOINT_POSITIONS : NULL);
 }
 
 static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) {   /* :214-281 */
-    double bx = KM_BUTTON_X, by = KM_BUTTON_Y; int i;
+    double bx = KM_BUTTON_X, by = KM_BUTTON_Y, speed = 0.0; int i;
+    if (cfg->moving) speed = 0.001 * (k_randint2(r) ? 1.0 : -1.0);   /* BUTTON_SPEED * np_random.choice([-1, 1]), drawn first */
     if (cfg->random_target) { bx += 0.15 * k_uniform(r, -1, 1); by += 0.3 * k_uniform(r, -1, 1); }
     *e = *settled;
-    e->button_xy[0] = bx; e->button_xy[1] = by;
+    e->button_xy[0] = bx; e->button_xy[1] = by; e->button_z = KM_BUTTON_BASE_Z; e->button_speed = speed;
     for (i = 0; i < KM_N_RANDOM_ACTIONS_AT_INIT; i++) {
         double action[5] = {0, 0, 0, 0, 0};
         if (cfg->is_discrete) {
@@ -463,7 +468,7 @@ static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) { 
         }
     }
     e->button_pos[0] = bx; e->button_pos[1] = by;
-    e->button_pos[2] = KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + e->bq + KM_BUTTON_DISTANCE_HEIGHT;   /* :273-274 */
+    e->button_pos[2] = e->button_z + KM_GLIDER_ORIGIN_Z + e->bq + KM_BUTTON_DISTANCE_HEIGHT;   /* :273-274 */
     e->counter = 0; e->n_contacts = 0; e->n_outside = 0; e->terminated = 0;
 }
 
@@ -476,6 +481,12 @@ static void observe(const kenv *e, int obs_mode, float *o) {     /* getSRLState 
 /* KukaButtonGymEnv.step (:293-340) + step2 (:342-368).  action < 0 == None. */
 static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const float *caction, int *done) {
     double motor[5] = {0, 0, 0, 0, 0}, joints[N]; const double *jt = NULL; int rep;
+    if (cfg->moving) {                                             /* kuka_moving_button_gym_env.py:111-119 */
+        if (e->button_pos[1] > 0.3 || e->button_pos[1] < -0.3) e->button_speed = -e->button_speed;
+        e->button_pos[1] += e->button_speed;
+        e->button_xy[1] = e->button_pos[1];
+        e->button_z = e->button_pos[2] - KM_BUTTON_DISTANCE_HEIGHT;   /* base re-placed at the recorded cap height */
+    }
     if (action < 0) { if (cfg->action_joints) jt = KM_JOINT_POSITIONS; }      /* None: :295-299, no RNG draw */
     else if (cfg->is_discrete) {
         double dv = KM_DELTA_V + k_normal(r, 0.0, KM_NOISE_STD);
@@ -496,11 +507,15 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
     e->button_motor_on = 1;                                        /* step2 :347 */
     for (rep = 0; rep < cfg->action_repeat; rep++) {
         physics_step(e, cfg, motor, jt);
-        if (termination(e)) break;
+        if (termination_cfg(e, cfg)) break;
         e->counter += 1;
     }
-    { double reward = reward_fn(e, cfg); *done = termination(e); return reward; }
+    { double reward = reward_fn(e, cfg); *done = termination_cfg(e, cfg); return reward; }
 }
+
+static int g_moving = 0;
+/* selects KukaMovingButtonGymEnv semantics for the following calls (tests are single-threaded callers) */
+void kuka_oracle_set_moving(int moving) { g_moving = moving; }
 
 /* ------------------------------------------------------------------ batch entry points */
 /* Rollout of n envs, T steps each, auto-reset (VecEnv worker semantics).
@@ -517,7 +532,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
     const int od = obs_mode == 1 ? 14 : obs_mode == 2 ? 17 : 3, adim = is_discrete ? 1 : action_joints ? 7 : 3;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
-    cfg.max_distance = max_distance;
+    cfg.max_distance = max_distance; cfg.moving = g_moving;
     settle(&settled, &cfg);
 #pragma omp parallel for schedule(dynamic, 4)
     for (e = 0; e < n; e++) {
@@ -557,6 +572,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             for (j = 0; j < N; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
             f[14] = env.ee_target[0]; f[15] = env.ee_target[1]; f[16] = env.ee_target[2]; f[17] = env.bq; f[18] = env.bqd;
             f[19] = env.counter; f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.button_pos[2];
+            if (cfg.moving) f[23] = env.button_pos[1];
         }
         if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
         free(r);
@@ -591,9 +607,9 @@ void kuka_oracle_wrapper_step(double *state8, const double *gripper, const doubl
     e.counter = (int)state8[0]; e.n_contacts = (int)state8[1]; e.n_outside = (int)state8[2]; e.terminated = (int)state8[3];
     memcpy(e.gripper, gripper, sizeof e.gripper); memcpy(e.button_pos, button_pos, sizeof e.button_pos);
     e.contact_button = contact_button; e.contact_table = contact_table;
-    cfg.shape_reward = shape_reward; cfg.is_discrete = is_discrete; cfg.max_distance = max_distance;
-    if (!termination(&e)) e.counter += 1;                         /* step2 loop with action_repeat = 1 */
-    *reward = reward_fn(&e, &cfg); *done = termination(&e);
+    cfg.shape_reward = shape_reward; cfg.is_discrete = is_discrete; cfg.max_distance = max_distance; cfg.moving = g_moving;
+    if (!termination_cfg(&e, &cfg)) e.counter += 1;                  /* step2 loop with action_repeat = 1 */
+    *reward = reward_fn(&e, &cfg); *done = termination_cfg(&e, &cfg);
     state8[0] = e.counter; state8[1] = e.n_contacts; state8[2] = e.n_outside; state8[3] = e.terminated;
 }
 
@@ -604,7 +620,7 @@ int kuka_oracle_command_trace(int is_discrete, int action_joints, int random_tar
                               int mt_key_len, int T, const void *actions, double *ee_trace, double *jt_trace, int *n_reset_cmds) {
     kcfg cfg; kenv settled, env; krng *r = (krng *)malloc(sizeof(krng)); int t, done = 0;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = 0; cfg.action_repeat = 1;
-    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = 0.8;
+    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = 0.8; cfg.moving = g_moving;
     settle(&settled, &cfg);
     r->mode = 2; np_rng_seed_array(&r->mt, mt_key, mt_key_len);
     g_trace_ee = ee_trace; g_trace_jt = jt_trace; g_trace_n = 0;

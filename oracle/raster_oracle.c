@@ -5,7 +5,7 @@
  * MobileRobotGymEnv.render (/root/reference/environments/kuka_gym/kuka_button_gym_env.py:370-420 and
  * the mobile_robot_env.py:282-334 counterpart: computeViewMatrixFromYawPitchRoll(target, dist, yaw,
  * pitch, roll, upAxisIndex=2), computeProjectionMatrixFOV(60, 1, 0.1, 100), 224x224 RGB, row 0 on top),
- * the object poses (reset() of each env) and the colours (urdf/*.urdf, changeVisualShape calls).
+ * the object poses (reset() of each env) and the colours (the urdf files, changeVisualShape calls).
  * What cannot be restated: TinyRenderer itself and the pybullet_data meshes (absent) — PARITY UNPINNED
  * against the reference's pixels; scene = analytic primitives, Lambert + ambient, no shadows.
  * float32 per pixel, compile with -ffp-contract=off. */

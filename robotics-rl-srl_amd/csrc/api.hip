@@ -54,7 +54,7 @@ size_t action_bytes(const Handle *h) {
 }
 size_t obs_bytes_per_env(const Handle *h) {
     if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
-        return (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3);
+        return (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind >= SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3);
     return sizeof(float) * obs_dim_of(h->cfg);
 }
 
@@ -119,7 +119,7 @@ extern "C" {
 int srlhip_abi_version(void) { return SRLHIP_ABI_VERSION; }
 
 int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
-    if (!cfg || env_kind < SRLHIP_ENV_MOBILE || env_kind > SRLHIP_ENV_KUKA_BUTTON) return SRLHIP_EINVAL;
+    if (!cfg || env_kind < SRLHIP_ENV_MOBILE || env_kind > SRLHIP_ENV_KUKA_MOVING) return SRLHIP_EINVAL;
     memset(cfg, 0, sizeof *cfg);
     cfg->struct_size = (int32_t)sizeof *cfg;
     cfg->env_kind = env_kind;
@@ -131,7 +131,7 @@ int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
     cfg->img_h = cfg->img_w = 224;                                  // RENDER_HEIGHT/WIDTH
     cfg->rng_mode = SRLHIP_RNG_MT19937;
     cfg->auto_reset = 1;
-    cfg->max_distance = env_kind == SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
+    cfg->max_distance = env_kind >= SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
     return 0;
 }
 
@@ -147,7 +147,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
         g_create_error = "create: srlhip_config.struct_size mismatch (ABI)"; return SRLHIP_EINVAL;
     }
     if (cfg->num_envs <= 0) { g_create_error = "create: num_envs must be positive"; return SRLHIP_EINVAL; }
-    if (cfg->env_kind < SRLHIP_ENV_MOBILE || cfg->env_kind > SRLHIP_ENV_KUKA_BUTTON) {
+    if (cfg->env_kind < SRLHIP_ENV_MOBILE || cfg->env_kind > SRLHIP_ENV_KUKA_MOVING) {
         g_create_error = "create: unknown env_kind"; return SRLHIP_EINVAL;
     }
     if (cfg->rng_mode < SRLHIP_RNG_HOST || cfg->rng_mode > SRLHIP_RNG_MT19937) {
@@ -168,7 +168,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     if (cfg->obs_mode == SRLHIP_OBS_RAW_PIXELS && (cfg->img_h < 8 || cfg->img_w < 8 || cfg->img_h > 1024 || cfg->img_w > 1024)) {
         g_create_error = "create: img_h / img_w must be in [8, 1024]"; return SRLHIP_EINVAL;
     }
-    if (cfg->env_kind == SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
+    if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
         g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;
     }
     hipError_t e = hipSetDevice(cfg->device_id);
@@ -408,7 +408,7 @@ int srlhip_render(srlhip_handle hh, void *img_out) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     if (rc) return rc;
-    const size_t bytes = (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3) * h->n;
+    const size_t bytes = (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind >= SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3) * h->n;
     void *d_img = img_out;
     if (!h->cfg.io_device) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, bytes))) return rc; d_img = h->st_obs; }
     if ((rc = raster_render(h, d_img))) return rc;

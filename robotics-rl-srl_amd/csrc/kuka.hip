@@ -16,10 +16,10 @@ namespace srl {
 using namespace kuka;
 
 constexpr int kWave = 64;
-constexpr int NDBL = 41, NINT = 7;
+constexpr int NDBL = 43, NINT = 7;
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
-enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38 };
+enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42 };
 // SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
 enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6 };
 
@@ -44,6 +44,7 @@ __device__ __forceinline__ void load_env(const KukaState &s, int64_t n, int64_t 
 #pragma unroll
     for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
     v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
+    v.bz = s.d[D_BZ * n + e]; v.bspeed = s.d[D_BSPEED * n + e];
     v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
     v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
     v.terminated = s.i[I_TERM * n + e];
@@ -57,6 +58,7 @@ __device__ __forceinline__ void store_env(const KukaState &s, int64_t n, int64_t
 #pragma unroll
     for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
     s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
+    s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
     s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
     s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
     s.i[I_TERM * n + e] = v.terminated;
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(kWave) kuka_starts_k(KukaParams p, KukaState s
     Scratch sc = make_scratch(s, p.n, 0);
     Env e;
     unpack_start(e, s.settled);
-    e.bx = kButtonX; e.by = kButtonY; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    e.bx = kButtonX; e.by = kButtonY; e.bz = kButtonBaseZ; e.bspeed = 0.0; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
     e.bpos[0] = e.bpos[1] = e.bpos[2] = 0.0;
     const int base = p.cfg.is_discrete ? 6 : 2;
@@ -216,6 +218,8 @@ KukaParams params_of(const Handle *h) {
     p.cfg.random_target = c.random_target; p.cfg.force_down = c.force_down; p.cfg.shape_reward = c.shape_reward;
     p.cfg.action_repeat = c.action_repeat; p.cfg.is_discrete = c.is_discrete; p.cfg.action_joints = c.action_joints;
     p.cfg.obs_mode = c.obs_mode; p.cfg.auto_reset = c.auto_reset; p.cfg.max_distance = c.max_distance;
+    p.cfg.moving = c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0;
+    p.cfg.max_steps = p.cfg.moving ? 1500 : kMaxSteps;
     p.n = h->n;
     return p;
 }
@@ -307,11 +311,11 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by; int64_t n; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz; int64_t n; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
-    v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n;
+    v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n; v->bz = s->d + D_BZ * n;
     v->n = (int64_t)n;
 }
 

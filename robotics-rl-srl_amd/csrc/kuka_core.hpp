@@ -119,7 +119,8 @@ struct Env {
     double sq[ND], cq[ND];     // sin/cos of q (cached: one sincos per joint per physics step)
     double ee[3];              // Kuka.end_effector_pos (IK target accumulator)
     double bq, bqd;            // button glider
-    double bx, by;             // button base xy
+    double bx, by, bz;         // button base position (bz moves only in the MovingButton env)
+    double bspeed;             // MovingButton: signed y increment per step
     double bpos[3];            // button_pos (target point: cap + 0.28)
     double grip[3];            // getArmPos() after the last physics step
     int32_t motor_on;          // button motor: 0 pybullet default velocity motor, 1 position target (step2)
@@ -129,6 +130,7 @@ struct Env {
 
 struct Cfg {
     int32_t random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, obs_mode, auto_reset;
+    int32_t moving, max_steps;  // KukaMovingButtonGymEnv: moving = 1, max_steps = 1500
     double max_distance;
 };
 
@@ -573,7 +575,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     double cc[kNSphere][3];
 #pragma unroll
     for (int s = 0; s < kNSphere; s++) tip_point(R, p, kSphere[s], cc[s]);
-    const double cap_z0 = kButtonBaseZ + kGliderOriginZ + e.bq;
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
     // motor targets need q, qd before the velocity update; keep what is needed
     double target[ND];
 #pragma unroll
@@ -647,7 +649,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             double n[3];
             const double dist = shape == 0
                 ? sphere_cylinder(cc[s], rad, e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n)
-                : sphere_cylinder(cc[s], rad, e.bx, e.by, kBaseRadius, kButtonBaseZ, kButtonBaseZ + kBaseHeight, n);
+                : sphere_cylinder(cc[s], rad, e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n);
             if (!(dist < kContactThreshold)) continue;
             if (shape == 0) e.contact_button = 1;
             double pt[3], J[ND];

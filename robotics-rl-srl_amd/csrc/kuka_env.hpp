@@ -41,7 +41,7 @@ SRL_HD void initial_env(Env &e) {
     for (int i = 0; i < ND; i++) { e.q[i] = kJointPositions[i]; e.qd[i] = 0.0; }
 #pragma unroll
     for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
-    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY;
+    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = kButtonBaseZ; e.bspeed = 0.0;
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
     update_trig_and_gripper(e);
@@ -65,7 +65,7 @@ SRL_HD double norm3(const double a[3], const double b[3]) {      // np.linalg.no
     const double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
     return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
 }
-SRL_HD bool termination(const Env &e) { return e.terminated || e.counter > kMaxSteps; }
+SRL_HD bool termination(const Env &e, const Cfg &cfg) { return e.terminated || e.counter > cfg.max_steps; }
 
 SRL_HD double reward_fn(Env &e, const Cfg &cfg) {
     const double distance = norm3(e.bpos, e.grip);
@@ -75,7 +75,7 @@ SRL_HD double reward_fn(Env &e, const Cfg &cfg) {
     else e.n_outside = 0;
     if (e.contact_table || e.n_contacts >= kNContactsBeforeTermination || e.n_outside >= kNStepsOutside) e.terminated = 1;
     if (cfg.shape_reward) {
-        if (cfg.is_discrete) return -distance;
+        if (cfg.is_discrete && !cfg.moving) return -distance;     // MovingButton: 50 / -250 / -d for every action type
         if (e.terminated && reward > 0) return 50.0;
         if (e.terminated && reward < 0) return -250.0;
         return -distance;
@@ -95,12 +95,13 @@ struct HostDraws {
 // KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.
 template <class R>
 SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const double *starts, const double *settled) {
-    double bx = kButtonX, by = kButtonY;
+    double bx = kButtonX, by = kButtonY, speed = 0.0;
+    if (cfg.moving) speed = 0.001 * (rng.bounded(1) ? 1.0 : -1.0);   // BUTTON_SPEED * np_random.choice([-1, 1]), drawn first
     if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     if (!cfg.is_discrete && cfg.action_joints) {
         unpack_start(e, settled);
-        e.bx = bx; e.by = by;
+        e.bx = bx; e.by = by; e.bz = kButtonBaseZ;
         // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1) per init action,
         // broadcast over the joints.  All five are drawn before the physics steps.
         double g[kNInitActions];
@@ -130,6 +131,7 @@ SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const d
         unpack_start(e, starts + (int64_t)idx * kStartDoubles);
         e.bx = bx; e.by = by;
     }
+    e.bz = kButtonBaseZ; e.bspeed = speed;
     e.bpos[0] = bx; e.bpos[1] = by;
     e.bpos[2] = kButtonBaseZ + kGliderOriginZ + e.bq + kButtonDistanceHeight;
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
@@ -148,6 +150,12 @@ template <class R>
 SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int action, const float *ca, bool *done) {
     double motor[3] = {0, 0, 0}, joints[ND];
     bool joint_mode = false;
+    if (cfg.moving) {                                            // kuka_moving_button_gym_env.py:111-119
+        if (e.bpos[1] > 0.3 || e.bpos[1] < -0.3) e.bspeed = -e.bspeed;
+        e.bpos[1] += e.bspeed;
+        e.by = e.bpos[1];
+        e.bz = e.bpos[2] - kButtonDistanceHeight;                // base re-placed at the recorded cap height
+    }
 #pragma unroll
     for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j];
     if (action < 0) {
@@ -170,11 +178,11 @@ SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int ac
     e.motor_on = 1;
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
         physics_step(e, cfg, sc, motor, joint_mode, joints);
-        if (termination(e)) break;
+        if (termination(e, cfg)) break;
         e.counter += 1;
     }
     const double reward = reward_fn(e, cfg);
-    *done = termination(e);
+    *done = termination(e, cfg);
     return reward;
 }
 

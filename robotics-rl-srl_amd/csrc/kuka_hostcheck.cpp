@@ -15,6 +15,7 @@ using namespace srl;
 using namespace srl::kuka;
 
 namespace {
+int g_moving = 0;
 struct MtHost {     // host-side generator over a private SoA view with stride 1
     std::vector<uint32_t> words;
     int32_t mti, has_g; double g;
@@ -105,7 +106,7 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
         double *f = final_state + 24 * (size_t)e_idx;
         for (int j = 0; j < ND; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
         f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
-        f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.bpos[2];
+        f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
     }
     if (ep_stats) { ep_stats[3 * (size_t)e_idx] = last_ret; ep_stats[3 * (size_t)e_idx + 1] = last_len; ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
 }
@@ -123,6 +124,7 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
+    cfg.moving = g_moving; cfg.max_steps = g_moving ? 1500 : kMaxSteps;
     std::vector<double> settled, starts;
     build_tables(cfg, settled, starts);
     for (int e = 0; e < n; e++) {
@@ -138,6 +140,8 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     return 0;
 }
 
+extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; }
+
 extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, double *out22) {
     Cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.random_target = random_target; cfg.action_joints = action_joints; cfg.action_repeat = 1; cfg.is_discrete = 1;
@@ -150,7 +154,7 @@ extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, dou
         Env e; initial_env(e);
         const double zero[3] = {0, 0, 0}; double jt[ND];
         for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
-        cfg.is_discrete = 1; cfg.action_joints = action_joints;
+        cfg.is_discrete = 1; cfg.action_joints = action_joints; cfg.moving = 0; cfg.max_steps = kMaxSteps;
         for (int i = 0; i < kNSettleSteps; i++) physics_step(e, cfg, sc, zero, action_joints != 0, jt);
         for (int j = 0; j < ND; j++) { out22[j] = e.q[j]; out22[7 + j] = e.qd[j]; }
         out22[14] = e.ee[0]; out22[15] = e.ee[1]; out22[16] = e.ee[2]; out22[17] = e.bq; out22[18] = e.bqd;

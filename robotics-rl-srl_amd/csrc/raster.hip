@@ -23,7 +23,7 @@
 namespace srl {
 
 // KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by; int64_t n; };     // sq/cq: [7][n]
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz; int64_t n; };     // sq/cq: [7][n]
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
@@ -193,11 +193,11 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
 #define SRL_FK(I) { fk_forward<I>(R, p, v.sq[(I) * n + e], v.cq[(I) * n + e]); jp[I][0] = (float)p[0]; jp[I][1] = (float)p[1]; jp[I][2] = (float)p[2]; }
     SRL_FK(0) SRL_FK(1) SRL_FK(2) SRL_FK(3) SRL_FK(4) SRL_FK(5) SRL_FK(6)
 #undef SRL_FK
-    const float bx = (float)v.bx[e], by = (float)v.by[e], cap_z = (float)(kButtonBaseZ + kGliderOriginZ + v.bq[e]);
+    const float bx = (float)v.bx[e], by = (float)v.by[e], cap_z = (float)(v.bz[e] + kGliderOriginZ + v.bq[e]);
     int k = 0;
     set_prim(prims[k++], PRIM_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
     set_prim(prims[k++], PRIM_BOX, 0.55f, 0.35f, 0.20f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);     // table top
-    set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, bx, by, (float)kButtonBaseZ, 0.10f, 0, 0.03f, 0, 1, 0);         // button base
+    set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, bx, by, (float)v.bz[e], 0.10f, 0, 0.03f, 0, 1, 0);              // button base
     set_prim(prims[k++], PRIM_CYL, 1.0f, 1.0f, 0.0f, bx, by, cap_z, 0.09f, 0, 0.03f, 0, 1, 0);                       // button cap
     set_prim(prims[k++], PRIM_CAPSULE, 0.35f, 0.35f, 0.38f, (float)kBasePos[0], (float)kBasePos[1], (float)kBasePos[2],
              jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
@@ -251,7 +251,7 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
     const int e = blockIdx.x, cam = blockIdx.y;
     if (threadIdx.x == 0)
-        nprims = rp.kind == SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
+        nprims = rp.kind >= SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
     __syncthreads();
     const Camera c = rp.cam[cam];
     const int npix = rp.h * rp.w;
@@ -317,11 +317,11 @@ int raster_render(Handle *h, void *d_img) {
     RasterParams rp;
     const srlhip_config &c = h->cfg;
     rp.kind = c.env_kind; rp.n = h->n; rp.h = c.img_h; rp.w = c.img_w;
-    rp.ncam = (c.env_kind == SRLHIP_ENV_KUKA_BUTTON && c.multi_view) ? 2 : 1;
+    rp.ncam = (c.env_kind >= SRLHIP_ENV_KUKA_BUTTON && c.multi_view) ? 2 : 1;
     rp.channels = 3 * rp.ncam;
     RasterKukaView kv = {};
     RasterMobileView mv = {};
-    if (c.env_kind == SRLHIP_ENV_KUKA_BUTTON) {
+    if (c.env_kind >= SRLHIP_ENV_KUKA_BUTTON) {
         const double t1[3] = {0.316, -0.2, -0.1}, t2[3] = {0.316, 0.316, -0.105};
         rp.cam[0] = make_camera(t1, 1.1, 145, -36, 0, 60);        // kuka_button_gym_env.py:94-102
         rp.cam[1] = make_camera(t2, 1.05, 32, -13, 0, 60);        // :403-409 (multi_view)

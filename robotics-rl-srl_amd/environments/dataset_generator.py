@@ -39,7 +39,7 @@ class _BatchState(object):
     """Host view of the per-env quantities the recorder needs."""
 
     def __init__(self, handle, env_cls):
-        self.h, self.kuka = handle, handle.cfg.env_kind == _lib.ENV_KUKA_BUTTON
+        self.h, self.kuka = handle, handle.cfg.env_kind >= _lib.ENV_KUKA_BUTTON
         self.kind = handle.cfg.env_kind
 
     def ground_truth_and_target(self):
@@ -66,6 +66,7 @@ def run_batched(args):
     cfg.shape_reward, cfg.force_down, cfg.multi_view = int(args.shape_reward), 1, int(args.multi_view)
     cfg.max_distance = args.max_distance
     cfg.obs_mode, cfg.rng_mode, cfg.auto_reset = _lib.OBS_GROUND_TRUTH, _lib.RNG_MT19937, 0
+    cfg.img_h = cfg.img_w = args.img_size                       # frames come from srlhip_render (tile rasteriser)
     h = _lib.Handle(cfg)
     view = _BatchState(h, env_cls)
     partition = n > 1
@@ -91,8 +92,9 @@ def run_batched(args):
         h.reset(mask=mask.astype(np.uint8), obs_out=np.zeros((n, h.obs_dim), np.float32))
         if savers is not None:
             gt, tgt = view.ground_truth_and_target()
+            frames_rgb = h.render()
             for i in np.nonzero(mask)[0]:
-                savers[i].reset(None, tgt[i], gt[i])
+                savers[i].reset(frames_rgb[i], tgt[i], gt[i])
         t_ep[mask] = 0
 
     start_episodes(active.copy())
@@ -113,10 +115,11 @@ def run_batched(args):
         if savers is not None:
             gt, _ = view.ground_truth_and_target()
             rew = h.get_state(_lib.F_LAST_REWARD)
+            frames_rgb = h.render()
             for i in np.nonzero(active)[0]:
                 r = float(rew[i]) if args.shape_reward else int(rew[i])
                 a = int(actions[i]) if cfg.is_discrete else actions[i]
-                savers[i].step(None, a, r, bool(done[i]), gt[i])
+                savers[i].step(frames_rgb[i], a, r, bool(done[i]), gt[i])
         if done.any():
             for i in np.nonzero(done)[0]:
                 print("Episode finished after {} timesteps".format(t_ep[i] + 1))
@@ -153,6 +156,7 @@ _FLAGS = [
     (("--ppo2-timesteps",), dict(type=int, default=1000)),
     (("--toward-target-timesteps-proportion",), dict(type=float, default=0.0)),
     (("--device-id",), dict(type=int, default=0, help="HIP device ordinal")),
+    (("--img-size",), dict(type=int, default=224, help="recorded frame size (reference: 224)")),
 ]
 
 

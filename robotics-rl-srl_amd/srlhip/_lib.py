@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsrlhip.so")
 
 # ---- constants mirrored from include/srlhip.h --------------------------------
-ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON = range(5)
+ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON, ENV_KUKA_MOVING = range(6)
 OBS_GROUND_TRUTH, OBS_JOINTS, OBS_JOINTS_POSITION, OBS_RAW_PIXELS = range(4)
 RNG_HOST, RNG_PHILOX, RNG_MT19937 = range(3)
 F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REWARD, F_EP_RETURN, F_EP_LENGTH = range(9)
@@ -146,7 +146,7 @@ class Handle(object):
         n = self.num_envs
         lead = (n,) if T is None else (T, n)
         if self.cfg.obs_mode == OBS_RAW_PIXELS:
-            ch = 6 if (self.cfg.multi_view and self.cfg.env_kind == ENV_KUKA_BUTTON) else 3
+            ch = 6 if (self.cfg.multi_view and self.cfg.env_kind >= ENV_KUKA_BUTTON) else 3
             return np.zeros(lead + (self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         return np.zeros(lead + (self.obs_dim,), np.float32)
 
@@ -234,7 +234,7 @@ class Handle(object):
         if self.cfg.io_device:
             self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
             return out
-        ch = 6 if (self.cfg.multi_view and self.cfg.env_kind == ENV_KUKA_BUTTON) else 3
+        ch = 6 if (self.cfg.multi_view and self.cfg.env_kind >= ENV_KUKA_BUTTON) else 3
         if out is None:
             out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")

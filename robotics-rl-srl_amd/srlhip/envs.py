@@ -393,8 +393,18 @@ class KukaButtonGymEnv(_HipEnv):
         return np.array(obs), reward, done, {}
 
 
+class KukaMovingButtonGymEnv(KukaButtonGymEnv):
+    """environments/kuka_gym/kuka_moving_button_gym_env.py:KukaMovingButtonGymEnv"""
+    ENV_KIND = _lib.ENV_KUKA_MOVING
+
+    def __init__(self, name="kuka_moving_button_gym", **kwargs):
+        super(KukaMovingButtonGymEnv, self).__init__(name=name, **kwargs)
+        self.max_steps = 1500
+
+
 ENV_CLASSES = {
     "KukaButtonGymEnv-v0": KukaButtonGymEnv,
+    "KukaMovingButtonGymEnv-v0": KukaMovingButtonGymEnv,
     "MobileRobotGymEnv-v0": MobileRobotGymEnv,
     "MobileRobot2TargetGymEnv-v0": MobileRobot2TargetGymEnv,
     "MobileRobot1DGymEnv-v0": MobileRobot1DGymEnv,

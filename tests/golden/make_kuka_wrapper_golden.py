@@ -110,6 +110,7 @@ def make_scripted_pybullet():
 _reference_stubs.install(make_scripted_pybullet())
 
 from environments.kuka_gym.kuka_button_gym_env import KukaButtonGymEnv  # noqa: E402
+from environments.kuka_gym.kuka_moving_button_gym_env import KukaMovingButtonGymEnv  # noqa: E402
 
 T = 1030          # crosses the 1001-step time limit
 
@@ -189,8 +190,44 @@ def reward_case(seed, shape_reward, is_discrete, max_distance):
     return out
 
 
+def moving_case(seed, shape_reward, random_target):
+    """KukaMovingButtonGymEnv: direction draw, moving target, IK targets, reward branch, 1500-step limit."""
+    env = KukaMovingButtonGymEnv(srl_model="ground_truth", shape_reward=shape_reward, random_target=random_target)
+    env.seed(seed)
+    srng = np.random.RandomState(99 + seed)
+    n = 1560
+    SCRIPT.reset(None, None, None)
+    env.reset()
+    speed0 = env.button_speed
+    reset_ik = np.array(SCRIPT.ik_targets[-5:])
+    grip = np.array([0.5, 0.0, 0.09]) + srng.normal(0, 0.3, size=(n + 10, 3))
+    cb = srng.rand(n + 10) < 0.002
+    ct = np.zeros(n + 10, bool)
+    SCRIPT.gripper, SCRIPT.contact_button, SCRIPT.contact_table = grip, cb, ct
+    SCRIPT.n_sim = 0
+    actions = srng.randint(0, 4, size=n)                  # x / y moves only
+    rec = {k: [] for k in ("reward", "done", "button_y", "ik", "sim_idx", "n_contacts")}
+    for t in range(n):
+        SCRIPT.ik_targets = []
+        _, r, d, _ = env.step(int(actions[t]))
+        rec["reward"].append(float(r)); rec["done"].append(bool(d)); rec["button_y"].append(float(env.button_pos[1]))
+        rec["ik"].append(SCRIPT.ik_targets[-1] if SCRIPT.ik_targets else np.full(3, np.nan))
+        rec["sim_idx"].append(SCRIPT.idx()); rec["n_contacts"].append(env.n_contacts)
+        if d:
+            break
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(speed0=speed0, reset_ik=reset_ik, actions=actions, gripper=grip, contact_button=cb,
+               button_pos0=np.array([env.button_pos[0], 0.0, env.button_pos[2]]), n_steps=len(rec["done"]))
+    return out
+
+
 def main():
     out = {}
+    for seed in (0, 1, 2, 3):
+        for shape_reward in (False, True):
+            tag = "mov|s{}|sr{}|rt{}".format(seed, int(shape_reward), seed % 2)
+            for k, v in moving_case(seed, shape_reward, bool(seed % 2)).items():
+                out[tag + "|" + k] = v
     for seed in (0, 1, 2):
         for mode in ("discrete", "continuous", "joints"):
             for random_target in (False, True):

@@ -22,6 +22,10 @@ def lib():
     return _lib
 
 
+def set_moving(flag):
+    lib().hostcheck_kuka_set_moving(int(bool(flag)))
+
+
 def rollout(seeds, T, actions=None, **kw):
     """Same arguments / outputs as oracle.kuka_clib.rollout, computed by the kernel source on the host."""
     fake = types.SimpleNamespace(kuka_oracle_rollout=lib().hostcheck_kuka_rollout)

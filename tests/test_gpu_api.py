@@ -105,10 +105,14 @@ def test_dataset_generator_cli(tmp_path):
     common = ["--num-cpu", "4", "--num-episode", "8", "--save-path", root, "--env", "MobileRobotGymEnv-v0", "--seed", "1"]
     dg.main(common + ["--name", "mob", "--no-record-data"])
     assert not os.path.exists(root + "mob")
-    dg.main(common + ["--name", "mob", "--force", "--reward-dist"])
+    dg.main(common + ["--name", "mob", "--force", "--reward-dist", "--img-size", "64"])
     assert sorted(os.listdir(root + "mob"))[:4] == ["dataset_config.json", "env_globals.json", "ground_truth.npz", "preprocessed_data.npz"]
     gt, pp = np.load(root + "mob/ground_truth.npz"), np.load(root + "mob/preprocessed_data.npz")
     assert len(pp["rewards"]) == 8 * 251 and pp["episode_starts"].sum() == 8 and gt["target_positions"].shape == (8, 2)
+    from PIL import Image
+    frame = np.asarray(Image.open(root + str(gt["images_path"][5]) + ".jpg"))
+    assert frame.shape == (64, 64, 3) and frame.std() > 10            # a rendered arena, written as JPEG
+    assert len(os.listdir(root + "mob/record_000")) == 251
     # episode k of the merged dataset == oracle episode seeded base+k with the action-space stream of the same seed
     base = np.random.RandomState(1).randint(int(1e10))
     for k in (0, 3, 7):
@@ -126,6 +130,7 @@ def test_dataset_generator_cli(tmp_path):
                 assert np.array_equal(gt["ground_truth_states"][sl][t + 1], env.ground_truth())
     with pytest.raises(AssertionError):
         dg.main(common + ["--name", "mob"])              # exists, no --force
-    dg.main(["--num-cpu", "2", "--num-episode", "3", "--save-path", root, "--name", "kuka", "--env", "KukaButtonGymEnv-v0"])
+    dg.main(["--num-cpu", "2", "--num-episode", "3", "--save-path", root, "--name", "kuka", "--env", "KukaButtonGymEnv-v0",
+             "--img-size", "64"])
     pp = np.load(root + "kuka/preprocessed_data.npz")
     assert pp["episode_starts"].sum() == 3 and set(np.unique(pp["rewards"])) <= {-1, 0, 1}

@@ -194,3 +194,31 @@ def test_state_checkpoint_restore_and_error_paths():
     with pytest.raises(_lib.SrlHipError):
         hst.reset()                                           # RNG_HOST reset without the draws
     a.close(); b.close(); hst.close()
+
+
+def test_moving_button_env():
+    """KukaMovingButtonGymEnv-v0 on the GPU vs the oracle (whose wrapper logic is pinned to the reference source)."""
+    n, T = 128, 1600
+    actions = np.random.RandomState(31).randint(6, size=(T, n)).astype(np.int32)
+    actions[:, :8] = 1                                                  # eight envs run into the 1500-step limit
+    cfg = _lib.default_config(_lib.ENV_KUKA_MOVING)
+    cfg.num_envs, cfg.seed0, cfg.shape_reward = n, 12, 1
+    h = _lib.Handle(cfg)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    kuka_clib.set_moving(True)
+    try:
+        ora = kuka_clib.rollout(12 + np.arange(n), T, actions=actions, shape_reward=True, trace=False)
+    finally:
+        kuka_clib.set_moving(False)
+    check_planes(ora, obs0, out, flags_exact=False)
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)) and length[:8].tolist() == [1501] * 8
+    h.close()
+    from environments.registry import registered_env
+    env = registered_env["KukaMovingButtonGymEnv-v0"][0](srl_model="ground_truth")
+    env.seed(1); env.reset()
+    y0 = env.getTargetPos()[1]
+    env.step(0)
+    assert abs(abs(env.getTargetPos()[1] - y0) - 0.001) < 1e-12 and env.max_steps == 1500
+    env.close()

@@ -64,3 +64,36 @@ def test_reward_and_termination_bookkeeping_matches_reference(golden):
         saw_contact_end |= golden[tag + "|n_contacts"][-1] >= 5
         saw_table_end |= bool(ct[int(sim_idx[-1])])
     assert saw_contact_end or saw_table_end
+
+
+def test_moving_button_wrapper_matches_reference(golden):
+    """KukaMovingButtonGymEnv (kuka_moving_button_gym_env.py): np_random.choice([-1, 1]) is drawn first, the target
+    moves +-1 mm per step and bounces at |y| = 0.3, shaped reward uses the 50 / -250 / -d branch, limit 1500 steps."""
+    cases = tags(golden, "mov|")
+    assert len(cases) == 8
+    kuka_clib.set_moving(True)
+    try:
+        for tag in cases:
+            _, s, sr, rt = tag.split("|")
+            seed, shape_reward, random_target = int(s[1:]), sr == "sr1", rt == "rt1"
+            actions = golden[tag + "|actions"].astype(np.int32)
+            assert int(golden[tag + "|n_steps"]) == 1501
+            tr = kuka_clib.command_trace(seed, 200, actions[:200], random_target=random_target)
+            assert np.array_equal(tr["reset_ee"][-5:], golden[tag + "|reset_ik"]), tag     # pins the draw order
+            assert np.array_equal(tr["ee"][:200], golden[tag + "|ik"][:200]), tag
+            if not random_target:       # button starts at y = 0: the oracle's target must follow the same track
+                T = 40
+                out = kuka_clib.rollout([seed], T, actions=actions[:T].reshape(T, 1), auto_reset=False, trace=False)
+                assert out["final_state"][0, 23] == golden[tag + "|button_y"][T - 1], tag
+            # reward / termination on the scripted physics, with the moving target
+            grip, cb, sim_idx = golden[tag + "|gripper"], golden[tag + "|contact_button"], golden[tag + "|sim_idx"]
+            bp0, by = golden[tag + "|button_pos0"], golden[tag + "|button_y"]
+            state = np.zeros(4)
+            for t in range(len(sim_idx)):
+                k = int(sim_idx[t])
+                state, reward, done = kuka_clib.wrapper_step(state, grip[k], [bp0[0], by[t], bp0[2]], cb[k], False,
+                                                             shape_reward, True, 0.8)
+                assert reward == golden[tag + "|reward"][t] and done == golden[tag + "|done"][t], (tag, t)
+            assert state[0] == 1501
+    finally:
+        kuka_clib.set_moving(False)
