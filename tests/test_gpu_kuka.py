@@ -200,7 +200,7 @@ def test_moving_button_env():
     """KukaMovingButtonGymEnv-v0 on the GPU vs the oracle (whose wrapper logic is pinned to the reference source)."""
     n, T = 128, 1600
     actions = np.random.RandomState(31).randint(6, size=(T, n)).astype(np.int32)
-    actions[:, :8] = 1                                                  # eight envs run into the 1500-step limit
+    actions[:, :8] = -1                                                 # eight idle envs (None action) run into the 1500-step limit
     cfg = _lib.default_config(_lib.ENV_KUKA_MOVING)
     cfg.num_envs, cfg.seed0, cfg.shape_reward = n, 12, 1
     h = _lib.Handle(cfg)

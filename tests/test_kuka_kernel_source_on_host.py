@@ -76,7 +76,7 @@ def test_moving_button_variant():
     move 1 mm per step and bounce at |y| = 0.3, 1500-step limit, shaped reward branch for discrete actions."""
     n, T = 6, 1600
     actions = np.random.RandomState(3).randint(6, size=(T, n)).astype(np.int32)
-    actions[:, 0] = 1                                                  # env 0 only moves in +x: runs into the step limit
+    actions[:, 0] = -1                                                 # env 0 idles (None action): runs into the step limit
     try:
         kuka_clib.set_moving(True); hostcheck.set_moving(True)
         for kw in (dict(), dict(shape_reward=True, random_target=True)):
