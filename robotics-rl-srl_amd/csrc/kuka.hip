@@ -1,7 +1,8 @@
 // kuka.hip — KukaButtonGymEnv stepper kernels for gfx950 (MI355X) and their host plumbing.
 //
 // Launch geometry: one lane per env, 64-lane workgroups (one wavefront), per-link ABA
-// staging and the generic constraint rows in LDS ([slot][lane], 112 KiB per workgroup),
+// staging + the first two constraint rows in LDS ([slot][lane], 70 KiB per workgroup -> 2 per CU), further rows in an
+// L2-resident scratch,
 // state structure-of-arrays in HBM (env index fastest: a wavefront's loads and
 // stores of a field are one coalesced 512-byte row).  kuka_rollout_k keeps the
 // whole env state in VGPRs for T steps and streams the [T][N] observation /
@@ -26,6 +27,7 @@ enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 
 struct KukaState {
     double *d;          // [NDBL][n]
     int32_t *i;         // [NINT][n]
+    double *rows;       // [SC_ROWS_TOTAL][n]  generic constraint rows (global scratch, L2-resident)
     double *settled;    // [kStartDoubles]
     double *starts;     // [nstarts][kStartDoubles]
     int32_t nstarts;
@@ -91,14 +93,14 @@ extern __shared__ double kuka_lds[];
 
 __device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, int64_t e) {
     Scratch sc;
-    sc.b = kuka_lds + threadIdx.x; sc.st = kWave;
+    sc.b = kuka_lds + threadIdx.x; sc.st = kWave; sc.g = s.rows + e; sc.gst = n;
     return sc;
 }
 
 // 500 settle steps (kuka_button_gym_env.py:242-247).  Every lane integrates the same env so that
 // wave-level votes stay uniform; lane 0 publishes.
 __global__ void __launch_bounds__(kWave) kuka_settle_k(KukaParams p, KukaState s) {
-    Scratch sc = make_scratch(s, p.n, 0);
+    Scratch sc = make_scratch(s, p.n, threadIdx.x % p.n);
     Env e;
     initial_env(e);
     const double zero[3] = {0, 0, 0};
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(kWave) kuka_settle_k(KukaParams p, KukaState s
 __global__ void __launch_bounds__(kWave) kuka_starts_k(KukaParams p, KukaState s) {
     const int idx = blockIdx.x * kWave + threadIdx.x;
     if (idx >= s.nstarts) return;
-    Scratch sc = make_scratch(s, p.n, 0);
+    Scratch sc = make_scratch(s, p.n, idx % p.n);     // start states are limit- and contact-free: rows are never touched
     Env e;
     unpack_start(e, s.settled);
     e.bx = kButtonX; e.by = kButtonY; e.bz = kButtonBaseZ; e.bspeed = 0.0; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
@@ -243,7 +245,7 @@ int kuka_alloc(Handle *h) {
     const size_t n = (size_t)h->n;
     int rc;
     s->nstarts = (!h->cfg.is_discrete && h->cfg.action_joints) ? 0 : h->cfg.is_discrete ? kNumStartsDiscrete : kNumStartsContinuous;
-    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) ||
+    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
     if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k)) ||

@@ -95,16 +95,22 @@ constexpr int SC_P = 21;             // p_i      [7][3]
 constexpr int SC_U = 42;             // U_i      [7][6]
 constexpr int SC_DINV = 84;          // 1/d_i    [7]
 constexpr int SC_UU = 91;            // u_i      [7]
-constexpr int SC_ROW = 98;           // generic rows [kMaxGenRows][21]: J7 WJ7 Jb WJb Dinv rhs lo hi applied
+constexpr int SC_STAGE = 98;         // end of the per-link staging
+// generic rows [kMaxGenRows][21]: J7 WJ7 Jb WJb Dinv rhs lo hi applied
+constexpr int kLdsRows = 2;
 constexpr int ROW_J = 0, ROW_WJ = 7, ROW_JB = 14, ROW_WJB = 15, ROW_DINV = 16, ROW_RHS = 17, ROW_LO = 18,
               ROW_HI = 19, ROW_APP = 20, ROW_STRIDE = 21;
-constexpr int SC_TOTAL = SC_ROW + kMaxGenRows * ROW_STRIDE;   // 224 doubles = 1792 B of LDS per env (112 KiB / workgroup)
+constexpr int SC_TOTAL = SC_STAGE + kLdsRows * ROW_STRIDE;   // 140 doubles = 1120 B of LDS per env (70 KiB / workgroup, 2 per CU)
+constexpr int SC_ROWS_TOTAL = kMaxGenRows * ROW_STRIDE;      // 126 doubles of global scratch per env (rows 2.. used)
 
 struct Scratch {
-    double *b;       // LDS base of this lane, [slot][lane]
+    double *b;       // LDS base of this lane, [slot][lane]: per-link ABA staging
     int st;
+    double *g;       // HBM (L2-resident) base of this env, [slot][env]: generic constraint rows.  They are written once
+    int64_t gst;     // per physics step; the first two rows of a lane are then held in VGPRs for all 150 sweeps.
     SRL_HD double &at(int i) const { return b[(int64_t)i * st]; }
-    SRL_HD double &row(int i) const { return b[(int64_t)(SC_ROW + i) * st]; }
+    // rows 0 and 1 (the common contact case) are staged in LDS, rows 2.. in the global scratch
+    SRL_HD double &row(int i) const { return i < kLdsRows * ROW_STRIDE ? b[(int64_t)(SC_STAGE + i) * st] : g[(int64_t)i * gst]; }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -40,8 +40,8 @@ struct PhHost {
 };
 
 void build_tables(const Cfg &cfg, std::vector<double> &settled, std::vector<double> &starts) {
-    std::vector<double> scratch(SC_TOTAL);
-    Scratch sc{scratch.data(), 1};
+    std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
+    Scratch sc{scratch.data(), 1, rows.data(), 1};
     Env e;
     initial_env(e);
     const double zero[3] = {0, 0, 0};
@@ -65,8 +65,8 @@ template <class R>
 void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const void *actions, const double *settled,
              const double *starts, float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out, void *act_out,
              double *q_trace, double *grip_trace, double *final_state, double *ep_stats) {
-    std::vector<double> scratch(SC_TOTAL);
-    Scratch sc{scratch.data(), 1};
+    std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
+    Scratch sc{scratch.data(), 1, rows.data(), 1};
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
     Env env;
@@ -149,8 +149,8 @@ extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, dou
     cfg.is_discrete = 0; cfg.action_joints = 1;        // skip the start table
     cfg.action_joints = action_joints ? 1 : 1;
     {   // settle only
-        std::vector<double> scratch(SC_TOTAL);
-        Scratch sc{scratch.data(), 1};
+        std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
+        Scratch sc{scratch.data(), 1, rows.data(), 1};
         Env e; initial_env(e);
         const double zero[3] = {0, 0, 0}; double jt[ND];
         for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
