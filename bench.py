@@ -172,9 +172,12 @@ def main():
 
     from srlhip import sharding
     rank, local_rank, world = sharding.dist_env()
+    backend = os.environ.get("SRLHIP_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI on ROCm
+    if os.environ.get("SRLHIP_SINGLE_DEVICE"):                # dry run of the N>1 path on a 1-GPU box (gloo)
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        sharding.init_process_group("nccl", local_rank)       # "nccl" == RCCL over xGMI on ROCm
+        sharding.init_process_group(backend, local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

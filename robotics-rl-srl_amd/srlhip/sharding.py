@@ -31,6 +31,11 @@ def init_process_group(backend, local_rank=0):
         dist.init_process_group(backend)
 
 
+def _via_cpu():
+    import torch.distributed as dist
+    return dist.get_backend() == "gloo"
+
+
 def gather_episode_returns(local_returns, out=None):
     """All-gather of float32[n_local] -> float32[world * n_local], rank-major == global env id order.
     128 KiB at 8 x 4096 envs: latency bound, so it is issued once per rollout, never per step."""
@@ -41,6 +46,11 @@ def gather_episode_returns(local_returns, out=None):
     world = dist.get_world_size()
     if out is None:
         out = torch.empty((world * local_returns.numel(),), dtype=local_returns.dtype, device=local_returns.device)
+    if _via_cpu() and local_returns.is_cuda:       # CPU-side collective (tests / single-GPU dry runs of the N>1 path)
+        tmp = torch.empty((world * local_returns.numel(),), dtype=local_returns.dtype)
+        dist.all_gather_into_tensor(tmp, local_returns.detach().cpu().contiguous())
+        out.copy_(tmp)
+        return out
     dist.all_gather_into_tensor(out, local_returns.contiguous())
     return out
 
@@ -50,6 +60,6 @@ def max_over_ranks(seconds, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=None if _via_cpu() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
