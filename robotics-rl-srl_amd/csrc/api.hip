@@ -42,6 +42,14 @@ int ensure(Handle *h, void **buf, size_t *cap, size_t bytes) {
     *cap = bytes;
     return 0;
 }
+int ensure_pinned(Handle *h, void **buf, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    SRL_HIP_CHECK(h, hipHostMalloc(buf, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return 0;
+}
 int stage_in(Handle *h, void **buf, size_t *cap, const void *host, size_t bytes) {
     int rc = ensure(h, buf, cap, bytes);
     if (rc) return rc;
@@ -181,6 +189,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     h->cfg = *cfg; h->n = cfg->num_envs; h->kuka = nullptr;
     h->st_actions = h->st_noise = h->st_obs = h->st_rew = h->st_done = h->st_mask = h->st_rand = nullptr;
     h->st_actions_sz = h->st_noise_sz = h->st_obs_sz = h->st_rew_sz = h->st_done_sz = h->st_mask_sz = h->st_rand_sz = 0;
+    h->pin_in = h->pin_out = nullptr; h->pin_in_sz = h->pin_out_sz = 0;
     memset(&h->rng, 0, sizeof h->rng); memset(&h->stats, 0, sizeof h->stats); memset(&h->mobile, 0, sizeof h->mobile);
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; srlhip_destroy(reinterpret_cast<srlhip_handle>(h)); return code; };
@@ -221,6 +230,8 @@ int srlhip_destroy(srlhip_handle hh) {
     for (void *p : h->allocs) (void)hipFree(p);
     void *st[] = {h->st_actions, h->st_noise, h->st_obs, h->st_rew, h->st_done, h->st_mask, h->st_rand};
     for (void *p : st) if (p) (void)hipFree(p);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -297,17 +308,23 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
         return h->fail(SRLHIP_EINVAL, "step: RNG_HOST needs host_noise");
     const void *d_act = actions; const double *d_noise = host_noise;
     void *d_obs = obs_out; float *d_rew = reward_out; uint8_t *d_done = done_out;
-    const size_t ob = obs_bytes_per_env(h) * n;
+    const size_t ob = obs_bytes_per_env(h) * n, ab = action_bytes(h);
+    // host-pointer mode: one pinned bounce buffer each way -> one H2D and one D2H transfer per step
+    const size_t in_noise = (ab + 15) & ~(size_t)15, in_total = in_noise + sizeof(double) * n;
+    const size_t out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * (size_t)n, out_total = out_done + n;
     if (!h->cfg.io_device) {
-        if ((rc = stage_in(h, &h->st_actions, &h->st_actions_sz, actions, action_bytes(h)))) return rc;
+        if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, out_total)) ||
+            (rc = ensure(h, &h->st_actions, &h->st_actions_sz, in_total)) || (rc = ensure(h, &h->st_obs, &h->st_obs_sz, out_total)))
+            return rc;
+        memcpy(h->pin_in, actions, ab);
+        if (host_noise) memcpy(static_cast<uint8_t *>(h->pin_in) + in_noise, host_noise, sizeof(double) * n);
+        SRL_HIP_CHECK(h, hipMemcpyAsync(h->st_actions, h->pin_in, host_noise ? in_total : ab, hipMemcpyHostToDevice, h->stream));
         d_act = h->st_actions;
-        if (host_noise) {
-            if ((rc = stage_in(h, &h->st_noise, &h->st_noise_sz, host_noise, sizeof(double) * n))) return rc;
-            d_noise = static_cast<const double *>(h->st_noise);
-        }
-        if (obs_out) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, ob))) return rc; d_obs = h->st_obs; }
-        if (reward_out) { if ((rc = ensure(h, &h->st_rew, &h->st_rew_sz, 4 * (size_t)n))) return rc; d_rew = static_cast<float *>(h->st_rew); }
-        if (done_out) { if ((rc = ensure(h, &h->st_done, &h->st_done_sz, n))) return rc; d_done = static_cast<uint8_t *>(h->st_done); }
+        if (host_noise) d_noise = reinterpret_cast<const double *>(static_cast<uint8_t *>(h->st_actions) + in_noise);
+        uint8_t *o = static_cast<uint8_t *>(h->st_obs);
+        d_obs = obs_out ? o : nullptr;
+        d_rew = reinterpret_cast<float *>(o + out_rew);
+        d_done = o + out_done;
     }
     const bool pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
     rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, d_act, d_noise, pixels ? nullptr : static_cast<float *>(d_obs), d_rew, d_done)
@@ -315,10 +332,14 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
     if (rc) return rc;
     if (pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;
     if (!h->cfg.io_device) {
-        if (obs_out) SRL_HIP_CHECK(h, hipMemcpyAsync(obs_out, d_obs, ob, hipMemcpyDeviceToHost, h->stream));
-        if (reward_out) SRL_HIP_CHECK(h, hipMemcpyAsync(reward_out, d_rew, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-        if (done_out) SRL_HIP_CHECK(h, hipMemcpyAsync(done_out, d_done, n, hipMemcpyDeviceToHost, h->stream));
+        const size_t from = obs_out ? 0 : out_rew;
+        SRL_HIP_CHECK(h, hipMemcpyAsync(static_cast<uint8_t *>(h->pin_out) + from, static_cast<uint8_t *>(h->st_obs) + from,
+                                        out_total - from, hipMemcpyDeviceToHost, h->stream));
         SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        const uint8_t *po = static_cast<const uint8_t *>(h->pin_out);
+        if (obs_out) memcpy(obs_out, po, ob);
+        if (reward_out) memcpy(reward_out, po + out_rew, 4 * (size_t)n);
+        if (done_out) memcpy(done_out, po + out_done, n);
     }
     return 0;
 }

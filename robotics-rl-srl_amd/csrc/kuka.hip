@@ -154,7 +154,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kWave)
 kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                float *obs, float *rew, uint8_t *done_out, void *act_out) {
-    const int e = blockIdx.x * kWave + threadIdx.x;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.n) return;
     const int64_t n = p.n;
     const Cfg &cfg = p.cfg;

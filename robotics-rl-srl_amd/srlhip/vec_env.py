@@ -60,6 +60,8 @@ class HipVecEnv(object):
         else:
             self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self._h.obs_dim,), dtype=np.float32)
         self._actions = None
+        self._infos = [{} for _ in range(self.num_envs)]     # reused between steps: one distinct dict per env
+        self._dirty_infos = []
         self._n_finished = np.zeros(self.num_envs, np.int32)
         self._t_start = time.time()
         self._monitors = None
@@ -79,7 +81,10 @@ class HipVecEnv(object):
 
     def step_async(self, actions):
         if self.cfg.is_discrete:
-            self._actions = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
+            if isinstance(actions, np.ndarray) and actions.dtype != object:      # fast path: no `None` entries possible
+                self._actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
+            else:
+                self._actions = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
         else:
             if any(a is None for a in actions):
                 raise NotImplementedError("None actions need a discrete action space")
@@ -88,18 +93,22 @@ class HipVecEnv(object):
     def step_wait(self):
         obs, rew, done = self._h.step(self._actions)
         dones = done.astype(bool)
-        infos = [{} for _ in range(self.num_envs)]
+        for i in self._dirty_infos:                      # entries that carried an 'episode' record last step
+            self._infos[i] = {}
+        self._dirty_infos = []
+        infos = self._infos
         if dones.any():
             ret, length, fin = self._h.episode_stats()
             t = round(time.time() - self._t_start, 6)
             for i in np.nonzero(dones)[0]:
                 ep = {"r": round(float(ret[i]), 6), "l": int(length[i]), "t": t}
-                infos[i]["episode"] = ep
+                infos[i] = {"episode": ep}
+                self._dirty_infos.append(int(i))
                 if self._monitors is not None:
                     self._monitors[i].write("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
                     self._monitors[i].flush()
             self._n_finished = fin
-        return obs, rew.astype(np.float32), dones, infos
+        return obs, rew, dones, list(infos)
 
     def step(self, actions):
         self.step_async(actions)
