@@ -211,9 +211,9 @@ mobile_reset_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, cons
 }
 
 // Synthetic random-agent action (rl_baselines/random_agent.py:36): Philox stream 1.
-__device__ __forceinline__ void sample_action(const MobileParams &p, const RngState &rs, int e, uint64_t &actr,
+__device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0, uint32_t k1, uint64_t &actr,
                                               int &a, float &a0, float &a1) {
-    Philox ph; ph.k0 = rs.key[e]; ph.k1 = rs.key[p.n + e]; ph.ctr = actr; ph.stream = 1;
+    Philox ph; ph.k0 = k0; ph.k1 = k1; ph.ctr = actr; ph.stream = 1;
     if (p.is_discrete) {
         a = (int)ph.bounded(p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u);
     } else {
@@ -226,10 +226,14 @@ __device__ __forceinline__ void sample_action(const MobileParams &p, const RngSt
 
 // One launch == T consecutive VecEnv steps; T == 1 with plain stores is the
 // per-step entry point, T > 1 the fused rollout.
-template <int MODE>
+// GIVEN = actions supplied by the caller; otherwise sampled on the device.  Kept a compile-time switch so that the
+// sampled loop contains no global load at all: a load in the loop would force an s_waitcnt that also drains the
+// streamed output stores of the previous step (vmcnt counts loads and stores together).
+template <int MODE, bool GIVEN>
 __global__ void __launch_bounds__(kBlock)
-mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, const void *actions,
-                 const double *noise, float *obs, float *rew, uint8_t *done_out, void *act_out) {
+mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, const void *__restrict__ actions,
+                 const double *__restrict__ noise, float *__restrict__ obs, float *__restrict__ rew,
+                 uint8_t *__restrict__ done_out, void *__restrict__ act_out) {
     int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.n) return;
     typename RngSel<MODE>::type rng;
@@ -238,16 +242,19 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     load_env(s, e, m);
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
-    uint64_t actr = actions ? 0 : rs.act_ctr[e];
+    uint64_t actr = GIVEN ? 0 : rs.act_ctr[e];
+    // the Philox key is loop invariant: keep it in registers (a per-step reload would have to wait for the
+    // streamed output stores to drain, since the compiler cannot prove they do not alias)
+    const uint32_t key0 = rs.key[e], key1 = rs.key[p.n + e];
     const int adim = p.is_discrete ? 1 : 2;
     for (int t = 0; t < T; t++) {
         const int64_t row = (int64_t)t * p.n + e;
         int a = 0; float a0 = 0.f, a1 = 0.f;
-        if (actions) {
+        if constexpr (GIVEN) {
             if (p.is_discrete) a = static_cast<const int32_t *>(actions)[row];
             else { float2 v = static_cast<const float2 *>(actions)[row]; a0 = v.x; a1 = v.y; }
         } else {
-            sample_action(p, rs, e, actr, a, a0, a1);
+            sample_action(p, key0, key1, actr, a, a0, a1);
             if (act_out) {
                 if (p.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
                 else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
@@ -276,7 +283,7 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     (void)adim;
     store_env(s, e, m);
     rng_store<MODE>(rng, rs, e);
-    if (!actions) rs.act_ctr[e] = actr;
+    if (!GIVEN) rs.act_ctr[e] = actr;
     st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret;
     st.last_length[e] = last_len; st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
@@ -341,12 +348,20 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX:
-            hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_PHILOX>, grid, block, 0, h->stream, p, h->mobile, h->rng,
-                               h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            if (d_actions)
+                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_PHILOX, true>), grid, block, 0, h->stream, p, h->mobile, h->rng,
+                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            else
+                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_PHILOX, false>), grid, block, 0, h->stream, p, h->mobile, h->rng,
+                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
             break;
         case SRLHIP_RNG_MT19937:
-            hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_MT19937>, grid, block, 0, h->stream, p, h->mobile, h->rng,
-                               h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            if (d_actions)
+                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_MT19937, true>), grid, block, 0, h->stream, p, h->mobile, h->rng,
+                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
+            else
+                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_MT19937, false>), grid, block, 0, h->stream, p, h->mobile, h->rng,
+                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
             break;
         default:
             return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
@@ -360,7 +375,7 @@ int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *
     if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return mobile_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
     MobileParams p = params_of(h);
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(mobile_rollout_k<SRLHIP_RNG_HOST>, grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
+    hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, true>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
                        1, d_actions, d_noise, d_obs, d_rew, d_done, (void *)nullptr);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
