@@ -12,8 +12,9 @@
 // analytic primitives (plane, z-rotated box, upright cylinder, capsule) — is built
 // once per workgroup into LDS from the SoA state (for the Kuka: float64 forward
 // kinematics from the cached joint sin/cos), then every lane ray-casts its pixels
-// against the LDS list (nearest hit = z-buffer in registers) and parks 3 bytes per
-// pixel in an LDS tile of 4096 pixels that is flushed with coalesced 16-byte stores:
+// against the primitives whose projected bounding box overlaps its wavefront's 8x8
+// tile (one ballot per tile; nearest hit = z-buffer in registers) and parks 3 bytes per
+// pixel in an LDS band buffer that is flushed with coalesced 16-byte stores:
 // the path's HBM traffic is the 12 288-byte image per env and nothing else.
 // float32 throughout, -ffp-contract=off so that the C oracle (oracle/raster_oracle.c)
 // reproduces the bytes.
@@ -30,7 +31,7 @@ namespace {
 
 constexpr int kRasterBlock = 256;
 constexpr int kMaxPrims = 16;
-constexpr int kTilePixels = 4096;
+constexpr int kTilePixels = 8192;       // LDS band buffer (24 KiB): whole 8-row tile strips, image width <= 1024
 
 enum { PRIM_PLANE = 0, PRIM_BOX = 1, PRIM_CYL = 2, PRIM_CAPSULE = 3 };
 
@@ -216,13 +217,15 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     return k;
 }
 
-__device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, int nprims, const Camera &c, float sx, float sy) {
+__device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask, const Camera &c, float sx, float sy) {
     float dx = c.fx + sx * c.rx + sy * c.ux, dy = c.fy + sx * c.ry + sy * c.uy, dz = c.fz + sx * c.rz + sy * c.uz;
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     dx *= inv; dy *= inv; dz *= inv;
     float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;     // background
     bool hit = false;
-    for (int k = 0; k < nprims; k++) {
+    while (mask) {                                   // wave-uniform list of the primitives that can touch this tile
+        const int k = __builtin_ctzll(mask);
+        mask &= mask - 1;
         const Prim &p = prims[k];
         float nx, ny, nz, t;
         if (p.type == PRIM_PLANE) t = hit_plane(p, c.ez, dz, nx, ny, nz);
@@ -244,26 +247,76 @@ __device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, int nprims, c
     return r8 | (g8 << 8) | (b8 << 16);
 }
 
+// Conservative screen rectangle (tangent-space x = X/Z, y = Y/Z in the camera frame) of a primitive: the eight
+// corners of its world-space bounding box are projected; anything reaching behind the near plane covers the screen.
+__device__ void prim_screen_rect(const Prim &p, const Camera &c, float rect[4]) {
+    float lo[3], hi[3];
+    if (p.type == PRIM_PLANE) { rect[0] = -3.0e38f; rect[1] = 3.0e38f; rect[2] = -3.0e38f; rect[3] = 3.0e38f; return; }
+    if (p.type == PRIM_BOX) {
+        const float hx = fabsf(p.cs) * p.bx + fabsf(p.sn) * p.by, hy = fabsf(p.sn) * p.bx + fabsf(p.cs) * p.by;
+        lo[0] = p.ax - hx; hi[0] = p.ax + hx; lo[1] = p.ay - hy; hi[1] = p.ay + hy; lo[2] = p.az - p.bz; hi[2] = p.az + p.bz;
+    } else if (p.type == PRIM_CYL) {
+        lo[0] = p.ax - p.bx; hi[0] = p.ax + p.bx; lo[1] = p.ay - p.bx; hi[1] = p.ay + p.bx; lo[2] = p.az; hi[2] = p.az + p.bz;
+    } else {
+        lo[0] = fminf(p.ax, p.bx) - p.rad; hi[0] = fmaxf(p.ax, p.bx) + p.rad;
+        lo[1] = fminf(p.ay, p.by) - p.rad; hi[1] = fmaxf(p.ay, p.by) + p.rad;
+        lo[2] = fminf(p.az, p.bz) - p.rad; hi[2] = fmaxf(p.az, p.bz) + p.rad;
+    }
+    const float eps = 1.0e-3f;                      // slack for float rounding of the projection
+    float x0 = 3.0e38f, x1 = -3.0e38f, y0 = 3.0e38f, y1 = -3.0e38f;
+    bool behind = false;
+    for (int k = 0; k < 8; k++) {
+        const float wx = ((k & 1) ? hi[0] : lo[0]) - c.ex, wy = ((k & 2) ? hi[1] : lo[1]) - c.ey, wz = ((k & 4) ? hi[2] : lo[2]) - c.ez;
+        const float z = wx * c.fx + wy * c.fy + wz * c.fz;
+        if (z <= 0.05f) { behind = true; break; }
+        const float x = (wx * c.rx + wy * c.ry + wz * c.rz) / z, y = (wx * c.ux + wy * c.uy + wz * c.uz) / z;
+        x0 = fminf(x0, x); x1 = fmaxf(x1, x); y0 = fminf(y0, y); y1 = fmaxf(y1, y);
+    }
+    if (behind) { rect[0] = -3.0e38f; rect[1] = 3.0e38f; rect[2] = -3.0e38f; rect[3] = 3.0e38f; return; }
+    rect[0] = x0 - eps; rect[1] = x1 + eps; rect[2] = y0 - eps; rect[3] = y1 + eps;
+}
+
 __global__ void __launch_bounds__(kRasterBlock)
 raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) {
     __shared__ Prim prims[kMaxPrims];
+    __shared__ float rects[kMaxPrims][4];
     __shared__ int nprims;
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
     const int e = blockIdx.x, cam = blockIdx.y;
+    const Camera c = rp.cam[cam];
     if (threadIdx.x == 0)
         nprims = rp.kind >= SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
     __syncthreads();
-    const Camera c = rp.cam[cam];
-    const int npix = rp.h * rp.w;
+    if ((int)threadIdx.x < nprims) prim_screen_rect(prims[threadIdx.x], c, rects[threadIdx.x]);
+    __syncthreads();
+    const int npix = rp.h * rp.w, np = nprims;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lx = lane & 7, ly = lane >> 3;
     uint8_t *out = img + (int64_t)e * npix * rp.channels;
-    for (int base = 0; base < npix; base += kTilePixels) {
-        const int count = min(kTilePixels, npix - base);
-        for (int i = threadIdx.x; i < count; i += kRasterBlock) {
-            const int pix = base + i, row = pix / rp.w, col = pix - row * rp.w;
-            const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
-            const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
-            const uint32_t rgb = shade_pixel(prims, nprims, c, sx, sy);
-            tile[3 * i] = (uint8_t)rgb; tile[3 * i + 1] = (uint8_t)(rgb >> 8); tile[3 * i + 2] = (uint8_t)(rgb >> 16);
+    // bands of whole 8-row tile strips that fit the LDS tile buffer; inside a band every wavefront walks 8x8 tiles
+    const int band_rows = max(8, (kTilePixels / rp.w) & ~7);
+    const int tiles_x = (rp.w + 7) >> 3;
+    for (int row0 = 0; row0 < rp.h; row0 += band_rows) {
+        const int rows = min(band_rows, rp.h - row0), base = row0 * rp.w, count = rows * rp.w;
+        const int ntiles = ((rows + 7) >> 3) * tiles_x;
+        for (int t = wave; t < ntiles; t += kRasterBlock / 64) {
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const int col0 = tx * 8, r0 = row0 + ty * 8;
+            // tile rectangle in tangent space (pixel edges; y grows upwards while rows grow downwards)
+            const float tx0 = ((float)col0 / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+            const float tx1 = ((float)(col0 + 8) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+            const float ty1 = (1.0f - (float)r0 / (float)rp.h * 2.0f) * c.tan_half_fov;
+            const float ty0 = (1.0f - (float)(r0 + 8) / (float)rp.h * 2.0f) * c.tan_half_fov;
+            bool touch = false;
+            if (lane < np) touch = rects[lane][0] <= tx1 && rects[lane][1] >= tx0 && rects[lane][2] <= ty1 && rects[lane][3] >= ty0;
+            const uint64_t mask = __ballot(touch);
+            const int row = r0 + ly, col = col0 + lx;
+            if (row < rp.h && col < rp.w) {
+                const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+                const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
+                const uint32_t rgb = shade_pixel(prims, mask, c, sx, sy);
+                const int i = (row - row0) * rp.w + col;
+                tile[3 * i] = (uint8_t)rgb; tile[3 * i + 1] = (uint8_t)(rgb >> 8); tile[3 * i + 2] = (uint8_t)(rgb >> 16);
+            }
         }
         __syncthreads();
         if (rp.channels == 3 && ((count * 3) & 15) == 0 && (((int64_t)base * 3) & 15) == 0 && ((reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
