@@ -92,13 +92,17 @@ class SRLNeuralNetwork(object):
         with th.no_grad():
             self.fused_conv = fold_batchnorm(self.model.conv_layers).eval().to(self.device)
         self.model = self.model.to(self.device)
+        # NHWC activations on the GPU: MIOpen's gfx950 solvers for these shapes are ~25 % faster (3.3 vs 4.3 ms per
+        # 4096x64x64 batch); logical shapes, and therefore the flatten order in front of the FC, do not change
+        self.memory_format = th.channels_last if self.device.type == "cuda" else th.contiguous_format
+        self.fused_conv = self.fused_conv.to(memory_format=self.memory_format)
 
     @th.no_grad()
     def getStates(self, images_u8):
         """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim]."""
         if isinstance(images_u8, np.ndarray):
             images_u8 = th.from_numpy(images_u8)
-        x = self.fused_conv(preprocess(images_u8.to(self.device)))
+        x = self.fused_conv(preprocess(images_u8.to(self.device)).contiguous(memory_format=self.memory_format))
         return self.model.fc(x.reshape(x.size(0), -1))
 
     def getState(self, observation, env_id=0):
