@@ -6,8 +6,12 @@
  * the mobile_robot_env.py:282-334 counterpart: computeViewMatrixFromYawPitchRoll(target, dist, yaw,
  * pitch, roll, upAxisIndex=2), computeProjectionMatrixFOV(60, 1, 0.1, 100), 224x224 RGB, row 0 on top),
  * the object poses (reset() of each env) and the colours (the urdf files, changeVisualShape calls).
- * What cannot be restated: TinyRenderer itself and the pybullet_data meshes (absent) — PARITY UNPINNED
- * against the reference's pixels; scene = analytic primitives, Lambert + ambient, no shadows.
+ * What cannot be restated: TinyRenderer itself and the pybullet_data meshes (absent); scene = analytic
+ * primitives, Lambert + ambient, no shadows.  Pinning: the camera model and the scene geometry are checked
+ * against measurements on the reference's own rendered frames (imgs/kuka.gif, imgs/mobile_robot.gif ->
+ * tests/golden/render_reference_measurements.json, tests/test_raster_reference_pin.py: button / table /
+ * checker / walls project within 2 px at 168x168, flat colours within 16/255); per-pixel PARITY with
+ * TinyRenderer's shading and meshes is UNPINNED.
  * float32 per pixel, compile with -ffp-contract=off. */
 #include <math.h>
 #include <stdint.h>
@@ -132,7 +136,13 @@ static void draw(const prim_t *prims, int np, const cam_t *c, int h, int w, int 
         for (j = 0; j < 3; j++) d[j] *= inv;
         for (k = 0; k < np; k++) {
             float n[3], t = hit(&prims[k], c->eye, d, n);
-            if (t > 0.0f && t < best) { best = t; memcpy(bn, n, sizeof bn); memcpy(colr, prims[k].col, sizeof colr); any = 1; }
+            if (t > 0.0f && t < best) {
+                best = t; memcpy(bn, n, sizeof bn); memcpy(colr, prims[k].col, sizeof colr); any = 1;
+                if (prims[k].type == P_PLANE) {   /* 1 m checker of plane.urdf, phase/colours read off the reference's gifs */
+                    int par = (int)floorf(c->eye[0] + t * d[0]) + (int)floorf(c->eye[1] + t * d[1]);
+                    if ((par & 1) == 0) colr[0] = colr[1] = colr[2] = 1.0f;
+                }
+            }
         }
         if (any) {
             const float lx = -0.40824829f, ly = 0.40824829f, lz = 0.81649658f;
@@ -168,8 +178,8 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
                 for (k = 0; k < 3; k++) { a[k] = p[18 + k] + R[54 + 3 * k] * locs[i][0] + R[54 + 3 * k + 1] * locs[i][1] + R[54 + 3 * k + 2] * locs[i][2]; pts[i][k] = (float)a[k]; }
             }
             (void)b;
-            prims[np++] = mk(P_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
-            prims[np++] = mk(P_BOX, 0.55f, 0.35f, 0.20f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);
+            prims[np++] = mk(P_PLANE, 0.68f, 0.78f, 0.94f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
+            prims[np++] = mk(P_BOX, 0.85f, 0.75f, 0.62f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);
             prims[np++] = mk(P_CYL, 0.0f, 1.0f, 0.0f, (float)s[8], (float)s[9], (float)KM_BUTTON_BASE_Z, 0.10f, 0, 0.03f, 0, 1, 0);
             prims[np++] = mk(P_CYL, 1.0f, 1.0f, 0.0f, (float)s[8], (float)s[9], (float)(KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + s[7]), 0.09f, 0, 0.03f, 0, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.35f, 0.35f, 0.38f, (float)KM_BASE_POS[0], (float)KM_BASE_POS[1], (float)KM_BASE_POS[2], jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
@@ -180,12 +190,12 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
         } else {
             const double *s = state + 6 * (size_t)e;
             float x = (float)s[0], y = (float)s[1], tx = (float)s[2], ty = (float)s[3], t2x = (float)s[4], t2y = (float)s[5];
-            prims[np++] = mk(P_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, 0.0f, 0, 0, 0, 0, 1, 0);
-            prims[np++] = mk(P_BOX, 0.8f, 0.0f, 0.0f, 2.0f, 0.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);
+            prims[np++] = mk(P_PLANE, 0.68f, 0.78f, 0.94f, 0, 0, 0.0f, 0, 0, 0, 0, 1, 0);
+            prims[np++] = mk(P_BOX, 0.66f, 0.0f, 0.0f, 2.0f, 0.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);
             if (kind != 1) {
                 prims[np++] = mk(P_BOX, 0.0f, 0.0f, 0.0f, 4.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);
-                prims[np++] = mk(P_BOX, 0.0f, 0.8f, 0.0f, 2.0f, 4.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);
-                prims[np++] = mk(P_BOX, 0.0f, 0.0f, 0.8f, 0.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);
+                prims[np++] = mk(P_BOX, 0.0f, 0.65f, 0.0f, 2.0f, 4.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);
+                prims[np++] = mk(P_BOX, 0.0f, 0.0f, 0.79f, 0.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);
             }
             if (kind == 3) prims[np++] = mk(P_BOX, 1.0f, 1.0f, 0.0f, tx, 2.0f, -0.045f, 2.0f, 0.25f, 0.05f, 0, 0.0f, 1.0f);
             else prims[np++] = mk(P_CYL, 1.0f, 1.0f, 0.0f, tx, ty, 0.0f, 0.18f, 0, 0.03f, 0, 1, 0);

@@ -169,12 +169,12 @@ __device__ int build_mobile_scene(const RasterParams &rp, const RasterMobileView
     const float x = (float)v.x[e], y = (float)v.y[e];
     const float tx = (float)v.tx[e], ty = (float)v.ty[e], t2x = (float)v.t2x[e], t2y = (float)v.t2y[e];
     int n = 0;
-    set_prim(prims[n++], PRIM_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, 0.0f, 0, 0, 0, 0, 1, 0);
-    set_prim(prims[n++], PRIM_BOX, 0.8f, 0.0f, 0.0f, 2.0f, 0.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);           // wall_left
+    set_prim(prims[n++], PRIM_PLANE, 0.68f, 0.78f, 0.94f, 0, 0, 0.0f, 0, 0, 0, 0, 1, 0);
+    set_prim(prims[n++], PRIM_BOX, 0.66f, 0.0f, 0.0f, 2.0f, 0.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);           // wall_left
     if (rp.kind != SRLHIP_ENV_MOBILE_1D) {
         set_prim(prims[n++], PRIM_BOX, 0.0f, 0.0f, 0.0f, 4.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);       // wall_bottom
-        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.8f, 0.0f, 2.0f, 4.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);       // wall_right
-        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.0f, 0.8f, 0.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);       // wall_top
+        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.65f, 0.0f, 2.0f, 4.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 1.0f, 0.0f);       // wall_right
+        set_prim(prims[n++], PRIM_BOX, 0.0f, 0.0f, 0.79f, 0.0f, 2.0f, 0.0f, 2.0f, 0.05f, 0.05f, 0, 0.0f, 1.0f);       // wall_top
     }
     if (rp.kind == SRLHIP_ENV_MOBILE_LINE)
         set_prim(prims[n++], PRIM_BOX, 1.0f, 1.0f, 0.0f, tx, 2.0f, -0.045f, 2.0f, 0.25f, 0.05f, 0, 0.0f, 1.0f);      // line target
@@ -196,8 +196,8 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
 #undef SRL_FK
     const float bx = (float)v.bx[e], by = (float)v.by[e], cap_z = (float)(v.bz[e] + kGliderOriginZ + v.bq[e]);
     int k = 0;
-    set_prim(prims[k++], PRIM_PLANE, 0.75f, 0.80f, 0.90f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
-    set_prim(prims[k++], PRIM_BOX, 0.55f, 0.35f, 0.20f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);     // table top
+    set_prim(prims[k++], PRIM_PLANE, 0.68f, 0.78f, 0.94f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
+    set_prim(prims[k++], PRIM_BOX, 0.85f, 0.75f, 0.62f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);     // table top
     set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, bx, by, (float)v.bz[e], 0.10f, 0, 0.03f, 0, 1, 0);              // button base
     set_prim(prims[k++], PRIM_CYL, 1.0f, 1.0f, 0.0f, bx, by, cap_z, 0.09f, 0, 0.03f, 0, 1, 0);                       // button cap
     set_prim(prims[k++], PRIM_CAPSULE, 0.35f, 0.35f, 0.38f, (float)kBasePos[0], (float)kBasePos[1], (float)kBasePos[2],
@@ -232,7 +232,15 @@ __device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask
         else if (p.type == PRIM_BOX) t = hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
         else if (p.type == PRIM_CYL) t = hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
         else t = hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
-        if (t > 0.0f && t < best) { best = t; bnx = nx; bny = ny; bnz = nz; cr = p.r; cg = p.g; cb = p.b; hit = true; }
+        if (t > 0.0f && t < best) {
+            best = t; bnx = nx; bny = ny; bnz = nz; cr = p.r; cg = p.g; cb = p.b; hit = true;
+            if (p.type == PRIM_PLANE) {
+                // plane.urdf's texture: 1 m blue/white checker aligned with the world axes (period, phase and the two
+                // colours measured on the reference's imgs/mobile_robot.gif: x in [0,1) x y in [0,1) is white)
+                const int par = (int)floorf(c.ex + t * dx) + (int)floorf(c.ey + t * dy);
+                if ((par & 1) == 0) { cr = 1.0f; cg = 1.0f; cb = 1.0f; }
+            }
+        }
     }
     float shade = 1.0f;
     if (hit) {
