@@ -30,6 +30,14 @@ def set_moving(flag):
     _lib().kuka_oracle_set_moving(int(bool(flag)))
 
 
+VARIANT_BUTTON, VARIANT_MOVING, VARIANT_TWO = 0, 1, 2
+
+
+def set_variant(variant):
+    """0 KukaButtonGymEnv, 1 KukaMovingButtonGymEnv, 2 Kuka2ButtonGymEnv for the following calls."""
+    _lib().kuka_oracle_set_variant(int(variant))
+
+
 def aba(q, qd, tau, gz=-10.0):
     q, qd, tau = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau))
     out = np.zeros(7)
@@ -77,7 +85,7 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
         "obs0": np.zeros((n, od), np.float32), "obs": np.zeros((T, n, od), np.float32),
         "reward": np.zeros((T, n), np.float32), "reward64": np.zeros((T, n)), "done": np.zeros((T, n), np.uint8),
         "q": np.zeros((T, n, 7)) if trace else None, "gripper": np.zeros((T, n, 3)) if trace else None,
-        "final_state": np.zeros((n, 24)), "ep_stats": np.zeros((n, 3)),
+        "final_state": np.zeros((n, 30)), "ep_stats": np.zeros((n, 3)),
     }
     act_out = None
     if actions is None:
@@ -106,6 +114,28 @@ def wrapper_step(state, gripper, button_pos, contact_button, contact_table, shap
     _lib().kuka_oracle_wrapper_step(_p(st), _p(g), _p(b), int(contact_button), int(contact_table), int(shape_reward),
                                     int(is_discrete), float(max_distance), ctypes.byref(reward), ctypes.byref(done))
     return st[:4].copy(), reward.value, bool(done.value)
+
+
+def wrapper_step_two(state, gripper, all_pos, contact_goal, contact_table, shape_reward=False, max_distance=2.0):
+    """Kuka2ButtonGymEnv bookkeeping probe; state = counter n_contacts[0] n_outside terminated goal_id n_contacts[1]."""
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    st = np.concatenate([st, np.zeros(8 - len(st))])
+    g = np.ascontiguousarray(gripper, dtype=np.float64)
+    b = np.ascontiguousarray(all_pos, dtype=np.float64).reshape(6)
+    reward, done = ctypes.c_double(), ctypes.c_int()
+    lib = _lib()
+    lib.kuka_oracle_wrapper_step_two.argtypes = ([ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_double] +
+                                                 [ctypes.c_void_p] * 2)
+    lib.kuka_oracle_wrapper_step_two(_p(st), _p(g), _p(b), int(contact_goal), int(contact_table), int(shape_reward),
+                                     float(max_distance), ctypes.byref(reward), ctypes.byref(done))
+    return st[:6].copy(), reward.value, bool(done.value)
+
+
+def last_buttons():
+    """button base positions (b1x b1y b2x b2y) drawn by the reset() of the last command_trace call"""
+    out = np.zeros(4)
+    _lib().kuka_oracle_last_buttons(_p(out))
+    return out
 
 
 def command_trace(seed, T, actions, is_discrete=True, action_joints=False, random_target=False, force_down=True):

@@ -60,6 +60,11 @@ static const double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, rad
     {0, 0.035, 0.200, 0.020}, {0, -0.035, 0.200, 0.020},      /* finger bodies                              */
     {0, 0, 0.100, 0.060}, {0, 0, 0.0, 0.070}};                /* gripper body, wrist                        */
 #define KM_IK_DAMPING 1e-5                                    /* kuka.py:41-42 jd                           */
+#define KM_IK_DAMPING_DEFAULT 0.5                             /* pybullet server default when no jointDamping is passed (Kuka2Button) [UNVERIFIED-MEMORY] */
+#define KM_BUTTON1_Y_2B 0.125                                 /* kuka_2button_gym_env.py:56-62 */
+#define KM_BUTTON2_Y_2B (-0.125)                              /* :66-70 */
+#define KM_Z_TABLE (-0.2)                                     /* kuka_button_gym_env.py Z_TABLE */
+#define KM_MAX_STEPS_2BUTTON 1500                             /* kuka_2button_gym_env.py:3 */
 #define KM_IK_MAX_ANGLE (45.0 * KM_PI / 180.0)                /* BussIK MaxAngleDLS                          */
 
 /* button (urdf/simple_button.urdf): static base, prismatic cap ("glider") */

@@ -8,6 +8,8 @@
  *   KukaButtonGymEnv.reset      .../kuka_button_gym_env.py:214-281
  *   KukaButtonGymEnv.step       :293-340      step2 :342-368
  *   _termination :422-426       _reward :428-463     getSRLState :175-189
+ *   Kuka2ButtonGymEnv           .../kuka_2button_gym_env.py:33-200 (reset draws, two buttons, goal switching, reward)
+ *   KukaMovingButtonGymEnv      .../kuka_moving_button_gym_env.py
  * Out-of-tree arithmetic restated from the dependency's PUBLISHED algorithm
  * (pybullet==1.8.6 / Bullet 2.87, absent here -> PARITY UNPINNED for this part):
  *   p.calculateInverseKinematics  one damped-least-squares step (BussIK DLS)
@@ -220,7 +222,7 @@ static int solve_linear(double A[N][N], double b[N], double x[N]) {   /* Gaussia
     for (i = N - 1; i >= 0; i--) { double s = b[i]; for (j = i + 1; j < N; j++) s -= A[i][j] * x[j]; x[i] = s / A[i][i]; }
     return 0;
 }
-static void inverse_kinematics(const double q[N], const mat3 R[N], const double p[N][3], const double target[3], double q_des[N]) {
+static void inverse_kinematics(const double q[N], const mat3 R[N], const double p[N][3], const double target[3], double damping, double q_des[N]) {
     /* target orientation p.getQuaternionFromEuler([0, -pi, 0]) = (0, sin(-pi/2), 0, cos(-pi/2)) */
     const double tq[4] = {0.0, sin(-KM_PI / 2), 0.0, cos(-KM_PI / 2)};
     double ee[3], Jv[3][N], Jw[3][N], J[6][N], dS[6], cq[4], cinv[4], dq[4], A[N][N], b[N], dth[N];
@@ -244,7 +246,7 @@ static void inverse_kinematics(const double q[N], const mat3 R[N], const double 
     /* (J^T J + diag(damping)) dtheta = J^T dS */
     for (i = 0; i < N; i++) {
         for (j = 0; j < N; j++) { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * J[k][j]; A[i][j] = s; }
-        A[i][i] += KM_IK_DAMPING;
+        A[i][i] += damping;
         { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * dS[k]; b[i] = s; }
     }
     if (solve_linear(A, b, dth) != 0) memset(dth, 0, sizeof dth);
@@ -266,9 +268,14 @@ typedef struct {
     double gripper[3];             /* getArmPos() after the last physics step      */
     int contact_button, contact_table;   /* manifolds of the last stepSimulation  */
     int counter, n_contacts, n_outside, terminated;
+    /* Kuka2ButtonGymEnv: second button (same urdf), per-body contact flags, goal bookkeeping */
+    double b2q, b2qd, button2_xy[2];
+    int contact_body[2];           /* any link (cap or base) of button k touches the arm: getContactPoints(button_uid[k], kuka) */
+    int goal_id, n_contacts2;      /* n_contacts[0] lives in n_contacts */
+    double all_pos[2][3];          /* button_all_pos */
 } kenv;
 
-typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving; double max_distance; } kcfg;
+typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving, two; double max_distance; } kcfg;
 
 /* ------------------------------------------------------------------ collision */
 /* signed distance between a sphere and an upright solid cylinder (axis z, centre xy, z in [z0, z1]);
@@ -287,11 +294,12 @@ static double sphere_cylinder(const double c[3], double rad, const double xy[2],
 }
 
 /* ------------------------------------------------------------------ one physics step */
-typedef struct { double J[N]; double Jb; double WJ[N]; double WJb; double Dinv, rhs, lo, hi, applied; } row_t;
+typedef struct { double J[N]; double Jb; double WJ[N]; double WJb; double Dinv, rhs, lo, hi, applied; int bsel; } row_t;
 
 static void add_row(row_t *rows, int *nrows, const double J[N], double Jb, const double W[N][N], double Wb,
-                    double desired_vel, double pos_error_vel, const double qd[N], double bqd, double lo, double hi) {
+                    double desired_vel, double pos_error_vel, const double qd[N], double bqd, double lo, double hi, int bsel) {
     row_t *r = &rows[(*nrows)++]; int i, j; double D = 0, rel = 0;
+    r->bsel = bsel;                       /* which button's glider the scalar Jb acts on (bqd = that glider's velocity) */
     for (i = 0; i < N; i++) { double s = 0; for (j = 0; j < N; j++) s += W[i][j] * J[j]; r->WJ[i] = s; r->J[i] = J[i]; }
     r->Jb = Jb; r->WJb = Wb * Jb;
     for (i = 0; i < N; i++) { D += J[i] * r->WJ[i]; rel += J[i] * qd[i]; }
@@ -303,11 +311,15 @@ static void add_row(row_t *rows, int *nrows, const double J[N], double Jb, const
 
 /* Kuka.applyAction (kuka.py:118-187) followed by p.stepSimulation() */
 static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets) {
-    mat3 R[N]; double p[N][3], q_des[N], tau[N], qdd[N], W[N][N], dv[N], dvb = 0.0;
+    mat3 R[N]; double p[N][3], q_des[N], tau[N], qdd[N], W[N][N], dv[N], dvb[2] = {0.0, 0.0};
     const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
-    row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s;
-    const double (*box)[3] = KM_EE_BOX[cfg->random_target ? 0 : 1];
+    const int nb = cfg->two ? 2 : 1;
+    row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s, b;
+    /* Kuka(small_constraints=False) for random_target and always for Kuka2Button (kuka_2button_gym_env.py:78) */
+    const double (*box)[3] = KM_EE_BOX[(cfg->random_target || cfg->two) ? 0 : 1];
     double zeroJ[N] = {0};
+    double *bq[2], *bqd[2]; const double *bxy[2];
+    bq[0] = &e->bq; bqd[0] = &e->bqd; bxy[0] = e->button_xy; bq[1] = &e->b2q; bqd[1] = &e->b2qd; bxy[1] = e->button2_xy;
 
     forward_kinematics(e->q, R, p);
     if (!joint_targets) {
@@ -316,19 +328,21 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             if (e->ee_target[k] < box[0][k]) e->ee_target[k] = box[0][k];
             if (e->ee_target[k] > box[1][k]) e->ee_target[k] = box[1][k];
         }
-        inverse_kinematics(e->q, R, p, e->ee_target, q_des);      /* kuka.py:155-156 */
+        /* kuka.py:147-156.  Kuka2Button sets use_null_space, but its ll/ul/jr/rp lists have 7 entries for a 12-DoF body:
+         * pybullet drops null-space arguments whose length differs from the DoF count, and the call then carries no
+         * jointDamping either -> plain DLS with the server's default damping 0.5 (KM_IK_DAMPING_DEFAULT). */
+        inverse_kinematics(e->q, R, p, e->ee_target, cfg->two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_des);
     } else memcpy(q_des, joint_targets, sizeof q_des);           /* kuka.py:160-163 */
     if (g_trace_ee) { memcpy(g_trace_ee + 3 * g_trace_n, e->ee_target, 3 * sizeof(double)); if (joint_targets) memcpy(g_trace_jt + N * g_trace_n, joint_targets, N * sizeof(double)); g_trace_n++; }
 
     /* -- collision detection at the current poses (start of stepSimulation) -- */
-    e->contact_button = 0; e->contact_table = 0;
+    e->contact_button = 0; e->contact_table = 0; e->contact_body[0] = 0; e->contact_body[1] = 0;
     {
-        double cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + e->bq;
         /* -- unconstrained velocities: ABA with joint damping torques and gravity -- */
         for (i = 0; i < N; i++) tau[i] = -KM_JOINT_DAMPING * e->qd[i];
         aba(e->q, e->qd, tau, KM_GRAVITY_Z, qdd);
         for (i = 0; i < N; i++) e->qd[i] += dt * qdd[i];
-        e->bqd += dt * KM_GRAVITY_Z;
+        for (b = 0; b < nb; b++) *bqd[b] += dt * KM_GRAVITY_Z;
         mass_matrix_inverse(e->q, W);
 
         /* -- constraint rows: motors, then joint limits, then contacts -- */
@@ -337,34 +351,40 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             if (target > KM_ARM_MAX_VEL) target = KM_ARM_MAX_VEL;
             if (target < -KM_ARM_MAX_VEL) target = -KM_ARM_MAX_VEL;
             J[i] = 1.0;
-            add_row(rows, &nrows, J, 0.0, W, Wb, target, 0.0, e->qd, e->bqd, -KM_ARM_MAX_FORCE * dt, KM_ARM_MAX_FORCE * dt);
+            add_row(rows, &nrows, J, 0.0, W, Wb, target, 0.0, e->qd, 0.0, -KM_ARM_MAX_FORCE * dt, KM_ARM_MAX_FORCE * dt, 0);
         }
-        if (e->button_motor_on)                                    /* kuka_button_gym_env.py:347 */
-            add_row(rows, &nrows, zeroJ, 1.0, W, Wb, KM_BUTTON_KP * (KM_BUTTON_TARGET - e->bq) / dt, 0.0, e->qd, e->bqd,
-                    -KM_BUTTON_MAX_FORCE * dt, KM_BUTTON_MAX_FORCE * dt);
-        else
-            add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, 0.0, e->qd, e->bqd, -KM_DEFAULT_MOTOR_IMPULSE, KM_DEFAULT_MOTOR_IMPULSE);
+        for (b = 0; b < nb; b++) {
+            if (e->button_motor_on)                                /* kuka_button_gym_env.py:347, kuka_2button_gym_env.py:118-119 */
+                add_row(rows, &nrows, zeroJ, 1.0, W, Wb, KM_BUTTON_KP * (KM_BUTTON_TARGET - *bq[b]) / dt, 0.0, e->qd, *bqd[b],
+                        -KM_BUTTON_MAX_FORCE * dt, KM_BUTTON_MAX_FORCE * dt, b);
+            else
+                add_row(rows, &nrows, zeroJ, 1.0, W, Wb, 0.0, 0.0, e->qd, *bqd[b], -KM_DEFAULT_MOTOR_IMPULSE, KM_DEFAULT_MOTOR_IMPULSE, b);
+        }
         /* joint limits (btMultiBodyJointLimitConstraint): unilateral rows.  A row whose stop is still `pen`
          * away only forbids approaching faster than pen/dt, so it is created when pen/dt is within reach
          * (arm: KM_LIMIT_ACTIVATION_VEL, far above the 0.35 rad/s motor clamp; button: always). */
         for (i = 0; i < N; i++) {
             double J[N] = {0}, pen_lo = e->q[i] - KM_JOINT_LOWER[i], pen_hi = KM_JOINT_UPPER[i] - e->q[i];
-            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
-            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
         }
-        { double pen_lo = e->bq - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - e->bq;
-          add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE);
-          add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, e->bqd, 0.0, KM_LIMIT_MAX_IMPULSE); }
-        for (s = 0; s < KM_NSPHERE; s++) {                          /* gripper spheres vs cap, base, table */
+        for (b = 0; b < nb; b++) {
+          double pen_lo = *bq[b] - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - *bq[b];
+          add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b);
+          add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b); }
+        for (s = 0; s < KM_NSPHERE; s++) {                          /* gripper spheres vs cap, base (of every button), table */
             double c[3], n[3], dist, pt[3], Jv[3][N], Jw[3][N], J[N]; int shape;
             link7_point(R, p, KM_SPHERE[s], c);
             if (c[2] - KM_SPHERE[s][3] - KM_TABLE_TOP_Z < KM_CONTACT_THRESHOLD) e->contact_table = 1;
-            for (shape = 0; shape < 2; shape++) {
-                double pos_err_vel, allow;
-                if (shape == 0) dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, n);
-                else dist = sphere_cylinder(c, KM_SPHERE[s][3], e->button_xy, KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, n);
+            for (shape = 0; shape < 2 * nb; shape++) {
+                double pos_err_vel, allow, cap_z0; const int is_cap = (shape & 1) == 0;
+                b = shape >> 1;
+                cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + *bq[b];
+                if (is_cap) dist = sphere_cylinder(c, KM_SPHERE[s][3], bxy[b], KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, n);
+                else dist = sphere_cylinder(c, KM_SPHERE[s][3], bxy[b], KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, n);
                 if (!(dist < KM_CONTACT_THRESHOLD)) continue;
-                if (shape == 0) e->contact_button = 1;
+                if (is_cap && b == 0) e->contact_button = 1;
+                e->contact_body[b] = 1;
                 if (ngeneric >= MAX_GENERIC_ROWS) continue;
                 ngeneric++;
                 for (k = 0; k < 3; k++) pt[k] = c[k] - KM_SPHERE[s][3] * n[k];      /* contact point on the sphere */
@@ -373,7 +393,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                 /* separated: allow approach up to dist/dt; penetrating: push out with erp */
                 allow = dist > 0 ? -dist / dt : 0.0;
                 pos_err_vel = dist > 0 ? 0.0 : -dist * KM_ERP / dt;
-                add_row(rows, &nrows, J, shape == 0 ? -n[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, e->bqd, 0.0, 1e10);
+                add_row(rows, &nrows, J, is_cap ? -n[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, *bqd[b], 0.0, 1e10, b);
             }
         }
     }
@@ -381,7 +401,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     memset(dv, 0, sizeof dv);
     for (it = 0; it < KM_SOLVER_ITERS; it++) {
         for (k = 0; k < nrows; k++) {
-            row_t *r = &rows[k]; double jdv = r->Jb * dvb, delta, sum;
+            row_t *r = &rows[k]; double jdv = r->Jb * dvb[r->bsel], delta, sum;
             for (i = 0; i < N; i++) jdv += r->J[i] * dv[i];
             delta = r->rhs - jdv * r->Dinv;
             sum = r->applied + delta;
@@ -389,12 +409,12 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             else if (sum > r->hi) { delta = r->hi - r->applied; r->applied = r->hi; }
             else r->applied = sum;
             for (i = 0; i < N; i++) dv[i] += delta * r->WJ[i];
-            dvb += delta * r->WJb;
+            dvb[r->bsel] += delta * r->WJb;
         }
     }
     /* -- semi-implicit Euler -- */
     for (i = 0; i < N; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
-    e->bqd += dvb; e->bq += dt * e->bqd;
+    for (b = 0; b < nb; b++) { *bqd[b] += dvb[b]; *bq[b] += dt * *bqd[b]; }
     forward_kinematics(e->q, R, p);
     link7_point(R, p, KM_GRIPPER_POINT, e->gripper);
 }
@@ -405,10 +425,40 @@ static double norm3(const double a[3], const double b[3]) {      /* np.linalg.no
     return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
 }
 static int g_max_steps_moving = 1500;   /* kuka_moving_button_gym_env.py:3,34 */
-static int termination_cfg(const kenv *e, const kcfg *cfg) { return e->terminated || e->counter > (cfg->moving ? g_max_steps_moving : KM_MAX_STEPS); }   /* :422-426 */
+static int termination_cfg(const kenv *e, const kcfg *cfg) {      /* :422-426 */
+    return e->terminated || e->counter > (cfg->two ? KM_MAX_STEPS_2BUTTON : cfg->moving ? g_max_steps_moving : KM_MAX_STEPS);
+}
+
+/* Kuka2ButtonGymEnv._reward (kuka_2button_gym_env.py:141-200) */
+static double reward_two(kenv *e, const kcfg *cfg) {
+    double distance = norm3(e->all_pos[e->goal_id], e->gripper);
+    int reward = 0, contact = e->contact_body[e->goal_id];   /* getContactPoints(button_uid[goal_id], kuka): any link of that button */
+    int *nc[2]; nc[0] = &e->n_contacts; nc[1] = &e->n_contacts2;
+    *nc[e->goal_id] += contact;
+    if (e->goal_id == 1) reward = contact;                    /* sparse reward only on the last button */
+    /* next button: button_pressed[goal_id] flips once, when its contact count reaches the threshold */
+    if (*nc[e->goal_id] >= KM_N_CONTACTS_BEFORE_TERMINATION && e->goal_id == 0) {
+        memcpy(e->button_pos, e->all_pos[1], sizeof e->button_pos);
+        e->goal_id = 1;
+    }
+    if (distance > cfg->max_distance || e->contact_table) { reward = -1; e->n_outside += 1; }
+    else e->n_outside = 0;
+    if (e->contact_table || e->n_contacts2 >= KM_N_CONTACTS_BEFORE_TERMINATION || e->n_outside >= KM_N_STEPS_OUTSIDE_SAFETY_SPHERE - 1)
+        e->terminated = 1;
+    if (cfg->shape_reward) {
+        if (e->terminated && reward > 0) return 50;
+        if (*nc[e->goal_id] < KM_N_CONTACTS_BEFORE_TERMINATION && contact) return 25;
+        if (e->contact_table) return -250;
+        if (distance > cfg->max_distance) return -20;
+        return -distance;
+    }
+    return reward;
+}
 
 static double reward_fn(kenv *e, const kcfg *cfg) {              /* :428-463 */
-    double distance = norm3(e->button_pos, e->gripper);
+    double distance;
+    if (cfg->two) return reward_two(e, cfg);
+    distance = norm3(e->button_pos, e->gripper);
     int reward = e->contact_button ? 1 : 0;
     e->n_contacts += reward;
     if (distance > cfg->max_distance || e->contact_table) { reward = -1; e->n_outside += 1; }
@@ -445,9 +495,15 @@ static void settle(kenv *e, const kcfg *cfg) {
 static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) {   /* :214-281 */
     double bx = KM_BUTTON_X, by = KM_BUTTON_Y, speed = 0.0; int i;
     if (cfg->moving) speed = 0.001 * (k_randint2(r) ? 1.0 : -1.0);   /* BUTTON_SPEED * np_random.choice([-1, 1]), drawn first */
-    if (cfg->random_target) { bx += 0.15 * k_uniform(r, -1, 1); by += 0.3 * k_uniform(r, -1, 1); }
+    double b2x = KM_BUTTON_X, b2y = KM_BUTTON2_Y_2B;
+    if (cfg->two) {                                                /* kuka_2button_gym_env.py:55-70 */
+        if (cfg->random_target) { (void)k_uniform(r, -1, 1); (void)k_uniform(r, 0, 1); }   /* overwritten two lines later */
+        bx = 0.5 + 0.0 * k_uniform(r, -1, 1); by = KM_BUTTON1_Y_2B + 0.0 * k_uniform(r, -1, 1);
+        if (cfg->random_target) { b2x += 0.15 * k_uniform(r, -1, 1); b2y += 0.175 * k_uniform(r, -1, 0); }
+    } else if (cfg->random_target) { bx += 0.15 * k_uniform(r, -1, 1); by += 0.3 * k_uniform(r, -1, 1); }
     *e = *settled;
     e->button_xy[0] = bx; e->button_xy[1] = by; e->button_z = KM_BUTTON_BASE_Z; e->button_speed = speed;
+    e->button2_xy[0] = b2x; e->button2_xy[1] = b2y; e->b2q = e->bq; e->b2qd = e->bqd;   /* same urdf, same 500 free steps */
     for (i = 0; i < KM_N_RANDOM_ACTIONS_AT_INIT; i++) {
         double action[5] = {0, 0, 0, 0, 0};
         if (cfg->is_discrete) {
@@ -469,6 +525,12 @@ static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) { 
     }
     e->button_pos[0] = bx; e->button_pos[1] = by;
     e->button_pos[2] = e->button_z + KM_GLIDER_ORIGIN_Z + e->bq + KM_BUTTON_DISTANCE_HEIGHT;   /* :273-274 */
+    if (cfg->two) {                                                /* button_all_pos: [x, y, Z_TABLE + BUTTON_DISTANCE_HEIGHT] */
+        e->all_pos[0][0] = bx; e->all_pos[0][1] = by; e->all_pos[0][2] = KM_Z_TABLE + KM_BUTTON_DISTANCE_HEIGHT;
+        e->all_pos[1][0] = b2x; e->all_pos[1][1] = b2y; e->all_pos[1][2] = KM_Z_TABLE + KM_BUTTON_DISTANCE_HEIGHT;
+        memcpy(e->button_pos, e->all_pos[0], sizeof e->button_pos);
+    }
+    e->goal_id = 0; e->n_contacts2 = 0;
     e->counter = 0; e->n_contacts = 0; e->n_outside = 0; e->terminated = 0;
 }
 
@@ -513,16 +575,18 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
     { double reward = reward_fn(e, cfg); *done = termination_cfg(e, cfg); return reward; }
 }
 
-static int g_moving = 0;
-/* selects KukaMovingButtonGymEnv semantics for the following calls (tests are single-threaded callers) */
-void kuka_oracle_set_moving(int moving) { g_moving = moving; }
+static int g_moving = 0, g_two = 0;
+/* selects KukaMovingButtonGymEnv / Kuka2ButtonGymEnv semantics for the following calls (tests are single-threaded callers) */
+void kuka_oracle_set_moving(int moving) { g_moving = moving; g_two = 0; }
+void kuka_oracle_set_variant(int variant) { g_moving = variant == 1; g_two = variant == 2; }
 
 /* ------------------------------------------------------------------ batch entry points */
 /* Rollout of n envs, T steps each, auto-reset (VecEnv worker semantics).
  * actions: int32 [T][n] (discrete, -1 = None) or float [T][n][adim]; NULL -> Philox random agent.
  * Outputs (any may be NULL): obs0 [n][od], obs [T][n][od] f32, rew f32 / rew64 f64 [T][n], done u8 [T][n],
  * q_trace [T][n][7] f64 (joint positions after each step, BEFORE a possible auto-reset),
- * grip_trace [T][n][3], final [n][24]: q7 qd7 ee3 bq bqd counter n_contacts n_outside terminated button_z. */
+ * grip_trace [T][n][3], final [n][30]: q7 qd7 ee3 bq bqd counter n_contacts n_outside terminated button_z,
+ * b2q b2qd goal_id n_contacts2 b2x b2y (second button: Kuka2Button only). */
 int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, int force_down, int shape_reward,
                         int action_repeat, double max_distance, int obs_mode, int rng_mode, int auto_reset, int n, int T,
                         const int64_t *seeds, const uint32_t *mt_keys, const int32_t *mt_key_len, const void *actions,
@@ -532,7 +596,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
     const int od = obs_mode == 1 ? 14 : obs_mode == 2 ? 17 : 3, adim = is_discrete ? 1 : action_joints ? 7 : 3;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
-    cfg.max_distance = max_distance; cfg.moving = g_moving;
+    cfg.max_distance = max_distance; cfg.moving = g_moving; cfg.two = g_two;
     settle(&settled, &cfg);
 #pragma omp parallel for schedule(dynamic, 4)
     for (e = 0; e < n; e++) {
@@ -568,11 +632,12 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             if (done_out) done_out[row] = (uint8_t)done;
         }
         if (final_state) {
-            double *f = final_state + 24 * (size_t)e; int j;
+            double *f = final_state + 30 * (size_t)e; int j;
             for (j = 0; j < N; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
             f[14] = env.ee_target[0]; f[15] = env.ee_target[1]; f[16] = env.ee_target[2]; f[17] = env.bq; f[18] = env.bqd;
             f[19] = env.counter; f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.button_pos[2];
             if (cfg.moving) f[23] = env.button_pos[1];
+            f[24] = env.b2q; f[25] = env.b2qd; f[26] = env.goal_id; f[27] = env.n_contacts2; f[28] = env.button2_xy[0]; f[29] = env.button2_xy[1];
         }
         if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
         free(r);
@@ -584,7 +649,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
  * independent numpy cross-check (tests/test_kuka_dynamics.py). */
 void kuka_oracle_settled(int random_target, int action_joints, double *out22) {
     kcfg cfg; kenv s; int j;
-    memset(&cfg, 0, sizeof cfg); cfg.random_target = random_target; cfg.action_joints = action_joints; cfg.action_repeat = 1; cfg.is_discrete = 1;
+    memset(&cfg, 0, sizeof cfg); cfg.random_target = random_target; cfg.action_joints = action_joints; cfg.action_repeat = 1; cfg.is_discrete = 1; cfg.two = g_two;
     settle(&s, &cfg);
     for (j = 0; j < N; j++) { out22[j] = s.q[j]; out22[7 + j] = s.qd[j]; }
     out22[14] = s.ee_target[0]; out22[15] = s.ee_target[1]; out22[16] = s.ee_target[2]; out22[17] = s.bq; out22[18] = s.bqd;
@@ -598,7 +663,7 @@ void kuka_oracle_fk(const double *q, double *R63, double *p21) {
     for (i = 0; i < N; i++) { for (a = 0; a < 3; a++) { for (b = 0; b < 3; b++) R63[i * 9 + a * 3 + b] = R[i][a][b]; p21[i * 3 + a] = p[i][a]; } }
 }
 void kuka_oracle_ik(const double *q, const double *target, double *q_des) {
-    mat3 R[N]; double p[N][3]; forward_kinematics(q, R, p); inverse_kinematics(q, R, p, target, q_des);
+    mat3 R[N]; double p[N][3]; forward_kinematics(q, R, p); inverse_kinematics(q, R, p, target, g_two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_des);
 }
 /* scripted-wrapper probe: reward/termination logic on caller-supplied physics outputs */
 void kuka_oracle_wrapper_step(double *state8, const double *gripper, const double *button_pos, int contact_button, int contact_table,
@@ -612,6 +677,25 @@ void kuka_oracle_wrapper_step(double *state8, const double *gripper, const doubl
     *reward = reward_fn(&e, &cfg); *done = termination_cfg(&e, &cfg);
     state8[0] = e.counter; state8[1] = e.n_contacts; state8[2] = e.n_outside; state8[3] = e.terminated;
 }
+/* same probe for Kuka2ButtonGymEnv: state8 = counter n_contacts[0] n_outside terminated goal_id n_contacts[1];
+ * contact_goal = contact with the CURRENT goal button (any link) */
+void kuka_oracle_wrapper_step_two(double *state8, const double *gripper, const double *all_pos6, int contact_goal, int contact_table,
+                                  int shape_reward, double max_distance, double *reward, int *done) {
+    kenv e; kcfg cfg; memset(&e, 0, sizeof e); memset(&cfg, 0, sizeof cfg);
+    e.counter = (int)state8[0]; e.n_contacts = (int)state8[1]; e.n_outside = (int)state8[2]; e.terminated = (int)state8[3];
+    e.goal_id = (int)state8[4]; e.n_contacts2 = (int)state8[5];
+    memcpy(e.gripper, gripper, sizeof e.gripper); memcpy(e.all_pos, all_pos6, sizeof e.all_pos);
+    e.contact_body[e.goal_id] = contact_goal; e.contact_table = contact_table;
+    cfg.shape_reward = shape_reward; cfg.is_discrete = 1; cfg.max_distance = max_distance; cfg.two = 1;
+    if (!termination_cfg(&e, &cfg)) e.counter += 1;
+    *reward = reward_fn(&e, &cfg); *done = termination_cfg(&e, &cfg);
+    state8[0] = e.counter; state8[1] = e.n_contacts; state8[2] = e.n_outside; state8[3] = e.terminated;
+    state8[4] = e.goal_id; state8[5] = e.n_contacts2;
+}
+
+static double g_last_buttons[4];
+/* button base positions drawn by the reset() of the last kuka_oracle_command_trace call: b1x b1y b2x b2y */
+void kuka_oracle_last_buttons(double *out4) { memcpy(out4, g_last_buttons, sizeof g_last_buttons); }
 
 /* Commands issued by reset() (5 init actions) and by every step of one env: Cartesian IK targets
  * (Kuka.end_effector_pos after the clip) and, in joint mode, the motor target list.  Returns the number of
@@ -620,12 +704,13 @@ int kuka_oracle_command_trace(int is_discrete, int action_joints, int random_tar
                               int mt_key_len, int T, const void *actions, double *ee_trace, double *jt_trace, int *n_reset_cmds) {
     kcfg cfg; kenv settled, env; krng *r = (krng *)malloc(sizeof(krng)); int t, done = 0;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = 0; cfg.action_repeat = 1;
-    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = 0.8; cfg.moving = g_moving;
+    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = g_two ? 2.0 : 0.8; cfg.moving = g_moving; cfg.two = g_two;
     settle(&settled, &cfg);
     r->mode = 2; np_rng_seed_array(&r->mt, mt_key, mt_key_len);
     g_trace_ee = ee_trace; g_trace_jt = jt_trace; g_trace_n = 0;
     env_reset(&env, &cfg, r, &settled);
     *n_reset_cmds = g_trace_n;
+    g_last_buttons[0] = env.button_xy[0]; g_last_buttons[1] = env.button_xy[1]; g_last_buttons[2] = env.button2_xy[0]; g_last_buttons[3] = env.button2_xy[1];
     for (t = 0; t < T && !done; t++) {
         int a = 0; float ca[7] = {0};
         if (is_discrete) a = ((const int32_t *)actions)[t];

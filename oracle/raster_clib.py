@@ -7,11 +7,12 @@ from . import clib
 
 
 def render(kind, state, h=64, w=64, multi_view=False):
-    """kind 0..3 mobile family (state [n][6]: x y tx ty t2x t2y), 4 kuka (state [n][10]: q7 bq bx by)."""
+    """kind 0..3 mobile family (state [n][6]: x y tx ty t2x t2y), 4 kuka (state [n][10]: q7 bq bx by),
+    6 kuka with two buttons (state [n][13]: q7 bq bx by b2q b2x b2y)."""
     state = np.ascontiguousarray(state, dtype=np.float64)
     n = len(state)
-    assert state.shape == (n, 10 if kind == 4 else 6)
-    img = np.zeros((n, h, w, 6 if (multi_view and kind == 4) else 3), np.uint8)
+    assert state.shape == (n, {4: 10, 6: 13}.get(kind, 6))
+    img = np.zeros((n, h, w, 6 if (multi_view and kind >= 4) else 3), np.uint8)
     clib.lib().raster_oracle_render(int(kind), n, int(h), int(w), int(bool(multi_view)),
                                     state.ctypes.data_as(ctypes.c_void_p), img.ctypes.data_as(ctypes.c_void_p))
     return img

@@ -153,11 +153,12 @@ static void draw(const prim_t *prims, int np, const cam_t *c, int h, int w, int 
     }
 }
 
-/* kuka state per env: q[7], bq, bx, by; mobile state per env: x, y, tx, ty, t2x, t2y.  kind: 0..3 mobile family, 4 kuka. */
+/* kuka state per env: q[7], bq, bx, by (kind 4) + b2q, b2x, b2y (kind 6, Kuka2Button); mobile state per env: x, y, tx, ty,
+ * t2x, t2y.  kind: 0..3 mobile family, 4 kuka, 6 kuka with two buttons. */
 int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const double *state, uint8_t *img) {
-    int e, ncam = (kind == 4 && multi_view) ? 2 : 1, channels = 3 * ncam;
+    int e, ncam = (kind >= 4 && multi_view) ? 2 : 1, channels = 3 * ncam;
     cam_t cams[2];
-    if (kind == 4) {
+    if (kind >= 4) {
         const double t1[3] = {0.316, -0.2, -0.1}, t2[3] = {0.316, 0.316, -0.105};
         cams[0] = camera(t1, 1.1, 145, -36, 0, 60); cams[1] = camera(t2, 1.05, 32, -13, 0, 60);
     } else {
@@ -168,8 +169,8 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
 #pragma omp parallel for
     for (e = 0; e < n; e++) {
         prim_t prims[16]; int np = 0, cam;
-        if (kind == 4) {
-            const double *s = state + 10 * (size_t)e; double R[63], p[21], a[3], b[3]; float jp[7][3]; int i, k;
+        if (kind >= 4) {
+            const double *s = state + (kind == 6 ? 13 : 10) * (size_t)e; double R[63], p[21], a[3], b[3]; float jp[7][3]; int i, k;
             const double locs[5][3] = {{0, 0, 0.10}, {0, 0.030, 0.10}, {0, 0.020, 0.255}, {0, -0.030, 0.10}, {0, -0.020, 0.255}};
             float pts[5][3];
             kuka_oracle_fk(s, R, p);
@@ -182,6 +183,10 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
             prims[np++] = mk(P_BOX, 0.85f, 0.75f, 0.62f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);
             prims[np++] = mk(P_CYL, 0.0f, 1.0f, 0.0f, (float)s[8], (float)s[9], (float)KM_BUTTON_BASE_Z, 0.10f, 0, 0.03f, 0, 1, 0);
             prims[np++] = mk(P_CYL, 1.0f, 1.0f, 0.0f, (float)s[8], (float)s[9], (float)(KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + s[7]), 0.09f, 0, 0.03f, 0, 1, 0);
+            if (kind == 6) {   /* urdf/simple_button_2.urdf: cap rgba (0.2, 0.6, 0.38) */
+                prims[np++] = mk(P_CYL, 0.0f, 1.0f, 0.0f, (float)s[11], (float)s[12], (float)KM_BUTTON_BASE_Z, 0.10f, 0, 0.03f, 0, 1, 0);
+                prims[np++] = mk(P_CYL, 0.2f, 0.6f, 0.38f, (float)s[11], (float)s[12], (float)(KM_BUTTON_BASE_Z + KM_GLIDER_ORIGIN_Z + s[10]), 0.09f, 0, 0.03f, 0, 1, 0);
+            }
             prims[np++] = mk(P_CAPSULE, 0.35f, 0.35f, 0.38f, (float)KM_BASE_POS[0], (float)KM_BASE_POS[1], (float)KM_BASE_POS[2], jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
             for (i = 0; i < 6; i++) prims[np++] = mk(P_CAPSULE, 1.0f, 0.45f, 0.05f, jp[i][0], jp[i][1], jp[i][2], jp[i + 1][0], jp[i + 1][1], jp[i + 1][2], 0.06f, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], pts[0][0], pts[0][1], pts[0][2], 0.045f, 1, 0);

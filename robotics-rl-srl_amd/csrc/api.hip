@@ -127,7 +127,7 @@ extern "C" {
 int srlhip_abi_version(void) { return SRLHIP_ABI_VERSION; }
 
 int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
-    if (!cfg || env_kind < SRLHIP_ENV_MOBILE || env_kind > SRLHIP_ENV_KUKA_MOVING) return SRLHIP_EINVAL;
+    if (!cfg || env_kind < SRLHIP_ENV_MOBILE || env_kind > SRLHIP_ENV_LAST) return SRLHIP_EINVAL;
     memset(cfg, 0, sizeof *cfg);
     cfg->struct_size = (int32_t)sizeof *cfg;
     cfg->env_kind = env_kind;
@@ -140,6 +140,7 @@ int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
     cfg->rng_mode = SRLHIP_RNG_MT19937;
     cfg->auto_reset = 1;
     cfg->max_distance = env_kind >= SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
+    if (env_kind == SRLHIP_ENV_KUKA_2BUTTON) { cfg->max_distance = 2.0; cfg->force_down = 0; }   // kuka_2button_gym_env.py:29
     return 0;
 }
 
@@ -155,7 +156,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
         g_create_error = "create: srlhip_config.struct_size mismatch (ABI)"; return SRLHIP_EINVAL;
     }
     if (cfg->num_envs <= 0) { g_create_error = "create: num_envs must be positive"; return SRLHIP_EINVAL; }
-    if (cfg->env_kind < SRLHIP_ENV_MOBILE || cfg->env_kind > SRLHIP_ENV_KUKA_MOVING) {
+    if (cfg->env_kind < SRLHIP_ENV_MOBILE || cfg->env_kind > SRLHIP_ENV_LAST) {
         g_create_error = "create: unknown env_kind"; return SRLHIP_EINVAL;
     }
     if (cfg->rng_mode < SRLHIP_RNG_HOST || cfg->rng_mode > SRLHIP_RNG_MT19937) {

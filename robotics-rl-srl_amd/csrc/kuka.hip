@@ -17,12 +17,13 @@ namespace srl {
 using namespace kuka;
 
 constexpr int kWave = 64;
-constexpr int NDBL = 43, NINT = 7;
+constexpr int NDBL = 47, NINT = 9;
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
-enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42 };
+enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42,
+       D_B2Q = 43, D_B2QD = 44, D_B2X = 45, D_B2Y = 46 };      // second button (Kuka2ButtonGymEnv)
 // SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
-enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6 };
+enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6, I_GOAL = 7, I_NCONTACT2 = 8 };
 
 struct KukaState {
     double *d;          // [NDBL][n]
@@ -37,7 +38,12 @@ namespace {
 
 struct KukaParams { Cfg cfg; int32_t n; };
 
+template <int NB>
 __device__ __forceinline__ void load_env(const KukaState &s, int64_t n, int64_t e, Env &v) {
+    if constexpr (NB == 2) {
+        v.b2q = s.d[D_B2Q * n + e]; v.b2qd = s.d[D_B2QD * n + e]; v.b2x = s.d[D_B2X * n + e]; v.b2y = s.d[D_B2Y * n + e];
+        v.goal_id = s.i[I_GOAL * n + e]; v.n_contacts2 = s.i[I_NCONTACT2 * n + e]; v.contact_body1 = 0; v.contact_body2 = 0;
+    }
 #pragma unroll
     for (int k = 0; k < ND; k++) {
         v.q[k] = s.d[(D_Q + k) * n + e]; v.qd[k] = s.d[(D_QD + k) * n + e];
@@ -51,7 +57,12 @@ __device__ __forceinline__ void load_env(const KukaState &s, int64_t n, int64_t 
     v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
     v.terminated = s.i[I_TERM * n + e];
 }
+template <int NB>
 __device__ __forceinline__ void store_env(const KukaState &s, int64_t n, int64_t e, const Env &v) {
+    if constexpr (NB == 2) {
+        s.d[D_B2Q * n + e] = v.b2q; s.d[D_B2QD * n + e] = v.b2qd; s.d[D_B2X * n + e] = v.b2x; s.d[D_B2Y * n + e] = v.b2y;
+        s.i[I_GOAL * n + e] = v.goal_id; s.i[I_NCONTACT2 * n + e] = v.n_contacts2;
+    }
 #pragma unroll
     for (int k = 0; k < ND; k++) {
         s.d[(D_Q + k) * n + e] = v.q[k]; s.d[(D_QD + k) * n + e] = v.qd[k];
@@ -101,13 +112,13 @@ __device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, i
 // wave-level votes stay uniform; lane 0 publishes.
 __global__ void __launch_bounds__(kWave) kuka_settle_k(KukaParams p, KukaState s) {
     Scratch sc = make_scratch(s, p.n, threadIdx.x % p.n);
-    Env e;
+    Env e = {};
     initial_env(e);
     const double zero[3] = {0, 0, 0};
     double jt[ND];
 #pragma unroll
     for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
-    for (int i = 0; i < kNSettleSteps; i++) physics_step(e, p.cfg, sc, zero, p.cfg.action_joints != 0, jt);
+    for (int i = 0; i < kNSettleSteps; i++) physics_step<1>(e, p.cfg, sc, zero, p.cfg.action_joints != 0, jt);
     if (threadIdx.x == 0) pack_start(e, s.settled);
 }
 
@@ -116,18 +127,26 @@ __global__ void __launch_bounds__(kWave) kuka_starts_k(KukaParams p, KukaState s
     const int idx = blockIdx.x * kWave + threadIdx.x;
     if (idx >= s.nstarts) return;
     Scratch sc = make_scratch(s, p.n, idx % p.n);     // start states are limit- and contact-free: rows are never touched
-    Env e;
+    Env e = {};
     unpack_start(e, s.settled);
     e.bx = kButtonX; e.by = kButtonY; e.bz = kButtonBaseZ; e.bspeed = 0.0; e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
     e.bpos[0] = e.bpos[1] = e.bpos[2] = 0.0;
     const int base = p.cfg.is_discrete ? 6 : 2;
     int rem = idx;
-    for (int k = 0; k < kNInitActions; k++) { init_action_step(e, p.cfg, sc, rem % base); rem /= base; }
+    // motor / jt are declared outside the loop on purpose (see the note in kuka_env.hpp:reset_env)
+    double motor[3], jt[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
+    for (int k = 0; k < kNInitActions; k++) {
+        init_action_motor(p.cfg, rem % base, motor);
+        physics_step<1>(e, p.cfg, sc, motor, false, jt);
+        rem /= base;
+    }
     pack_start(e, s.starts + (int64_t)idx * kStartDoubles);
 }
 
-template <int MODE>
+template <int MODE, int NB>
 __global__ void __launch_bounds__(kWave)
 kuka_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand,
              int rand_stride, float *obs) {
@@ -138,9 +157,9 @@ kuka_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint
     Scratch sc = make_scratch(s, n, e);
     typename KRng<MODE>::type rng;
     krng_load<MODE>(rng, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
-    Env v;
-    reset_env(v, p.cfg, sc, rng, s.starts, s.settled);
-    store_env(s, n, e, v);
+    Env v = {};
+    reset_env<NB>(v, p.cfg, sc, rng, s.starts, s.settled);
+    store_env<NB>(s, n, e, v);
     krng_store<MODE>(rng, rs, e);
     st.ep_return[e] = 0.0; st.ep_length[e] = 0;
     if (obs) {
@@ -150,7 +169,7 @@ kuka_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint
 }
 
 // T consecutive VecEnv steps per launch (T == 1: the per-step entry point).
-template <int MODE>
+template <int MODE, int NB>
 __global__ void __launch_bounds__(kWave)
 kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                float *obs, float *rew, uint8_t *done_out, void *act_out) {
@@ -161,8 +180,8 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
     Scratch sc = make_scratch(s, n, e);
     typename KRng<MODE>::type rng;
     krng_load<MODE>(rng, rs, e, p.n, noise ? noise + e : nullptr);
-    Env v;
-    load_env(s, n, e, v);
+    Env v = {};
+    load_env<NB>(s, n, e, v);
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
     Philox act; act.k0 = rs.key[e]; act.k1 = rs.key[n + e]; act.ctr = rs.act_ctr[e]; act.stream = 1;
@@ -187,17 +206,17 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
             }
         }
         bool done;
-        const double reward = env_step(v, cfg, sc, rng, a, ca, &done);
+        const double reward = env_step<NB>(v, cfg, sc, rng, a, ca, &done);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
-            if (cfg.auto_reset) reset_env(v, cfg, sc, rng, s.starts, s.settled);
+            if (cfg.auto_reset) reset_env<NB>(v, cfg, sc, rng, s.starts, s.settled);
         }
         if (obs) observe(v, cfg, obs + row * od, 1);
         if (rew) rew[row] = (float)reward;
         if (done_out) done_out[row] = (uint8_t)done;
     }
-    store_env(s, n, e, v);
+    store_env<NB>(s, n, e, v);
     krng_store<MODE>(rng, rs, e);
     if (!actions) rs.act_ctr[e] = act.ctr;
     st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
@@ -208,10 +227,10 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
 __global__ void kuka_refresh_k(KukaState s, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    Env v;
-    load_env(s, n, e, v);
+    Env v = {};
+    load_env<1>(s, n, e, v);
     update_trig_and_gripper(v);
-    store_env(s, n, e, v);
+    store_env<1>(s, n, e, v);
 }
 
 KukaParams params_of(const Handle *h) {
@@ -221,7 +240,9 @@ KukaParams params_of(const Handle *h) {
     p.cfg.action_repeat = c.action_repeat; p.cfg.is_discrete = c.is_discrete; p.cfg.action_joints = c.action_joints;
     p.cfg.obs_mode = c.obs_mode; p.cfg.auto_reset = c.auto_reset; p.cfg.max_distance = c.max_distance;
     p.cfg.moving = c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0;
-    p.cfg.max_steps = p.cfg.moving ? 1500 : kMaxSteps;
+    p.cfg.two = c.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
+    p.cfg.max_steps = p.cfg.moving ? 1500 : p.cfg.two ? kMaxSteps2Button : kMaxSteps;
+    p.cfg.ik_damping = p.cfg.two ? kIkDampingDefault : kIkDamping;
     p.n = h->n;
     return p;
 }
@@ -237,7 +258,11 @@ int allow_lds(Handle *h, K kernel) {
 
 }  // namespace
 
-int kuka_reset_rand_count(const srlhip_config &c) { return (c.random_target ? 2 : 0) + (c.is_discrete ? 10 : 5); }
+int kuka_reset_rand_count(const srlhip_config &c) {
+    const int init = c.is_discrete ? 10 : 5;
+    if (c.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return (c.random_target ? 4 : 0) + 2 + init;   // kuka_2button_gym_env.py:55-70
+    return (c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0) + (c.random_target ? 2 : 0) + init;
+}
 
 int kuka_alloc(Handle *h) {
     KukaState *s = new KukaState();
@@ -248,11 +273,14 @@ int kuka_alloc(Handle *h) {
     if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
-    if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k)) ||
-        (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_HOST>)) || (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_PHILOX>)) ||
-        (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_MT19937>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_HOST>)) ||
-        (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_PHILOX>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_MT19937>)))
+    if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k))) return rc;
+#define SRL_ALLOW(NB)                                                                                                     \
+    if ((rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_HOST, NB>)) || (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_PHILOX, NB>)) ||     \
+        (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_MT19937, NB>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_HOST, NB>)) ||  \
+        (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_PHILOX, NB>)) || (rc = allow_lds(h, kuka_rollout_k<SRLHIP_RNG_MT19937, NB>))) \
         return rc;
+    if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) { SRL_ALLOW(2) } else { SRL_ALLOW(1) }
+#undef SRL_ALLOW
     KukaParams p = params_of(h);
     hipLaunchKernelGGL(kuka_settle_k, dim3(1), dim3(kWave), kLdsBytes, h->stream, p, *s);
     SRL_HIP_CHECK(h, hipGetLastError());
@@ -270,17 +298,22 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
     const int stride = kuka_reset_rand_count(h->cfg);
     float *obs = static_cast<float *>(d_obs);
+    const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
+#define SRL_RESET(MODE)                                                                                                          \
+    if (two) hipLaunchKernelGGL((kuka_reset_k<MODE, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
+    else hipLaunchKernelGGL((kuka_reset_k<MODE, 1>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_HOST:
             if (!d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
-            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_HOST>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+            SRL_RESET(SRLHIP_RNG_HOST)
             break;
         case SRLHIP_RNG_PHILOX:
-            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_PHILOX>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+            SRL_RESET(SRLHIP_RNG_PHILOX)
             break;
         default:
-            hipLaunchKernelGGL(kuka_reset_k<SRLHIP_RNG_MT19937>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs);
+            SRL_RESET(SRLHIP_RNG_MT19937)
     }
+#undef SRL_RESET
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -289,16 +322,21 @@ int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_
     KukaParams p = params_of(h);
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
     float *obs = static_cast<float *>(d_obs);
+    const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
+#define SRL_ROLLOUT(MODE)                                                                                                        \
+    if (two) hipLaunchKernelGGL((kuka_rollout_k<MODE, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out); \
+    else hipLaunchKernelGGL((kuka_rollout_k<MODE, 1>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX:
-            hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_PHILOX>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
+            SRL_ROLLOUT(SRLHIP_RNG_PHILOX)
             break;
         case SRLHIP_RNG_MT19937:
-            hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_MT19937>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
+            SRL_ROLLOUT(SRLHIP_RNG_MT19937)
             break;
         default:
             return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
     }
+#undef SRL_ROLLOUT
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -307,18 +345,23 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return kuka_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
     KukaParams p = params_of(h);
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
-    hipLaunchKernelGGL(kuka_rollout_k<SRLHIP_RNG_HOST>, grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, 1,
-                       d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, (void *)nullptr);
+    if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON)
+        hipLaunchKernelGGL((kuka_rollout_k<SRLHIP_RNG_HOST, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, 1,
+                           d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, (void *)nullptr);
+    else
+        hipLaunchKernelGGL((kuka_rollout_k<SRLHIP_RNG_HOST, 1>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, 1,
+                           d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, (void *)nullptr);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz; int64_t n; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y; int64_t n; int32_t two; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
     v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n; v->bz = s->d + D_BZ * n;
-    v->n = (int64_t)n;
+    v->b2q = s->d + D_B2Q * n; v->b2x = s->d + D_B2X * n; v->b2y = s->d + D_B2Y * n;
+    v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
 }
 
 int kuka_refresh(Handle *h) {
@@ -341,6 +384,10 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_GRIPPER: *dptr = s->d + D_GRIP * n; *count = 3; return 0;
         case SRLHIP_F_STEP_COUNT: *dptr = s->i + I_COUNTER * n; *elem = 4; return 0;
         case SRLHIP_F_KUKA_COUNTERS: *dptr = s->i + I_NCONTACT * n; *elem = 4; *count = 3; return 0;
+        case SRLHIP_F_KUKA_BUTTON_XY: *dptr = s->d + D_BX * n; *count = 2; return 0;
+        case SRLHIP_F_KUKA_BUTTON2_Q: *dptr = s->d + D_B2Q * n; *count = 2; return 0;
+        case SRLHIP_F_KUKA_BUTTON2_XY: *dptr = s->d + D_B2X * n; *count = 2; return 0;
+        case SRLHIP_F_KUKA_GOAL: *dptr = s->i + I_GOAL * n; *elem = 4; *count = 2; return 0;
     }
     return h->fail(SRLHIP_EINVAL, "unknown field for KukaButtonGymEnv");
 }

@@ -73,6 +73,12 @@ constexpr int kNSphere = 6;
 constexpr double kSphere[kNSphere][4] = {{0, 0.020, 0.255, 0.015}, {0, -0.020, 0.255, 0.015}, {0, 0.035, 0.200, 0.020},
                                          {0, -0.035, 0.200, 0.020}, {0, 0, 0.100, 0.060}, {0, 0, 0.0, 0.070}};
 constexpr double kIkDamping = 1e-5;
+// Kuka2Button calls calculateInverseKinematics with 7-entry null-space lists on a 12-DoF body and without jointDamping
+// (kuka.py:147-148): pybullet ignores null-space lists whose length is not the DoF count and then falls back to its
+// default damping [UNVERIFIED-MEMORY, DESIGN.md §Kuka2Button]
+constexpr double kIkDampingDefault = 0.5;
+constexpr double kButton1Y2B = 0.125, kButton2Y2B = -0.125, kZTable = -0.2;   // kuka_2button_gym_env.py:56-70
+constexpr int kMaxSteps2Button = 1500;
 constexpr double kIkMaxAngle = 45.0 * kPi / 180.0;
 constexpr double kTableTopZ = -0.195, kButtonBaseZ = -0.195, kButtonX = 0.5, kButtonY = 0.0;
 constexpr double kGliderOriginZ = 0.005, kGliderLower = 0.0, kGliderUpper = 0.01, kCapMass = 0.1;
@@ -132,12 +138,17 @@ struct Env {
     int32_t motor_on;          // button motor: 0 pybullet default velocity motor, 1 position target (step2)
     int32_t contact_button, contact_table;
     int32_t counter, n_contacts, n_outside, terminated;
+    // Kuka2ButtonGymEnv only (touched by the NB == 2 instantiations): second button, per-body contact flags
+    // (getContactPoints(button_uid[k], kuka) has no link filter there), goal bookkeeping
+    double b2q, b2qd, b2x, b2y;
+    int32_t contact_body1, contact_body2, goal_id, n_contacts2;
 };
 
 struct Cfg {
     int32_t random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, obs_mode, auto_reset;
     int32_t moving, max_steps;  // KukaMovingButtonGymEnv: moving = 1, max_steps = 1500
-    double max_distance;
+    int32_t two;                // Kuka2ButtonGymEnv: large workspace, default IK damping, max_steps = 1500
+    double max_distance, ik_damping;
 };
 
 SRL_HD void cross3(const double a[3], const double b[3], double o[3]) {
@@ -224,7 +235,7 @@ SRL_HD void update_trig_and_gripper(Env &e) {
 
 // ---------------------------------------------------------------- inverse kinematics
 // One damped-least-squares step towards (target, orientation quat(euler(0,-pi,0))): kuka.py:144-156.
-SRL_HD void ik_step(const Env &e, const Scratch &sc, const double R[9], const double p[3], double qdes[ND]) {
+SRL_HD void ik_step(const Env &e, const Scratch &sc, const double R[9], const double p[3], double damping, double qdes[ND]) {
     double ee[3], J[6][ND], dS[6];
     tip_point(R, p, kEePoint, ee);
 #pragma unroll
@@ -275,7 +286,7 @@ SRL_HD void ik_step(const Env &e, const Scratch &sc, const double R[9], const do
             for (int k = 0; k < 6; k++) s += J[k][i] * J[k][j];
             A[i][j] = s;
         }
-        A[i][i] += kIkDamping;
+        A[i][i] += damping;
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) s += J[k][i] * dS[k];
@@ -515,7 +526,7 @@ SRL_HD double sphere_cylinder(const double c[3], double rad, double bx, double b
 
 // generic (LDS) constraint row: arm Jacobian J, button Jacobian Jb
 SRL_HD void add_generic_row(const Scratch &sc, int &ngen, const double J[ND], double Jb, const double W[ND][ND],
-                            double desired, double pos_err, const Env &e, double lo, double hi) {
+                            double desired, double pos_err, const Env &e, double bqd, double lo, double hi) {
     if (ngen >= kMaxGenRows) return;
     const int base = ngen * ROW_STRIDE;
     ngen++;
@@ -532,7 +543,7 @@ SRL_HD void add_generic_row(const Scratch &sc, int &ngen, const double J[ND], do
     }
     const double wjb = Jb * (1.0 / kCapMass);
     D += Jb * wjb;
-    rel += Jb * e.bqd;
+    rel += Jb * bqd;              // velocity of the glider this row acts on
     const double dinv = 1.0 / D;
     sc.row(base + ROW_JB) = Jb; sc.row(base + ROW_WJB) = wjb; sc.row(base + ROW_DINV) = dinv;
     sc.row(base + ROW_RHS) = (desired - rel) * dinv + pos_err * dinv;
@@ -541,8 +552,11 @@ SRL_HD void add_generic_row(const Scratch &sc, int &ngen, const double J[ND], do
 
 // One Gauss-Seidel update of LDS row k in impulse space: the arm velocity change so far is
 // W lam + g with g = sum_l WJ_l mu_l, so J_k . dv = WJ_k . lam + J_k . g (+ the button part).
-SRL_HD void pgs_generic_row(const Scratch &sc, int k, const double lam[ND], double g[ND], double &dvb) {
+template <int NB>
+SRL_HD void pgs_generic_row(const Scratch &sc, int k, const double lam[ND], double g[ND], double &dvb1, double &dvb2, uint32_t bsel) {
     const int base = k * ROW_STRIDE;
+    const bool second = NB == 2 && ((bsel >> k) & 1u);      // the row's scalar Jacobian acts on button 2's glider
+    double dvb = second ? dvb2 : dvb1;
     double jdv = sc.row(base + ROW_JB) * dvb;
 #pragma unroll
     for (int i = 0; i < ND; i++) jdv += sc.row(base + ROW_WJ + i) * lam[i] + sc.row(base + ROW_J + i) * g[i];
@@ -554,17 +568,19 @@ SRL_HD void pgs_generic_row(const Scratch &sc, int k, const double lam[ND], doub
 #pragma unroll
     for (int i = 0; i < ND; i++) g[i] += delta * sc.row(base + ROW_WJ + i);
     dvb += delta * sc.row(base + ROW_WJB);
+    if (second) dvb2 = dvb; else dvb1 = dvb;
 }
 
 // ---------------------------------------------------------------- one physics step
 // Kuka.applyAction (kuka.py:118-187) followed by p.stepSimulation().
+template <int NB>
 SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double motor[3], bool joint_mode,
                          const double joint_targets[ND]) {
     const double dt = kDt;
     double R[9], p[3], w[3], vo[3], qdes[ND];
     fk_all(e, sc, R, p, w, vo);
     if (!joint_mode) {
-        const int b = cfg.random_target ? 0 : 1;
+        const int b = (cfg.random_target || cfg.two) ? 0 : 1;      // Kuka(small_constraints=False)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             double v = e.ee[k] + motor[k];
@@ -572,7 +588,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
             e.ee[k] = v;
         }
-        ik_step(e, sc, R, p, qdes);
+        ik_step(e, sc, R, p, cfg.two ? kIkDampingDefault : kIkDamping, qdes);
     } else {
 #pragma unroll
         for (int i = 0; i < ND; i++) qdes[i] = joint_targets[i];
@@ -609,6 +625,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
 #pragma unroll
     for (int i = 0; i < ND; i++) e.qd[i] += dt * qdd[i];
     e.bqd += dt * kGravityZ;
+    if constexpr (NB == 2) e.b2qd += dt * kGravityZ;
 
     // -- rows.  Register rows: 7 arm motors, button motor, button limit.  LDS rows: arm limits, contacts.
     double dinv[ND];
@@ -629,11 +646,11 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             for (int j = 0; j < ND; j++) J[j] = 0.0;
             if (pen_lo <= kLimitActivationVel * dt) {
                 J[i] = 1.0;
-                add_generic_row(sc, ngen, J, 0.0, W, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt, e, 0.0, kLimitMaxImpulse);
+                add_generic_row(sc, ngen, J, 0.0, W, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt, e, 0.0, 0.0, kLimitMaxImpulse);
             }
             if (pen_hi <= kLimitActivationVel * dt) {
                 J[i] = -1.0;
-                add_generic_row(sc, ngen, J, 0.0, W, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt, e, 0.0, kLimitMaxImpulse);
+                add_generic_row(sc, ngen, J, 0.0, W, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt, e, 0.0, 0.0, kLimitMaxImpulse);
             }
         }
     }
@@ -646,18 +663,34 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
         rhs_blo = ((pen_lo > 0 ? -pen_lo / dt : 0.0) - e.bqd) * dinvb + (pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt) * dinvb;
         rhs_bhi = ((pen_hi > 0 ? -pen_hi / dt : 0.0) + e.bqd) * dinvb + (pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt) * dinvb;
     }
+    // second button (NB == 2): same scalar rows on its own glider
+    double rhs_bm2 = 0.0, app_bm2 = 0.0, rhs_b2lo = 0.0, app_b2lo = 0.0, rhs_b2hi = 0.0, app_b2hi = 0.0, cap2_z0 = 0.0;
+    uint32_t bsel = 0;          // bit k: generic row k pushes on button 2's glider
+    if constexpr (NB == 2) {
+        cap2_z0 = e.bz + kGliderOriginZ + e.b2q;
+        if (e.motor_on) rhs_bm2 = (kButtonKp * (kButtonTarget - e.b2q) / dt - e.b2qd) * dinvb;
+        else rhs_bm2 = (0.0 - e.b2qd) * dinvb;
+        const double pen_lo = e.b2q - kGliderLower, pen_hi = kGliderUpper - e.b2q;
+        rhs_b2lo = ((pen_lo > 0 ? -pen_lo / dt : 0.0) - e.b2qd) * dinvb + (pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt) * dinvb;
+        rhs_b2hi = ((pen_hi > 0 ? -pen_hi / dt : 0.0) + e.b2qd) * dinvb + (pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt) * dinvb;
+        e.contact_body1 = 0; e.contact_body2 = 0;
+    }
     e.contact_button = 0; e.contact_table = 0;
     // walk the kinematics again for contact Jacobians only when some sphere is close
     for (int s = 0; s < kNSphere; s++) {
         const double rad = kSphere[s][3];
         if (cc[s][2] - rad - kTableTopZ < kContactThreshold) e.contact_table = 1;
-        for (int shape = 0; shape < 2; shape++) {
+        for (int sh = 0; sh < 2 * NB; sh++) {
             double n[3];
+            const int shape = sh & 1;                                   // 0 cap, 1 base
+            const bool b2 = NB == 2 && sh >= 2;
+            const double bx_ = b2 ? e.b2x : e.bx, by_ = b2 ? e.b2y : e.by, cz0 = b2 ? cap2_z0 : cap_z0;
             const double dist = shape == 0
-                ? sphere_cylinder(cc[s], rad, e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n)
-                : sphere_cylinder(cc[s], rad, e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n);
+                ? sphere_cylinder(cc[s], rad, bx_, by_, kCapRadius, cz0, cz0 + kCapHeight, n)
+                : sphere_cylinder(cc[s], rad, bx_, by_, kBaseRadius, e.bz, e.bz + kBaseHeight, n);
             if (!(dist < kContactThreshold)) continue;
-            if (shape == 0) e.contact_button = 1;
+            if (shape == 0 && !b2) e.contact_button = 1;
+            if constexpr (NB == 2) { if (b2) e.contact_body2 = 1; else e.contact_body1 = 1; }
             double pt[3], J[ND];
 #pragma unroll
             for (int k = 0; k < 3; k++) pt[k] = cc[s][k] - rad * n[k];
@@ -671,7 +704,8 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             }
             const double allow = dist > 0 ? -dist / dt : 0.0;
             const double pos_err = dist > 0 ? 0.0 : -dist * kErp / dt;
-            add_generic_row(sc, ngen, J, shape == 0 ? -n[2] : 0.0, W, allow, pos_err, e, 0.0, 1e10);
+            if (b2 && ngen < kMaxGenRows) bsel |= 1u << ngen;
+            add_generic_row(sc, ngen, J, shape == 0 ? -n[2] : 0.0, W, allow, pos_err, e, b2 ? e.b2qd : e.bqd, 0.0, 1e10);
         }
     }
     // -- projected Gauss-Seidel, 150 sweeps.  Row order: arm motors, button motor, arm limits, button
@@ -686,7 +720,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     // with cur_i = cs_i - sum_{j<i} Ws_ij lam_j(this sweep) - sum_{j>i} Ws_ij lam_j(previous sweep): the only
     // dependent chain per row is fma -> max -> min.  The three scalar button rows clamp the impulse increment
     // against (lo - applied, hi - applied), known one sweep ahead: fma -> max -> min -> fma.
-    double Ws[ND][ND], lam[ND], g[ND], cs[ND], cur[ND], nxt[ND], dvb = 0.0;
+    double Ws[ND][ND], lam[ND], g[ND], cs[ND], cur[ND], nxt[ND], dvb = 0.0, dvb2 = 0.0;
 #pragma unroll
     for (int i = 0; i < ND; i++) {
         lam[i] = 0.0; g[i] = 0.0; cs[i] = (target[i] - e.qd[i]) * dinv[i]; cur[i] = cs[i]; nxt[i] = 0.0;
@@ -694,12 +728,16 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
         for (int j = 0; j < ND; j++) Ws[i][j] = j == i ? 0.0 : SRL_W(i, j) * dinv[i];
     }
     const double blim = kLimitMaxImpulse;
-#define SRL_BUTTON_ROW(app, rhs, jsign, lo, hi)                                          \
+#define SRL_BUTTON_ROW_ON(dv_, app, rhs, jsign, lo, hi)                                  \
     {                                                                                    \
-        const double d__ = fmin(fmax((rhs) - (jsign) * dvb * dinvb, (lo) - (app)), (hi) - (app)); \
-        dvb += (jsign) * d__ * wb;                                                       \
+        const double d__ = fmin(fmax((rhs) - (jsign) * (dv_) * dinvb, (lo) - (app)), (hi) - (app)); \
+        (dv_) += (jsign) * d__ * wb;                                                     \
         (app) += d__;                                                                    \
     }
+#define SRL_BUTTON_ROW(app, rhs, jsign, lo, hi) SRL_BUTTON_ROW_ON(dvb, app, rhs, jsign, lo, hi)
+    // the scalar rows of button 2 only touch dvb2, so their position relative to button 1's scalar rows is immaterial
+#define SRL_BUTTON2_MOTOR  if constexpr (NB == 2) { SRL_BUTTON_ROW_ON(dvb2, app_bm2, rhs_bm2, 1.0, -bound_bm, bound_bm) }
+#define SRL_BUTTON2_LIMITS if constexpr (NB == 2) { SRL_BUTTON_ROW_ON(dvb2, app_b2lo, rhs_b2lo, 1.0, 0.0, blim) SRL_BUTTON_ROW_ON(dvb2, app_b2hi, rhs_b2hi, -1.0, 0.0, blim) }
     // FUSED = 1: cs is constant over the solve, so next sweep's partial sum starts from cs at its first term
 #define SRL_ARM_ROWS(FUSED)                                                              \
     _Pragma("unroll") for (int j = 0; j < ND; j++) {                                     \
@@ -718,6 +756,8 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
             SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
             SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+            SRL_BUTTON2_MOTOR
+            SRL_BUTTON2_LIMITS
 #pragma unroll
             for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
             cur[ND - 1] = cs[ND - 1];
@@ -737,26 +777,29 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             rDinv[k] = has ? sc.row(base + ROW_DINV) : 0.0; rRhs[k] = has ? sc.row(base + ROW_RHS) : 0.0;
             rLo[k] = has ? sc.row(base + ROW_LO) : 0.0; rHi[k] = has ? sc.row(base + ROW_HI) : 0.0; rMu[k] = 0.0;
         }
+        const bool rSel[2] = {NB == 2 && (bsel & 1u) != 0, NB == 2 && (bsel & 2u) != 0};
         const bool second = SRL_ANY(ngen > 1);
         for (int it = 0; it < kSolverIters; it++) {
             SRL_ARM_ROWS(0)
             SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
             SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
             SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+            SRL_BUTTON2_MOTOR
+            SRL_BUTTON2_LIMITS
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 if (k == 1 && !second) break;
-                double jdv = rJb[k] * dvb;
+                double jdv = rJb[k] * (rSel[k] ? dvb2 : dvb);
 #pragma unroll
                 for (int i = 0; i < ND; i++) jdv += rWJ[k][i] * lam[i] + rJ[k][i] * g[i];
                 const double d = fmin(fmax(rRhs[k] - jdv * rDinv[k], rLo[k] - rMu[k]), rHi[k] - rMu[k]);
                 rMu[k] += d;
 #pragma unroll
                 for (int i = 0; i < ND; i++) g[i] += d * rWJ[k][i];
-                dvb += d * rWJb[k];
+                if (rSel[k]) dvb2 += d * rWJb[k]; else dvb += d * rWJb[k];
             }
             for (int k = 2; SRL_ANY(k < ngen); k++)
-                if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
+                if (k < ngen) pgs_generic_row<NB>(sc, k, lam, g, dvb, dvb2, bsel);
 #pragma unroll
             for (int i = 0; i < ND; i++) { cs[i] = ((target[i] - e.qd[i]) - g[i]) * dinv[i]; cur[i] = cs[i] + nxt[i]; nxt[i] = 0.0; }
         }
@@ -765,18 +808,23 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
         for (int it = 0; it < kSolverIters; it++) {
             SRL_ARM_ROWS(0)
             SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
+            SRL_BUTTON2_MOTOR
             for (int k = 0; SRL_ANY(k < nlim); k++)
-                if (k < nlim) pgs_generic_row(sc, k, lam, g, dvb);
+                if (k < nlim) pgs_generic_row<NB>(sc, k, lam, g, dvb, dvb2, bsel);
             SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
             SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+            SRL_BUTTON2_LIMITS
             for (int k = nlim; SRL_ANY(k < ngen); k++)
-                if (k < ngen) pgs_generic_row(sc, k, lam, g, dvb);
+                if (k < ngen) pgs_generic_row<NB>(sc, k, lam, g, dvb, dvb2, bsel);
 #pragma unroll
             for (int i = 0; i < ND; i++) { cs[i] = ((target[i] - e.qd[i]) - g[i]) * dinv[i]; cur[i] = cs[i] + nxt[i]; nxt[i] = 0.0; }
         }
     }
 #undef SRL_ARM_ROWS
 #undef SRL_BUTTON_ROW
+#undef SRL_BUTTON_ROW_ON
+#undef SRL_BUTTON2_MOTOR
+#undef SRL_BUTTON2_LIMITS
     double dv[ND];
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -791,6 +839,7 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     for (int i = 0; i < ND; i++) { e.qd[i] += dv[i]; e.q[i] += dt * e.qd[i]; }
     e.bqd += dvb;
     e.bq += dt * e.bqd;
+    if constexpr (NB == 2) { e.b2qd += dvb2; e.b2q += dt * e.b2qd; }
     update_trig_and_gripper(e);
 }
 

@@ -1,6 +1,8 @@
 // kuka_env.hpp — env-level logic of KukaButtonGymEnv on top of kuka_core.hpp:
 //   reset   kuka_button_gym_env.py:214-281   (settled state + 5 random init actions)
 //   step    :293-340, step2 :342-368, _termination :422-426, _reward :428-463, getSRLState :175-189
+// and of its variants: KukaMovingButtonGymEnv (runtime flag cfg.moving) and Kuka2ButtonGymEnv
+// (kuka_2button_gym_env.py:33-200; compile-time NB == 2: a second button body, goal switching, its own reward).
 //
 // Reset is O(1) on the device.  The 500 settle steps are RNG- and contact-free,
 // and each of the 5 init actions is one of only six (sign, axis) moves of 0.03 m
@@ -44,21 +46,17 @@ SRL_HD void initial_env(Env &e) {
     e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = kButtonBaseZ; e.bspeed = 0.0;
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    e.b2q = 0.0; e.b2qd = 0.0; e.b2x = kButtonX; e.b2y = kButton2Y2B;
+    e.contact_body1 = 0; e.contact_body2 = 0; e.goal_id = 0; e.n_contacts2 = 0;
     update_trig_and_gripper(e);
 }
 
-// one init action of reset(): code = sign_bit * 3 + axis (discrete) or sign_bit (continuous)
-SRL_HD void init_action_step(Env &e, const Cfg &cfg, const Scratch &sc, int code) {
-    double motor[3] = {0, 0, 0};
-    if (cfg.is_discrete) {
-        const double sign = code >= 3 ? 1.0 : -1.0;
-        const int axis = code % 3;
-        motor[axis] += sign * kDeltaV;
-    } else {
-        const double dir = code ? 1.0 : -1.0;
-        motor[0] += kDeltaVContinuous * dir; motor[1] += kDeltaVContinuous * dir; motor[2] += kDeltaVContinuous * dir;
-    }
-    physics_step(e, cfg, sc, motor, false, motor);
+// one init action of reset(): code = sign_bit * 3 + axis (discrete) or sign_bit (continuous) -> Cartesian increment
+SRL_HD void init_action_motor(const Cfg &cfg, int code, double motor[3]) {
+    const int axis = code % 3;
+    const double sign = code >= 3 ? 1.0 : -1.0, dir = code ? 1.0 : -1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) motor[k] = cfg.is_discrete ? (k == axis ? sign * kDeltaV : 0.0) : kDeltaVContinuous * dir;
 }
 
 SRL_HD double norm3(const double a[3], const double b[3]) {      // np.linalg.norm(a - b, 2): ddot with fma
@@ -66,6 +64,31 @@ SRL_HD double norm3(const double a[3], const double b[3]) {      // np.linalg.no
     return sqrt(fma(d2, d2, fma(d1, d1, fma(d0, d0, 0.0))));
 }
 SRL_HD bool termination(const Env &e, const Cfg &cfg) { return e.terminated || e.counter > cfg.max_steps; }
+
+// Kuka2ButtonGymEnv._reward (kuka_2button_gym_env.py:141-200).  bpos = button_all_pos[goal_id].
+SRL_HD double reward_two(Env &e, const Cfg &cfg) {
+    const double distance = norm3(e.bpos, e.grip);
+    const int contact = e.goal_id ? e.contact_body2 : e.contact_body1;
+    int reward = 0;
+    if (e.goal_id) { e.n_contacts2 += contact; reward = contact; }      // sparse reward only on the last button
+    else e.n_contacts += contact;
+    if (e.goal_id == 0 && e.n_contacts >= kNContactsBeforeTermination) {  // first button pressed: switch the goal
+        e.goal_id = 1;
+        e.bpos[0] = e.b2x; e.bpos[1] = e.b2y;                             // z is Z_TABLE + 0.28 for both
+    }
+    if (distance > cfg.max_distance || e.contact_table) { reward = -1; e.n_outside += 1; }
+    else e.n_outside = 0;
+    if (e.contact_table || e.n_contacts2 >= kNContactsBeforeTermination || e.n_outside >= kNStepsOutside - 1) e.terminated = 1;
+    if (cfg.shape_reward) {
+        const int nc_goal = e.goal_id ? e.n_contacts2 : e.n_contacts;
+        if (e.terminated && reward > 0) return 50.0;
+        if (nc_goal < kNContactsBeforeTermination && contact) return 25.0;
+        if (e.contact_table) return -250.0;
+        if (distance > cfg.max_distance) return -20.0;
+        return -distance;
+    }
+    return (double)reward;
+}
 
 SRL_HD double reward_fn(Env &e, const Cfg &cfg) {
     const double distance = norm3(e.bpos, e.grip);
@@ -93,24 +116,32 @@ struct HostDraws {
 };
 
 // KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.
-template <class R>
+template <int NB, class R>
 SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const double *starts, const double *settled) {
-    double bx = kButtonX, by = kButtonY, speed = 0.0;
+#pragma clang fp contract(off)   // wrapper arithmetic is numpy's: unfused (physics_step keeps the file's setting)
+    double bx = kButtonX, by = kButtonY, speed = 0.0, b2x = kButtonX, b2y = kButton2Y2B;
     if (cfg.moving) speed = 0.001 * (rng.bounded(1) ? 1.0 : -1.0);   // BUTTON_SPEED * np_random.choice([-1, 1]), drawn first
-    if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
+    if constexpr (NB == 2) {                                          // kuka_2button_gym_env.py:55-70
+        if (cfg.random_target) { (void)rng.uniform(-1, 1); (void)rng.uniform(0, 1); }   // overwritten two lines later
+        bx = 0.5 + 0.0 * rng.uniform(-1, 1); by = kButton1Y2B + 0.0 * rng.uniform(-1, 1);
+        if (cfg.random_target) { b2x += 0.15 * rng.uniform(-1, 1); b2y += 0.175 * rng.uniform(-1, 0); }
+    } else if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     if (!cfg.is_discrete && cfg.action_joints) {
         unpack_start(e, settled);
         e.bx = bx; e.by = by; e.bz = kButtonBaseZ;
+        if constexpr (NB == 2) { e.b2x = b2x; e.b2y = b2y; e.b2q = e.bq; e.b2qd = e.bqd; }
         // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1) per init action,
         // broadcast over the joints.  All five are drawn before the physics steps.
         double g[kNInitActions];
         for (int k = 0; k < kNInitActions; k++) g[k] = rng.normal(7.0, 1.0);
+        // (arrays handed to physics_step live outside the loop: per-iteration locals next to the inlined step have been
+        //  seen to be mis-coloured onto live state by the gfx950 backend, DESIGN.md §Kuka kernel, compiler notes)
+        double joints[ND], motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
-            double joints[ND], motor[3] = {0, 0, 0};
 #pragma unroll
             for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * g[k];
-            physics_step(e, cfg, sc, motor, true, joints);
+            physics_step<NB>(e, cfg, sc, motor, true, joints);
         }
     } else {
         int idx = 0, mul = 1;
@@ -130,10 +161,12 @@ SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const d
         }
         unpack_start(e, starts + (int64_t)idx * kStartDoubles);
         e.bx = bx; e.by = by;
+        if constexpr (NB == 2) { e.b2x = b2x; e.b2y = b2y; e.b2q = e.bq; e.b2qd = e.bqd; }   // same urdf, same free steps
     }
     e.bz = kButtonBaseZ; e.bspeed = speed;
     e.bpos[0] = bx; e.bpos[1] = by;
     e.bpos[2] = kButtonBaseZ + kGliderOriginZ + e.bq + kButtonDistanceHeight;
+    if constexpr (NB == 2) { e.bpos[2] = kZTable + kButtonDistanceHeight; e.goal_id = 0; e.n_contacts2 = 0; e.contact_body1 = 0; e.contact_body2 = 0; }
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
 }
 
@@ -146,8 +179,9 @@ SRL_HD void observe(const Env &e, const Cfg &cfg, float *o, int64_t stride) {   
 }
 
 // KukaButtonGymEnv.step + step2.  action < 0 == None.  Returns the reward; *done = _termination().
-template <class R>
+template <int NB, class R>
 SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int action, const float *ca, bool *done) {
+#pragma clang fp contract(off)
     double motor[3] = {0, 0, 0}, joints[ND];
     bool joint_mode = false;
     if (cfg.moving) {                                            // kuka_moving_button_gym_env.py:111-119
@@ -177,11 +211,11 @@ SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int ac
     }
     e.motor_on = 1;
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        physics_step(e, cfg, sc, motor, joint_mode, joints);
+        physics_step<NB>(e, cfg, sc, motor, joint_mode, joints);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }
-    const double reward = reward_fn(e, cfg);
+    const double reward = NB == 2 ? reward_two(e, cfg) : reward_fn(e, cfg);
     *done = termination(e, cfg);
     return reward;
 }

@@ -15,7 +15,7 @@ using namespace srl;
 using namespace srl::kuka;
 
 namespace {
-int g_moving = 0;
+int g_moving = 0, g_two = 0;
 struct MtHost {     // host-side generator over a private SoA view with stride 1
     std::vector<uint32_t> words;
     int32_t mti, has_g; double g;
@@ -47,7 +47,7 @@ void build_tables(const Cfg &cfg, std::vector<double> &settled, std::vector<doub
     const double zero[3] = {0, 0, 0};
     double jt[ND];
     for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
-    for (int i = 0; i < kNSettleSteps; i++) physics_step(e, cfg, sc, zero, cfg.action_joints != 0, jt);
+    for (int i = 0; i < kNSettleSteps; i++) physics_step<1>(e, cfg, sc, zero, cfg.action_joints != 0, jt);
     settled.resize(kStartDoubles);
     pack_start(e, settled.data());
     if (!cfg.is_discrete && cfg.action_joints) return;
@@ -56,12 +56,17 @@ void build_tables(const Cfg &cfg, std::vector<double> &settled, std::vector<doub
     for (int idx = 0; idx < nstarts; idx++) {
         Env s = e;
         int rem = idx;
-        for (int k = 0; k < kNInitActions; k++) { init_action_step(s, cfg, sc, rem % base); rem /= base; }
+        for (int k = 0; k < kNInitActions; k++) {
+            double motor[3];
+            init_action_motor(cfg, rem % base, motor);
+            physics_step<1>(s, cfg, sc, motor, false, jt);
+            rem /= base;
+        }
         pack_start(s, starts.data() + (size_t)idx * kStartDoubles);
     }
 }
 
-template <class R>
+template <int NB, class R>
 void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const void *actions, const double *settled,
              const double *starts, float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out, void *act_out,
              double *q_trace, double *grip_trace, double *final_state, double *ep_stats) {
@@ -71,7 +76,7 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
     Env env;
     memset(&env, 0, sizeof env);
-    reset_env(env, cfg, sc, rng, starts, settled);
+    reset_env<NB>(env, cfg, sc, rng, starts, settled);
     if (obs0) observe(env, cfg, obs0 + (size_t)e_idx * od, 1);
     double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
     for (int t = 0; t < T; t++) {
@@ -89,13 +94,13 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
             }
             if (act_out) { if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a; else memcpy(static_cast<float *>(act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = env_step(env, cfg, sc, rng, a, ca, &done);
+        const double reward = env_step<NB>(env, cfg, sc, rng, a, ca, &done);
         if (q_trace) memcpy(q_trace + row * ND, env.q, sizeof(double) * ND);
         if (grip_trace) memcpy(grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
-            if (cfg.auto_reset) reset_env(env, cfg, sc, rng, starts, settled);
+            if (cfg.auto_reset) reset_env<NB>(env, cfg, sc, rng, starts, settled);
         }
         if (obs) observe(env, cfg, obs + row * od, 1);
         if (rew) rew[row] = (float)reward;
@@ -103,10 +108,11 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
         if (done_out) done_out[row] = (uint8_t)done;
     }
     if (final_state) {
-        double *f = final_state + 24 * (size_t)e_idx;
+        double *f = final_state + 30 * (size_t)e_idx;
         for (int j = 0; j < ND; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
         f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
         f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
+        if (NB == 2) { f[24] = env.b2q; f[25] = env.b2qd; f[26] = env.goal_id; f[27] = env.n_contacts2; f[28] = env.b2x; f[29] = env.b2y; }
     }
     if (ep_stats) { ep_stats[3 * (size_t)e_idx] = last_ret; ep_stats[3 * (size_t)e_idx + 1] = last_len; ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
 }
@@ -124,23 +130,27 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
-    cfg.moving = g_moving; cfg.max_steps = g_moving ? 1500 : kMaxSteps;
+    cfg.moving = g_moving; cfg.two = g_two; cfg.max_steps = g_moving ? 1500 : g_two ? kMaxSteps2Button : kMaxSteps;
+    cfg.ik_damping = g_two ? kIkDampingDefault : kIkDamping;
     std::vector<double> settled, starts;
     build_tables(cfg, settled, starts);
     for (int e = 0; e < n; e++) {
         Philox act; act.k0 = (uint32_t)(uint64_t)seeds[e]; act.k1 = (uint32_t)((uint64_t)seeds[e] >> 32); act.ctr = 0; act.stream = 1;
         if (rng_mode == 2) {
             MtHost r; r.seed(mt_keys + 2 * (size_t)e, mt_key_len[e]);
-            run_env(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
+            if (g_two) run_env<2>(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
+            else run_env<1>(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
         } else {
             PhHost r; r.p = act; r.p.stream = 0;
-            run_env(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
+            if (g_two) run_env<2>(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
+            else run_env<1>(cfg, r, act, T, n, e, actions, settled.data(), starts.data(), obs0, obs, rew, rew64, done_out, act_out, q_trace, grip_trace, final_state, ep_stats);
         }
     }
     return 0;
 }
 
-extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; }
+extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; g_two = 0; }
+extern "C" void hostcheck_kuka_set_variant(int v) { g_moving = v == 1; g_two = v == 2; }
 
 extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, double *out22) {
     Cfg cfg; memset(&cfg, 0, sizeof cfg);
@@ -154,8 +164,9 @@ extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, dou
         Env e; initial_env(e);
         const double zero[3] = {0, 0, 0}; double jt[ND];
         for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
-        cfg.is_discrete = 1; cfg.action_joints = action_joints; cfg.moving = 0; cfg.max_steps = kMaxSteps;
-        for (int i = 0; i < kNSettleSteps; i++) physics_step(e, cfg, sc, zero, action_joints != 0, jt);
+        cfg.is_discrete = 1; cfg.action_joints = action_joints; cfg.moving = 0; cfg.two = g_two; cfg.max_steps = kMaxSteps;
+        cfg.ik_damping = g_two ? kIkDampingDefault : kIkDamping;
+        for (int i = 0; i < kNSettleSteps; i++) physics_step<1>(e, cfg, sc, zero, action_joints != 0, jt);
         for (int j = 0; j < ND; j++) { out22[j] = e.q[j]; out22[7 + j] = e.qd[j]; }
         out22[14] = e.ee[0]; out22[15] = e.ee[1]; out22[16] = e.ee[2]; out22[17] = e.bq; out22[18] = e.bqd;
         out22[19] = e.grip[0]; out22[20] = e.grip[1]; out22[21] = e.grip[2];

@@ -24,7 +24,7 @@
 namespace srl {
 
 // KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz; int64_t n; };     // sq/cq: [7][n]
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y; int64_t n; int32_t two; };     // sq/cq: [7][n]
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
@@ -200,6 +200,11 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     set_prim(prims[k++], PRIM_BOX, 0.85f, 0.75f, 0.62f, 0.5f, 0.0f, -0.22f, 0.75f, 0.5f, 0.025f, 0, 1.0f, 0.0f);     // table top
     set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, bx, by, (float)v.bz[e], 0.10f, 0, 0.03f, 0, 1, 0);              // button base
     set_prim(prims[k++], PRIM_CYL, 1.0f, 1.0f, 0.0f, bx, by, cap_z, 0.09f, 0, 0.03f, 0, 1, 0);                       // button cap
+    if (v.two) {                                                      // urdf/simple_button_2.urdf: cap rgba (0.2, 0.6, 0.38)
+        const float b2x = (float)v.b2x[e], b2y = (float)v.b2y[e], cap2_z = (float)(v.bz[e] + kGliderOriginZ + v.b2q[e]);
+        set_prim(prims[k++], PRIM_CYL, 0.0f, 1.0f, 0.0f, b2x, b2y, (float)v.bz[e], 0.10f, 0, 0.03f, 0, 1, 0);
+        set_prim(prims[k++], PRIM_CYL, 0.2f, 0.6f, 0.38f, b2x, b2y, cap2_z, 0.09f, 0, 0.03f, 0, 1, 0);
+    }
     set_prim(prims[k++], PRIM_CAPSULE, 0.35f, 0.35f, 0.38f, (float)kBasePos[0], (float)kBasePos[1], (float)kBasePos[2],
              jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
     for (int i = 0; i < ND - 1; i++)

@@ -97,6 +97,7 @@ struct Mt19937 {
     }
     // legacy_gauss (polar Box-Muller, caches the second deviate)
     SRL_HD double std_normal() {
+#pragma clang fp contract(off)
         if (has_g) { double t = g; g = 0.0; has_g = 0; return t; }
         double x1, x2, r2;
         do {
@@ -108,8 +109,14 @@ struct Mt19937 {
         g = f * x1; has_g = 1;
         return f * x2;
     }
-    SRL_HD double normal(double loc, double scale) { return loc + scale * std_normal(); }
-    SRL_HD double uniform(double low, double high) { return low + (high - low) * double01(); }
+    SRL_HD double normal(double loc, double scale) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+        return loc + scale * std_normal();
+    }
+    SRL_HD double uniform(double low, double high) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+        return low + (high - low) * double01();
+    }
     // RandomState.randint(0, rng+1): masked rejection on 32-bit draws (rng < 2^32)
     SRL_HD uint32_t bounded(uint32_t rng) {
         if (rng == 0) return 0;
@@ -151,15 +158,22 @@ struct Philox {
         return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
     }
     SRL_HD double double01() { uint32_t o[4]; block(o); return to_double(o[0], o[1]); }
-    SRL_HD double uniform(double low, double high) { return low + (high - low) * double01(); }
+    SRL_HD double uniform(double low, double high) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+        return low + (high - low) * double01();
+    }
     // Box-Muller on one block, no caching (counter-based streams stay random-access)
     SRL_HD double std_normal() {
+#pragma clang fp contract(off)
         uint32_t o[4]; block(o);
         double u1 = 1.0 - to_double(o[0], o[1]);   // (0, 1]
         double u2 = to_double(o[2], o[3]);
         return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
     }
-    SRL_HD double normal(double loc, double scale) { return loc + scale * std_normal(); }
+    SRL_HD double normal(double loc, double scale) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+        return loc + scale * std_normal();
+    }
     SRL_HD uint32_t bounded(uint32_t rng) {       // multiply-shift into [0, rng]
         uint32_t o[4]; block(o);
         return (uint32_t)(((uint64_t)o[0] * ((uint64_t)rng + 1)) >> 32);

@@ -5,6 +5,7 @@ from environments import PlottingType, ThreadingType
 from environments.srl_env import SRLGymEnv
 from environments.kuka_gym.kuka_button_gym_env import KukaButtonGymEnv
 from environments.kuka_gym.kuka_moving_button_gym_env import KukaMovingButtonGymEnv
+from environments.kuka_gym.kuka_2button_gym_env import Kuka2ButtonGymEnv
 from environments.mobile_robot.mobile_robot_env import MobileRobotGymEnv
 from environments.mobile_robot.mobile_robot_2target_env import MobileRobot2TargetGymEnv
 from environments.mobile_robot.mobile_robot_1D_env import MobileRobot1DGymEnv
@@ -13,6 +14,7 @@ from environments.mobile_robot.mobile_robot_line_target_env import MobileRobotLi
 registered_env = {
     "KukaButtonGymEnv-v0":            (KukaButtonGymEnv, SRLGymEnv, PlottingType.PLOT_3D, ThreadingType.PROCESS),
     "KukaMovingButtonGymEnv-v0":      (KukaMovingButtonGymEnv, KukaButtonGymEnv, PlottingType.PLOT_3D, ThreadingType.PROCESS),
+    "Kuka2ButtonGymEnv-v0":           (Kuka2ButtonGymEnv, KukaButtonGymEnv, PlottingType.PLOT_3D, ThreadingType.PROCESS),
     "MobileRobotGymEnv-v0":           (MobileRobotGymEnv, SRLGymEnv, PlottingType.PLOT_2D, ThreadingType.PROCESS),
     "MobileRobot2TargetGymEnv-v0":    (MobileRobot2TargetGymEnv, MobileRobotGymEnv, PlottingType.PLOT_2D, ThreadingType.PROCESS),
     "MobileRobot1DGymEnv-v0":         (MobileRobot1DGymEnv, MobileRobotGymEnv, PlottingType.PLOT_2D, ThreadingType.PROCESS),

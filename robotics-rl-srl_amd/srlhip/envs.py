@@ -402,9 +402,34 @@ class KukaMovingButtonGymEnv(KukaButtonGymEnv):
         self.max_steps = 1500
 
 
+class Kuka2ButtonGymEnv(KukaButtonGymEnv):
+    """environments/kuka_gym/kuka_2button_gym_env.py:Kuka2ButtonGymEnv — two buttons pressed in order (y = +0.125 first,
+    then the darker one at y = -0.125); ctor defaults max_distance=2, force_down=False (:29), max_steps 1500 (:3, :33)."""
+    ENV_KIND = _lib.ENV_KUKA_2BUTTON
+
+    def __init__(self, name="kuka_2button_gym", max_distance=2, force_down=False, **kwargs):
+        super(Kuka2ButtonGymEnv, self).__init__(name=name, max_distance=max_distance, force_down=force_down, **kwargs)
+        self.max_steps = 1500
+
+    @property
+    def n_contacts(self):
+        return [int(self._f(_lib.F_KUKA_COUNTERS)[0, 0]), int(self._f(_lib.F_KUKA_GOAL)[1, 0])]
+
+    @property
+    def goal_id(self):
+        return int(self._f(_lib.F_KUKA_GOAL)[0, 0])
+
+    @property
+    def button_all_pos(self):
+        z = self.button_pos[2]
+        b1, b2 = self._f(_lib.F_KUKA_BUTTON_XY)[:, 0], self._f(_lib.F_KUKA_BUTTON2_XY)[:, 0]
+        return [np.array([b1[0], b1[1], z]), np.array([b2[0], b2[1], z])]
+
+
 ENV_CLASSES = {
     "KukaButtonGymEnv-v0": KukaButtonGymEnv,
     "KukaMovingButtonGymEnv-v0": KukaMovingButtonGymEnv,
+    "Kuka2ButtonGymEnv-v0": Kuka2ButtonGymEnv,
     "MobileRobotGymEnv-v0": MobileRobotGymEnv,
     "MobileRobot2TargetGymEnv-v0": MobileRobot2TargetGymEnv,
     "MobileRobot1DGymEnv-v0": MobileRobot1DGymEnv,

@@ -26,6 +26,10 @@ def set_moving(flag):
     lib().hostcheck_kuka_set_moving(int(bool(flag)))
 
 
+def set_variant(variant):
+    lib().hostcheck_kuka_set_variant(int(variant))
+
+
 def rollout(seeds, T, actions=None, **kw):
     """Same arguments / outputs as oracle.kuka_clib.rollout, computed by the kernel source on the host."""
     fake = types.SimpleNamespace(kuka_oracle_rollout=lib().hostcheck_kuka_rollout)

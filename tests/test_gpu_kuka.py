@@ -222,3 +222,49 @@ def test_moving_button_env():
     env.step(0)
     assert abs(abs(env.getTargetPos()[1] - y0) - 0.001) < 1e-12 and env.max_steps == 1500
     env.close()
+
+
+def test_two_button_env():
+    """Kuka2ButtonGymEnv-v0 on the GPU (NB = 2 kernels: second button body, goal switching) vs the oracle, whose wrapper
+    logic is pinned to the reference source (tests/test_kuka_2button_golden.py).  Env 0 presses both buttons in order."""
+    from test_kuka_kernel_source_on_host import two_button_actions
+    n, T = 128, 1600
+    actions = two_button_actions(n, T)
+    for kw in (dict(), dict(shape_reward=1, random_target=1)):
+        cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
+        assert cfg.max_distance == 2.0 and cfg.force_down == 0
+        cfg.num_envs, cfg.seed0 = n, 60
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = _lib.Handle(cfg)
+        obs0 = h.reset()
+        b2_xy0 = h.get_state(_lib.F_KUKA_BUTTON2_XY).copy()
+        out = h.rollout(T, actions=actions)
+        kuka_clib.set_variant(kuka_clib.VARIANT_TWO)
+        try:
+            ora = kuka_clib.rollout(60 + np.arange(n), T, actions=actions, force_down=False, max_distance=2.0,
+                                    shape_reward=bool(kw.get("shape_reward")), random_target=bool(kw.get("random_target")), trace=False)
+        finally:
+            kuka_clib.set_variant(kuka_clib.VARIANT_BUTTON)
+        check_planes(ora, obs0, out, flags_exact=not kw)
+        ret, length, fin = h.episode_stats()
+        assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)) and np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32))
+        fs = ora["final_state"]
+        goal = h.get_state(_lib.F_KUKA_GOAL)
+        assert np.array_equal(goal[0], fs[:, 26].astype(np.int32)) and np.array_equal(goal[1], fs[:, 27].astype(np.int32))
+        assert np.abs(h.get_state(_lib.F_KUKA_BUTTON2_Q).T - fs[:, 24:26]).max() <= TOL
+        assert np.array_equal(h.get_state(_lib.F_KUKA_BUTTON2_XY).T, fs[:, 28:30])           # reset draws: bit-exact
+        if not kw:
+            assert (b2_xy0.T == [0.5, -0.125]).all()
+            first = int(np.argmax(out["done"][:, 0]))
+            assert out["done"][first, 0] and out["reward"][first, 0] == 1.0 and out["reward"][:first, 0].sum() == 4
+            assert length[1] == 1501                                                          # idle env: counter > 1500
+        h.close()
+    from environments.registry import registered_env
+    env = registered_env["Kuka2ButtonGymEnv-v0"][0](srl_model="ground_truth")
+    env.seed(1)
+    o = env.reset()
+    assert env.max_steps == 1500 and env.goal_id == 0 and env.n_contacts == [0, 0] and o.shape == (3,)
+    assert np.allclose(env.button_all_pos[0], [0.5, 0.125, 0.08]) and np.allclose(env.button_all_pos[1], [0.5, -0.125, 0.08])
+    assert np.array_equal(env.getTargetPos(), env.button_all_pos[0])
+    env.close()

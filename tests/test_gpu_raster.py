@@ -81,3 +81,24 @@ def test_facade_render_and_raw_pixel_vec_env():
     o, r, d, info = venv.step([0] * 16)
     assert len(venv.get_images()) == 16
     venv.close()
+
+
+def test_two_button_images_match_oracle():
+    """Kuka2ButtonGymEnv scene: the second button (simple_button_2.urdf colours) is rendered at its drawn position."""
+    n = 32
+    cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
+    cfg.num_envs, cfg.seed0, cfg.random_target = n, 4, 1
+    cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, 64, 64
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+
+    def state():
+        s = kuka_state(h)
+        return np.concatenate([s, h.get_state(_lib.F_KUKA_BUTTON2_Q)[0][:, None], h.get_state(_lib.F_KUKA_BUTTON2_XY).T], axis=1)
+    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64))
+    dark_green = (obs[..., 0] < 80) & (obs[..., 1] > 100) & (obs[..., 2] > 50) & (obs[..., 2] < 130)
+    assert dark_green.reshape(n, -1).sum(1).min() > 20          # the darker second cap is visible in every env
+    for t in range(30):
+        obs, r, d = h.step(np.full(n, 4, np.int32))
+    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64))
+    h.close()

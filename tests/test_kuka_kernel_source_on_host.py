@@ -87,3 +87,40 @@ def test_moving_button_variant():
         assert a["ep_stats"][:, 1].max() == 1501                        # counter > 1500
     finally:
         kuka_clib.set_moving(False); hostcheck.set_moving(False)
+
+
+def two_button_actions(n, T, seed=5):
+    """random walks, plus scripted envs that press button 1 (y = +0.125), come back up and press button 2"""
+    actions = np.random.RandomState(seed).randint(6, size=(T, n)).astype(np.int32)
+    # the arm follows its IK target at <= 0.35 rad/s per joint (~1 mm per step): move, then wait with None actions
+    script = [3] * 4 + [0] * 2 + [4] * 17 + [-1] * 420 + [5] * 10 + [-1] * 160 + [2] * 9 + [-1] * 260 + [4] * 10
+    actions[:len(script), 0] = script
+    actions[len(script):, 0] = -1
+    actions[:, 1] = -1                                                  # idles into the 1500-step limit
+    script2 = [2] * 4 + [4] * 50                                        # presses the wrong (second) button first
+    actions[:len(script2), 2] = script2
+    return actions
+
+
+def test_two_button_variant():
+    """Kuka2ButtonGymEnv (kuka_2button_gym_env.py): two button bodies, goal switching after 5 contacts with the first,
+    episode ends after 5 contacts with the second, large workspace, default-damping IK, 1500-step limit."""
+    n, T = 8, 1600
+    actions = two_button_actions(n, T)
+    try:
+        kuka_clib.set_variant(2); hostcheck.set_variant(2)
+        for kw in (dict(force_down=False, max_distance=2.0), dict(force_down=False, max_distance=2.0, shape_reward=True, random_target=True)):
+            a = kuka_clib.rollout(60 + np.arange(n), T, actions=actions, **kw)
+            b = hostcheck.rollout(60 + np.arange(n), T, actions=actions, **kw)
+            compare(a, b)
+            assert np.abs(a["reward64"] - b["reward64"]).max() <= TOL
+            assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])      # goal_id, n_contacts[1]
+            assert np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL  # second glider
+            assert np.array_equal(a["final_state"][:, 28:30], b["final_state"][:, 28:30])      # second button position
+            if not kw.get("random_target"):
+                first = np.argmax(a["done"][:, 0])
+                assert a["done"][first, 0] and 900 < first < 1400 and a["reward"][first, 0] == 1.0   # both buttons pressed in order
+                assert a["reward"][:first, 0].sum() == 4 and (a["reward"][:first, 0] != 0).sum() == 4   # sparse: last button only
+        assert a["ep_stats"][:, 1].max() == 1501
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
