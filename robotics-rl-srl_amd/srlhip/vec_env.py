@@ -36,7 +36,7 @@ class HipVecEnv(object):
         cfg.is_discrete = int(kw.get("is_discrete", True))
         cfg.random_target = int(kw.get("random_target", False))
         cfg.shape_reward = int(kw.get("shape_reward", False))
-        cfg.force_down = int(kw.get("force_down", True))
+        cfg.force_down = int(kw.get("force_down", bool(cfg.force_down)))      # ctor default differs per env (Kuka2Button: False)
         cfg.action_repeat = int(kw.get("action_repeat", 1))
         cfg.action_joints = int(kw.get("action_joints", False))
         cfg.multi_view = int(kw.get("multi_view", False))
