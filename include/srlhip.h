@@ -53,7 +53,8 @@ extern "C" {
 #define SRLHIP_ENV_KUKA_BUTTON     4  /* KukaButtonGymEnv-v0             */
 #define SRLHIP_ENV_KUKA_MOVING     5  /* KukaMovingButtonGymEnv-v0 (kuka_moving_button_gym_env.py) */
 #define SRLHIP_ENV_KUKA_2BUTTON    6  /* Kuka2ButtonGymEnv-v0 (kuka_2button_gym_env.py): two buttons pressed in order */
-#define SRLHIP_ENV_LAST            SRLHIP_ENV_KUKA_2BUTTON
+#define SRLHIP_ENV_KUKA_RAND       7  /* KukaRandButtonGymEnv-v0 (kuka_rand_button_gym_env.py): distractor objects as scenery */
+#define SRLHIP_ENV_LAST            SRLHIP_ENV_KUKA_RAND
 
 /* ---- observation modes: kuka_button_gym_env.py:162-173 ------------------ */
 #define SRLHIP_OBS_GROUND_TRUTH     0  /* f32[obs_dim] relative position        */
@@ -168,6 +169,7 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_KUKA_BUTTON2_Q 24  /* f64[2]  Kuka2Button: second glider position, velocity */
 #define SRLHIP_F_KUKA_BUTTON2_XY 25 /* f64[2]  Kuka2Button: second button base position */
 #define SRLHIP_F_KUKA_GOAL      26  /* i32[2]  Kuka2Button: goal_id, n_contacts[1] (n_contacts[0] is COUNTERS[0]) */
+#define SRLHIP_F_KUKA_OBJECTS   27  /* f64[30] KukaRandButton: (x, y, present) of the ten distractor objects */
 int srlhip_get_state(srlhip_handle h, int32_t field, void *out);
 int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
 /* Zero-copy hand-off of a field's device array (e.g. to torch via

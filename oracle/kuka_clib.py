@@ -30,11 +30,11 @@ def set_moving(flag):
     _lib().kuka_oracle_set_moving(int(bool(flag)))
 
 
-VARIANT_BUTTON, VARIANT_MOVING, VARIANT_TWO = 0, 1, 2
+VARIANT_BUTTON, VARIANT_MOVING, VARIANT_TWO, VARIANT_RAND = 0, 1, 2, 3
 
 
 def set_variant(variant):
-    """0 KukaButtonGymEnv, 1 KukaMovingButtonGymEnv, 2 Kuka2ButtonGymEnv for the following calls."""
+    """0 KukaButtonGymEnv, 1 KukaMovingButtonGymEnv, 2 Kuka2ButtonGymEnv, 3 KukaRandButtonGymEnv for the following calls."""
     _lib().kuka_oracle_set_variant(int(variant))
 
 
@@ -135,6 +135,13 @@ def last_buttons():
     """button base positions (b1x b1y b2x b2y) drawn by the reset() of the last command_trace call"""
     out = np.zeros(4)
     _lib().kuka_oracle_last_buttons(_p(out))
+    return out
+
+
+def last_objects():
+    """KukaRandButton: (x, y, present) of the ten distractors drawn by the reset() of the last command_trace call"""
+    out = np.zeros((10, 3))
+    _lib().kuka_oracle_last_objects(_p(out))
     return out
 
 

@@ -10,6 +10,10 @@
  *   _termination :422-426       _reward :428-463     getSRLState :175-189
  *   Kuka2ButtonGymEnv           .../kuka_2button_gym_env.py:33-200 (reset draws, two buttons, goal switching, reward)
  *   KukaMovingButtonGymEnv      .../kuka_moving_button_gym_env.py
+ *   KukaRandButtonGymEnv        .../kuka_rand_button_gym_env.py:38-127: the 20 extra np_random draws of reset() and the
+ *                               placement rule of the ten distractor objects.  The objects (duck / lego / cube meshes,
+ *                               types drawn from the GLOBAL unseeded np.random) and the pushed ball are free rigid bodies
+ *                               inside pybullet; here they are scenery (recorded for the renderer, no dynamics).
  * Out-of-tree arithmetic restated from the dependency's PUBLISHED algorithm
  * (pybullet==1.8.6 / Bullet 2.87, absent here -> PARITY UNPINNED for this part):
  *   p.calculateInverseKinematics  one damped-least-squares step (BussIK DLS)
@@ -273,9 +277,11 @@ typedef struct {
     int contact_body[2];           /* any link (cap or base) of button k touches the arm: getContactPoints(button_uid[k], kuka) */
     int goal_id, n_contacts2;      /* n_contacts[0] lives in n_contacts */
     double all_pos[2][3];          /* button_all_pos */
+    /* KukaRandButtonGymEnv: distractor objects (x, y, present) in draw order */
+    double obj_xy[10][2]; int obj_present[10];
 } kenv;
 
-typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving, two; double max_distance; } kcfg;
+typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving, two, rand_objects; double max_distance; } kcfg;
 
 /* ------------------------------------------------------------------ collision */
 /* signed distance between a sphere and an upright solid cylinder (axis z, centre xy, z in [z0, z1]);
@@ -502,6 +508,13 @@ static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) { 
         if (cfg->random_target) { b2x += 0.15 * k_uniform(r, -1, 1); b2y += 0.175 * k_uniform(r, -1, 0); }
     } else if (cfg->random_target) { bx += 0.15 * k_uniform(r, -1, 1); by += 0.3 * k_uniform(r, -1, 1); }
     *e = *settled;
+    if (cfg->rand_objects) {                                       /* kuka_rand_button_gym_env.py:62-69 */
+        for (i = 0; i < 10; i++) {
+            double ox = 0.5 + 0.15 * k_uniform(r, -1, 1), oy = 0 + 0.3 * k_uniform(r, -1, 1);
+            e->obj_xy[i][0] = ox; e->obj_xy[i][1] = oy;
+            e->obj_present[i] = (ox < bx - 0.1) || (ox > bx + 0.1) || (oy < by - 0.1) || (oy > by + 0.1);
+        }
+    }
     e->button_xy[0] = bx; e->button_xy[1] = by; e->button_z = KM_BUTTON_BASE_Z; e->button_speed = speed;
     e->button2_xy[0] = b2x; e->button2_xy[1] = b2y; e->b2q = e->bq; e->b2qd = e->bqd;   /* same urdf, same 500 free steps */
     for (i = 0; i < KM_N_RANDOM_ACTIONS_AT_INIT; i++) {
@@ -575,10 +588,11 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
     { double reward = reward_fn(e, cfg); *done = termination_cfg(e, cfg); return reward; }
 }
 
-static int g_moving = 0, g_two = 0;
-/* selects KukaMovingButtonGymEnv / Kuka2ButtonGymEnv semantics for the following calls (tests are single-threaded callers) */
-void kuka_oracle_set_moving(int moving) { g_moving = moving; g_two = 0; }
-void kuka_oracle_set_variant(int variant) { g_moving = variant == 1; g_two = variant == 2; }
+static int g_moving = 0, g_two = 0, g_rand = 0;
+/* selects KukaMovingButtonGymEnv (1) / Kuka2ButtonGymEnv (2) / KukaRandButtonGymEnv (3) semantics for the following calls
+ * (tests are single-threaded callers) */
+void kuka_oracle_set_moving(int moving) { g_moving = moving; g_two = 0; g_rand = 0; }
+void kuka_oracle_set_variant(int variant) { g_moving = variant == 1; g_two = variant == 2; g_rand = variant == 3; }
 
 /* ------------------------------------------------------------------ batch entry points */
 /* Rollout of n envs, T steps each, auto-reset (VecEnv worker semantics).
@@ -596,7 +610,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
     const int od = obs_mode == 1 ? 14 : obs_mode == 2 ? 17 : 3, adim = is_discrete ? 1 : action_joints ? 7 : 3;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
-    cfg.max_distance = max_distance; cfg.moving = g_moving; cfg.two = g_two;
+    cfg.max_distance = max_distance; cfg.moving = g_moving; cfg.two = g_two; cfg.rand_objects = g_rand;
     settle(&settled, &cfg);
 #pragma omp parallel for schedule(dynamic, 4)
     for (e = 0; e < n; e++) {
@@ -693,7 +707,9 @@ void kuka_oracle_wrapper_step_two(double *state8, const double *gripper, const d
     state8[4] = e.goal_id; state8[5] = e.n_contacts2;
 }
 
-static double g_last_buttons[4];
+static double g_last_buttons[4], g_last_objects[30];
+/* KukaRandButton: (x, y, present) of the ten distractors drawn by the reset() of the last kuka_oracle_command_trace call */
+void kuka_oracle_last_objects(double *out30) { memcpy(out30, g_last_objects, sizeof g_last_objects); }
 /* button base positions drawn by the reset() of the last kuka_oracle_command_trace call: b1x b1y b2x b2y */
 void kuka_oracle_last_buttons(double *out4) { memcpy(out4, g_last_buttons, sizeof g_last_buttons); }
 
@@ -704,12 +720,13 @@ int kuka_oracle_command_trace(int is_discrete, int action_joints, int random_tar
                               int mt_key_len, int T, const void *actions, double *ee_trace, double *jt_trace, int *n_reset_cmds) {
     kcfg cfg; kenv settled, env; krng *r = (krng *)malloc(sizeof(krng)); int t, done = 0;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = 0; cfg.action_repeat = 1;
-    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = g_two ? 2.0 : 0.8; cfg.moving = g_moving; cfg.two = g_two;
+    cfg.is_discrete = is_discrete; cfg.action_joints = action_joints; cfg.max_distance = g_two ? 2.0 : 0.8; cfg.moving = g_moving; cfg.two = g_two; cfg.rand_objects = g_rand;
     settle(&settled, &cfg);
     r->mode = 2; np_rng_seed_array(&r->mt, mt_key, mt_key_len);
     g_trace_ee = ee_trace; g_trace_jt = jt_trace; g_trace_n = 0;
     env_reset(&env, &cfg, r, &settled);
     *n_reset_cmds = g_trace_n;
+    { int k; for (k = 0; k < 10; k++) { g_last_objects[3 * k] = env.obj_xy[k][0]; g_last_objects[3 * k + 1] = env.obj_xy[k][1]; g_last_objects[3 * k + 2] = env.obj_present[k]; } }
     g_last_buttons[0] = env.button_xy[0]; g_last_buttons[1] = env.button_xy[1]; g_last_buttons[2] = env.button2_xy[0]; g_last_buttons[3] = env.button2_xy[1];
     for (t = 0; t < T && !done; t++) {
         int a = 0; float ca[7] = {0};

@@ -8,10 +8,11 @@ from . import clib
 
 def render(kind, state, h=64, w=64, multi_view=False):
     """kind 0..3 mobile family (state [n][6]: x y tx ty t2x t2y), 4 kuka (state [n][10]: q7 bq bx by),
-    6 kuka with two buttons (state [n][13]: q7 bq bx by b2q b2x b2y)."""
+    6 kuka with two buttons (state [n][13]: q7 bq bx by b2q b2x b2y), 7 kuka with the RandButton distractors
+    (state [n][40]: q7 bq bx by + (x, y, present) x 10)."""
     state = np.ascontiguousarray(state, dtype=np.float64)
     n = len(state)
-    assert state.shape == (n, {4: 10, 6: 13}.get(kind, 6))
+    assert state.shape == (n, {4: 10, 6: 13, 7: 40}.get(kind, 6))
     img = np.zeros((n, h, w, 6 if (multi_view and kind >= 4) else 3), np.uint8)
     clib.lib().raster_oracle_render(int(kind), n, int(h), int(w), int(bool(multi_view)),
                                     state.ctypes.data_as(ctypes.c_void_p), img.ctypes.data_as(ctypes.c_void_p))

@@ -116,7 +116,7 @@ inline int obs_dim_of(const srlhip_config &c) {
     switch (c.env_kind) {
         case SRLHIP_ENV_MOBILE_1D: return 1;
         case SRLHIP_ENV_MOBILE: case SRLHIP_ENV_MOBILE_2TARGET: case SRLHIP_ENV_MOBILE_LINE: return 2;
-        case SRLHIP_ENV_KUKA_BUTTON: case SRLHIP_ENV_KUKA_MOVING: case SRLHIP_ENV_KUKA_2BUTTON:
+        case SRLHIP_ENV_KUKA_BUTTON: case SRLHIP_ENV_KUKA_MOVING: case SRLHIP_ENV_KUKA_2BUTTON: case SRLHIP_ENV_KUKA_RAND:
             return c.obs_mode == SRLHIP_OBS_JOINTS ? 14 : c.obs_mode == SRLHIP_OBS_JOINTS_POSITION ? 17 : 3;
     }
     return 0;
@@ -125,7 +125,7 @@ inline int num_actions_of(const srlhip_config &c) {
     if (!c.is_discrete) return 0;
     switch (c.env_kind) {
         case SRLHIP_ENV_MOBILE_1D: return 2;
-        case SRLHIP_ENV_KUKA_BUTTON: case SRLHIP_ENV_KUKA_MOVING: case SRLHIP_ENV_KUKA_2BUTTON: return 6;
+        case SRLHIP_ENV_KUKA_BUTTON: case SRLHIP_ENV_KUKA_MOVING: case SRLHIP_ENV_KUKA_2BUTTON: case SRLHIP_ENV_KUKA_RAND: return 6;
         default: return 4;
     }
 }

@@ -29,6 +29,7 @@ struct KukaState {
     double *d;          // [NDBL][n]
     int32_t *i;         // [NINT][n]
     double *rows;       // [SC_ROWS_TOTAL][n]  generic constraint rows (global scratch, L2-resident)
+    double *objs;       // [30][n]  KukaRandButton distractor objects (x, y, present) x 10
     double *settled;    // [kStartDoubles]
     double *starts;     // [nstarts][kStartDoubles]
     int32_t nstarts;
@@ -104,7 +105,7 @@ extern __shared__ double kuka_lds[];
 
 __device__ __forceinline__ Scratch make_scratch(const KukaState &s, int64_t n, int64_t e) {
     Scratch sc;
-    sc.b = kuka_lds + threadIdx.x; sc.st = kWave; sc.g = s.rows + e; sc.gst = n;
+    sc.b = kuka_lds + threadIdx.x; sc.st = kWave; sc.g = s.rows + e; sc.gst = n; sc.objs = s.objs + e;
     return sc;
 }
 
@@ -241,8 +242,8 @@ KukaParams params_of(const Handle *h) {
     p.cfg.obs_mode = c.obs_mode; p.cfg.auto_reset = c.auto_reset; p.cfg.max_distance = c.max_distance;
     p.cfg.moving = c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0;
     p.cfg.two = c.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
+    p.cfg.rand_objects = c.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
     p.cfg.max_steps = p.cfg.moving ? 1500 : p.cfg.two ? kMaxSteps2Button : kMaxSteps;
-    p.cfg.ik_damping = p.cfg.two ? kIkDampingDefault : kIkDamping;
     p.n = h->n;
     return p;
 }
@@ -261,7 +262,7 @@ int allow_lds(Handle *h, K kernel) {
 int kuka_reset_rand_count(const srlhip_config &c) {
     const int init = c.is_discrete ? 10 : 5;
     if (c.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return (c.random_target ? 4 : 0) + 2 + init;   // kuka_2button_gym_env.py:55-70
-    return (c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0) + (c.random_target ? 2 : 0) + init;
+    return (c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0) + (c.random_target ? 2 : 0) + (c.env_kind == SRLHIP_ENV_KUKA_RAND ? 20 : 0) + init;
 }
 
 int kuka_alloc(Handle *h) {
@@ -270,7 +271,7 @@ int kuka_alloc(Handle *h) {
     const size_t n = (size_t)h->n;
     int rc;
     s->nstarts = (!h->cfg.is_discrete && h->cfg.action_joints) ? 0 : h->cfg.is_discrete ? kNumStartsDiscrete : kNumStartsContinuous;
-    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) ||
+    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) || (rc = h->dalloc(&s->objs, 30 * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
     if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k))) return rc;
@@ -355,13 +356,14 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y; int64_t n; int32_t two; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs; int64_t n; int32_t two, rand_objects; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
     v->sq = s->d + D_SQ * n; v->cq = s->d + D_CQ * n; v->bq = s->d + D_BQ * n; v->bx = s->d + D_BX * n; v->by = s->d + D_BY * n; v->bz = s->d + D_BZ * n;
     v->b2q = s->d + D_B2Q * n; v->b2x = s->d + D_B2X * n; v->b2y = s->d + D_B2Y * n;
     v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
+    v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
 }
 
 int kuka_refresh(Handle *h) {
@@ -388,6 +390,7 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_BUTTON2_Q: *dptr = s->d + D_B2Q * n; *count = 2; return 0;
         case SRLHIP_F_KUKA_BUTTON2_XY: *dptr = s->d + D_B2X * n; *count = 2; return 0;
         case SRLHIP_F_KUKA_GOAL: *dptr = s->i + I_GOAL * n; *elem = 4; *count = 2; return 0;
+        case SRLHIP_F_KUKA_OBJECTS: *dptr = s->objs; *count = 30; return 0;
     }
     return h->fail(SRLHIP_EINVAL, "unknown field for KukaButtonGymEnv");
 }

@@ -114,6 +114,7 @@ struct Scratch {
     int st;
     double *g;       // HBM (L2-resident) base of this env, [slot][env]: generic constraint rows.  They are written once
     int64_t gst;     // per physics step; the first two rows of a lane are then held in VGPRs for all 150 sweeps.
+    double *objs;    // KukaRandButton: [30][env] (x, y, present) of the distractor objects, stride gst; may be null
     SRL_HD double &at(int i) const { return b[(int64_t)i * st]; }
     // rows 0 and 1 (the common contact case) are staged in LDS, rows 2.. in the global scratch
     SRL_HD double &row(int i) const { return i < kLdsRows * ROW_STRIDE ? b[(int64_t)(SC_STAGE + i) * st] : g[(int64_t)i * gst]; }
@@ -148,7 +149,8 @@ struct Cfg {
     int32_t random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, obs_mode, auto_reset;
     int32_t moving, max_steps;  // KukaMovingButtonGymEnv: moving = 1, max_steps = 1500
     int32_t two;                // Kuka2ButtonGymEnv: large workspace, default IK damping, max_steps = 1500
-    double max_distance, ik_damping;
+    int32_t rand_objects;       // KukaRandButtonGymEnv: reset() draws ten distractor positions (scenery only)
+    double max_distance;
 };
 
 SRL_HD void cross3(const double a[3], const double b[3], double o[3]) {

@@ -126,6 +126,13 @@ SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const d
         bx = 0.5 + 0.0 * rng.uniform(-1, 1); by = kButton1Y2B + 0.0 * rng.uniform(-1, 1);
         if (cfg.random_target) { b2x += 0.15 * rng.uniform(-1, 1); b2y += 0.175 * rng.uniform(-1, 0); }
     } else if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
+    if (cfg.rand_objects) {                                           // kuka_rand_button_gym_env.py:62-69: two draws per candidate
+        for (int i = 0; i < 10; i++) {
+            const double ox = 0.5 + 0.15 * rng.uniform(-1, 1), oy = 0 + 0.3 * rng.uniform(-1, 1);
+            const bool keep = (ox < bx - 0.1) || (ox > bx + 0.1) || (oy < by - 0.1) || (oy > by + 0.1);
+            if (sc.objs) { sc.objs[(3 * i) * sc.gst] = ox; sc.objs[(3 * i + 1) * sc.gst] = oy; sc.objs[(3 * i + 2) * sc.gst] = keep ? 1.0 : 0.0; }
+        }
+    }
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     if (!cfg.is_discrete && cfg.action_joints) {
         unpack_start(e, settled);

@@ -15,7 +15,7 @@ using namespace srl;
 using namespace srl::kuka;
 
 namespace {
-int g_moving = 0, g_two = 0;
+int g_moving = 0, g_two = 0, g_rand = 0;
 struct MtHost {     // host-side generator over a private SoA view with stride 1
     std::vector<uint32_t> words;
     int32_t mti, has_g; double g;
@@ -41,7 +41,7 @@ struct PhHost {
 
 void build_tables(const Cfg &cfg, std::vector<double> &settled, std::vector<double> &starts) {
     std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
-    Scratch sc{scratch.data(), 1, rows.data(), 1};
+    Scratch sc{scratch.data(), 1, rows.data(), 1, nullptr};
     Env e;
     initial_env(e);
     const double zero[3] = {0, 0, 0};
@@ -71,7 +71,7 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
              const double *starts, float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out, void *act_out,
              double *q_trace, double *grip_trace, double *final_state, double *ep_stats) {
     std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
-    Scratch sc{scratch.data(), 1, rows.data(), 1};
+    Scratch sc{scratch.data(), 1, rows.data(), 1, nullptr};
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
     Env env;
@@ -131,7 +131,7 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
     cfg.moving = g_moving; cfg.two = g_two; cfg.max_steps = g_moving ? 1500 : g_two ? kMaxSteps2Button : kMaxSteps;
-    cfg.ik_damping = g_two ? kIkDampingDefault : kIkDamping;
+    cfg.rand_objects = g_rand;
     std::vector<double> settled, starts;
     build_tables(cfg, settled, starts);
     for (int e = 0; e < n; e++) {
@@ -149,8 +149,8 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     return 0;
 }
 
-extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; g_two = 0; }
-extern "C" void hostcheck_kuka_set_variant(int v) { g_moving = v == 1; g_two = v == 2; }
+extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; g_two = 0; g_rand = 0; }
+extern "C" void hostcheck_kuka_set_variant(int v) { g_moving = v == 1; g_two = v == 2; g_rand = v == 3; }
 
 extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, double *out22) {
     Cfg cfg; memset(&cfg, 0, sizeof cfg);
@@ -160,12 +160,11 @@ extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, dou
     cfg.action_joints = action_joints ? 1 : 1;
     {   // settle only
         std::vector<double> scratch(SC_TOTAL), rows(SC_ROWS_TOTAL);
-        Scratch sc{scratch.data(), 1, rows.data(), 1};
+        Scratch sc{scratch.data(), 1, rows.data(), 1, nullptr};
         Env e; initial_env(e);
         const double zero[3] = {0, 0, 0}; double jt[ND];
         for (int j = 0; j < ND; j++) jt[j] = kJointPositions[j];
-        cfg.is_discrete = 1; cfg.action_joints = action_joints; cfg.moving = 0; cfg.two = g_two; cfg.max_steps = kMaxSteps;
-        cfg.ik_damping = g_two ? kIkDampingDefault : kIkDamping;
+        cfg.is_discrete = 1; cfg.action_joints = action_joints; cfg.moving = 0; cfg.two = g_two; cfg.rand_objects = 0; cfg.max_steps = kMaxSteps;
         for (int i = 0; i < kNSettleSteps; i++) physics_step<1>(e, cfg, sc, zero, action_joints != 0, jt);
         for (int j = 0; j < ND; j++) { out22[j] = e.q[j]; out22[7 + j] = e.qd[j]; }
         out22[14] = e.ee[0]; out22[15] = e.ee[1]; out22[16] = e.ee[2]; out22[17] = e.bq; out22[18] = e.bqd;

@@ -24,13 +24,13 @@
 namespace srl {
 
 // KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y; int64_t n; int32_t two; };     // sq/cq: [7][n]
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs; int64_t n; int32_t two, rand_objects; };     // sq/cq: [7][n]
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
 
 constexpr int kRasterBlock = 256;
-constexpr int kMaxPrims = 16;
+constexpr int kMaxPrims = 28;   // Kuka scene 14 + second button 2 or ten distractors + ball 11
 constexpr int kTilePixels = 8192;       // LDS band buffer (24 KiB): whole 8-row tile strips, image width <= 1024
 
 enum { PRIM_PLANE = 0, PRIM_BOX = 1, PRIM_CYL = 2, PRIM_CAPSULE = 3 };
@@ -219,6 +219,22 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
     tip_point(R, p, fb0, a); tip_point(R, p, fb1, b);
     set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+    if (v.rand_objects) {
+        // KukaRandButtonGymEnv scenery (kuka_rand_button_gym_env.py:60-71): kept distractors resting on the table, and the
+        // ball at its drop position.  The reference draws the object TYPE from the global unseeded np.random; here it is a
+        // hash of the position: 0 duck (yellow blob), 1 lego (small red brick), 2 cube_small (5 cm cube).
+        const float top = (float)kTableTopZ;
+        for (int i = 0; i < 10; i++) {
+            const double ox = v.objs[(3 * i) * n + e], oy = v.objs[(3 * i + 1) * n + e];
+            if (v.objs[(3 * i + 2) * n + e] == 0.0) continue;
+            const uint32_t type = (uint32_t)(((uint64_t)__double_as_longlong(ox) >> 20) ^ ((uint64_t)__double_as_longlong(oy) >> 20)) % 3u;
+            const float x = (float)ox, y = (float)oy;
+            if (type == 0) set_prim(prims[k++], PRIM_CAPSULE, 1.0f, 0.85f, 0.1f, x - 0.015f, y, top + 0.035f, x + 0.015f, y, top + 0.035f, 0.035f, 1, 0);
+            else if (type == 1) set_prim(prims[k++], PRIM_BOX, 0.8f, 0.1f, 0.1f, x, y, top + 0.012f, 0.016f, 0.032f, 0.012f, 0, 1.0f, 0.0f);
+            else set_prim(prims[k++], PRIM_BOX, 0.9f, 0.9f, 0.9f, x, y, top + 0.025f, 0.025f, 0.025f, 0.025f, 0, 1.0f, 0.0f);
+        }
+        set_prim(prims[k++], PRIM_CAPSULE, 0.9f, 0.2f, 0.2f, 0.25f, -0.2f, top + 0.03f, 0.25f, -0.2f, top + 0.031f, 0.03f, 1, 0);   // sphere_small
+    }
     return k;
 }
 

@@ -12,13 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsrlhip.so")
 
 # ---- constants mirrored from include/srlhip.h --------------------------------
-ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON, ENV_KUKA_MOVING, ENV_KUKA_2BUTTON = range(7)
+ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON, ENV_KUKA_MOVING, ENV_KUKA_2BUTTON, ENV_KUKA_RAND = range(8)
 OBS_GROUND_TRUTH, OBS_JOINTS, OBS_JOINTS_POSITION, OBS_RAW_PIXELS = range(4)
 RNG_HOST, RNG_PHILOX, RNG_MT19937 = range(3)
 F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REWARD, F_EP_RETURN, F_EP_LENGTH = range(9)
 F_TARGET2_X, F_TARGET2_Y = 9, 10
 F_KUKA_Q, F_KUKA_QD, F_KUKA_EE_TARGET, F_KUKA_BUTTON_Q, F_KUKA_BUTTON_POS, F_KUKA_GRIPPER, F_KUKA_COUNTERS = range(16, 23)
-F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL = range(23, 27)
+F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS = range(23, 28)
 
 _FIELD_SHAPES = {
     F_POS_X: (np.float64, 1), F_POS_Y: (np.float64, 1), F_TARGET_X: (np.float64, 1), F_TARGET_Y: (np.float64, 1),
@@ -27,7 +27,7 @@ _FIELD_SHAPES = {
     F_KUKA_Q: (np.float64, 7), F_KUKA_QD: (np.float64, 7), F_KUKA_EE_TARGET: (np.float64, 3),
     F_KUKA_BUTTON_Q: (np.float64, 2), F_KUKA_BUTTON_POS: (np.float64, 3), F_KUKA_GRIPPER: (np.float64, 3),
     F_KUKA_COUNTERS: (np.int32, 3), F_KUKA_BUTTON_XY: (np.float64, 2), F_KUKA_BUTTON2_Q: (np.float64, 2),
-    F_KUKA_BUTTON2_XY: (np.float64, 2), F_KUKA_GOAL: (np.int32, 2),
+    F_KUKA_BUTTON2_XY: (np.float64, 2), F_KUKA_GOAL: (np.int32, 2), F_KUKA_OBJECTS: (np.float64, 30),
 }
 
 EXPORTS = [

@@ -426,8 +426,26 @@ class Kuka2ButtonGymEnv(KukaButtonGymEnv):
         return [np.array([b1[0], b1[1], z]), np.array([b2[0], b2[1], z])]
 
 
+class KukaRandButtonGymEnv(KukaButtonGymEnv):
+    """environments/kuka_gym/kuka_rand_button_gym_env.py:KukaRandButtonGymEnv — KukaButtonGymEnv plus ten randomly placed
+    distractor objects and a ball.  reset() consumes the reference's 20 extra np_random draws and applies its keep rule;
+    the objects are scenery for the rasteriser (their rigid-body dynamics, their types and the push on the ball come from
+    pybullet / the global unseeded np.random in the reference and are not modelled)."""
+    ENV_KIND = _lib.ENV_KUKA_RAND
+
+    def __init__(self, name="kuka_rand_button_gym", **kwargs):
+        super(KukaRandButtonGymEnv, self).__init__(name=name, **kwargs)
+        self.max_steps = 1000
+
+    @property
+    def objects(self):
+        """(x, y, present) of the ten candidate distractors of the current episode"""
+        return self._f(_lib.F_KUKA_OBJECTS)[:, 0].reshape(10, 3).copy()
+
+
 ENV_CLASSES = {
     "KukaButtonGymEnv-v0": KukaButtonGymEnv,
+    "KukaRandButtonGymEnv-v0": KukaRandButtonGymEnv,
     "KukaMovingButtonGymEnv-v0": KukaMovingButtonGymEnv,
     "Kuka2ButtonGymEnv-v0": Kuka2ButtonGymEnv,
     "MobileRobotGymEnv-v0": MobileRobotGymEnv,

@@ -63,7 +63,7 @@ def test_kuka_facade_against_oracle():
     env.close()
 
 
-@pytest.mark.parametrize("env_id", ["KukaButtonGymEnv-v0", "KukaMovingButtonGymEnv-v0", "Kuka2ButtonGymEnv-v0",
+@pytest.mark.parametrize("env_id", ["KukaButtonGymEnv-v0", "KukaMovingButtonGymEnv-v0", "Kuka2ButtonGymEnv-v0", "KukaRandButtonGymEnv-v0",
                                     "MobileRobotGymEnv-v0", "MobileRobot2TargetGymEnv-v0",
                                     "MobileRobot1DGymEnv-v0", "MobileRobotLineTargetGymEnv-v0"])
 def test_random_agent_through_createEnvs(env_id, tmp_path):

@@ -268,3 +268,31 @@ def test_two_button_env():
     assert np.allclose(env.button_all_pos[0], [0.5, 0.125, 0.08]) and np.allclose(env.button_all_pos[1], [0.5, -0.125, 0.08])
     assert np.array_equal(env.getTargetPos(), env.button_all_pos[0])
     env.close()
+
+
+def test_rand_button_env():
+    """KukaRandButtonGymEnv-v0 on the GPU vs the oracle (reset draws pinned to the reference source,
+    tests/test_kuka_rand_button_golden.py); distractor positions and keep flags are bit-exact."""
+    n, T = 128, 1100
+    actions = np.random.RandomState(41).randint(6, size=(T, n)).astype(np.int32)
+    cfg = _lib.default_config(_lib.ENV_KUKA_RAND)
+    cfg.num_envs, cfg.seed0, cfg.random_target = n, 80, 1
+    h = _lib.Handle(cfg)
+    obs0 = h.reset()
+    objs = h.get_state(_lib.F_KUKA_OBJECTS).T.reshape(n, 10, 3).copy()
+    bxy = h.get_state(_lib.F_KUKA_BUTTON_XY).T
+    keep = (objs[:, :, 0] < bxy[:, None, 0] - 0.1) | (objs[:, :, 0] > bxy[:, None, 0] + 0.1) | \
+           (objs[:, :, 1] < bxy[:, None, 1] - 0.1) | (objs[:, :, 1] > bxy[:, None, 1] + 0.1)
+    assert np.array_equal(objs[:, :, 2] > 0, keep) and (np.abs(objs[:, :, 0] - 0.5) <= 0.15).all() and (np.abs(objs[:, :, 1]) <= 0.3).all()
+    kuka_clib.set_variant(kuka_clib.VARIANT_RAND)
+    try:
+        tr = kuka_clib.command_trace(80, 1, np.zeros(1, np.int32), random_target=True)
+        assert np.array_equal(kuka_clib.last_objects(), objs[0])                            # env 0: same 20 draws
+        ora = kuka_clib.rollout(80 + np.arange(n), T, actions=actions, random_target=True, trace=False)
+    finally:
+        kuka_clib.set_variant(kuka_clib.VARIANT_BUTTON)
+    out = h.rollout(T, actions=actions)
+    check_planes(ora, obs0, out)
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)) and fin.min() >= 1
+    h.close()

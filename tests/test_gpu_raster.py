@@ -102,3 +102,18 @@ def test_two_button_images_match_oracle():
         obs, r, d = h.step(np.full(n, 4, np.int32))
     assert_images_equal(obs, raster_clib.render(6, state(), 64, 64))
     h.close()
+
+
+def test_rand_button_images_match_oracle():
+    """KukaRandButtonGymEnv scene: the kept distractors and the ball are rendered as scenery."""
+    n = 32
+    cfg = _lib.default_config(_lib.ENV_KUKA_RAND)
+    cfg.num_envs, cfg.seed0 = n, 6
+    cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, 64, 64
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    state = np.concatenate([kuka_state(h), h.get_state(_lib.F_KUKA_OBJECTS).T], axis=1)
+    assert_images_equal(obs, raster_clib.render(7, state, 64, 64))
+    plain = raster_clib.render(4, state[:, :10], 64, 64)
+    assert (obs != plain).reshape(n, -1).any(1).all()           # every env shows at least the ball
+    h.close()

@@ -35,7 +35,7 @@ def test_spaces():
 def test_registry_and_globals_surface():
     from environments.registry import registered_env
     from environments import PlottingType, ThreadingType
-    assert set(registered_env) == {"KukaButtonGymEnv-v0", "KukaMovingButtonGymEnv-v0", "Kuka2ButtonGymEnv-v0", "MobileRobotGymEnv-v0", "MobileRobot2TargetGymEnv-v0",
+    assert set(registered_env) == {"KukaButtonGymEnv-v0", "KukaMovingButtonGymEnv-v0", "Kuka2ButtonGymEnv-v0", "KukaRandButtonGymEnv-v0", "MobileRobotGymEnv-v0", "MobileRobot2TargetGymEnv-v0",
                                    "MobileRobot1DGymEnv-v0", "MobileRobotLineTargetGymEnv-v0"}
     for name, entry in registered_env.items():
         cls, sup, plot, thr = entry

@@ -124,3 +124,19 @@ def test_two_button_variant():
         assert a["ep_stats"][:, 1].max() == 1501
     finally:
         kuka_clib.set_variant(0); hostcheck.set_variant(0)
+
+
+def test_rand_button_variant():
+    """KukaRandButtonGymEnv: same stepping as KukaButtonGymEnv with the env's RNG stream shifted by the 20 distractor draws."""
+    n, T = 6, 1100
+    actions = np.random.RandomState(9).randint(6, size=(T, n)).astype(np.int32)
+    base = kuka_clib.rollout(80 + np.arange(n), 40, actions=actions[:40], random_target=True)
+    try:
+        kuka_clib.set_variant(3); hostcheck.set_variant(3)
+        a = kuka_clib.rollout(80 + np.arange(n), T, actions=actions, random_target=True)
+        b = hostcheck.rollout(80 + np.arange(n), T, actions=actions, random_target=True)
+        compare(a, b)
+        assert np.array_equal(a["reward"], b["reward"])
+        assert np.abs(a["obs"][:40] - base["obs"]).max() > 1e-3       # a different episode than the base env's on the same seed
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
