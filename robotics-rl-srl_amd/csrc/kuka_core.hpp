@@ -710,6 +710,9 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             add_generic_row(sc, ngen, J, shape == 0 ? -n[2] : 0.0, W, allow, pos_err, e, b2 ? e.b2qd : e.bqd, 0.0, 1e10);
         }
     }
+#ifdef SRL_ROW_STAT_HOOK          // host-side instrumentation of the test harness only (kuka_hostcheck.cpp)
+    SRL_ROW_STAT_HOOK(ngen, nlim);
+#endif
     // -- projected Gauss-Seidel, 150 sweeps.  Row order: arm motors, button motor, arm limits, button
     //    limits, contacts (LDS rows [0, nlim) are the arm limits, [nlim, ngen) the contacts).
     //    The arm motor block is iterated in impulse space: lam_i <- clamp((c_i - g_i - sum_{j!=i} W_ij lam_j) / W_ii),

@@ -9,6 +9,9 @@
 
 #include <vector>
 
+// row-count instrumentation: ngen (limit + contact rows) of every env step, for the path statistics in DESIGN.md
+static unsigned char *g_stat = nullptr; static long g_stat_idx = -1;
+#define SRL_ROW_STAT_HOOK(ngen, nlim) do { if (g_stat && g_stat_idx >= 0) g_stat[g_stat_idx] = (unsigned char)((ngen) | ((nlim) > 0 ? 0x80 : 0)); } while (0)
 #include "kuka_env.hpp"
 
 using namespace srl;
@@ -94,7 +97,9 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
             }
             if (act_out) { if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a; else memcpy(static_cast<float *>(act_out) + row * adim, ca, sizeof(float) * adim); }
         }
+        g_stat_idx = (long)row;
         const double reward = env_step<NB>(env, cfg, sc, rng, a, ca, &done);
+        g_stat_idx = -1;
         if (q_trace) memcpy(q_trace + row * ND, env.q, sizeof(double) * ND);
         if (grip_trace) memcpy(grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
@@ -149,6 +154,7 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
     return 0;
 }
 
+extern "C" void hostcheck_kuka_set_row_stats(unsigned char *buf) { g_stat = buf; }
 extern "C" void hostcheck_kuka_set_moving(int m) { g_moving = m; g_two = 0; g_rand = 0; }
 extern "C" void hostcheck_kuka_set_variant(int v) { g_moving = v == 1; g_two = v == 2; g_rand = v == 3; }
 

@@ -85,6 +85,9 @@ class HipVecEnv(object):
                 self._actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
             else:
                 self._actions = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
+            if self._actions.size and (self._actions.min() < -1 or self._actions.max() >= self._h.num_actions):
+                # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
+                raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(self._h.num_actions))
         else:
             if any(a is None for a in actions):
                 raise NotImplementedError("None actions need a discrete action space")
