@@ -11,9 +11,16 @@
 // a wavefront's 64 loads/stores of a field are one coalesced 512-byte row.
 // Arithmetic is float64 with -ffp-contract=off, the reference's numpy f64; the
 // only fused op is the explicit fma chain of np.linalg.norm's ddot (see
-// norm2()).  ~40 flops per env-step: the path is HBM/launch bound, no LDS, no
+// step_env()).  ~40 flops per env-step: the path is HBM/launch bound, no LDS, no
 // MFMA.  mobile_rollout_k keeps the state in VGPRs for T steps and streams the
 // [T][N] observation / reward / done planes with non-temporal stores.
+//
+// The sequential part of a rollout is only the state recurrence.  The synthetic agent's actions do not depend
+// on the state, so they are drawn by a separate, fully parallel kernel (mobile_sample_actions_k: one thread per
+// (step, env), Philox is random access) into the [T][N] action plane; the recurrence kernel then reads them one
+// step ahead of use (software-pipelined load) and is specialised at compile time on the env kind and the action type.
+// At the 4096-env BASELINE size only 64 wavefronts exist, so the launch time is T x (cycles per step of one
+// wavefront): taking the 10-round Philox block out of that chain is what matters.
 #include "internal.hpp"
 
 namespace srl {
@@ -22,9 +29,7 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// np.linalg.norm(v, 2) == sqrt(ddot(v, v)); OpenBLAS accumulates with FMA.
-__device__ __forceinline__ double norm2(double a) { return sqrt(fma(a, a, 0.0)); }
-__device__ __forceinline__ double norm2(double a, double b) { return sqrt(fma(b, b, fma(a, a, 0.0))); }
+// np.linalg.norm(v, 2) == sqrt(ddot(v, v)); OpenBLAS accumulates with FMA: see step_env.
 
 struct MobileEnv {
     double x, y, tx, ty, t2x, t2y;
@@ -126,8 +131,12 @@ __device__ __forceinline__ void observe(const MobileParams &p, const MobileEnv &
 }
 
 // step: mobile_robot_env.py:235-280 --------------------------------------------
-__device__ __forceinline__ void step_env(const MobileParams &p, MobileEnv &m, int a, float a0, float a1, double dv,
+// KIND / DISC >= 0: env kind / action type known at compile time (rollout kernels); -1: read from the params.
+template <int KIND = -1, int DISC = -1>
+__device__ __forceinline__ void step_env(const MobileParams &pp, MobileEnv &m, int a, float a0, float a1, double dv,
                                          double &reward, bool &done) {
+    struct { int32_t kind, is_discrete, shape_reward; } p = {KIND >= 0 ? KIND : pp.kind, DISC >= 0 ? DISC : pp.is_discrete,
+                                                             pp.shape_reward};
     double dx = 0.0, dy = 0.0;
     if (p.is_discrete) {
         if (p.kind == SRLHIP_ENV_MOBILE_1D) {
@@ -157,17 +166,23 @@ __device__ __forceinline__ void step_env(const MobileParams &p, MobileEnv &m, in
     m.counter += 1;
     // _reward
     double tx = m.cur ? m.t2x : m.tx, ty = m.cur ? m.t2y : m.ty;
-    double distance, threshold = 0.4;
+    double distance = 0.0;
+    bool within;
     if (p.kind == SRLHIP_ENV_MOBILE_LINE) {
         distance = fabs((tx - 0.2) - m.x);
-        threshold = 0.1;
-    } else if (p.kind == SRLHIP_ENV_MOBILE_1D) {
-        distance = norm2(tx - m.x);
+        within = distance <= 0.1;
     } else {
-        distance = norm2(tx - m.x, ty - m.y);
+        // np.linalg.norm = sqrt(ddot): sqrt is correctly rounded and monotonic, so `sqrt(s2) <= 0.4` holds exactly when
+        // s2 <= the largest double whose rounded square root is <= 0.4.  The sparse reward only needs that predicate;
+        // the square root itself (a ~25-instruction dependent chain in f64) is taken only for the shaped reward.
+        constexpr double kSqMax04 = 0x1.47ae147ae147cp-3;
+        const double ex = tx - m.x, ey = ty - m.y;
+        const double s2 = p.kind == SRLHIP_ENV_MOBILE_1D ? fma(ex, ex, 0.0) : fma(ey, ey, fma(ex, ex, 0.0));
+        if (p.shape_reward) { distance = sqrt(s2); within = distance <= 0.4; }
+        else within = s2 <= kSqMax04;
     }
     reward = 0.0;
-    if (distance <= threshold) {
+    if (within) {
         reward = 1.0;
         if (p.kind == SRLHIP_ENV_MOBILE_2TARGET && m.cur < 1) m.cur += 1;
     }
@@ -210,80 +225,96 @@ mobile_reset_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, cons
     }
 }
 
-// Synthetic random-agent action (rl_baselines/random_agent.py:36): Philox stream 1.
-__device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0, uint32_t k1, uint64_t &actr,
+// Synthetic random-agent action (rl_baselines/random_agent.py:36): Philox stream 1, block `actr` of the env.
+__device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0, uint32_t k1, uint64_t actr,
                                               int &a, float &a0, float &a1) {
     Philox ph; ph.k0 = k0; ph.k1 = k1; ph.ctr = actr; ph.stream = 1;
     if (p.is_discrete) {
-        a = (int)ph.bounded(p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u);
+        a = (int)ph.bounded(p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u);      // masks 1 / 3: never rejects -> exactly one block
     } else {
         uint32_t o[4]; ph.block(o);
         a0 = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
         a1 = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
     }
-    actr = ph.ctr;
 }
 
-// One launch == T consecutive VecEnv steps; T == 1 with plain stores is the
-// per-step entry point, T > 1 the fused rollout.
-// GIVEN = actions supplied by the caller; otherwise sampled on the device.  Kept a compile-time switch so that the
-// sampled loop contains no global load at all: a load in the loop would force an s_waitcnt that also drains the
-// streamed output stores of the previous step (vmcnt counts loads and stores together).
-template <int MODE, bool GIVEN>
+// All T x N synthetic actions of a rollout at once: thread (t, e) draws block act_ctr[e] + t of env e's action stream.
+__global__ void __launch_bounds__(kBlock)
+mobile_sample_actions_k(MobileParams p, RngState rs, int T, void *__restrict__ act) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)T * p.n) return;
+    const int e = (int)(i % p.n);
+    const int64_t t = i / p.n;
+    int a = 0; float a0 = 0.f, a1 = 0.f;
+    sample_action(p, rs.key[e], rs.key[p.n + e], rs.act_ctr[e] + (uint64_t)t, a, a0, a1);
+    if (p.is_discrete) static_cast<int32_t *>(act)[i] = a;
+    else static_cast<float2 *>(act)[i] = make_float2(a0, a1);
+}
+
+// One launch == T consecutive VecEnv steps; T == 1 with plain stores is the per-step entry point, T > 1 the fused
+// rollout.  Actions always come from the [T][N] plane (the caller's, or the one mobile_sample_actions_k just filled:
+// `advance_actr` then moves the env's action-stream counter past the T consumed blocks).
+template <int MODE, int KIND, int DISC>
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, const void *__restrict__ actions,
                  const double *__restrict__ noise, float *__restrict__ obs, float *__restrict__ rew,
-                 uint8_t *__restrict__ done_out, void *__restrict__ act_out) {
+                 uint8_t *__restrict__ done_out, int advance_actr) {
     int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.n) return;
+    if (KIND >= 0) p.kind = KIND;                 // compile-time constants from here on
+    if (DISC >= 0) p.is_discrete = DISC;
     typename RngSel<MODE>::type rng;
     rng_load<MODE>(rng, rs, e, p.n, nullptr, 0, noise);
     MobileEnv m;
     load_env(s, e, m);
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
-    uint64_t actr = GIVEN ? 0 : rs.act_ctr[e];
-    // the Philox key is loop invariant: keep it in registers (a per-step reload would have to wait for the
-    // streamed output stores to drain, since the compiler cannot prove they do not alias)
-    const uint32_t key0 = rs.key[e], key1 = rs.key[p.n + e];
-    const int adim = p.is_discrete ? 1 : 2;
-    for (int t = 0; t < T; t++) {
-        const int64_t row = (int64_t)t * p.n + e;
-        int a = 0; float a0 = 0.f, a1 = 0.f;
-        if constexpr (GIVEN) {
-            if (p.is_discrete) a = static_cast<const int32_t *>(actions)[row];
-            else { float2 v = static_cast<const float2 *>(actions)[row]; a0 = v.x; a1 = v.y; }
-        } else {
-            sample_action(p, key0, key1, actr, a, a0, a1);
-            if (act_out) {
-                if (p.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
-                else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+    const int32_t *act_i = static_cast<const int32_t *>(actions);
+    const float2 *act_f = static_cast<const float2 *>(actions);
+    // Actions are fetched kChunk steps at a time: on gfx9 loads and stores share one in-order counter (vmcnt), so waiting
+    // for a load also drains every output store issued before it.  One wait per kChunk steps instead of one per step
+    // keeps the streamed stores in flight.
+    constexpr int kChunk = 16;
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+        int ai[kChunk]; float2 af[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int64_t r = (int64_t)min(t0 + k, T - 1) * p.n + e;
+            if (p.is_discrete) ai[k] = act_i[r]; else af[k] = act_f[r];
+        }
+        // one full drain per chunk (vmcnt(0), expcnt / lgkmcnt untouched): afterwards no step of the chunk waits on memory
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int t = t0 + k;
+            if (t >= T) continue;                     // (uniform) tail of the last chunk
+            const int64_t row = (int64_t)t * p.n + e;
+            const int a = p.is_discrete ? ai[k] : 0;
+            const float a0 = p.is_discrete ? 0.f : af[k].x, a1 = p.is_discrete ? 0.f : af[k].y;
+            double dv = 0.1 + rng.normal(0.0, 0.0);       // DELTA_POS + N(0, NOISE_STD = 0): drawn, value 0
+            double reward; bool done;
+            step_env<KIND, DISC>(p, m, a, a0, a1, dv, reward, done);
+            ep_ret += reward; ep_len += 1; last_reward = reward;
+            if (done) {
+                last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+                if (p.auto_reset) reset_env(p, rng, m);
             }
-        }
-        double dv = 0.1 + rng.normal(0.0, 0.0);       // DELTA_POS + N(0, NOISE_STD = 0): drawn, value 0
-        double reward; bool done;
-        step_env(p, m, a, a0, a1, dv, reward, done);
-        ep_ret += reward; ep_len += 1; last_reward = reward;
-        if (done) {
-            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
-            if (p.auto_reset) reset_env(p, rng, m);
-        }
-        float o0, o1;
-        observe(p, m, o0, o1);
-        if (obs) {
-            if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
-            else {
-                __builtin_nontemporal_store(o0, obs + 2 * row);
-                __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+            float o0, o1;
+            observe(p, m, o0, o1);
+            if (obs) {
+                if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
+                else {
+                    __builtin_nontemporal_store(o0, obs + 2 * row);
+                    __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+                }
             }
+            if (rew) __builtin_nontemporal_store((float)reward, rew + row);
+            if (done_out) __builtin_nontemporal_store((uint8_t)done, done_out + row);
         }
-        if (rew) __builtin_nontemporal_store((float)reward, rew + row);
-        if (done_out) __builtin_nontemporal_store((uint8_t)done, done_out + row);
     }
-    (void)adim;
     store_env(s, e, m);
     rng_store<MODE>(rng, rs, e);
-    if (!GIVEN) rs.act_ctr[e] = actr;
+    if (advance_actr) rs.act_ctr[e] += (uint64_t)T;
     st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret;
     st.last_length[e] = last_len; st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
@@ -342,30 +373,56 @@ int mobile_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, fl
     return 0;
 }
 
+namespace {
+
+template <int MODE>
+void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actions, const double *d_noise, float *d_obs,
+                    float *d_rew, uint8_t *d_done, int advance_actr) {
+    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+#define SRL_GO(KIND, DISC)                                                                                              \
+    hipLaunchKernelGGL((mobile_rollout_k<MODE, KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats, T, \
+                       d_actions, d_noise, d_obs, d_rew, d_done, advance_actr)
+#define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
+    switch (p.kind) {
+        case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
+        case SRLHIP_ENV_MOBILE_1D: SRL_KIND(SRLHIP_ENV_MOBILE_1D) break;
+        case SRLHIP_ENV_MOBILE_2TARGET: SRL_KIND(SRLHIP_ENV_MOBILE_2TARGET) break;
+        default: SRL_KIND(SRLHIP_ENV_MOBILE_LINE)
+    }
+#undef SRL_KIND
+#undef SRL_GO
+}
+
+}  // namespace
+
 int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done,
                    void *d_act_out) {
     MobileParams p = params_of(h);
-    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
-    switch (h->cfg.rng_mode) {
-        case SRLHIP_RNG_PHILOX:
-            if (d_actions)
-                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_PHILOX, true>), grid, block, 0, h->stream, p, h->mobile, h->rng,
-                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
-            else
-                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_PHILOX, false>), grid, block, 0, h->stream, p, h->mobile, h->rng,
-                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
-            break;
-        case SRLHIP_RNG_MT19937:
-            if (d_actions)
-                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_MT19937, true>), grid, block, 0, h->stream, p, h->mobile, h->rng,
-                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
-            else
-                hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_MT19937, false>), grid, block, 0, h->stream, p, h->mobile, h->rng,
-                                   h->stats, T, d_actions, (const double *)nullptr, d_obs, d_rew, d_done, d_act_out);
-            break;
-        default:
-            return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
+    if (h->cfg.rng_mode != SRLHIP_RNG_PHILOX && h->cfg.rng_mode != SRLHIP_RNG_MT19937)
+        return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
+    int advance = 0;
+    if (!d_actions) {
+        // synthetic agent: draw the whole [T][N] action plane in parallel, into the caller's plane when there is one
+        const size_t bytes = (size_t)T * h->n * (p.is_discrete ? 4 : 8);
+        void *plane = d_act_out;
+        if (!plane) {
+            if (h->st_noise_sz < bytes) {
+                if (h->st_noise) (void)hipFree(h->st_noise);
+                h->st_noise = nullptr; h->st_noise_sz = 0;
+                SRL_HIP_CHECK(h, hipMalloc(&h->st_noise, bytes));
+                h->st_noise_sz = bytes;
+            }
+            plane = h->st_noise;
+        }
+        const int64_t total = (int64_t)T * h->n;
+        hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                           p, h->rng, T, plane);
+        SRL_HIP_CHECK(h, hipGetLastError());
+        d_actions = plane;
+        advance = 1;
     }
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
+    else launch_rollout<SRLHIP_RNG_MT19937>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -375,8 +432,8 @@ int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *
     if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return mobile_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
     MobileParams p = params_of(h);
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, true>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
-                       1, d_actions, d_noise, d_obs, d_rew, d_done, (void *)nullptr);
+    hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, -1, -1>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
+                       1, d_actions, d_noise, d_obs, d_rew, d_done, 0);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }

@@ -101,3 +101,33 @@ def test_large_handle_mobile_one_million_envs():
         assert np.array_equal(out["actions"][:, lo:lo + 64], ora["actions"])
     assert (np.abs(out["obs"]) < 10).all()
     h.close()
+
+
+def test_sparse_reward_threshold_is_exact_at_the_ulp_boundary():
+    """The kernel decides `norm <= 0.4` on the squared norm (exact threshold, no square root); walk the robot's x through
+    every double within +-8 ulp of the boundary and compare with the oracle's sqrt(ddot) predicate."""
+    cfg = _lib.default_config(_lib.ENV_MOBILE)
+    n = 64
+    cfg.num_envs, cfg.seed0 = n, 0
+    h = _lib.Handle(cfg)
+    h.reset()
+    tx, ty = 3.6, 3.0                                        # default target
+    checked = flips = 0
+    for base_dx, y in ((0.4, ty), (0.24, ty - 0.32), (0.32, ty + 0.24), (0.4, ty + 1e-9)):   # all clear of the walls
+        x0 = tx - base_dx - 0.1                              # action 1 moves +0.1 in x (dv = 0.1 exactly)
+        xs = np.full(n, x0)
+        for k in range(n):
+            v = x0
+            for _ in range(abs(k - n // 2)):
+                v = np.nextafter(v, np.inf if k > n // 2 else -np.inf)
+            xs[k] = v
+        h.set_state(_lib.F_POS_X, xs); h.set_state(_lib.F_POS_Y, np.full(n, y))
+        h.set_state(_lib.F_STEP_COUNT, np.zeros(n, np.int32))
+        obs, rew, done = h.step(np.full(n, 1, np.int32))
+        xn, yn = h.get_state(_lib.F_POS_X), h.get_state(_lib.F_POS_Y)
+        want = np.array([1.0 if mobile_oracle.norm2(tx - a, ty - b) <= 0.4 else 0.0 for a, b in zip(xn, yn)], np.float32)
+        assert np.array_equal(rew, want), (base_dx, rew, want)
+        checked += n
+        flips += int(want.min() != want.max())
+    assert checked == 4 * n and flips >= 2                   # the scan really straddles the boundary
+    h.close()
