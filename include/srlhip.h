@@ -30,6 +30,7 @@
 #ifndef SRLHIP_H
 #define SRLHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -196,6 +197,38 @@ int srlhip_timing_end(srlhip_handle h, float *elapsed_ms);   /* synchronises */
 
 const char *srlhip_last_error(srlhip_handle h);
 int srlhip_abi_version(void);
+
+/* ---- SRL encoder (raw_pixels -> state) ----------------------------------------------------------------
+ * Replaces SRLNeuralNetwork.getState (state_representation/models.py:178-193: preprocessImage, the H/W
+ * transpose, one CustomCNN forward) and the one-image-at-a-time encoder server MultiprocessSRLModel._run
+ * (rl_baselines/utils.py:181-191) for a whole DEVICE-resident batch of frames, in one fused HIP kernel
+ * (csrc/encoder.hip).  Weights are plain float32 host arrays in torch layout with the BatchNorms already
+ * folded into the preceding convolution (w' = w*gamma/sigma, b' = beta - mu*gamma/sigma):
+ *   conv1_w [64][3][7][7] conv1_b [64]   conv2_w, conv3_w [64][64][3][3]   conv2_b, conv3_b [64]
+ *   fc_w [state_dim][64]  fc_b [state_dim]
+ * Covered shape: 64x64 frames with 3 channels (BASELINE configs 4-5); anything else -> SRLHIP_ENOTSUP
+ * (srlhip_encoder_supported() tells beforehand) and the caller keeps the PyTorch-ROCm forward.
+ * images_dev uint8 [n][64][64][3] and states_dev float [n][state_dim] are DEVICE pointers on device_id; the
+ * call only enqueues on hip_stream (NULL = the default stream). */
+typedef struct srlhip_encoder *srlhip_encoder_handle;
+int srlhip_encoder_supported(int32_t img_h, int32_t img_w, int32_t n_channels);
+int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32_t n_channels, int32_t state_dim,
+                          const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv2_b,
+                          const float *conv3_w, const float *conv3_b, const float *fc_w, const float *fc_b,
+                          srlhip_encoder_handle *out);
+int srlhip_encoder_forward(srlhip_encoder_handle e, const uint8_t *images_dev, int32_t n, float *states_dev,
+                           void *hip_stream);
+/* Synchronises the device; *flag = 1 if an activation ever left float16's range (|x| >= 65504: the split-f16
+ * matrix path then lost accuracy and the caller should use the PyTorch forward for these weights). */
+int srlhip_encoder_overflow(srlhip_encoder_handle e, int32_t *flag);
+int srlhip_encoder_destroy(srlhip_encoder_handle e);
+const char *srlhip_encoder_last_error(srlhip_encoder_handle e);
+/* Host-only: the MFMA B-operand image create() uploads (normalisation folded into layer 1, every weight split
+ * into f16 hi/lo), srlhip_encoder_pack_bytes() bytes.  Exposed so the packing can be checked without a GPU. */
+size_t srlhip_encoder_pack_bytes(void);
+int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv3_w,
+                        void *out, size_t out_bytes);
+
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ EXPORTS = [
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error",
+    "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
+    "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
 ]
 
 
@@ -88,6 +90,16 @@ def load():
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.srlhip_encoder_supported.argtypes = [i32, i32, i32]
+    lib.srlhip_encoder_create.argtypes = [i32, i32, i32, i32, i32] + [vp] * 8 + [ctypes.POINTER(vp)]
+    lib.srlhip_encoder_forward.argtypes = [vp, vp, i32, vp, vp]
+    lib.srlhip_encoder_overflow.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.srlhip_encoder_destroy.argtypes = [vp]
+    lib.srlhip_encoder_last_error.restype = ctypes.c_char_p
+    lib.srlhip_encoder_last_error.argtypes = [vp]
+    lib.srlhip_encoder_pack_bytes.restype = ctypes.c_size_t
+    lib.srlhip_encoder_pack_bytes.argtypes = []
+    lib.srlhip_encoder_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t]
     _lib = lib
     return lib
 
@@ -264,3 +276,67 @@ class Handle(object):
         ms = ctypes.c_float()
         self._check(self._lib.srlhip_timing_end(self._h, ctypes.byref(ms)), "srlhip_timing_end")
         return ms.value
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def encoder_supported(img_h, img_w, n_channels):
+    return bool(load().srlhip_encoder_supported(int(img_h), int(img_w), int(n_channels)))
+
+
+def encoder_pack(conv1_w, conv1_b, conv2_w, conv3_w):
+    """Host-only: the packed MFMA B-operand image (float16 words) srlhip_encoder_create uploads."""
+    lib = load()
+    out = np.zeros(lib.srlhip_encoder_pack_bytes() // 2, np.float16)
+    w1, b1, w2, w3 = _f32(conv1_w), _f32(conv1_b), _f32(conv2_w), _f32(conv3_w)
+    assert w1.shape == (64, 3, 7, 7) and b1.shape == (64,) and w2.shape == (64, 64, 3, 3) and w3.shape == (64, 64, 3, 3)
+    rc = lib.srlhip_encoder_pack(_ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), _ptr(out), out.nbytes)
+    if rc:
+        raise SrlHipError("srlhip_encoder_pack failed ({})".format(rc))
+    return out
+
+
+class Encoder(object):
+    """srlhip_encoder_handle: the fused CustomCNN forward on device-resident uint8 frames (csrc/encoder.hip).
+    Weights: float32 arrays in torch layout with the BatchNorms already folded (see include/srlhip.h)."""
+
+    def __init__(self, device_id, img_shape, n_channels, state_dim, conv1, conv2, conv3, fc):
+        self._lib = load()
+        self._e = ctypes.c_void_p()
+        arrs = [_f32(a) for pair in (conv1, conv2, conv3, fc) for a in pair]
+        assert arrs[0].shape == (64, 3, 7, 7) and arrs[2].shape == (64, 64, 3, 3) and arrs[4].shape == (64, 64, 3, 3)
+        assert arrs[6].shape == (state_dim, 64) and arrs[7].shape == (state_dim,)
+        rc = self._lib.srlhip_encoder_create(int(device_id), int(img_shape[0]), int(img_shape[1]), int(n_channels),
+                                             int(state_dim), *[_ptr(a) for a in arrs], ctypes.byref(self._e))
+        if rc:
+            self._e = None
+            raise SrlHipError("srlhip_encoder_create failed ({}): {}".format(
+                rc, self._lib.srlhip_encoder_last_error(None).decode()))
+        self.state_dim = int(state_dim)
+
+    def _check(self, rc, what):
+        if rc:
+            raise SrlHipError("{} failed ({}): {}".format(what, rc, self._lib.srlhip_encoder_last_error(self._e).decode()))
+
+    def forward(self, images_ptr, n, states_ptr, stream=None):
+        """images_ptr / states_ptr: raw device pointers (e.g. torch.Tensor.data_ptr()); enqueue-only on `stream`."""
+        self._check(self._lib.srlhip_encoder_forward(self._e, _ptr(images_ptr), int(n), _ptr(states_ptr),
+                                                     ctypes.c_void_p(stream) if stream else None), "srlhip_encoder_forward")
+
+    def overflow(self):
+        flag = ctypes.c_int32()
+        self._check(self._lib.srlhip_encoder_overflow(self._e, ctypes.byref(flag)), "srlhip_encoder_overflow")
+        return bool(flag.value)
+
+    def close(self):
+        if self._e:
+            self._lib.srlhip_encoder_destroy(self._e)
+            self._e = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

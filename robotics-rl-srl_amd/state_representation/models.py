@@ -3,7 +3,9 @@ rl_baselines/utils.py:162-191), batched and device-resident.
 
 The reference runs ONE encoder process that serves every env serially at batch size 1 through
 multiprocessing queues (150 KB pickled per observation).  Here the rasteriser's uint8 NHWC batch stays
-in HBM and goes through one batched forward under PyTorch-ROCm (MIOpen / rocBLAS do the convolutions).
+in HBM and goes through one batched forward: the fused HIP kernel csrc/encoder.hip (split-float16 MFMA, whole
+network per image inside one CU) for 64x64x3 frames, the PyTorch-ROCm forward (MIOpen / rocBLAS) for every other
+shape — the PyTorch forward is also the float32 reference the kernel is tested against.
 
 srl_zoo is an empty submodule in the reference checkout, so the architecture is restated from its
 published description: CustomCNN = conv7x7/2(3->64)+BN+ReLU+maxpool3/2,
@@ -81,7 +83,7 @@ class SRLNeuralNetwork(object):
     surface) and getStates(images) for a whole device-resident batch."""
 
     def __init__(self, state_dim, cuda=False, model_type="custom_cnn", n_channels=3, img_shape=(224, 224),
-                 state_dict=None, device=None):
+                 state_dict=None, device=None, backend="auto"):
         assert model_type == "custom_cnn", "only the srl_zoo CustomCNN encoder is restated"
         self.state_dim = state_dim
         self.device = th.device(device if device is not None else ("cuda" if cuda else "cpu"))
@@ -96,14 +98,55 @@ class SRLNeuralNetwork(object):
         # 4096x64x64 batch); logical shapes, and therefore the flatten order in front of the FC, do not change
         self.memory_format = th.channels_last if self.device.type == "cuda" else th.contiguous_format
         self.fused_conv = self.fused_conv.to(memory_format=self.memory_format)
+        # Fused HIP forward (csrc/encoder.hip) for the shape it covers (64x64x3 frames on the GPU); every other
+        # shape keeps the PyTorch-ROCm forward above.  backend: "auto" | "hip" | "torch".
+        self.hip = None
+        self.backend = "torch"
+        if backend not in ("auto", "hip", "torch"):
+            raise ValueError("backend must be auto, hip or torch")
+        if backend != "torch" and self.device.type == "cuda":
+            from srlhip import _lib
+            if _lib.encoder_supported(img_shape[0], img_shape[1], n_channels):
+                self.hip = _lib.Encoder(self.device.index or 0, img_shape, n_channels, state_dim, *self.folded_weights())
+                self.backend = "hip"
+        if backend == "hip" and self.hip is None:
+            raise RuntimeError("the fused HIP encoder needs a GPU and 64x64x3 frames (got device {}, shape {}x{})".format(
+                self.device, img_shape, n_channels))
+
+    def folded_weights(self):
+        """((conv1_w, conv1_b), (conv2_w, conv2_b), (conv3_w, conv3_b), (fc_w, fc_b)) as float32 numpy arrays in torch
+        layout with the BatchNorms folded — what srlhip_encoder_create takes."""
+        convs = [m for m in self.fused_conv if isinstance(m, nn.Conv2d)]
+        out = [(c.weight.detach().to("cpu", th.float32).contiguous().numpy(),
+                c.bias.detach().to("cpu", th.float32).contiguous().numpy()) for c in convs]
+        out.append((self.model.fc.weight.detach().to("cpu", th.float32).contiguous().numpy(),
+                    self.model.fc.bias.detach().to("cpu", th.float32).contiguous().numpy()))
+        return out
 
     @th.no_grad()
-    def getStates(self, images_u8):
-        """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim]."""
+    def getStatesTorch(self, images_u8):
+        """The PyTorch-ROCm forward (MIOpen / rocBLAS): reference for the fused kernel and path for other shapes."""
         if isinstance(images_u8, np.ndarray):
             images_u8 = th.from_numpy(images_u8)
         x = self.fused_conv(preprocess(images_u8.to(self.device)).contiguous(memory_format=self.memory_format))
         return self.model.fc(x.reshape(x.size(0), -1))
+
+    @th.no_grad()
+    def getStates(self, images_u8, stream=None):
+        """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim].
+        stream: raw HIP stream to enqueue the fused kernel on (default: torch's current stream)."""
+        if self.hip is None:
+            return self.getStatesTorch(images_u8)
+        if isinstance(images_u8, np.ndarray):
+            images_u8 = th.from_numpy(images_u8)
+        images_u8 = images_u8.to(self.device).contiguous()
+        assert images_u8.dtype == th.uint8 and tuple(images_u8.shape[1:]) == (64, 64, 3), images_u8.shape
+        n = images_u8.shape[0]
+        out = th.empty((n, self.state_dim), dtype=th.float32, device=self.device)
+        if stream is None:
+            stream = th.cuda.current_stream(self.device).cuda_stream
+        self.hip.forward(images_u8.data_ptr(), n, out.data_ptr(), stream)
+        return out
 
     def getState(self, observation, env_id=0):
         return self.getStates(np.asarray(observation)[None])[0].to("cpu").numpy()

@@ -1,0 +1,110 @@
+"""CPU check of the fused HIP encoder's host half (csrc/encoder.hip, no GPU needed): the packed MFMA B-operand
+image — ImageNet normalisation folded into layer 1, the padding-mask channel, the H/W axis swap, the k ordering of
+the im2col fragments and the float16 hi/lo split — is decoded with numpy and pushed through a float64 emulation of
+the kernel's data flow (padded RGB+mask input, conv / ReLU / max-pool stages as the kernel indexes them); the
+result has to match the PyTorch CustomCNN evaluated on the reference's preprocessing."""
+import numpy as np
+import torch
+
+from srlhip import _lib
+from state_representation.models import SRLNeuralNetwork, preprocess
+
+S1, S2 = 14, 36
+
+
+def random_bn_net(state_dim, seed):
+    torch.manual_seed(seed)
+    net = SRLNeuralNetwork(state_dim, img_shape=(64, 64), backend="torch")
+    for m in net.model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    return SRLNeuralNetwork(state_dim, img_shape=(64, 64), state_dict=net.model.state_dict(), backend="torch")
+
+
+def decode_pack(pack):
+    """-> effective weights w1[64][224] (already divided by the 256 scale), w2[64][576], w3[64][576]."""
+    pack = pack.astype(np.float64)
+
+    def layer(words, steps):
+        frag = words.reshape(2, steps, 64, 16)                    # [n-half][k-step][lane][8 hi | 8 lo]
+        eff = frag[..., :8] + frag[..., 8:] / 2048.0
+        w = np.zeros((64, steps * 16))
+        for nh in range(2):
+            for lane in range(64):
+                o, h = 32 * nh + (lane & 31), lane >> 5
+                for s in range(steps):
+                    w[o, 16 * s + 8 * h:16 * s + 8 * h + 8] = eff[nh, s, lane]
+        return w
+
+    n1, n2 = 2 * S1 * 64 * 16, 2 * S2 * 64 * 16
+    return layer(pack[:n1], S1) / 256.0, layer(pack[n1:n1 + n2], S2), layer(pack[n1 + n2:], S2)
+
+
+def emulate(img, w1, w2, w3, b2, b3, fcw, fcb):
+    """float64 walk through the kernel's stages for ONE uint8 frame [64][64][3]."""
+    inp = np.zeros((70, 72, 4))
+    inp[3:67, 3:67, :3] = img
+    inp[3:67, 3:67, 3] = 1.0
+    c1 = np.zeros((32, 32, 64))
+    for oy in range(32):
+        for ox in range(32):
+            patch = inp[2 * oy:2 * oy + 7, 2 * ox:2 * ox + 8, :].reshape(-1)      # k = ky*32 + slot*4 + c4
+            c1[oy, ox] = w1 @ patch
+    c1 = np.maximum(c1, 0)
+    pad = np.zeros((34, 34, 64)); pad[1:33, 1:33] = c1
+    a2 = np.zeros((16, 16, 64))
+    for py in range(16):
+        for px in range(16):
+            a2[py, px] = pad[2 * py:2 * py + 3, 2 * px:2 * px + 3].max(axis=(0, 1))
+    pad = np.zeros((18, 18, 64)); pad[1:17, 1:17] = a2
+    c2 = np.zeros((16, 16, 64))
+    for oy in range(16):
+        for ox in range(16):
+            c2[oy, ox] = w2 @ pad[oy:oy + 3, ox:ox + 3, :].reshape(-1) + b2        # k = (ky*3 + kx)*64 + c
+    c2 = np.maximum(c2, 0)
+    a3 = np.zeros((7, 7, 64))
+    for py in range(7):
+        for px in range(7):
+            a3[py, px] = c2[2 * py:2 * py + 3, 2 * px:2 * px + 3].max(axis=(0, 1))
+    pad = np.zeros((9, 9, 64)); pad[1:8, 1:8] = a3
+    c3 = np.zeros((4, 4, 64))
+    for oy in range(4):
+        for ox in range(4):
+            c3[oy, ox] = w3 @ pad[2 * oy:2 * oy + 3, 2 * ox:2 * ox + 3, :].reshape(-1) + b3
+    feat = np.maximum(c3, 0)[:3, :3].max(axis=(0, 1))
+    return fcw @ feat + fcb
+
+
+def test_pack_decodes_to_the_network():
+    net = random_bn_net(5, 3)
+    (w1, b1), (w2, b2), (w3, b3), (fw, fb) = net.folded_weights()
+    pack = _lib.encoder_pack(w1, b1, w2, w3)
+    assert pack.nbytes == _lib.load().srlhip_encoder_pack_bytes() and np.isfinite(pack.astype(np.float32)).all()
+    e1, e2, e3 = decode_pack(pack)
+    # layers 2/3: plain weights with the two kernel axes swapped (the network sees the frame transposed)
+    ref2 = np.transpose(w2, (0, 3, 2, 1)).reshape(64, 576)        # [o][ky][kx][c] with w[o][c][kx][ky]
+    assert np.abs(e2 - ref2).max() <= 2.0 ** -21 * np.abs(ref2).max()
+    ref3 = np.transpose(w3, (0, 3, 2, 1)).reshape(64, 576)
+    assert np.abs(e3 - ref3).max() <= 2.0 ** -21 * np.abs(ref3).max()
+    # layer 1: pixel slot 7 of every kernel row carries zero weights
+    assert np.all(e1.reshape(64, 7, 8, 4)[:, :, 7, :] == 0)
+    rs = np.random.RandomState(0)
+    imgs = rs.randint(0, 256, size=(3, 64, 64, 3)).astype(np.uint8)
+    imgs[1, :, :32] = 0                                            # flat regions: the padding-mask path matters at borders
+    imgs[2] = 255
+    with torch.no_grad():
+        ref = net.model.getStates(preprocess(torch.from_numpy(imgs))).numpy()
+    for i in range(3):
+        out = emulate(imgs[i].astype(np.float64), e1, e2, e3, b2.astype(np.float64), b3.astype(np.float64),
+                      fw.astype(np.float64), fb.astype(np.float64))
+        assert np.abs(out - ref[i]).max() < 2e-4 * max(1.0, np.abs(ref[i]).max()), (i, out, ref[i])
+
+
+def test_pack_rejects_short_buffers_and_encoder_needs_a_gpu():
+    lib = _lib.load()
+    z = np.zeros(16, np.float32)
+    assert lib.srlhip_encoder_pack(_lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), 16) == -22
+    assert not _lib.encoder_supported(224, 224, 3) and not _lib.encoder_supported(64, 64, 6)
+    if not torch.cuda.is_available():
+        net = SRLNeuralNetwork(2, img_shape=(64, 64))              # CPU device: PyTorch forward, never the HIP handle
+        assert net.backend == "torch" and net.hip is None

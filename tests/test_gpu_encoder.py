@@ -1,0 +1,78 @@
+"""Fused HIP encoder (csrc/encoder.hip, through the C-ABI) against the plain PyTorch float32 forward of the same
+network on the CPU — the reference the op restates (state_representation/models.py:178-193).  Tolerance: the kernel
+computes on the float16 matrix pipe with every operand split into hi + lo/2048 (22 significant bits per product,
+float32 accumulation), so it is held to 2e-5 relative to the largest state component; MIOpen's own float32
+forward differs from the CPU by about as much."""
+import numpy as np
+import pytest
+import torch
+
+from state_representation.models import SRLNeuralNetwork
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def make_net(state_dim, seed, cuda):
+    torch.manual_seed(seed)
+    net = SRLNeuralNetwork(state_dim, img_shape=(64, 64), backend="torch")
+    for m in net.model.modules():                       # non-trivial BatchNorm statistics: exercises the folding
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    sd = net.model.state_dict()
+    return (SRLNeuralNetwork(state_dim, cuda=cuda, img_shape=(64, 64), state_dict=sd, backend="hip" if cuda else "torch"),
+            SRLNeuralNetwork(state_dim, cuda=False, img_shape=(64, 64), state_dict=sd, backend="torch"))
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("state_dim,n", [(3, 1), (5, 37), (2, 600), (200, 64), (300, 5)])
+def test_hip_encoder_matches_torch_fp32(state_dim, n):
+    gpu, cpu = make_net(state_dim, 7 + state_dim, True)
+    assert gpu.backend == "hip"
+    rs = np.random.RandomState(n)
+    imgs = rs.randint(0, 256, size=(n, 64, 64, 3)).astype(np.uint8)
+    imgs[0, :, :20] = 0                                   # flat borders: zero padding in normalised space
+    if n > 2:
+        imgs[1] = 255
+        imgs[2, 10:50, 5:60] = rs.randint(0, 256, size=3).astype(np.uint8)
+    out = gpu.getStates(imgs).cpu().numpy()
+    ref = cpu.getStates(imgs).numpy()
+    assert out.shape == (n, state_dim) and np.isfinite(out).all()
+    assert rel_err(out, ref) < TOL, rel_err(out, ref)
+    assert not gpu.hip.overflow()
+
+
+def test_hip_encoder_on_rasterised_frames_and_foreign_stream():
+    from srlhip.pixel_env import PixelStateVecEnv
+    gpu, cpu = make_net(8, 1, True)
+    env = PixelStateVecEnv("KukaButtonGymEnv-v0", 300, gpu, seed=2)
+    states = env.reset()
+    for _ in range(5):
+        states, rew, done = env.step()
+    torch.cuda.synchronize()
+    ref = cpu.getStates(env.images.cpu().numpy()).numpy()
+    assert rel_err(states.cpu().numpy(), ref) < TOL
+    # the PyTorch-ROCm forward of the same weights agrees too (looser: MIOpen picks its own algorithms)
+    assert rel_err(gpu.getStatesTorch(env.images).cpu().numpy(), ref) < 2e-3
+    # explicit stream: enqueue on a side stream, then order torch's stream behind it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out = gpu.getStates(env.images, stream=side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    env.close()
+
+
+def test_hip_encoder_rejects_what_it_does_not_cover():
+    from srlhip import _lib
+    with pytest.raises(RuntimeError):
+        SRLNeuralNetwork(2, cuda=True, img_shape=(224, 224), backend="hip")
+    net = SRLNeuralNetwork(2, cuda=True, img_shape=(224, 224))            # auto: falls to the PyTorch-ROCm forward, on the GPU
+    assert net.backend == "torch" and net.getStates(np.zeros((2, 224, 224, 3), np.uint8)).is_cuda
+    gpu, _ = make_net(2, 0, True)
+    with pytest.raises(_lib.SrlHipError):
+        gpu.hip.forward(0, 4, 0)                                           # null buffers
+    assert gpu.getStates(np.zeros((0, 64, 64, 3), np.uint8)).shape == (0, 2)
