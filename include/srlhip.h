@@ -221,13 +221,19 @@ int srlhip_encoder_forward(srlhip_encoder_handle e, const uint8_t *images_dev, i
 /* Synchronises the device; *flag = 1 if an activation ever left float16's range (|x| >= 65504: the split-f16
  * matrix path then lost accuracy and the caller should use the PyTorch forward for these weights). */
 int srlhip_encoder_overflow(srlhip_encoder_handle e, int32_t *flag);
+/* Diagnostic: one synchronous forward whose workgroup 0 stamps the shader clock (s_memtime) at nine points of its
+ * first frames; cycles9[k] = cycles between stamp k and k+1, slowest wave, averaged over frames:
+ * 0 unpack, 1 layer-1 MFMA + pooling, 2 barrier, 3 layer-2 k-loop, 4 layer-2 epilogue, 5 barrier, 6 layer 3,
+ * 7 FC, 8 loop turn-around.  Used by bench.py / DESIGN.md to attribute the kernel's time. */
+int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_dev, int32_t n, float *states_dev,
+                                int64_t *cycles9);
 int srlhip_encoder_destroy(srlhip_encoder_handle e);
 const char *srlhip_encoder_last_error(srlhip_encoder_handle e);
 /* Host-only: the MFMA B-operand image create() uploads (normalisation folded into layer 1, every weight split
  * into f16 hi/lo), srlhip_encoder_pack_bytes() bytes.  Exposed so the packing can be checked without a GPU. */
 size_t srlhip_encoder_pack_bytes(void);
 int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv3_w,
-                        void *out, size_t out_bytes);
+                        void *out, size_t out_bytes, float *scales3 /* power-of-two pre-scale of layers 1..3 */);
 
 
 #ifdef __cplusplus

@@ -1,20 +1,41 @@
-import sys, time
-sys.path.insert(0, 'robotics-rl-srl_amd')
+"""Micro-benchmark of the fused HIP encoder against the PyTorch-ROCm forward on a 4096 x 64x64x3 batch (run on the GPU box).
+ENC_REPS < 10: short HIP-only run for the PMC passes of collect_encoder.sh."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'robotics-rl-srl_amd'))
 import numpy as np, torch
 from state_representation.models import SRLNeuralNetwork
 torch.manual_seed(0)
 net = SRLNeuralNetwork(8, cuda=True, img_shape=(64, 64), backend="hip")
 imgs = torch.randint(0, 256, (4096, 64, 64, 3), dtype=torch.uint8, device="cuda")
-for fn, name in ((net.getStates, "hip"), (net.getStatesTorch, "torch")):
-    for _ in range(3): fn(imgs)
+REPS = int(os.environ.get("ENC_REPS", "10"))
+for fn, name in ((net.getStates, "hip"),) + (((net.getStatesTorch, "torch"),) if REPS >= 10 else ()):
+    for _ in range(1 if REPS < 10 else 3): fn(imgs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): out = fn(imgs)
+    for _ in range(REPS): out = fn(imgs)
     e1.record(); torch.cuda.synchronize()
-    print(name, "ms per 4096-batch:", e0.elapsed_time(e1) / 10)
+    print(name, "ms per 4096-batch:", e0.elapsed_time(e1) / REPS)
+if REPS < 10: sys.exit(0)
 a = net.getStates(imgs).cpu().numpy(); b = net.getStatesTorch(imgs).cpu().numpy()
 cpu = SRLNeuralNetwork(8, cuda=False, img_shape=(64, 64), state_dict=net.model.state_dict(), backend="torch")
 c = cpu.getStates(imgs[:256].cpu().numpy()).numpy()
 print("hip vs cpu", np.abs(a[:256]-c).max()/np.abs(c).max(), "miopen vs cpu", np.abs(b[:256]-c).max()/np.abs(c).max(), "scale", np.abs(c).max())
 print("overflow", net.hip.overflow())
+# data dependence (power / clocks): the same kernel on constant frames and on rasterised frames
+from srlhip.pixel_env import PixelStateVecEnv
+env = PixelStateVecEnv("KukaButtonGymEnv-v0", 4096, net, seed=0)
+env.reset()
+for _ in range(3): env.step()
+torch.cuda.synchronize()
+for name, batch in (("zeros", torch.zeros_like(imgs)), ("rasterised", env.images.clone()), ("random", imgs)):
+    for _ in range(3): net.getStates(batch)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): net.getStates(batch)
+    e1.record(); torch.cuda.synchronize()
+    print("hip on", name, "frames: ms per 4096-batch:", e0.elapsed_time(e1) / 20)
+env.close()
+out = torch.empty((4096, 8), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+print("phase cycles (workgroup 0):", net.hip.phase_cycles(imgs.data_ptr(), 4096, out.data_ptr()))

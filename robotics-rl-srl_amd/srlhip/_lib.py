@@ -37,6 +37,7 @@ EXPORTS = [
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
+    "srlhip_encoder_phase_cycles",
     "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
 ]
 
@@ -94,12 +95,13 @@ def load():
     lib.srlhip_encoder_create.argtypes = [i32, i32, i32, i32, i32] + [vp] * 8 + [ctypes.POINTER(vp)]
     lib.srlhip_encoder_forward.argtypes = [vp, vp, i32, vp, vp]
     lib.srlhip_encoder_overflow.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.srlhip_encoder_phase_cycles.argtypes = [vp, vp, i32, vp, vp]
     lib.srlhip_encoder_destroy.argtypes = [vp]
     lib.srlhip_encoder_last_error.restype = ctypes.c_char_p
     lib.srlhip_encoder_last_error.argtypes = [vp]
     lib.srlhip_encoder_pack_bytes.restype = ctypes.c_size_t
     lib.srlhip_encoder_pack_bytes.argtypes = []
-    lib.srlhip_encoder_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t]
+    lib.srlhip_encoder_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     _lib = lib
     return lib
 
@@ -287,15 +289,17 @@ def encoder_supported(img_h, img_w, n_channels):
 
 
 def encoder_pack(conv1_w, conv1_b, conv2_w, conv3_w):
-    """Host-only: the packed MFMA B-operand image (float16 words) srlhip_encoder_create uploads."""
+    """Host-only: (packed MFMA B-operand image as float16 words, the three per-layer power-of-two weight scales)
+    exactly as srlhip_encoder_create uploads them."""
     lib = load()
     out = np.zeros(lib.srlhip_encoder_pack_bytes() // 2, np.float16)
     w1, b1, w2, w3 = _f32(conv1_w), _f32(conv1_b), _f32(conv2_w), _f32(conv3_w)
     assert w1.shape == (64, 3, 7, 7) and b1.shape == (64,) and w2.shape == (64, 64, 3, 3) and w3.shape == (64, 64, 3, 3)
-    rc = lib.srlhip_encoder_pack(_ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), _ptr(out), out.nbytes)
+    scales = np.zeros(3, np.float32)
+    rc = lib.srlhip_encoder_pack(_ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), _ptr(out), out.nbytes, _ptr(scales))
     if rc:
         raise SrlHipError("srlhip_encoder_pack failed ({})".format(rc))
-    return out
+    return out, scales
 
 
 class Encoder(object):
@@ -324,6 +328,15 @@ class Encoder(object):
         """images_ptr / states_ptr: raw device pointers (e.g. torch.Tensor.data_ptr()); enqueue-only on `stream`."""
         self._check(self._lib.srlhip_encoder_forward(self._e, _ptr(images_ptr), int(n), _ptr(states_ptr),
                                                      ctypes.c_void_p(stream) if stream else None), "srlhip_encoder_forward")
+
+    PHASES = ("unpack", "layer1", "barrier1", "layer2_kloop", "layer2_epilogue", "barrier2", "layer3", "fc", "turnaround")
+
+    def phase_cycles(self, images_ptr, n, states_ptr):
+        """Diagnostic forward: {phase: shader cycles} of workgroup 0 (slowest wave, averaged over its first frames)."""
+        c = np.zeros(9, np.int64)
+        self._check(self._lib.srlhip_encoder_phase_cycles(self._e, _ptr(images_ptr), int(n), _ptr(states_ptr), _ptr(c)),
+                    "srlhip_encoder_phase_cycles")
+        return dict(zip(self.PHASES, c.tolist()))
 
     def overflow(self):
         flag = ctypes.c_int32()

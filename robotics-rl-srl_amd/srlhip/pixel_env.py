@@ -26,21 +26,33 @@ class PixelStateVecEnv(object):
         self.rewards = torch.zeros((num_envs,), dtype=torch.float32, device=self.device)
         self.dones = torch.zeros((num_envs,), dtype=torch.uint8, device=self.device)
         self.actions = torch.zeros((num_envs,), dtype=torch.int32, device=self.device)
+        self.states = torch.zeros((num_envs, encoder.state_dim), dtype=torch.float32, device=self.device)
+        self._stream_ptr = self.h.stream()
+        self._stream = torch.cuda.ExternalStream(self._stream_ptr, device=self.device)
 
     def _encode(self):
+        if self.encoder.hip is not None:
+            # fused HIP encoder: enqueue on the stepper's own stream right behind the rasteriser (no host sync), then
+            # order torch's current stream behind it so the caller can consume states / rewards / dones as usual
+            states = self.encoder.getStates(self.images, stream=self._stream_ptr, out=self.states)
+            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+            return states
         self.h.sync()                                  # images were written on the stepper's stream
         return self.encoder.getStates(self.images)
 
     def reset(self):
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
         self.h.reset(obs_out=self.images.data_ptr())
         return self._encode()
 
     def step(self, actions=None):
-        """actions: int32 device tensor [N] (None -> device-sampled random agent).  -> states, rewards, dones."""
+        """actions: int32 device tensor [N] (None -> device-sampled random agent).  -> states, rewards, dones
+        (device tensors, overwritten by the next call)."""
+        # the stepper's stream overwrites images / states / rewards / dones: wait for their readers (and for `actions`)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
         if actions is None:
             self.h.rollout(1, out=(self.images.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(), self.actions.data_ptr()))
         else:
-            torch.cuda.current_stream(self.device).synchronize()
             self.h.step(actions.data_ptr(), out=(self.images.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr()))
         return self._encode(), self.rewards, self.dones
 

@@ -132,9 +132,10 @@ class SRLNeuralNetwork(object):
         return self.model.fc(x.reshape(x.size(0), -1))
 
     @th.no_grad()
-    def getStates(self, images_u8, stream=None):
+    def getStates(self, images_u8, stream=None, out=None):
         """uint8 [N][H][W][C] (numpy, or a torch tensor already on the device) -> float32 [N][state_dim].
-        stream: raw HIP stream to enqueue the fused kernel on (default: torch's current stream)."""
+        stream: raw HIP stream to enqueue the fused kernel on (default: torch's current stream); out: optional
+        preallocated float32 [N][state_dim] device tensor (both only used by the fused HIP path)."""
         if self.hip is None:
             return self.getStatesTorch(images_u8)
         if isinstance(images_u8, np.ndarray):
@@ -142,7 +143,9 @@ class SRLNeuralNetwork(object):
         images_u8 = images_u8.to(self.device).contiguous()
         assert images_u8.dtype == th.uint8 and tuple(images_u8.shape[1:]) == (64, 64, 3), images_u8.shape
         n = images_u8.shape[0]
-        out = th.empty((n, self.state_dim), dtype=th.float32, device=self.device)
+        if out is None:
+            out = th.empty((n, self.state_dim), dtype=th.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == th.float32 and tuple(out.shape) == (n, self.state_dim)
         if stream is None:
             stream = th.cuda.current_stream(self.device).cuda_stream
         self.hip.forward(images_u8.data_ptr(), n, out.data_ptr(), stream)

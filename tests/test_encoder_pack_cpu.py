@@ -21,13 +21,13 @@ def random_bn_net(state_dim, seed):
     return SRLNeuralNetwork(state_dim, img_shape=(64, 64), state_dict=net.model.state_dict(), backend="torch")
 
 
-def decode_pack(pack):
-    """-> effective weights w1[64][224] (already divided by the 256 scale), w2[64][576], w3[64][576]."""
+def decode_pack(pack, scales):
+    """-> effective weights w1[64][224], w2[64][576], w3[64][576] with the per-layer pre-scales undone."""
     pack = pack.astype(np.float64)
 
     def layer(words, steps):
         frag = words.reshape(2, steps, 64, 16)                    # [n-half][k-step][lane][8 hi | 8 lo]
-        eff = frag[..., :8] + frag[..., 8:] / 2048.0
+        eff = frag[..., :8] + frag[..., 8:]
         w = np.zeros((64, steps * 16))
         for nh in range(2):
             for lane in range(64):
@@ -37,7 +37,7 @@ def decode_pack(pack):
         return w
 
     n1, n2 = 2 * S1 * 64 * 16, 2 * S2 * 64 * 16
-    return layer(pack[:n1], S1) / 256.0, layer(pack[n1:n1 + n2], S2), layer(pack[n1 + n2:], S2)
+    return layer(pack[:n1], S1) / scales[0], layer(pack[n1:n1 + n2], S2) / scales[1], layer(pack[n1 + n2:], S2) / scales[2]
 
 
 def emulate(img, w1, w2, w3, b2, b3, fcw, fcb):
@@ -78,9 +78,11 @@ def emulate(img, w1, w2, w3, b2, b3, fcw, fcb):
 def test_pack_decodes_to_the_network():
     net = random_bn_net(5, 3)
     (w1, b1), (w2, b2), (w3, b3), (fw, fb) = net.folded_weights()
-    pack = _lib.encoder_pack(w1, b1, w2, w3)
+    pack, scales = _lib.encoder_pack(w1, b1, w2, w3)
     assert pack.nbytes == _lib.load().srlhip_encoder_pack_bytes() and np.isfinite(pack.astype(np.float32)).all()
-    e1, e2, e3 = decode_pack(pack)
+    assert all(s > 0 and np.log2(s) == np.round(np.log2(s)) for s in scales)          # powers of two: undone exactly
+    assert 8192 <= np.abs(pack.astype(np.float32)[:2 * S1 * 64 * 16]).max() <= 16384   # top of the scaled range
+    e1, e2, e3 = decode_pack(pack, scales.astype(np.float64))
     # layers 2/3: plain weights with the two kernel axes swapped (the network sees the frame transposed)
     ref2 = np.transpose(w2, (0, 3, 2, 1)).reshape(64, 576)        # [o][ky][kx][c] with w[o][c][kx][ky]
     assert np.abs(e2 - ref2).max() <= 2.0 ** -21 * np.abs(ref2).max()
@@ -103,7 +105,7 @@ def test_pack_decodes_to_the_network():
 def test_pack_rejects_short_buffers_and_encoder_needs_a_gpu():
     lib = _lib.load()
     z = np.zeros(16, np.float32)
-    assert lib.srlhip_encoder_pack(_lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), 16) == -22
+    assert lib.srlhip_encoder_pack(_lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), 16, _lib._ptr(z)) == -22
     assert not _lib.encoder_supported(224, 224, 3) and not _lib.encoder_supported(64, 64, 6)
     if not torch.cuda.is_available():
         net = SRLNeuralNetwork(2, img_shape=(64, 64))              # CPU device: PyTorch forward, never the HIP handle
