@@ -214,14 +214,13 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
             } else {
                 conv1_single(B1h, B1l, 15, lane_base, carry);
             }
-#pragma unroll 1
-            for (int p = 0; p < 8; p++) {
-                const int prow = 8 * mh + p;                               // pooled row <- conv rows 2p-1, 2p, 2p+1
-                conv1_pair(B1h, B1l, 2 * prow, 2 * prow + 1, lane_base, v0, v1);
+            // Software pipeline: the 56 MFMAs of pooled row p+1 and the pooling / split / store epilogue of row p are
+            // independent instruction streams in one basic block, so the epilogue's VALU and LDS work issues in the
+            // shadow of the matrix pipe (one wave per SIMD: nothing else would hide it).
+            auto epilogue = [&](int prow, const f32x16 &above, const f32x16 &r0, const f32x16 &r1) {
                 f32x16 m;
 #pragma unroll
-                for (int r = 0; r < 16; r++) m[r] = fmaxf(carry[r], fmaxf(v0[r], v1[r]));
-                carry = v1;
+                for (int r = 0; r < 16; r++) m[r] = fmaxf(above[r], fmaxf(r0[r], r1[r]));
                 // a lane holds pixels x = 8g + 4h + r (register 4g + r); the pixel left of its 4-group is lane^32's
                 const float t3 = __shfl_xor(m[3], 32), t7 = __shfl_xor(m[7], 32), t11 = __shfl_xor(m[11], 32),
                             t15 = __shfl_xor(m[15], 32);
@@ -234,7 +233,24 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
                     store_split(A2H, A2L, (prow * 16 + k) * PX + ch * 2, fmaxf(0.f, ka * inv1), ovf);
                     store_split(A2H, A2L, (prow * 16 + k + 1) * PX + ch * 2, fmaxf(0.f, kb * inv1), ovf);
                 }
+            };
+            conv1_pair(B1h, B1l, 16 * mh, 16 * mh + 1, lane_base, v0, v1);
+#pragma unroll 1
+            for (int p = 0; p < 7; p++) {
+                const int prow = 8 * mh + p;                               // pooled row <- conv rows 2p-1, 2p, 2p+1
+                f32x16 n0, n1;
+                conv1_pair(B1h, B1l, 2 * prow + 2, 2 * prow + 3, lane_base, n0, n1);
+                epilogue(prow, carry, v0, v1);
+                // pin the interleave: per MFMA (32 cycles of matrix pipe) four VALU and one LDS instruction
+#pragma unroll
+                for (int u = 0; u < 56; u++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+                }
+                carry = v1; v0 = n0; v1 = n1;
             }
+            epilogue(8 * mh + 7, carry, v0, v1);
         }
         ENC_STAMP(2);
         __syncthreads();
