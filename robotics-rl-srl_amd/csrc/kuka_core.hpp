@@ -714,7 +714,8 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
     SRL_ROW_STAT_HOOK(ngen, nlim);
 #endif
     // -- projected Gauss-Seidel, 150 sweeps.  Row order: arm motors, button motor, arm limits, button
-    //    limits, contacts (LDS rows [0, nlim) are the arm limits, [nlim, ngen) the contacts).
+    //    limits, contacts (LDS rows [0, nlim) are the arm limits, [nlim, ngen) the contacts).  Four wave-uniform
+    //    code paths: 1 no generic rows, 2a <= 2 contact rows, 2b more contact rows, 3 arm-limit rows present.
     //    The arm motor block is iterated in impulse space: lam_i <- clamp((c_i - g_i - sum_{j!=i} W_ij lam_j) / W_ii),
     //    which is the same Gauss-Seidel update as accumulating dv = W lam row by row, with a 4-deep
     //    dependent chain per row and 6 FMAs instead of 7 + bookkeeping; the velocity change is formed once
@@ -767,8 +768,67 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
             for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
             cur[ND - 1] = cs[ND - 1];
         }
+    } else if (!SRL_ANY(nlim > 0) && !SRL_ANY(ngen > 2)) {
+        // -- path 2a (the common contact case: at most two contact rows per lane, no arm joint near its stop).  Both rows
+        //    live in VGPRs (lanes without one carry an all-zero row, a no-op) and are folded into the arm rows' scatter
+        //    scheme: a contact impulse change d moves the arm rows' constant terms directly (cs_i -= d WJ_i / W_ii), so the
+        //    sweep's tail is cur = cs + nxt, and a row's own residual needs WJ.lam (7 FMAs) plus the 2x2 row-row
+        //    couplings K_kr = (J_k . WJ_r) / D_k instead of J.g (7 more).  g = sum_k WJ_k mu_k is formed once at the end.
+        double rC[2][ND], rWJs[2][ND], rWJ[2][ND], rK[2][2], rJbD[2], rWJb[2], rRhs[2], rLo[2], rHi[2], rMu[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const bool has = k < ngen;
+            const int base = k * ROW_STRIDE;
+            const double di = has ? sc.row(base + ROW_DINV) : 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; i++) {
+                rWJ[k][i] = has ? sc.row(base + ROW_WJ + i) : 0.0;
+                rC[k][i] = rWJ[k][i] * di;
+                rWJs[k][i] = rWJ[k][i] * dinv[i];
+            }
+            rJbD[k] = has ? sc.row(base + ROW_JB) * di : 0.0; rWJb[k] = has ? sc.row(base + ROW_WJB) : 0.0;
+            rRhs[k] = has ? sc.row(base + ROW_RHS) : 0.0;
+            rLo[k] = has ? sc.row(base + ROW_LO) : 0.0; rHi[k] = has ? sc.row(base + ROW_HI) : 0.0; rMu[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                double a = 0.0;
+#pragma unroll
+                for (int i = 0; i < ND; i++) a += ((k < ngen) ? sc.row(k * ROW_STRIDE + ROW_J + i) : 0.0) * rWJ[r][i];
+                rK[k][r] = a * ((k < ngen) ? sc.row(k * ROW_STRIDE + ROW_DINV) : 0.0);
+            }
+        const bool rSel[2] = {NB == 2 && (bsel & 1u) != 0, NB == 2 && (bsel & 2u) != 0};
+        const bool second = SRL_ANY(ngen > 1);
+        for (int it = 0; it < kSolverIters; it++) {
+            SRL_ARM_ROWS(0)
+            SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
+            SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
+            SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+            SRL_BUTTON2_MOTOR
+            SRL_BUTTON2_LIMITS
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (k == 1 && !second) break;
+                double a = rRhs[k] - rJbD[k] * (rSel[k] ? dvb2 : dvb);
+#pragma unroll
+                for (int i = 0; i < ND; i++) a -= rC[k][i] * lam[i];
+                a -= rK[k][0] * rMu[0];
+                a -= rK[k][1] * rMu[1];
+                const double d = fmin(fmax(a, rLo[k] - rMu[k]), rHi[k] - rMu[k]);
+                rMu[k] += d;
+#pragma unroll
+                for (int i = 0; i < ND; i++) cs[i] -= d * rWJs[k][i];
+                if (rSel[k]) dvb2 += d * rWJb[k]; else dvb += d * rWJb[k];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; i++) { cur[i] = cs[i] + nxt[i]; nxt[i] = 0.0; }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; i++) g[i] = rWJ[0][i] * rMu[0] + rWJ[1][i] * rMu[1];
     } else if (!SRL_ANY(nlim > 0)) {
-        // -- path 2: contact rows only (no arm joint near its stop).  The first two contact rows of every lane are
+        // -- path 2b: contact rows only (no arm joint near its stop), more than two on some lane.  The first two contact rows of every lane are
         //    held in VGPRs for all 150 sweeps (lanes without one carry an all-zero row, which is a no-op), the
         //    rest stay in LDS.  Arm velocity change so far = W lam + g with g = sum_k WJ_k mu_k.
         double rJ[2][ND], rWJ[2][ND], rJb[2], rWJb[2], rDinv[2], rRhs[2], rLo[2], rHi[2], rMu[2];
