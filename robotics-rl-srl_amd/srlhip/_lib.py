@@ -71,6 +71,12 @@ def load():
         raise SrlHipError(
             "libsrlhip.so is not built ({}). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C robotics-rl-srl_amd/csrc`. There is no CPU fallback for the env stepper.".format(LIB_PATH))
+    # PyTorch ships its own libamdhip64.so; the first HIP runtime loaded serves the whole process and torch cannot see
+    # the GPU through /opt/rocm's copy.  When torch is installed, let it load its runtime first (libsrlhip.so works with either).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     lib.srlhip_last_error.restype = ctypes.c_char_p
