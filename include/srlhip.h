@@ -85,7 +85,9 @@ typedef struct srlhip_config {
     int32_t action_joints;    /* ctor kwarg action_joints (Kuka)                           */
     int32_t obs_mode;         /* SRLHIP_OBS_*  (ctor kwarg srl_model)                      */
     int32_t img_h, img_w;     /* raw_pixels size (reference: 224x224)                      */
-    int32_t multi_view;       /* ctor kwarg multi_view (Kuka, 6-channel image)             */
+    int32_t multi_view;       /* second camera stacked behind the first (6-channel image): ctor kwarg
+                                 multi_view (Kuka, kuka_button_gym_env.py:401-417) / fpv (MobileRobot,
+                                 mobile_robot_env.py:313-332: the camera riding on the robot)       */
     int32_t rng_mode;         /* SRLHIP_RNG_*                                              */
     int32_t auto_reset;       /* 1: step() resets finished envs itself and returns the first
                                  observation of the next episode (SB VecEnv semantics,
@@ -178,7 +180,7 @@ int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
 int srlhip_device_ptr(srlhip_handle h, int32_t field, void **dptr);
 
 /* Replaces <Env>.render("rgb_array") (kuka_button_gym_env.py:370-420, mobile_robot_env.py:282-334)
- * for the whole batch: uint8 [num_envs][img_h][img_w][3 (6 with multi_view)] of the CURRENT state,
+ * for the whole batch: uint8 [num_envs][img_h][img_w][3 (6 with multi_view / fpv)] of the CURRENT state,
  * produced by the tile rasteriser.  Also what step()/reset()/rollout() write to obs_out when
  * cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS.  img_out follows cfg.io_device. */
 int srlhip_render(srlhip_handle h, void *img_out);

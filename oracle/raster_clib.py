@@ -13,7 +13,7 @@ def render(kind, state, h=64, w=64, multi_view=False):
     state = np.ascontiguousarray(state, dtype=np.float64)
     n = len(state)
     assert state.shape == (n, {4: 10, 6: 13, 7: 40}.get(kind, 6))
-    img = np.zeros((n, h, w, 6 if (multi_view and kind >= 4) else 3), np.uint8)
+    img = np.zeros((n, h, w, 6 if multi_view else 3), np.uint8)
     clib.lib().raster_oracle_render(int(kind), n, int(h), int(w), int(bool(multi_view)),
                                     state.ctypes.data_as(ctypes.c_void_p), img.ctypes.data_as(ctypes.c_void_p))
     return img

@@ -157,7 +157,7 @@ static void draw(const prim_t *prims, int np, const cam_t *c, int h, int w, int 
  * t2x, t2y.  kind: 0..3 mobile family, 4 kuka, 6 kuka with two buttons, 7 kuka with the ten RandButton distractors
  * (state [n][40]: the 10 kuka values + (x, y, present) x 10). */
 int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const double *state, uint8_t *img) {
-    int e, ncam = (kind >= 4 && multi_view) ? 2 : 1, channels = 3 * ncam;
+    int e, ncam = multi_view ? 2 : 1, channels = 3 * ncam;
     cam_t cams[2];
     if (kind >= 4) {
         const double t1[3] = {0.316, -0.2, -0.1}, t2[3] = {0.316, 0.316, -0.105};
@@ -165,7 +165,8 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
     } else {
         double t[3] = {2, 2, 0};
         if (kind == 1) t[1] = 0.0;
-        cams[0] = camera(t, 4.4, 90, -90, 0, 60); cams[1] = cams[0];
+        const double tf[3] = {-0.25, 0.0, 0.15};   /* fpv camera relative to the robot: mobile_robot_env.py:313-332 */
+        cams[0] = camera(t, 4.4, 90, -90, 0, 60); cams[1] = camera(tf, 0.3, 90, -17, 0, 90);
     }
 #pragma omp parallel for
     for (e = 0; e < n; e++) {
@@ -221,7 +222,11 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
             if (kind == 2) prims[np++] = mk(P_CYL, 0.8f, 0.0f, 0.0f, t2x, t2y, 0.0f, 0.18f, 0, 0.03f, 0, 1, 0);
             prims[np++] = mk(P_BOX, 0.15f, 0.15f, 0.60f, x, y, 0.075f, 0.325f, 0.1f, 0.075f, 0, 1.0f, 0.0f);
         }
-        for (cam = 0; cam < ncam; cam++) draw(prims, np, &cams[cam], h, w, channels, 3 * cam, img + (size_t)e * h * w * channels);
+        for (cam = 0; cam < ncam; cam++) {
+            cam_t c = cams[cam];
+            if (kind < 4 && cam == 1) { c.eye[0] += (float)state[6 * (size_t)e]; c.eye[1] += (float)state[6 * (size_t)e + 1]; }
+            draw(prims, np, &c, h, w, channels, 3 * cam, img + (size_t)e * h * w * channels);
+        }
     }
     return 0;
 }

@@ -62,7 +62,7 @@ size_t action_bytes(const Handle *h) {
 }
 size_t obs_bytes_per_env(const Handle *h) {
     if (h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS)
-        return (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind >= SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3);
+        return (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.multi_view ? 6 : 3);
     return sizeof(float) * obs_dim_of(h->cfg);
 }
 
@@ -430,7 +430,7 @@ int srlhip_render(srlhip_handle hh, void *img_out) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     if (rc) return rc;
-    const size_t bytes = (size_t)h->cfg.img_h * h->cfg.img_w * ((h->cfg.env_kind >= SRLHIP_ENV_KUKA_BUTTON && h->cfg.multi_view) ? 6 : 3) * h->n;
+    const size_t bytes = (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.multi_view ? 6 : 3) * h->n;
     void *d_img = img_out;
     if (!h->cfg.io_device) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, bytes))) return rc; d_img = h->st_obs; }
     if ((rc = raster_render(h, d_img))) return rc;

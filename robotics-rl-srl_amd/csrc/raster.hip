@@ -54,6 +54,7 @@ struct Camera {
 
 struct RasterParams {
     int32_t kind, n, h, w, channels, ncam;
+    int32_t fpv;           // mobile family, second camera: rides on the robot (cam[1] is stored relative to the robot position)
     Camera cam[2];
 };
 
@@ -312,7 +313,8 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     __shared__ int nprims;
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
     const int e = blockIdx.x, cam = blockIdx.y;
-    const Camera c = rp.cam[cam];
+    Camera c = rp.cam[cam];
+    if (rp.fpv && cam == 1) { c.ex += (float)mv.x[e]; c.ey += (float)mv.y[e]; }      // mobile_robot_env.py:315-323
     if (threadIdx.x == 0)
         nprims = rp.kind >= SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
     __syncthreads();
@@ -399,7 +401,8 @@ int raster_render(Handle *h, void *d_img) {
     RasterParams rp;
     const srlhip_config &c = h->cfg;
     rp.kind = c.env_kind; rp.n = h->n; rp.h = c.img_h; rp.w = c.img_w;
-    rp.ncam = (c.env_kind >= SRLHIP_ENV_KUKA_BUTTON && c.multi_view) ? 2 : 1;
+    rp.ncam = c.multi_view ? 2 : 1;
+    rp.fpv = (c.env_kind < SRLHIP_ENV_KUKA_BUTTON && c.multi_view) ? 1 : 0;
     rp.channels = 3 * rp.ncam;
     RasterKukaView kv = {};
     RasterMobileView mv = {};
@@ -411,7 +414,10 @@ int raster_render(Handle *h, void *d_img) {
     } else {
         const double t[3] = {2, c.env_kind == SRLHIP_ENV_MOBILE_1D ? 0.0 : 2.0, 0};
         rp.cam[0] = make_camera(t, 4.4, 90, -90, 0, 60);          // mobile_robot_env.py:76-84, 1D :33
-        rp.cam[1] = rp.cam[0];
+        // fpv=True (mobile_robot_env.py:313-332): camera target (robot_x - 0.25, robot_y, 0.15), distance 0.3, yaw = the
+        // env's camera yaw, pitch -17, fov 90; stored relative to the robot, the kernel adds each env's (x, y)
+        const double tf[3] = {-0.25, 0.0, 0.15};
+        rp.cam[1] = make_camera(tf, 0.3, 90, -17, 0, 90);
         const MobileState &s = h->mobile;
         mv.x = s.pos_x; mv.y = s.pos_y; mv.tx = s.tgt_x; mv.ty = s.tgt_y; mv.t2x = s.tgt2_x; mv.t2y = s.tgt2_y; mv.cur = s.cur_target;
     }

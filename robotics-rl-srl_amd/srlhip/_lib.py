@@ -168,7 +168,7 @@ class Handle(object):
         n = self.num_envs
         lead = (n,) if T is None else (T, n)
         if self.cfg.obs_mode == OBS_RAW_PIXELS:
-            ch = 6 if (self.cfg.multi_view and self.cfg.env_kind >= ENV_KUKA_BUTTON) else 3
+            ch = 6 if self.cfg.multi_view else 3
             return np.zeros(lead + (self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         return np.zeros(lead + (self.obs_dim,), np.float32)
 
@@ -256,7 +256,7 @@ class Handle(object):
         if self.cfg.io_device:
             self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
             return out
-        ch = 6 if (self.cfg.multi_view and self.cfg.env_kind >= ENV_KUKA_BUTTON) else 3
+        ch = 6 if self.cfg.multi_view else 3
         if out is None:
             out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")

@@ -154,7 +154,7 @@ class MobileRobotGymEnv(_HipEnv):
         if not is_discrete and self.ENV_KIND in (_lib.ENV_MOBILE_1D, _lib.ENV_MOBILE_2TARGET):
             raise ValueError("Only discrete actions is supported")
         self._open(is_discrete=is_discrete, random_target=random_target, shape_reward=shape_reward,
-                   srl_model=srl_model, max_distance=max_distance, device_id=device_id)
+                   srl_model=srl_model, max_distance=max_distance, device_id=device_id, multi_view=bool(fpv))
         self.seed(0)
         if is_discrete:
             self.action_space = Discrete(self.N_DISCRETE_ACTIONS)
@@ -163,7 +163,8 @@ class MobileRobotGymEnv(_HipEnv):
         if self.srl_model == "ground_truth":
             self.state_dim = self.getGroundTruthDim()
         if self.srl_model == "raw_pixels":
-            self.observation_space = Box(low=0, high=255, shape=(self._height, self._width, 3), dtype=np.uint8)
+            # fpv=True stacks the car-camera view behind the top-down one (mobile_robot_env.py:313-332, getNChannels)
+            self.observation_space = Box(low=0, high=255, shape=(self._height, self._width, 6 if fpv else 3), dtype=np.uint8)
         else:
             self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.state_dim,), dtype=np.float32)
 

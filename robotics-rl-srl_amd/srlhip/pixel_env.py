@@ -15,7 +15,7 @@ class PixelStateVecEnv(object):
         kw = dict(env_kwargs or {})
         cfg = _lib.default_config(ENV_CLASSES[env_id].ENV_KIND)
         cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = num_envs, device_id, first_env_id, seed
-        cfg.random_target, cfg.multi_view = int(kw.get("random_target", False)), int(kw.get("multi_view", False))
+        cfg.random_target, cfg.multi_view = int(kw.get("random_target", False)), int(bool(kw.get("multi_view", False)) or bool(kw.get("fpv", False)))
         cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, img_shape[0], img_shape[1]
         cfg.rng_mode, cfg.auto_reset, cfg.io_device = rng_mode, 1, 1
         self.h = _lib.Handle(cfg)

@@ -39,7 +39,7 @@ class HipVecEnv(object):
         cfg.force_down = int(kw.get("force_down", bool(cfg.force_down)))      # ctor default differs per env (Kuka2Button: False)
         cfg.action_repeat = int(kw.get("action_repeat", 1))
         cfg.action_joints = int(kw.get("action_joints", False))
-        cfg.multi_view = int(kw.get("multi_view", False))
+        cfg.multi_view = int(bool(kw.get("multi_view", False)) or bool(kw.get("fpv", False)))   # Kuka: multi_view, Mobile: fpv
         if "max_distance" in kw:
             cfg.max_distance = float(kw["max_distance"])
         self.srl_model = kw.get("srl_model", "raw_pixels")

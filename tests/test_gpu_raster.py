@@ -64,6 +64,27 @@ def test_mobile_images_match_oracle(kind):
     h.close()
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_mobile_fpv_camera_matches_oracle(kind):
+    """fpv=True (mobile_robot_env.py:313-332): the car camera's view is stacked behind the top-down one and follows the robot."""
+    n = 32
+    cfg = _lib.default_config(kind)
+    cfg.num_envs, cfg.seed0, cfg.random_target, cfg.multi_view = n, 5, 1, 1
+    cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, 64, 64
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    assert obs.shape == (n, 64, 64, 6)
+    assert_images_equal(obs, raster_clib.render(kind, mobile_state(h), multi_view=True))
+    plain = raster_clib.render(kind, mobile_state(h))
+    assert_images_equal(obs[..., :3], plain)                       # the first three channels are the usual top-down view
+    first = obs.copy()
+    out = h.rollout(20, actions=np.random.RandomState(2).randint(2, size=(20, n)).astype(np.int32))
+    assert_images_equal(out["obs"][-1], raster_clib.render(kind, mobile_state(h), multi_view=True))
+    assert (out["obs"][-1][..., 3:] != first[..., 3:]).reshape(n, -1).any(1).mean() > 0.5   # the view moves with the robot
+    assert len(np.unique(obs[..., 3:].reshape(-1, 3), axis=0)) > 3   # robot hood, floor checker, wall, sky: not a flat fill
+    h.close()
+
+
 def test_facade_render_and_raw_pixel_vec_env():
     from environments.kuka_gym.kuka_button_gym_env import KukaButtonGymEnv
     from srlhip.vec_env import HipVecEnv
@@ -75,6 +96,10 @@ def test_facade_render_and_raw_pixel_vec_env():
     obs2, r, d, _ = env.step(4)
     assert obs2.shape == (224, 224, 3)
     env.close()
+    from environments.mobile_robot.mobile_robot_env import MobileRobotGymEnv
+    fenv = MobileRobotGymEnv(fpv=True)
+    assert fenv.observation_space.shape == (224, 224, 6) and fenv.reset().shape == (224, 224, 6)
+    fenv.close()
     venv = HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "raw_pixels", "img_shape": (64, 64)})
     o = venv.reset()
     assert o.shape == (16, 64, 64, 3) and o.dtype == np.uint8
