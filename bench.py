@@ -57,14 +57,15 @@ def measured_traffic(kernel, env_steps_per_launch):
     import glob
     import re
     wl = "kuka" if kernel.startswith("kuka") else "mobile"
+    kernels = [kernel] + (["mobile_sample_actions_k"] if wl == "mobile" else [])   # the timed region covers both mobile kernels
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_{}_pmc_{}.csv".format(wl, counter))))
         if not files:
             return None
         for row in csv.DictReader(open(files[-1])):
-            if row["kernel"] == kernel and row["counter"] == counter:
-                out[counter] = float(row["avg_per_dispatch"])
+            if row["kernel"] in kernels and row["counter"] == counter:
+                out[counter] = out.get(counter, 0.0) + float(row["avg_per_dispatch"])
     if len(out) != 2:
         return None
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
@@ -222,8 +223,8 @@ def main():
     if workload == "kuka_pixels":
         return bench_pixels(args, rank, local_rank, world, dev)
     n = args.envs_per_gpu
-    inner = args.inner_steps or (256 if workload == "mobile" else 32)
-    K = args.steps if args.steps is not None else (40 if workload == "mobile" else 20)
+    inner = args.inner_steps or (2048 if workload == "mobile" else 32)     # T = 2048
+    K = args.steps if args.steps is not None else (20 if workload == "mobile" else 20)
     W = args.warmup if args.warmup is not None else (5 if workload == "mobile" else 3)
 
     kind = _lib.ENV_MOBILE if workload == "mobile" else _lib.ENV_KUKA_BUTTON
@@ -281,10 +282,10 @@ def main():
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
     roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "mobile_rollout_k" if workload == "mobile" else "kuka_rollout_k",
+                "kernel": "mobile_rollout_ep_k" if workload == "mobile" else "kuka_rollout_k",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
-    if n == 4096 and inner == (256 if workload == "mobile" else 32):       # geometry the PMC passes were taken at
+    if n == 4096 and inner == (2048 if workload == "mobile" else 32):       # geometry the PMC passes were taken at
         roofline["traffic"] = measured_traffic(roofline["kernel"], steps_per_launch)
         roofline["traffic_source"] = "profiles/ PMC summaries (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
     if workload == "kuka":

@@ -319,6 +319,100 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     st.last_length[e] = last_len; st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 
+// Episode-parallel rollout (Philox mode with auto-reset).  In the MobileRobot family an episode always lasts exactly
+// 251 steps (`done = counter > 250`, `terminated` is never set: mobile_robot_env.py:336-343) and a reset consumes a
+// fixed number of counter-based draws, so the state an env has right after its k-th reset inside a rollout is a pure
+// function of (key, counter + (k-1) * draws): the T-step rollout of one env splits into independent segments — the
+// rest of its running episode, then whole episodes — which run on separate lanes.  At the 4096-env BASELINE size a
+// 2048-step rollout becomes 4096 x 10 lanes of <= 251 steps instead of 4096 lanes of 2048 steps: the recurrence is the
+// only sequential thing on this path, and this cuts it ~8x.  Outputs, final state, counters and episode statistics
+// are bit-identical to mobile_rollout_k (tests/test_gpu_mobile.py).  Lane (j, e) = segment j of env e; the waves of a
+// segment slot store whole [t][e..e+63] rows when their envs' episode clocks agree (they do after a common reset).
+constexpr int kEpisodeSteps = 251;
+
+template <int KIND, int DISC>
+__global__ void __launch_bounds__(kBlock)
+mobile_rollout_ep_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
+                    const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
+                    uint8_t *__restrict__ done_out, int advance_actr) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int e = (int)(gid % p.n), j = (int)(gid / p.n);
+    if (j >= smax) return;
+    p.kind = KIND; p.is_discrete = DISC;                                   // compile-time constants from here on
+    const int c0 = s.counter[e];
+    const int L0 = c0 <= kEpisodeSteps - 1 ? kEpisodeSteps - c0 : 1;       // steps until the running episode ends
+    const int t_lo = j == 0 ? 0 : L0 + kEpisodeSteps * (j - 1);
+    if (t_lo >= T) return;
+    const int t_end = L0 + kEpisodeSteps * j;                             // the step after this segment's episode ends
+    const int t_hi = t_end < T ? t_end : T;
+    const bool last = t_hi == T;                                          // this lane leaves the env's final state
+    const int n_completed = T >= L0 ? 1 + (T - L0) / kEpisodeSteps : 0;   // episodes of env e that finish inside the rollout
+    PhiloxRng rng;
+    rng.p.k0 = rs.key[e]; rng.p.k1 = rs.key[p.n + e]; rng.p.stream = 0;
+    const uint64_t ctr0 = rs.ctr[e];
+    MobileEnv m;
+    double ep_ret = 0.0, seg_ret = 0.0, last_reward = 0.0;
+    int32_t ep_len = 0, seg_len = 0;
+    if (j == 0) {
+        load_env(s, e, m);
+        rng.p.ctr = ctr0;
+        ep_ret = st.ep_return[e]; ep_len = st.ep_length[e];
+    } else {
+        rng.p.ctr = ctr0 + (uint64_t)(j - 1) * (uint64_t)draws_per_reset;
+        reset_env(p, rng, m);                                              // the reset the previous segment ends with
+    }
+    const int32_t *act_i = static_cast<const int32_t *>(actions);
+    const float2 *act_f = static_cast<const float2 *>(actions);
+    constexpr int kChunk = 16;                                             // see mobile_rollout_k: one vmcnt drain per chunk
+    for (int t0 = t_lo; t0 < t_hi; t0 += kChunk) {
+        int ai[kChunk]; float2 af[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int64_t r = (int64_t)min(t0 + k, t_hi - 1) * p.n + e;
+            if (p.is_discrete) ai[k] = act_i[r]; else af[k] = act_f[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int t = t0 + k;
+            if (t < t_hi) {
+                const int64_t row = (int64_t)t * p.n + e;
+                const int a = p.is_discrete ? ai[k] : 0;
+                const float a0 = p.is_discrete ? 0.f : af[k].x, a1 = p.is_discrete ? 0.f : af[k].y;
+                const double dv = 0.1 + rng.normal(0.0, 0.0);              // DELTA_POS + N(0, NOISE_STD = 0): draws nothing
+                double reward; bool done;
+                step_env<KIND, DISC>(p, m, a, a0, a1, dv, reward, done);
+                ep_ret += reward; ep_len += 1; last_reward = reward;
+                if (done) {
+                    seg_ret = ep_ret; seg_len = ep_len; ep_ret = 0.0; ep_len = 0;
+                    reset_env(p, rng, m);
+                }
+                float o0, o1;
+                observe(p, m, o0, o1);
+                if (obs) {
+                    if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
+                    else {
+                        __builtin_nontemporal_store(o0, obs + 2 * row);
+                        __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+                    }
+                }
+                if (rew) __builtin_nontemporal_store((float)reward, rew + row);
+                if (done_out) __builtin_nontemporal_store((uint8_t)done, done_out + row);
+            }
+        }
+    }
+    if (t_end <= T && j == n_completed - 1) {        // the last episode that finished inside the rollout
+        st.last_return[e] = seg_ret; st.last_length[e] = seg_len;
+    }
+    if (last) {
+        store_env(s, e, m);
+        rs.ctr[e] = rng.p.ctr;
+        if (advance_actr) rs.act_ctr[e] += (uint64_t)T;
+        st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_reward[e] = last_reward;
+        st.n_finished[e] += n_completed;
+    }
+}
+
 MobileParams params_of(const Handle *h) {
     MobileParams p;
     p.kind = h->cfg.env_kind; p.is_discrete = h->cfg.is_discrete; p.random_target = h->cfg.random_target;
@@ -393,6 +487,26 @@ void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actio
 #undef SRL_GO
 }
 
+void launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
+                       uint8_t *d_done, int advance_actr) {
+    const int smax = 1 + (T - 1 + kEpisodeSteps - 1) / kEpisodeSteps;     // first segment of one step + whole episodes
+    const int64_t lanes = (int64_t)smax * h->n;
+    dim3 grid((unsigned)((lanes + kBlock - 1) / kBlock)), block(kBlock);
+    const int draws = mobile_reset_rand_count(h->cfg);
+#define SRL_GO(KIND, DISC)                                                                                              \
+    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats, T, \
+                       draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr)
+#define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
+    switch (p.kind) {
+        case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
+        case SRLHIP_ENV_MOBILE_1D: SRL_KIND(SRLHIP_ENV_MOBILE_1D) break;
+        case SRLHIP_ENV_MOBILE_2TARGET: SRL_KIND(SRLHIP_ENV_MOBILE_2TARGET) break;
+        default: SRL_KIND(SRLHIP_ENV_MOBILE_LINE)
+    }
+#undef SRL_KIND
+#undef SRL_GO
+}
+
 }  // namespace
 
 int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done,
@@ -421,7 +535,9 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
         d_actions = plane;
         advance = 1;
     }
-    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
+    // counter-based streams + fixed-length episodes: segments of the rollout run in parallel (mobile_rollout_ep_k)
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX && p.auto_reset && T >= 32) launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance);
+    else if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     else launch_rollout<SRLHIP_RNG_MT19937>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;

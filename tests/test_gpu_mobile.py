@@ -95,6 +95,51 @@ def test_philox_random_agent_rollout_matches_oracle(discrete):
     h.close(); h2.close()
 
 
+@pytest.mark.parametrize("kind,random_target,discrete", [(0, 1, 1), (1, 1, 1), (2, 1, 1), (3, 0, 1), (0, 0, 0)])
+def test_episode_parallel_rollout_equals_step_by_step(kind, random_target, discrete):
+    """The Philox rollout runs the segments of an env's rollout (rest of the running episode, then whole 251-step
+    episodes) on separate lanes (mobile_rollout_ep_k); everything it leaves behind — output planes, env state, RNG
+    counters, episode statistics — has to equal T single-step launches of the sequential kernel.  Episode clocks are
+    desynchronised first (masked resets, odd chunk lengths) so that wavefronts mix different segment boundaries."""
+    n, T = 333, 3 * 251 + 77
+    rs = np.random.RandomState(kind + 10)
+    if discrete:
+        acts = rs.randint(N_ACT[kind], size=(T + 200, n)).astype(np.int32)
+    else:
+        acts = rs.uniform(-1.2, 1.2, size=(T + 200, n, 2)).astype(np.float32)
+    hs = [make(kind, n, _lib.RNG_PHILOX, seed0=21, random_target=random_target, is_discrete=discrete) for _ in range(2)]
+    for h in hs:
+        h.reset()
+        h.rollout(70, actions=acts[:70])                               # T >= 32: already the episode-parallel kernel
+        mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+        h.reset(mask=mask)                                             # a third of the envs restart their episode clock
+        for t in range(70, 113):
+            h.step(acts[t])
+        h.reset(mask=(np.arange(n) % 7 == 1).astype(np.uint8))
+    assert len(np.unique(hs[0].get_state(_lib.F_STEP_COUNT))) >= 3
+    a, b = hs
+    out = a.rollout(T, actions=acts[200:200 + T])
+    obs, rew, done = [], [], []
+    for t in range(T):
+        o, r, d = b.step(acts[200 + t])
+        obs.append(o.copy()); rew.append(r.copy()); done.append(d.copy())
+    assert np.array_equal(out["obs"], np.stack(obs)) and np.array_equal(out["reward"], np.stack(rew))
+    assert np.array_equal(out["done"], np.stack(done)) and out["done"].sum() >= 3 * n
+    for f in (_lib.F_POS_X, _lib.F_POS_Y, _lib.F_TARGET_X, _lib.F_TARGET_Y, _lib.F_TARGET2_X, _lib.F_TARGET2_Y,
+              _lib.F_STEP_COUNT, _lib.F_CUR_TARGET, _lib.F_LAST_REWARD, _lib.F_EP_RETURN, _lib.F_EP_LENGTH):
+        assert np.array_equal(a.get_state(f), b.get_state(f)), f
+    for x, y in zip(a.episode_stats(), b.episode_stats()):
+        assert np.array_equal(x, y)
+    # and the streams continue identically afterwards (same RNG counters): one more episode-parallel rollout on both
+    more = acts[:60]
+    assert np.array_equal(a.rollout(60, actions=more)["obs"], b.rollout(60, actions=more)["obs"])
+    # sampled actions: the action-stream counter advances by T as well
+    if discrete:
+        x, y = a.rollout(300), b.rollout(300)
+        assert np.array_equal(x["actions"], y["actions"]) and np.array_equal(x["obs"], y["obs"])
+    a.close(); b.close()
+
+
 def test_host_rng_mode_and_manual_reset():
     """RNG_HOST harness: every draw supplied by the caller (numpy RandomState per env),
     no auto-reset: finished envs are reset with srlhip_reset(mask) like a VecEnv worker."""
