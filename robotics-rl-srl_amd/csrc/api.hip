@@ -191,6 +191,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     h->st_actions = h->st_noise = h->st_obs = h->st_rew = h->st_done = h->st_mask = h->st_rand = nullptr;
     h->st_actions_sz = h->st_noise_sz = h->st_obs_sz = h->st_rew_sz = h->st_done_sz = h->st_mask_sz = h->st_rand_sz = 0;
     h->pin_in = h->pin_out = nullptr; h->pin_in_sz = h->pin_out_sz = 0;
+    h->raster_rays[0] = h->raster_rays[1] = nullptr; h->raster_bg[0] = h->raster_bg[1] = nullptr;
     memset(&h->rng, 0, sizeof h->rng); memset(&h->stats, 0, sizeof h->stats); memset(&h->mobile, 0, sizeof h->mobile);
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; srlhip_destroy(reinterpret_cast<srlhip_handle>(h)); return code; };

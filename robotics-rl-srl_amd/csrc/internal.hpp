@@ -88,6 +88,10 @@ struct Handle {
     // staging buffers for io_device == 0
     void *st_actions, *st_noise, *st_obs, *st_rew, *st_done, *st_mask, *st_rand;
     size_t st_actions_sz, st_noise_sz, st_obs_sz, st_rew_sz, st_done_sz, st_mask_sz, st_rand_sz;
+    // rasteriser: per fixed camera, the unit ray of every pixel + depth / colour of the static scenery behind it
+    // (built lazily on the first render; lives in `allocs`)
+    float4 *raster_rays[2];
+    uint32_t *raster_bg[2];
     void *pin_in, *pin_out;          // pinned host bounce buffers of srlhip_step (host-pointer mode)
     size_t pin_in_sz, pin_out_sz;
 

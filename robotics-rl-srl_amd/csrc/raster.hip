@@ -12,10 +12,16 @@
 // analytic primitives (plane, z-rotated box, upright cylinder, capsule) — is built
 // once per workgroup into LDS from the SoA state (for the Kuka: float64 forward
 // kinematics from the cached joint sin/cos), then every lane ray-casts its pixels
-// against the primitives whose projected bounding box overlaps its wavefront's 8x8
+// against the MOVING primitives whose projected bounding box overlaps its wavefront's 8x8
 // tile (one ballot per tile; nearest hit = z-buffer in registers) and parks 3 bytes per
 // pixel in an LDS band buffer that is flushed with coalesced 16-byte stores:
 // the path's HBM traffic is the 12 288-byte image per env and nothing else.
+// The cameras are fixed and the first primitives of a scene (floor plane, table / arena walls)
+// never move, so a per-handle setup kernel (raster_bg_k) stores for every pixel its unit ray,
+// the depth of the nearest static hit and the shaded static colour: a tile no moving primitive
+// can touch is a copy of that background, and the other tiles start their z-test from it —
+// same arithmetic per primitive, same bytes, without normalising the ray and re-hitting the
+// floor for every env.  (The MobileRobot fpv camera rides on the robot: it takes the full path.)
 // float32 throughout, -ffp-contract=off so that the C oracle (oracle/raster_oracle.c)
 // reproduces the bytes.
 #include "internal.hpp"
@@ -55,6 +61,9 @@ struct Camera {
 struct RasterParams {
     int32_t kind, n, h, w, channels, ncam;
     int32_t fpv;           // mobile family, second camera: rides on the robot (cam[1] is stored relative to the robot position)
+    int32_t nstatic;       // the first nstatic primitives of every env's scene are identical and never move
+    const float4 *rays[2]; // per fixed camera: (unit ray, depth of the nearest static hit or 3e38) per pixel; null = full path
+    const uint32_t *bg[2]; //                   shaded static colour per pixel (r | g << 8 | b << 16)
     Camera cam[2];
 };
 
@@ -239,11 +248,23 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     return k;
 }
 
-__device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask, const Camera &c, float sx, float sy) {
-    float dx = c.fx + sx * c.rx + sy * c.ux, dy = c.fy + sx * c.ry + sy * c.uy, dz = c.fz + sx * c.rz + sy * c.uz;
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    dx *= inv; dy *= inv; dz *= inv;
-    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;     // background
+__device__ __forceinline__ uint32_t finish_pixel(bool hit, float bnx, float bny, float bnz, float cr, float cg, float cb) {
+    float shade = 1.0f;
+    if (hit) {
+        // one directional light, ambient 0.6 + diffuse 0.4 (TinyRenderer-like proportions), no shadows
+        const float lx = -0.40824829f, ly = 0.40824829f, lz = 0.81649658f;
+        const float ndl = fmaxf(bnx * lx + bny * ly + bnz * lz, 0.0f);
+        shade = 0.6f + 0.4f * ndl;
+    }
+    const uint32_t r8 = (uint32_t)(fminf(cr * shade, 1.0f) * 255.0f + 0.5f);
+    const uint32_t g8 = (uint32_t)(fminf(cg * shade, 1.0f) * 255.0f + 0.5f);
+    const uint32_t b8 = (uint32_t)(fminf(cb * shade, 1.0f) * 255.0f + 0.5f);
+    return r8 | (g8 << 8) | (b8 << 16);
+}
+
+// z-test of the unit ray (dx, dy, dz) from the eye against the primitives in `mask` (wave-uniform), starting from `best`
+__device__ __forceinline__ bool trace(const Prim *prims, uint64_t mask, const Camera &c, float dx, float dy, float dz, float &best,
+                                      float &bnx, float &bny, float &bnz, float &cr, float &cg, float &cb) {
     bool hit = false;
     while (mask) {                                   // wave-uniform list of the primitives that can touch this tile
         const int k = __builtin_ctzll(mask);
@@ -264,17 +285,21 @@ __device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask
             }
         }
     }
-    float shade = 1.0f;
-    if (hit) {
-        // one directional light, ambient 0.6 + diffuse 0.4 (TinyRenderer-like proportions), no shadows
-        const float lx = -0.40824829f, ly = 0.40824829f, lz = 0.81649658f;
-        const float ndl = fmaxf(bnx * lx + bny * ly + bnz * lz, 0.0f);
-        shade = 0.6f + 0.4f * ndl;
-    }
-    const uint32_t r8 = (uint32_t)(fminf(cr * shade, 1.0f) * 255.0f + 0.5f);
-    const uint32_t g8 = (uint32_t)(fminf(cg * shade, 1.0f) * 255.0f + 0.5f);
-    const uint32_t b8 = (uint32_t)(fminf(cb * shade, 1.0f) * 255.0f + 0.5f);
-    return r8 | (g8 << 8) | (b8 << 16);
+    return hit;
+}
+
+__device__ __forceinline__ void pixel_ray(const Camera &c, float sx, float sy, float &dx, float &dy, float &dz) {
+    dx = c.fx + sx * c.rx + sy * c.ux; dy = c.fy + sx * c.ry + sy * c.uy; dz = c.fz + sx * c.rz + sy * c.uz;
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+}
+
+__device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask, const Camera &c, float sx, float sy) {
+    float dx, dy, dz;
+    pixel_ray(c, sx, sy, dx, dy, dz);
+    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;     // background
+    const bool hit = trace(prims, mask, c, dx, dy, dz, best, bnx, bny, bnz, cr, cg, cb);
+    return finish_pixel(hit, bnx, bny, bnz, cr, cg, cb);
 }
 
 // Conservative screen rectangle (tangent-space x = X/Z, y = Y/Z in the camera frame) of a primitive: the eight
@@ -321,6 +346,9 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     if ((int)threadIdx.x < nprims) prim_screen_rect(prims[threadIdx.x], c, rects[threadIdx.x]);
     __syncthreads();
     const int npix = rp.h * rp.w, np = nprims;
+    const float4 *__restrict__ rays = rp.rays[cam];
+    const uint32_t *__restrict__ bg = rp.bg[cam];
+    const bool use_bg = rays != nullptr && !(rp.fpv && cam == 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lx = lane & 7, ly = lane >> 3;
     uint8_t *out = img + (int64_t)e * npix * rp.channels;
     // bands of whole 8-row tile strips that fit the LDS tile buffer; inside a band every wavefront walks 8x8 tiles
@@ -339,12 +367,25 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
             const float ty0 = (1.0f - (float)(r0 + 8) / (float)rp.h * 2.0f) * c.tan_half_fov;
             bool touch = false;
             if (lane < np) touch = rects[lane][0] <= tx1 && rects[lane][1] >= tx0 && rects[lane][2] <= ty1 && rects[lane][3] >= ty0;
-            const uint64_t mask = __ballot(touch);
+            uint64_t mask = __ballot(touch);
             const int row = r0 + ly, col = col0 + lx;
             if (row < rp.h && col < rp.w) {
-                const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
-                const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
-                const uint32_t rgb = shade_pixel(prims, mask, c, sx, sy);
+                uint32_t rgb;
+                if (use_bg) {
+                    // static scenery comes from the per-handle background; only moving primitives are traced
+                    mask &= ~((1ull << rp.nstatic) - 1ull);
+                    rgb = bg[row * rp.w + col];
+                    if (mask) {
+                        const float4 ray = rays[row * rp.w + col];
+                        float best = ray.w, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                        if (trace(prims, mask, c, ray.x, ray.y, ray.z, best, bnx, bny, bnz, cr, cg, cb))
+                            rgb = finish_pixel(true, bnx, bny, bnz, cr, cg, cb);
+                    }
+                } else {
+                    const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+                    const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
+                    rgb = shade_pixel(prims, mask, c, sx, sy);
+                }
                 const int i = (row - row0) * rp.w + col;
                 tile[3 * i] = (uint8_t)rgb; tile[3 * i + 1] = (uint8_t)(rgb >> 8); tile[3 * i + 2] = (uint8_t)(rgb >> 16);
             }
@@ -363,6 +404,30 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
         }
         __syncthreads();
     }
+}
+
+// Per-handle setup: unit ray, nearest static depth and shaded static colour of every pixel of fixed camera `cam`.  The
+// static primitives are the first rp.nstatic ones of ANY env's scene (env 0 is used); same code path as raster_k's
+// full trace, so the bytes are the ones the full path would produce.
+__global__ void __launch_bounds__(kRasterBlock)
+raster_bg_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, int cam, float4 *rays, uint32_t *bg) {
+    __shared__ Prim prims[kMaxPrims];
+    const Camera c = rp.cam[cam];
+    if (threadIdx.x == 0) {
+        if (rp.kind >= SRLHIP_ENV_KUKA_BUTTON) build_kuka_scene(kv, 0, prims); else build_mobile_scene(rp, mv, 0, prims);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kRasterBlock + threadIdx.x;
+    if (i >= rp.h * rp.w) return;
+    const int row = i / rp.w, col = i - row * rp.w;
+    const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
+    const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
+    float dx, dy, dz;
+    pixel_ray(c, sx, sy, dx, dy, dz);
+    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;
+    const bool hit = trace(prims, (1ull << rp.nstatic) - 1ull, c, dx, dy, dz, best, bnx, bny, bnz, cr, cg, cb);
+    rays[i] = make_float4(dx, dy, dz, best);
+    bg[i] = finish_pixel(hit, bnx, bny, bnz, cr, cg, cb);
 }
 
 // pybullet computeViewMatrixFromYawPitchRoll (upAxisIndex = 2): eye = target + Rz(yaw) Ry(roll) Rx(pitch) (0,-d,0),
@@ -420,6 +485,22 @@ int raster_render(Handle *h, void *d_img) {
         rp.cam[1] = make_camera(tf, 0.3, 90, -17, 0, 90);
         const MobileState &s = h->mobile;
         mv.x = s.pos_x; mv.y = s.pos_y; mv.tx = s.tgt_x; mv.ty = s.tgt_y; mv.t2x = s.tgt2_x; mv.t2y = s.tgt2_y; mv.cur = s.cur_target;
+    }
+    // static scenery: Kuka = floor plane + table; MobileRobot = floor plane + arena walls (1 in the 1-D env, 4 otherwise)
+    rp.nstatic = c.env_kind >= SRLHIP_ENV_KUKA_BUTTON ? 2 : (c.env_kind == SRLHIP_ENV_MOBILE_1D ? 2 : 5);
+    const int ncached = rp.fpv ? 1 : rp.ncam;                  // the fpv camera moves with the robot
+    for (int cam = 0; cam < 2; cam++) { rp.rays[cam] = nullptr; rp.bg[cam] = nullptr; }
+    for (int cam = 0; cam < ncached; cam++) {
+        if (!h->raster_rays[cam]) {
+            const size_t npix = (size_t)rp.h * rp.w;
+            int rc;
+            if ((rc = h->dalloc(&h->raster_rays[cam], npix)) || (rc = h->dalloc(&h->raster_bg[cam], npix))) return rc;
+            hipLaunchKernelGGL(raster_bg_k, dim3((unsigned)((npix + kRasterBlock - 1) / kRasterBlock)), dim3(kRasterBlock), 0, h->stream,
+                               rp, kv, mv, cam, h->raster_rays[cam], h->raster_bg[cam]);
+            SRL_HIP_CHECK(h, hipGetLastError());
+        }
+        rp.rays[cam] = h->raster_rays[cam];
+        rp.bg[cam] = h->raster_bg[cam];
     }
     hipLaunchKernelGGL(raster_k, dim3(h->n, rp.ncam), dim3(kRasterBlock), 0, h->stream, rp, kv, mv, static_cast<uint8_t *>(d_img));
     SRL_HIP_CHECK(h, hipGetLastError());
