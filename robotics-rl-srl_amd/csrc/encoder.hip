@@ -27,13 +27,16 @@
 //   * B fragments come from L2 (352 KiB, shared by every CU): layer 1's (112 VGPRs per wave) are requested before
 //     the frame is unpacked and stay in registers for the layer, layer 2's are streamed through a 6-deep register
 //     ring, layer 3's arrive in one burst behind layer 2's k-loop; the next frame's bytes are fetched during layer 2.
-//     (Tried and measured no faster: two waves per SIMD — each wave then streams its own copies through the
-//     64 B/clk vector-memory path; weights resident across frames — starves the layer-2 loop of registers.)
+//     Two waves per SIMD (MG = 4, SRLHIP_ENCODER_WAVES=8) is kept as a measured alternative: 0.55 ms against 0.43 ms
+//     per 4096 frames — each wave then streams its own B copies, 256 registers per lane spill the hoisted
+//     addresses, and the groups wait for each other at the barriers.  Weights resident across frames starve the
+//     layer-2 loop of registers (its ring becomes loop-carried copies behind `s_waitcnt vmcnt(0)`).
 // The reference transposes H and W before the network (models.py:185-188); all layers are symmetric in the two
 // spatial dims, so the kernel works on the frame as rasterised and the host packer swaps the two kernel axes.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -59,7 +62,7 @@ constexpr float kNegInf = -3.0e38f;     // max-pool padding on raw (pre-ReLU) ac
 constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
 
 // ---- LDS map (bytes) -------------------------------------------------------------------------------
-constexpr int kThreads = 256;                    // 4 waves, one per SIMD, 512 registers each: layer-1 and layer-3 weights live in them
+constexpr int kMaxGroups = 4;                    // wave groups along M: 2 (4 waves, one per SIMD) or 4 (8 waves, two per SIMD)
 constexpr int IN_PITCH = 72 * 8;                 // padded input row: 72 pixels x (R, G, B, mask) f16
 constexpr int IN_BYTES = 70 * IN_PITCH;          // 3-pixel zero ring around 64x64
 constexpr int PX = 144;                          // pixel pitch of the f16 activation planes (128 B + 16 B skew)
@@ -67,15 +70,16 @@ constexpr int A2_PLANE = 257 * PX;               // 16x16 pixels + one all-zero 
 constexpr int A2H = IN_BYTES, A2L = A2H + A2_PLANE;
 constexpr int A3_PLANE = 50 * PX;                // 7x7 pixels + one all-zero pixel (index 49)
 constexpr int A3H = A2L + A2_PLANE, A3L = A3H + A3_PLANE;
-constexpr int XCH = A3L + A3_PLANE;              // [2][8][64] f32: conv-2 row 8 (upper half), needed by the lower half's last pooled row
-constexpr int FEAT = XCH + 4096;                 // [64] f32 pooled features
+constexpr int XCH = A3L + A3_PLANE;              // [groups-1][2][8][64] f32: first conv-2 row of group g+1, needed by group g's last pooled row
+constexpr int FEAT = XCH + (kMaxGroups - 1) * 4096;   // [64] f32 pooled features
 constexpr int RAW = FEAT + 256;                  // the NEXT frame's 12 288 raw bytes (prefetched during layer 2)
 constexpr int LDS_TOTAL = RAW + kImg * kImg * 3;
-constexpr int PART = A2H;                        // [2][8][64] f32 layer-3 partial sums of the second K half (A2 is dead by then)
+constexpr int PART = A2H;                        // [groups-1][2][8][64] f32 layer-3 partial sums of K parts 1.. (A2 is dead by then)
 static_assert(IN_BYTES % 16 == 0 && A2_PLANE % 16 == 0 && A3_PLANE % 16 == 0, "LDS planes must stay 16-byte aligned");
 static_assert(LDS_TOTAL <= 160 * 1024, "encoder LDS map exceeds one CU");
 
 constexpr size_t kPack1Bytes = 2 * kS1 * 64 * 32, kPack2Bytes = 2 * kS2 * 64 * 32;
+constexpr int kDefaultGroups = 2;
 
 struct EncParams {
     const uint8_t *images;      // [n][64][64][3]
@@ -86,7 +90,7 @@ struct EncParams {
     int state_dim;
     float *out;                 // [n][state_dim]
     int *status;                // bit 0: an activation left f16's range
-    long long *prof;            // PROF only: [kProfFrames][kProfStamps][4 waves] cycle stamps of workgroup 0
+    long long *prof;            // PROF only: [kProfFrames][kProfStamps][8 waves] cycle stamps of workgroup 0
 };
 
 extern __shared__ __attribute__((aligned(16))) char enc_lds[];
@@ -137,17 +141,21 @@ __device__ __forceinline__ void conv1_single(const half8 (&Bh)[kS1], const half8
 }
 
 // PROF: workgroup 0 stamps s_memtime at 9 points of its first kProfFrames frames (srlhip_encoder_phase_cycles)
-constexpr int kProfFrames = 8, kProfStamps = 9;
+constexpr int kProfFrames = 8, kProfStamps = 9, kProfWaves = 2 * kMaxGroups;
 #define ENC_STAMP(k)                                                                                          \
     do {                                                                                                      \
         if (PROF && blockIdx.x == 0 && lane == 0 && frame < kProfFrames)                                      \
-            P.prof[(frame * kProfStamps + (k)) * 4 + wave] = (long long)__builtin_readcyclecounter();        \
+            P.prof[(frame * kProfStamps + (k)) * kProfWaves + wave] = (long long)__builtin_readcyclecounter(); \
     } while (0)
 
-template <bool PROF>
-__global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
+// MG = wave groups along M (output pixels): group g owns 16/MG pooled layer-1 rows, 8/MG layer-2 tiles, 36/MG of
+// layer 3's k-steps; the two waves of a group own 32 output channels each.
+template <bool PROF, int MG>
+__global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
+    constexpr int kThreads = 128 * MG, kRows1 = 16 / MG, kTiles2 = 8 / MG, kSteps3 = kS2 / MG;
+    constexpr int kRawIters = (768 + kThreads - 1) / kThreads;          // 16-byte pieces of a frame per thread
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int mh = wave >> 1, nh = wave & 1;      // which half of the pixels / of the output channels this wave owns
+    const int mh = wave >> 1, nh = wave & 1;      // which wave group (part of the pixels) / half of the output channels this wave owns
     const int j = lane & 31, h = lane >> 5;       // MFMA lane coordinates: column (channel) j, k / row half h
     const int ch = 32 * nh + j;                   // the output channel this lane owns in every layer
     bool ovf = false;
@@ -165,7 +173,9 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
     if (blockIdx.x < P.n) {                       // first frame of this workgroup (later ones are prefetched in layer 2)
         const uint4 *src = reinterpret_cast<const uint4 *>(P.images + (size_t)blockIdx.x * (kImg * kImg * 3));
         uint4 *raw = reinterpret_cast<uint4 *>(enc_lds + RAW);
-        raw[tid] = src[tid]; raw[tid + 256] = src[tid + 256]; raw[tid + 512] = src[tid + 512];
+#pragma unroll
+        for (int i = 0; i < kRawIters; i++)
+            if (tid + i * kThreads < 768) raw[tid + i * kThreads] = src[tid + i * kThreads];
     }
     __syncthreads();
 
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
         }
         // ---- phase 0: uint8 frame (already staged in LDS) -> f16 (R, G, B, 1) pixels inside the zero ring ------
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 1024 / kThreads; i++) {
             const int q = tid + kThreads * i;                              // four consecutive pixels = 12 bytes
             const uint32_t *w = reinterpret_cast<const uint32_t *>(enc_lds + RAW + 12 * q);
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
@@ -204,7 +214,8 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
         ENC_STAMP(1);
 
         // ---- layer 1: conv7x7/2 + ReLU + maxpool3/2 p1 -> A2 planes (16x16x64 f16 hi/lo) ----------------------
-        // wave half m owns pooled rows 8m .. 8m+7 <- conv rows 16m-1 .. 16m+15 (row 15 is recomputed, not exchanged)
+        // wave group g owns pooled rows R g .. R g + R-1 (R = 16 / MG) <- conv rows 2R g - 1 .. 2R (g+1) - 1 (its first
+        // row is recomputed, not exchanged)
         {
             const int lane_base = j * 16 + h * 16;
             f32x16 carry, v0, v1;
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) carry[r] = kNegInf;           // conv row -1 is pool padding
             } else {
-                conv1_single(B1h, B1l, 15, lane_base, carry);
+                conv1_single(B1h, B1l, 2 * kRows1 * mh - 1, lane_base, carry);
             }
             // Software pipeline: the 56 MFMAs of pooled row p+1 and the pooling / split / store epilogue of row p are
             // independent instruction streams in one basic block, so the epilogue's VALU and LDS work issues in the
@@ -234,45 +245,60 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
                     store_split(A2H, A2L, (prow * 16 + k + 1) * PX + ch * 2, fmaxf(0.f, kb * inv1), ovf);
                 }
             };
-            conv1_pair(B1h, B1l, 16 * mh, 16 * mh + 1, lane_base, v0, v1);
+            if constexpr (MG == 2) {
+                conv1_pair(B1h, B1l, 2 * kRows1 * mh, 2 * kRows1 * mh + 1, lane_base, v0, v1);
 #pragma unroll 1
-            for (int p = 0; p < 7; p++) {
-                const int prow = 8 * mh + p;                               // pooled row <- conv rows 2p-1, 2p, 2p+1
-                f32x16 n0, n1;
-                conv1_pair(B1h, B1l, 2 * prow + 2, 2 * prow + 3, lane_base, n0, n1);
-                epilogue(prow, carry, v0, v1);
-                // pin the interleave: per MFMA (32 cycles of matrix pipe) four VALU and one LDS instruction
+                for (int p = 0; p < kRows1 - 1; p++) {
+                    const int prow = kRows1 * mh + p;                      // pooled row <- conv rows 2p-1, 2p, 2p+1
+                    f32x16 n0, n1;
+                    conv1_pair(B1h, B1l, 2 * prow + 2, 2 * prow + 3, lane_base, n0, n1);
+                    epilogue(prow, carry, v0, v1);
+                    // pin the interleave: per MFMA (32 cycles of matrix pipe) four VALU and one LDS instruction
 #pragma unroll
-                for (int u = 0; u < 56; u++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+                    for (int u = 0; u < 56; u++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+                    }
+                    carry = v1; v0 = n0; v1 = n1;
                 }
-                carry = v1; v0 = n0; v1 = n1;
+                epilogue(kRows1 * mh + kRows1 - 1, carry, v0, v1);
+            } else {
+                // two waves per SIMD: the partner wave's MFMAs cover this wave's epilogue, no in-wave pipelining (registers)
+#pragma unroll 1
+                for (int p = 0; p < kRows1; p++) {
+                    const int prow = kRows1 * mh + p;
+                    conv1_pair(B1h, B1l, 2 * prow, 2 * prow + 1, lane_base, v0, v1);
+                    epilogue(prow, carry, v0, v1);
+                    carry = v1;
+                }
             }
-            epilogue(8 * mh + 7, carry, v0, v1);
         }
         ENC_STAMP(2);
         __syncthreads();
         ENC_STAMP(3);
 
         // ---- layer 2: conv3x3 p1 + ReLU + maxpool3/2 -> A3 planes (7x7x64) -----------------------------------
-        // wave half m owns tiles T = 4m .. 4m+3 (tile = conv rows 2T, 2T+1 x 16 columns) -> pooled rows 4m .. 4m+3
-        half8 B3h[18], B3l[18];
+        // wave group g owns tiles T = K g .. K g + K-1 (K = 8 / MG; tile = conv rows 2T, 2T+1 x 16 columns) -> pooled rows T
+        half8 B3h[kSteps3], B3l[kSteps3];
         {
-            f32x16 acc[4];
+            f32x16 acc[kTiles2];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < kTiles2; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
             const int row = j >> 4, ox = j & 15;
             const char *bp = P.b2 + ((size_t)(nh * kS2) * 64 + lane) * 32;
             // the next frame of this workgroup: fetched now, parked in LDS after the k-loop
             const int next_img = img + gridDim.x;
-            uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
+            uint4 nxt_raw[kRawIters];
+#pragma unroll
+            for (int i = 0; i < kRawIters; i++) nxt_raw[i] = make_uint4(0, 0, 0, 0);
             if (next_img < P.n) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(P.images + (size_t)next_img * (kImg * kImg * 3));
-                n0 = src[tid]; n1 = src[tid + 256]; n2 = src[tid + 512];
+#pragma unroll
+                for (int i = 0; i < kRawIters; i++)
+                    if (tid + i * kThreads < 768) nxt_raw[i] = src[tid + i * kThreads];
             }
             // Layer-2 B fragments come from L2 (they do not fit in the registers the resident layers leave) through a
             // ring of kB2Ahead register slots: the fragment of k-step s + kB2Ahead is requested right after step s has
@@ -288,19 +314,19 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
             // A fragments are double-buffered by hand (the loads of step s+1 are issued before the MFMAs of step s)
             // and the MFMA order is pinned with scheduling barriers: left alone, the compiler serialises
             // ds_read -> wait -> two dependent MFMAs on one accumulator, which runs at half the matrix rate.
-            int addr[4];
+            int addr[kTiles2];
             auto tap_addr = [&](int ky, int kx) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int sy = 2 * (4 * mh + t) + row + ky - 1, sx = ox + kx - 1;
+                for (int t = 0; t < kTiles2; t++) {
+                    const int sy = 2 * (kTiles2 * mh + t) + row + ky - 1, sx = ox + kx - 1;
                     const bool ok = (unsigned)sy < 16u && (unsigned)sx < 16u;
                     addr[t] = (ok ? sy * 16 + sx : 256) * PX + h * 16;
                 }
             };
-            half8 ah[4], al[4], nh_[4], nl_[4];
+            half8 ah[kTiles2], al[kTiles2], nh_[kTiles2], nl_[kTiles2];
             tap_addr(0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; t++) { ah[t] = lds16(A2H + addr[t]); al[t] = lds16(A2L + addr[t]); }
+            for (int t = 0; t < kTiles2; t++) { ah[t] = lds16(A2H + addr[t]); al[t] = lds16(A2L + addr[t]); }
             // One rolled iteration = one kernel row = 12 k-steps, so ring slots are compile-time indices.
 #pragma unroll 1
             for (int ky = 0; ky < 3; ky++) {
@@ -311,14 +337,14 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
                     const int in = (i + 1) % 12, qn = in & 3;
                     if (qn == 0) tap_addr(in == 0 ? ky + 1 : ky, in >> 2);   // ky + 1 == 3: every row is out of range -> zero pixel
 #pragma unroll
-                    for (int t = 0; t < 4; t++) { nh_[t] = lds16(A2H + addr[t] + qn * 32); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
+                    for (int t = 0; t < kTiles2; t++) { nh_[t] = lds16(A2H + addr[t] + qn * 32); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[t] = mfma16(ah[t], Rh[slot], acc[t]);
+                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(ah[t], Rh[slot], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[t] = mfma16(ah[t], Rl[slot], acc[t]);
+                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(ah[t], Rl[slot], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[t] = mfma16(al[t], Rh[slot], acc[t]);
+                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(al[t], Rh[slot], acc[t]);
                     __builtin_amdgcn_sched_barrier(0);
                     // refill the slot
                     const int sn = 12 * ky + i + kB2Ahead;
@@ -326,40 +352,43 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
                     Rh[slot] = pn[0];                                      // (the last requests of a frame re-read fragment 35: harmless)
                     Rl[slot] = pn[1];
 #pragma unroll
-                    for (int t = 0; t < 4; t++) { ah[t] = nh_[t]; al[t] = nl_[t]; }
+                    for (int t = 0; t < kTiles2; t++) { ah[t] = nh_[t]; al[t] = nl_[t]; }
                 }
             }
             ENC_STAMP(4);
-            // layer 3's B fragments for this wave's K half: one burst, in flight during the epilogue below
+            // layer 3's B fragments for this wave's K part: one burst, in flight during the epilogue below
 #pragma unroll
-            for (int ii = 0; ii < 18; ii++) {
-                const half8 *p3 = reinterpret_cast<const half8 *>(P.b3 + ((size_t)(nh * kS2 + 18 * mh + ii) * 64 + lane) * 32);
+            for (int ii = 0; ii < kSteps3; ii++) {
+                const half8 *p3 = reinterpret_cast<const half8 *>(P.b3 + ((size_t)(nh * kS2 + kSteps3 * mh + ii) * 64 + lane) * 32);
                 B3h[ii] = p3[0];
                 B3l[ii] = p3[1];
             }
             if (next_img < P.n) {
                 uint4 *raw = reinterpret_cast<uint4 *>(enc_lds + RAW);
-                raw[tid] = n0; raw[tid + 256] = n1; raw[tid + 512] = n2;
+#pragma unroll
+                for (int i = 0; i < kRawIters; i++)
+                    if (tid + i * kThreads < 768) raw[tid + i * kThreads] = nxt_raw[i];
             }
             // registers 0..7 = conv row 2T, 8..15 = row 2T+1; pixel x = 4h + (r & 3) + 8 ((r >> 2) & 1)
-            float *xch = reinterpret_cast<float *>(enc_lds + XCH) + nh * 8 * 64 + lane;
-            if (mh == 1) {                                                 // conv row 8 completes pooled row 3 of the other half
+            if (mh > 0) {                                                  // this group's first conv row completes the previous group's last pooled row
+                float *xw = reinterpret_cast<float *>(enc_lds + XCH) + ((mh - 1) * 2 + nh) * 8 * 64 + lane;
 #pragma unroll
-                for (int r = 0; r < 8; r++) xch[r * 64] = acc[0][r];
+                for (int r = 0; r < 8; r++) xw[r * 64] = acc[0][r];
             }
             __syncthreads();
+            const float *xch = reinterpret_cast<const float *>(enc_lds + XCH) + ((mh < MG - 1 ? mh : MG - 2) * 2 + nh) * 8 * 64 + lane;
         ENC_STAMP(5);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (t == 3 && mh == 1) break;                              // pooled row 7 does not exist
+            for (int t = 0; t < kTiles2; t++) {
+                if (t == kTiles2 - 1 && mh == MG - 1) break;               // pooled row 7 does not exist
                 float w[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const float below = t < 3 ? acc[t < 3 ? t + 1 : 3][r] : xch[r * 64];
+                    const float below = t < kTiles2 - 1 ? acc[t < kTiles2 - 1 ? t + 1 : kTiles2 - 1][r] : xch[r * 64];
                     w[r] = fmaxf(fmaxf(acc[t][r], acc[t][r + 8]), below);
                 }
                 const float t0 = __shfl_xor(w[0], 32), t4 = __shfl_xor(w[4], 32);
-                const int prow = 4 * mh + t;
+                const int prow = kTiles2 * mh + t;
                 const float ka = fmaxf(fmaxf(w[0], w[1]), w[2]);           // x = 4h .. 4h+2      -> k = 2h
                 const float kb = fmaxf(fmaxf(w[2], w[3]), h ? t4 : t0);    // x = 4h+2 .. 4h+4    -> k = 2h+1
                 const float kc = fmaxf(fmaxf(w[4], w[5]), w[6]);           // x = 8+4h .. 8+4h+2  -> k = 4+2h
@@ -375,14 +404,14 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
         __syncthreads();
         ENC_STAMP(6);
 
-        // ---- layer 3: conv3x3/2 p1 (7x7 -> 4x4) + ReLU + maxpool3/2 (-> 1x1); K split over the two wave halves ----
+        // ---- layer 3: conv3x3/2 p1 (7x7 -> 4x4) + ReLU + maxpool3/2 (-> 1x1); K split over the wave groups ----
         {
             f32x16 c0 = {0}, c1 = {0};                                     // two chains: 3 dependent MFMAs per k-step otherwise
             const bool pix = j < 16;
             const int oy = (j >> 2) & 3, ox = j & 3;
 #pragma unroll
-            for (int ii = 0; ii < 18; ii++) {
-                const int s = 18 * mh + ii, tap = s >> 2, q = s & 3;
+            for (int ii = 0; ii < kSteps3; ii++) {
+                const int s = kSteps3 * mh + ii, tap = s >> 2, q = s & 3;
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
                 const bool ok = pix && (unsigned)sy < 7u && (unsigned)sx < 7u;
@@ -394,19 +423,22 @@ __global__ __launch_bounds__(kThreads, 1) void encoder_fwd_k(EncParams P) {
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) c0[r] += c1[r];
-            float *part = reinterpret_cast<float *>(enc_lds + PART) + nh * 8 * 64 + lane;
-            if (mh == 1) {                                                 // A2 is dead: its first 4 KiB carry the partial sums
+            if (mh > 0) {                                                  // A2 is dead: its first KiBs carry the partial sums
+                float *pw = reinterpret_cast<float *>(enc_lds + PART) + ((mh - 1) * 2 + nh) * 8 * 64 + lane;
 #pragma unroll
-                for (int r = 0; r < 8; r++) part[r * 64] = c0[r];
+                for (int r = 0; r < 8; r++) pw[r * 64] = c0[r];
             }
             __syncthreads();
+            const float *part = reinterpret_cast<const float *>(enc_lds + PART) + nh * 8 * 64 + lane;
             if (mh == 0) {
                 // registers 0..3 -> output pixels 4h + r, 4..7 -> 8 + 4h + (r - 4); the 3x3 pool window is
                 // pixels {0,1,2,4,5,6,8,9,10}
                 float m = kNegInf;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const float v = c0[r] + part[r * 64];
+                    float v = c0[r];
+#pragma unroll
+                    for (int g = 0; g < MG - 1; g++) v += part[(g * 16 + r) * 64];
                     const bool in_window = (r & 3) != 3 && (h == 0 || r < 4);
                     if (in_window) m = fmaxf(m, v);
                 }
@@ -516,6 +548,7 @@ struct srlhip_encoder {
     float *d_f32;          // inv_scale[3] pad bias2[64] bias3[64] fcw[state_dim][64] fcb[state_dim]
     int *d_status;
     int num_cus;
+    int groups;            // wave groups along M: 2 = 4 waves per workgroup, 4 = 8 waves
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 };
@@ -589,8 +622,14 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     ENC_CHECK(hipMemcpy(e->d_pack, pack.data(), pack.size(), hipMemcpyHostToDevice));
     ENC_CHECK(hipMemcpy(e->d_f32, f.data(), nf * sizeof(float), hipMemcpyHostToDevice));
     ENC_CHECK(hipMemset(e->d_status, 0, sizeof(int)));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    {
+        const char *w = getenv("SRLHIP_ENCODER_WAVES");       // experiment knob: 4 (one wave per SIMD) or 8 (two)
+        e->groups = (w && atoi(w) == 4) ? 2 : (w && atoi(w) == 8) ? 4 : kDefaultGroups;
+    }
 #undef ENC_CHECK
     *out = e;
     return SRLHIP_OK;
@@ -610,7 +649,8 @@ int srlhip_encoder_forward(srlhip_encoder_handle e, const uint8_t *images_dev, i
     p.fcb = e->d_f32 + 132 + (size_t)e->state_dim * kCh;
     p.state_dim = e->state_dim; p.out = states_dev; p.status = e->d_status; p.prof = nullptr;
     const int grid = n < e->num_cus ? n : e->num_cus;
-    hipLaunchKernelGGL(encoder_fwd_k<false>, dim3(grid), dim3(kThreads), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
+    if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<false, 2>), dim3(grid), dim3(256), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
+    else hipLaunchKernelGGL((encoder_fwd_k<false, 4>), dim3(grid), dim3(512), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
     rc = hipGetLastError();
     if (rc != hipSuccess) return e->fail(SRLHIP_EHIP, std::string("encoder_fwd_k launch: ") + hipGetErrorString(rc));
     return SRLHIP_OK;
@@ -626,7 +666,7 @@ int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_d
         if (e__ != hipSuccess) return e->fail(SRLHIP_EHIP, std::string(#expr ": ") + hipGetErrorString(e__)); \
     } while (0)
     ENC_RC(hipSetDevice(e->device_id));
-    const size_t words = (size_t)kProfFrames * kProfStamps * 4;
+    const size_t words = (size_t)kProfFrames * kProfStamps * kProfWaves;
     long long *d_prof = nullptr;
     ENC_RC(hipMalloc(reinterpret_cast<void **>(&d_prof), words * sizeof(long long)));
     ENC_RC(hipMemset(d_prof, 0, words * sizeof(long long)));
@@ -637,7 +677,8 @@ int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_d
     p.fcb = e->d_f32 + 132 + (size_t)e->state_dim * kCh;
     p.state_dim = e->state_dim; p.out = states_dev; p.status = e->d_status; p.prof = d_prof;
     const int grid = n < e->num_cus ? n : e->num_cus;
-    hipLaunchKernelGGL(encoder_fwd_k<true>, dim3(grid), dim3(kThreads), LDS_TOTAL, nullptr, p);
+    if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<true, 2>), dim3(grid), dim3(256), LDS_TOTAL, nullptr, p);
+    else hipLaunchKernelGGL((encoder_fwd_k<true, 4>), dim3(grid), dim3(512), LDS_TOTAL, nullptr, p);
     ENC_RC(hipGetLastError());
     std::vector<long long> host(words);
     ENC_RC(hipMemcpy(host.data(), d_prof, words * sizeof(long long), hipMemcpyDeviceToHost));
@@ -651,11 +692,11 @@ int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_d
     for (int f = 0; f + 1 < frames || (frames == 1 && f == 0); f++) {
         for (int k = 0; k < kProfStamps; k++) {
             long long worst = 0;
-            for (int w = 0; w < 4; w++) {
-                const long long a = host[(f * kProfStamps + k) * 4 + w];
+            for (int w = 0; w < 2 * e->groups; w++) {
+                const long long a = host[(f * kProfStamps + k) * kProfWaves + w];
                 const bool last = k + 1 == kProfStamps;
                 if (last && f + 1 >= frames) continue;
-                const long long b = last ? host[((f + 1) * kProfStamps) * 4 + w] : host[(f * kProfStamps + k + 1) * 4 + w];
+                const long long b = last ? host[((f + 1) * kProfStamps) * kProfWaves + w] : host[(f * kProfStamps + k + 1) * kProfWaves + w];
                 if (b - a > worst) worst = b - a;
             }
             cycles9[k] += worst;
