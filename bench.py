@@ -249,12 +249,21 @@ def main():
         import torch.distributed as dist
         gathered = torch.zeros((world * n,), dtype=torch.float32, device=dev)
 
+    ext = torch.cuda.ExternalStream(h.stream(), device=dev) if world > 1 else None
+
     def one_step():
         h.rollout(inner, out=out)
         if world > 1:
-            # the path's only exchange: episode returns, once per rollout, RCCL over xGMI
-            h.sync()
-            sharding.gather_episode_returns(rew.sum(dim=0), out=gathered)
+            # the path's only exchange: episode returns, once per rollout, RCCL over xGMI.  No host sync:
+            # torch's stream waits for this rollout, reduces the reward plane, and the stepper's stream is released for
+            # the next rollout as soon as that reduction is done — the all-gather itself overlaps the next rollout.
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(ext)
+            ret = rew.sum(dim=0)
+            done_reading = torch.cuda.Event()
+            done_reading.record(cur)
+            ext.wait_event(done_reading)
+            sharding.gather_episode_returns(ret, out=gathered)
 
     def fence():
         h.sync()
