@@ -13,4 +13,10 @@ for env_id, nact in (("MobileRobotGymEnv-v0", 4), ("KukaButtonGymEnv-v0", 6)):
     for t in range(50, 350): venv.step(acts[t])
     dt = (time.perf_counter() - t0) / 300
     print("{}: {:.1f} us per 4096-env VecEnv.step -> {:.2e} env-steps/s".format(env_id, dt * 1e6, 4096 / dt))
+    a32 = acts.astype(np.int32)
+    out = venv._h.step(a32[0])
+    t0 = time.perf_counter()
+    for t in range(50, 350): venv._h.step(a32[t], out=out)
+    dt = (time.perf_counter() - t0) / 300
+    print("{}: {:.1f} us per 4096-env srlhip_step (ctypes, reused numpy buffers) -> {:.2e} env-steps/s".format(env_id, dt * 1e6, 4096 / dt))
     venv.close()
