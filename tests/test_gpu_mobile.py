@@ -140,6 +140,28 @@ def test_episode_parallel_rollout_equals_step_by_step(kind, random_target, discr
     a.close(); b.close()
 
 
+def test_bench_configuration_rollout_matches_oracle():
+    """Exactly what bench.py --workload mobile times (BASELINE config 2): 4096 envs, one 2048-step device-sampled
+    random-agent rollout after a warm-up rollout — every observation / reward / done of the 8.4M env-steps against the
+    C oracle's Philox restatement, plus the episode statistics the Monitor equivalent reports."""
+    n, T = 4096, 2048
+    h = make(0, n, _lib.RNG_PHILOX, seed0=0)
+    obs0 = h.reset()
+    warm = h.rollout(256)
+    out = h.rollout(T)
+    ora = clib.mobile_rollout(0, np.arange(n), 256 + T, actions=None, rng_mode=clib.RNG_PHILOX)
+    assert np.array_equal(ora["obs0"], obs0)
+    for k in ("actions", "obs", "reward", "done"):
+        assert np.array_equal(ora[k][:256], warm[k]), k
+        assert np.array_equal(ora[k][256:], out[k]), k
+    ret, length, fin = h.episode_stats()
+    assert (fin == (256 + T) // 251).all() and (length == 251).all()
+    done_rows = np.nonzero(ora["done"][:, 0])[0]
+    last = slice(done_rows[-2] + 1, done_rows[-1] + 1)
+    assert np.array_equal(ret, ora["reward"][last].astype(np.float64).sum(axis=0))
+    h.close()
+
+
 def test_host_rng_mode_and_manual_reset():
     """RNG_HOST harness: every draw supplied by the caller (numpy RandomState per env),
     no auto-reset: finished envs are reset with srlhip_reset(mask) like a VecEnv worker."""
