@@ -756,17 +756,54 @@ SRL_HD void physics_step(Env &e, const Cfg &cfg, const Scratch &sc, const double
         }                                                                                \
     }
     if (!SRL_ANY(ngen > 0)) {
-        // -- path 1: the whole wavefront is free of limit / contact rows: one straight-line block per sweep
-        for (int it = 0; it < kSolverIters; it++) {
-            SRL_ARM_ROWS(1)
-            SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
-            SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
-            SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
-            SRL_BUTTON2_MOTOR
-            SRL_BUTTON2_LIMITS
+        // -- path 1: the whole wavefront is free of limit / contact rows: one straight-line block per sweep.
+        //    Without contact rows the button glider is decoupled from the arm: its three scalar rows (21 of the sweep's
+        //    79 instructions) form their own little iteration on dvb.  After three sweeps it is usually PERIODIC — the
+        //    sweep maps dvb onto itself bit for bit while only the applied impulses keep growing (motor pushing the cap
+        //    against its stop) or nothing changes at all.  When every row of every lane is provably in a mode that
+        //    the remaining sweeps cannot leave (unclamped with room for the impulse drift, or held at a zero bound
+        //    with zero applied impulse), the remaining sweeps would recompute the same dvb: they run the arm rows only.
+        //    Bit-identical to the full iteration by construction; any doubt falls back to it.
+        int it = 0;
+        bool skip_button = false;
+        if (NB == 1 && kSolverIters > 3) {
+            double dvb_prev = 0.0, xm = 0.0, dm = 0.0, xl = 0.0, dl = 0.0, xh = 0.0, dh = 0.0;
+            for (; it < 3; it++) {
+                SRL_ARM_ROWS(1)
+                dvb_prev = dvb;
+                xm = rhs_bm - dvb * dinvb;  dm = fmin(fmax(xm, -bound_bm - app_bm), bound_bm - app_bm); dvb += dm * wb; app_bm += dm;
+                xl = rhs_blo - dvb * dinvb; dl = fmin(fmax(xl, 0.0 - app_blo), blim - app_blo);         dvb += dl * wb; app_blo += dl;
+                xh = rhs_bhi + dvb * dinvb; dh = fmin(fmax(xh, 0.0 - app_bhi), blim - app_bhi);         dvb -= dh * wb; app_bhi += dh;
 #pragma unroll
-            for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
-            cur[ND - 1] = cs[ND - 1];
+                for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
+                cur[ND - 1] = cs[ND - 1];
+            }
+            const double left = (double)(kSolverIters - 3 + 1) * (1.0 + 1e-6), room = 1.0 - 1e-6;
+            const bool stable_m = dm == xm && fabs(app_bm) + left * fabs(xm) <= bound_bm * room;
+            const bool stable_l = (dl == xl && xl >= 0.0 && app_blo + left * xl <= blim * room) || (dl == 0.0 && app_blo == 0.0 && xl <= 0.0);
+            const bool stable_h = (dh == xh && xh >= 0.0 && app_bhi + left * xh <= blim * room) || (dh == 0.0 && app_bhi == 0.0 && xh <= 0.0);
+            const bool ok = dvb == dvb_prev && stable_m && stable_l && stable_h;     // dvb_prev: value the last sweep started from
+            skip_button = !SRL_ANY(!ok);
+        }
+        if (skip_button) {
+            for (; it < kSolverIters; it++) {
+                SRL_ARM_ROWS(1)
+#pragma unroll
+                for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
+                cur[ND - 1] = cs[ND - 1];
+            }
+        } else {
+            for (; it < kSolverIters; it++) {
+                SRL_ARM_ROWS(1)
+                SRL_BUTTON_ROW(app_bm, rhs_bm, 1.0, -bound_bm, bound_bm)
+                SRL_BUTTON_ROW(app_blo, rhs_blo, 1.0, 0.0, blim)
+                SRL_BUTTON_ROW(app_bhi, rhs_bhi, -1.0, 0.0, blim)
+                SRL_BUTTON2_MOTOR
+                SRL_BUTTON2_LIMITS
+#pragma unroll
+                for (int i = 0; i < ND - 1; i++) cur[i] = nxt[i];
+                cur[ND - 1] = cs[ND - 1];
+            }
         }
     } else if (!SRL_ANY(nlim > 0) && !SRL_ANY(ngen > 2)) {
         // -- path 2a (the common contact case: at most two contact rows per lane, no arm joint near its stop).  Both rows
