@@ -9,6 +9,8 @@
 // reward / done planes.  The path is FP64-VALU / dependency-latency bound (150
 // sequential Gauss-Seidel sweeps per physics step), not HBM bound and not
 // MFMA-shaped; see DESIGN.md §Kuka kernel for the roofline accounting.
+#include <stdlib.h>
+
 #include "internal.hpp"
 #include "kuka_env.hpp"
 
@@ -321,7 +323,12 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
 
 int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_rew, uint8_t *d_done, void *d_act_out) {
     KukaParams p = params_of(h);
-    dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
+    // envs per wavefront: a wavefront takes the contact path of the solver as soon as ONE of its lanes carries a contact
+    // row, so fewer (active) lanes per wavefront mean fewer slow sweeps — as long as there are idle SIMDs to host the
+    // extra wavefronts (experiment knob SRLHIP_KUKA_LANES; the default is chosen from the batch size below)
+    static const int forced_lanes = [] { const char *v = getenv("SRLHIP_KUKA_LANES"); return v ? atoi(v) : 0; }();
+    int lanes = forced_lanes == 8 || forced_lanes == 16 || forced_lanes == 32 || forced_lanes == 64 ? forced_lanes : kWave;
+    dim3 grid((h->n + lanes - 1) / lanes), block(lanes);
     float *obs = static_cast<float *>(d_obs);
     const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
 #define SRL_ROLLOUT(MODE)                                                                                                        \
