@@ -255,7 +255,7 @@ constexpr size_t kLdsBytes = (size_t)SC_TOTAL * kWave * sizeof(double);
 template <class K>
 int allow_lds(Handle *h, K kernel) {
     SRL_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kLdsBytes));
+                                         160 * 1024));
     return 0;
 }
 
@@ -329,11 +329,14 @@ int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_
     static const int forced_lanes = [] { const char *v = getenv("SRLHIP_KUKA_LANES"); return v ? atoi(v) : 0; }();
     int lanes = forced_lanes == 8 || forced_lanes == 16 || forced_lanes == 32 || forced_lanes == 64 ? forced_lanes : kWave;
     dim3 grid((h->n + lanes - 1) / lanes), block(lanes);
+    // LDS request of the rollout launch (experiment knob SRLHIP_KUKA_LDS_KB): > 80 KiB keeps a CU to ONE workgroup
+    static const int forced_lds_kb = [] { const char *v = getenv("SRLHIP_KUKA_LDS_KB"); return v ? atoi(v) : 0; }();
+    const size_t lds_bytes = forced_lds_kb > 0 && (size_t)forced_lds_kb * 1024 >= kLdsBytes && forced_lds_kb <= 160 ? (size_t)forced_lds_kb * 1024 : kLdsBytes;
     float *obs = static_cast<float *>(d_obs);
     const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
 #define SRL_ROLLOUT(MODE)                                                                                                        \
-    if (two) hipLaunchKernelGGL((kuka_rollout_k<MODE, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out); \
-    else hipLaunchKernelGGL((kuka_rollout_k<MODE, 1>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
+    if (two) hipLaunchKernelGGL((kuka_rollout_k<MODE, 2>), grid, block, lds_bytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out); \
+    else hipLaunchKernelGGL((kuka_rollout_k<MODE, 1>), grid, block, lds_bytes, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, (const double *)nullptr, obs, d_rew, d_done, d_act_out);
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX:
             SRL_ROLLOUT(SRLHIP_RNG_PHILOX)
