@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in kuka mobile kuka_pixels; do
   rm -rf /tmp/prof_$w
-  extra="--no-cpu-baseline"; [ $w = kuka_pixels ] && extra=""
+  extra=""                                    # the kernel-stats run is the full default command (cpu_baseline leg included)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -o $w -- python $R/bench.py --workload $w $extra > $OUT/bench_$w.json 2>/dev/null
   cp $(find /tmp/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${w}_kernel_stats.csv
 done
