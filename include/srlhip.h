@@ -197,6 +197,16 @@ int srlhip_stream(srlhip_handle h, void **hip_stream);
 int srlhip_timing_begin(srlhip_handle h);
 int srlhip_timing_end(srlhip_handle h, float *elapsed_ms);   /* synchronises */
 
+/* HIP graphs for launch-bound step loops (cfg.io_device = 1 only): everything enqueued on the handle's stream between
+ * graph_begin and graph_end — srlhip_step / srlhip_rollout / srlhip_render with device pointers, srlhip_encoder_forward
+ * on srlhip_stream() — is captured instead of executed; srlhip_graph_launch() replays it (same buffers) with one launch.
+ * Make one eager call of the same sequence first: lazily allocated scratch must exist before the capture. */
+typedef struct srlhip_graph *srlhip_graph_handle;
+int srlhip_graph_begin(srlhip_handle h);
+int srlhip_graph_end(srlhip_handle h, srlhip_graph_handle *out);
+int srlhip_graph_launch(srlhip_handle h, srlhip_graph_handle g);
+int srlhip_graph_destroy(srlhip_graph_handle g);
+
 const char *srlhip_last_error(srlhip_handle h);
 int srlhip_abi_version(void);
 

@@ -485,6 +485,54 @@ int srlhip_stream(srlhip_handle hh, void **hip_stream) {
     return 0;
 }
 
+// ---- HIP graphs: capture whatever the caller enqueues on the handle's stream between begin and end (device-pointer
+// calls of this library, srlhip_encoder_forward on the same stream, ...) and replay it with one launch per step.
+struct srlhip_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int srlhip_graph_begin(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (!h->cfg.io_device) return h->fail(SRLHIP_EINVAL, "graph capture needs io_device = 1 (host-pointer calls synchronise)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    SRL_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+
+int srlhip_graph_end(srlhip_handle hh, srlhip_graph_handle *out) {
+    if (!hh || !out) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    SRL_HIP_CHECK(h, hipStreamEndCapture(h->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return h->fail(SRLHIP_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    srlhip_graph *sg = new (std::nothrow) srlhip_graph();
+    if (!sg) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); return h->fail(SRLHIP_ENOMEM, "graph handle"); }
+    sg->graph = g; sg->exec = ex;
+    *out = sg;
+    return 0;
+}
+
+int srlhip_graph_launch(srlhip_handle hh, srlhip_graph_handle g) {
+    if (!hh || !g) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    SRL_HIP_CHECK(h, hipGraphLaunch(g->exec, h->stream));
+    return 0;
+}
+
+int srlhip_graph_destroy(srlhip_graph_handle g) {
+    if (!g) return SRLHIP_OK;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return SRLHIP_OK;
+}
+
 int srlhip_timing_begin(srlhip_handle hh) {
     if (!hh) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);

@@ -36,6 +36,7 @@ EXPORTS = [
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error",
+    "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
     "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
@@ -97,6 +98,10 @@ def load():
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.srlhip_graph_begin.argtypes = [vp]
+    lib.srlhip_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.srlhip_graph_launch.argtypes = [vp, vp]
+    lib.srlhip_graph_destroy.argtypes = [vp]
     lib.srlhip_encoder_supported.argtypes = [i32, i32, i32]
     lib.srlhip_encoder_create.argtypes = [i32, i32, i32, i32, i32] + [vp] * 8 + [ctypes.POINTER(vp)]
     lib.srlhip_encoder_forward.argtypes = [vp, vp, i32, vp, vp]
@@ -276,6 +281,21 @@ class Handle(object):
         p = ctypes.c_void_p()
         self._check(self._lib.srlhip_stream(self._h, ctypes.byref(p)), "srlhip_stream")
         return p.value
+
+    # ---- HIP graphs (device-io handles): capture a step sequence once, replay it with one launch per step
+    def graph_begin(self):
+        self._check(self._lib.srlhip_graph_begin(self._h), "srlhip_graph_begin")
+
+    def graph_end(self):
+        g = ctypes.c_void_p()
+        self._check(self._lib.srlhip_graph_end(self._h, ctypes.byref(g)), "srlhip_graph_end")
+        return g
+
+    def graph_launch(self, g):
+        self._check(self._lib.srlhip_graph_launch(self._h, g), "srlhip_graph_launch")
+
+    def graph_destroy(self, g):
+        self._lib.srlhip_graph_destroy(g)
 
     def timing_begin(self):
         self._check(self._lib.srlhip_timing_begin(self._h), "srlhip_timing_begin")

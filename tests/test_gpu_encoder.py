@@ -66,6 +66,32 @@ def test_hip_encoder_on_rasterised_frames_and_foreign_stream():
     env.close()
 
 
+def test_graph_replayed_pixel_step_equals_eager_step():
+    """PixelStateVecEnv replays stepper + rasteriser + encoder of one step from a HIP graph (srlhip_graph_*): same
+    states / rewards / dones / frames as three eager launches, with device-sampled and with given actions."""
+    from srlhip.pixel_env import PixelStateVecEnv
+    gpu, _ = make_net(6, 3, True)
+    envs = [PixelStateVecEnv("KukaButtonGymEnv-v0", 200, gpu, seed=4, use_graph=flag) for flag in (True, False)]
+    for e in envs:
+        e.reset()
+    acts = torch.zeros((200,), dtype=torch.int32, device="cuda")
+    for t in range(12):
+        outs = []
+        for e in envs:
+            if t % 3 == 2:
+                acts.copy_(torch.full((200,), t % 6, dtype=torch.int32))
+                s, r, d = e.step(acts)
+            else:
+                s, r, d = e.step()
+            torch.cuda.synchronize()
+            outs.append((s.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy(), e.images.cpu().numpy().copy()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b), t
+    assert len(envs[0]._graphs) == 2 and not envs[1]._graphs
+    for e in envs:
+        e.close()
+
+
 def test_hip_encoder_rejects_what_it_does_not_cover():
     from srlhip import _lib
     with pytest.raises(RuntimeError):
