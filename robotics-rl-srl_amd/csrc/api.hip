@@ -1,6 +1,7 @@
 // api.hip — C-ABI front end of libsrlhip (include/srlhip.h): handle lifetime,
 // seeding, host<->device staging, state access, timing.  The env kernels live
 // in mobile.hip / kuka.hip.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -318,7 +319,8 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
     const size_t in_noise = (ab + 15) & ~(size_t)15, in_total = in_noise + sizeof(double) * n;
     const size_t out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * (size_t)n, out_total = out_done + n;
     const bool pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
-    const bool zero_copy = !h->cfg.io_device && !pixels && out_total <= ((size_t)1 << 20);
+    static const bool zc_enabled = [] { const char *v = getenv("SRLHIP_ZERO_COPY"); return !v || atoi(v) != 0; }();   // =0: bounce buffers
+    const bool zero_copy = zc_enabled && !h->cfg.io_device && !pixels && out_total <= ((size_t)1 << 20);
     if (!h->cfg.io_device) {
         if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, out_total)))
             return rc;
