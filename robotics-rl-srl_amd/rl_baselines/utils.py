@@ -17,6 +17,9 @@ def createEnvs(args, allow_early_resets=False, env_kwargs=None, load_path_normal
         "Error: cannot have more than 1 CPU for the environment {}".format(args.env)
     kwargs = dict(env_kwargs or {})
     kwargs.setdefault("srl_model", getattr(args, "srl_model", "raw_pixels"))
+    # learned SRL models (registered_srl[...][0] is SRLType.SRL): the reference starts a MultiprocessSRLModel server and hands
+    # every env a queue pair (:213-216); HipVecEnv loads the encoder once on the GPU (env_kwargs["srl_model_path"],
+    # ["state_dim"]) and returns its states as the observation
     envs = HipVecEnv(args.env, args.num_cpu, seed=args.seed, env_kwargs=kwargs, log_dir=getattr(args, "log_dir", None),
                      device_id=getattr(args, "device_id", 0), allow_early_resets=allow_early_resets)
     envs = VecFrameStack(envs, getattr(args, "num_stack", 1))

@@ -5,7 +5,13 @@ Duck-types stable_baselines.common.vec_env.VecEnv (2.5.0): num_envs,
 observation_space, action_space, reset(), step_async(), step_wait(), step(),
 close(), get_images(), render(); auto-reset on done; `None` actions allowed
 (rl_baselines/evolution_strategies/ars.py:170); per-env Monitor CSV files and
-info['episode'] like stable_baselines.bench.Monitor (environments/utils.py:54)."""
+info['episode'] like stable_baselines.bench.Monitor (environments/utils.py:54).
+
+Learned SRL models (state_representation/registry.py: SRLType.SRL — autoencoder, robotic_priors, ...): the reference
+runs ONE encoder process that every env queries through queues (MultiprocessSRLModel, rl_baselines/utils.py:162-191).
+Here the stepper renders all frames into HBM, the encoder (state_representation.models: fused HIP kernel for 64x64x3
+frames, PyTorch-ROCm otherwise) maps the batch to states on the same device, and only [N][state_dim] floats cross
+PCIe: the observation the policy sees is `srl_model.getState(render())`, as in the reference."""
 import json
 import os
 import time
@@ -27,7 +33,7 @@ def _env_kind(env_id):
 
 class HipVecEnv(object):
     def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode="mt19937",
-                 log_dir=None, allow_early_resets=False):
+                 log_dir=None, allow_early_resets=False, encoder=None):
         kw = dict(env_kwargs or {})
         self.env_id, self.num_envs, self.log_dir = env_id, int(num_envs), log_dir
         kind = _env_kind(env_id)
@@ -43,19 +49,42 @@ class HipVecEnv(object):
         if "max_distance" in kw:
             cfg.max_distance = float(kw["max_distance"])
         self.srl_model = kw.get("srl_model", "raw_pixels")
-        if self.srl_model not in OBS_MODES:
-            raise NotImplementedError("srl_model={!r}: learned SRL encoders plug in on top of raw_pixels".format(self.srl_model))
-        cfg.obs_mode = OBS_MODES[self.srl_model]
         if "img_shape" in kw:                       # (H, W); the reference renders 224 x 224
             cfg.img_h, cfg.img_w = kw["img_shape"]
-        cfg.rng_mode, cfg.auto_reset, cfg.io_device = RNG_MODES[rng_mode], 1, 0
+        self._enc = None
+        if self.srl_model not in OBS_MODES:
+            # a learned SRL model: pixels stay on the device, the encoder turns them into the observation
+            from state_representation.registry import registered_srl, SRLType
+            if registered_srl.get(self.srl_model, (None,))[0] is not SRLType.SRL:
+                raise KeyError("unknown srl_model {!r}".format(self.srl_model))
+            if encoder is None:
+                from state_representation.models import loadSRLModel
+                encoder = loadSRLModel(kw.get("srl_model_path"), cuda=True, state_dim=kw.get("state_dim"),
+                                       img_shape=(cfg.img_h, cfg.img_w), n_channels=6 if cfg.multi_view else 3)
+            self._enc = encoder
+            cfg.obs_mode, cfg.io_device = _lib.OBS_RAW_PIXELS, 1
+        else:
+            cfg.obs_mode, cfg.io_device = OBS_MODES[self.srl_model], 0
+        cfg.rng_mode, cfg.auto_reset = RNG_MODES[rng_mode], 1
         self.cfg = cfg
         self._h = _lib.Handle(cfg)
+        if self._enc is not None:
+            import torch
+            dev = torch.device("cuda", device_id)
+            ch = 6 if cfg.multi_view else 3
+            self._t = {"images": torch.zeros((self.num_envs, cfg.img_h, cfg.img_w, ch), dtype=torch.uint8, device=dev),
+                       "rew": torch.zeros((self.num_envs,), dtype=torch.float32, device=dev),
+                       "done": torch.zeros((self.num_envs,), dtype=torch.uint8, device=dev),
+                       "act": torch.zeros((self.num_envs,) if cfg.is_discrete else (self.num_envs, self._h.action_dim),
+                                          dtype=torch.int32 if cfg.is_discrete else torch.float32, device=dev)}
+            self.state_dim = int(self._enc.state_dim)
         if cfg.is_discrete:
             self.action_space = Discrete(self._h.num_actions)
         else:
             self.action_space = Box(low=-1, high=1, shape=(self._h.action_dim,), dtype=np.float32)
-        if cfg.obs_mode == _lib.OBS_RAW_PIXELS:
+        if self._enc is not None:
+            self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.state_dim,), dtype=np.float32)
+        elif cfg.obs_mode == _lib.OBS_RAW_PIXELS:
             self.observation_space = Box(low=0, high=255, shape=(cfg.img_h, cfg.img_w, 6 if cfg.multi_view else 3), dtype=np.uint8)
         else:
             self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self._h.obs_dim,), dtype=np.float32)
@@ -76,8 +105,23 @@ class HipVecEnv(object):
                 self._monitors.append(f)
 
     # -- VecEnv API ----------------------------------------------------------------
+    def _encode(self):
+        """states of the frames the stepper just rendered (its stream) -> float32 numpy [N][state_dim]"""
+        import torch
+        if getattr(self._enc, "hip", None) is not None:
+            st = self._enc.getStates(self._t["images"], stream=self._h.stream())     # same stream: ordered behind the rasteriser
+            self._h.sync()
+        else:
+            self._h.sync()
+            st = self._enc.getStates(self._t["images"])
+            torch.cuda.synchronize()
+        return st.to("cpu").numpy()
+
     def reset(self):
-        return self._h.reset()
+        if self._enc is None:
+            return self._h.reset()
+        self._h.reset(obs_out=self._t["images"].data_ptr())
+        return self._encode()
 
     def step_async(self, actions):
         if self.cfg.is_discrete:
@@ -94,7 +138,16 @@ class HipVecEnv(object):
             self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._h.action_dim)
 
     def step_wait(self):
-        obs, rew, done = self._h.step(self._actions)
+        if self._enc is None:
+            obs, rew, done = self._h.step(self._actions)
+        else:
+            import torch
+            t = self._t
+            t["act"].copy_(torch.from_numpy(self._actions))
+            torch.cuda.current_stream().synchronize()                    # the actions must be in HBM before the stepper's stream reads them
+            self._h.step(t["act"].data_ptr(), out=(t["images"].data_ptr(), t["rew"].data_ptr(), t["done"].data_ptr()))
+            obs = self._encode()                                         # syncs the stepper's stream
+            rew, done = t["rew"].to("cpu").numpy(), t["done"].to("cpu").numpy()
         dones = done.astype(bool)
         for i in self._dirty_infos:                      # entries that carried an 'episode' record last step
             self._infos[i] = {}
@@ -119,9 +172,15 @@ class HipVecEnv(object):
 
     def rollout(self, n_steps, actions=None):
         """Fused device-side rollout (no per-step host round trip): dict of [T][N] planes."""
+        if self._enc is not None:
+            raise NotImplementedError("fused rollouts with a learned SRL encoder: use srlhip.pixel_env.PixelStateVecEnv")
         return self._h.rollout(n_steps, actions=actions)
 
     def get_images(self):
+        if self._enc is not None:
+            self._h.render(out=self._t["images"].data_ptr())
+            self._h.sync()
+            return list(self._t["images"].to("cpu").numpy())
         return list(self._h.render())
 
     def render(self, mode="human"):

@@ -92,6 +92,48 @@ def test_graph_replayed_pixel_step_equals_eager_step():
         e.close()
 
 
+@pytest.mark.parametrize("img_shape", [(64, 64), (96, 96)])
+def test_vec_env_with_a_learned_srl_model(img_shape, tmp_path):
+    """createEnvs / HipVecEnv with a learned SRL model (registered_srl[...] is SRLType.SRL; the reference's
+    MultiprocessSRLModel path, rl_baselines/utils.py:162-216): the observation is encoder(render()) — checked against a
+    raw_pixels twin stepped with the same seeds and actions whose frames go through the same network on the CPU.
+    64x64 frames take the fused HIP encoder, 96x96 the PyTorch-ROCm forward."""
+    from srlhip.vec_env import HipVecEnv
+    n, sd = 48, 5
+    gpu, cpu = make_net(sd, 11, True) if img_shape == (64, 64) else (None, None)
+    if gpu is None:
+        torch.manual_seed(3)
+        gpu = SRLNeuralNetwork(sd, cuda=True, img_shape=img_shape)
+        cpu = SRLNeuralNetwork(sd, cuda=False, img_shape=img_shape, state_dict=gpu.model.state_dict(), backend="torch")
+    assert (gpu.backend == "hip") == (img_shape == (64, 64))
+    kw = {"img_shape": img_shape, "random_target": True}
+    env = HipVecEnv("KukaButtonGymEnv-v0", n, seed=9, env_kwargs=dict(kw, srl_model="autoencoder"), encoder=gpu, log_dir=str(tmp_path))
+    twin = HipVecEnv("KukaButtonGymEnv-v0", n, seed=9, env_kwargs=dict(kw, srl_model="raw_pixels"))
+    assert env.observation_space.shape == (sd,) and env.observation_space.dtype == np.float32
+    tol = TOL if img_shape == (64, 64) else 2e-3
+    obs, frames = env.reset(), twin.reset()
+    assert obs.shape == (n, sd) and rel_err(obs, cpu.getStates(frames).numpy()) < tol
+    rs = np.random.RandomState(0)
+    for t in range(25):
+        a = rs.randint(6, size=n)
+        obs, r, d, info = env.step(a)
+        frames, r2, d2, _ = twin.step(a)
+        assert np.array_equal(r, r2) and np.array_equal(d, d2)
+        assert rel_err(obs, cpu.getStates(frames).numpy()) < tol, t
+    assert len(env.get_images()) == n and env.get_images()[0].shape == img_shape + (3,)
+    env.close(); twin.close()
+    # the createEnvs entry point: a Namespace like rl_baselines.train builds, random-initialised encoder of state_dim 4
+    import argparse
+    from rl_baselines.utils import createEnvs
+    args = argparse.Namespace(env="MobileRobotGymEnv-v0", num_cpu=8, seed=0, log_dir=None, srl_model="robotic_priors", num_stack=1)
+    venv = createEnvs(args, env_kwargs={"state_dim": 4, "img_shape": img_shape})
+    o = venv.reset()
+    assert o.shape == (8, 4) and np.isfinite(o).all()
+    o, r, d, _ = venv.step([0] * 8)
+    assert o.shape == (8, 4)
+    venv.close()
+
+
 def test_hip_encoder_rejects_what_it_does_not_cover():
     from srlhip import _lib
     with pytest.raises(RuntimeError):
