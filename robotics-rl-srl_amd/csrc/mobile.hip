@@ -20,7 +20,9 @@
 // (step, env), Philox is random access) into the [T][N] action plane; the recurrence kernel then reads them one
 // step ahead of use (software-pipelined load) and is specialised at compile time on the env kind and the action type.
 // At the 4096-env BASELINE size only 64 wavefronts exist, so the launch time is T x (cycles per step of one
-// wavefront): taking the 10-round Philox block out of that chain is what matters.
+// wavefront): taking the 10-round Philox block out of that chain is what matters — and so is cutting the chain
+// itself: with counter-based streams the episodes of an env are independent of each other, so a T-step rollout runs
+// as ceil(T / 251) + 1 segments per env on separate lanes (mobile_rollout_ep_k below).
 #include "internal.hpp"
 
 namespace srl {
