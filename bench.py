@@ -101,6 +101,36 @@ def cpu_baseline(workload, n_envs, budget_s=12.0):
     return kuka_clib.cpu_baseline(budget_s)
 
 
+def pixel_cpu_baseline(enc, env, budget_s=4.0):
+    """Config 4 on the host cores ('port'): the C oracles step the physics (OpenMP) and ray-cast 64x64 frames (OpenMP), the
+    same CustomCNN runs in float32 under PyTorch on the CPU; each stage timed on a bounded sample and combined per
+    env-step (the stages are sequential in the reference: render inside env.step, then the encoder)."""
+    from oracle import kuka_clib, raster_clib
+    from state_representation.models import SRLNeuralNetwork
+    from srlhip import _lib
+    phys = kuka_clib.cpu_baseline(budget_s)                                   # env-steps/s, physics only
+    n = 1024
+    h = env.h
+    state = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_BUTTON_Q)[0][:, None],
+                            h.get_state(_lib.F_KUKA_BUTTON_XY).T], axis=1)[:n]
+    frames = raster_clib.render(4, state, 64, 64)
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < budget_s:
+        frames = raster_clib.render(4, state, 64, 64); reps += 1
+    raster_rate = reps * n / (time.perf_counter() - t0)
+    cpu_enc = SRLNeuralNetwork(enc.state_dim, cuda=False, img_shape=(64, 64), state_dict=enc.model.state_dict(), backend="torch")
+    cpu_enc.getStates(frames[:64])
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < budget_s:
+        cpu_enc.getStates(frames); reps += 1
+    enc_rate = reps * n / (time.perf_counter() - t0)
+    value = 1.0 / (1.0 / phys["value"] + 1.0 / raster_rate + 1.0 / enc_rate)
+    return {"value": value, "unit": "env-steps/s", "cores": phys["cores"], "kind": "port",
+            "sample": "per stage ~{:.0f} s on the host cores: oracle/kuka_oracle.c physics {:.3g} env-steps/s, oracle/raster_oracle.c "
+                      "64x64 frames {:.3g}/s ({} frames per pass), PyTorch CPU float32 CustomCNN {:.3g} frames/s; combined as "
+                      "sequential stages".format(budget_s, phys["value"], raster_rate, n, enc_rate)}
+
+
 def bench_pixels(args, rank, local_rank, world, dev):
     """BASELINE config 4/5: KukaButtonGymEnv raw_pixels 64x64 -> tile rasteriser -> SRL encoder forward
     (fused HIP kernel, csrc/encoder.hip) on the same device.  One bench step = `inner` VecEnv steps of this rank's shard."""
@@ -195,6 +225,12 @@ def bench_pixels(args, rank, local_rank, world, dev):
                                      "stepper_and_launch_gaps": step_ms - raster_ms - (enc_ms or 0.0)},
                        "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
             "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = pixel_cpu_baseline(enc, env)
+            line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
+        except Exception as exc:      # the checker must never sink the measurement
+            line["cpu_baseline"] = {"value": None, "error": repr(exc)}
     env.close()
     if rank == 0:
         print(json.dumps(line))
