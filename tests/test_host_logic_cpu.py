@@ -122,3 +122,18 @@ def test_recorder_layout_and_merge(tmp_path):
     assert gt["images_path"][6] == "ds/record_002/frame000000" and os.path.exists(root + "ds/record_003/frame000002.jpg")
     assert json.load(open(root + "ds/env_globals.json")) == {"MAX_STEPS": 250}
     assert not os.path.exists(root + "ds_part-0")
+
+
+def test_srl_registry_and_vec_env_argument_checks():
+    """state_representation/registry.py mirror + the checks HipVecEnv makes before it touches the GPU."""
+    import pytest
+    from state_representation import SRLType
+    from state_representation.registry import registered_srl
+    from srlhip.vec_env import HipVecEnv
+    assert registered_srl["ground_truth"][0] is SRLType.ENVIRONMENT and registered_srl["joints"][1] == ["KukaButtonGymEnv"]
+    learned = [k for k, v in registered_srl.items() if v[0] is SRLType.SRL]
+    assert len(learned) == 20 and {"autoencoder", "robotic_priors", "vae", "pca", "srl_splits"} <= set(learned)
+    with pytest.raises(KeyError):
+        HipVecEnv("KukaButtonGymEnv-v0", 4, env_kwargs={"srl_model": "no_such_model"})
+    with pytest.raises(KeyError):
+        HipVecEnv("NoSuchEnv-v0", 4)
