@@ -354,17 +354,20 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     // bands of whole 8-row tile strips that fit the LDS tile buffer; inside a band every wavefront walks 8x8 tiles
     const int band_rows = max(8, (kTilePixels / rp.w) & ~7);
     const int tiles_x = (rp.w + 7) >> 3;
+    const float inv_w2 = 2.0f / (float)rp.w, inv_h2 = 2.0f / (float)rp.h;
     for (int row0 = 0; row0 < rp.h; row0 += band_rows) {
         const int rows = min(band_rows, rp.h - row0), base = row0 * rp.w, count = rows * rp.w;
         const int ntiles = ((rows + 7) >> 3) * tiles_x;
-        for (int t = wave; t < ntiles; t += kRasterBlock / 64) {
-            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        int ty = wave / tiles_x, tx = wave - ty * tiles_x;                 // one division per band, not per tile
+        for (int t = wave; t < ntiles; t += kRasterBlock / 64, tx += kRasterBlock / 64) {
+            while (tx >= tiles_x) { tx -= tiles_x; ty++; }
             const int col0 = tx * 8, r0 = row0 + ty * 8;
             // tile rectangle in tangent space (pixel edges; y grows upwards while rows grow downwards)
-            const float tx0 = ((float)col0 / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
-            const float tx1 = ((float)(col0 + 8) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
-            const float ty1 = (1.0f - (float)r0 / (float)rp.h * 2.0f) * c.tan_half_fov;
-            const float ty0 = (1.0f - (float)(r0 + 8) / (float)rp.h * 2.0f) * c.tan_half_fov;
+            // (culling only — the primitives' rectangles carry 1e-3 of slack — so reciprocals instead of divisions)
+            const float tx0 = ((float)col0 * inv_w2 - 1.0f) * c.tan_half_fov;
+            const float tx1 = ((float)(col0 + 8) * inv_w2 - 1.0f) * c.tan_half_fov;
+            const float ty1 = (1.0f - (float)r0 * inv_h2) * c.tan_half_fov;
+            const float ty0 = (1.0f - (float)(r0 + 8) * inv_h2) * c.tan_half_fov;
             bool touch = false;
             if (lane < np) touch = rects[lane][0] <= tx1 && rects[lane][1] >= tx0 && rects[lane][2] <= ty1 && rects[lane][3] >= ty0;
             uint64_t mask = __ballot(touch);
