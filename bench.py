@@ -98,7 +98,7 @@ def cpu_baseline(workload, n_envs, budget_s=12.0):
         base["c_port_1_thread_env_steps_per_s"] = reps * T * n_envs / (time.perf_counter() - t0)
         return base
     from oracle import kuka_clib
-    return kuka_clib.cpu_baseline(budget_s)
+    return kuka_clib.cpu_baseline(10.0)
 
 
 def pixel_cpu_baseline(enc, env, budget_s=4.0):
@@ -108,7 +108,7 @@ def pixel_cpu_baseline(enc, env, budget_s=4.0):
     from oracle import kuka_clib, raster_clib
     from state_representation.models import SRLNeuralNetwork
     from srlhip import _lib
-    phys = kuka_clib.cpu_baseline(budget_s)                                   # env-steps/s, physics only
+    phys = kuka_clib.cpu_baseline(budget_s, subproc=False)                    # env-steps/s, physics only
     n = 1024
     h = env.h
     state = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_BUTTON_Q)[0][:, None],
@@ -137,9 +137,9 @@ def bench_pixels(args, rank, local_rank, world, dev):
     from srlhip import _lib, sharding
     from srlhip.pixel_env import PixelStateVecEnv
     from state_representation.models import SRLNeuralNetwork
-    n, inner = args.envs_per_gpu, args.inner_steps or 8
-    K = args.steps if args.steps is not None else 10
-    W = args.warmup if args.warmup is not None else 2
+    n, inner = args.envs_per_gpu, args.inner_steps or 256     # >= 256 VecEnv steps per bench step
+    K = args.steps if args.steps is not None else 8
+    W = args.warmup if args.warmup is not None else 1
     torch.manual_seed(0)
     enc = SRLNeuralNetwork(3, cuda=True, img_shape=(64, 64), device=dev)
     first, _ = sharding.shard_range(world * n, world, rank)
@@ -149,11 +149,11 @@ def bench_pixels(args, rank, local_rank, world, dev):
     ret = torch.zeros((n,), dtype=torch.float32, device=dev)
 
     def one_step():
-        ret.zero_()
         for _ in range(inner):
             states, rew, done = env.step()
-            ret.add_(rew)
         if world > 1:
+            env.h.episode_stats_device(last_return=ret.data_ptr())     # enqueued on the stepper's stream
+            torch.cuda.current_stream(dev).wait_stream(env._stream)
             sharding.gather_episode_returns(ret, out=gathered)
 
     def fence():
@@ -259,9 +259,11 @@ def main():
     if workload == "kuka_pixels":
         return bench_pixels(args, rank, local_rank, world, dev)
     n = args.envs_per_gpu
-    inner = args.inner_steps or (2048 if workload == "mobile" else 32)     # T = 2048
-    K = args.steps if args.steps is not None else (20 if workload == "mobile" else 20)
-    W = args.warmup if args.warmup is not None else (5 if workload == "mobile" else 3)
+    # one bench step = a T = 2048-step rollout of every env (each Kuka env crosses >= 2 auto-resets, each
+    # MobileRobot env 8), after a warm-up of >= 256 steps (one 2048-step rollout by default)
+    inner = args.inner_steps or 2048
+    K = args.steps if args.steps is not None else 20
+    W = args.warmup if args.warmup is not None else (5 if workload == "mobile" else 1)
 
     kind = _lib.ENV_MOBILE if workload == "mobile" else _lib.ENV_KUKA_BUTTON
     cfg = _lib.default_config(kind)
@@ -287,19 +289,21 @@ def main():
 
     ext = torch.cuda.ExternalStream(h.stream(), device=dev) if world > 1 else None
 
+    ep_ret = torch.zeros((n,), dtype=torch.float32, device=dev)      # Monitor's r of each env's last finished episode
+
     def one_step():
         h.rollout(inner, out=out)
         if world > 1:
-            # the path's only exchange: episode returns, once per rollout, RCCL over xGMI.  No host sync:
-            # torch's stream waits for this rollout, reduces the reward plane, and the stepper's stream is released for
-            # the next rollout as soon as that reduction is done — the all-gather itself overlaps the next rollout.
+            # the path's only exchange: per-env episode returns, once per rollout, RCCL over xGMI.  No host
+            # sync: the stepper's stream narrows its episode statistics into `ep_ret` (srlhip_episode_stats_device),
+            # torch's stream waits for that and all-gathers; the next rollout only waits until the gather has read `ep_ret`.
+            h.episode_stats_device(last_return=ep_ret.data_ptr())
             cur = torch.cuda.current_stream(dev)
             cur.wait_stream(ext)
-            ret = rew.sum(dim=0)
+            sharding.gather_episode_returns(ep_ret, out=gathered)
             done_reading = torch.cuda.Event()
             done_reading.record(cur)
             ext.wait_event(done_reading)
-            sharding.gather_episode_returns(ret, out=gathered)
 
     def fence():
         h.sync()
@@ -330,7 +334,7 @@ def main():
                 "kernel": "mobile_rollout_ep_k" if workload == "mobile" else "kuka_rollout_k",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
-    if n == 4096 and inner == (2048 if workload == "mobile" else 32):       # geometry the PMC passes were taken at
+    if n == 4096 and inner == 2048:       # geometry the PMC passes were taken at
         roofline["traffic"] = measured_traffic(roofline["kernel"], steps_per_launch)
         roofline["traffic_source"] = "profiles/ PMC summaries (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
     if workload == "kuka":
@@ -354,6 +358,10 @@ def main():
             "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
         "roofline": roofline,
     }
+    if world > 1:
+        torch.cuda.synchronize()
+        line["config"]["episode_returns_allgathered"] = {"count": int(gathered.numel()), "mean": float(gathered.mean().item()),
+                                                         "collective": "all_gather_into_tensor float32[{}] per rank, once per rollout ({})".format(n, backend)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(workload, n)

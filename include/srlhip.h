@@ -159,6 +159,9 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_LAST_REWARD    6   /* f64 reward of the last step, uncast   */
 #define SRLHIP_F_EP_RETURN      7   /* f64 running episode return            */
 #define SRLHIP_F_EP_LENGTH      8   /* i32 running episode length            */
+#define SRLHIP_F_LAST_RETURN    11  /* f64 return of the last finished episode (Monitor's r) */
+#define SRLHIP_F_LAST_LENGTH    12  /* i32 its length (Monitor's l)          */
+#define SRLHIP_F_N_FINISHED     13  /* i32 episodes finished so far          */
 #define SRLHIP_F_TARGET2_X      9   /* f64 second target (2Target)           */
 #define SRLHIP_F_TARGET2_Y      10  /* f64 */
 #define SRLHIP_F_KUKA_Q         16  /* f64[7]  arm joint positions           */
@@ -190,6 +193,11 @@ int srlhip_render(srlhip_handle h, void *img_out);
  * (environments/utils.py:54).  HOST pointers, any may be NULL. */
 int srlhip_episode_stats(srlhip_handle h, double *last_return, int32_t *last_length,
                          int32_t *n_finished);
+
+/* Same statistics for DEVICE-resident consumers (cfg.io_device-independent): enqueue-only on the handle's stream, no
+ * host synchronisation.  last_return is narrowed to float32 — the element the multi-GPU path all-gathers over RCCL
+ * (one all-gather of per-env episode returns per rollout).  DEVICE pointers, any may be NULL. */
+int srlhip_episode_stats_device(srlhip_handle h, float *d_last_return, int32_t *d_last_length, int32_t *d_n_finished);
 
 /* Stream ordering and live kernel timing (HIP events on the handle's stream). */
 int srlhip_sync(srlhip_handle h);

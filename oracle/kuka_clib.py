@@ -159,18 +159,80 @@ def command_trace(seed, T, actions, is_discrete=True, action_joints=False, rando
             "jt": jt[n_reset.value:n_reset.value + n], "n_steps": n}
 
 
-def cpu_baseline(budget_s=12.0, n_envs=None):
-    """Time the oracle on the host cores (OpenMP over envs): bench.py's cpu_baseline leg."""
+class OracleEnv:
+    """One KukaButtonGymEnv the way a SubprocVecEnv worker holds it (literal 505-step reset): bench cpu_baseline only."""
+
+    def __init__(self, seed, rng_mode=RNG_MT19937, is_discrete=True, random_target=False, force_down=True,
+                 shape_reward=False, action_repeat=1, max_distance=0.8, obs_mode=0):
+        lib = _lib()
+        lib.kuka_oracle_env_new.restype = ctypes.c_void_p
+        lib.kuka_oracle_env_new.argtypes = [ctypes.c_int] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                                 ctypes.c_void_p, ctypes.c_int]
+        lib.kuka_oracle_env_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.kuka_oracle_env_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.kuka_oracle_env_step.restype = ctypes.c_double
+        lib.kuka_oracle_env_free.argtypes = [ctypes.c_void_p]
+        keys, lens = clib.mt_keys([seed])
+        self._lib = lib
+        self._obs = np.zeros({0: 3, 1: 14, 2: 17}[obs_mode], np.float32)
+        self._done = ctypes.c_int()
+        self._h = lib.kuka_oracle_env_new(int(is_discrete), int(random_target), int(force_down), int(shape_reward),
+                                          int(action_repeat), float(max_distance), int(obs_mode), int(rng_mode), int(seed),
+                                          _p(keys), int(lens[0]))
+
+    def reset(self):
+        self._lib.kuka_oracle_env_reset(self._h, _p(self._obs))
+        return self._obs.copy()
+
+    def step(self, action):
+        r = self._lib.kuka_oracle_env_step(self._h, -1 if action is None else int(action), _p(self._obs), ctypes.byref(self._done))
+        return self._obs.copy(), r, bool(self._done.value)
+
+    def close(self):
+        if self._h:
+            self._lib.kuka_oracle_env_free(self._h)
+            self._h = None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=10.0, n_envs=None, subproc=True):
+    """bench.py's cpu_baseline leg (rank 0, N=1): the oracle timed on the host cores, two ways.
+    value   = OpenMP over envs, T = 2048 steps per env with auto-reset inside (SURVEY 8(d) rollout length); the 500 RNG-free
+              settle steps are integrated once per pass and cached, a reset then costs its 5 init-action steps — the most
+              generous reading for the CPU (the reference re-simulates all 505 steps and renders 224x224 every step).
+    subproc = the reference's own vectorisation protocol (SubprocVecEnv: one worker process per env, Pipe + pickle per
+              step, auto-reset in the worker with the literal 505-step reset), num_cpu = os.cpu_count()."""
     threads = os.cpu_count() or 1
     n = n_envs or max(64, min(4096, 4 * threads))
-    T = 8
-    rollout(np.arange(n), 2, actions=None, rng_mode=RNG_PHILOX, trace=False)      # warm-up / settle
+    T = 2048
+    rollout(np.arange(min(n, 64)), 2, actions=None, rng_mode=RNG_PHILOX, trace=False)      # warm-up (page in, OpenMP pool)
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < budget_s:
-        rollout(np.arange(n), T, actions=None, rng_mode=RNG_PHILOX, trace=False)
+    reps, resets = 0, 0
+    while True:
+        out = rollout(np.arange(n) + reps * n, T, actions=None, rng_mode=RNG_PHILOX, trace=False)
+        resets += int(out["ep_stats"][:, 2].sum())
         reps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
     dt = time.perf_counter() - t0
-    return {"value": reps * T * n / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle/kuka_oracle.c (OpenMP over envs), {} envs x {} steps x {} passes incl. a 505-step "
-                      "settle per pass, physics only (no rendering)".format(n, T, reps)}
+    res = {"value": reps * T * n / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "physics_steps_per_s": (reps * (T * n + 5 * n + 500) + 5 * resets) / dt,
+           "sample": "oracle/kuka_oracle.c (OpenMP over envs, {} threads), {} envs x {} steps x {} passes with auto-reset inside "
+                     "({} episode ends; settled state cached per pass, a reset = 5 init-action steps), physics only "
+                     "(no rendering)".format(threads, n, T, reps, resets)}
+    if subproc:
+        from . import subproc_baseline
+        try:
+            res["subproc"] = subproc_baseline.kuka_subproc_fps(num_cpu=threads)
+        except Exception as exc:           # a failing worker pool must not sink the bench line
+            res["subproc"] = {"value": None, "error": repr(exc)}
+    return res

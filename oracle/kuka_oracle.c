@@ -738,3 +738,35 @@ int kuka_oracle_command_trace(int is_discrete, int action_joints, int random_tar
     free(r);
     return t;
 }
+
+/* ------------------------------------------------------------------ single-env handle
+ * One KukaButtonGymEnv object the way a SubprocVecEnv worker holds it (rl_baselines/utils.py:216-220,
+ * environments/utils.py:48-57): bench.py's cpu_baseline leg drives one of these per worker process through
+ * oracle/subproc_baseline.py.  reset() integrates the literal 505 steps (kuka_button_gym_env.py:242-269). */
+typedef struct { kcfg cfg; kenv env; krng rng; int obs_mode; } koracle_env;
+
+void *kuka_oracle_env_new(int is_discrete, int random_target, int force_down, int shape_reward, int action_repeat,
+                          double max_distance, int obs_mode, int rng_mode, int64_t seed, const uint32_t *mt_key, int mt_key_len) {
+    koracle_env *h = (koracle_env *)calloc(1, sizeof(koracle_env));
+    h->cfg.is_discrete = is_discrete; h->cfg.random_target = random_target; h->cfg.force_down = force_down;
+    h->cfg.shape_reward = shape_reward; h->cfg.action_repeat = action_repeat; h->cfg.max_distance = max_distance;
+    h->cfg.moving = g_moving; h->cfg.two = g_two; h->cfg.rand_objects = g_rand;
+    h->obs_mode = obs_mode; h->rng.mode = rng_mode;
+    if (rng_mode == 2) np_rng_seed_array(&h->rng.mt, mt_key, mt_key_len);
+    h->rng.ph.k0 = (uint32_t)(uint64_t)seed; h->rng.ph.k1 = (uint32_t)((uint64_t)seed >> 32); h->rng.ph.ctr = 0; h->rng.ph.stream = 0;
+    return h;
+}
+void kuka_oracle_env_reset(void *hv, float *obs) {
+    koracle_env *h = (koracle_env *)hv; kenv settled;
+    settle(&settled, &h->cfg);                        /* the reference re-runs its 500 settle steps on every reset */
+    env_reset(&h->env, &h->cfg, &h->rng, &settled);
+    observe(&h->env, h->obs_mode, obs);
+}
+double kuka_oracle_env_step(void *hv, int action, float *obs, int *done) {
+    koracle_env *h = (koracle_env *)hv;
+    const float ca[7] = {0};
+    double r = env_step(&h->env, &h->cfg, &h->rng, action, ca, done);
+    observe(&h->env, h->obs_mode, obs);
+    return r;
+}
+void kuka_oracle_env_free(void *hv) { free(hv); }

@@ -110,9 +110,21 @@ int seed_impl(Handle *h, const uint8_t *mask, const int64_t *seeds) {
     return 0;
 }
 
+// srlhip_episode_stats_device: Monitor's per-env (r, l) of the last finished episode as f32 / i32 planes in caller memory
+__global__ void episode_stats_k(EpisodeStats st, int n, float *ret, int32_t *len, int32_t *fin) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (ret) ret[e] = (float)st.last_return[e];
+    if (len) len[e] = st.last_length[e];
+    if (fin) fin[e] = st.n_finished[e];
+}
+
 int field_lookup(Handle *h, int field, void **dptr, size_t *elem, int *count) {
     *count = 1;
     switch (field) {
+        case SRLHIP_F_LAST_RETURN: *dptr = h->stats.last_return; *elem = 8; return 0;
+        case SRLHIP_F_LAST_LENGTH: *dptr = h->stats.last_length; *elem = 4; return 0;
+        case SRLHIP_F_N_FINISHED: *dptr = h->stats.n_finished; *elem = 4; return 0;
         case SRLHIP_F_LAST_REWARD: *dptr = h->stats.last_reward; *elem = 8; return 0;
         case SRLHIP_F_EP_RETURN: *dptr = h->stats.ep_return; *elem = 8; return 0;
         case SRLHIP_F_EP_LENGTH: *dptr = h->stats.ep_length; *elem = 4; return 0;
@@ -471,6 +483,17 @@ int srlhip_episode_stats(srlhip_handle hh, double *last_return, int32_t *last_le
     if (last_return) SRL_HIP_CHECK(h, hipMemcpy(last_return, h->stats.last_return, 8 * n, hipMemcpyDeviceToHost));
     if (last_length) SRL_HIP_CHECK(h, hipMemcpy(last_length, h->stats.last_length, 4 * n, hipMemcpyDeviceToHost));
     if (n_finished) SRL_HIP_CHECK(h, hipMemcpy(n_finished, h->stats.n_finished, 4 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int srlhip_episode_stats_device(srlhip_handle hh, float *d_last_return, int32_t *d_last_length, int32_t *d_n_finished) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(episode_stats_k, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->stats, h->n, d_last_return,
+                       d_last_length, d_n_finished);
+    SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
 

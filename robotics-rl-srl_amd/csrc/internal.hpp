@@ -83,6 +83,12 @@ struct Handle {
     RngState rng;
     EpisodeStats stats;
     MobileState mobile;
+    // read-only snapshot of everything mobile_rollout_ep_k's segment lanes read from the live state (taken by a copy kernel
+    // right before the launch): a lane may start after the lane that writes its env's final state has retired
+    MobileState mobile_snap = {};
+    uint64_t *snap_ctr = nullptr;
+    double *snap_ep_return = nullptr;
+    int32_t *snap_ep_length = nullptr;
     KukaState *kuka;
     std::vector<void *> allocs;      // everything hipMalloc'ed for this handle
     // staging buffers for io_device == 0

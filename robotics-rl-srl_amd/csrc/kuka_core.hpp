@@ -90,8 +90,6 @@ constexpr int kMaxSteps = 1000, kNContactsBeforeTermination = 5, kNStepsOutside 
 constexpr double kDeltaV = 0.03, kDeltaVContinuous = 0.0035, kDeltaTheta = 0.1;
 constexpr double kNoiseStd = 0.01, kNoiseStdContinuous = 0.0001, kNoiseStdJoints = 0.002;
 constexpr int kNInitActions = 5, kNSettleSteps = 500;
-// algorithmic work of one physics step, counted from this file (DESIGN.md §Kuka kernel)
-constexpr double kFlopsPerPhysicsStep = 5.6e4;
 
 // ---------------------------------------------------------------- LDS scratch
 // [slot][lane] doubles; `st` = lanes per workgroup (64 on the device, 1 on the host).

@@ -332,16 +332,31 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
 // segment slot store whole [t][e..e+63] rows when their envs' episode clocks agree (they do after a common reset).
 constexpr int kEpisodeSteps = 251;
 
+// Everything a segment lane reads from the per-env state.  The lanes of one env are NOT guaranteed to be co-resident
+// (beyond ~0.5 M lanes later blocks are dispatched after earlier ones retire), and the lane that finishes an env's rollout
+// overwrites its state: the segments therefore read this snapshot, taken by mobile_snapshot_k in stream order right
+// before the launch, and only write the live state.
+struct MobileSnap { MobileState s; const uint64_t *ctr; const double *ep_return; const int32_t *ep_length; };
+
+__global__ void __launch_bounds__(kBlock)
+mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileState d, uint64_t *ctr, double *ep_return, int32_t *ep_length) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    d.pos_x[e] = s.pos_x[e]; d.pos_y[e] = s.pos_y[e]; d.tgt_x[e] = s.tgt_x[e]; d.tgt_y[e] = s.tgt_y[e];
+    d.tgt2_x[e] = s.tgt2_x[e]; d.tgt2_y[e] = s.tgt2_y[e]; d.counter[e] = s.counter[e]; d.cur_target[e] = s.cur_target[e];
+    ctr[e] = rs.ctr[e]; ep_return[e] = st.ep_return[e]; ep_length[e] = st.ep_length[e];
+}
+
 template <int KIND, int DISC>
 __global__ void __launch_bounds__(kBlock)
-mobile_rollout_ep_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
+mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
                     const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
                     uint8_t *__restrict__ done_out, int advance_actr) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(gid % p.n), j = (int)(gid / p.n);
     if (j >= smax) return;
     p.kind = KIND; p.is_discrete = DISC;                                   // compile-time constants from here on
-    const int c0 = s.counter[e];
+    const int c0 = snap.s.counter[e];
     const int L0 = c0 <= kEpisodeSteps - 1 ? kEpisodeSteps - c0 : 1;       // steps until the running episode ends
     const int t_lo = j == 0 ? 0 : L0 + kEpisodeSteps * (j - 1);
     if (t_lo >= T) return;
@@ -351,14 +366,14 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st,
     const int n_completed = T >= L0 ? 1 + (T - L0) / kEpisodeSteps : 0;   // episodes of env e that finish inside the rollout
     PhiloxRng rng;
     rng.p.k0 = rs.key[e]; rng.p.k1 = rs.key[p.n + e]; rng.p.stream = 0;
-    const uint64_t ctr0 = rs.ctr[e];
+    const uint64_t ctr0 = snap.ctr[e];
     MobileEnv m;
     double ep_ret = 0.0, seg_ret = 0.0, last_reward = 0.0;
     int32_t ep_len = 0, seg_len = 0;
     if (j == 0) {
-        load_env(s, e, m);
+        load_env(snap.s, e, m);
         rng.p.ctr = ctr0;
-        ep_ret = st.ep_return[e]; ep_len = st.ep_length[e];
+        ep_ret = snap.ep_return[e]; ep_len = snap.ep_length[e];
     } else {
         rng.p.ctr = ctr0 + (uint64_t)(j - 1) * (uint64_t)draws_per_reset;
         reset_env(p, rng, m);                                              // the reset the previous segment ends with
@@ -489,14 +504,26 @@ void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actio
 #undef SRL_GO
 }
 
-void launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
-                       uint8_t *d_done, int advance_actr) {
+int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
+                      uint8_t *d_done, int advance_actr) {
+    if (!h->snap_ctr) {
+        MobileState &d = h->mobile_snap;
+        const size_t n = (size_t)h->n;
+        int rc;
+        if ((rc = h->dalloc(&d.pos_x, n)) || (rc = h->dalloc(&d.pos_y, n)) || (rc = h->dalloc(&d.tgt_x, n)) || (rc = h->dalloc(&d.tgt_y, n)) ||
+            (rc = h->dalloc(&d.tgt2_x, n)) || (rc = h->dalloc(&d.tgt2_y, n)) || (rc = h->dalloc(&d.counter, n)) || (rc = h->dalloc(&d.cur_target, n)) ||
+            (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)))
+            return rc;
+    }
+    hipLaunchKernelGGL(mobile_snapshot_k, dim3((h->n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->n, h->mobile, h->rng, h->stats,
+                       h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length);
+    const MobileSnap snap{h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length};
     const int smax = 1 + (T - 1 + kEpisodeSteps - 1) / kEpisodeSteps;     // first segment of one step + whole episodes
     const int64_t lanes = (int64_t)smax * h->n;
     dim3 grid((unsigned)((lanes + kBlock - 1) / kBlock)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
 #define SRL_GO(KIND, DISC)                                                                                              \
-    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats, T, \
+    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
                        draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr)
 #define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
     switch (p.kind) {
@@ -507,6 +534,7 @@ void launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_ac
     }
 #undef SRL_KIND
 #undef SRL_GO
+    return 0;
 }
 
 }  // namespace
@@ -538,7 +566,7 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
         advance = 1;
     }
     // counter-based streams + fixed-length episodes: segments of the rollout run in parallel (mobile_rollout_ep_k)
-    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX && p.auto_reset && T >= 32) launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance);
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX && p.auto_reset && T >= 32) { int rc = launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance); if (rc) return rc; }
     else if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     else launch_rollout<SRLHIP_RNG_MT19937>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     SRL_HIP_CHECK(h, hipGetLastError());

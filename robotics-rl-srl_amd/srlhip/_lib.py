@@ -17,6 +17,7 @@ OBS_GROUND_TRUTH, OBS_JOINTS, OBS_JOINTS_POSITION, OBS_RAW_PIXELS = range(4)
 RNG_HOST, RNG_PHILOX, RNG_MT19937 = range(3)
 F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REWARD, F_EP_RETURN, F_EP_LENGTH = range(9)
 F_TARGET2_X, F_TARGET2_Y = 9, 10
+F_LAST_RETURN, F_LAST_LENGTH, F_N_FINISHED = 11, 12, 13
 F_KUKA_Q, F_KUKA_QD, F_KUKA_EE_TARGET, F_KUKA_BUTTON_Q, F_KUKA_BUTTON_POS, F_KUKA_GRIPPER, F_KUKA_COUNTERS = range(16, 23)
 F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS = range(23, 28)
 
@@ -24,6 +25,7 @@ _FIELD_SHAPES = {
     F_POS_X: (np.float64, 1), F_POS_Y: (np.float64, 1), F_TARGET_X: (np.float64, 1), F_TARGET_Y: (np.float64, 1),
     F_STEP_COUNT: (np.int32, 1), F_CUR_TARGET: (np.int32, 1), F_LAST_REWARD: (np.float64, 1),
     F_EP_RETURN: (np.float64, 1), F_EP_LENGTH: (np.int32, 1), F_TARGET2_X: (np.float64, 1), F_TARGET2_Y: (np.float64, 1),
+    F_LAST_RETURN: (np.float64, 1), F_LAST_LENGTH: (np.int32, 1), F_N_FINISHED: (np.int32, 1),
     F_KUKA_Q: (np.float64, 7), F_KUKA_QD: (np.float64, 7), F_KUKA_EE_TARGET: (np.float64, 3),
     F_KUKA_BUTTON_Q: (np.float64, 2), F_KUKA_BUTTON_POS: (np.float64, 3), F_KUKA_GRIPPER: (np.float64, 3),
     F_KUKA_COUNTERS: (np.int32, 3), F_KUKA_BUTTON_XY: (np.float64, 2), F_KUKA_BUTTON2_Q: (np.float64, 2),
@@ -34,7 +36,7 @@ EXPORTS = [
     "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
-    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
+    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
@@ -95,6 +97,7 @@ def load():
     lib.srlhip_set_state.argtypes = [vp, i32, vp]
     lib.srlhip_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
     lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_episode_stats_device.argtypes = [vp, vp, vp, vp]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -266,6 +269,12 @@ class Handle(object):
             out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
         return out
+
+    def episode_stats_device(self, last_return=0, last_length=0, n_finished=0):
+        """Enqueue-only: float32 returns / int32 lengths / counts of the last finished episodes into DEVICE buffers
+        (raw pointers, 0 = skip) on the handle's stream."""
+        self._check(self._lib.srlhip_episode_stats_device(self._h, last_return or None, last_length or None, n_finished or None),
+                    "srlhip_episode_stats_device")
 
     def episode_stats(self):
         n = self.num_envs

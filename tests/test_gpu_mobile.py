@@ -249,3 +249,43 @@ def test_device_io_mode_with_torch_buffers():
     assert np.array_equal(act.cpu().numpy(), ora["actions"])
     assert np.array_equal(rew.cpu().numpy(), ora["reward"])
     h.close()
+
+
+@pytest.mark.parametrize("T", [200, 400, 2200])
+def test_episode_parallel_rollout_beyond_resident_lanes(T):
+    """2^20 envs: the episode-parallel rollout launches up to 10 M lanes, far more than can be resident at once, so
+    later segment lanes of an env start after the lane that stores the env's final state has retired.  The kernel reads
+    the per-env state from a snapshot taken right before the launch; results have to equal the sequential kernel
+    (chunks shorter than 32 steps) bit for bit: reward / done planes, state, RNG counters, episode statistics."""
+    import torch
+    n, chunk = 1 << 20, 25
+    dev = torch.device("cuda", 0)
+    hs = []
+    for _ in range(2):
+        cfg = _lib.default_config(_lib.ENV_MOBILE)
+        cfg.num_envs, cfg.seed0, cfg.rng_mode, cfg.auto_reset, cfg.io_device = n, 5, _lib.RNG_PHILOX, 1, 1
+        hs.append(_lib.Handle(cfg))
+    a, b = hs
+    planes = []
+    for h in hs:
+        h.reset(obs_out=0)
+        h.rollout(70, out=(0, 0, 0, 0))                      # desynchronise from step 0 (counter 70)
+        planes.append((torch.zeros((T, n), dtype=torch.float32, device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)))
+    a.rollout(T, out=(0, planes[0][0].data_ptr(), planes[0][1].data_ptr(), 0))
+    t = 0
+    while t < T:
+        c = min(chunk, T - t)
+        b.rollout(c, out=(0, planes[1][0][t].data_ptr(), planes[1][1][t].data_ptr(), 0))
+        t += c
+    a.sync(); b.sync()
+    assert torch.equal(planes[0][0], planes[1][0]) and torch.equal(planes[0][1], planes[1][1])
+    assert int(planes[0][1].sum()) >= n * ((T + 70) // 251)
+    for f in (_lib.F_POS_X, _lib.F_POS_Y, _lib.F_STEP_COUNT, _lib.F_LAST_REWARD, _lib.F_EP_RETURN, _lib.F_EP_LENGTH,
+              _lib.F_LAST_RETURN, _lib.F_LAST_LENGTH, _lib.F_N_FINISHED):
+        assert np.array_equal(a.get_state(f), b.get_state(f)), f
+    # the streams continue identically (RNG and action counters)
+    a.rollout(40, out=(0, planes[0][0].data_ptr(), 0, 0)); b.rollout(20, out=(0, planes[1][0].data_ptr(), 0, 0))
+    b.rollout(20, out=(0, planes[1][0][20].data_ptr(), 0, 0))
+    a.sync(); b.sync()
+    assert torch.equal(planes[0][0][:40], planes[1][0][:40])
+    a.close(); b.close()
