@@ -115,66 +115,91 @@ struct HostDraws {
     SRL_HD uint32_t bounded(uint32_t) { return (uint32_t)v[i++]; }
 };
 
-// KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.
+// Everything KukaButtonGymEnv.reset draws from the env's RNG, in the reference's order (kuka_button_gym_env.py:214-255 and
+// the variants' overrides), turned into what the state assembly needs.  Shared by the lane-per-env and the lane-group kernels.
+struct ResetDraw {
+    double bx, by, speed, b2x, b2y;
+    int idx;                        // row of the start-state table (Cartesian action modes)
+    double g[kNInitActions];        // joints mode: 7 + N(0,1) of each init action
+};
 template <int NB, class R>
-SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const double *starts, const double *settled) {
+SRL_HD void reset_draw(const Cfg &cfg, double *objs, int64_t objs_stride, R &rng, ResetDraw &d) {
 #pragma clang fp contract(off)   // wrapper arithmetic is numpy's: unfused (physics_step keeps the file's setting)
-    double bx = kButtonX, by = kButtonY, speed = 0.0, b2x = kButtonX, b2y = kButton2Y2B;
-    if (cfg.moving) speed = 0.001 * (rng.bounded(1) ? 1.0 : -1.0);   // BUTTON_SPEED * np_random.choice([-1, 1]), drawn first
+    d.bx = kButtonX; d.by = kButtonY; d.speed = 0.0; d.b2x = kButtonX; d.b2y = kButton2Y2B; d.idx = 0;
+    if (cfg.moving) d.speed = 0.001 * (rng.bounded(1) ? 1.0 : -1.0);   // BUTTON_SPEED * np_random.choice([-1, 1]), drawn first
     if constexpr (NB == 2) {                                          // kuka_2button_gym_env.py:55-70
         if (cfg.random_target) { (void)rng.uniform(-1, 1); (void)rng.uniform(0, 1); }   // overwritten two lines later
-        bx = 0.5 + 0.0 * rng.uniform(-1, 1); by = kButton1Y2B + 0.0 * rng.uniform(-1, 1);
-        if (cfg.random_target) { b2x += 0.15 * rng.uniform(-1, 1); b2y += 0.175 * rng.uniform(-1, 0); }
-    } else if (cfg.random_target) { bx += 0.15 * rng.uniform(-1, 1); by += 0.3 * rng.uniform(-1, 1); }
+        d.bx = 0.5 + 0.0 * rng.uniform(-1, 1); d.by = kButton1Y2B + 0.0 * rng.uniform(-1, 1);
+        if (cfg.random_target) { d.b2x += 0.15 * rng.uniform(-1, 1); d.b2y += 0.175 * rng.uniform(-1, 0); }
+    } else if (cfg.random_target) { d.bx += 0.15 * rng.uniform(-1, 1); d.by += 0.3 * rng.uniform(-1, 1); }
     if (cfg.rand_objects) {                                           // kuka_rand_button_gym_env.py:62-69: two draws per candidate
         for (int i = 0; i < 10; i++) {
             const double ox = 0.5 + 0.15 * rng.uniform(-1, 1), oy = 0 + 0.3 * rng.uniform(-1, 1);
-            const bool keep = (ox < bx - 0.1) || (ox > bx + 0.1) || (oy < by - 0.1) || (oy > by + 0.1);
-            if (sc.objs) { sc.objs[(3 * i) * sc.gst] = ox; sc.objs[(3 * i + 1) * sc.gst] = oy; sc.objs[(3 * i + 2) * sc.gst] = keep ? 1.0 : 0.0; }
+            const bool keep = (ox < d.bx - 0.1) || (ox > d.bx + 0.1) || (oy < d.by - 0.1) || (oy > d.by + 0.1);
+            if (objs) { objs[(3 * i) * objs_stride] = ox; objs[(3 * i + 1) * objs_stride] = oy; objs[(3 * i + 2) * objs_stride] = keep ? 1.0 : 0.0; }
         }
     }
-    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     if (!cfg.is_discrete && cfg.action_joints) {
-        unpack_start(e, settled);
-        e.bx = bx; e.by = by; e.bz = kButtonBaseZ;
-        if constexpr (NB == 2) { e.b2x = b2x; e.b2y = b2y; e.b2q = e.bq; e.b2qd = e.bqd; }
         // np_random.normal(joints.shape): the shape tuple is `loc` -> one draw 7 + N(0,1) per init action,
         // broadcast over the joints.  All five are drawn before the physics steps.
-        double g[kNInitActions];
-        for (int k = 0; k < kNInitActions; k++) g[k] = rng.normal(7.0, 1.0);
-        // (arrays handed to physics_step live outside the loop: per-iteration locals next to the inlined step have been
-        //  seen to be mis-coloured onto live state by the gfx950 backend, DESIGN.md §Kuka kernel, compiler notes)
-        double joints[ND], motor[3] = {0, 0, 0};
-        for (int k = 0; k < kNInitActions; k++) {
-#pragma unroll
-            for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * g[k];
-            physics_step<NB>(e, cfg, sc, motor, true, joints);
-        }
+        for (int k = 0; k < kNInitActions; k++) d.g[k] = rng.normal(7.0, 1.0);
     } else {
-        int idx = 0, mul = 1;
+        int mul = 1;
         for (int k = 0; k < kNInitActions; k++) {
             int code;
             if (cfg.is_discrete) {
                 const int sign_bit = rng.double01() > 0.5 ? 1 : 0;
                 const int axis = (int)rng.bounded(2);
                 code = sign_bit * 3 + axis;
-                idx += code * mul; mul *= 6;
+                d.idx += code * mul; mul *= 6;
             } else {
                 // np_random.normal((3,)) -> one draw 3 + N(0,1); L2-normalised 1-vector = +-1, broadcast
                 const double g = rng.normal(3.0, 1.0);
                 code = (g / sqrt(fma(g, g, 0.0))) > 0 ? 1 : 0;
-                idx += code * mul; mul *= 2;
+                d.idx += code * mul; mul *= 2;
             }
         }
-        unpack_start(e, starts + (int64_t)idx * kStartDoubles);
-        e.bx = bx; e.by = by;
-        if constexpr (NB == 2) { e.b2x = b2x; e.b2y = b2y; e.b2q = e.bq; e.b2qd = e.bqd; }   // same urdf, same free steps
     }
-    e.bz = kButtonBaseZ; e.bspeed = speed;
-    e.bpos[0] = bx; e.bpos[1] = by;
+}
+// scalar part of the state after reset (everything but the arm / glider state, which comes from the start table or from
+// the five joint-mode init steps)
+template <int NB>
+SRL_HD void reset_finish(Env &e, const ResetDraw &d) {
+#pragma clang fp contract(off)
+    e.bx = d.bx; e.by = d.by;
+    if constexpr (NB == 2) { e.b2x = d.b2x; e.b2y = d.b2y; }
+    e.bz = kButtonBaseZ; e.bspeed = d.speed;
+    e.bpos[0] = d.bx; e.bpos[1] = d.by;
     e.bpos[2] = kButtonBaseZ + kGliderOriginZ + e.bq + kButtonDistanceHeight;
     if constexpr (NB == 2) { e.bpos[2] = kZTable + kButtonDistanceHeight; e.goal_id = 0; e.n_contacts2 = 0; e.contact_body1 = 0; e.contact_body2 = 0; }
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+}
+
+// KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.
+template <int NB, class R>
+SRL_HD void reset_env(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, const double *starts, const double *settled) {
+#pragma clang fp contract(off)   // wrapper arithmetic is numpy's: unfused (physics_step keeps the file's setting)
+    ResetDraw d;
+    reset_draw<NB>(cfg, sc.objs, sc.gst, rng, d);
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    if (!cfg.is_discrete && cfg.action_joints) {
+        unpack_start(e, settled);
+        e.bx = d.bx; e.by = d.by; e.bz = kButtonBaseZ;
+        if constexpr (NB == 2) { e.b2x = d.b2x; e.b2y = d.b2y; e.b2q = e.bq; e.b2qd = e.bqd; }
+        // (arrays handed to physics_step live outside the loop: per-iteration locals next to the inlined step have been
+        //  seen to be mis-coloured onto live state by the gfx950 backend, DESIGN.md §Kuka kernel, compiler notes)
+        double joints[ND], motor[3] = {0, 0, 0};
+        for (int k = 0; k < kNInitActions; k++) {
+#pragma unroll
+            for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j] + kDeltaTheta * d.g[k];
+            physics_step<NB>(e, cfg, sc, motor, true, joints);
+        }
+    } else {
+        unpack_start(e, starts + (int64_t)d.idx * kStartDoubles);
+        e.bx = d.bx; e.by = d.by;
+        if constexpr (NB == 2) { e.b2x = d.b2x; e.b2y = d.b2y; e.b2q = e.bq; e.b2qd = e.bqd; }   // same urdf, same free steps
+    }
+    reset_finish<NB>(e, d);
 }
 
 SRL_HD void observe(const Env &e, const Cfg &cfg, float *o, int64_t stride) {   // getSRLState
@@ -185,40 +210,53 @@ SRL_HD void observe(const Env &e, const Cfg &cfg, float *o, int64_t stride) {   
         for (int j = 0; j < 14; j++) o[(k++) * stride] = (float)kJointPositions[j];
 }
 
-// KukaButtonGymEnv.step + step2.  action < 0 == None.  Returns the reward; *done = _termination().
-template <int NB, class R>
-SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int action, const float *ca, bool *done) {
+// First half of KukaButtonGymEnv.step (:293-340): the moving-button update, the noise draw and the action mapping.
+// Cartesian modes fill motor[3]; joints mode returns the noisy scale `dth` (targets = a_j * dth + q0_j, built by the
+// caller); action < 0 == None (no RNG draw, :295-299).  Shared by the lane-per-env and the lane-group kernels.
+struct StepCmd { double motor[3]; double dth; bool joint_mode; bool scaled_joints; };
+template <class R>
+SRL_HD void step_command(Env &e, const Cfg &cfg, R &rng, int action, const float *ca3, StepCmd &c) {
 #pragma clang fp contract(off)
-    double motor[3] = {0, 0, 0}, joints[ND];
-    bool joint_mode = false;
+    c.motor[0] = 0; c.motor[1] = 0; c.motor[2] = 0; c.dth = 0; c.joint_mode = false; c.scaled_joints = false;
     if (cfg.moving) {                                            // kuka_moving_button_gym_env.py:111-119
         if (e.bpos[1] > 0.3 || e.bpos[1] < -0.3) e.bspeed = -e.bspeed;
         e.bpos[1] += e.bspeed;
         e.by = e.bpos[1];
         e.bz = e.bpos[2] - kButtonDistanceHeight;                // base re-placed at the recorded cap height
     }
-#pragma unroll
-    for (int j = 0; j < ND; j++) joints[j] = kJointPositions[j];
     if (action < 0) {
-        joint_mode = cfg.action_joints != 0;
+        c.joint_mode = cfg.action_joints != 0;
     } else if (cfg.is_discrete) {
         const double dv = kDeltaV + rng.normal(0.0, kNoiseStd);
-        if (action == 0) motor[0] = -dv; else if (action == 1) motor[0] = dv;
-        else if (action == 2) motor[1] = -dv; else if (action == 3) motor[1] = dv;
-        else if (action == 4) motor[2] = -dv; else if (action == 5) motor[2] = cfg.force_down ? -dv : dv;
+        if (action == 0) c.motor[0] = -dv; else if (action == 1) c.motor[0] = dv;
+        else if (action == 2) c.motor[1] = -dv; else if (action == 3) c.motor[1] = dv;
+        else if (action == 4) c.motor[2] = -dv; else if (action == 5) c.motor[2] = cfg.force_down ? -dv : dv;
     } else if (cfg.action_joints) {
-        const double dth = kDeltaTheta + rng.normal(0.0, kNoiseStdJoints);
-        joint_mode = true;
-#pragma unroll
-        for (int j = 0; j < ND; j++) joints[j] = (double)(ca[j] * (float)dth) + kJointPositions[j];
+        c.dth = kDeltaTheta + rng.normal(0.0, kNoiseStdJoints);
+        c.joint_mode = true; c.scaled_joints = true;
     } else {
         const double dv = kDeltaVContinuous + rng.normal(0.0, kNoiseStdContinuous);
-        motor[0] = (double)ca[0] * dv; motor[1] = (double)ca[1] * dv;
-        motor[2] = cfg.force_down ? -fabs((double)ca[2] * dv) : (double)ca[2] * dv;
+        c.motor[0] = (double)ca3[0] * dv; c.motor[1] = (double)ca3[1] * dv;
+        c.motor[2] = cfg.force_down ? -fabs((double)ca3[2] * dv) : (double)ca3[2] * dv;
     }
     e.motor_on = 1;
+}
+// joint target of joint j in joints mode: float32 action * python float stays float32, + float64 list -> float64
+SRL_HD double joint_target(const StepCmd &c, float a, double q0) {
+#pragma clang fp contract(off)
+    return c.scaled_joints ? (double)(a * (float)c.dth) + q0 : q0;
+}
+
+// KukaButtonGymEnv.step + step2.  action < 0 == None.  Returns the reward; *done = _termination().
+template <int NB, class R>
+SRL_HD double env_step(Env &e, const Cfg &cfg, const Scratch &sc, R &rng, int action, const float *ca, bool *done) {
+    StepCmd c;
+    step_command(e, cfg, rng, action, ca, c);
+    double joints[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) joints[j] = joint_target(c, ca[j], kJointPositions[j]);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        physics_step<NB>(e, cfg, sc, motor, joint_mode, joints);
+        physics_step<NB>(e, cfg, sc, c.motor, c.joint_mode, joints);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

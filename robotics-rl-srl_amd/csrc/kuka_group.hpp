@@ -1,0 +1,735 @@
+// kuka_group.hpp — lane-GROUP formulation of the KukaButtonGymEnv physics step for gfx950: 16 lanes (one DPP row of a
+// wavefront) integrate ONE env, so a 4096-env batch launches 1024 wavefronts (one per SIMD of the MI355X) instead of the
+// 64 of the lane-per-env kernel (kuka_core.hpp), and the sequential part of a step shrinks from ~17 000 to ~5 000
+// instructions per wavefront.  Same model, same row semantics, same env wrapper (kuka_env.hpp) as the lane-per-env kernel
+// — only the decomposition differs:
+//
+//   lane l < 7 owns joint / link l (q, qd, sin/cos, world frame, spatial axis, inertia, row l of M^-1, arm-motor row l);
+//   lanes 8, 9, 10 own the button's scalar rows (motor, lower stop, upper stop); lanes 7, 11..15 the <= 6 generic rows
+//   (arm joint limits, gripper-sphere contacts) — one constraint row per lane.
+//
+//   * kinematics: the seven joint transforms are composed by a 3-level parallel prefix (row_shr DPP), so every lane
+//     gets its own link's world frame in 3 compositions instead of 7;
+//   * dynamics in WORLD coordinates about the world origin, where the recursions of RNEA / CRBA are plain prefix /
+//     suffix sums over the chain: link velocities and bias accelerations (prefix), link forces and composite inertias
+//     (suffix) are masked row-broadcast FMAs (v_fmac_f64_dpp row_newbcast — the only DPP control gfx950 has for 64-bit
+//     operands); M (CRBA) is inverted in place by a lane-parallel Gauss-Jordan sweep (row i on lane i);
+//   * IK: Jacobian column per lane, J^T J by broadcast FMAs, the 7x7 SPD solve by the same Gauss-Jordan scheme;
+//   * projected Gauss-Seidel in impulse space with one row per lane, every row rescaled to u = (lambda - lo) / (hi - lo)
+//     in [0, 1] so that the projection is the hardware clamp modifier of the add that forms the row's residual:
+//     a row update is  t = clamp01(cs + acc);  acc -= e_prev * acc;  acc += n_j * bcast_j(t)  — three instructions,
+//     the "wavefront-level reduction for contact resolution" of the north star done as broadcast-accumulate.
+//
+// Numerics: float64 like the reference; the association order of sums differs from kuka_core.hpp / the oracle
+// (parallel prefix instead of chain walks, Gauss-Jordan instead of LDL^T / ABA), so results agree to ~1e-11, not bit
+// for bit — the north-star bar is 1e-4 on joints and bit-exact discrete flags, which the parity tests check.
+//
+// The same source is compiled for the host by the CPU-side parity harness (csrc/kuka_hostcheck.cpp, tests only): there
+// the 16 lanes of a group are 16 cooperatively scheduled fibers and the cross-lane primitives below go through a small
+// exchange runtime.
+#pragma once
+#include "kuka_env.hpp"
+
+#ifndef SRL_GDBG          // host-side instrumentation of the test harness only (kuka_hostcheck.cpp)
+#define SRL_GDBG(tag, idx, val)
+#endif
+
+namespace srl {
+namespace kuka {
+namespace grp {
+
+constexpr int GL = 16;                 // lanes per env = one DPP row
+constexpr int kBM = 8, kBLo = 9, kBHi = 10;                       // lanes of the button's scalar rows
+constexpr int kGenLane[kMaxGenRows] = {7, 11, 12, 13, 14, 15};    // lanes of the generic rows, in creation order
+// per-group scratch for the (rare) generic-row setup: [row][12] definitions + [row][7] W J
+constexpr int kRowDef = 12, kScratchDoubles = kMaxGenRows * (kRowDef + ND);
+
+// ------------------------------------------------------------------ cross-lane primitives
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SRL_G __device__ __forceinline__
+SRL_G int lane_id() { return (int)(threadIdx.x & (GL - 1)); }
+template <int J> SRL_G double bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false); }   // row_newbcast:J
+template <int D> SRL_G double shr(double x, double fill) {                                                                 // row_shr:D
+    const long long v = __double_as_longlong(x), f = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)v, 0x110 + D, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(v >> 32), 0x110 + D, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+SRL_G uint32_t ballot(bool p) { return (uint32_t)(__ballot(p) >> (threadIdx.x & 48)) & 0xffffu; }
+SRL_G bool gany(bool p) { return ballot(p) != 0; }
+SRL_G bool wany(bool p) { return __any(p); }
+SRL_G double shfl(double x, int src) { return __shfl(x, src, GL); }
+SRL_G void sync_scratch() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+SRL_G double rcp(double x) {          // ~1 ulp reciprocal: v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+// acc += w * bcast<J>(x) in one v_fmac_f64_dpp.  The caller guarantees that x was not written by the instruction right
+// before (VALU write -> DPP read needs two wait states); `s_nop 1` covers it when it cannot.
+template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
+}
+SRL_G double clamp01_add(double a, double b) {
+    double t;
+    asm volatile("v_add_f64 %0, %1, %2 clamp" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+// one projected Gauss-Seidel row update (see the file header): acc -= ep * acc; acc += n * bcast<J>(t).
+// The reset FMA and one s_nop sit between the instruction that produced t and the DPP read of t (two wait states).
+template <int J> SRL_G void pgs_row(double &acc, double t, double n, double ep) {
+    asm volatile("v_fma_f64 %0, -%3, %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(t), "v"(n), "v"(ep), "n"(J));
+}
+template <int J, int J2> SRL_G void pgs_row2(double &acc, double t, double n, double n2, double ep) {     // two decoupled rows at once
+    asm volatile("v_fma_f64 %0, -%4, %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(t), "v"(n), "v"(n2), "v"(ep), "n"(J), "n"(J2));
+}
+#else
+#define SRL_G inline
+// host emulation runtime (csrc/kuka_hostcheck.cpp): the calling fiber's lane, a lockstep value exchange, a group vote
+int host_lane();
+double host_exchange(double x, int src);
+uint32_t host_ballot(bool p);
+SRL_G int lane_id() { return host_lane(); }
+template <int J> SRL_G double bcast(double x) { return host_exchange(x, J); }
+template <int D> SRL_G double shr(double x, double fill) {
+    const int l = host_lane();
+    const double v = host_exchange(x, l >= D ? l - D : l);
+    return l >= D ? v : fill;
+}
+SRL_G uint32_t ballot(bool p) { return host_ballot(p); }
+SRL_G bool gany(bool p) { return host_ballot(p) != 0; }
+SRL_G bool wany(bool p) { return host_ballot(p) != 0; }
+SRL_G double shfl(double x, int src) { return host_exchange(x, src); }
+SRL_G void sync_scratch() { (void)host_ballot(false); }
+SRL_G double rcp(double x) { return 1.0 / x; }
+template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) { acc = fma(host_exchange(x, J), w, acc); }
+SRL_G double clamp01_add(double a, double b) { const double s = a + b; return s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s); }
+template <int J> SRL_G void pgs_row(double &acc, double t, double n, double ep) {
+    acc = fma(-ep, acc, acc);
+    acc = fma(host_exchange(t, J), n, acc);
+}
+template <int J, int J2> SRL_G void pgs_row2(double &acc, double t, double n, double n2, double ep) {
+    acc = fma(-ep, acc, acc);
+    const double a = host_exchange(t, J), b = host_exchange(t, J2);
+    acc = fma(a, n, acc);
+    acc = fma(b, n2, acc);
+}
+#endif
+
+// ------------------------------------------------------------------ per-lane constants
+struct Lane {
+    int l;
+    bool arm;                 // l < 7: owns a joint / link
+    double am;                // 1.0 on arm lanes
+    double e[GL];             // e[j] = (l == j)
+    double le[ND];            // le[k] = (k <= l)   prefix masks over the chain
+    double ge[ND];            // ge[k] = (k >= l)   suffix masks (0 on non-arm lanes)
+    double mass, mcomp;       // link mass, composite mass of links l..6
+    double com[3], in[3];     // centre of mass and principal inertia in the link frame
+    double len;               // joint origin translation along the parent's y (axis 1) or z (axis 2)
+    int fix, axis;
+    double jlo, jhi, q0;      // joint limits, kJointPositions[l]
+    double sph[4];            // l < 6: gripper sphere l (centre in the link-7 frame, radius)
+};
+
+SRL_G void lane_init(Lane &L) {
+    const int l = lane_id();
+    L.l = l; L.arm = l < ND; L.am = L.arm ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < GL; j++) L.e[j] = l == j ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < ND; k++) { L.le[k] = k <= l ? 1.0 : 0.0; L.ge[k] = (k >= l && L.arm) ? 1.0 : 0.0; }
+    const int i = L.arm ? l : 0;
+    double mc = 0.0;
+#pragma unroll
+    for (int k = 0; k < ND; k++) mc += k >= l ? kMass[k] : 0.0;
+    L.mass = L.arm ? kMass[i] : 0.0; L.mcomp = L.arm ? mc : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.com[k] = kCom[i][k]; L.in[k] = L.arm ? kInertia[i][k] : 0.0; }
+    L.len = L.arm ? kTransLen[i] : 0.0; L.fix = kFix[i]; L.axis = kTransAxis[i];
+    L.jlo = kJointLower[i]; L.jhi = kJointUpper[i]; L.q0 = kJointPositions[i];
+    const int s = l < kNSphere ? l : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) L.sph[k] = kSphere[s][k];
+}
+
+// ------------------------------------------------------------------ per-lane dynamic state kept across steps
+struct GState {
+    double q, qd, sq, cq;      // own joint (arm lanes; 0 / 0 / 0 / 1 elsewhere)
+    double R[9], p[3];         // world frame of the own link (columns x y z; lanes >= 7: unused)
+    double Rt[9], pt[3];       // world frame of link 7, replicated
+};
+
+SRL_G void compose(const double Ra[9], const double pa[3], const double Rb[9], const double pb[3], double Ro[9], double po[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Ro[3 * j + k] = Ra[k] * Rb[3 * j] + Ra[3 + k] * Rb[3 * j + 1] + Ra[6 + k] * Rb[3 * j + 2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) po[k] = pa[k] + Ra[k] * pb[0] + Ra[3 + k] * pb[1] + Ra[6 + k] * pb[2];
+}
+
+// Forward kinematics of the whole chain: local joint transform per lane, inclusive prefix composition over the row.
+SRL_G void gfk(const Lane &L, GState &g) {
+    const double s = g.sq, c = g.cq;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    if (L.arm) {
+        // columns of the joint frame in the parent link's frame: fixed signed permutation (URDF rpy) times Rz(q)
+        if (L.fix == 0) { R[0] = c; R[1] = s; R[2] = 0; R[3] = -s; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1; }
+        else if (L.fix == 1) { R[0] = -c; R[1] = 0; R[2] = s; R[3] = s; R[4] = 0; R[5] = c; R[6] = 0; R[7] = 1; R[8] = 0; }
+        else { R[0] = c; R[1] = 0; R[2] = s; R[3] = -s; R[4] = 0; R[5] = c; R[6] = 0; R[7] = -1; R[8] = 0; }
+        if (L.axis == 2) p[2] = L.len; else p[1] = L.len;
+        if (L.l == 0) { p[0] += kBasePos[0]; p[1] += kBasePos[1]; p[2] += kBasePos[2]; }
+    }
+#define SRL_SCAN(D)                                                                              \
+    {                                                                                            \
+        double Ra[9], pa[3], Ro[9], po[3];                                                       \
+        _Pragma("unroll") for (int k = 0; k < 9; k++) Ra[k] = shr<D>(R[k], (k % 4 == 0) ? 1.0 : 0.0); \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) pa[k] = shr<D>(p[k], 0.0);                 \
+        compose(Ra, pa, R, p, Ro, po);                                                           \
+        _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Ro[k];                              \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = po[k];                              \
+    }
+    SRL_SCAN(1) SRL_SCAN(2) SRL_SCAN(4)
+#undef SRL_SCAN
+#pragma unroll
+    for (int k = 0; k < 9; k++) { g.R[k] = R[k]; g.Rt[k] = bcast<ND - 1>(R[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { g.p[k] = p[k]; g.pt[k] = bcast<ND - 1>(p[k]); }
+}
+
+// sin/cos of the own joint, frames, gripper position (what update_trig_and_gripper() does for the lane-per-env kernel)
+SRL_G void grefresh(const Lane &L, GState &g, Env &e) {
+    if (L.arm) sincos(g.q, &g.sq, &g.cq); else { g.sq = 0.0; g.cq = 1.0; }
+    gfk(L, g);
+    tip_point(g.Rt, g.pt, kGripperPoint, e.grip);
+}
+
+// prefix / suffix sums over the chain by masked row broadcasts: out = base + sum_k m[k] * bcast_k(x)
+template <int K> SRL_G void masked_sum_step(double &acc, double x, const double m[ND]) {
+    fmac_bcast<K>(acc, x, m[K]);
+    if constexpr (K + 1 < ND) masked_sum_step<K + 1>(acc, x, m);
+}
+SRL_G double masked_sum(double x, const double m[ND], double base = 0.0) {
+    double acc = base;
+    masked_sum_step<0>(acc, x, m);
+    return acc;
+}
+
+// In-place Gauss-Jordan on the rows of a 7x7 SPD matrix held one row per lane (lanes >= 7 carry zero rows).
+// INV = true: A <- A^-1.  INV = false: A x = b, solution left in b (columns <= the pivot are not maintained).
+template <int K, bool INV> SRL_G void gj_step(const Lane &L, double A[ND], double &b) {
+    const double r = rcp(bcast<K>(A[K]));
+    const double g = -((A[K] - L.e[K]) * r);          // lane K: -(1 - 1/pivot): its row ends up scaled by 1/pivot
+    if constexpr (INV) {
+        A[K] = L.e[K];                                  // the identity's column K takes the place of column K
+#pragma unroll
+        for (int c = 0; c < ND; c++) fmac_bcast<K>(A[c], A[c], g);
+    } else {
+#pragma unroll
+        for (int c = K + 1; c < ND; c++) fmac_bcast<K>(A[c], A[c], g);
+        fmac_bcast<K>(b, b, g);
+    }
+    if constexpr (K + 1 < ND) gj_step<K + 1, INV>(L, A, b);
+}
+
+template <int K> SRL_G void row_dot_step(double &acc, const double row[ND], double x) {
+    fmac_bcast<K>(acc, x, row[K]);
+    if constexpr (K + 1 < ND) row_dot_step<K + 1>(acc, row, x);
+}
+// sum_k row[k] * x_k with x_k living on lane k
+SRL_G double row_dot(const double row[ND], double x) { double acc = 0.0; row_dot_step<0>(acc, row, x); return acc; }
+
+template <int K> SRL_G void bcast_all_step(double x, double out[ND]) {
+    out[K] = bcast<K>(x);
+    if constexpr (K + 1 < ND) bcast_all_step<K + 1>(x, out);
+}
+
+template <int K> SRL_G void gram_step(const double J[6], double A[ND]) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) fmac_bcast<K>(a, J[c], J[c]);
+    A[K] = a;
+    if constexpr (K + 1 < ND) gram_step<K + 1>(J, A);
+}
+
+template <int K> SRL_G void transpose_upper_step(const Lane &L, const double low[ND], double M[ND]) {
+    // M[k] for k > l comes from lane k's low[l]: every lane j < K picks lane K's low[j]
+#pragma unroll
+    for (int j = 0; j < K; j++) fmac_bcast<K>(M[K], low[j], L.e[j]);
+    if constexpr (K + 1 < ND) transpose_upper_step<K + 1>(L, low, M);
+}
+
+// ------------------------------------------------------------------ PGS sweeps
+struct Rows {
+    double acc0;               // the couplings to rows that come LATER in the first sweep, at their initial impulse 0
+    double cs;                 // scaled constant term of the own row
+    double n[GL];              // scaled couplings -a_rk S_k / (a_rr S_r), n[own] = 0
+    double a[GL];              // unscaled row of A = J W J^T (arm lanes: what the velocity update needs)
+    double lo, S;              // lambda = lo + S u
+    double jb;                 // the row's Jacobian entry on the button glider
+};
+
+// fast path: no generic row in the wavefront.  The button's three scalar rows (lanes 8, 9, 10) are decoupled from the
+// arm rows, so arm row j and button row 8 + j are updated by the same instructions for j < 3.
+SRL_G double pgs_sweeps_free(const Lane &L, const Rows &r) {
+    double acc = r.acc0, t = 0.0, u = 0.0;
+    const double e0 = L.e[0] + L.e[kBM], e1 = L.e[1] + L.e[kBLo], e2 = L.e[2] + L.e[kBHi];
+    double ep = 0.0;       // mask of the row whose accumulator is reset next (the row updated last)
+#define SRL_SWEEP(LASTSWEEP)                                                                     \
+    t = clamp01_add(r.cs, acc); pgs_row2<0, kBM>(acc, t, r.n[0], r.n[kBM], ep);   if (LASTSWEEP) u = fma(e0, t, u);      \
+    t = clamp01_add(r.cs, acc); pgs_row2<1, kBLo>(acc, t, r.n[1], r.n[kBLo], e0); if (LASTSWEEP) u = fma(e1, t, u);      \
+    t = clamp01_add(r.cs, acc); pgs_row2<2, kBHi>(acc, t, r.n[2], r.n[kBHi], e1); if (LASTSWEEP) u = fma(e2, t, u);      \
+    t = clamp01_add(r.cs, acc); pgs_row<3>(acc, t, r.n[3], e2);                   if (LASTSWEEP) u = fma(L.e[3], t, u);  \
+    t = clamp01_add(r.cs, acc); pgs_row<4>(acc, t, r.n[4], L.e[3]);               if (LASTSWEEP) u = fma(L.e[4], t, u);  \
+    t = clamp01_add(r.cs, acc); pgs_row<5>(acc, t, r.n[5], L.e[4]);               if (LASTSWEEP) u = fma(L.e[5], t, u);  \
+    t = clamp01_add(r.cs, acc); pgs_row<6>(acc, t, r.n[6], L.e[5]);               if (LASTSWEEP) u = fma(L.e[6], t, u);  \
+    ep = L.e[6];
+    for (int it = 0; it < kSolverIters - 1; it++) { SRL_SWEEP(false) }
+    SRL_SWEEP(true)
+#undef SRL_SWEEP
+    return u;
+}
+
+template <int G> SRL_G void pgs_generic_phase(const Lane &L, const Rows &r, double &acc, double &t, double &u, double &ep, uint32_t wave_slots,
+                                              double act, bool last) {
+    if (wave_slots & (1u << G)) {            // wave-uniform: some env of this wavefront has a row in slot G
+        constexpr int J = kGenLane[G];
+        t = clamp01_add(r.cs, acc) * act;    // rows that do not belong to this phase broadcast nothing ...
+        pgs_row<J>(acc, t, r.n[J], ep);
+        ep = L.e[J] * act;                   // ... and keep their accumulator
+        if (last) u = fma(ep, t, u);
+    }
+    if constexpr (G + 1 < kMaxGenRows) pgs_generic_phase<G + 1>(L, r, acc, t, u, ep, wave_slots, act, last);
+}
+
+// general path: arm motors, button motor, [arm joint limits], button stops, [contacts] — Bullet's row order.
+// wave_slots: bit g = some env of the wavefront uses generic slot g; nlim = joint-limit rows of THIS env (they fill
+// the first slots); has_lim: some env of the wavefront has a joint-limit row.
+SRL_G double pgs_sweeps_general(const Lane &L, const Rows &r, uint32_t wave_slots, int nlim, bool has_lim) {
+    double acc = r.acc0, t = 0.0, u = 0.0, ep = 0.0;
+    // a generic row takes part in the limit phase iff its slot index < nlim, else in the contact phase
+    int slot = -1;
+#pragma unroll
+    for (int g = 0; g < kMaxGenRows; g++) if (L.l == kGenLane[g]) slot = g;
+    const double in_lim = (slot >= 0 && slot < nlim) ? 1.0 : 0.0, in_con = (slot >= 0 && slot >= nlim) ? 1.0 : 0.0;
+    for (int it = 0; it < kSolverIters; it++) {
+        const bool last = it == kSolverIters - 1;
+        t = clamp01_add(r.cs, acc); pgs_row<0>(acc, t, r.n[0], ep);     if (last) u = fma(L.e[0], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<1>(acc, t, r.n[1], L.e[0]); if (last) u = fma(L.e[1], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<2>(acc, t, r.n[2], L.e[1]); if (last) u = fma(L.e[2], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<3>(acc, t, r.n[3], L.e[2]); if (last) u = fma(L.e[3], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<4>(acc, t, r.n[4], L.e[3]); if (last) u = fma(L.e[4], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<5>(acc, t, r.n[5], L.e[4]); if (last) u = fma(L.e[5], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<6>(acc, t, r.n[6], L.e[5]); if (last) u = fma(L.e[6], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<kBM>(acc, t, r.n[kBM], L.e[6]); if (last) u = fma(L.e[kBM], t, u);
+        ep = L.e[kBM];
+        if (has_lim) pgs_generic_phase<0>(L, r, acc, t, u, ep, wave_slots, in_lim, last);
+        t = clamp01_add(r.cs, acc); pgs_row<kBLo>(acc, t, r.n[kBLo], ep);       if (last) u = fma(L.e[kBLo], t, u);
+        t = clamp01_add(r.cs, acc); pgs_row<kBHi>(acc, t, r.n[kBHi], L.e[kBLo]); if (last) u = fma(L.e[kBHi], t, u);
+        ep = L.e[kBHi];
+        pgs_generic_phase<0>(L, r, acc, t, u, ep, wave_slots, in_con, last);
+    }
+    return u;
+}
+
+// ------------------------------------------------------------------ one physics step
+// Kuka.applyAction (kuka.py:118-187) + p.stepSimulation(), same semantics as physics_step<1>() of kuka_core.hpp.
+// `e` holds the env's scalar state replicated on the 16 lanes (its q / qd / sq / cq arrays are not used here), `g` the
+// lane's own joint and frames (valid on entry: grefresh()), jt_own the joint-mode target of the own joint.
+SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode,
+                         double jt_own) {
+    const double dt = kDt;
+    // ---- spatial joint axes about the world origin, replicated: S_k = [z_k ; p_k x z_k]
+    double z[3], s2[3], Sz[ND][3], S2[ND][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) z[k] = g.R[6 + k] * L.am;
+    cross3(g.p, z, s2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double tz[ND], t2[ND];
+        bcast_all_step<0>(z[k], tz); bcast_all_step<0>(s2[k], t2);
+#pragma unroll
+        for (int j = 0; j < ND; j++) { Sz[j][k] = tz[j]; S2[j][k] = t2[j]; }
+    }
+    // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step (kuka.py:144-156)
+    double qdes = jt_own;
+    if (!joint_mode) {
+        const int b = (cfg.random_target || cfg.two) ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double v = e.ee[k] + motor[k];
+            v = v < kEeBox[b][0][k] ? kEeBox[b][0][k] : v;
+            v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
+            e.ee[k] = v;
+        }
+        double ee[3], dS[6], J[6];
+        tip_point(g.Rt, g.pt, kEePoint, ee);
+        {
+            double d[3], c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) d[k] = ee[k] - g.p[k];
+            cross3(z, d, c);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { J[k] = c[k]; J[3 + k] = z[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
+        {   // orientation error (same construction as ik_step() of kuka_core.hpp), replicated
+            const double *R = g.Rt;
+            double qx, qy, qz, qw;
+            const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+            const double tr = m00 + m11 + m22;
+            if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
+            else if (m00 > m11 && m00 > m22) { double s = sqrt(1.0 + m00 - m11 - m22) * 2; qw = (m21 - m12) / s; qx = 0.25 * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
+            else if (m11 > m22) { double s = sqrt(1.0 + m11 - m00 - m22) * 2; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25 * s; qz = (m12 + m21) / s; }
+            else { double s = sqrt(1.0 + m22 - m00 - m11) * 2; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25 * s; }
+            const double tx = 0.0, ty = -1.0, tz = 0.0, tw = 6.123233995736766e-17;
+            const double ix = -qx, iy = -qy, iz = -qz, iw = qw;
+            const double dw = tw * iw - tx * ix - ty * iy - tz * iz;
+            const double dx = tw * ix + tx * iw + ty * iz - tz * iy;
+            const double dy = tw * iy - tx * iz + ty * iw + tz * ix;
+            const double dz = tw * iz + tx * iy - ty * ix + tz * iw;
+            const double sv = sqrt(dx * dx + dy * dy + dz * dz);
+            double angle = 2.0 * atan2(sv, dw), ax, ay, az;
+            if (sv * sv < 10.0 * 2.2204460492503131e-16) { ax = 1; ay = 0; az = 0; }
+            else { ax = dx / sv; ay = dy / sv; az = dz / sv; }
+            if (angle > kPi) angle -= 2 * kPi;
+            dS[3] = angle * ax; dS[4] = angle * ay; dS[5] = angle * az;
+        }
+        // (J^T J + damping I) dtheta = J^T dS: row l on lane l
+        double A[ND], bb = 0.0;
+        gram_step<0>(J, A);
+        const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
+#pragma unroll
+        for (int k = 0; k < ND; k++) A[k] = fma(damping, L.e[k], A[k]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
+        gj_step<0, false>(L, A, bb);
+        bb *= L.am;
+        double all[ND], maxabs = 0.0;
+        bcast_all_step<0>(bb, all);
+#pragma unroll
+        for (int k = 0; k < ND; k++) maxabs = fmax(maxabs, fabs(all[k]));
+        const double scale = maxabs > kIkMaxAngle ? kIkMaxAngle / maxabs : 1.0;
+        qdes = g.q + (maxabs > kIkMaxAngle ? bb * scale : bb);
+    }
+    // ---- collision detection at the current poses: lane s < 6 owns gripper sphere s
+    double cc[3], n_cap[3], n_base[3], d_cap = 1e30, d_base = 1e30;
+    tip_point(g.Rt, g.pt, L.sph, cc);
+    const bool sphere = L.l < kNSphere;
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
+    if (sphere) {
+        d_cap = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+        d_base = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+    }
+    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    e.contact_table = gany(sphere && (cc[2] - L.sph[3] - kTableTopZ < kContactThreshold)) ? 1 : 0;
+    // ---- motor target velocity of the own joint
+    double target = kArmKp * (qdes - g.q) / dt;
+    target = target > kArmMaxVel ? kArmMaxVel : target;
+    target = target < -kArmMaxVel ? -kArmMaxVel : target;
+    // ---- dynamics in world coordinates: velocities and bias accelerations by prefix sums over the chain
+    const double qd = g.qd * L.am;
+    double w[3], vo[3], aw[3], av[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { w[k] = masked_sum(z[k] * qd, L.le); vo[k] = masked_sum(s2[k] * qd, L.le); }
+    {
+        double t0[3], t1[3], t2[3];
+        cross3(w, z, t0); cross3(w, s2, t1); cross3(vo, z, t2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            aw[k] = masked_sum(t0[k] * qd, L.le);
+            av[k] = masked_sum((t1[k] + t2[k]) * qd, L.le, k == 2 ? -kGravityZ : 0.0);
+        }
+    }
+    // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c, m
+    double Io[6], h[3];
+    {
+        const double *R = g.R;
+        double cw[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) cw[k] = g.p[k] + R[k] * L.com[0] + R[3 + k] * L.com[1] + R[6 + k] * L.com[2];
+        const double m = L.mass, ccs = dot3(cw, cw);
+        const double ix = L.in[0], iy = L.in[1], iz = L.in[2];
+        Io[0] = ix * R[0] * R[0] + iy * R[3] * R[3] + iz * R[6] * R[6] + m * (ccs - cw[0] * cw[0]);
+        Io[1] = ix * R[0] * R[1] + iy * R[3] * R[4] + iz * R[6] * R[7] - m * cw[0] * cw[1];
+        Io[2] = ix * R[0] * R[2] + iy * R[3] * R[5] + iz * R[6] * R[8] - m * cw[0] * cw[2];
+        Io[3] = ix * R[1] * R[1] + iy * R[4] * R[4] + iz * R[7] * R[7] + m * (ccs - cw[1] * cw[1]);
+        Io[4] = ix * R[1] * R[2] + iy * R[4] * R[5] + iz * R[7] * R[8] - m * cw[1] * cw[2];
+        Io[5] = ix * R[2] * R[2] + iy * R[5] * R[5] + iz * R[8] * R[8] + m * (ccs - cw[2] * cw[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) h[k] = m * cw[k];
+    }
+    // link force f = I a + v x* (I v); then suffix sums: total force on the sub-chain, composite inertia
+    double Fn[3], Ff[3], Ioc[6], hc[3];
+    {
+        double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
+        sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass * av[k] - t1[k]; }
+        sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass * vo[k] - t1[k]; }
+        cross3(w, n, t0); cross3(vo, f, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
+        cross3(w, f, t0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) ff[k] += t0[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Fn[k] = masked_sum(fn[k], L.ge); Ff[k] = masked_sum(ff[k], L.ge); hc[k] = masked_sum(h[k], L.ge); }
+#pragma unroll
+        for (int k = 0; k < 6; k++) Ioc[k] = masked_sum(Io[k], L.ge);
+    }
+    const double tau = -kJointDamping * qd - (dot3(z, Fn) + dot3(s2, Ff));
+    // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k <= l on lane l, the upper part by transposition; W = M^-1 in place
+    double W[ND];
+    {
+        double fn[3], ff[3], t0[3], t1[3], low[ND];
+        sym_mul(Ioc, z, fn); cross3(hc, s2, t0); cross3(hc, z, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { fn[k] += t0[k]; ff[k] = L.mcomp * s2[k] - t1[k]; }
+#pragma unroll
+        for (int k = 0; k < ND; k++) { low[k] = dot3(Sz[k], fn) + dot3(S2[k], ff); W[k] = low[k] * L.le[k] * L.am; }
+        transpose_upper_step<1>(L, low, W);
+        double unused = 0.0;
+        gj_step<0, true>(L, W, unused);
+    }
+    const double qdd = row_dot(W, tau);
+#pragma unroll
+    for (int k = 0; k < ND; k++) SRL_GDBG(0, L.l * ND + k, W[k]);
+    SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
+    double qd_new = qd + dt * qdd;            // unconstrained velocity; the solver corrects it below
+    e.bqd += dt * kGravityZ;
+    // ---- constraint rows
+    const double arm_bound = kArmMaxForce * dt, wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
+    const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
+    Rows r;
+    double rhs = 0.0;                         // desired velocity change of the own row (velocity units)
+#pragma unroll
+    for (int k = 0; k < GL; k++) { r.a[k] = 0.0; r.n[k] = 0.0; }
+    r.lo = 0.0; r.S = 0.0; r.jb = 0.0;
+    if (L.arm) {
+#pragma unroll
+        for (int k = 0; k < ND; k++) r.a[k] = W[k];
+        rhs = target - qd_new; r.lo = -arm_bound; r.S = 2.0 * arm_bound;
+    } else if (L.l == kBM) {
+        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) / dt : 0.0) - e.bqd;
+        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0;
+    } else if (L.l == kBLo) {
+        const double pen = e.bq - kGliderLower;
+        rhs = ((pen > 0 ? -pen / dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
+        r.S = blim; r.jb = 1.0;
+    } else if (L.l == kBHi) {
+        const double pen = kGliderUpper - e.bq;
+        rhs = ((pen > 0 ? -pen / dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
+        r.S = blim; r.jb = -1.0;
+    }
+    if (L.l == kBM || L.l == kBLo || L.l == kBHi) {      // the three scalar rows share the glider: a_rk = J_r J_k / m
+        r.a[kBM] = r.jb * wb; r.a[kBLo] = r.jb * wb; r.a[kBHi] = -r.jb * wb;
+    }
+    // generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
+    const double pen_lo = g.q - L.jlo, pen_hi = L.jhi - g.q;
+    const bool lim_lo = L.arm && pen_lo <= kLimitActivationVel * dt, lim_hi = L.arm && pen_hi <= kLimitActivationVel * dt;
+    e.contact_button = gany(c_cap) ? 1 : 0;
+    uint32_t wave_slots = 0; int nlim = 0; bool has_lim = false;
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
+    if (any_generic) {
+        // slot of a candidate = number of candidates before it in Bullet's creation order: limits (joint 0 lower, joint 0
+        // upper, joint 1 lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first six are kept
+        const uint32_t b_lo = ballot(lim_lo), b_hi = ballot(lim_hi), b_cap = ballot(c_cap), b_base = ballot(c_base);
+        const uint32_t below = (1u << L.l) - 1u;
+        nlim = __builtin_popcount(b_lo) + __builtin_popcount(b_hi);
+        const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base);
+        const int s_lo = __builtin_popcount(b_lo & below) + __builtin_popcount(b_hi & below), s_hi = s_lo + (lim_lo ? 1 : 0);
+        const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
+        if (nlim > kMaxGenRows) nlim = kMaxGenRows;
+        int ngen = nlim + ncon; if (ngen > kMaxGenRows) ngen = kMaxGenRows;
+        // row definitions -> scratch [slot][12]: J[7] Jb desired pos_err lo hi
+        double *def = scratch, *wj = scratch + kMaxGenRows * kRowDef;
+#define SRL_DEF_ROW(slot_, fillJ, Jb_, des_, perr_, hi_)                                     \
+        if ((slot_) < kMaxGenRows) {                                                         \
+            double *o = def + (slot_) * kRowDef;                                             \
+            fillJ                                                                            \
+            o[7] = (Jb_); o[8] = (des_); o[9] = (perr_); o[10] = 0.0; o[11] = (hi_);         \
+        }
+        if (lim_lo) { SRL_DEF_ROW(s_lo, _Pragma("unroll") for (int j = 0; j < ND; j++) o[j] = L.e[j];, 0.0, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * kErp / dt, blim) }
+        if (lim_hi) { SRL_DEF_ROW(s_hi, _Pragma("unroll") for (int j = 0; j < ND; j++) o[j] = -L.e[j];, 0.0, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt, blim) }
+#define SRL_CONTACT_J(nrm)                                                                   \
+        {                                                                                    \
+            double pt[3];                                                                    \
+            _Pragma("unroll") for (int k = 0; k < 3; k++) pt[k] = cc[k] - L.sph[3] * nrm[k]; \
+            _Pragma("unroll") for (int j = 0; j < ND; j++) {                                 \
+                double c3[3];                                                                \
+                cross3(Sz[j], pt, c3);                                                       \
+                o[j] = dot3(nrm, c3) + dot3(nrm, S2[j]);      /* n . (z_j x (pt - p_j)) */   \
+            }                                                                                \
+        }
+        if (c_cap) { SRL_DEF_ROW(s_cap, SRL_CONTACT_J(n_cap), -n_cap[2], d_cap > 0 ? -d_cap / dt : 0.0, d_cap > 0 ? 0.0 : -d_cap * kErp / dt, 1e10) }
+        if (c_base) { SRL_DEF_ROW(s_base, SRL_CONTACT_J(n_base), 0.0, d_base > 0 ? -d_base / dt : 0.0, d_base > 0 ? 0.0 : -d_base * kErp / dt, 1e10) }
+#undef SRL_CONTACT_J
+#undef SRL_DEF_ROW
+        sync_scratch();
+        has_lim = wany(nlim > 0);
+        int myslot = -1;
+#pragma unroll
+        for (int gi = 0; gi < kMaxGenRows; gi++) if (L.l == kGenLane[gi]) myslot = gi;
+        // W J of every row: lane k < 7 computes (W J_g)_k = a_{k,g}; gathered per row through the scratch
+        double Jb[kMaxGenRows];
+#pragma unroll
+        for (int gi = 0; gi < kMaxGenRows; gi++) {
+            const bool have = gi < ngen;
+            Jb[gi] = have ? def[gi * kRowDef + 7] : 0.0;
+            double wjk = 0.0;
+#pragma unroll
+            for (int j = 0; j < ND; j++) wjk = fma(W[j], have ? def[gi * kRowDef + j] : 0.0, wjk);
+            if (L.arm) { r.a[kGenLane[gi]] = wjk; wj[gi * ND + L.l] = wjk; }
+            else if (L.l == kBM || L.l == kBLo || L.l == kBHi) r.a[kGenLane[gi]] = r.jb * wb * Jb[gi];
+            wave_slots |= wany(have) ? (1u << gi) : 0u;
+        }
+        sync_scratch();
+        if (myslot >= 0 && myslot < ngen) {
+            const double *o = def + myslot * kRowDef, *mywj = wj + myslot * ND;
+            r.jb = o[7];
+#pragma unroll
+            for (int k = 0; k < ND; k++) r.a[k] = mywj[k];
+            r.a[kBM] = r.jb * wb; r.a[kBLo] = r.jb * wb; r.a[kBHi] = -r.jb * wb;
+#pragma unroll
+            for (int gi = 0; gi < kMaxGenRows; gi++) {
+                double c = r.jb * wb * Jb[gi];
+#pragma unroll
+                for (int j = 0; j < ND; j++) c = fma(o[j], gi < ngen ? wj[gi * ND + j] : 0.0, c);
+                r.a[kGenLane[gi]] = gi < ngen ? c : 0.0;
+            }
+            r.lo = o[10]; r.S = o[11] - o[10];
+            rhs = o[8] + o[9] - o[7] * e.bqd;    // the arm part of the row velocity is subtracted below (needs every lane's qd_new)
+        }
+        // J . qd_new of every generic row (qd_new lives one joint per lane): replicated dot products
+        {
+            double qall[ND];
+            bcast_all_step<0>(qd_new, qall);
+            if (myslot >= 0 && myslot < ngen) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < ND; j++) s = fma(def[myslot * kRowDef + j], qall[j], s);
+                rhs -= s;
+            }
+        }
+        sync_scratch();                          // scratch is reused by the next step
+    }
+    // ---- scale every row to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
+    {
+        // lo_k, S_k of every row, replicated (arm rows and button rows are constants; generic rows come by broadcast)
+        double lo_k[GL], S_k[GL];
+#pragma unroll
+        for (int k = 0; k < GL; k++) { lo_k[k] = 0.0; S_k[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < ND; k++) { lo_k[k] = -arm_bound; S_k[k] = 2.0 * arm_bound; }
+        lo_k[kBM] = -bound_bm; S_k[kBM] = 2.0 * bound_bm; S_k[kBLo] = blim; S_k[kBHi] = blim;
+        if (any_generic) {
+            S_k[kGenLane[0]] = bcast<kGenLane[0]>(r.S); S_k[kGenLane[1]] = bcast<kGenLane[1]>(r.S); S_k[kGenLane[2]] = bcast<kGenLane[2]>(r.S);
+            S_k[kGenLane[3]] = bcast<kGenLane[3]>(r.S); S_k[kGenLane[4]] = bcast<kGenLane[4]>(r.S); S_k[kGenLane[5]] = bcast<kGenLane[5]>(r.S);
+        }
+        double diag = 0.0, off = 0.0;
+#pragma unroll
+        for (int k = 0; k < GL; k++) { diag = fma(L.e[k], r.a[k], diag); off = fma(r.a[k] * (1.0 - L.e[k]), lo_k[k], off); }
+        const bool live = r.S > 0.0 && diag > 0.0;
+        const double inv = live ? 1.0 / (diag * r.S) : 0.0;
+        r.cs = live ? (rhs - off) * inv - r.lo / r.S : 0.0;
+#pragma unroll
+        for (int k = 0; k < GL; k++) r.n[k] = -(r.a[k] * (1.0 - L.e[k])) * S_k[k] * inv;
+        // lambda starts at 0, i.e. u_k = -lo_k / S_k = 1/2 for the symmetric rows (arm motors; the button motor couples to
+        // no row that comes before it): what arm row l sees of the arm rows behind it during the first sweep
+        r.acc0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < ND; k++) r.acc0 = fma(r.n[k] * (1.0 - L.le[k]), 0.5, r.acc0);
+    }
+    const double u = any_generic ? pgs_sweeps_general(L, r, wave_slots, nlim, has_lim) : pgs_sweeps_free(L, r);
+    const double lam = r.lo + r.S * u;
+    SRL_GDBG(5, L.l, lam);
+    // ---- velocity change: arm lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
+    double dv = 0.0, dvb = 0.0;
+    {
+        const double pb = r.jb * lam * wb;
+#define SRL_ACC(K) fmac_bcast<K>(dv, lam, r.a[K]);
+        SRL_ACC(0) SRL_ACC(1) SRL_ACC(2) SRL_ACC(3) SRL_ACC(4) SRL_ACC(5) SRL_ACC(6)
+        dvb = bcast<kBM>(pb) + bcast<kBLo>(pb) + bcast<kBHi>(pb);
+        if (any_generic) {
+            SRL_ACC(7) SRL_ACC(11) SRL_ACC(12) SRL_ACC(13) SRL_ACC(14) SRL_ACC(15)
+            dvb += bcast<7>(pb) + bcast<11>(pb) + bcast<12>(pb) + bcast<13>(pb) + bcast<14>(pb) + bcast<15>(pb);
+        }
+#undef SRL_ACC
+    }
+    // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position
+    if (L.arm) { g.qd = qd_new + dv; g.q += dt * g.qd; }
+    e.bqd += dvb;
+    e.bq += dt * e.bqd;
+    grefresh(L, g, e);
+}
+
+// ------------------------------------------------------------------ env level (mirrors kuka_env.hpp for a lane group)
+// RNG adaptor for generators whose state lives in HBM (MT19937): lane 0 draws, the row receives the value.
+template <class R> struct Lane0Rng {
+    R *r; bool own;        // own: this lane is lane 0 of a valid env
+    SRL_G double double01() { double v = 0.0; if (own) v = r->double01(); return bcast<0>(v); }
+    SRL_G double uniform(double a, double b) { double v = 0.0; if (own) v = r->uniform(a, b); return bcast<0>(v); }
+    SRL_G double normal(double a, double b) { double v = 0.0; if (own) v = r->normal(a, b); return bcast<0>(v); }
+    SRL_G uint32_t bounded(uint32_t m) { double v = 0.0; if (own) v = (double)r->bounded(m); return (uint32_t)bcast<0>(v); }
+};
+
+// arm / glider part of a packed start state (pack_start() layout) -> lane group
+SRL_G void gunpack_start(Env &e, GState &g, const Lane &L, const double *o) {
+    if (L.arm) { g.q = o[L.l]; g.qd = o[7 + L.l]; g.sq = o[14 + L.l]; g.cq = o[21 + L.l]; }
+    else { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = o[28 + k]; e.grip[k] = o[33 + k]; }
+    e.bq = o[31]; e.bqd = o[32];
+}
+
+// KukaButtonGymEnv.reset for one lane group (same draws, same table as reset_env<1>)
+template <class R>
+SRL_G void genv_reset(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
+                      double *objs, int64_t objs_stride) {
+#pragma clang fp contract(off)
+    ResetDraw d;
+    reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    const bool joints = !cfg.is_discrete && cfg.action_joints;
+    gunpack_start(e, g, L, joints ? settled : starts + (int64_t)d.idx * kStartDoubles);
+    e.bx = d.bx; e.by = d.by; e.bz = kButtonBaseZ;
+    gfk(L, g);
+    if (joints) {
+        const double motor[3] = {0, 0, 0};
+        for (int k = 0; k < kNInitActions; k++) {
+            const double jt = L.q0 + kDeltaTheta * d.g[k];
+            gphysics_step(e, g, L, cfg, scratch, motor, true, jt);
+        }
+    }
+    reset_finish<1>(e, d);
+}
+
+// KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own joint's action.
+template <class R>
+SRL_G double genv_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own,
+                       bool *done) {
+    StepCmd c;
+    step_command(e, cfg, rng, action, ca3, c);
+    const double jt = joint_target(c, ca_own, L.q0);
+    for (int rep = 0; rep < cfg.action_repeat; rep++) {
+        gphysics_step(e, g, L, cfg, scratch, c.motor, c.joint_mode, jt);
+        if (termination(e, cfg)) break;
+        e.counter += 1;
+    }
+    const double reward = reward_fn(e, cfg);
+    *done = termination(e, cfg);
+    return reward;
+}
+
+}  // namespace grp
+}  // namespace kuka
+}  // namespace srl

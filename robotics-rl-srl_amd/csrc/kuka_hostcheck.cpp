@@ -13,6 +13,9 @@
 static unsigned char *g_stat = nullptr; static long g_stat_idx = -1;
 #define SRL_ROW_STAT_HOOK(ngen, nlim) do { if (g_stat && g_stat_idx >= 0) g_stat[g_stat_idx] = (unsigned char)((ngen) | ((nlim) > 0 ? 0x80 : 0)); } while (0)
 #include "kuka_env.hpp"
+static double g_gdbg[8][128]; static int g_gdbg_on = 0;
+#define SRL_GDBG(tag, idx, val) do { if (g_gdbg_on && (idx) < 128) g_gdbg[tag][idx] = (val); } while (0)
+#include "kuka_group.hpp"
 
 using namespace srl;
 using namespace srl::kuka;
@@ -177,3 +180,215 @@ extern "C" void hostcheck_kuka_settled(int random_target, int action_joints, dou
         out22[19] = e.grip[0]; out22[20] = e.grip[1]; out22[21] = e.grip[2];
     }
 }
+
+
+// =====================================================================================================================
+// Lane-group stepper (kuka_group.hpp) on the host: the 16 lanes of an env's DPP row are 16 cooperatively scheduled fibers
+// that run the kernel's own SIMT source in lockstep; every cross-lane primitive is one value exchange (write own slot,
+// yield round-robin through the other 15 fibers, read the source lane's slot).
+namespace {
+extern "C" void srl_fiber_switch(void **save_sp, void *new_sp);
+}
+asm(R"(
+    .text
+    .globl srl_fiber_switch
+    .type srl_fiber_switch,@function
+srl_fiber_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
+namespace {
+struct FiberGroup {
+    static constexpr int N = grp::GL;
+    static constexpr size_t kStack = 1 << 20;
+    void *sp[N], *main_sp;
+    std::vector<char> stacks;
+    int cur = 0, done = 0;
+    long ops[N];
+    double slot[2][N];
+    uint32_t vote[2];
+    void (*body)(void *);
+    void *arg;
+    FiberGroup() : stacks(N * kStack) {}
+};
+FiberGroup *g_group = nullptr;
+
+void fiber_yield() {
+    FiberGroup *G = g_group;
+    const int me = G->cur;
+    G->cur = (me + 1) % FiberGroup::N;
+    srl_fiber_switch(&G->sp[me], G->sp[G->cur]);
+}
+void fiber_entry() {
+    FiberGroup *G = g_group;
+    G->body(G->arg);
+    // lockstep: fibers finish in lane order; hand over to the next one (still inside its last exchange), the last to main
+    const int me = G->cur;
+    G->done++;
+    if (me + 1 < FiberGroup::N) { G->cur = me + 1; srl_fiber_switch(&G->sp[me], G->sp[me + 1]); }
+    else srl_fiber_switch(&G->sp[me], G->main_sp);
+    abort();
+}
+void run_group(void (*body)(void *), void *arg) {
+    static FiberGroup group;
+    FiberGroup *G = &group;
+    g_group = G;
+    G->body = body; G->arg = arg; G->cur = 0; G->done = 0; G->vote[0] = G->vote[1] = 0;
+    for (int l = 0; l < FiberGroup::N; l++) {
+        G->ops[l] = 0;
+        char *top = G->stacks.data() + (size_t)(l + 1) * FiberGroup::kStack;
+        uintptr_t a = ((uintptr_t)top - 64) & ~(uintptr_t)15;          // 16-aligned: after 6 pops + ret, rsp = a + 56 == 8 (mod 16)
+        void **st = (void **)a;
+        for (int k = 0; k < 6; k++) st[k] = nullptr;
+        st[6] = (void *)&fiber_entry;
+        st[7] = nullptr;
+        G->sp[l] = st;
+    }
+    srl_fiber_switch(&G->main_sp, G->sp[0]);
+    if (G->done != FiberGroup::N) abort();
+    for (int l = 1; l < FiberGroup::N; l++) if (G->ops[l] != G->ops[0]) abort();      // every lane ran the same cross-lane ops
+}
+}  // namespace
+
+namespace srl { namespace kuka { namespace grp {
+int host_lane() { return g_group->cur; }
+double host_exchange(double x, int src) {
+    FiberGroup *G = g_group;
+    const int me = G->cur, buf = (int)(G->ops[me]++ & 1);
+    G->slot[buf][me] = x;
+    fiber_yield();
+    return G->slot[buf][src];
+}
+uint32_t host_ballot(bool p) {
+    FiberGroup *G = g_group;
+    const int me = G->cur, buf = (int)(G->ops[me]++ & 1);
+    G->slot[buf][me] = p ? 1.0 : 0.0;
+    fiber_yield();
+    uint32_t m = 0;
+    for (int l = 0; l < FiberGroup::N; l++) if (G->slot[buf][l] != 0.0) m |= 1u << l;
+    return m;
+}
+}}}  // namespace srl::kuka::grp
+
+namespace {
+struct GroupArgs {
+    Cfg cfg; int rng_mode; const uint32_t *mt_key; int mt_key_len; Philox act; int T, n, e_idx; const void *actions;
+    const double *settled, *starts; float *obs0, *obs, *rew; double *rew64; uint8_t *done_out; void *act_out;
+    double *q_trace, *grip_trace, *final_state, *ep_stats;
+    MtHost *mt; double *scratch;
+};
+
+template <class R>
+void group_env_body(GroupArgs &a, R &rng) {
+    using namespace grp;
+    const Cfg &cfg = a.cfg;
+    const int n = a.n, e_idx = a.e_idx, T = a.T;
+    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
+    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    Lane L; lane_init(L);
+    const bool lead = L.l == 0;
+    Env env; memset(&env, 0, sizeof env);
+    GState g; memset(&g, 0, sizeof g);
+    genv_reset(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
+    Philox act = a.act;
+    double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
+    for (int t = 0; t < T; t++) {
+        const size_t row = (size_t)t * n + e_idx;
+        int ac = 0; float ca[7] = {0}; bool done;
+        if (a.actions) {
+            if (cfg.is_discrete) ac = static_cast<const int32_t *>(a.actions)[row];
+            else memcpy(ca, static_cast<const float *>(a.actions) + row * adim, sizeof(float) * adim);
+        } else {
+            if (cfg.is_discrete) ac = (int)act.bounded(5);
+            else for (int j = 0; j < adim; j += 2) {
+                uint32_t o[4]; act.block(o);
+                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+            }
+            if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
+        }
+        const double reward = genv_step(env, g, L, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
+        if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
+        ep_ret += reward; ep_len += 1;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
+            if (cfg.auto_reset) genv_reset(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+        }
+        if (lead) {
+            if (a.obs) observe(env, cfg, a.obs + row * od, 1);
+            if (a.rew) a.rew[row] = (float)reward;
+            if (a.rew64) a.rew64[row] = reward;
+            if (a.done_out) a.done_out[row] = (uint8_t)done;
+        }
+    }
+    if (a.final_state) {
+        double *f = a.final_state + 30 * (size_t)e_idx;
+        if (L.arm) { f[L.l] = g.q; f[7 + L.l] = g.qd; }
+        if (lead) {
+            f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
+            f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
+        }
+    }
+    if (a.ep_stats && lead) { a.ep_stats[3 * (size_t)e_idx] = last_ret; a.ep_stats[3 * (size_t)e_idx + 1] = last_len; a.ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
+}
+
+void group_fiber_body(void *p) {
+    GroupArgs &a = *static_cast<GroupArgs *>(p);
+    if (a.rng_mode == 2) {
+        grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0};
+        group_env_body(a, r);
+    } else {
+        PhHost r; r.p = a.act; r.p.stream = 0;          // counter-based: every lane replays the same stream
+        group_env_body(a, r);
+    }
+}
+}  // namespace
+
+// same signature as hostcheck_kuka_rollout; KukaButton / Moving / RandButton (the lane-group kernel has no two-button form)
+extern "C" int hostcheck_kuka_group_rollout(int is_discrete, int action_joints, int random_target, int force_down,
+                                            int shape_reward, int action_repeat, double max_distance, int obs_mode,
+                                            int rng_mode, int auto_reset, int n, int T, const int64_t *seeds,
+                                            const uint32_t *mt_keys, const int32_t *mt_key_len, const void *actions,
+                                            float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out,
+                                            void *act_out, double *q_trace, double *grip_trace, double *final_state,
+                                            double *ep_stats) {
+    if (g_two) return -1;
+    GroupArgs a;
+    Cfg &cfg = a.cfg;
+    cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
+    cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
+    cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
+    cfg.moving = g_moving; cfg.two = 0; cfg.max_steps = g_moving ? 1500 : kMaxSteps; cfg.rand_objects = g_rand;
+    std::vector<double> settled, starts, scratch(grp::kScratchDoubles);
+    build_tables(cfg, settled, starts);
+    a.rng_mode = rng_mode; a.T = T; a.n = n; a.actions = actions; a.settled = settled.data(); a.starts = starts.data();
+    a.obs0 = obs0; a.obs = obs; a.rew = rew; a.rew64 = rew64; a.done_out = done_out; a.act_out = act_out;
+    a.q_trace = q_trace; a.grip_trace = grip_trace; a.final_state = final_state; a.ep_stats = ep_stats; a.scratch = scratch.data();
+    for (int e = 0; e < n; e++) {
+        a.e_idx = e;
+        a.act.k0 = (uint32_t)(uint64_t)seeds[e]; a.act.k1 = (uint32_t)((uint64_t)seeds[e] >> 32); a.act.ctr = 0; a.act.stream = 1;
+        MtHost mt;
+        if (rng_mode == 2) mt.seed(mt_keys + 2 * (size_t)e, mt_key_len[e]);
+        a.mt = &mt;
+        run_group(group_fiber_body, &a);
+    }
+    return 0;
+}
+
+extern "C" void hostcheck_group_debug(int on, double *out) { g_gdbg_on = on; if (out) memcpy(out, g_gdbg, sizeof g_gdbg); }

@@ -39,3 +39,16 @@ def rollout(seeds, T, actions=None, **kw):
         return kuka_clib.rollout(seeds, T, actions=actions, **kw)
     finally:
         kuka_clib._lib = real
+
+
+def group_rollout(seeds, T, actions=None, **kw):
+    """Same, computed by the lane-GROUP stepper (csrc/kuka_group.hpp) with its 16 lanes emulated as lockstep fibers."""
+    l = lib()
+    l.hostcheck_kuka_group_rollout.argtypes = l.hostcheck_kuka_rollout.argtypes
+    fake = types.SimpleNamespace(kuka_oracle_rollout=l.hostcheck_kuka_group_rollout)
+    real = kuka_clib._lib
+    kuka_clib._lib = lambda: fake
+    try:
+        return kuka_clib.rollout(seeds, T, actions=actions, **kw)
+    finally:
+        kuka_clib._lib = real

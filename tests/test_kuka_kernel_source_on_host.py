@@ -1,7 +1,9 @@
-"""CPU-side parity of the HIP Kuka stepper's arithmetic: the kernel's own source
-(world-frame ABA, LDL^T IK, table-driven reset, FMA contraction) compiled for the
-host vs the independent plain-C oracle (link-frame ABA, Gaussian elimination,
-literal 505-step reset).  Tolerance 1e-4 on joints (north star); flags bit-exact."""
+"""CPU-side parity of the HIP Kuka steppers' arithmetic: the kernels' own source compiled for the host vs the
+independent plain-C oracle (link-frame ABA, Gaussian elimination, literal 505-step reset).  Two kernels:
+  lane   lane-per-env (kuka_core.hpp: world-frame ABA, LDL^T IK, table-driven reset, FMA contraction)
+  group  16-lane group per env (kuka_group.hpp: prefix-sum RNEA / CRBA, Gauss-Jordan, one solver row per lane); its
+         lanes run as lockstep fibers, every DPP primitive is an exchange between them.
+Tolerance 1e-4 on joints (north star); flags bit-exact."""
 import numpy as np
 import pytest
 
@@ -28,11 +30,16 @@ def compare(a, b):
     return np.abs(a["q"] - b["q"]).max()
 
 
-def test_default_discrete_env_full_episodes():
+STEPPERS = {"lane": hostcheck.rollout, "group": hostcheck.group_rollout}
+both = pytest.mark.parametrize("stepper", ["lane", "group"])
+
+
+@both
+def test_default_discrete_env_full_episodes(stepper):
     n, T = 12, 1100
     actions = np.random.RandomState(0).randint(6, size=(T, n)).astype(np.int32)
     a = kuka_clib.rollout(np.arange(n), T, actions=actions)
-    b = hostcheck.rollout(np.arange(n), T, actions=actions)
+    b = STEPPERS[stepper](np.arange(n), T, actions=actions)
     err = compare(a, b)
     assert np.array_equal(a["reward"], b["reward"])
     assert a["done"].sum() >= n          # every env crossed at least one reset
@@ -45,33 +52,37 @@ def test_default_discrete_env_full_episodes():
     dict(obs_mode=2, auto_reset=False),
     dict(rng_mode=kuka_clib.RNG_PHILOX, random_target=True),
 ])
-def test_env_options(kw):
+@both
+def test_env_options(kw, stepper):
     n, T = 6, 500
     actions = np.random.RandomState(1).randint(-1, 6, size=(T, n)).astype(np.int32)     # includes None (-1)
     a = kuka_clib.rollout(100 + np.arange(n), T, actions=actions, **kw)
-    b = hostcheck.rollout(100 + np.arange(n), T, actions=actions, **kw)
+    b = STEPPERS[stepper](100 + np.arange(n), T, actions=actions, **kw)
     compare(a, b)
     assert np.abs(a["reward64"] - b["reward64"]).max() <= TOL
 
 
+@both
 @pytest.mark.parametrize("joints", [False, True])
-def test_continuous_actions(joints):
+def test_continuous_actions(joints, stepper):
     n, T, adim = 4, 300, 7 if joints else 3
     actions = np.random.RandomState(2).uniform(-1, 1, size=(T, n, adim)).astype(np.float32)
     kw = dict(is_discrete=False, action_joints=joints)
     a = kuka_clib.rollout(7 + np.arange(n), T, actions=actions, **kw)
-    b = hostcheck.rollout(7 + np.arange(n), T, actions=actions, **kw)
+    b = STEPPERS[stepper](7 + np.arange(n), T, actions=actions, **kw)
     compare(a, b)
 
 
-def test_device_sampled_actions_stream():
+@both
+def test_device_sampled_actions_stream(stepper):
     a = kuka_clib.rollout(np.arange(5), 200, actions=None, rng_mode=kuka_clib.RNG_PHILOX)
-    b = hostcheck.rollout(np.arange(5), 200, actions=None, rng_mode=kuka_clib.RNG_PHILOX)
+    b = STEPPERS[stepper](np.arange(5), 200, actions=None, rng_mode=kuka_clib.RNG_PHILOX)
     assert np.array_equal(a["actions"], b["actions"])
     compare(a, b)
 
 
-def test_moving_button_variant():
+@both
+def test_moving_button_variant(stepper):
     """KukaMovingButtonGymEnv semantics (kuka_moving_button_gym_env.py): direction draw first, button and target
     move 1 mm per step and bounce at |y| = 0.3, 1500-step limit, shaped reward branch for discrete actions."""
     n, T = 6, 1600
@@ -81,7 +92,7 @@ def test_moving_button_variant():
         kuka_clib.set_moving(True); hostcheck.set_moving(True)
         for kw in (dict(), dict(shape_reward=True, random_target=True)):
             a = kuka_clib.rollout(40 + np.arange(n), T, actions=actions, **kw)
-            b = hostcheck.rollout(40 + np.arange(n), T, actions=actions, **kw)
+            b = STEPPERS[stepper](40 + np.arange(n), T, actions=actions, **kw)
             compare(a, b)
             assert np.abs(a["reward64"] - b["reward64"]).max() <= TOL
         assert a["ep_stats"][:, 1].max() == 1501                        # counter > 1500
@@ -126,7 +137,8 @@ def test_two_button_variant():
         kuka_clib.set_variant(0); hostcheck.set_variant(0)
 
 
-def test_rand_button_variant():
+@both
+def test_rand_button_variant(stepper):
     """KukaRandButtonGymEnv: same stepping as KukaButtonGymEnv with the env's RNG stream shifted by the 20 distractor draws."""
     n, T = 6, 1100
     actions = np.random.RandomState(9).randint(6, size=(T, n)).astype(np.int32)
@@ -134,7 +146,7 @@ def test_rand_button_variant():
     try:
         kuka_clib.set_variant(3); hostcheck.set_variant(3)
         a = kuka_clib.rollout(80 + np.arange(n), T, actions=actions, random_target=True)
-        b = hostcheck.rollout(80 + np.arange(n), T, actions=actions, random_target=True)
+        b = STEPPERS[stepper](80 + np.arange(n), T, actions=actions, random_target=True)
         compare(a, b)
         assert np.array_equal(a["reward"], b["reward"])
         assert np.abs(a["obs"][:40] - base["obs"]).max() > 1e-3       # a different episode than the base env's on the same seed
