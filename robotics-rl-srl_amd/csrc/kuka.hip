@@ -13,6 +13,7 @@
 
 #include "internal.hpp"
 #include "kuka_env.hpp"
+#include "kuka_group.hpp"
 
 namespace srl {
 
@@ -20,6 +21,7 @@ using namespace kuka;
 
 constexpr int kWave = 64;
 constexpr int NDBL = 47, NINT = 9;
+constexpr int kGroupKernelMaxEnvs = 16384;     // batches up to this size are stepped by the lane-group kernel (see use_group_kernel)
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
 enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42,
@@ -226,6 +228,111 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
     st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane-group rollout (kuka_group.hpp): 16 lanes = one DPP row per env, one wavefront (4 envs) per workgroup.  A 4096-env
+// batch is 1024 wavefronts — one per SIMD of the MI355X — instead of the 64 of kuka_rollout_k; same state planes, same
+// start-state table, same outputs.  KukaButton / MovingButton / RandButton (NB == 1).
+constexpr int kGroupBlock = 64;
+constexpr int kGroupEnvs = kGroupBlock / grp::GL;
+
+template <int MODE>
+__global__ void __launch_bounds__(kGroupBlock)
+kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
+                     float *obs, float *rew, uint8_t *done_out, void *act_out) {
+    using namespace grp;
+    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
+    const int64_t n = p.n;
+    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
+    const bool valid = e_raw < p.n;
+    const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the DPP ops)
+    const Cfg &cfg = p.cfg;
+    double *scratch = scratch_all[threadIdx.x / GL];
+    Lane L;
+    lane_init(L);
+    const bool lead = L.l == 0 && valid;
+    typename KRng<MODE>::type rng0;
+    krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
+    // generators whose state lives in HBM (MT19937) are advanced by lane 0 only; counter-based / host streams are replayed by all
+    Lane0Rng<typename KRng<MODE>::type> rng_l0{&rng0, lead};
+    Env v = {};
+    GState g;
+    {   // env scalars replicated on the row, the own joint per arm lane
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
+        v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
+        v.bz = s.d[D_BZ * n + e]; v.bspeed = s.d[D_BSPEED * n + e];
+        v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
+        v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
+        v.terminated = s.i[I_TERM * n + e];
+        const int j = L.arm ? L.l : 0;
+        g.q = s.d[(D_Q + j) * n + e]; g.qd = s.d[(D_QD + j) * n + e]; g.sq = s.d[(D_SQ + j) * n + e]; g.cq = s.d[(D_CQ + j) * n + e];
+        if (!L.arm) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
+        gfk(L, g);
+    }
+    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    Philox act; act.k0 = rs.key[e]; act.k1 = rs.key[n + e]; act.ctr = rs.act_ctr[e]; act.stream = 1;
+    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
+    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    for (int t = 0; t < T; t++) {
+        const int64_t row = (int64_t)t * n + e;
+        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (actions) {
+            if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
+            else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
+        } else {
+            if (cfg.is_discrete) a = (int)act.bounded(5);
+            else for (int j = 0; j < adim; j += 2) {
+                uint32_t o[4]; act.block(o);
+                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+            }
+            if (act_out && lead) {
+                if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
+                else for (int j = 0; j < adim; j++) static_cast<float *>(act_out)[row * adim + j] = ca[j];
+            }
+        }
+        float ca_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
+        bool done;
+        double reward;
+        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = genv_step(v, g, L, cfg, scratch, rng_l0, a, ca, ca_own, &done);
+        else reward = genv_step(v, g, L, cfg, scratch, rng0, a, ca, ca_own, &done);
+        ep_ret += reward; ep_len += 1; last_reward = reward;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+            if (cfg.auto_reset) {
+                double *objs = valid ? s.objs + e : nullptr;
+                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
+                else genv_reset(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
+            }
+        }
+        if (lead) {
+            if (obs) observe(v, cfg, obs + row * od, 1);
+            if (rew) rew[row] = (float)reward;
+            if (done_out) done_out[row] = (uint8_t)done;
+        }
+    }
+    if (valid && L.arm) {
+        s.d[(D_Q + L.l) * n + e] = g.q; s.d[(D_QD + L.l) * n + e] = g.qd; s.d[(D_SQ + L.l) * n + e] = g.sq; s.d[(D_CQ + L.l) * n + e] = g.cq;
+    }
+    if (lead) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
+        s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
+        s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
+        s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
+        s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
+        s.i[I_TERM * n + e] = v.terminated;
+        krng_store<MODE>(rng0, rs, e);
+        if (!actions) rs.act_ctr[e] = act.ctr;
+        st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
+        st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
+    }
+}
+
 // after srlhip_set_state(KUKA_Q): refresh the cached sin/cos and the gripper position
 __global__ void kuka_refresh_k(KukaState s, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,8 +428,36 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
     return 0;
 }
 
+// Which kernel steps a batch: the lane-group kernel fills the chip at small batches (16 lanes per env), the lane-per-env
+// kernel does less total work per env once every SIMD has several wavefronts anyway.  SRLHIP_KUKA_KERNEL=group|lane forces one.
+static bool use_group_kernel(const Handle *h) {
+    if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return false;        // the lane-group kernel has no two-button form
+    const char *v = getenv("SRLHIP_KUKA_KERNEL");                        // read per call: tests and probes flip it inside one process
+    if (v && (v[0] == 'g' || v[0] == 'l')) return v[0] == 'g';
+    return h->n <= kGroupKernelMaxEnvs;
+}
+
+static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
+                             uint8_t *d_done, void *d_act_out) {
+    dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
+#define SRL_GROUP(MODE) hipLaunchKernelGGL((kuka_group_rollout_k<MODE>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+    switch (h->cfg.rng_mode) {
+        case SRLHIP_RNG_PHILOX: SRL_GROUP(SRLHIP_RNG_PHILOX); break;
+        case SRLHIP_RNG_MT19937: SRL_GROUP(SRLHIP_RNG_MT19937); break;
+        default: SRL_GROUP(SRLHIP_RNG_HOST);
+    }
+#undef SRL_GROUP
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
 int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_rew, uint8_t *d_done, void *d_act_out) {
     KukaParams p = params_of(h);
+    if (use_group_kernel(h)) {
+        if (h->cfg.rng_mode != SRLHIP_RNG_PHILOX && h->cfg.rng_mode != SRLHIP_RNG_MT19937)
+            return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
+        return kuka_group_launch(h, p, T, d_actions, nullptr, static_cast<float *>(d_obs), d_rew, d_done, d_act_out);
+    }
     // envs per wavefront: a wavefront takes the contact path of the solver as soon as ONE of its lanes carries a contact
     // row, so fewer (active) lanes per wavefront mean fewer slow sweeps — as long as there are idle SIMDs to host the
     // extra wavefronts (experiment knob SRLHIP_KUKA_LANES; the default is chosen from the batch size below)
@@ -355,6 +490,7 @@ int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_
 int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_obs, float *d_rew, uint8_t *d_done) {
     if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return kuka_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
     KukaParams p = params_of(h);
+    if (use_group_kernel(h)) return kuka_group_launch(h, p, 1, d_actions, d_noise, static_cast<float *>(d_obs), d_rew, d_done, nullptr);
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON)
         hipLaunchKernelGGL((kuka_rollout_k<SRLHIP_RNG_HOST, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, 1,

@@ -45,80 +45,121 @@ constexpr int kGenLane[kMaxGenRows] = {7, 11, 12, 13, 14, 15};    // lanes of th
 constexpr int kRowDef = 12, kScratchDoubles = kMaxGenRows * (kRowDef + ND);
 
 // ------------------------------------------------------------------ cross-lane primitives
+// Device bodies: DPP / ballot instructions.  Host bodies (the host pass of hipcc never calls them; the parity harness
+// csrc/kuka_hostcheck.cpp does): the calling fiber's lane, a lockstep value exchange, a group vote.
+#define SRL_G __host__ __device__ __forceinline__
+int host_lane();
+double host_exchange(double x, int src);
+uint32_t host_ballot(bool p);
 #if defined(__HIP_DEVICE_COMPILE__)
-#define SRL_G __device__ __forceinline__
-SRL_G int lane_id() { return (int)(threadIdx.x & (GL - 1)); }
-template <int J> SRL_G double bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false); }   // row_newbcast:J
-template <int D> SRL_G double shr(double x, double fill) {                                                                 // row_shr:D
+#define SRL_G_DEVICE 1
+#else
+#define SRL_G_DEVICE 0
+#endif
+
+SRL_G int lane_id() {
+#if SRL_G_DEVICE
+    return (int)(threadIdx.x & (GL - 1));
+#else
+    return host_lane();
+#endif
+}
+template <int J> SRL_G double bcast(double x) {                                   // row_newbcast:J
+#if SRL_G_DEVICE
+    return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false);
+#else
+    return host_exchange(x, J);
+#endif
+}
+template <int D> SRL_G double shr(double x, double fill) {                        // row_shr:D, `fill` shifted in
+#if SRL_G_DEVICE
     const long long v = __double_as_longlong(x), f = __double_as_longlong(fill);
     const int lo = __builtin_amdgcn_update_dpp((int)f, (int)v, 0x110 + D, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(v >> 32), 0x110 + D, 0xf, 0xf, false);
     return __longlong_as_double(((long long)(unsigned)hi << 32) | (unsigned)lo);
+#else
+    const int l = host_lane();
+    const double v = host_exchange(x, l >= D ? l - D : l);
+    return l >= D ? v : fill;
+#endif
 }
-SRL_G uint32_t ballot(bool p) { return (uint32_t)(__ballot(p) >> (threadIdx.x & 48)) & 0xffffu; }
+SRL_G uint32_t ballot(bool p) {
+#if SRL_G_DEVICE
+    return (uint32_t)(__ballot(p) >> (threadIdx.x & 48)) & 0xffffu;
+#else
+    return host_ballot(p);
+#endif
+}
 SRL_G bool gany(bool p) { return ballot(p) != 0; }
-SRL_G bool wany(bool p) { return __any(p); }
-SRL_G double shfl(double x, int src) { return __shfl(x, src, GL); }
-SRL_G void sync_scratch() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+SRL_G bool wany(bool p) {
+#if SRL_G_DEVICE
+    return __any(p);
+#else
+    return host_ballot(p) != 0;
+#endif
+}
+SRL_G void sync_scratch() {
+#if SRL_G_DEVICE
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#else
+    (void)host_ballot(false);
+#endif
+}
 SRL_G double rcp(double x) {          // ~1 ulp reciprocal: v_rcp_f64 + two Newton steps
+#if SRL_G_DEVICE
     double r = __builtin_amdgcn_rcp(x);
     double e = fma(-x, r, 1.0); r = fma(r, e, r);
     e = fma(-x, r, 1.0); r = fma(r, e, r);
     return r;
-}
-// acc += w * bcast<J>(x) in one v_fmac_f64_dpp.  The caller guarantees that x was not written by the instruction right
-// before (VALU write -> DPP read needs two wait states); `s_nop 1` covers it when it cannot.
-template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
-}
-SRL_G double clamp01_add(double a, double b) {
-    double t;
-    asm volatile("v_add_f64 %0, %1, %2 clamp" : "=v"(t) : "v"(a), "v"(b));
-    return t;
-}
-// one projected Gauss-Seidel row update (see the file header): acc -= ep * acc; acc += n * bcast<J>(t).
-// The reset FMA and one s_nop sit between the instruction that produced t and the DPP read of t (two wait states).
-template <int J> SRL_G void pgs_row(double &acc, double t, double n, double ep) {
-    asm volatile("v_fma_f64 %0, -%3, %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(t), "v"(n), "v"(ep), "n"(J));
-}
-template <int J, int J2> SRL_G void pgs_row2(double &acc, double t, double n, double n2, double ep) {     // two decoupled rows at once
-    asm volatile("v_fma_f64 %0, -%4, %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(t), "v"(n), "v"(n2), "v"(ep), "n"(J), "n"(J2));
-}
 #else
-#define SRL_G inline
-// host emulation runtime (csrc/kuka_hostcheck.cpp): the calling fiber's lane, a lockstep value exchange, a group vote
-int host_lane();
-double host_exchange(double x, int src);
-uint32_t host_ballot(bool p);
-SRL_G int lane_id() { return host_lane(); }
-template <int J> SRL_G double bcast(double x) { return host_exchange(x, J); }
-template <int D> SRL_G double shr(double x, double fill) {
-    const int l = host_lane();
-    const double v = host_exchange(x, l >= D ? l - D : l);
-    return l >= D ? v : fill;
+    return 1.0 / x;
+#endif
 }
-SRL_G uint32_t ballot(bool p) { return host_ballot(p); }
-SRL_G bool gany(bool p) { return host_ballot(p) != 0; }
-SRL_G bool wany(bool p) { return host_ballot(p) != 0; }
-SRL_G double shfl(double x, int src) { return host_exchange(x, src); }
-SRL_G void sync_scratch() { (void)host_ballot(false); }
-SRL_G double rcp(double x) { return 1.0 / x; }
-template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) { acc = fma(host_exchange(x, J), w, acc); }
-SRL_G double clamp01_add(double a, double b) { const double s = a + b; return s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s); }
-template <int J> SRL_G void pgs_row(double &acc, double t, double n, double ep) {
+// acc += w * bcast<J>(x) in one v_fmac_f64_dpp; `s_nop 1` = the two wait states a DPP read needs after a VALU write of x
+template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) {
+#if SRL_G_DEVICE
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
+#else
+    acc = fma(host_exchange(x, J), w, acc);
+#endif
+}
+SRL_G double clamp01(double s) { return s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s); }
+// One projected Gauss-Seidel row update (file header), rows in [0, 1] units:
+//     t = clamp01(cs + acc);  acc -= ep * acc;  acc += n * bcast<J>(t)        -> returns t (only lane J's t means something)
+// i.e. v_add_f64 ... clamp / v_fma_f64 / v_fmac_f64_dpp.  The reset FMA and one s_nop are the two wait states a DPP read of
+// t needs after the VALU write of t.  Each row is ONE asm statement so that nothing else is scheduled into it.
+template <int J> SRL_G double pgs_row(double &acc, double cs, double n, double ep) {
+#if SRL_G_DEVICE
+    double t;
+    asm volatile("v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%4, %0, %0\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc), "=&v"(t) : "v"(cs), "v"(n), "v"(ep), "n"(J));
+    return t;
+#else
+    const double t = clamp01(cs + acc);
     acc = fma(-ep, acc, acc);
     acc = fma(host_exchange(t, J), n, acc);
+    return t;
+#endif
 }
-template <int J, int J2> SRL_G void pgs_row2(double &acc, double t, double n, double n2, double ep) {
+// two mutually decoupled rows (lanes J and J2) updated by the same instructions
+template <int J, int J2> SRL_G double pgs_row2(double &acc, double cs, double n, double n2, double ep) {
+#if SRL_G_DEVICE
+    double t;
+    asm volatile("v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%5, %0, %0\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc), "=&v"(t) : "v"(cs), "v"(n), "v"(n2), "v"(ep), "n"(J), "n"(J2));
+    return t;
+#else
+    const double t = clamp01(cs + acc);
     acc = fma(-ep, acc, acc);
     const double a = host_exchange(t, J), b = host_exchange(t, J2);
     acc = fma(a, n, acc);
     acc = fma(b, n2, acc);
-}
+    return t;
 #endif
+}
 
 // ------------------------------------------------------------------ per-lane constants
 struct Lane {
@@ -275,65 +316,89 @@ struct Rows {
 };
 
 // fast path: no generic row in the wavefront.  The button's three scalar rows (lanes 8, 9, 10) are decoupled from the
-// arm rows, so arm row j and button row 8 + j are updated by the same instructions for j < 3.
+// arm rows, so arm row j and button row 8 + j are updated by the same instructions for j < 3.  One sweep = 24 VALU
+// instructions; the whole sweep is one asm statement (the compiler pads every asm boundary with wait states).
+SRL_G void pgs_sweep_free(double &acc, double cs, const double n[GL], const double e[GL], double e0, double e1, double e2, double ep_first) {
+#if SRL_G_DEVICE
+    double t;
+#define SRL_ROW(J, NJ, EP) "v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%" #EP ", %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %" #NJ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define SRL_ROWB(J, NJ) "v_fmac_f64_dpp %0, %1, %" #NJ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile(SRL_ROW(0, 3, 13) SRL_ROWB(8, 10)
+                 SRL_ROW(1, 4, 14) SRL_ROWB(9, 11)
+                 SRL_ROW(2, 5, 15) SRL_ROWB(10, 12)
+                 SRL_ROW(3, 6, 16) SRL_ROW(4, 7, 17) SRL_ROW(5, 8, 18) SRL_ROW(6, 9, 19)
+                 : "+v"(acc), "=&v"(t)
+                 : "v"(cs), "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]),      // %2 .. %9
+                   "v"(n[kBM]), "v"(n[kBLo]), "v"(n[kBHi]),                                                      // %10 .. %12
+                   "v"(ep_first), "v"(e0), "v"(e1), "v"(e2), "v"(e[3]), "v"(e[4]), "v"(e[5]));                   // %13 .. %19
+#undef SRL_ROW
+#undef SRL_ROWB
+#else
+    pgs_row2<0, kBM>(acc, cs, n[0], n[kBM], ep_first);
+    pgs_row2<1, kBLo>(acc, cs, n[1], n[kBLo], e0);
+    pgs_row2<2, kBHi>(acc, cs, n[2], n[kBHi], e1);
+    pgs_row<3>(acc, cs, n[3], e2); pgs_row<4>(acc, cs, n[4], e[3]); pgs_row<5>(acc, cs, n[5], e[4]); pgs_row<6>(acc, cs, n[6], e[5]);
+#endif
+}
 SRL_G double pgs_sweeps_free(const Lane &L, const Rows &r) {
-    double acc = r.acc0, t = 0.0, u = 0.0;
+    double acc = r.acc0, u = 0.0, t;
     const double e0 = L.e[0] + L.e[kBM], e1 = L.e[1] + L.e[kBLo], e2 = L.e[2] + L.e[kBHi];
-    double ep = 0.0;       // mask of the row whose accumulator is reset next (the row updated last)
-#define SRL_SWEEP(LASTSWEEP)                                                                     \
-    t = clamp01_add(r.cs, acc); pgs_row2<0, kBM>(acc, t, r.n[0], r.n[kBM], ep);   if (LASTSWEEP) u = fma(e0, t, u);      \
-    t = clamp01_add(r.cs, acc); pgs_row2<1, kBLo>(acc, t, r.n[1], r.n[kBLo], e0); if (LASTSWEEP) u = fma(e1, t, u);      \
-    t = clamp01_add(r.cs, acc); pgs_row2<2, kBHi>(acc, t, r.n[2], r.n[kBHi], e1); if (LASTSWEEP) u = fma(e2, t, u);      \
-    t = clamp01_add(r.cs, acc); pgs_row<3>(acc, t, r.n[3], e2);                   if (LASTSWEEP) u = fma(L.e[3], t, u);  \
-    t = clamp01_add(r.cs, acc); pgs_row<4>(acc, t, r.n[4], L.e[3]);               if (LASTSWEEP) u = fma(L.e[4], t, u);  \
-    t = clamp01_add(r.cs, acc); pgs_row<5>(acc, t, r.n[5], L.e[4]);               if (LASTSWEEP) u = fma(L.e[5], t, u);  \
-    t = clamp01_add(r.cs, acc); pgs_row<6>(acc, t, r.n[6], L.e[5]);               if (LASTSWEEP) u = fma(L.e[6], t, u);  \
-    ep = L.e[6];
-    for (int it = 0; it < kSolverIters - 1; it++) { SRL_SWEEP(false) }
-    SRL_SWEEP(true)
-#undef SRL_SWEEP
+    pgs_sweep_free(acc, r.cs, r.n, L.e, e0, e1, e2, 0.0);          // first sweep: nothing to reset yet
+    for (int it = 1; it < kSolverIters - 1; it++) pgs_sweep_free(acc, r.cs, r.n, L.e, e0, e1, e2, L.e[6]);
+    // last sweep row by row: every lane keeps the value of its own row
+    t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], L.e[6]);  u = fma(e0, t, u);
+    t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);    u = fma(e1, t, u);
+    t = pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);    u = fma(e2, t, u);
+    t = pgs_row<3>(acc, r.cs, r.n[3], e2);                      u = fma(L.e[3], t, u);
+    t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);                  u = fma(L.e[4], t, u);
+    t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);                  u = fma(L.e[5], t, u);
+    t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);                  u = fma(L.e[6], t, u);
     return u;
 }
 
-template <int G> SRL_G void pgs_generic_phase(const Lane &L, const Rows &r, double &acc, double &t, double &u, double &ep, uint32_t wave_slots,
-                                              double act, bool last) {
+// A generic row (slot G, lane kGenLane[G]) in one of the two phases of the general sweep.  act = 1 on lanes whose row
+// belongs to this phase: the others broadcast nothing and keep their accumulator.
+template <int G, bool LAST> SRL_G void pgs_generic_phase(const Lane &L, const Rows &r, double &acc, double &u, double &ep, uint32_t wave_slots, double act) {
     if (wave_slots & (1u << G)) {            // wave-uniform: some env of this wavefront has a row in slot G
         constexpr int J = kGenLane[G];
-        t = clamp01_add(r.cs, acc) * act;    // rows that do not belong to this phase broadcast nothing ...
-        pgs_row<J>(acc, t, r.n[J], ep);
-        ep = L.e[J] * act;                   // ... and keep their accumulator
-        if (last) u = fma(ep, t, u);
+        // (1 - act) * 1e300 pushes the residual of a row outside its phase below 0: it broadcasts t = 0
+        const double t = pgs_row<J>(acc, r.cs - (1.0 - act) * 1e300, r.n[J], ep);
+        ep = L.e[J] * act;
+        if (LAST) u = fma(ep, t, u);
     }
-    if constexpr (G + 1 < kMaxGenRows) pgs_generic_phase<G + 1>(L, r, acc, t, u, ep, wave_slots, act, last);
+    if constexpr (G + 1 < kMaxGenRows) pgs_generic_phase<G + 1, LAST>(L, r, acc, u, ep, wave_slots, act);
 }
 
-// general path: arm motors, button motor, [arm joint limits], button stops, [contacts] — Bullet's row order.
+// general sweep: arm motors, button motor, [arm joint limits], button stops, [contacts] — Bullet's row order.
+template <bool LAST> SRL_G void pgs_sweep_general(const Lane &L, const Rows &r, double &acc, double &u, double &ep, uint32_t wave_slots, bool has_lim,
+                                                  double in_lim, double in_con) {
+    double t;
+    t = pgs_row<0>(acc, r.cs, r.n[0], ep);       if (LAST) u = fma(L.e[0], t, u);
+    t = pgs_row<1>(acc, r.cs, r.n[1], L.e[0]);   if (LAST) u = fma(L.e[1], t, u);
+    t = pgs_row<2>(acc, r.cs, r.n[2], L.e[1]);   if (LAST) u = fma(L.e[2], t, u);
+    t = pgs_row<3>(acc, r.cs, r.n[3], L.e[2]);   if (LAST) u = fma(L.e[3], t, u);
+    t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);   if (LAST) u = fma(L.e[4], t, u);
+    t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);   if (LAST) u = fma(L.e[5], t, u);
+    t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);   if (LAST) u = fma(L.e[6], t, u);
+    t = pgs_row<kBM>(acc, r.cs, r.n[kBM], L.e[6]); if (LAST) u = fma(L.e[kBM], t, u);
+    ep = L.e[kBM];
+    if (has_lim) pgs_generic_phase<0, LAST>(L, r, acc, u, ep, wave_slots, in_lim);
+    t = pgs_row<kBLo>(acc, r.cs, r.n[kBLo], ep);        if (LAST) u = fma(L.e[kBLo], t, u);
+    t = pgs_row<kBHi>(acc, r.cs, r.n[kBHi], L.e[kBLo]); if (LAST) u = fma(L.e[kBHi], t, u);
+    ep = L.e[kBHi];
+    pgs_generic_phase<0, LAST>(L, r, acc, u, ep, wave_slots, in_con);
+}
 // wave_slots: bit g = some env of the wavefront uses generic slot g; nlim = joint-limit rows of THIS env (they fill
 // the first slots); has_lim: some env of the wavefront has a joint-limit row.
 SRL_G double pgs_sweeps_general(const Lane &L, const Rows &r, uint32_t wave_slots, int nlim, bool has_lim) {
-    double acc = r.acc0, t = 0.0, u = 0.0, ep = 0.0;
+    double acc = r.acc0, u = 0.0, ep = 0.0;
     // a generic row takes part in the limit phase iff its slot index < nlim, else in the contact phase
     int slot = -1;
 #pragma unroll
     for (int g = 0; g < kMaxGenRows; g++) if (L.l == kGenLane[g]) slot = g;
     const double in_lim = (slot >= 0 && slot < nlim) ? 1.0 : 0.0, in_con = (slot >= 0 && slot >= nlim) ? 1.0 : 0.0;
-    for (int it = 0; it < kSolverIters; it++) {
-        const bool last = it == kSolverIters - 1;
-        t = clamp01_add(r.cs, acc); pgs_row<0>(acc, t, r.n[0], ep);     if (last) u = fma(L.e[0], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<1>(acc, t, r.n[1], L.e[0]); if (last) u = fma(L.e[1], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<2>(acc, t, r.n[2], L.e[1]); if (last) u = fma(L.e[2], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<3>(acc, t, r.n[3], L.e[2]); if (last) u = fma(L.e[3], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<4>(acc, t, r.n[4], L.e[3]); if (last) u = fma(L.e[4], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<5>(acc, t, r.n[5], L.e[4]); if (last) u = fma(L.e[5], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<6>(acc, t, r.n[6], L.e[5]); if (last) u = fma(L.e[6], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<kBM>(acc, t, r.n[kBM], L.e[6]); if (last) u = fma(L.e[kBM], t, u);
-        ep = L.e[kBM];
-        if (has_lim) pgs_generic_phase<0>(L, r, acc, t, u, ep, wave_slots, in_lim, last);
-        t = clamp01_add(r.cs, acc); pgs_row<kBLo>(acc, t, r.n[kBLo], ep);       if (last) u = fma(L.e[kBLo], t, u);
-        t = clamp01_add(r.cs, acc); pgs_row<kBHi>(acc, t, r.n[kBHi], L.e[kBLo]); if (last) u = fma(L.e[kBHi], t, u);
-        ep = L.e[kBHi];
-        pgs_generic_phase<0>(L, r, acc, t, u, ep, wave_slots, in_con, last);
-    }
+    for (int it = 0; it < kSolverIters - 1; it++) pgs_sweep_general<false>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con);
+    pgs_sweep_general<true>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con);
     return u;
 }
 

@@ -296,3 +296,47 @@ def test_rand_button_env():
     ret, length, fin = h.episode_stats()
     assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)) and fin.min() >= 1
     h.close()
+
+
+@pytest.mark.parametrize("kernel", ["lane", "group"])
+def test_both_kernels_at_the_headline_size(kernel, monkeypatch):
+    """The library picks the lane-group kernel (16 lanes per env, kuka_group.hpp) for batches up to 16384 envs and the
+    lane-per-env kernel (kuka_core.hpp) above; SRLHIP_KUKA_KERNEL forces one.  Both against the oracle at 4096 envs, in
+    the throughput mode (Philox streams, device-sampled actions), through two auto-resets per env."""
+    monkeypatch.setenv("SRLHIP_KUKA_KERNEL", kernel)
+    n, T = 4096, 1100
+    h = make(n, rng_mode=_lib.RNG_PHILOX, seed0=11)
+    obs0 = h.reset()
+    out = h.rollout(T)
+    ora = kuka_clib.rollout(11 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False)
+    assert np.array_equal(ora["actions"], out["actions"])
+    check_planes(ora, obs0, out)
+    assert np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, :7]).max() <= TOL
+    ret, length, fin = h.episode_stats()
+    assert np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32)) and fin.min() >= 1
+    h.close()
+
+
+def test_kernels_agree_on_state_handover():
+    """A rollout may be continued by the other kernel: both read and write the same state planes."""
+    import os
+    n, T = 512, 300
+    actions = np.random.RandomState(21).randint(6, size=(2 * T, n)).astype(np.int32)
+    actions[np.random.RandomState(22).rand(2 * T, n) < 0.3] = 4
+    outs = []
+    for first, second in (("group", "lane"), ("lane", "group")):
+        h = make(n, seed0=5)
+        h.reset()
+        os.environ["SRLHIP_KUKA_KERNEL"] = first
+        a = h.rollout(T, actions=actions[:T])
+        os.environ["SRLHIP_KUKA_KERNEL"] = second
+        b = h.rollout(T, actions=actions[T:])
+        os.environ.pop("SRLHIP_KUKA_KERNEL")
+        outs.append((a, b, h.get_state(_lib.F_KUKA_Q)))
+        h.close()
+    ora = kuka_clib.rollout(5 + np.arange(n), 2 * T, actions=actions, trace=False)
+    for a, b, q in outs:
+        assert np.array_equal(np.concatenate([a["done"], b["done"]]), ora["done"])
+        assert np.array_equal(np.concatenate([a["reward"], b["reward"]]), ora["reward"])
+        assert np.abs(np.concatenate([a["obs"], b["obs"]]) - ora["obs"]).max() <= TOL
+        assert np.abs(q.T - ora["final_state"][:, :7]).max() <= TOL
