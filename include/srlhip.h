@@ -215,6 +215,12 @@ int srlhip_graph_end(srlhip_handle h, srlhip_graph_handle *out);
 int srlhip_graph_launch(srlhip_handle h, srlhip_graph_handle g);
 int srlhip_graph_destroy(srlhip_graph_handle g);
 
+/* Diagnostic: runs every cross-lane primitive of the lane-group Kuka kernel (csrc/kuka_group.hpp: DPP row broadcasts and
+ * shifts, row votes, the fused solver-row instructions, the lane-parallel Gauss-Jordan, the prefix-composed forward
+ * kinematics for joint angles q7) on one wavefront of device_id and returns their per-lane results, out[40][64] doubles.
+ * tests/test_gpu_group_primitives.py checks them against the definitions the CPU-side emulation of the same source uses. */
+int srlhip_selftest_group_primitives(int32_t device_id, const double *q7, double *out, int32_t out_doubles);
+
 const char *srlhip_last_error(srlhip_handle h);
 int srlhip_abi_version(void);
 

@@ -343,6 +343,53 @@ __global__ void kuka_refresh_k(KukaState s, int n) {
     store_env<1>(s, n, e, v);
 }
 
+
+// Self-test of the lane-group primitives on the device (tests/test_gpu_group_primitives.py compares with what the host
+// emulation of the same source defines): one wavefront, out[k][lane].
+constexpr int kProbeRows = 40;
+__global__ void __launch_bounds__(64) kuka_group_probe_k(const double *q7, double *out) {
+    using namespace grp;
+    const int t = threadIdx.x;
+    Lane L; lane_init(L);
+    const double x = 1.5 * t + 0.25;
+    int k = 0;
+#define SRL_OUT(v) out[(k++) * 64 + t] = (v);
+    SRL_OUT((double)L.l)
+    SRL_OUT(bcast<3>(x)) SRL_OUT(bcast<15>(x))
+    SRL_OUT(shr<1>(x, -1.0)) SRL_OUT(shr<2>(x, -2.0)) SRL_OUT(shr<4>(x, -4.0))
+    SRL_OUT((double)ballot(t % 3 == 0)) SRL_OUT(gany(t == 37) ? 1.0 : 0.0) SRL_OUT(wany(t == 37) ? 1.0 : 0.0)
+    { double acc = (double)t; fmac_bcast<5>(acc, x, 2.0); SRL_OUT(acc) }
+    { double acc = 0.125 * t; const double tt = pgs_row<2>(acc, 0.125 * (t & 15) - 0.25, 0.5, t % 16 == 4 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
+    { double acc = 0.125 * t; const double tt = pgs_row2<1, 9>(acc, 0.25 * (t & 15) - 0.5, 0.5, t % 16 >= 8 ? 0.25 : 0.0, t % 16 == 0 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
+    SRL_OUT(rcp(x + 1.0))
+    SRL_OUT(masked_sum(x, L.le)) SRL_OUT(masked_sum(x, L.ge, 3.0))
+    {
+        double A[ND];
+#pragma unroll
+        for (int c = 0; c < ND; c++) A[c] = L.arm ? (c == L.l ? 4.0 + L.l : 1.0 / (1.0 + L.l + c)) : 0.0;      // SPD, row l on lane l
+        double b = L.arm ? 1.0 + L.l : 0.0, unused = 0.0, B[ND];
+#pragma unroll
+        for (int c = 0; c < ND; c++) B[c] = A[c];
+        gj_step<0, false>(L, B, b);
+        SRL_OUT(b)
+        gj_step<0, true>(L, A, unused);
+#pragma unroll
+        for (int c = 0; c < ND; c++) SRL_OUT(A[c])
+    }
+    {
+        GState g; Env e = {};
+        g.q = L.arm ? q7[L.l] : 0.0; g.qd = 0.0;
+        grefresh(L, g, e);
+#pragma unroll
+        for (int c = 0; c < 9; c++) SRL_OUT(g.R[c])
+#pragma unroll
+        for (int c = 0; c < 3; c++) SRL_OUT(g.p[c])
+#pragma unroll
+        for (int c = 0; c < 3; c++) SRL_OUT(e.grip[c])
+    }
+#undef SRL_OUT
+}
+
 KukaParams params_of(const Handle *h) {
     KukaParams p;
     const srlhip_config &c = h->cfg;
@@ -510,6 +557,19 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     v->b2q = s->d + D_B2Q * n; v->b2x = s->d + D_B2X * n; v->b2y = s->d + D_B2Y * n;
     v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
     v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
+}
+
+int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles) {
+    if (out_doubles < kProbeRows * 64) return SRLHIP_EINVAL;
+    double *dq = nullptr, *dout = nullptr;
+    if (hipMalloc(&dq, 7 * sizeof(double)) != hipSuccess || hipMalloc(&dout, kProbeRows * 64 * sizeof(double)) != hipSuccess) return SRLHIP_ENOMEM;
+    (void)hipMemcpy(dq, q7_host, 7 * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemset(dout, 0, kProbeRows * 64 * sizeof(double));
+    hipLaunchKernelGGL(kuka_group_probe_k, dim3(1), dim3(64), 0, 0, dq, dout);
+    const hipError_t err = hipDeviceSynchronize();
+    (void)hipMemcpy(out_host, dout, kProbeRows * 64 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dq); (void)hipFree(dout);
+    return err == hipSuccess ? 0 : SRLHIP_EHIP;
 }
 
 int kuka_refresh(Handle *h) {

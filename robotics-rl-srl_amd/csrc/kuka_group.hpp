@@ -171,8 +171,9 @@ struct Lane {
     double ge[ND];            // ge[k] = (k >= l)   suffix masks (0 on non-arm lanes)
     double mass, mcomp;       // link mass, composite mass of links l..6
     double com[3], in[3];     // centre of mass and principal inertia in the link frame
-    double len;               // joint origin translation along the parent's y (axis 1) or z (axis 2)
-    int fix, axis;
+    // joint frame in the parent link's frame, branch-free: columns x' = (sx c, f0 s, (1-f0) s), y' = (-sx s, f0 c, (1-f0) c),
+    // z' = (0, zy, f0); origin t.  (kFix 0: Rz(q); 1: rpy (pi/2,0,pi) Rz(q); 2: rpy (pi/2,0,0) Rz(q); identity off the arm)
+    double sx, f0, zy, t[3];
     double jlo, jhi, q0;      // joint limits, kJointPositions[l]
     double sph[4];            // l < 6: gripper sphere l (centre in the link-7 frame, radius)
 };
@@ -191,7 +192,11 @@ SRL_G void lane_init(Lane &L) {
     L.mass = L.arm ? kMass[i] : 0.0; L.mcomp = L.arm ? mc : 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) { L.com[k] = kCom[i][k]; L.in[k] = L.arm ? kInertia[i][k] : 0.0; }
-    L.len = L.arm ? kTransLen[i] : 0.0; L.fix = kFix[i]; L.axis = kTransAxis[i];
+    const int fix = L.arm ? kFix[i] : 0, axis = kTransAxis[i];
+    const double len = L.arm ? kTransLen[i] : 0.0;
+    L.sx = fix == 1 ? -1.0 : 1.0; L.f0 = fix == 0 ? 1.0 : 0.0; L.zy = fix == 1 ? 1.0 : fix == 2 ? -1.0 : 0.0;
+    L.t[0] = l == 0 ? kBasePos[0] : 0.0; L.t[1] = (l == 0 ? kBasePos[1] : 0.0) + (axis == 1 ? len : 0.0);
+    L.t[2] = (l == 0 ? kBasePos[2] : 0.0) + (axis == 2 ? len : 0.0);
     L.jlo = kJointLower[i]; L.jhi = kJointUpper[i]; L.q0 = kJointPositions[i];
     const int s = l < kNSphere ? l : 0;
 #pragma unroll
@@ -216,16 +221,12 @@ SRL_G void compose(const double Ra[9], const double pa[3], const double Rb[9], c
 
 // Forward kinematics of the whole chain: local joint transform per lane, inclusive prefix composition over the row.
 SRL_G void gfk(const Lane &L, GState &g) {
-    const double s = g.sq, c = g.cq;
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
-    if (L.arm) {
-        // columns of the joint frame in the parent link's frame: fixed signed permutation (URDF rpy) times Rz(q)
-        if (L.fix == 0) { R[0] = c; R[1] = s; R[2] = 0; R[3] = -s; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1; }
-        else if (L.fix == 1) { R[0] = -c; R[1] = 0; R[2] = s; R[3] = s; R[4] = 0; R[5] = c; R[6] = 0; R[7] = 1; R[8] = 0; }
-        else { R[0] = c; R[1] = 0; R[2] = s; R[3] = -s; R[4] = 0; R[5] = c; R[6] = 0; R[7] = -1; R[8] = 0; }
-        if (L.axis == 2) p[2] = L.len; else p[1] = L.len;
-        if (L.l == 0) { p[0] += kBasePos[0]; p[1] += kBasePos[1]; p[2] += kBasePos[2]; }
-    }
+    const double s = g.sq, c = g.cq, f1 = 1.0 - L.f0;      // lanes off the arm carry s = 0, c = 1: the identity
+    double R[9], p[3];
+    R[0] = L.sx * c; R[1] = L.f0 * s; R[2] = f1 * s;
+    R[3] = -(L.sx * s); R[4] = L.f0 * c; R[5] = f1 * c;
+    R[6] = 0.0; R[7] = L.zy; R[8] = L.f0;
+    p[0] = L.t[0]; p[1] = L.t[1]; p[2] = L.t[2];
 #define SRL_SCAN(D)                                                                              \
     {                                                                                            \
         double Ra[9], pa[3], Ro[9], po[3];                                                       \

@@ -37,7 +37,7 @@ EXPORTS = [
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
-    "srlhip_timing_end", "srlhip_last_error",
+    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
@@ -98,6 +98,7 @@ def load():
     lib.srlhip_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
     lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
     lib.srlhip_episode_stats_device.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_selftest_group_primitives.argtypes = [i32, vp, vp, i32]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
