@@ -236,7 +236,10 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
 constexpr int kGroupBlock = 64;
 constexpr int kGroupEnvs = kGroupBlock / grp::GL;
 
-template <int MODE>
+// GIVEN: the caller supplies the actions.  A compile-time switch because a possible action load inside the step loop makes
+// the compiler wait for vmcnt(0) every step — which on gfx9 also waits for the previous step's output STORES to retire
+// (loads and stores share the counter): the random-agent variant has no load in its loop and never waits on memory.
+template <int MODE, bool JOINTS, bool GIVEN>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                      float *obs, float *rew, uint8_t *done_out, void *act_out) {
@@ -278,7 +281,7 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
     for (int t = 0; t < T; t++) {
         const int64_t row = (int64_t)t * n + e;
         int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (actions) {
+        if constexpr (GIVEN) {
             if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
             else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
         } else {
@@ -305,8 +308,11 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
                 double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
-                else genv_reset(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
+                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS>(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
+                else genv_reset<JOINTS>(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
+                // the start-state loads retire HERE: otherwise the wait for them lands at their first use in the next step, on
+                // every path, where vmcnt(0) also waits for the output stores of steps that did not reset
+                __builtin_amdgcn_s_waitcnt(0x0F70);
             }
         }
         if (lead) {
@@ -315,6 +321,13 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
             if (done_out) done_out[row] = (uint8_t)done;
         }
     }
+    // (the exit stores recompute their plane addresses from an opaque copy of the env index: otherwise the ~25 addresses
+    //  formed for the entry loads stay live across the whole rollout loop and push its working set into scratch)
+    int e_out = e;
+    asm volatile("" : "+v"(e_out));
+    const int e_in = e;
+    (void)e_in;
+#define e e_out
     if (valid && L.arm) {
         s.d[(D_Q + L.l) * n + e] = g.q; s.d[(D_QD + L.l) * n + e] = g.qd; s.d[(D_SQ + L.l) * n + e] = g.sq; s.d[(D_CQ + L.l) * n + e] = g.cq;
     }
@@ -327,10 +340,11 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
         s.i[I_TERM * n + e] = v.terminated;
         krng_store<MODE>(rng0, rs, e);
-        if (!actions) rs.act_ctr[e] = act.ctr;
+        if constexpr (!GIVEN) rs.act_ctr[e] = act.ctr;
         st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
         st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
     }
+#undef e
 }
 
 // after srlhip_set_state(KUKA_Q): refresh the cached sin/cos and the gripper position
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__(64) kuka_group_probe_k(const double *q7, doubl
     { double acc = 0.125 * t; const double tt = pgs_row<2>(acc, 0.125 * (t & 15) - 0.25, 0.5, t % 16 == 4 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
     { double acc = 0.125 * t; const double tt = pgs_row2<1, 9>(acc, 0.25 * (t & 15) - 0.5, 0.5, t % 16 >= 8 ? 0.25 : 0.0, t % 16 == 0 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
     SRL_OUT(rcp(x + 1.0))
-    SRL_OUT(masked_sum(x, L.le)) SRL_OUT(masked_sum(x, L.ge, 3.0))
+    { Masks M; make_masks(L.l, M); SRL_OUT(masked_sum(x, M.le)) SRL_OUT(masked_sum(x, M.ge, 3.0)) }
     {
         double A[ND];
 #pragma unroll
@@ -487,7 +501,12 @@ static bool use_group_kernel(const Handle *h) {
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
-#define SRL_GROUP(MODE) hipLaunchKernelGGL((kuka_group_rollout_k<MODE>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+#define SRL_GROUP(MODE)                                                                                                             \
+    if (joints && d_actions) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, true, true>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
+    else if (joints) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, true, false>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
+    else if (d_actions) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, false, true>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
+    else hipLaunchKernelGGL((kuka_group_rollout_k<MODE, false, false>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_GROUP(SRLHIP_RNG_PHILOX); break;
         case SRLHIP_RNG_MT19937: SRL_GROUP(SRLHIP_RNG_MT19937); break;

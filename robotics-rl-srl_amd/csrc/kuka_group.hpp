@@ -118,7 +118,9 @@ SRL_G double rcp(double x) {          // ~1 ulp reciprocal: v_rcp_f64 + two Newt
 // acc += w * bcast<J>(x) in one v_fmac_f64_dpp; `s_nop 1` = the two wait states a DPP read needs after a VALU write of x
 template <int J> SRL_G void fmac_bcast(double &acc, double x, double w) {
 #if SRL_G_DEVICE
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
+    // (not volatile: a pure function of its operands, so independent chains of these can be interleaved by the scheduler —
+    //  a dependent f64 instruction issues every ~9 cycles on gfx950, an independent one every ~5)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
 #else
     acc = fma(host_exchange(x, J), w, acc);
 #endif
@@ -162,13 +164,12 @@ template <int J, int J2> SRL_G double pgs_row2(double &acc, double cs, double n,
 }
 
 // ------------------------------------------------------------------ per-lane constants
+// Kept in registers for the whole rollout, so only what every step needs; chain masks are rebuilt per step (Masks).
 struct Lane {
     int l;
     bool arm;                 // l < 7: owns a joint / link
     double am;                // 1.0 on arm lanes
-    double e[GL];             // e[j] = (l == j)
-    double le[ND];            // le[k] = (k <= l)   prefix masks over the chain
-    double ge[ND];            // ge[k] = (k >= l)   suffix masks (0 on non-arm lanes)
+    double e[ND];             // e[j] = (l == j), j < 7
     double mass, mcomp;       // link mass, composite mass of links l..6
     double com[3], in[3];     // centre of mass and principal inertia in the link frame
     // joint frame in the parent link's frame, branch-free: columns x' = (sx c, f0 s, (1-f0) s), y' = (-sx s, f0 c, (1-f0) c),
@@ -182,9 +183,7 @@ SRL_G void lane_init(Lane &L) {
     const int l = lane_id();
     L.l = l; L.arm = l < ND; L.am = L.arm ? 1.0 : 0.0;
 #pragma unroll
-    for (int j = 0; j < GL; j++) L.e[j] = l == j ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < ND; k++) { L.le[k] = k <= l ? 1.0 : 0.0; L.ge[k] = (k >= l && L.arm) ? 1.0 : 0.0; }
+    for (int j = 0; j < ND; j++) L.e[j] = l == j ? 1.0 : 0.0;
     const int i = L.arm ? l : 0;
     double mc = 0.0;
 #pragma unroll
@@ -203,11 +202,21 @@ SRL_G void lane_init(Lane &L) {
     for (int k = 0; k < 4; k++) L.sph[k] = kSphere[s][k];
 }
 
+// prefix / suffix masks over the chain, rebuilt inside every step from an opaque copy of the lane index (kept out of the
+// rollout loop's live registers on purpose)
+struct Masks { double le[ND], ge[ND]; };     // le[k] = (k <= l);  ge[k] = (k >= l) on arm lanes, 0 elsewhere
+SRL_G void make_masks(int l, Masks &m) {
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(l));
+#endif
+#pragma unroll
+    for (int k = 0; k < ND; k++) { m.le[k] = k <= l ? 1.0 : 0.0; m.ge[k] = (k >= l && l < ND) ? 1.0 : 0.0; }
+}
+
 // ------------------------------------------------------------------ per-lane dynamic state kept across steps
 struct GState {
     double q, qd, sq, cq;      // own joint (arm lanes; 0 / 0 / 0 / 1 elsewhere)
     double R[9], p[3];         // world frame of the own link (columns x y z; lanes >= 7: unused)
-    double Rt[9], pt[3];       // world frame of link 7, replicated
 };
 
 SRL_G void compose(const double Ra[9], const double pa[3], const double Rb[9], const double pb[3], double Ro[9], double po[3]) {
@@ -239,16 +248,25 @@ SRL_G void gfk(const Lane &L, GState &g) {
     SRL_SCAN(1) SRL_SCAN(2) SRL_SCAN(4)
 #undef SRL_SCAN
 #pragma unroll
-    for (int k = 0; k < 9; k++) { g.R[k] = R[k]; g.Rt[k] = bcast<ND - 1>(R[k]); }
+    for (int k = 0; k < 9; k++) g.R[k] = R[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { g.p[k] = p[k]; g.pt[k] = bcast<ND - 1>(p[k]); }
+    for (int k = 0; k < 3; k++) g.p[k] = p[k];
+}
+// world frame of link 7, replicated on the row
+SRL_G void tip_frame(const GState &g, double Rt[9], double pt[3]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rt[k] = bcast<ND - 1>(g.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pt[k] = bcast<ND - 1>(g.p[k]);
 }
 
 // sin/cos of the own joint, frames, gripper position (what update_trig_and_gripper() does for the lane-per-env kernel)
 SRL_G void grefresh(const Lane &L, GState &g, Env &e) {
     if (L.arm) sincos(g.q, &g.sq, &g.cq); else { g.sq = 0.0; g.cq = 1.0; }
     gfk(L, g);
-    tip_point(g.Rt, g.pt, kGripperPoint, e.grip);
+    double Rt[9], pt[3];
+    tip_frame(g, Rt, pt);
+    tip_point(Rt, pt, kGripperPoint, e.grip);
 }
 
 // prefix / suffix sums over the chain by masked row broadcasts: out = base + sum_k m[k] * bcast_k(x)
@@ -291,12 +309,13 @@ template <int K> SRL_G void bcast_all_step(double x, double out[ND]) {
     if constexpr (K + 1 < ND) bcast_all_step<K + 1>(x, out);
 }
 
-template <int K> SRL_G void gram_step(const double J[6], double A[ND]) {
-    double a = 0.0;
+// out[K] = sum_c a[c] * bcast_K(b[c]) for K = 0..6: Gram rows (a = b = J) and the CRBA products S_K . (Ic S)
+template <int K> SRL_G void dot6_bcast_step(const double a[6], const double b[6], double out[ND]) {
+    double acc = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; c++) fmac_bcast<K>(a, J[c], J[c]);
-    A[K] = a;
-    if constexpr (K + 1 < ND) gram_step<K + 1>(J, A);
+    for (int c = 0; c < 6; c++) fmac_bcast<K>(acc, b[c], a[c]);
+    out[K] = acc;
+    if constexpr (K + 1 < ND) dot6_bcast_step<K + 1>(a, b, out);
 }
 
 template <int K> SRL_G void transpose_upper_step(const Lane &L, const double low[ND], double M[ND]) {
@@ -310,8 +329,8 @@ template <int K> SRL_G void transpose_upper_step(const Lane &L, const double low
 struct Rows {
     double acc0;               // the couplings to rows that come LATER in the first sweep, at their initial impulse 0
     double cs;                 // scaled constant term of the own row
-    double n[GL];              // scaled couplings -a_rk S_k / (a_rr S_r), n[own] = 0
-    double a[GL];              // unscaled row of A = J W J^T (arm lanes: what the velocity update needs)
+    double n[GL];              // scaled couplings -a_rk S_k / (a_rr S_r), n[own] = 0 (the free path touches 0..6 and 8..10 only)
+    double diag;               // a_rr
     double lo, S;              // lambda = lo + S u
     double jb;                 // the row's Jacobian entry on the button glider
 };
@@ -319,7 +338,7 @@ struct Rows {
 // fast path: no generic row in the wavefront.  The button's three scalar rows (lanes 8, 9, 10) are decoupled from the
 // arm rows, so arm row j and button row 8 + j are updated by the same instructions for j < 3.  One sweep = 24 VALU
 // instructions; the whole sweep is one asm statement (the compiler pads every asm boundary with wait states).
-SRL_G void pgs_sweep_free(double &acc, double cs, const double n[GL], const double e[GL], double e0, double e1, double e2, double ep_first) {
+SRL_G void pgs_sweep_free(double &acc, double cs, const double n[GL], const double e[ND], double e0, double e1, double e2, double ep_first) {
 #if SRL_G_DEVICE
     double t;
 #define SRL_ROW(J, NJ, EP) "v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%" #EP ", %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %" #NJ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
@@ -343,9 +362,15 @@ SRL_G void pgs_sweep_free(double &acc, double cs, const double n[GL], const doub
 }
 SRL_G double pgs_sweeps_free(const Lane &L, const Rows &r) {
     double acc = r.acc0, u = 0.0, t;
-    const double e0 = L.e[0] + L.e[kBM], e1 = L.e[1] + L.e[kBLo], e2 = L.e[2] + L.e[kBHi];
+    const double e0 = L.e[0] + (L.l == kBM ? 1.0 : 0.0), e1 = L.e[1] + (L.l == kBLo ? 1.0 : 0.0), e2 = L.e[2] + (L.l == kBHi ? 1.0 : 0.0);
     pgs_sweep_free(acc, r.cs, r.n, L.e, e0, e1, e2, 0.0);          // first sweep: nothing to reset yet
+#ifdef SRL_GDBG_FIXPOINT      // host harness only: at which sweep does the iteration reach a bitwise fixed point?
+    { int fixed_at = -1; double prev = acc;
+      for (int it = 1; it < kSolverIters - 1; it++) { pgs_sweep_free(acc, r.cs, r.n, L.e, e0, e1, e2, L.e[6]); const bool same = !gany(acc != prev); if (same && fixed_at < 0) fixed_at = it; if (!same) fixed_at = -1; prev = acc; }
+      if (L.l == 0) SRL_GDBG_FIXPOINT(fixed_at); }
+#else
     for (int it = 1; it < kSolverIters - 1; it++) pgs_sweep_free(acc, r.cs, r.n, L.e, e0, e1, e2, L.e[6]);
+#endif
     // last sweep row by row: every lane keeps the value of its own row
     t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], L.e[6]);  u = fma(e0, t, u);
     t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);    u = fma(e1, t, u);
@@ -364,7 +389,7 @@ template <int G, bool LAST> SRL_G void pgs_generic_phase(const Lane &L, const Ro
         constexpr int J = kGenLane[G];
         // (1 - act) * 1e300 pushes the residual of a row outside its phase below 0: it broadcasts t = 0
         const double t = pgs_row<J>(acc, r.cs - (1.0 - act) * 1e300, r.n[J], ep);
-        ep = L.e[J] * act;
+        ep = (L.l == J ? 1.0 : 0.0) * act;
         if (LAST) u = fma(ep, t, u);
     }
     if constexpr (G + 1 < kMaxGenRows) pgs_generic_phase<G + 1, LAST>(L, r, acc, u, ep, wave_slots, act);
@@ -372,7 +397,7 @@ template <int G, bool LAST> SRL_G void pgs_generic_phase(const Lane &L, const Ro
 
 // general sweep: arm motors, button motor, [arm joint limits], button stops, [contacts] — Bullet's row order.
 template <bool LAST> SRL_G void pgs_sweep_general(const Lane &L, const Rows &r, double &acc, double &u, double &ep, uint32_t wave_slots, bool has_lim,
-                                                  double in_lim, double in_con) {
+                                                  double in_lim, double in_con, double ebm, double eblo, double ebhi) {
     double t;
     t = pgs_row<0>(acc, r.cs, r.n[0], ep);       if (LAST) u = fma(L.e[0], t, u);
     t = pgs_row<1>(acc, r.cs, r.n[1], L.e[0]);   if (LAST) u = fma(L.e[1], t, u);
@@ -381,47 +406,100 @@ template <bool LAST> SRL_G void pgs_sweep_general(const Lane &L, const Rows &r, 
     t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);   if (LAST) u = fma(L.e[4], t, u);
     t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);   if (LAST) u = fma(L.e[5], t, u);
     t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);   if (LAST) u = fma(L.e[6], t, u);
-    t = pgs_row<kBM>(acc, r.cs, r.n[kBM], L.e[6]); if (LAST) u = fma(L.e[kBM], t, u);
-    ep = L.e[kBM];
+    t = pgs_row<kBM>(acc, r.cs, r.n[kBM], L.e[6]); if (LAST) u = fma(ebm, t, u);
+    ep = ebm;
     if (has_lim) pgs_generic_phase<0, LAST>(L, r, acc, u, ep, wave_slots, in_lim);
-    t = pgs_row<kBLo>(acc, r.cs, r.n[kBLo], ep);        if (LAST) u = fma(L.e[kBLo], t, u);
-    t = pgs_row<kBHi>(acc, r.cs, r.n[kBHi], L.e[kBLo]); if (LAST) u = fma(L.e[kBHi], t, u);
-    ep = L.e[kBHi];
+    t = pgs_row<kBLo>(acc, r.cs, r.n[kBLo], ep);   if (LAST) u = fma(eblo, t, u);
+    t = pgs_row<kBHi>(acc, r.cs, r.n[kBHi], eblo); if (LAST) u = fma(ebhi, t, u);
+    ep = ebhi;
     pgs_generic_phase<0, LAST>(L, r, acc, u, ep, wave_slots, in_con);
 }
+// The common contact case — no joint-limit row in the wavefront and at most two contact rows per env (slots 0, 1 = lanes 7,
+// 11): arm motors, button motor and stops, contacts, one asm statement per sweep like the free path.  TWO = slot 1 in use.
+template <bool TWO>
+SRL_G void pgs_sweep_contact(double &acc, double cs, const double n[GL], const double e[ND], double ebm, double eblo, double ebhi, double eg0,
+                             double ep_first) {
+#if SRL_G_DEVICE
+    double t;
+#define SRL_ROW(J, NJ, EP) "v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%" #EP ", %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %" #NJ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+    if constexpr (TWO) {
+        asm volatile(SRL_ROW(0, 3, 15) SRL_ROW(1, 4, 16) SRL_ROW(2, 5, 17) SRL_ROW(3, 6, 18) SRL_ROW(4, 7, 19) SRL_ROW(5, 8, 20) SRL_ROW(6, 9, 21)
+                     SRL_ROW(8, 10, 22) SRL_ROW(9, 11, 23) SRL_ROW(10, 12, 24) SRL_ROW(7, 13, 25) SRL_ROW(11, 14, 26)
+                     : "+v"(acc), "=&v"(t)
+                     : "v"(cs), "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]),      // %2 .. %9
+                       "v"(n[kBM]), "v"(n[kBLo]), "v"(n[kBHi]), "v"(n[7]), "v"(n[11]),                              // %10 .. %14
+                       "v"(ep_first), "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]),  // %15 .. %22
+                       "v"(ebm), "v"(eblo), "v"(ebhi), "v"(eg0));                                                    // %23 .. %26
+    } else {
+        asm volatile(SRL_ROW(0, 3, 14) SRL_ROW(1, 4, 15) SRL_ROW(2, 5, 16) SRL_ROW(3, 6, 17) SRL_ROW(4, 7, 18) SRL_ROW(5, 8, 19) SRL_ROW(6, 9, 20)
+                     SRL_ROW(8, 10, 21) SRL_ROW(9, 11, 22) SRL_ROW(10, 12, 23) SRL_ROW(7, 13, 24)
+                     : "+v"(acc), "=&v"(t)
+                     : "v"(cs), "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]),      // %2 .. %9
+                       "v"(n[kBM]), "v"(n[kBLo]), "v"(n[kBHi]), "v"(n[7]),                                          // %10 .. %13
+                       "v"(ep_first), "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]),  // %14 .. %21
+                       "v"(ebm), "v"(eblo), "v"(ebhi));                                                              // %22 .. %24
+    }
+#undef SRL_ROW
+#else
+    pgs_row<0>(acc, cs, n[0], ep_first); pgs_row<1>(acc, cs, n[1], e[0]); pgs_row<2>(acc, cs, n[2], e[1]); pgs_row<3>(acc, cs, n[3], e[2]);
+    pgs_row<4>(acc, cs, n[4], e[3]); pgs_row<5>(acc, cs, n[5], e[4]); pgs_row<6>(acc, cs, n[6], e[5]);
+    pgs_row<kBM>(acc, cs, n[kBM], e[6]); pgs_row<kBLo>(acc, cs, n[kBLo], ebm); pgs_row<kBHi>(acc, cs, n[kBHi], eblo);
+    pgs_row<7>(acc, cs, n[7], ebhi);
+    if (TWO) pgs_row<11>(acc, cs, n[11], eg0);
+#endif
+}
+template <bool TWO>
+SRL_G double pgs_sweeps_contact(const Lane &L, const Rows &r) {
+    double acc = r.acc0, u = 0.0, t;
+    const double ebm = L.l == kBM ? 1.0 : 0.0, eblo = L.l == kBLo ? 1.0 : 0.0, ebhi = L.l == kBHi ? 1.0 : 0.0;
+    const double eg0 = L.l == 7 ? 1.0 : 0.0, eg1 = L.l == 11 ? 1.0 : 0.0, elast = TWO ? eg1 : eg0;
+    pgs_sweep_contact<TWO>(acc, r.cs, r.n, L.e, ebm, eblo, ebhi, eg0, 0.0);
+    for (int it = 1; it < kSolverIters - 1; it++) pgs_sweep_contact<TWO>(acc, r.cs, r.n, L.e, ebm, eblo, ebhi, eg0, elast);
+    t = pgs_row<0>(acc, r.cs, r.n[0], elast);     u = fma(L.e[0], t, u);
+    t = pgs_row<1>(acc, r.cs, r.n[1], L.e[0]);    u = fma(L.e[1], t, u);
+    t = pgs_row<2>(acc, r.cs, r.n[2], L.e[1]);    u = fma(L.e[2], t, u);
+    t = pgs_row<3>(acc, r.cs, r.n[3], L.e[2]);    u = fma(L.e[3], t, u);
+    t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);    u = fma(L.e[4], t, u);
+    t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);    u = fma(L.e[5], t, u);
+    t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);    u = fma(L.e[6], t, u);
+    t = pgs_row<kBM>(acc, r.cs, r.n[kBM], L.e[6]);   u = fma(ebm, t, u);
+    t = pgs_row<kBLo>(acc, r.cs, r.n[kBLo], ebm);    u = fma(eblo, t, u);
+    t = pgs_row<kBHi>(acc, r.cs, r.n[kBHi], eblo);   u = fma(ebhi, t, u);
+    t = pgs_row<7>(acc, r.cs, r.n[7], ebhi);         u = fma(eg0, t, u);
+    if (TWO) { t = pgs_row<11>(acc, r.cs, r.n[11], eg0); u = fma(eg1, t, u); }
+    return u;
+}
+
 // wave_slots: bit g = some env of the wavefront uses generic slot g; nlim = joint-limit rows of THIS env (they fill
 // the first slots); has_lim: some env of the wavefront has a joint-limit row.
 SRL_G double pgs_sweeps_general(const Lane &L, const Rows &r, uint32_t wave_slots, int nlim, bool has_lim) {
+    if (!has_lim && wave_slots == 1u) return pgs_sweeps_contact<false>(L, r);
+    if (!has_lim && wave_slots == 3u) return pgs_sweeps_contact<true>(L, r);
     double acc = r.acc0, u = 0.0, ep = 0.0;
     // a generic row takes part in the limit phase iff its slot index < nlim, else in the contact phase
     int slot = -1;
 #pragma unroll
     for (int g = 0; g < kMaxGenRows; g++) if (L.l == kGenLane[g]) slot = g;
     const double in_lim = (slot >= 0 && slot < nlim) ? 1.0 : 0.0, in_con = (slot >= 0 && slot >= nlim) ? 1.0 : 0.0;
-    for (int it = 0; it < kSolverIters - 1; it++) pgs_sweep_general<false>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con);
-    pgs_sweep_general<true>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con);
+    const double ebm = L.l == kBM ? 1.0 : 0.0, eblo = L.l == kBLo ? 1.0 : 0.0, ebhi = L.l == kBHi ? 1.0 : 0.0;
+    for (int it = 0; it < kSolverIters - 1; it++) pgs_sweep_general<false>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con, ebm, eblo, ebhi);
+    pgs_sweep_general<true>(L, r, acc, u, ep, wave_slots, has_lim, in_lim, in_con, ebm, eblo, ebhi);
     return u;
 }
 
 // ------------------------------------------------------------------ one physics step
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation(), same semantics as physics_step<1>() of kuka_core.hpp.
 // `e` holds the env's scalar state replicated on the 16 lanes (its q / qd / sq / cq arrays are not used here), `g` the
-// lane's own joint and frames (valid on entry: grefresh()), jt_own the joint-mode target of the own joint.
+// lane's own joint and frame (valid on entry: grefresh()), jt_own the joint-mode target of the own joint.
 SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode,
                          double jt_own) {
     const double dt = kDt;
-    // ---- spatial joint axes about the world origin, replicated: S_k = [z_k ; p_k x z_k]
-    double z[3], s2[3], Sz[ND][3], S2[ND][3];
+    // ---- spatial joint axis about the world origin: S = [z ; p x z]; link-7 frame replicated
+    double S[6], Rt[9], pt[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) z[k] = g.R[6 + k] * L.am;
-    cross3(g.p, z, s2);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double tz[ND], t2[ND];
-        bcast_all_step<0>(z[k], tz); bcast_all_step<0>(s2[k], t2);
-#pragma unroll
-        for (int j = 0; j < ND; j++) { Sz[j][k] = tz[j]; S2[j][k] = t2[j]; }
-    }
+    for (int k = 0; k < 3; k++) S[k] = g.R[6 + k] * L.am;
+    cross3(g.p, S, S + 3);
+    tip_frame(g, Rt, pt);
     // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step (kuka.py:144-156)
     double qdes = jt_own;
     if (!joint_mode) {
@@ -434,19 +512,19 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
             e.ee[k] = v;
         }
         double ee[3], dS[6], J[6];
-        tip_point(g.Rt, g.pt, kEePoint, ee);
+        tip_point(Rt, pt, kEePoint, ee);
         {
-            double d[3], c[3];
+            double d[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) d[k] = ee[k] - g.p[k];
-            cross3(z, d, c);
+            cross3(S, d, J);
 #pragma unroll
-            for (int k = 0; k < 3; k++) { J[k] = c[k]; J[3 + k] = z[k]; }
+            for (int k = 0; k < 3; k++) J[3 + k] = S[k];
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
         {   // orientation error (same construction as ik_step() of kuka_core.hpp), replicated
-            const double *R = g.Rt;
+            const double *R = Rt;
             double qx, qy, qz, qw;
             const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
             const double tr = m00 + m11 + m22;
@@ -469,7 +547,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         }
         // (J^T J + damping I) dtheta = J^T dS: row l on lane l
         double A[ND], bb = 0.0;
-        gram_step<0>(J, A);
+        dot6_bcast_step<0>(J, J, A);
         const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
 #pragma unroll
         for (int k = 0; k < ND; k++) A[k] = fma(damping, L.e[k], A[k]);
@@ -486,7 +564,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     }
     // ---- collision detection at the current poses: lane s < 6 owns gripper sphere s
     double cc[3], n_cap[3], n_base[3], d_cap = 1e30, d_base = 1e30;
-    tip_point(g.Rt, g.pt, L.sph, cc);
+    tip_point(Rt, pt, L.sph, cc);
     const bool sphere = L.l < kNSphere;
     const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
     if (sphere) {
@@ -501,67 +579,70 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     target = target < -kArmMaxVel ? -kArmMaxVel : target;
     // ---- dynamics in world coordinates: velocities and bias accelerations by prefix sums over the chain
     const double qd = g.qd * L.am;
-    double w[3], vo[3], aw[3], av[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { w[k] = masked_sum(z[k] * qd, L.le); vo[k] = masked_sum(s2[k] * qd, L.le); }
+    double W[ND], tau;
     {
-        double t0[3], t1[3], t2[3];
-        cross3(w, z, t0); cross3(w, s2, t1); cross3(vo, z, t2);
+        Masks M;
+        make_masks(L.l, M);
+        double w[3], vo[3], aw[3], av[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            aw[k] = masked_sum(t0[k] * qd, L.le);
-            av[k] = masked_sum((t1[k] + t2[k]) * qd, L.le, k == 2 ? -kGravityZ : 0.0);
+        for (int k = 0; k < 3; k++) { w[k] = masked_sum(S[k] * qd, M.le); vo[k] = masked_sum(S[3 + k] * qd, M.le); }
+        {
+            double t0[3], t1[3], t2[3];
+            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                aw[k] = masked_sum(t0[k] * qd, M.le);
+                av[k] = masked_sum((t1[k] + t2[k]) * qd, M.le, k == 2 ? -kGravityZ : 0.0);
+            }
         }
-    }
-    // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c, m
-    double Io[6], h[3];
-    {
-        const double *R = g.R;
-        double cw[3];
+        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c, m
+        double Io[6], h[3];
+        {
+            const double *R = g.R;
+            double cw[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) cw[k] = g.p[k] + R[k] * L.com[0] + R[3 + k] * L.com[1] + R[6 + k] * L.com[2];
-        const double m = L.mass, ccs = dot3(cw, cw);
-        const double ix = L.in[0], iy = L.in[1], iz = L.in[2];
-        Io[0] = ix * R[0] * R[0] + iy * R[3] * R[3] + iz * R[6] * R[6] + m * (ccs - cw[0] * cw[0]);
-        Io[1] = ix * R[0] * R[1] + iy * R[3] * R[4] + iz * R[6] * R[7] - m * cw[0] * cw[1];
-        Io[2] = ix * R[0] * R[2] + iy * R[3] * R[5] + iz * R[6] * R[8] - m * cw[0] * cw[2];
-        Io[3] = ix * R[1] * R[1] + iy * R[4] * R[4] + iz * R[7] * R[7] + m * (ccs - cw[1] * cw[1]);
-        Io[4] = ix * R[1] * R[2] + iy * R[4] * R[5] + iz * R[7] * R[8] - m * cw[1] * cw[2];
-        Io[5] = ix * R[2] * R[2] + iy * R[5] * R[5] + iz * R[8] * R[8] + m * (ccs - cw[2] * cw[2]);
+            for (int k = 0; k < 3; k++) cw[k] = g.p[k] + R[k] * L.com[0] + R[3 + k] * L.com[1] + R[6 + k] * L.com[2];
+            const double m = L.mass, ccs = dot3(cw, cw);
+            const double ix = L.in[0], iy = L.in[1], iz = L.in[2];
+            Io[0] = ix * R[0] * R[0] + iy * R[3] * R[3] + iz * R[6] * R[6] + m * (ccs - cw[0] * cw[0]);
+            Io[1] = ix * R[0] * R[1] + iy * R[3] * R[4] + iz * R[6] * R[7] - m * cw[0] * cw[1];
+            Io[2] = ix * R[0] * R[2] + iy * R[3] * R[5] + iz * R[6] * R[8] - m * cw[0] * cw[2];
+            Io[3] = ix * R[1] * R[1] + iy * R[4] * R[4] + iz * R[7] * R[7] + m * (ccs - cw[1] * cw[1]);
+            Io[4] = ix * R[1] * R[2] + iy * R[4] * R[5] + iz * R[7] * R[8] - m * cw[1] * cw[2];
+            Io[5] = ix * R[2] * R[2] + iy * R[5] * R[5] + iz * R[8] * R[8] + m * (ccs - cw[2] * cw[2]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) h[k] = m * cw[k];
-    }
-    // link force f = I a + v x* (I v); then suffix sums: total force on the sub-chain, composite inertia
-    double Fn[3], Ff[3], Ioc[6], hc[3];
-    {
-        double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
-        sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
+            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
+        }
+        // link force f = I a + v x* (I v); then suffix sums: total force on the sub-chain, composite inertia
+        double Fn[3], Ff[3], Ioc[6], hc[3];
+        {
+            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
+            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass * av[k] - t1[k]; }
-        sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
+            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass * av[k] - t1[k]; }
+            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass * vo[k] - t1[k]; }
-        cross3(w, n, t0); cross3(vo, f, t1);
+            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass * vo[k] - t1[k]; }
+            cross3(w, n, t0); cross3(vo, f, t1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
-        cross3(w, f, t0);
+            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
+            cross3(w, f, t0);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ff[k] += t0[k];
+            for (int k = 0; k < 3; k++) ff[k] += t0[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { Fn[k] = masked_sum(fn[k], L.ge); Ff[k] = masked_sum(ff[k], L.ge); hc[k] = masked_sum(h[k], L.ge); }
+            for (int k = 0; k < 3; k++) { Fn[k] = masked_sum(fn[k], M.ge); Ff[k] = masked_sum(ff[k], M.ge); hc[k] = masked_sum(h[k], M.ge); }
 #pragma unroll
-        for (int k = 0; k < 6; k++) Ioc[k] = masked_sum(Io[k], L.ge);
-    }
-    const double tau = -kJointDamping * qd - (dot3(z, Fn) + dot3(s2, Ff));
-    // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k <= l on lane l, the upper part by transposition; W = M^-1 in place
-    double W[ND];
-    {
-        double fn[3], ff[3], t0[3], t1[3], low[ND];
-        sym_mul(Ioc, z, fn); cross3(hc, s2, t0); cross3(hc, z, t1);
+            for (int k = 0; k < 6; k++) Ioc[k] = masked_sum(Io[k], M.ge);
+        }
+        tau = -kJointDamping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k <= l on lane l, the upper part by transposition; W = M^-1 in place
+        double Fc[6], t0[3], t1[3], low[ND];
+        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { fn[k] += t0[k]; ff[k] = L.mcomp * s2[k] - t1[k]; }
+        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp * S[3 + k] - t1[k]; }
+        dot6_bcast_step<0>(Fc, S, low);
 #pragma unroll
-        for (int k = 0; k < ND; k++) { low[k] = dot3(Sz[k], fn) + dot3(S2[k], ff); W[k] = low[k] * L.le[k] * L.am; }
+        for (int k = 0; k < ND; k++) W[k] = low[k] * M.le[k] * L.am;
         transpose_upper_step<1>(L, low, W);
         double unused = 0.0;
         gj_step<0, true>(L, W, unused);
@@ -572,39 +653,43 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
     double qd_new = qd + dt * qdd;            // unconstrained velocity; the solver corrects it below
     e.bqd += dt * kGravityZ;
-    // ---- constraint rows
+    // ---- constraint rows (impulse space, A = J W J^T one row per lane)
     const double arm_bound = kArmMaxForce * dt, wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
     const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
+    const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
     Rows r;
     double rhs = 0.0;                         // desired velocity change of the own row (velocity units)
+    double off = 0.0;                         // sum_{k != own} a_rk lo_k
 #pragma unroll
-    for (int k = 0; k < GL; k++) { r.a[k] = 0.0; r.n[k] = 0.0; }
-    r.lo = 0.0; r.S = 0.0; r.jb = 0.0;
+    for (int k = 0; k < GL; k++) r.n[k] = 0.0;
+    r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
     if (L.arm) {
+        double sumw = 0.0;
 #pragma unroll
-        for (int k = 0; k < ND; k++) r.a[k] = W[k];
-        rhs = target - qd_new; r.lo = -arm_bound; r.S = 2.0 * arm_bound;
-    } else if (L.l == kBM) {
+        for (int k = 0; k < ND; k++) { r.diag = fma(L.e[k], W[k], r.diag); sumw += W[k] * (1.0 - L.e[k]); }
+        rhs = target - qd_new; r.lo = -arm_bound; r.S = 2.0 * arm_bound; off = -arm_bound * sumw;
+    } else if (is_bm) {
         rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) / dt : 0.0) - e.bqd;
-        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0;
-    } else if (L.l == kBLo) {
+        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
+    } else if (is_blo) {
         const double pen = e.bq - kGliderLower;
         rhs = ((pen > 0 ? -pen / dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
-        r.S = blim; r.jb = 1.0;
-    } else if (L.l == kBHi) {
+        r.S = blim; r.jb = 1.0; r.diag = wb; off = wb * -bound_bm;
+    } else if (is_bhi) {
         const double pen = kGliderUpper - e.bq;
         rhs = ((pen > 0 ? -pen / dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
-        r.S = blim; r.jb = -1.0;
-    }
-    if (L.l == kBM || L.l == kBLo || L.l == kBHi) {      // the three scalar rows share the glider: a_rk = J_r J_k / m
-        r.a[kBM] = r.jb * wb; r.a[kBLo] = r.jb * wb; r.a[kBHi] = -r.jb * wb;
+        r.S = blim; r.jb = -1.0; r.diag = wb; off = -wb * -bound_bm;
     }
     // generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
     const double pen_lo = g.q - L.jlo, pen_hi = L.jhi - g.q;
     const bool lim_lo = L.arm && pen_lo <= kLimitActivationVel * dt, lim_hi = L.arm && pen_hi <= kLimitActivationVel * dt;
     e.contact_button = gany(c_cap) ? 1 : 0;
     uint32_t wave_slots = 0; int nlim = 0; bool has_lim = false;
+    double agen[kMaxGenRows] = {0, 0, 0, 0, 0, 0};       // unscaled couplings of the own row to the generic rows
     const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
+#ifdef SRL_GDBG_COUNTS       // host harness only: how often a step carries generic rows
+    { const bool gl = gany(lim_lo || lim_hi), gc = gany(c_cap), gb = gany(c_base); if (L.l == 0) SRL_GDBG_COUNTS(any_generic, gl, gc, gb); }
+#endif
     if (any_generic) {
         // slot of a candidate = number of candidates before it in Bullet's creation order: limits (joint 0 lower, joint 0
         // upper, joint 1 lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first six are kept
@@ -616,6 +701,15 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
         if (nlim > kMaxGenRows) nlim = kMaxGenRows;
         int ngen = nlim + ncon; if (ngen > kMaxGenRows) ngen = kMaxGenRows;
+        // every joint axis on every lane (contact Jacobians): only here, off the common path
+        double Sz[ND][3], S2[ND][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double tz[ND], t2[ND];
+            bcast_all_step<0>(S[k], tz); bcast_all_step<0>(S[3 + k], t2);
+#pragma unroll
+            for (int j = 0; j < ND; j++) { Sz[j][k] = tz[j]; S2[j][k] = t2[j]; }
+        }
         // row definitions -> scratch [slot][12]: J[7] Jb desired pos_err lo hi
         double *def = scratch, *wj = scratch + kMaxGenRows * kRowDef;
 #define SRL_DEF_ROW(slot_, fillJ, Jb_, des_, perr_, hi_)                                     \
@@ -628,11 +722,11 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         if (lim_hi) { SRL_DEF_ROW(s_hi, _Pragma("unroll") for (int j = 0; j < ND; j++) o[j] = -L.e[j];, 0.0, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * kErp / dt, blim) }
 #define SRL_CONTACT_J(nrm)                                                                   \
         {                                                                                    \
-            double pt[3];                                                                    \
-            _Pragma("unroll") for (int k = 0; k < 3; k++) pt[k] = cc[k] - L.sph[3] * nrm[k]; \
+            double pt3[3];                                                                   \
+            _Pragma("unroll") for (int k = 0; k < 3; k++) pt3[k] = cc[k] - L.sph[3] * nrm[k]; \
             _Pragma("unroll") for (int j = 0; j < ND; j++) {                                 \
                 double c3[3];                                                                \
-                cross3(Sz[j], pt, c3);                                                       \
+                cross3(Sz[j], pt3, c3);                                                      \
                 o[j] = dot3(nrm, c3) + dot3(nrm, S2[j]);      /* n . (z_j x (pt - p_j)) */   \
             }                                                                                \
         }
@@ -654,75 +748,90 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
             double wjk = 0.0;
 #pragma unroll
             for (int j = 0; j < ND; j++) wjk = fma(W[j], have ? def[gi * kRowDef + j] : 0.0, wjk);
-            if (L.arm) { r.a[kGenLane[gi]] = wjk; wj[gi * ND + L.l] = wjk; }
-            else if (L.l == kBM || L.l == kBLo || L.l == kBHi) r.a[kGenLane[gi]] = r.jb * wb * Jb[gi];
+            if (L.arm) { agen[gi] = wjk; wj[gi * ND + L.l] = wjk; }
+            else if (is_button) agen[gi] = r.jb * wb * Jb[gi];
             wave_slots |= wany(have) ? (1u << gi) : 0u;
         }
         sync_scratch();
-        if (myslot >= 0 && myslot < ngen) {
+        double aarm[ND] = {0, 0, 0, 0, 0, 0, 0};       // a generic row's couplings to the arm rows
+        const bool mine = myslot >= 0 && myslot < ngen;
+        if (mine) {
             const double *o = def + myslot * kRowDef, *mywj = wj + myslot * ND;
             r.jb = o[7];
 #pragma unroll
-            for (int k = 0; k < ND; k++) r.a[k] = mywj[k];
-            r.a[kBM] = r.jb * wb; r.a[kBLo] = r.jb * wb; r.a[kBHi] = -r.jb * wb;
+            for (int k = 0; k < ND; k++) aarm[k] = mywj[k];
 #pragma unroll
             for (int gi = 0; gi < kMaxGenRows; gi++) {
                 double c = r.jb * wb * Jb[gi];
 #pragma unroll
                 for (int j = 0; j < ND; j++) c = fma(o[j], gi < ngen ? wj[gi * ND + j] : 0.0, c);
-                r.a[kGenLane[gi]] = gi < ngen ? c : 0.0;
+                agen[gi] = gi < ngen ? c : 0.0;
+                if (gi == myslot) r.diag = c;
             }
             r.lo = o[10]; r.S = o[11] - o[10];
             rhs = o[8] + o[9] - o[7] * e.bqd;    // the arm part of the row velocity is subtracted below (needs every lane's qd_new)
+            // couplings to rows with a non-zero lower bound: the arm motors (-arm_bound) and the button motor (-bound_bm)
+            off = r.jb * wb * -bound_bm;
+#pragma unroll
+            for (int k = 0; k < ND; k++) off = fma(aarm[k], -arm_bound, off);
         }
         // J . qd_new of every generic row (qd_new lives one joint per lane): replicated dot products
         {
             double qall[ND];
             bcast_all_step<0>(qd_new, qall);
-            if (myslot >= 0 && myslot < ngen) {
-                double s = 0.0;
+            if (mine) {
+                double sdot = 0.0;
 #pragma unroll
-                for (int j = 0; j < ND; j++) s = fma(def[myslot * kRowDef + j], qall[j], s);
-                rhs -= s;
+                for (int j = 0; j < ND; j++) sdot = fma(def[myslot * kRowDef + j], qall[j], sdot);
+                rhs -= sdot;
             }
         }
         sync_scratch();                          // scratch is reused by the next step
-    }
-    // ---- scale every row to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
-    {
-        // lo_k, S_k of every row, replicated (arm rows and button rows are constants; generic rows come by broadcast)
-        double lo_k[GL], S_k[GL];
+        // scaled couplings: n_rk = -a_rk S_k / (a_rr S_r)
+        const double S0 = bcast<kGenLane[0]>(r.S), S1 = bcast<kGenLane[1]>(r.S), S2g = bcast<kGenLane[2]>(r.S), S3 = bcast<kGenLane[3]>(r.S),
+                     S4 = bcast<kGenLane[4]>(r.S), S5 = bcast<kGenLane[5]>(r.S);
+        const bool live = r.S > 0.0 && r.diag > 0.0;
+        const double inv = live ? 1.0 / (r.diag * r.S) : 0.0;
+        const double Sg[kMaxGenRows] = {S0, S1, S2g, S3, S4, S5};
 #pragma unroll
-        for (int k = 0; k < GL; k++) { lo_k[k] = 0.0; S_k[k] = 0.0; }
+        for (int gi = 0; gi < kMaxGenRows; gi++) r.n[kGenLane[gi]] = (mine && gi == myslot) ? 0.0 : -agen[gi] * Sg[gi] * inv;
+        if (mine) {
 #pragma unroll
-        for (int k = 0; k < ND; k++) { lo_k[k] = -arm_bound; S_k[k] = 2.0 * arm_bound; }
-        lo_k[kBM] = -bound_bm; S_k[kBM] = 2.0 * bound_bm; S_k[kBLo] = blim; S_k[kBHi] = blim;
-        if (any_generic) {
-            S_k[kGenLane[0]] = bcast<kGenLane[0]>(r.S); S_k[kGenLane[1]] = bcast<kGenLane[1]>(r.S); S_k[kGenLane[2]] = bcast<kGenLane[2]>(r.S);
-            S_k[kGenLane[3]] = bcast<kGenLane[3]>(r.S); S_k[kGenLane[4]] = bcast<kGenLane[4]>(r.S); S_k[kGenLane[5]] = bcast<kGenLane[5]>(r.S);
+            for (int k = 0; k < ND; k++) r.n[k] = -aarm[k] * (2.0 * arm_bound) * inv;
+            r.n[kBM] = -(r.jb * wb) * (2.0 * bound_bm) * inv; r.n[kBLo] = -(r.jb * wb) * blim * inv; r.n[kBHi] = (r.jb * wb) * blim * inv;
         }
-        double diag = 0.0, off = 0.0;
-#pragma unroll
-        for (int k = 0; k < GL; k++) { diag = fma(L.e[k], r.a[k], diag); off = fma(r.a[k] * (1.0 - L.e[k]), lo_k[k], off); }
-        const bool live = r.S > 0.0 && diag > 0.0;
-        const double inv = live ? 1.0 / (diag * r.S) : 0.0;
+    }
+    // ---- scale the arm / button rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
+    {
+        const bool live = r.S > 0.0 && r.diag > 0.0;
+        const double inv = live ? 1.0 / (r.diag * r.S) : 0.0;
         r.cs = live ? (rhs - off) * inv - r.lo / r.S : 0.0;
+        if (L.arm) {
 #pragma unroll
-        for (int k = 0; k < GL; k++) r.n[k] = -(r.a[k] * (1.0 - L.e[k])) * S_k[k] * inv;
+            for (int k = 0; k < ND; k++) r.n[k] = -(W[k] * (1.0 - L.e[k])) * (2.0 * arm_bound) * inv;
+        } else if (is_button) {
+            r.n[kBM] = is_bm ? 0.0 : -(r.jb * wb) * (2.0 * bound_bm) * inv;
+            r.n[kBLo] = is_blo ? 0.0 : -(r.jb * wb) * blim * inv;
+            r.n[kBHi] = is_bhi ? 0.0 : (r.jb * wb) * blim * inv;
+        }
         // lambda starts at 0, i.e. u_k = -lo_k / S_k = 1/2 for the symmetric rows (arm motors; the button motor couples to
         // no row that comes before it): what arm row l sees of the arm rows behind it during the first sweep
         r.acc0 = 0.0;
+        if (L.arm) {
 #pragma unroll
-        for (int k = 0; k < ND; k++) r.acc0 = fma(r.n[k] * (1.0 - L.le[k]), 0.5, r.acc0);
+            for (int k = 0; k < ND; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
+        }
     }
     const double u = any_generic ? pgs_sweeps_general(L, r, wave_slots, nlim, has_lim) : pgs_sweeps_free(L, r);
     const double lam = r.lo + r.S * u;
     SRL_GDBG(5, L.l, lam);
-    // ---- velocity change: arm lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
+    // ---- velocity change: arm lane i gets sum_r a_ir lambda_r = diag_i (lambda_i - S_i sum_{k != i} n_ik lambda_k / S_k),
+    //      the glider sum_r jb_r lambda_r / m
     double dv = 0.0, dvb = 0.0;
     {
-        const double pb = r.jb * lam * wb;
-#define SRL_ACC(K) fmac_bcast<K>(dv, lam, r.a[K]);
+        const double v = r.S > 0.0 ? lam / r.S : 0.0, pb = r.jb * lam * wb;
+        double acc = 0.0;
+#define SRL_ACC(K) fmac_bcast<K>(acc, v, r.n[K]);
         SRL_ACC(0) SRL_ACC(1) SRL_ACC(2) SRL_ACC(3) SRL_ACC(4) SRL_ACC(5) SRL_ACC(6)
         dvb = bcast<kBM>(pb) + bcast<kBLo>(pb) + bcast<kBHi>(pb);
         if (any_generic) {
@@ -730,6 +839,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
             dvb += bcast<7>(pb) + bcast<11>(pb) + bcast<12>(pb) + bcast<13>(pb) + bcast<14>(pb) + bcast<15>(pb);
         }
 #undef SRL_ACC
+        dv = r.diag * (lam - r.S * acc);
     }
     // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position
     if (L.arm) { g.qd = qd_new + dv; g.q += dt * g.qd; }
@@ -757,19 +867,20 @@ SRL_G void gunpack_start(Env &e, GState &g, const Lane &L, const double *o) {
     e.bq = o[31]; e.bqd = o[32];
 }
 
-// KukaButtonGymEnv.reset for one lane group (same draws, same table as reset_env<1>)
-template <class R>
+// KukaButtonGymEnv.reset for one lane group (same draws, same table as reset_env<1>).  JOINTS = the continuous joint-space
+// action mode, whose five init actions are integrated here: a compile-time switch so that the other modes carry a single
+// copy of the physics step.
+template <bool JOINTS, class R>
 SRL_G void genv_reset(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
                       double *objs, int64_t objs_stride) {
 #pragma clang fp contract(off)
     ResetDraw d;
     reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
-    const bool joints = !cfg.is_discrete && cfg.action_joints;
-    gunpack_start(e, g, L, joints ? settled : starts + (int64_t)d.idx * kStartDoubles);
+    gunpack_start(e, g, L, JOINTS ? settled : starts + (int64_t)d.idx * kStartDoubles);
     e.bx = d.bx; e.by = d.by; e.bz = kButtonBaseZ;
     gfk(L, g);
-    if (joints) {
+    if constexpr (JOINTS) {
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0 + kDeltaTheta * d.g[k];

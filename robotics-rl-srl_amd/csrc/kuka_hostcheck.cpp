@@ -15,6 +15,9 @@ static unsigned char *g_stat = nullptr; static long g_stat_idx = -1;
 #include "kuka_env.hpp"
 static double g_gdbg[8][128]; static int g_gdbg_on = 0;
 #define SRL_GDBG(tag, idx, val) do { if (g_gdbg_on && (idx) < 128) g_gdbg[tag][idx] = (val); } while (0)
+static long g_fix_hist[152];
+#define SRL_GDBG_FIXPOINT(at) do { if (g_gdbg_on) g_fix_hist[(at) < 0 ? 151 : (at)]++; } while (0)
+#define SRL_GDBG_COUNTS(any, gl, gc, gb) do { if (g_gdbg_on) { g_gdbg[6][0] += 1; g_gdbg[6][1] += (any); g_gdbg[6][2] += (gl); g_gdbg[6][3] += (gc); g_gdbg[6][4] += (gb); } } while (0)
 #include "kuka_group.hpp"
 
 using namespace srl;
@@ -303,7 +306,9 @@ void group_env_body(GroupArgs &a, R &rng) {
     const bool lead = L.l == 0;
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
-    genv_reset(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    const bool joints = !cfg.is_discrete && cfg.action_joints;
+    if (joints) genv_reset<true>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    else genv_reset<false>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
@@ -328,7 +333,10 @@ void group_env_body(GroupArgs &a, R &rng) {
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
-            if (cfg.auto_reset) genv_reset(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+            if (cfg.auto_reset) {
+                if (joints) genv_reset<true>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                else genv_reset<false>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+            }
         }
         if (lead) {
             if (a.obs) observe(env, cfg, a.obs + row * od, 1);
@@ -392,3 +400,5 @@ extern "C" int hostcheck_kuka_group_rollout(int is_discrete, int action_joints, 
 }
 
 extern "C" void hostcheck_group_debug(int on, double *out) { g_gdbg_on = on; if (out) memcpy(out, g_gdbg, sizeof g_gdbg); }
+
+extern "C" void hostcheck_group_fix_hist(long *out) { memcpy(out, g_fix_hist, sizeof g_fix_hist); memset(g_fix_hist, 0, sizeof g_fix_hist); }
