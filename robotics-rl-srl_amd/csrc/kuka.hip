@@ -11,6 +11,8 @@
 // MFMA-shaped; see DESIGN.md §Kuka kernel for the roofline accounting.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "internal.hpp"
 #include "kuka_env.hpp"
 #include "kuka_group.hpp"
@@ -254,10 +256,13 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
     Lane L;
     lane_init(L);
     const bool lead = L.l == 0 && valid;
-    typename KRng<MODE>::type rng0;
-    krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
+    // Philox mode: the lane-group stream adaptor (batched Gaussian draws); otherwise the generators of the lane-per-env kernel
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
+    Rng rng0;
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
     // generators whose state lives in HBM (MT19937) are advanced by lane 0 only; counter-based / host streams are replayed by all
-    Lane0Rng<typename KRng<MODE>::type> rng_l0{&rng0, lead};
+    Lane0Rng<Rng> rng_l0{&rng0, lead};
     Env v = {};
     GState g;
     {   // env scalars replicated on the row, the own joint per arm lane
@@ -275,7 +280,8 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
     }
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
-    Philox act; act.k0 = rs.key[e]; act.k1 = rs.key[n + e]; act.ctr = rs.act_ctr[e]; act.stream = 1;
+    GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
+    Philox &act = gact.p;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
     for (int t = 0; t < T; t++) {
@@ -285,7 +291,7 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
             if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
             else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
         } else {
-            if (cfg.is_discrete) a = (int)act.bounded(5);
+            if (cfg.is_discrete) a = gact.next(5);
             else for (int j = 0; j < adim; j += 2) {
                 uint32_t o[4]; act.block(o);
                 ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
@@ -339,7 +345,8 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
         s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
         s.i[I_TERM * n + e] = v.terminated;
-        krng_store<MODE>(rng0, rs, e);
+        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
+        else krng_store<MODE>(rng0, rs, e);
         if constexpr (!GIVEN) rs.act_ctr[e] = act.ctr;
         st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
         st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;

@@ -91,6 +91,13 @@ SRL_G uint32_t ballot(bool p) {
 #endif
 }
 SRL_G bool gany(bool p) { return ballot(p) != 0; }
+SRL_G double shfl(double x, int src) {                                            // value of lane `src` of the row (src varies per row)
+#if SRL_G_DEVICE
+    return __shfl(x, src, GL);
+#else
+    return host_exchange(x, src);
+#endif
+}
 SRL_G bool wany(bool p) {
 #if SRL_G_DEVICE
     return __any(p);
@@ -559,22 +566,36 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         bcast_all_step<0>(bb, all);
 #pragma unroll
         for (int k = 0; k < ND; k++) maxabs = fmax(maxabs, fabs(all[k]));
-        const double scale = maxabs > kIkMaxAngle ? kIkMaxAngle / maxabs : 1.0;
-        qdes = g.q + (maxabs > kIkMaxAngle ? bb * scale : bb);
+        qdes = g.q + bb;
+        if (wany(maxabs > kIkMaxAngle)) {                    // rare: the step is rescaled to at most 45 degrees per joint
+            const double scale = kIkMaxAngle / maxabs;
+            if (maxabs > kIkMaxAngle) qdes = g.q + bb * scale;
+        }
     }
-    // ---- collision detection at the current poses: lane s < 6 owns gripper sphere s
+    // ---- collision detection at the current poses: lane s < 6 owns gripper sphere s.  The exact sphere-cylinder distances
+    //      (square roots, divisions) are only evaluated when some sphere of the wavefront can be within the contact
+    //      threshold of the button at all: conservative box / disc rejection first (margin 1e-9 over the threshold).
     double cc[3], n_cap[3], n_base[3], d_cap = 1e30, d_base = 1e30;
     tip_point(Rt, pt, L.sph, cc);
     const bool sphere = L.l < kNSphere;
     const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
-    if (sphere) {
-        d_cap = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
-        d_base = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+    {
+        const double reach = L.sph[3] + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
+        const double rmax = kBaseRadius + reach;           // the base is the wider cylinder
+        const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
+        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+        if (wany(sphere && !far)) {
+            if (sphere) {
+                d_cap = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+                d_base = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+            }
+        }
     }
     const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
     e.contact_table = gany(sphere && (cc[2] - L.sph[3] - kTableTopZ < kContactThreshold)) ? 1 : 0;
     // ---- motor target velocity of the own joint
-    double target = kArmKp * (qdes - g.q) / dt;
+    const double inv_dt = 1.0 / kDt;
+    double target = kArmKp * (qdes - g.q) * inv_dt;
     target = target > kArmMaxVel ? kArmMaxVel : target;
     target = target < -kArmMaxVel ? -kArmMaxVel : target;
     // ---- dynamics in world coordinates: velocities and bias accelerations by prefix sums over the chain
@@ -669,15 +690,15 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         for (int k = 0; k < ND; k++) { r.diag = fma(L.e[k], W[k], r.diag); sumw += W[k] * (1.0 - L.e[k]); }
         rhs = target - qd_new; r.lo = -arm_bound; r.S = 2.0 * arm_bound; off = -arm_bound * sumw;
     } else if (is_bm) {
-        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) / dt : 0.0) - e.bqd;
+        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - e.bqd;
         r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
     } else if (is_blo) {
         const double pen = e.bq - kGliderLower;
-        rhs = ((pen > 0 ? -pen / dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
         r.S = blim; r.jb = 1.0; r.diag = wb; off = wb * -bound_bm;
     } else if (is_bhi) {
         const double pen = kGliderUpper - e.bq;
-        rhs = ((pen > 0 ? -pen / dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp / dt);
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
         r.S = blim; r.jb = -1.0; r.diag = wb; off = -wb * -bound_bm;
     }
     // generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
@@ -804,8 +825,9 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     // ---- scale the arm / button rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
         const bool live = r.S > 0.0 && r.diag > 0.0;
-        const double inv = live ? 1.0 / (r.diag * r.S) : 0.0;
-        r.cs = live ? (rhs - off) * inv - r.lo / r.S : 0.0;
+        const double inv = live ? rcp(r.diag * r.S) : 0.0;
+        // -lo / S: 1/2 for the symmetric rows (arm motors, button motor), 0 for the unilateral ones
+        r.cs = live ? (rhs - off) * inv + ((L.arm || is_bm) ? 0.5 : 0.0) : 0.0;
         if (L.arm) {
 #pragma unroll
             for (int k = 0; k < ND; k++) r.n[k] = -(W[k] * (1.0 - L.e[k])) * (2.0 * arm_bound) * inv;
@@ -856,6 +878,52 @@ template <class R> struct Lane0Rng {
     SRL_G double uniform(double a, double b) { double v = 0.0; if (own) v = r->uniform(a, b); return bcast<0>(v); }
     SRL_G double normal(double a, double b) { double v = 0.0; if (own) v = r->normal(a, b); return bcast<0>(v); }
     SRL_G uint32_t bounded(uint32_t m) { double v = 0.0; if (own) v = (double)r->bounded(m); return (uint32_t)bcast<0>(v); }
+};
+
+// Counter-based env stream (Philox) for a lane group.  Every lane holds the same key / counter; the expensive draw — the
+// per-step Gaussian noise (log, sqrt, cos in float64) — is produced 16 counters at a time, one per lane, and handed out by a
+// row shuffle, so its cost is shared by 16 steps instead of being replayed on all 16 lanes every step.  Values are the
+// sequential stream's bit for bit (a deviate is a pure function of key and counter).
+struct GroupPhilox {
+    Philox p;
+    uint64_t base;       // counter the batch starts at
+    double z;            // std_normal() at counter base + lane
+    bool have;
+    SRL_G void init(uint32_t k0, uint32_t k1, uint64_t ctr) { p.k0 = k0; p.k1 = k1; p.ctr = ctr; p.stream = 0; base = 0; z = 0.0; have = false; }
+    SRL_G double double01() { return p.double01(); }
+    SRL_G double uniform(double a, double b) { return p.uniform(a, b); }
+    SRL_G uint32_t bounded(uint32_t m) { return p.bounded(m); }
+    SRL_G double normal(double loc, double scale) {
+#pragma clang fp contract(off)
+        if (wany(!have || p.ctr - base >= (uint64_t)GL)) {       // every row of the wavefront refills together
+            base = p.ctr;
+            Philox q = p; q.ctr = base + (uint64_t)lane_id();
+            z = q.std_normal();
+            have = true;
+        }
+        const double zz = shfl(z, (int)(p.ctr - base));
+        p.ctr++;
+        return loc + scale * zz;
+    }
+};
+// the synthetic agent's discrete action stream, batched the same way
+struct GroupActions {
+    Philox p;            // stream 1
+    uint64_t base;
+    double a;            // bounded(5) at counter base + lane (as a double: it travels by the same shuffle)
+    bool have;
+    SRL_G void init(uint32_t k0, uint32_t k1, uint64_t ctr) { p.k0 = k0; p.k1 = k1; p.ctr = ctr; p.stream = 1; base = 0; a = 0.0; have = false; }
+    SRL_G int next(uint32_t m) {
+        if (wany(!have || p.ctr - base >= (uint64_t)GL)) {
+            base = p.ctr;
+            Philox q = p; q.ctr = base + (uint64_t)lane_id();
+            a = (double)q.bounded(m);
+            have = true;
+        }
+        const int v = (int)shfl(a, (int)(p.ctr - base));
+        p.ctr++;
+        return v;
+    }
 };
 
 // arm / glider part of a packed start state (pack_start() layout) -> lane group

@@ -311,6 +311,7 @@ void group_env_body(GroupArgs &a, R &rng) {
     else genv_reset<false>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
+    GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
     double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
     for (int t = 0; t < T; t++) {
         const size_t row = (size_t)t * n + e_idx;
@@ -319,7 +320,7 @@ void group_env_body(GroupArgs &a, R &rng) {
             if (cfg.is_discrete) ac = static_cast<const int32_t *>(a.actions)[row];
             else memcpy(ca, static_cast<const float *>(a.actions) + row * adim, sizeof(float) * adim);
         } else {
-            if (cfg.is_discrete) ac = (int)act.bounded(5);
+            if (cfg.is_discrete) ac = gact.next(5);
             else for (int j = 0; j < adim; j += 2) {
                 uint32_t o[4]; act.block(o);
                 ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
@@ -362,7 +363,7 @@ void group_fiber_body(void *p) {
         grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0};
         group_env_body(a, r);
     } else {
-        PhHost r; r.p = a.act; r.p.stream = 0;          // counter-based: every lane replays the same stream
+        grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0);      // counter-based: every lane holds the same stream
         group_env_body(a, r);
     }
 }
