@@ -331,7 +331,7 @@ def main():
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
     roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "mobile_rollout_ep_k" if workload == "mobile" else "kuka_rollout_k",
+                "kernel": "mobile_rollout_ep_k" if workload == "mobile" else ("kuka_group_rollout_k" if h.kuka_kernel() == "group" else "kuka_rollout_k"),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
     if n == 4096 and inner == 2048:       # geometry the PMC passes were taken at
@@ -341,8 +341,10 @@ def main():
         from srlhip import kuka_model
         flops = kuka_model.FLOPS_PER_ENV_STEP
         tf = flops * steps_per_launch / avg_launch_s / 1e12
-        roofline.update({"note": "Kuka stepper is FP64-VALU / dependency-latency bound, not HBM bound "
+        roofline.update({"note": "Kuka stepper is FP64-VALU issue / dependency-latency bound, not HBM bound "
                                  "(SURVEY §7 hard parts); HBM fraction reported because the north star asks for it",
+                         "launch_geometry": "16 lanes per env, 1 wavefront per workgroup: {} wavefronts".format((n + 3) // 4)
+                         if h.kuka_kernel() == "group" else "1 lane per env: {} wavefronts".format((n + 63) // 64),
                          "valu_fp64_tflops": tf, "valu_fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
                          "valu_frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_env_step": flops})
     line = {

@@ -215,6 +215,12 @@ int srlhip_graph_end(srlhip_handle h, srlhip_graph_handle *out);
 int srlhip_graph_launch(srlhip_handle h, srlhip_graph_handle g);
 int srlhip_graph_destroy(srlhip_graph_handle g);
 
+/* Which kernel steps this Kuka handle's batch: 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 16384
+ * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and Kuka2ButtonGymEnv); the environment variable
+ * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs
+ * (to ~1e-11 on joint positions; discrete flags identical). */
+int srlhip_kuka_kernel(srlhip_handle h);
+
 /* Diagnostic: runs every cross-lane primitive of the lane-group Kuka kernel (csrc/kuka_group.hpp: DPP row broadcasts and
  * shifts, row votes, the fused solver-row instructions, the lane-parallel Gauss-Jordan, the prefix-composed forward
  * kinematics for joint angles q7) on one wavefront of device_id and returns their per-lane results, out[40][64] doubles.

@@ -497,6 +497,13 @@ int srlhip_episode_stats_device(srlhip_handle hh, float *d_last_return, int32_t 
     return 0;
 }
 
+int srlhip_kuka_kernel(srlhip_handle hh) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (is_mobile(h->cfg.env_kind)) return SRLHIP_EINVAL;
+    return kuka_uses_group_kernel(h);
+}
+
 int srlhip_selftest_group_primitives(int32_t device_id, const double *q7, double *out, int32_t out_doubles) {
     if (!q7 || !out) return SRLHIP_EINVAL;
     if (hipSetDevice(device_id) != hipSuccess) return SRLHIP_EHIP;

@@ -68,6 +68,7 @@ int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_
 int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
 int kuka_reset_rand_count(const srlhip_config &c);
 int kuka_refresh(Handle *h);
+int kuka_uses_group_kernel(const Handle *h);
 int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
 
 // raster.hip

@@ -505,6 +505,8 @@ static bool use_group_kernel(const Handle *h) {
     return h->n <= kGroupKernelMaxEnvs;
 }
 
+int kuka_uses_group_kernel(const Handle *h) { return use_group_kernel(h) ? 1 : 0; }
+
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);

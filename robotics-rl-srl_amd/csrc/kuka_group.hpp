@@ -847,6 +847,12 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     const double u = any_generic ? pgs_sweeps_general(L, r, wave_slots, nlim, has_lim) : pgs_sweeps_free(L, r);
     const double lam = r.lo + r.S * u;
     SRL_GDBG(5, L.l, lam);
+#ifdef SRL_GDBG_CLAMPS        // host harness only: how often does an arm motor row end the solve at its bound?
+    { const bool cl = gany(L.arm && (u <= 0.0 || u >= 1.0));
+      // a-priori test (energy norm of the Gauss-Seidel error is non-increasing): can a clamp trigger at all?
+      double lamstar = 0.0; { double Mrow_dummy = 0.0; (void)Mrow_dummy; }
+      if (L.l == 0) SRL_GDBG_CLAMPS(cl); }
+#endif
     // ---- velocity change: arm lane i gets sum_r a_ir lambda_r = diag_i (lambda_i - S_i sum_{k != i} n_ik lambda_k / S_k),
     //      the glider sum_r jb_r lambda_r / m
     double dv = 0.0, dvb = 0.0;

@@ -17,6 +17,8 @@ static double g_gdbg[8][128]; static int g_gdbg_on = 0;
 #define SRL_GDBG(tag, idx, val) do { if (g_gdbg_on && (idx) < 128) g_gdbg[tag][idx] = (val); } while (0)
 static long g_fix_hist[152];
 #define SRL_GDBG_FIXPOINT(at) do { if (g_gdbg_on) g_fix_hist[(at) < 0 ? 151 : (at)]++; } while (0)
+static long g_clamp_cnt[2];
+#define SRL_GDBG_CLAMPS(cl) do { if (g_gdbg_on) { g_clamp_cnt[0]++; g_clamp_cnt[1] += (cl); } } while (0)
 #define SRL_GDBG_COUNTS(any, gl, gc, gb) do { if (g_gdbg_on) { g_gdbg[6][0] += 1; g_gdbg[6][1] += (any); g_gdbg[6][2] += (gl); g_gdbg[6][3] += (gc); g_gdbg[6][4] += (gb); } } while (0)
 #include "kuka_group.hpp"
 
@@ -403,3 +405,5 @@ extern "C" int hostcheck_kuka_group_rollout(int is_discrete, int action_joints, 
 extern "C" void hostcheck_group_debug(int on, double *out) { g_gdbg_on = on; if (out) memcpy(out, g_gdbg, sizeof g_gdbg); }
 
 extern "C" void hostcheck_group_fix_hist(long *out) { memcpy(out, g_fix_hist, sizeof g_fix_hist); memset(g_fix_hist, 0, sizeof g_fix_hist); }
+
+extern "C" void hostcheck_group_clamp_cnt(long *out) { out[0] = g_clamp_cnt[0]; out[1] = g_clamp_cnt[1]; g_clamp_cnt[0] = g_clamp_cnt[1] = 0; }

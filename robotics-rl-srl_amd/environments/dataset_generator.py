@@ -63,7 +63,7 @@ def run_batched(args):
     cfg = _lib.default_config(env_cls.ENV_KIND)
     cfg.num_envs, cfg.device_id = n, args.device_id
     cfg.is_discrete, cfg.random_target = int(not args.continuous_actions), int(args.random_target)
-    cfg.shape_reward, cfg.force_down, cfg.multi_view = int(args.shape_reward), 1, int(args.multi_view)
+    cfg.shape_reward, cfg.multi_view = int(args.shape_reward), int(args.multi_view)     # force_down: the env class's own ctor default (srlhip_default_config), the reference never passes it
     cfg.max_distance = args.max_distance
     cfg.obs_mode, cfg.rng_mode, cfg.auto_reset = _lib.OBS_GROUND_TRUTH, _lib.RNG_MT19937, 0
     cfg.img_h = cfg.img_w = args.img_size                       # frames come from srlhip_render (tile rasteriser)

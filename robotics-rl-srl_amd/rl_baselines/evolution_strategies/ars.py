@@ -59,25 +59,26 @@ class ARSModel(object):
         return {"top_population": (int, (1, 5)), "exploration_noise": (float, (0, 0.1)), "step_size": (float, (0, 0.1)),
                 "max_step_amplitude": (float, (1, 100))}
 
-    # ---- host-side single-policy interface (replay / enjoy), as in the reference --------------------------------
-    def getActionProba(self, observation, dones=None, delta=0):
+    # ---- host-side single-policy interface (replay / enjoy: rl_baselines/evolution_strategies/ars.py:77-104) ------
+    def _scores(self, observation, delta=0):
         assert self.M is not None, "Error: must train or load model before use"
-        action = np.dot(observation, self.M + delta)
+        return np.atleast_2d(np.asarray(observation, dtype=np.float64)) @ (self.M + delta)
+
+    def getActionProba(self, observation, dones=None, delta=0):
+        """Continuous actions: the linear policy's output; discrete: its softmax, one row per observation."""
+        scores = self._scores(observation, delta)
         if self.continuous_actions:
-            return action
-        e_x = np.exp(action.T - np.max(action.T, axis=0))
-        return (e_x / e_x.sum(axis=0)).T
+            return scores
+        z = np.exp(scores - scores.max(axis=1, keepdims=True))
+        return z / z.sum(axis=1, keepdims=True)
 
     def getAction(self, observation, dones=None, delta=0):
-        assert self.M is not None, "Error: must train or load model before use"
-        action = np.dot(observation, self.M + delta)
-        if not self.continuous_actions:
-            if self.deterministic:
-                action = np.argmax(action, axis=1)
-            else:
-                proba = self.getActionProba(observation, delta=delta)
-                action = np.array([np.random.choice(len(a), p=a) for a in proba])
-        return action
+        if self.continuous_actions:
+            return self._scores(observation, delta)
+        if self.deterministic:
+            return self._scores(observation, delta).argmax(axis=1)
+        cdf = np.cumsum(self.getActionProba(observation, delta=delta), axis=1)          # inverse-CDF sampling, all rows at once
+        return (np.random.random_sample((len(cdf), 1)) * cdf[:, -1:] < cdf).argmax(axis=1)
 
     # ---- env assembly: ars.py:107-126 with the device-resident stack ----------------------------------------------
     @classmethod
@@ -91,6 +92,9 @@ class ARSModel(object):
         envs = DeviceVecFrameStack(envs, getattr(args, "num_stack", 1))
         if getattr(args, "srl_model", "ground_truth") != "raw_pixels" and getattr(args, "algo_type", "v2") == "v2":
             envs = DeviceVecNormalize(envs, norm_obs=True, norm_reward=False)
+            if load_path_normalise is not None:        # replay: frozen statistics of the training run (rl_baselines/utils.py:232-237)
+                envs.training = False
+                envs.load_running_average(load_path_normalise)
         return envs
 
     @staticmethod
@@ -130,15 +134,19 @@ class ARSModel(object):
         M = torch.zeros((obs_dim, action_space), dtype=torch.float64, device=dev)
         start_time, step = time.time(), 0
         self.history = []
+        log_dir = getattr(args, "log_dir", None)
         with torch.cuda.stream(env.torch_stream):          # policy math and stepper kernels on ONE stream: no host syncs
             while step < num_updates:
                 r = torch.zeros((P, 2), dtype=torch.float64, device=dev)
                 delta = torch.randn((P, obs_dim, action_space), dtype=torch.float64, device=dev, generator=gen)
                 done = torch.zeros(2 * P, dtype=torch.bool, device=dev)
+                live_steps = torch.zeros((), dtype=torch.int64, device=dev)      # env steps taken while some direction was still running
+                step0 = step
                 obs = env.reset()
                 while True:
                     actions = self.batched_actions(obs, M, delta, self.exploration_noise, ~done, continuous,
                                                    self.deterministic, gen)
+                    live_steps += (~done).any().to(torch.int64)
                     obs, reward, new_done = env.step(actions)
                     step += P
                     done = done | (new_done != 0)
@@ -147,6 +155,7 @@ class ARSModel(object):
                     if callback is not None:
                         callback(locals(), globals())
                     if (step // P) % 16 == 0 and bool(done.all()):      # the only device->host read: every 16 env steps
+                        step = step0 + P * int(live_steps)                # the <= 15 idle steps since the last direction ended do not count
                         break
                     if (step / P + 1) % 500 == 0:
                         print("{} steps - {:.2f} FPS".format(step, step / (time.time() - start_time)))
@@ -156,7 +165,10 @@ class ARSModel(object):
                 # the normalisation of step_size guards against zero variance on sparse rewards (ars.py:196-199)
                 denom = torch.clamp(self.top_population * top.std(unbiased=False), min=1.0 / self.max_step_amplitude)
                 M = M + (self.step_size / denom) * delta_sum
+                self.M = M.cpu().numpy()                   # callbacks may save() the model at any time
                 self.history.append(float(r.mean()))
         self.M = M.cpu().numpy()
+        if log_dir is not None and hasattr(env, "save_running_average"):      # the policy was trained on normalised observations
+            env.save_running_average(log_dir)
         env.close()
         return self

@@ -37,7 +37,7 @@ EXPORTS = [
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
-    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives",
+    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
@@ -99,6 +99,7 @@ def load():
     lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
     lib.srlhip_episode_stats_device.argtypes = [vp, vp, vp, vp]
     lib.srlhip_selftest_group_primitives.argtypes = [i32, vp, vp, i32]
+    lib.srlhip_kuka_kernel.argtypes = [vp]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -270,6 +271,13 @@ class Handle(object):
             out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
         return out
+
+    def kuka_kernel(self):
+        """'group' (16 lanes per env) or 'lane' (one lane per env): the kernel that steps this Kuka batch."""
+        rc = self._lib.srlhip_kuka_kernel(self._h)
+        if rc < 0:
+            raise SrlHipError("srlhip_kuka_kernel: not a Kuka handle")
+        return "group" if rc else "lane"
 
     def episode_stats_device(self, last_return=0, last_length=0, n_finished=0):
         """Enqueue-only: float32 returns / int32 lengths / counts of the last finished episodes into DEVICE buffers

@@ -16,12 +16,13 @@ from . import _lib
 from .envs import ENV_CLASSES, OBS_MODES
 from .gym_compat import Box, Discrete
 
-RNG_MODES = {"mt19937": _lib.RNG_MT19937, "philox": _lib.RNG_PHILOX}
+from .vec_env import RNG_MODES, default_rng_mode
 
 
 class DeviceVecEnv(object):
-    def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode="mt19937"):
+    def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode=None):
         kw = dict(env_kwargs or {})
+        rng_mode = rng_mode or default_rng_mode()
         cfg = _lib.default_config(ENV_CLASSES[env_id].ENV_KIND)
         cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = int(num_envs), device_id, first_env_id, int(seed)
         for name in ("is_discrete", "random_target", "shape_reward", "force_down", "action_repeat", "action_joints"):
@@ -151,6 +152,28 @@ class DeviceVecNormalize(DeviceVecEnvWrapper):
         self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
         self.old_obs = None
+
+    # same files as stable_baselines' VecNormalize (and srlhip.vec_wrappers.VecNormalize): {path}/obs_rms.pkl, ret_rms.pkl with
+    # host-side (mean, var, count) objects, so statistics move freely between the host and the device wrapper
+    def save_running_average(self, path):
+        import pickle
+        from .vec_wrappers import _RunningMeanStd as HostRms
+        for rms, name in ((self.obs_rms, "obs_rms"), (self.ret_rms, "ret_rms")):
+            host = HostRms(tuple(rms.mean.shape))
+            host.mean, host.var, host.count = rms.mean.cpu().numpy(), rms.var.cpu().numpy(), float(rms.count)
+            with open("{}/{}.pkl".format(path, name), "wb") as f:
+                pickle.dump(host, f)
+
+    def load_running_average(self, path):
+        import pickle
+        for rms, name in ((self.obs_rms, "obs_rms"), (self.ret_rms, "ret_rms")):
+            with open("{}/{}.pkl".format(path, name), "rb") as f:
+                host = pickle.load(f)
+            rms.mean = torch.as_tensor(np.asarray(host.mean), dtype=torch.float64, device=rms.mean.device).reshape(rms.mean.shape)
+            rms.var = torch.as_tensor(np.asarray(host.var), dtype=torch.float64, device=rms.var.device).reshape(rms.var.shape)
+            rms.count = float(host.count)
+
+    saveRunningAverage, loadRunningAverage = save_running_average, load_running_average
 
     def _obfilt(self, obs):
         if not self.norm_obs:

@@ -196,8 +196,8 @@ class MobileRobotGymEnv(_HipEnv):
         self.terminated = False
         self._h.reset()
         obs = self._obs()
-        if self.saver is not None:
-            self.saver.reset(obs, self.getTargetPos(), self.getGroundTruth())
+        if self.saver is not None:          # the recorder always stores the rendered frame, whatever srl_model returns (kuka_button_gym_env.py:276-277)
+            self.saver.reset(self.render("rgb_array"), self.getTargetPos(), self.getGroundTruth())
         return np.array(obs)
 
     def step(self, action):
@@ -211,7 +211,7 @@ class MobileRobotGymEnv(_HipEnv):
         obs = self._obs()
         done = bool(done[0])
         if self.saver is not None:
-            self.saver.step(obs, action, reward, done, self.getGroundTruth())
+            self.saver.step(self.render("rgb_array"), action, reward, done, self.getGroundTruth())
         return np.array(obs), reward, done, {}
 
 
@@ -372,8 +372,8 @@ class KukaButtonGymEnv(_HipEnv):
     def reset(self):
         self._h.reset()
         obs = self._obs()
-        if self.saver is not None:
-            self.saver.reset(obs, self.getTargetPos(), self.getGroundTruth())
+        if self.saver is not None:          # the recorder always stores the rendered frame, whatever srl_model returns (kuka_button_gym_env.py:276-277)
+            self.saver.reset(self.render("rgb_array"), self.getTargetPos(), self.getGroundTruth())
         return np.array(obs)
 
     def step(self, action):
@@ -390,7 +390,7 @@ class KukaButtonGymEnv(_HipEnv):
         obs = self._obs()
         done = bool(done[0])
         if self.saver is not None:
-            self.saver.step(obs, self.action, reward, done, self.getGroundTruth())
+            self.saver.step(self.render("rgb_array"), self.action, reward, done, self.getGroundTruth())
         return np.array(obs), reward, done, {}
 
 

@@ -22,7 +22,18 @@ from . import _lib
 from .envs import ENV_CLASSES, OBS_MODES
 from .gym_compat import Box, Discrete
 
+# "philox" (default): counter-based per-env streams, the fast path of both steppers.  "mt19937": the reference's own
+# streams — every env draws from a device-resident numpy RandomState seeded like gym.utils.seeding.np_random(seed + rank)
+# (srl_env.py:71-78), so noise / reset draws are the reference's bit for bit; its 624-word regenerations make the Kuka
+# step ~1.5x slower.  SRLHIP_RNG_MODE overrides the default for code that does not pass rng_mode (rl_baselines.train).
 RNG_MODES = {"mt19937": _lib.RNG_MT19937, "philox": _lib.RNG_PHILOX}
+
+
+def default_rng_mode():
+    mode = os.environ.get("SRLHIP_RNG_MODE", "philox")
+    if mode not in RNG_MODES:
+        raise ValueError("SRLHIP_RNG_MODE must be one of {}".format(sorted(RNG_MODES)))
+    return mode
 
 
 def _env_kind(env_id):
@@ -32,9 +43,11 @@ def _env_kind(env_id):
 
 
 class HipVecEnv(object):
-    def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode="mt19937",
+    def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode=None,
                  log_dir=None, allow_early_resets=False, encoder=None):
         kw = dict(env_kwargs or {})
+        rng_mode = rng_mode or default_rng_mode()
+        self.allow_early_resets, self._was_reset = bool(allow_early_resets), False
         self.env_id, self.num_envs, self.log_dir = env_id, int(num_envs), log_dir
         kind = _env_kind(env_id)
         cfg = _lib.default_config(kind)
@@ -93,16 +106,16 @@ class HipVecEnv(object):
         self._dirty_infos = []
         self._n_finished = np.zeros(self.num_envs, np.int32)
         self._t_start = time.time()
+        # bench.Monitor files, one per env like the reference (environments/utils.py:54).  They are NOT kept open: at the
+        # batch sizes this env is meant for (4096+) that would exceed RLIMIT_NOFILE; rows are appended when episodes end.
         self._monitors = None
         if log_dir is not None:
             os.makedirs(log_dir, exist_ok=True)
-            self._monitors = []
-            for i in range(self.num_envs):
-                f = open(os.path.join(log_dir, "{}.monitor.csv".format(first_env_id + i)), "wt")
-                f.write("#%s\n" % json.dumps({"t_start": self._t_start, "env_id": env_id}))
-                f.write("r,l,t\n")
-                f.flush()
-                self._monitors.append(f)
+            self._monitors = [os.path.join(log_dir, "{}.monitor.csv".format(first_env_id + i)) for i in range(self.num_envs)]
+            header = "#%s\nr,l,t\n" % json.dumps({"t_start": self._t_start, "env_id": env_id})
+            for path in self._monitors:
+                with open(path, "wt") as f:
+                    f.write(header)
 
     # -- VecEnv API ----------------------------------------------------------------
     def _encode(self):
@@ -118,6 +131,12 @@ class HipVecEnv(object):
         return st.to("cpu").numpy()
 
     def reset(self):
+        # stable_baselines.bench.Monitor(allow_early_resets=False) refuses a reset() in the middle of an episode
+        # (environments/utils.py:54, rl_baselines/utils.py:194): here that is a reset while some env's running episode has steps
+        if self._was_reset and not self.allow_early_resets and (self._h.get_state(_lib.F_EP_LENGTH) > 0).any():
+            raise RuntimeError("Tried to reset an environment before done. If you want to allow early resets, "
+                               "wrap your env with Monitor(env, path, allow_early_resets=True)")
+        self._was_reset = True
         if self._enc is None:
             return self._h.reset()
         self._h.reset(obs_out=self._t["images"].data_ptr())
@@ -161,10 +180,10 @@ class HipVecEnv(object):
                 infos[i] = {"episode": ep}
                 self._dirty_infos.append(int(i))
                 if self._monitors is not None:
-                    self._monitors[i].write("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
-                    self._monitors[i].flush()
+                    with open(self._monitors[i], "at") as f:
+                        f.write("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
             self._n_finished = fin
-        return obs, rew, dones, list(infos)
+        return obs, rew, dones, infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -194,10 +213,7 @@ class HipVecEnv(object):
         return self._h.episode_stats()
 
     def close(self):
-        if self._monitors is not None:
-            for f in self._monitors:
-                f.close()
-            self._monitors = None
+        self._monitors = None
         if self._h is not None:
             self._h.close()
             self._h = None

@@ -130,3 +130,51 @@ def test_ars_trains_on_the_device():
     model.save(path)
     again = ARSModel.load(path)
     assert np.array_equal(again.M, model.M) and again.getAction(np.ones((3, 1))).shape == (3,)
+
+
+@pytest.mark.gpu
+def test_device_normalize_statistics_round_trip(tmp_path):
+    """ARS v2 trains on normalised observations: the running statistics have to survive save / load, in the file layout of
+    stable_baselines' VecNormalize (obs_rms.pkl / ret_rms.pkl), interchangeable with the host-side wrapper."""
+    from srlhip.device_env import DeviceVecEnv, DeviceVecNormalize
+    from srlhip.vec_env import HipVecEnv
+    from srlhip.vec_wrappers import VecNormalize
+    kw = {"srl_model": "ground_truth"}
+    env = DeviceVecNormalize(DeviceVecEnv("MobileRobotGymEnv-v0", 32, seed=1, env_kwargs=kw), norm_reward=False)
+    with torch.cuda.stream(env.torch_stream):
+        env.reset()
+        for _ in range(40):
+            env.step(torch.randint(0, 4, (32,), dtype=torch.int32, device=env.device))
+    env.save_running_average(str(tmp_path))
+    twin = DeviceVecNormalize(DeviceVecEnv("MobileRobotGymEnv-v0", 32, seed=1, env_kwargs=kw), norm_reward=False, training=False)
+    twin.load_running_average(str(tmp_path))
+    assert torch.equal(twin.obs_rms.mean, env.obs_rms.mean) and torch.equal(twin.obs_rms.var, env.obs_rms.var)
+    assert twin.obs_rms.count == env.obs_rms.count
+    host = VecNormalize(HipVecEnv("MobileRobotGymEnv-v0", 32, seed=1, env_kwargs=kw), norm_reward=False, training=False)
+    host.load_running_average(str(tmp_path))
+    assert np.array_equal(host.obs_rms.mean, env.obs_rms.mean.cpu().numpy())
+    o_dev, o_host = twin.reset(), host.reset()
+    assert np.allclose(o_dev.cpu().numpy(), o_host, atol=1e-6)
+    env.close(); twin.close(); host.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_monitor_files_and_early_reset_policy(tmp_path):
+    """4096 envs with a log_dir: one monitor file per env without holding 4096 descriptors open; a second reset() in the
+    middle of an episode is refused unless allow_early_resets (stable_baselines.bench.Monitor semantics)."""
+    from srlhip.vec_env import HipVecEnv
+    env = HipVecEnv("MobileRobotGymEnv-v0", 4096, seed=0, env_kwargs={"srl_model": "ground_truth"}, log_dir=str(tmp_path))
+    env.reset()
+    acts = np.zeros(4096, np.int32)
+    for _ in range(251):
+        obs, rew, done, infos = env.step(acts)
+    assert done.all() and infos[4095]["episode"]["l"] == 251
+    assert open(str(tmp_path / "4095.monitor.csv")).read().splitlines()[2].split(",")[1] == "251"
+    env.reset()                                   # right after the episode end: no running episode
+    env.step(acts)
+    with pytest.raises(RuntimeError):
+        env.reset()
+    env.close()
+    env = HipVecEnv("MobileRobotGymEnv-v0", 8, seed=0, env_kwargs={"srl_model": "ground_truth"}, allow_early_resets=True)
+    env.reset(); env.step(np.zeros(8, np.int32)); env.reset()
+    env.close()
