@@ -215,7 +215,7 @@ int srlhip_graph_end(srlhip_handle h, srlhip_graph_handle *out);
 int srlhip_graph_launch(srlhip_handle h, srlhip_graph_handle g);
 int srlhip_graph_destroy(srlhip_graph_handle g);
 
-/* Which kernel steps this Kuka handle's batch: 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 16384
+/* Which kernel steps this Kuka handle's batch: 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 12288
  * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and Kuka2ButtonGymEnv); the environment variable
  * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs
  * (to ~1e-11 on joint positions; discrete flags identical). */

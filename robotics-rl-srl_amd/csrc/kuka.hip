@@ -23,7 +23,7 @@ using namespace kuka;
 
 constexpr int kWave = 64;
 constexpr int NDBL = 47, NINT = 9;
-constexpr int kGroupKernelMaxEnvs = 16384;     // batches up to this size are stepped by the lane-group kernel (see use_group_kernel)
+constexpr int kGroupKernelMaxEnvs = 12288;     // batches up to this size are stepped by the lane-group kernel (measured crossover, profiles/r02_nsweep_kuka.jsonl)
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
 enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42,

@@ -300,7 +300,7 @@ def test_rand_button_env():
 
 @pytest.mark.parametrize("kernel", ["lane", "group"])
 def test_both_kernels_at_the_headline_size(kernel, monkeypatch):
-    """The library picks the lane-group kernel (16 lanes per env, kuka_group.hpp) for batches up to 16384 envs and the
+    """The library picks the lane-group kernel (16 lanes per env, kuka_group.hpp) for batches up to 12288 envs and the
     lane-per-env kernel (kuka_core.hpp) above; SRLHIP_KUKA_KERNEL forces one.  Both against the oracle at 4096 envs, in
     the throughput mode (Philox streams, device-sampled actions), through two auto-resets per env."""
     monkeypatch.setenv("SRLHIP_KUKA_KERNEL", kernel)
