@@ -215,6 +215,27 @@ int srlhip_graph_end(srlhip_handle h, srlhip_graph_handle *out);
 int srlhip_graph_launch(srlhip_handle h, srlhip_graph_handle g);
 int srlhip_graph_destroy(srlhip_graph_handle g);
 
+/* The part of the Kuka-button model that is NOT pinned by the reference's own source: link frames, inertial parameters,
+ * joint limits / damping of pybullet_data/kuka_iiwa/kuka_with_gripper2.sdf (loaded at kuka.py:60), the IK / gripper
+ * reference points, the gripper's collision spheres, the table and button-base heights of table/table.urdf — recalled
+ * from upstream in this repo, so kept as DATA: 138 doubles.  srlhip_kuka_default_model() returns the baked
+ * table; srlhip_set_kuka_model() installs another one on a Kuka handle (before the next srlhip_reset): the settled state is
+ * re-integrated, every following reset / step uses it.  A 7-joint serial arm whose joints turn about their local z is
+ * assumed (joint_rpy = URDF rpy of the joint frame in the parent link frame, joint_xyz its origin; inertia = principal
+ * moments about com, axes parallel to the link frame).  With a table installed the batch is stepped by the lane-group
+ * kernel at any size; Kuka2ButtonGymEnv handles return SRLHIP_ENOTSUP.  tests/golden/make_kuka_pybullet_golden.py
+ * fills this struct from pybullet_data when PyBullet is importable. */
+typedef struct srlhip_kuka_model {
+    double joint_xyz[7][3], joint_rpy[7][3], joint_lower[7], joint_upper[7], joint_damping;
+    double mass[7], com[7][3], inertia[7][3];
+    double ee_point[3];          /* IK end effector (link_7 inertial frame) in the link_7 frame          */
+    double gripper_point[3];     /* COM of gripper link 8 (getArmPos) in the link_7 frame                 */
+    double sphere[6][4];         /* gripper collision spheres: centre in the link_7 frame, radius         */
+    double table_top_z, button_base_z;
+} srlhip_kuka_model;
+int srlhip_kuka_default_model(srlhip_kuka_model *m);
+int srlhip_set_kuka_model(srlhip_handle h, const srlhip_kuka_model *m);
+
 /* Which kernel steps this Kuka handle's batch: 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 12288
  * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and Kuka2ButtonGymEnv); the environment variable
  * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs

@@ -38,6 +38,42 @@ def set_variant(variant):
     _lib().kuka_oracle_set_variant(int(variant))
 
 
+MODEL_DOUBLES = 138
+MODEL_FIELDS = (("joint_xyz", (7, 3)), ("joint_rpy", (7, 3)), ("joint_lower", (7,)), ("joint_upper", (7,)), ("joint_damping", ()),
+                ("mass", (7,)), ("com", (7, 3)), ("inertia", (7, 3)), ("ee_point", (3,)), ("gripper_point", (3,)), ("sphere", (6, 4)),
+                ("table_top_z", ()), ("button_base_z", ()))
+
+
+def model_to_dict(table):
+    out, k = {}, 0
+    for name, shape in MODEL_FIELDS:
+        n = int(np.prod(shape)) if shape else 1
+        out[name] = np.array(table[k:k + n]).reshape(shape) if shape else float(table[k])
+        k += n
+    assert k == MODEL_DOUBLES
+    return out
+
+
+def model_to_table(model):
+    return np.concatenate([np.asarray(model[name], dtype=np.float64).reshape(-1) for name, _ in MODEL_FIELDS])
+
+
+def get_model():
+    """The recalled part of the Kuka model (link frames, inertial parameters, limits, collision spheres, table / button
+    heights) as the oracle currently integrates it: a dict of arrays in the layout of srlhip_kuka_model."""
+    t = np.zeros(MODEL_DOUBLES)
+    clib.lib().kuka_oracle_get_model(_p(t))
+    return model_to_dict(t)
+
+
+def set_model(model):
+    """Install a model table (dict as returned by get_model(), or the flat 138 doubles) in the physics AND the raster oracle."""
+    t = np.ascontiguousarray(model if not isinstance(model, dict) else model_to_table(model), dtype=np.float64)
+    assert t.shape == (MODEL_DOUBLES,)
+    clib.lib().kuka_oracle_set_model(_p(t))
+    clib.lib().raster_oracle_set_model(_p(t))
+
+
 def aba(q, qd, tau, gz=-10.0):
     q, qd, tau = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau))
     out = np.zeros(7)

@@ -22,21 +22,21 @@
 
 static const double KM_BASE_POS[3] = {-0.1, 0.0, -0.15};        /* kuka.py:63 */
 /* joint frame in parent link frame: xyz then URDF rpy (R = Rz(y) Ry(p) Rx(r)) */
-static const double KM_JOINT_XYZ[7][3] = {
+static double KM_JOINT_XYZ[7][3] = {
     {0, 0, 0.1575}, {0, 0, 0.2025}, {0, 0.2045, 0}, {0, 0, 0.2155}, {0, 0.1845, 0}, {0, 0, 0.2155}, {0, 0.081, 0}};
-static const double KM_JOINT_RPY[7][3] = {
+static double KM_JOINT_RPY[7][3] = {
     {0, 0, 0}, {KM_PI / 2, 0, KM_PI}, {KM_PI / 2, 0, KM_PI}, {KM_PI / 2, 0, 0}, {-KM_PI / 2, KM_PI, 0},
     {KM_PI / 2, 0, 0}, {-KM_PI / 2, KM_PI, 0}};
-static const double KM_JOINT_LOWER[7] = {-2.96705972839, -2.09439510239, -2.96705972839, -2.09439510239,
+static double KM_JOINT_LOWER[7] = {-2.96705972839, -2.09439510239, -2.96705972839, -2.09439510239,
                                          -2.96705972839, -2.09439510239, -3.05432619099};
-static const double KM_JOINT_UPPER[7] = {2.96705972839, 2.09439510239, 2.96705972839, 2.09439510239,
+static double KM_JOINT_UPPER[7] = {2.96705972839, 2.09439510239, 2.96705972839, 2.09439510239,
                                          2.96705972839, 2.09439510239, 3.05432619099};
-static const double KM_JOINT_DAMPING = 0.5;
+static double KM_JOINT_DAMPING = 0.5;
 /* inertial parameters in the link frame; link 6 = link_7 + lumped gripper */
-static const double KM_MASS[7] = {4.0, 4.0, 3.0, 2.7, 1.7, 1.8, 1.8};
-static const double KM_COM[7][3] = {{0, -0.03, 0.12}, {0.0003, 0.059, 0.042}, {0, 0.03, 0.13}, {0, 0.067, 0.034},
+static double KM_MASS[7] = {4.0, 4.0, 3.0, 2.7, 1.7, 1.8, 1.8};
+static double KM_COM[7][3] = {{0, -0.03, 0.12}, {0.0003, 0.059, 0.042}, {0, 0.03, 0.13}, {0, 0.067, 0.034},
                                     {0.0001, 0.021, 0.076}, {0, 0.0006, 0.0004}, {0, 0, 0.31 / 3.0}};
-static const double KM_INERTIA[7][3] = {{0.1, 0.09, 0.02}, {0.05, 0.018, 0.044}, {0.08, 0.075, 0.01},
+static double KM_INERTIA[7][3] = {{0.1, 0.09, 0.02}, {0.05, 0.018, 0.044}, {0.08, 0.075, 0.01},
                                         {0.03, 0.01, 0.029}, {0.02, 0.018, 0.005}, {0.005, 0.0036, 0.0047},
                                         {0.0075, 0.0075, 0.003}};
 /* initial joint state, kuka.py:65-66 (first 7 of 14) and the full constant list
@@ -52,10 +52,10 @@ static const double KM_EE_BOX[2][2][3] = {{{0.35, -0.30, 0.0}, {0.65, 0.30, 0.5}
 #define KM_ARM_MAX_VEL 0.35
 #define KM_ARM_MAX_FORCE 200.0
 /* points fixed in the link_7 frame */
-static const double KM_EE_POINT[3] = {0, 0, 0.02};            /* IK end effector = link_7 inertial frame   */
-static const double KM_GRIPPER_POINT[3] = {0, 0.024, 0.10};   /* COM of gripper link 8 (getArmPos)         */
+static double KM_EE_POINT[3] = {0, 0, 0.02};            /* IK end effector = link_7 inertial frame   */
+static double KM_GRIPPER_POINT[3] = {0, 0.024, 0.10};   /* COM of gripper link 8 (getArmPos)         */
 #define KM_NSPHERE 6
-static const double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, radius                        */
+static double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, radius                        */
     {0, 0.020, 0.255, 0.015}, {0, -0.020, 0.255, 0.015},      /* finger tips                                */
     {0, 0.035, 0.200, 0.020}, {0, -0.035, 0.200, 0.020},      /* finger bodies                              */
     {0, 0, 0.100, 0.060}, {0, 0, 0.0, 0.070}};                /* gripper body, wrist                        */
@@ -68,8 +68,8 @@ static const double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, rad
 #define KM_IK_MAX_ANGLE (45.0 * KM_PI / 180.0)                /* BussIK MaxAngleDLS                          */
 
 /* button (urdf/simple_button.urdf): static base, prismatic cap ("glider") */
-#define KM_TABLE_TOP_Z (-0.195)      /* table.urdf top box, base at z=-0.82 (recalled)                     */
-#define KM_BUTTON_BASE_Z (-0.195)    /* spawned at Z_TABLE=-0.2 inside the table top, settles on it        */
+static double KM_TABLE_TOP_Z = -0.195;   /* table.urdf top box, base at z=-0.82 (recalled)                     */
+static double KM_BUTTON_BASE_Z = -0.195; /* spawned at Z_TABLE=-0.2 inside the table top, settles on it        */
 #define KM_BUTTON_X 0.5
 #define KM_BUTTON_Y 0.0
 #define KM_GLIDER_ORIGIN_Z 0.005     /* simple_button.urdf:13 */
@@ -102,4 +102,41 @@ static const double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, rad
 #define KM_NOISE_STD_JOINTS 0.002
 #define KM_N_RANDOM_ACTIONS_AT_INIT 5
 #define KM_N_SETTLE_STEPS 500
+
+/* The RECALLED part of the model (everything above that is not pinned by the in-tree reference source) as one runtime table,
+ * in the layout of `srlhip_kuka_model` (include/srlhip.h): joint_xyz[7][3] joint_rpy[7][3] joint_lower[7] joint_upper[7]
+ * joint_damping mass[7] com[7][3] inertia[7][3] ee_point[3] gripper_point[3] sphere[6][4] table_top_z button_base_z.
+ * tests/golden/make_kuka_pybullet_golden.py extracts it from pybullet_data when PyBullet is available; km_set_model()
+ * installs it in the including translation unit's copies (kuka_oracle.c and raster_oracle.c each export a setter). */
+#define KM_MODEL_DOUBLES 138
+static void km_get_model(double *t) {
+    int k = 0, i, j;
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) t[k++] = KM_JOINT_XYZ[i][j];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) t[k++] = KM_JOINT_RPY[i][j];
+    for (i = 0; i < 7; i++) t[k++] = KM_JOINT_LOWER[i];
+    for (i = 0; i < 7; i++) t[k++] = KM_JOINT_UPPER[i];
+    t[k++] = KM_JOINT_DAMPING;
+    for (i = 0; i < 7; i++) t[k++] = KM_MASS[i];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) t[k++] = KM_COM[i][j];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) t[k++] = KM_INERTIA[i][j];
+    for (j = 0; j < 3; j++) t[k++] = KM_EE_POINT[j];
+    for (j = 0; j < 3; j++) t[k++] = KM_GRIPPER_POINT[j];
+    for (i = 0; i < KM_NSPHERE; i++) for (j = 0; j < 4; j++) t[k++] = KM_SPHERE[i][j];
+    t[k++] = KM_TABLE_TOP_Z; t[k++] = KM_BUTTON_BASE_Z;
+}
+static void km_set_model(const double *t) {
+    int k = 0, i, j;
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) KM_JOINT_XYZ[i][j] = t[k++];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) KM_JOINT_RPY[i][j] = t[k++];
+    for (i = 0; i < 7; i++) KM_JOINT_LOWER[i] = t[k++];
+    for (i = 0; i < 7; i++) KM_JOINT_UPPER[i] = t[k++];
+    KM_JOINT_DAMPING = t[k++];
+    for (i = 0; i < 7; i++) KM_MASS[i] = t[k++];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) KM_COM[i][j] = t[k++];
+    for (i = 0; i < 7; i++) for (j = 0; j < 3; j++) KM_INERTIA[i][j] = t[k++];
+    for (j = 0; j < 3; j++) KM_EE_POINT[j] = t[k++];
+    for (j = 0; j < 3; j++) KM_GRIPPER_POINT[j] = t[k++];
+    for (i = 0; i < KM_NSPHERE; i++) for (j = 0; j < 4; j++) KM_SPHERE[i][j] = t[k++];
+    KM_TABLE_TOP_Z = t[k++]; KM_BUTTON_BASE_Z = t[k++];
+}
 #endif

@@ -770,3 +770,7 @@ double kuka_oracle_env_step(void *hv, int action, float *obs, int *done) {
     return r;
 }
 void kuka_oracle_env_free(void *hv) { free(hv); }
+
+/* runtime model table (oracle/kuka_model.h): this translation unit's copy */
+void kuka_oracle_set_model(const double *table138) { km_set_model(table138); }
+void kuka_oracle_get_model(double *table138) { km_get_model(table138); }

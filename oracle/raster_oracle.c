@@ -230,3 +230,7 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
     }
     return 0;
 }
+
+/* runtime model table (oracle/kuka_model.h): this translation unit's copy */
+void raster_oracle_set_model(const double *table138) { km_set_model(table138); }
+void raster_oracle_get_model(double *table138) { km_get_model(table138); }

@@ -497,6 +497,24 @@ int srlhip_episode_stats_device(srlhip_handle hh, float *d_last_return, int32_t 
     return 0;
 }
 
+int srlhip_kuka_default_model(srlhip_kuka_model *m) {
+    if (!m) return SRLHIP_EINVAL;
+    kuka_default_model(reinterpret_cast<double *>(m));
+    return 0;
+}
+
+int srlhip_set_kuka_model(srlhip_handle hh, const srlhip_kuka_model *m) {
+    if (!hh || !m) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_EINVAL, "set_kuka_model: not a Kuka handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    for (int i = 0; i < 7; i++)
+        if (!(m->mass[i] > 0.0) || !(m->inertia[i][0] > 0.0) || !(m->inertia[i][1] > 0.0) || !(m->inertia[i][2] > 0.0) || !(m->joint_lower[i] < m->joint_upper[i]))
+            return h->fail(SRLHIP_EINVAL, "set_kuka_model: masses and principal inertias must be positive, joint_lower < joint_upper");
+    return kuka_set_model(h, reinterpret_cast<const double *>(m));
+}
+
 int srlhip_kuka_kernel(srlhip_handle hh) {
     if (!hh) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);

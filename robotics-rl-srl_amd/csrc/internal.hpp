@@ -69,6 +69,8 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
 int kuka_reset_rand_count(const srlhip_config &c);
 int kuka_refresh(Handle *h);
 int kuka_uses_group_kernel(const Handle *h);
+int kuka_set_model(Handle *h, const double *table138);
+void kuka_default_model(double *table138);
 int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
 
 // raster.hip

@@ -10,6 +10,7 @@
 // sequential Gauss-Seidel sweeps per physics step), not HBM bound and not
 // MFMA-shaped; see DESIGN.md §Kuka kernel for the roofline accounting.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -39,6 +40,8 @@ struct KukaState {
     double *settled;    // [kStartDoubles]
     double *starts;     // [nstarts][kStartDoubles]
     int32_t nstarts;
+    Model *model;       // runtime model table (device copy); the baked one unless srlhip_set_kuka_model() installed another
+    int32_t custom_model;
 };
 
 namespace {
@@ -241,7 +244,9 @@ constexpr int kGroupEnvs = kGroupBlock / grp::GL;
 // GIVEN: the caller supplies the actions.  A compile-time switch because a possible action load inside the step loop makes
 // the compiler wait for vmcnt(0) every step — which on gfx9 also waits for the previous step's output STORES to retire
 // (loads and stores share the counter): the random-agent variant has no load in its loop and never waits on memory.
-template <int MODE, bool JOINTS, bool GIVEN>
+// CM: a runtime model table is installed (srlhip_set_kuka_model): per-lane constants come from s.model, resets integrate
+// their init actions from the settled state instead of reading the start table.
+template <int MODE, bool JOINTS, bool GIVEN, bool CM>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                      float *obs, float *rew, uint8_t *done_out, void *act_out) {
@@ -254,7 +259,7 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
     const Cfg &cfg = p.cfg;
     double *scratch = scratch_all[threadIdx.x / GL];
     Lane L;
-    lane_init(L);
+    lane_init<CM>(L, s.model);
     const bool lead = L.l == 0 && valid;
     // Philox mode: the lane-group stream adaptor (batched Gaussian draws); otherwise the generators of the lane-per-env kernel
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
@@ -276,7 +281,7 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         const int j = L.arm ? L.l : 0;
         g.q = s.d[(D_Q + j) * n + e]; g.qd = s.d[(D_QD + j) * n + e]; g.sq = s.d[(D_SQ + j) * n + e]; g.cq = s.d[(D_CQ + j) * n + e];
         if (!L.arm) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
-        gfk(L, g);
+        gfk<CM>(L, g);
     }
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
@@ -307,15 +312,15 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
         bool done;
         double reward;
-        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = genv_step(v, g, L, cfg, scratch, rng_l0, a, ca, ca_own, &done);
-        else reward = genv_step(v, g, L, cfg, scratch, rng0, a, ca, ca_own, &done);
+        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = genv_step<CM>(v, g, L, cfg, scratch, rng_l0, a, ca, ca_own, &done);
+        else reward = genv_step<CM>(v, g, L, cfg, scratch, rng0, a, ca, ca_own, &done);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
                 double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS>(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
-                else genv_reset<JOINTS>(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
+                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS, CM>(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
+                else genv_reset<JOINTS, CM>(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
                 // the start-state loads retire HERE: otherwise the wait for them lands at their first use in the next step, on
                 // every path, where vmcnt(0) also waits for the output stores of steps that did not reset
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -365,13 +370,39 @@ __global__ void kuka_refresh_k(KukaState s, int n) {
 }
 
 
+// Settled state of a runtime model table: 500 zero-action steps (kuka_button_gym_env.py:242-247) by the lane-group stepper
+// (every group of the wavefront integrates the same env; group 0 publishes, pack_start() layout).
+__global__ void __launch_bounds__(kGroupBlock) kuka_group_settle_k(KukaParams p, KukaState s) {
+    using namespace grp;
+    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
+    Lane L; lane_init<true>(L, s.model);
+    Env e = {};
+    GState g;
+    g.q = L.arm ? L.q0 : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
+    e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z;
+    grefresh<true>(L, g, e);
+    const double zero[3] = {0, 0, 0};
+    for (int i = 0; i < kNSettleSteps; i++) gphysics_step<true>(e, g, L, p.cfg, scratch_all[threadIdx.x / GL], zero, p.cfg.action_joints != 0, L.q0);
+    if (threadIdx.x < GL) {
+        double *o = s.settled;
+        if (L.arm) { o[L.l] = g.q; o[7 + L.l] = g.qd; o[14 + L.l] = g.sq; o[21 + L.l] = g.cq; }
+        if (L.l == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o[28 + k] = e.ee[k]; o[33 + k] = e.grip[k]; }
+            o[31] = e.bq; o[32] = e.bqd;
+        }
+    }
+}
+
 // Self-test of the lane-group primitives on the device (tests/test_gpu_group_primitives.py compares with what the host
 // emulation of the same source defines): one wavefront, out[k][lane].
 constexpr int kProbeRows = 40;
 __global__ void __launch_bounds__(64) kuka_group_probe_k(const double *q7, double *out) {
     using namespace grp;
     const int t = threadIdx.x;
-    Lane L; lane_init(L);
+    Lane L; lane_init<false>(L, nullptr);
     const double x = 1.5 * t + 0.25;
     int k = 0;
 #define SRL_OUT(v) out[(k++) * 64 + t] = (v);
@@ -400,7 +431,7 @@ __global__ void __launch_bounds__(64) kuka_group_probe_k(const double *q7, doubl
     {
         GState g; Env e = {};
         g.q = L.arm ? q7[L.l] : 0.0; g.qd = 0.0;
-        grefresh(L, g, e);
+        grefresh<false>(L, g, e);
 #pragma unroll
         for (int c = 0; c < 9; c++) SRL_OUT(g.R[c])
 #pragma unroll
@@ -451,6 +482,13 @@ int kuka_alloc(Handle *h) {
     if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) || (rc = h->dalloc(&s->objs, 30 * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
+    if ((rc = h->dalloc(&s->model, 1))) return rc;
+    {
+        Model m; default_model(m);
+        SRL_HIP_CHECK(h, hipMemcpyAsync(s->model, &m, sizeof m, hipMemcpyHostToDevice, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    s->custom_model = 0;
     if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k))) return rc;
 #define SRL_ALLOW(NB)                                                                                                     \
     if ((rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_HOST, NB>)) || (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_PHILOX, NB>)) ||     \
@@ -500,28 +538,50 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
 // kernel does less total work per env once every SIMD has several wavefronts anyway.  SRLHIP_KUKA_KERNEL=group|lane forces one.
 static bool use_group_kernel(const Handle *h) {
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return false;        // the lane-group kernel has no two-button form
+    if (h->kuka->custom_model) return true;                              // only the lane-group kernel reads the runtime model table
     const char *v = getenv("SRLHIP_KUKA_KERNEL");                        // read per call: tests and probes flip it inside one process
     if (v && (v[0] == 'g' || v[0] == 'l')) return v[0] == 'g';
     return h->n <= kGroupKernelMaxEnvs;
 }
+
+// srlhip_set_kuka_model: install a runtime model table; the settled state is re-integrated with it.  Envs must be reset afterwards.
+int kuka_set_model(Handle *h, const double *table138) {
+    if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return h->fail(SRLHIP_ENOTSUP, "set_kuka_model: Kuka2ButtonGymEnv is stepped by the lane-per-env kernel, which is specialised for the baked model");
+    KukaState *s = h->kuka;
+    SRL_HIP_CHECK(h, hipMemcpyAsync(s->model, table138, sizeof(Model), hipMemcpyHostToDevice, h->stream));
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    s->custom_model = 1;
+    KukaParams p = params_of(h);
+    hipLaunchKernelGGL(kuka_group_settle_k, dim3(1), dim3(kGroupBlock), 0, h->stream, p, *s);
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+void kuka_default_model(double *table138) { Model m; default_model(m); memcpy(table138, &m, sizeof m); }
 
 int kuka_uses_group_kernel(const Handle *h) { return use_group_kernel(h) ? 1 : 0; }
 
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
-    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, cm = h->kuka->custom_model != 0;
+#define SRL_GROUP_GO(MODE, J, G, CM) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, J, G, CM>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+#define SRL_GROUP_CM(MODE, CM)                                                              \
+    if (cm == CM) {                                                                         \
+        if (joints && d_actions) SRL_GROUP_GO(MODE, true, true, CM);                        \
+        else if (joints) SRL_GROUP_GO(MODE, true, false, CM);                               \
+        else if (d_actions) SRL_GROUP_GO(MODE, false, true, CM);                            \
+        else SRL_GROUP_GO(MODE, false, false, CM);                                          \
+    }
 #define SRL_GROUP(MODE)                                                                                                             \
-    if (joints && d_actions) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, true, true>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
-    else if (joints) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, true, false>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
-    else if (d_actions) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, false, true>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out); \
-    else hipLaunchKernelGGL((kuka_group_rollout_k<MODE, false, false>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+    SRL_GROUP_CM(MODE, false) else SRL_GROUP_CM(MODE, true)
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_GROUP(SRLHIP_RNG_PHILOX); break;
         case SRLHIP_RNG_MT19937: SRL_GROUP(SRLHIP_RNG_MT19937); break;
         default: SRL_GROUP(SRLHIP_RNG_HOST);
     }
 #undef SRL_GROUP
+#undef SRL_GROUP_CM
+#undef SRL_GROUP_GO
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }

@@ -91,6 +91,34 @@ constexpr double kDeltaV = 0.03, kDeltaVContinuous = 0.0035, kDeltaTheta = 0.1;
 constexpr double kNoiseStd = 0.01, kNoiseStdContinuous = 0.0001, kNoiseStdJoints = 0.002;
 constexpr int kNInitActions = 5, kNSettleSteps = 500;
 
+// ---------------------------------------------------------------- runtime model table
+// The RECALLED part of the model above as data: `srlhip_kuka_model` of include/srlhip.h (138 doubles, same layout as the
+// oracle's table in oracle/kuka_model.h).  The lane-group kernel (kuka_group.hpp) can integrate any table of this shape — a
+// 7-joint serial arm whose joints turn about their local z — so that link frames / inertial parameters extracted from
+// pybullet_data's kuka_with_gripper2.sdf can be dropped in the moment PyBullet is available
+// (tests/golden/make_kuka_pybullet_golden.py); the lane-per-env kernel is specialised for the baked table.
+struct Model {
+    double joint_xyz[ND][3], joint_rpy[ND][3], joint_lower[ND], joint_upper[ND], joint_damping;
+    double mass[ND], com[ND][3], inertia[ND][3], ee_point[3], gripper_point[3], sphere[kNSphere][4], table_top_z, button_base_z;
+};
+static_assert(sizeof(Model) == 138 * sizeof(double), "srlhip_kuka_model layout");
+inline void default_model(Model &m) {
+    const double hp = kPi / 2;
+    const double rpy[3][3] = {{0, 0, 0}, {hp, 0, kPi}, {hp, 0, 0}};        // kFix 0 / 1 / 2 (1 is also (-pi/2, pi, 0))
+    for (int i = 0; i < ND; i++) {
+        for (int k = 0; k < 3; k++) {
+            m.joint_xyz[i][k] = k == kTransAxis[i] ? kTransLen[i] : 0.0;
+            m.joint_rpy[i][k] = (kFix[i] == 1 && i >= 4) ? (k == 0 ? -hp : k == 1 ? kPi : 0.0) : rpy[kFix[i]][k];   // same rotation, the sdf's spelling
+            m.com[i][k] = kCom[i][k]; m.inertia[i][k] = kInertia[i][k];
+        }
+        m.joint_lower[i] = kJointLower[i]; m.joint_upper[i] = kJointUpper[i]; m.mass[i] = kMass[i];
+    }
+    m.joint_damping = kJointDamping;
+    for (int k = 0; k < 3; k++) { m.ee_point[k] = kEePoint[k]; m.gripper_point[k] = kGripperPoint[k]; }
+    for (int s = 0; s < kNSphere; s++) for (int k = 0; k < 4; k++) m.sphere[s][k] = kSphere[s][k];
+    m.table_top_z = kTableTopZ; m.button_base_z = kButtonBaseZ;
+}
+
 // ---------------------------------------------------------------- LDS scratch
 // [slot][lane] doubles; `st` = lanes per workgroup (64 on the device, 1 on the host).
 constexpr int kMaxGenRows = 6;       // arm-limit rows + contact rows kept per step (first come, first kept)

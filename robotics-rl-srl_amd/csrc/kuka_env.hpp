@@ -164,13 +164,13 @@ SRL_HD void reset_draw(const Cfg &cfg, double *objs, int64_t objs_stride, R &rng
 // scalar part of the state after reset (everything but the arm / glider state, which comes from the start table or from
 // the five joint-mode init steps)
 template <int NB>
-SRL_HD void reset_finish(Env &e, const ResetDraw &d) {
+SRL_HD void reset_finish(Env &e, const ResetDraw &d, double base_z = kButtonBaseZ) {
 #pragma clang fp contract(off)
     e.bx = d.bx; e.by = d.by;
     if constexpr (NB == 2) { e.b2x = d.b2x; e.b2y = d.b2y; }
-    e.bz = kButtonBaseZ; e.bspeed = d.speed;
+    e.bz = base_z; e.bspeed = d.speed;
     e.bpos[0] = d.bx; e.bpos[1] = d.by;
-    e.bpos[2] = kButtonBaseZ + kGliderOriginZ + e.bq + kButtonDistanceHeight;
+    e.bpos[2] = base_z + kGliderOriginZ + e.bq + kButtonDistanceHeight;
     if constexpr (NB == 2) { e.bpos[2] = kZTable + kButtonDistanceHeight; e.goal_id = 0; e.n_contacts2 = 0; e.contact_body1 = 0; e.contact_body2 = 0; }
     e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
 }

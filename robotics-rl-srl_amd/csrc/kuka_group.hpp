@@ -179,34 +179,77 @@ struct Lane {
     double e[ND];             // e[j] = (l == j), j < 7
     double mass, mcomp;       // link mass, composite mass of links l..6
     double com[3], in[3];     // centre of mass and principal inertia in the link frame
-    // joint frame in the parent link's frame, branch-free: columns x' = (sx c, f0 s, (1-f0) s), y' = (-sx s, f0 c, (1-f0) c),
-    // z' = (0, zy, f0); origin t.  (kFix 0: Rz(q); 1: rpy (pi/2,0,pi) Rz(q); 2: rpy (pi/2,0,0) Rz(q); identity off the arm)
+    // joint frame in the parent link's frame.  Baked model (CM = false), branch-free: columns x' = (sx c, f0 s, (1-f0) s),
+    // y' = (-sx s, f0 c, (1-f0) c), z' = (0, zy, f0) (kFix 0: Rz(q); 1: rpy (pi/2,0,pi) Rz(q); 2: rpy (pi/2,0,0) Rz(q); identity
+    // off the arm).  Runtime table (CM = true): F = the fixed rotation's columns, x' = c Fx + s Fy, y' = c Fy - s Fx, z' = Fz.
     double sx, f0, zy, t[3];
+    double F[9];
     double jlo, jhi, q0;      // joint limits, kJointPositions[l]
     double sph[4];            // l < 6: gripper sphere l (centre in the link-7 frame, radius)
+    // replicated scalars of the model (compile-time constants unless a table is installed)
+    double damping, eept[3], grpt[3], table_z, base_z;
 };
 
-SRL_G void lane_init(Lane &L) {
+// URDF rpy -> rotation (Rz(yaw) Ry(pitch) Rx(roll)), columns x y z; entries within 1e-12 of 0 / +-1 are snapped (the iiwa
+// chain is made of quarter turns, which pi/2 in floating point only approximates)
+SRL_G void rpy_columns(const double rpy[3], double F[9]) {
+    const double sr = sin(rpy[0]), cr = cos(rpy[0]), sp = sin(rpy[1]), cp = cos(rpy[1]), sy = sin(rpy[2]), cy = cos(rpy[2]);
+    F[0] = cy * cp; F[1] = sy * cp; F[2] = -sp;
+    F[3] = cy * sp * sr - sy * cr; F[4] = sy * sp * sr + cy * cr; F[5] = cp * sr;
+    F[6] = cy * sp * cr + sy * sr; F[7] = sy * sp * cr - cy * sr; F[8] = cp * cr;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (fabs(F[k]) < 1e-12) F[k] = 0.0;
+        else if (fabs(F[k] - 1.0) < 1e-12) F[k] = 1.0;
+        else if (fabs(F[k] + 1.0) < 1e-12) F[k] = -1.0;
+    }
+}
+
+// CM = false: the baked model (constants of kuka_core.hpp).  CM = true: the runtime table `m` (device or host memory).
+template <bool CM>
+SRL_G void lane_init(Lane &L, const Model *m) {
     const int l = lane_id();
     L.l = l; L.arm = l < ND; L.am = L.arm ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < ND; j++) L.e[j] = l == j ? 1.0 : 0.0;
     const int i = L.arm ? l : 0;
-    double mc = 0.0;
-#pragma unroll
-    for (int k = 0; k < ND; k++) mc += k >= l ? kMass[k] : 0.0;
-    L.mass = L.arm ? kMass[i] : 0.0; L.mcomp = L.arm ? mc : 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { L.com[k] = kCom[i][k]; L.in[k] = L.arm ? kInertia[i][k] : 0.0; }
-    const int fix = L.arm ? kFix[i] : 0, axis = kTransAxis[i];
-    const double len = L.arm ? kTransLen[i] : 0.0;
-    L.sx = fix == 1 ? -1.0 : 1.0; L.f0 = fix == 0 ? 1.0 : 0.0; L.zy = fix == 1 ? 1.0 : fix == 2 ? -1.0 : 0.0;
-    L.t[0] = l == 0 ? kBasePos[0] : 0.0; L.t[1] = (l == 0 ? kBasePos[1] : 0.0) + (axis == 1 ? len : 0.0);
-    L.t[2] = (l == 0 ? kBasePos[2] : 0.0) + (axis == 2 ? len : 0.0);
-    L.jlo = kJointLower[i]; L.jhi = kJointUpper[i]; L.q0 = kJointPositions[i];
     const int s = l < kNSphere ? l : 0;
+    L.q0 = kJointPositions[i];
+    L.sx = 1.0; L.f0 = 1.0; L.zy = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) L.sph[k] = kSphere[s][k];
+    for (int k = 0; k < 9; k++) L.F[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if constexpr (!CM) {
+        double mc = 0.0;
+#pragma unroll
+        for (int k = 0; k < ND; k++) mc += k >= l ? kMass[k] : 0.0;
+        L.mass = L.arm ? kMass[i] : 0.0; L.mcomp = L.arm ? mc : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { L.com[k] = kCom[i][k]; L.in[k] = L.arm ? kInertia[i][k] : 0.0; }
+        const int fix = L.arm ? kFix[i] : 0, axis = kTransAxis[i];
+        const double len = L.arm ? kTransLen[i] : 0.0;
+        L.sx = fix == 1 ? -1.0 : 1.0; L.f0 = fix == 0 ? 1.0 : 0.0; L.zy = fix == 1 ? 1.0 : fix == 2 ? -1.0 : 0.0;
+        L.t[0] = l == 0 ? kBasePos[0] : 0.0; L.t[1] = (l == 0 ? kBasePos[1] : 0.0) + (axis == 1 ? len : 0.0);
+        L.t[2] = (l == 0 ? kBasePos[2] : 0.0) + (axis == 2 ? len : 0.0);
+        L.jlo = kJointLower[i]; L.jhi = kJointUpper[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) L.sph[k] = kSphere[s][k];
+        L.damping = kJointDamping; L.table_z = kTableTopZ; L.base_z = kButtonBaseZ;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { L.eept[k] = kEePoint[k]; L.grpt[k] = kGripperPoint[k]; }
+    } else {
+        double mc = 0.0;
+        for (int k = 0; k < ND; k++) mc += k >= l ? m->mass[k] : 0.0;
+        L.mass = L.arm ? m->mass[i] : 0.0; L.mcomp = L.arm ? mc : 0.0;
+        for (int k = 0; k < 3; k++) {
+            L.com[k] = m->com[i][k]; L.in[k] = L.arm ? m->inertia[i][k] : 0.0;
+            L.t[k] = (L.arm ? m->joint_xyz[i][k] : 0.0) + (l == 0 ? kBasePos[k] : 0.0);
+            L.eept[k] = m->ee_point[k]; L.grpt[k] = m->gripper_point[k];
+        }
+        if (L.arm) rpy_columns(m->joint_rpy[i], L.F);
+        L.jlo = m->joint_lower[i]; L.jhi = m->joint_upper[i];
+        for (int k = 0; k < 4; k++) L.sph[k] = m->sphere[s][k];
+        L.damping = m->joint_damping; L.table_z = m->table_top_z; L.base_z = m->button_base_z;
+    }
 }
 
 // prefix / suffix masks over the chain, rebuilt inside every step from an opaque copy of the lane index (kept out of the
@@ -236,12 +279,19 @@ SRL_G void compose(const double Ra[9], const double pa[3], const double Rb[9], c
 }
 
 // Forward kinematics of the whole chain: local joint transform per lane, inclusive prefix composition over the row.
+template <bool CM>
 SRL_G void gfk(const Lane &L, GState &g) {
-    const double s = g.sq, c = g.cq, f1 = 1.0 - L.f0;      // lanes off the arm carry s = 0, c = 1: the identity
+    const double s = g.sq, c = g.cq;                       // lanes off the arm carry s = 0, c = 1: the identity
     double R[9], p[3];
-    R[0] = L.sx * c; R[1] = L.f0 * s; R[2] = f1 * s;
-    R[3] = -(L.sx * s); R[4] = L.f0 * c; R[5] = f1 * c;
-    R[6] = 0.0; R[7] = L.zy; R[8] = L.f0;
+    if constexpr (!CM) {
+        const double f1 = 1.0 - L.f0;
+        R[0] = L.sx * c; R[1] = L.f0 * s; R[2] = f1 * s;
+        R[3] = -(L.sx * s); R[4] = L.f0 * c; R[5] = f1 * c;
+        R[6] = 0.0; R[7] = L.zy; R[8] = L.f0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { R[k] = c * L.F[k] + s * L.F[3 + k]; R[3 + k] = c * L.F[3 + k] - s * L.F[k]; R[6 + k] = L.F[6 + k]; }
+    }
     p[0] = L.t[0]; p[1] = L.t[1]; p[2] = L.t[2];
 #define SRL_SCAN(D)                                                                              \
     {                                                                                            \
@@ -268,12 +318,13 @@ SRL_G void tip_frame(const GState &g, double Rt[9], double pt[3]) {
 }
 
 // sin/cos of the own joint, frames, gripper position (what update_trig_and_gripper() does for the lane-per-env kernel)
+template <bool CM>
 SRL_G void grefresh(const Lane &L, GState &g, Env &e) {
     if (L.arm) sincos(g.q, &g.sq, &g.cq); else { g.sq = 0.0; g.cq = 1.0; }
-    gfk(L, g);
+    gfk<CM>(L, g);
     double Rt[9], pt[3];
     tip_frame(g, Rt, pt);
-    tip_point(Rt, pt, kGripperPoint, e.grip);
+    tip_point(Rt, pt, L.grpt, e.grip);
 }
 
 // prefix / suffix sums over the chain by masked row broadcasts: out = base + sum_k m[k] * bcast_k(x)
@@ -498,6 +549,7 @@ SRL_G double pgs_sweeps_general(const Lane &L, const Rows &r, uint32_t wave_slot
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation(), same semantics as physics_step<1>() of kuka_core.hpp.
 // `e` holds the env's scalar state replicated on the 16 lanes (its q / qd / sq / cq arrays are not used here), `g` the
 // lane's own joint and frame (valid on entry: grefresh()), jt_own the joint-mode target of the own joint.
+template <bool CM>
 SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode,
                          double jt_own) {
     const double dt = kDt;
@@ -519,7 +571,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
             e.ee[k] = v;
         }
         double ee[3], dS[6], J[6];
-        tip_point(Rt, pt, kEePoint, ee);
+        tip_point(Rt, pt, L.eept, ee);
         {
             double d[3];
 #pragma unroll
@@ -592,7 +644,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
         }
     }
     const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
-    e.contact_table = gany(sphere && (cc[2] - L.sph[3] - kTableTopZ < kContactThreshold)) ? 1 : 0;
+    e.contact_table = gany(sphere && (cc[2] - L.sph[3] - L.table_z < kContactThreshold)) ? 1 : 0;
     // ---- motor target velocity of the own joint
     const double inv_dt = 1.0 / kDt;
     double target = kArmKp * (qdes - g.q) * inv_dt;
@@ -655,7 +707,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
 #pragma unroll
             for (int k = 0; k < 6; k++) Ioc[k] = masked_sum(Io[k], M.ge);
         }
-        tau = -kJointDamping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        tau = -L.damping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
         // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k <= l on lane l, the upper part by transposition; W = M^-1 in place
         double Fc[6], t0[3], t1[3], low[ND];
         sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
@@ -873,7 +925,7 @@ SRL_G void gphysics_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, doubl
     if (L.arm) { g.qd = qd_new + dv; g.q += dt * g.qd; }
     e.bqd += dvb;
     e.bq += dt * e.bqd;
-    grefresh(L, g, e);
+    grefresh<CM>(L, g, e);
 }
 
 // ------------------------------------------------------------------ env level (mirrors kuka_env.hpp for a lane group)
@@ -944,35 +996,45 @@ SRL_G void gunpack_start(Env &e, GState &g, const Lane &L, const double *o) {
 // KukaButtonGymEnv.reset for one lane group (same draws, same table as reset_env<1>).  JOINTS = the continuous joint-space
 // action mode, whose five init actions are integrated here: a compile-time switch so that the other modes carry a single
 // copy of the physics step.
-template <bool JOINTS, class R>
+template <bool JOINTS, bool CM, class R>
 SRL_G void genv_reset(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
                       double *objs, int64_t objs_stride) {
 #pragma clang fp contract(off)
     ResetDraw d;
     reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
-    gunpack_start(e, g, L, JOINTS ? settled : starts + (int64_t)d.idx * kStartDoubles);
-    e.bx = d.bx; e.by = d.by; e.bz = kButtonBaseZ;
-    gfk(L, g);
+    // baked model: the start-state table; runtime model table: the init actions are integrated from the settled state
+    gunpack_start(e, g, L, (JOINTS || CM) ? settled : starts + (int64_t)d.idx * kStartDoubles);
+    e.bx = d.bx; e.by = d.by; e.bz = L.base_z;
+    gfk<CM>(L, g);
     if constexpr (JOINTS) {
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0 + kDeltaTheta * d.g[k];
-            gphysics_step(e, g, L, cfg, scratch, motor, true, jt);
+            gphysics_step<CM>(e, g, L, cfg, scratch, motor, true, jt);
+        }
+    } else if constexpr (CM) {
+        const int base = cfg.is_discrete ? 6 : 2;
+        int rem = d.idx;
+        for (int k = 0; k < kNInitActions; k++) {
+            double motor[3];
+            init_action_motor(cfg, rem % base, motor);
+            gphysics_step<CM>(e, g, L, cfg, scratch, motor, false, L.q0);
+            rem /= base;
         }
     }
-    reset_finish<1>(e, d);
+    reset_finish<1>(e, d, L.base_z);
 }
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own joint's action.
-template <class R>
+template <bool CM, class R>
 SRL_G double genv_step(Env &e, GState &g, const Lane &L, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own,
                        bool *done) {
     StepCmd c;
     step_command(e, cfg, rng, action, ca3, c);
     const double jt = joint_target(c, ca_own, L.q0);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        gphysics_step(e, g, L, cfg, scratch, c.motor, c.joint_mode, jt);
+        gphysics_step<CM>(e, g, L, cfg, scratch, c.motor, c.joint_mode, jt);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

@@ -290,27 +290,29 @@ uint32_t host_ballot(bool p) {
 }}}  // namespace srl::kuka::grp
 
 namespace {
+Model g_model; bool g_model_set = false;
 struct GroupArgs {
+    const Model *model;        // runtime model table, or null for the baked one
     Cfg cfg; int rng_mode; const uint32_t *mt_key; int mt_key_len; Philox act; int T, n, e_idx; const void *actions;
     const double *settled, *starts; float *obs0, *obs, *rew; double *rew64; uint8_t *done_out; void *act_out;
     double *q_trace, *grip_trace, *final_state, *ep_stats;
     MtHost *mt; double *scratch;
 };
 
-template <class R>
+template <bool CM, class R>
 void group_env_body(GroupArgs &a, R &rng) {
     using namespace grp;
     const Cfg &cfg = a.cfg;
     const int n = a.n, e_idx = a.e_idx, T = a.T;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
-    Lane L; lane_init(L);
+    Lane L; lane_init<CM>(L, a.model);
     const bool lead = L.l == 0;
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
     const bool joints = !cfg.is_discrete && cfg.action_joints;
-    if (joints) genv_reset<true>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-    else genv_reset<false>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (joints) genv_reset<true, CM>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    else genv_reset<false, CM>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
@@ -330,15 +332,15 @@ void group_env_body(GroupArgs &a, R &rng) {
             }
             if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = genv_step(env, g, L, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        const double reward = genv_step<CM>(env, g, L, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
             if (cfg.auto_reset) {
-                if (joints) genv_reset<true>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-                else genv_reset<false>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                if (joints) genv_reset<true, CM>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                else genv_reset<false, CM>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
             }
         }
         if (lead) {
@@ -363,11 +365,30 @@ void group_fiber_body(void *p) {
     GroupArgs &a = *static_cast<GroupArgs *>(p);
     if (a.rng_mode == 2) {
         grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0};
-        group_env_body(a, r);
+        if (a.model) group_env_body<true>(a, r); else group_env_body<false>(a, r);
     } else {
         grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0);      // counter-based: every lane holds the same stream
-        group_env_body(a, r);
+        if (a.model) group_env_body<true>(a, r); else group_env_body<false>(a, r);
     }
+}
+
+// settled state of a runtime model table: 500 zero-action steps of one lane group (kuka_button_gym_env.py:242-247)
+struct SettleArgs { const Model *model; Cfg cfg; double *out36; double *scratch; };
+void group_settle_body(void *p) {
+    using namespace grp;
+    SettleArgs &a = *static_cast<SettleArgs *>(p);
+    Lane L; lane_init<true>(L, a.model);
+    Env e; memset(&e, 0, sizeof e);
+    GState g; memset(&g, 0, sizeof g);
+    g.q = L.arm ? L.q0 : 0.0; g.qd = 0.0;
+    for (int k = 0; k < 3; k++) e.ee[k] = kEeInit[k];
+    e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z;
+    grefresh<true>(L, g, e);
+    const double zero[3] = {0, 0, 0};
+    for (int i = 0; i < kNSettleSteps; i++) gphysics_step<true>(e, g, L, a.cfg, a.scratch, zero, a.cfg.action_joints != 0, L.q0);
+    double *o = a.out36;
+    if (L.arm) { o[L.l] = g.q; o[7 + L.l] = g.qd; o[14 + L.l] = g.sq; o[21 + L.l] = g.cq; }
+    if (L.l == 0) { for (int k = 0; k < 3; k++) { o[28 + k] = e.ee[k]; o[33 + k] = e.grip[k]; } o[31] = e.bq; o[32] = e.bqd; }
 }
 }  // namespace
 
@@ -381,13 +402,18 @@ extern "C" int hostcheck_kuka_group_rollout(int is_discrete, int action_joints, 
                                             double *ep_stats) {
     if (g_two) return -1;
     GroupArgs a;
+    a.model = g_model_set ? &g_model : nullptr;
     Cfg &cfg = a.cfg;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
     cfg.moving = g_moving; cfg.two = 0; cfg.max_steps = g_moving ? 1500 : kMaxSteps; cfg.rand_objects = g_rand;
     std::vector<double> settled, starts, scratch(grp::kScratchDoubles);
-    build_tables(cfg, settled, starts);
+    if (a.model) {            // runtime table: settle with the lane-group stepper itself; no start table (resets integrate their init actions)
+        settled.assign(kStartDoubles, 0.0);
+        SettleArgs sa{a.model, cfg, settled.data(), scratch.data()};
+        run_group(group_settle_body, &sa);
+    } else build_tables(cfg, settled, starts);
     a.rng_mode = rng_mode; a.T = T; a.n = n; a.actions = actions; a.settled = settled.data(); a.starts = starts.data();
     a.obs0 = obs0; a.obs = obs; a.rew = rew; a.rew64 = rew64; a.done_out = done_out; a.act_out = act_out;
     a.q_trace = q_trace; a.grip_trace = grip_trace; a.final_state = final_state; a.ep_stats = ep_stats; a.scratch = scratch.data();
@@ -407,3 +433,10 @@ extern "C" void hostcheck_group_debug(int on, double *out) { g_gdbg_on = on; if 
 extern "C" void hostcheck_group_fix_hist(long *out) { memcpy(out, g_fix_hist, sizeof g_fix_hist); memset(g_fix_hist, 0, sizeof g_fix_hist); }
 
 extern "C" void hostcheck_group_clamp_cnt(long *out) { out[0] = g_clamp_cnt[0]; out[1] = g_clamp_cnt[1]; g_clamp_cnt[0] = g_clamp_cnt[1] = 0; }
+
+// runtime model table for the lane-group harness (138 doubles, srlhip_kuka_model layout); null -> the baked model
+extern "C" void hostcheck_kuka_set_model(const double *table138) {
+    g_model_set = table138 != nullptr;
+    if (table138) memcpy(&g_model, table138, sizeof g_model);
+}
+extern "C" void hostcheck_kuka_default_model(double *table138) { Model m; default_model(m); memcpy(table138, &m, sizeof m); }

@@ -37,12 +37,23 @@ EXPORTS = [
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
-    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel",
+    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
     "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
 ]
+
+
+KUKA_MODEL_DOUBLES = 138
+
+
+def kuka_default_model():
+    """The baked srlhip_kuka_model as a flat float64[138] (no GPU needed)."""
+    t = np.zeros(KUKA_MODEL_DOUBLES)
+    rc = load().srlhip_kuka_default_model(t.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return t
 
 
 class Config(ctypes.Structure):
@@ -100,6 +111,8 @@ def load():
     lib.srlhip_episode_stats_device.argtypes = [vp, vp, vp, vp]
     lib.srlhip_selftest_group_primitives.argtypes = [i32, vp, vp, i32]
     lib.srlhip_kuka_kernel.argtypes = [vp]
+    lib.srlhip_kuka_default_model.argtypes = [vp]
+    lib.srlhip_set_kuka_model.argtypes = [vp, vp]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -271,6 +284,12 @@ class Handle(object):
             out = np.zeros((self.num_envs, self.cfg.img_h, self.cfg.img_w, ch), np.uint8)
         self._check(self._lib.srlhip_render(self._h, _ptr(out)), "srlhip_render")
         return out
+
+    def set_kuka_model(self, table):
+        """Install a runtime model table (srlhip_kuka_model: 138 float64, see srlhip.kuka_model) — reset() afterwards."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        assert t.shape == (KUKA_MODEL_DOUBLES,)
+        self._check(self._lib.srlhip_set_kuka_model(self._h, _ptr(t)), "srlhip_set_kuka_model")
 
     def kuka_kernel(self):
         """'group' (16 lanes per env) or 'lane' (one lane per env): the kernel that steps this Kuka batch."""

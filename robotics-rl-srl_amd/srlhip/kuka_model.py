@@ -1,4 +1,10 @@
-"""Bookkeeping constants of the Kuka stepper used by bench.py's roofline line.
+"""The Kuka-button model as data, and bookkeeping constants of the Kuka stepper used by bench.py's roofline line.
+
+`srlhip_kuka_model` (include/srlhip.h) holds every constant of the arm / scene model that the reference does NOT pin in its
+own source — link frames, inertial parameters, joint limits and damping of pybullet_data/kuka_iiwa/kuka_with_gripper2.sdf
+(kuka.py:60), the IK / gripper reference points, the gripper's collision spheres, the table / button-base heights — as 138
+float64.  The library ships a baked table (recalled from upstream, SURVEY App. B.4: PARITY UNPINNED); `from_sdf()` builds
+the table from the real files when they are available, and `Handle.set_kuka_model()` installs it.
 
 FLOPS_PER_ENV_STEP counts the float64 operations of one physics step as
 implemented in csrc/kuka_core.hpp (action_repeat = 1), an FMA = 2 flops:
@@ -7,4 +13,126 @@ implemented in csrc/kuka_core.hpp (action_repeat = 1), an FMA = 2 flops:
   ABA backward (7 x ~330) + forward (7 x ~60)                                  =  2 700
   FK x2, IK (J^T J, LDL^T solve), 7 sincos (~40 each), contacts, rows          =  2 400
 """
+import numpy as np
+
 FLOPS_PER_ENV_STEP = 3.1e4
+
+MODEL_DOUBLES = 138
+MODEL_FIELDS = (("joint_xyz", (7, 3)), ("joint_rpy", (7, 3)), ("joint_lower", (7,)), ("joint_upper", (7,)), ("joint_damping", ()),
+                ("mass", (7,)), ("com", (7, 3)), ("inertia", (7, 3)), ("ee_point", (3,)), ("gripper_point", (3,)), ("sphere", (6, 4)),
+                ("table_top_z", ()), ("button_base_z", ()))
+
+
+def to_dict(table):
+    """flat float64[138] -> {field: array}"""
+    table = np.asarray(table, dtype=np.float64).reshape(-1)
+    assert table.shape == (MODEL_DOUBLES,)
+    out, k = {}, 0
+    for name, shape in MODEL_FIELDS:
+        n = int(np.prod(shape)) if shape else 1
+        out[name] = table[k:k + n].reshape(shape).copy() if shape else float(table[k])
+        k += n
+    return out
+
+
+def to_table(model):
+    """{field: array} -> flat float64[138]"""
+    t = np.concatenate([np.asarray(model[name], dtype=np.float64).reshape(-1) for name, _ in MODEL_FIELDS])
+    assert t.shape == (MODEL_DOUBLES,)
+    return t
+
+
+def default():
+    """The baked table of the library (no GPU needed)."""
+    from . import _lib
+    return to_dict(_lib.kuka_default_model())
+
+
+def _rpy_matrix(rpy):
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def _matrix_rpy(R):
+    p = -np.arcsin(np.clip(R[2, 0], -1.0, 1.0))
+    if abs(np.cos(p)) > 1e-9:
+        return np.array([np.arctan2(R[2, 1], R[2, 2]), p, np.arctan2(R[1, 0], R[0, 0])])
+    return np.array([np.arctan2(-R[1, 2], R[1, 1]), p, 0.0])
+
+
+def from_sdf(sdf_path, base=None):
+    """Arm part of the table from kuka_iiwa/kuka_with_gripper2.sdf (or any sdf / urdf-like model whose first 7 revolute joints
+    form a serial chain turning about the child frames' z): link poses -> joint origins in the parent frame, inertial
+    pose / mass / diagonal inertia per link, joint limits and damping.  Fields the file does not carry (ee_point,
+    gripper_point, collision spheres, table / button heights) are taken from `base` (default: the baked table).
+    The gripper links behind link_7 are lumped into link 7 (mass, centre of mass, inertia by the parallel-axis theorem)."""
+    import xml.etree.ElementTree as ET
+    model = dict(base or default())
+    root = ET.parse(sdf_path).getroot()
+    mdl = root.find(".//model")
+    links, joints = {}, []
+
+    def pose_of(node):
+        txt = node.findtext("pose")
+        v = np.array([float(x) for x in txt.split()]) if txt else np.zeros(6)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = _rpy_matrix(v[3:]), v[:3]
+        return T
+
+    for ln in mdl.findall("link"):
+        inert = ln.find("inertial")
+        I = np.zeros(3)
+        mass, Tin = 0.0, np.eye(4)
+        if inert is not None:
+            mass = float(inert.findtext("mass"))
+            Tin = pose_of(inert)
+            I = np.array([float(inert.findtext("inertia/" + k)) for k in ("ixx", "iyy", "izz")])
+        links[ln.get("name")] = {"T": pose_of(ln), "mass": mass, "Tin": Tin, "I": I}
+    for jn in mdl.findall("joint"):
+        joints.append({"name": jn.get("name"), "type": jn.get("type"), "parent": jn.findtext("parent"), "child": jn.findtext("child"),
+                       "lower": jn.findtext("axis/limit/lower"), "upper": jn.findtext("axis/limit/upper"),
+                       "damping": jn.findtext("axis/dynamics/damping")})
+    chain = [j for j in joints if j["type"] == "revolute"][:7]
+    assert len(chain) == 7, "expected 7 revolute arm joints"
+    parent_T = links[chain[0]["parent"]]["T"]
+    base_T = parent_T.copy()
+    for i, j in enumerate(chain):
+        child = links[j["child"]]
+        rel = np.linalg.inv(parent_T) @ child["T"]
+        # the library places the arm's base at Kuka.reset's base position itself (kuka.py:63): joint 0 is relative to the base link
+        model["joint_xyz"][i], model["joint_rpy"][i] = rel[:3, 3], _matrix_rpy(rel[:3, :3])
+        model["joint_lower"][i], model["joint_upper"][i] = float(j["lower"]), float(j["upper"])
+        model["mass"][i], model["com"][i], model["inertia"][i] = child["mass"], child["Tin"][:3, 3], child["I"]
+        parent_T = child["T"]
+    if chain[0]["damping"] is not None:
+        model["joint_damping"] = float(chain[0]["damping"])
+    # lump everything behind link 7 (the gripper) rigidly into it
+    tip = links[chain[-1]["child"]]
+    behind, frontier = [], [chain[-1]["child"]]
+    while frontier:
+        cur = frontier.pop()
+        for j in joints:
+            if j["parent"] == cur and j["child"] not in behind and j not in chain:
+                behind.append(j["child"])
+                frontier.append(j["child"])
+    m_tot = tip["mass"]
+    c_tot = tip["mass"] * tip["Tin"][:3, 3]
+    parts = [(tip["mass"], tip["Tin"][:3, 3], tip["Tin"][:3, :3] @ np.diag(tip["I"]) @ tip["Tin"][:3, :3].T)]
+    for name in behind:
+        ln = links[name]
+        T = np.linalg.inv(tip["T"]) @ ln["T"] @ ln["Tin"]
+        parts.append((ln["mass"], T[:3, 3], T[:3, :3] @ np.diag(ln["I"]) @ T[:3, :3].T))
+        m_tot += ln["mass"]
+        c_tot = c_tot + ln["mass"] * T[:3, 3]
+    if m_tot > 0:
+        c = c_tot / m_tot
+        I = np.zeros((3, 3))
+        for m, p, Ip in parts:
+            d = p - c
+            I += Ip + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        model["mass"][6], model["com"][6], model["inertia"][6] = m_tot, c, np.diag(I)      # off-diagonal terms dropped
+    del base_T
+    return model

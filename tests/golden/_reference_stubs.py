@@ -59,8 +59,9 @@ def make_fake_pybullet(height=224, width=224):
     return p
 
 
-def install(pybullet_module=None):
-    """Put the stubs in sys.modules and the reference on sys.path."""
+def install(pybullet_module=None, real_pybullet_data=False):
+    """Put the stubs in sys.modules and the reference on sys.path.  real_pybullet_data: keep the importable pybullet_data
+    (make_kuka_pybullet_golden.py runs the reference against the real PyBullet)."""
     sys.path.insert(0, REPO)
     from oracle import gym_seeding
 
@@ -116,9 +117,10 @@ def install(pybullet_module=None):
     # --- pybullet (+ data) -------------------------------------------------
     p = pybullet_module if pybullet_module is not None else make_fake_pybullet()
     sys.modules["pybullet"] = p
-    pd = types.ModuleType("pybullet_data")
-    pd.getDataPath = lambda: "/nonexistent/pybullet_data"
-    sys.modules["pybullet_data"] = pd
+    if not real_pybullet_data:
+        pd = types.ModuleType("pybullet_data")
+        pd.getDataPath = lambda: "/nonexistent/pybullet_data"
+        sys.modules["pybullet_data"] = pd
 
     # --- recording side-car / srl_zoo ---------------------------------------
     sr = types.ModuleType("state_representation")

@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""make_kuka_pybullet_golden.py — the one command that pins the Kuka dynamics against PyBullet.
+
+Run it where `import pybullet` works (pybullet==1.8.6 is what the reference pins, environment.yml:109) and a checkout of
+the reference is available:
+
+    python tests/golden/make_kuka_pybullet_golden.py [--reference /root/reference] [--out tests/golden/kuka_pybullet_reference.npz]
+
+It drives the REFERENCE's own KukaButtonGymEnv (environments/kuka_gym/kuka_button_gym_env.py + kuka.py, unmodified; gym is
+stubbed by tests/golden/_reference_stubs.py when it is not installed, with the restated gym==0.11.0 seeding) on the real
+PyBullet, and records for seeds {0, 1, 2} x 2 episodes of RandomState(1234) discrete actions, per step:
+arm joint positions / velocities (7), button glider position / velocity, gripper position (getArmPos), button_pos, the two
+contact predicates of _reward (button link <-> arm, table <-> arm), reward, done, Kuka.end_effector_pos and the observation.
+It also extracts the model table (`srlhip_kuka_model`, 138 doubles) from pybullet_data's kuka_iiwa/kuka_with_gripper2.sdf
+and from the loaded scene (table top / settled button base height).
+
+tests/test_kuka_pybullet_pin.py then installs that table in the oracle (oracle.kuka_clib.set_model) and in the HIP stepper
+(Handle.set_kuka_model), replays the same seeds / actions and compares: joint positions within 1e-4, reward / done flags
+bit-exact — the north-star bar.  Until this script has been run somewhere, that test SKIPS with "PARITY UNPINNED".
+
+This container has no PyBullet: the script exits with status 2 and says so."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(HERE, "kuka_pybullet_reference.npz"))
+    ap.add_argument("--episodes", type=int, default=2)
+    args = ap.parse_args()
+    try:
+        import pybullet as p
+        import pybullet_data
+    except ImportError as exc:
+        print("PyBullet is not importable here ({}): the Kuka dynamics stay UNPINNED.  Run this script on a machine with "
+              "pybullet==1.8.6 and commit the .npz it writes.".format(exc))
+        return 2
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(REPO, "robotics-rl-srl_amd"))
+    sys.path.insert(0, REPO)
+    import _reference_stubs
+    _reference_stubs.REFERENCE = args.reference
+    try:
+        import gym  # noqa: F401  the real one, if present
+        sys.path.insert(0, args.reference)
+    except ImportError:
+        _reference_stubs.install(pybullet_module=p, real_pybullet_data=True)
+    from environments.kuka_gym import kuka_button_gym_env as ref
+    from srlhip import kuka_model
+
+    # ---- model table from the files the reference loads (kuka.py:60, kuka_button_gym_env.py:221-223)
+    sdf = os.path.join(pybullet_data.getDataPath(), "kuka_iiwa", "kuka_with_gripper2.sdf")
+    model = kuka_model.from_sdf(sdf)
+
+    records = {k: [] for k in ("seed", "episode", "action", "q", "qd", "glider", "gripper", "button_pos", "contact_button",
+                               "contact_table", "reward", "done", "ee_target", "obs", "obs0")}
+    arng = np.random.RandomState(1234)
+    for seed in (0, 1, 2):
+        env = ref.KukaButtonGymEnv(renders=False, is_discrete=True, srl_model="ground_truth", record_data=False)
+        env.seed(seed)
+        for episode in range(args.episodes):
+            obs = env.reset()
+            records["obs0"].append(np.asarray(obs, dtype=np.float64))
+            if seed == 0 and episode == 0:
+                # scene heights as PyBullet settles them: top of the table, origin of the button's base link
+                model["table_top_z"] = float(p.getAABB(env.table_uid)[1][2])
+                model["button_base_z"] = float(p.getBasePositionAndOrientation(env.button_uid)[0][2])
+                ls = p.getLinkState(env._kuka.kuka_uid, 6, computeForwardKinematics=True)      # link_7: world frame of the link
+                R7 = np.array(p.getMatrixFromQuaternion(ls[5])).reshape(3, 3)
+                p7 = np.array(ls[4])
+                model["ee_point"] = R7.T @ (np.array(ls[0]) - p7)                                # its inertial frame = IK end effector
+                model["gripper_point"] = R7.T @ (np.array(env.getArmPos()) - p7)
+            done = False
+            while not done:
+                a = int(arng.randint(6))
+                obs, reward, done, _ = env.step(a)
+                js = [p.getJointState(env._kuka.kuka_uid, j) for j in range(7)]
+                gl = p.getJointState(env.button_uid, ref.BUTTON_GLIDER_IDX)
+                records["seed"].append(seed); records["episode"].append(episode); records["action"].append(a)
+                records["q"].append([s[0] for s in js]); records["qd"].append([s[1] for s in js])
+                records["glider"].append([gl[0], gl[1]])
+                records["gripper"].append(list(env.getArmPos())); records["button_pos"].append(list(env.button_pos))
+                records["contact_button"].append(int(len(p.getContactPoints(env.button_uid, env._kuka.kuka_uid, ref.BUTTON_LINK_IDX)) > 0))
+                records["contact_table"].append(int(len(p.getContactPoints(env.table_uid, env._kuka.kuka_uid)) > 0))
+                records["reward"].append(float(reward)); records["done"].append(int(done))
+                records["ee_target"].append(list(env._kuka.end_effector_pos)); records["obs"].append(np.asarray(obs, dtype=np.float64))
+        env.close()
+    out = {k: np.asarray(v) for k, v in records.items()}
+    out["model_table"] = kuka_model.to_table(model)
+    out["pybullet_version"] = np.array(str(getattr(p, "getAPIVersion", lambda: "?")()))
+    np.savez_compressed(args.out, **out)
+    print("wrote {}: {} steps, model table from {}".format(args.out, len(out["action"]), sdf))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -52,3 +52,21 @@ def group_rollout(seeds, T, actions=None, **kw):
         return kuka_clib.rollout(seeds, T, actions=actions, **kw)
     finally:
         kuka_clib._lib = real
+
+
+def set_model(table):
+    """Runtime model table (138 doubles or a dict, see oracle.kuka_clib.MODEL_FIELDS) for group_rollout(); None -> baked model."""
+    import numpy as np
+    if table is None:
+        lib().hostcheck_kuka_set_model(None)
+        return
+    t = np.ascontiguousarray(kuka_clib.model_to_table(table) if isinstance(table, dict) else table, dtype=np.float64)
+    assert t.shape == (kuka_clib.MODEL_DOUBLES,)
+    lib().hostcheck_kuka_set_model(t.ctypes.data_as(ctypes.c_void_p))
+
+
+def default_model():
+    import numpy as np
+    t = np.zeros(kuka_clib.MODEL_DOUBLES)
+    lib().hostcheck_kuka_default_model(t.ctypes.data_as(ctypes.c_void_p))
+    return kuka_clib.model_to_dict(t)

@@ -340,3 +340,44 @@ def test_kernels_agree_on_state_handover():
         assert np.array_equal(np.concatenate([a["reward"], b["reward"]]), ora["reward"])
         assert np.abs(np.concatenate([a["obs"], b["obs"]]) - ora["obs"]).max() <= TOL
         assert np.abs(q.T - ora["final_state"][:, :7]).max() <= TOL
+
+
+def test_runtime_model_table_on_the_device():
+    """srlhip_set_kuka_model: another arm (masses, centres of mass, inertias, link lengths, joint frames, damping, gripper
+    geometry) installed as DATA — the lane-group kernel integrates it, the oracle with the same table agrees; the baked table
+    sent through the same entry point reproduces the baked model."""
+    from srlhip import kuka_model
+    n, T = 256, 500
+    actions = np.random.RandomState(31).randint(6, size=(T, n)).astype(np.int32)
+    actions[np.random.RandomState(32).rand(T, n) < 0.3] = 4
+    m0 = kuka_clib.get_model()
+    rs = np.random.RandomState(5)
+    m = {k: (np.array(v, copy=True) if not np.isscalar(v) else v) for k, v in m0.items()}
+    m["mass"] = m0["mass"] * rs.uniform(0.8, 1.3, 7); m["com"] = m0["com"] + rs.uniform(-0.01, 0.01, (7, 3))
+    m["inertia"] = m0["inertia"] * rs.uniform(0.8, 1.3, (7, 3)); m["joint_xyz"] = m0["joint_xyz"] * 1.05
+    m["joint_rpy"] = m0["joint_rpy"] + rs.uniform(-0.03, 0.03, (7, 3)); m["joint_damping"] = 0.7
+    m["gripper_point"] = m0["gripper_point"] + np.array([0.0, 0.01, 0.02]); m["sphere"] = m0["sphere"] * 1.1
+    base = kuka_clib.rollout(7 + np.arange(n), T, actions=actions, trace=False)
+    try:
+        for table, ref in ((m0, base), (m, None)):
+            h = make(n, seed0=7)
+            h.set_kuka_model(kuka_model.to_table(table))
+            assert h.kuka_kernel() == "group"
+            obs0 = h.reset()
+            out = h.rollout(T, actions=actions)
+            if ref is None:
+                kuka_clib.set_model(table)
+                ref = kuka_clib.rollout(7 + np.arange(n), T, actions=actions, trace=False)
+                assert np.abs(ref["obs"] - base["obs"]).max() > 1e-2          # it IS a different arm
+            check_planes(ref, obs0, out)
+            assert np.abs(h.get_state(_lib.F_KUKA_Q).T - ref["final_state"][:, :7]).max() <= TOL
+            h.close()
+    finally:
+        kuka_clib.set_model(m0)
+    # Kuka2Button handles are stepped by the lane-per-env kernel (baked model only): they refuse a table
+    cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
+    cfg.num_envs = 4
+    h = _lib.Handle(cfg)
+    with pytest.raises(_lib.SrlHipError):
+        h.set_kuka_model(kuka_model.to_table(m0))
+    h.close()
