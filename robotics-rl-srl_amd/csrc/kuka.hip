@@ -370,6 +370,51 @@ __global__ void kuka_refresh_k(KukaState s, int n) {
 }
 
 
+// srlhip_reset with a runtime model table installed: KukaButtonGymEnv.reset by lane groups (the start-state table of
+// kuka_reset_k belongs to the baked model).
+template <int MODE, bool JOINTS>
+__global__ void __launch_bounds__(kGroupBlock)
+kuka_group_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand, int rand_stride,
+                   float *obs) {
+    using namespace grp;
+    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
+    const int64_t n = p.n;
+    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
+    const bool valid = e_raw < p.n && !(mask && !mask[e_raw < p.n ? e_raw : 0]);
+    const int e = e_raw < p.n ? e_raw : p.n - 1;
+    Lane L; lane_init<true>(L, s.model);
+    const bool lead = L.l == 0 && valid;
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
+    Rng rng0;
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
+    Lane0Rng<Rng> rng_l0{&rng0, lead};
+    Env v = {};
+    GState g;
+    double *objs = valid ? s.objs + e : nullptr;
+    if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS, true>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.starts, s.settled, objs, n);
+    else genv_reset<JOINTS, true>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.starts, s.settled, objs, n);
+    if (valid && L.arm) {
+        s.d[(D_Q + L.l) * n + e] = g.q; s.d[(D_QD + L.l) * n + e] = g.qd; s.d[(D_SQ + L.l) * n + e] = g.sq; s.d[(D_CQ + L.l) * n + e] = g.cq;
+    }
+    if (lead) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
+        s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
+        s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
+        s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
+        s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
+        s.i[I_TERM * n + e] = v.terminated;
+        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
+        else krng_store<MODE>(rng0, rs, e);
+        st.ep_return[e] = 0.0; st.ep_length[e] = 0;
+        if (obs) {
+            const int od = p.cfg.obs_mode == 1 ? 14 : p.cfg.obs_mode == 2 ? 17 : 3;
+            observe(v, p.cfg, obs + (int64_t)e * od, 1);
+        }
+    }
+}
+
 // Settled state of a runtime model table: 500 zero-action steps (kuka_button_gym_env.py:242-247) by the lane-group stepper
 // (every group of the wavefront integrates the same env; group 0 publishes, pack_start() layout).
 __global__ void __launch_bounds__(kGroupBlock) kuka_group_settle_k(KukaParams p, KukaState s) {
@@ -514,6 +559,22 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
     const int stride = kuka_reset_rand_count(h->cfg);
     float *obs = static_cast<float *>(d_obs);
+    if (h->kuka->custom_model) {
+        if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
+        dim3 ggrid((h->n + kGroupEnvs - 1) / kGroupEnvs), gblock(kGroupBlock);
+        const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+#define SRL_GRESET(MODE)                                                                                                                       \
+        if (joints) hipLaunchKernelGGL((kuka_group_reset_k<MODE, true>), ggrid, gblock, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
+        else hipLaunchKernelGGL((kuka_group_reset_k<MODE, false>), ggrid, gblock, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs)
+        switch (h->cfg.rng_mode) {
+            case SRLHIP_RNG_HOST: SRL_GRESET(SRLHIP_RNG_HOST); break;
+            case SRLHIP_RNG_PHILOX: SRL_GRESET(SRLHIP_RNG_PHILOX); break;
+            default: SRL_GRESET(SRLHIP_RNG_MT19937);
+        }
+#undef SRL_GRESET
+        SRL_HIP_CHECK(h, hipGetLastError());
+        return 0;
+    }
     const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
 #define SRL_RESET(MODE)                                                                                                          \
     if (two) hipLaunchKernelGGL((kuka_reset_k<MODE, 2>), grid, block, kLdsBytes, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
