@@ -1,5 +1,6 @@
 """Device-resident VecEnv stack and the batched ARS evaluation.  The tensor wrappers are device
 agnostic, so their arithmetic is checked on CPU tensors against the numpy shims; the GPU tests run the real handle."""
+import os
 import sys
 import types
 
@@ -178,3 +179,41 @@ def test_vec_env_monitor_files_and_early_reset_policy(tmp_path):
     env = HipVecEnv("MobileRobotGymEnv-v0", 8, seed=0, env_kwargs={"srl_model": "ground_truth"}, allow_early_resets=True)
     env.reset(); env.step(np.zeros(8, np.int32)); env.reset()
     env.close()
+
+
+def test_cma_es_strategy_minimises_a_quadratic():
+    """the restated (mu/mu_w, lambda)-CMA-ES on a rotated ill-conditioned quadratic (CPU tensors)"""
+    from rl_baselines.evolution_strategies.cma_es import CMAES, BatchedMLP
+    n = 12
+    rs = np.random.RandomState(0)
+    Q = np.linalg.qr(rs.randn(n, n))[0]
+    A = torch.as_tensor(Q @ np.diag(np.logspace(0, 3, n)) @ Q.T)
+    es = CMAES(n * [1.0], 0.5, 16, torch.device("cpu"), seed=1)
+    for _ in range(400):
+        x = es.ask()
+        es.tell(x, ((x @ A) * x).sum(1))
+    assert es.fbest < 1e-12 and float((es.mean ** 2).sum()) < 1e-12           # log-linear convergence on a 1e3-conditioned bowl
+    mlp = BatchedMLP(3, 2, hidden=5)                                     # parameter layout = nn.Module.parameters() order
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2)).double()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    obs = torch.randn(4, 3, dtype=torch.float64)
+    assert torch.allclose(mlp.forward(flat.unsqueeze(0).expand(4, -1), obs), net(obs))
+
+
+@pytest.mark.gpu
+def test_cma_es_trains_on_the_device(tmp_path):
+    from rl_baselines.evolution_strategies.cma_es import CMAESModel
+    args = types.SimpleNamespace(env="MobileRobot1DGymEnv-v0", seed=0, num_population=16, mu=0.0, sigma=0.14, cuda=True,
+                                 deterministic=True, num_stack=1, srl_model="ground_truth", continuous_actions=False,
+                                 num_timesteps=16 * 251 * 4, log_dir=str(tmp_path))
+    seen = []
+    model = CMAESModel().train(args, callback=lambda l, g: seen.append(l["k"]),
+                               env_kwargs={"srl_model": "ground_truth", "shape_reward": True})
+    assert len(model.history) >= 4 and len(seen) >= 4 * 251 and np.isfinite(model.best_model).all()
+    assert model.best_model.shape == (model.policy.n_params,) and np.abs(model.best_model).max() > 0
+    assert os.path.exists(os.path.join(str(tmp_path), "obs_rms.pkl"))
+    path = os.path.join(str(tmp_path), "cma.pkl")
+    model.save(path)
+    again = CMAESModel.load(path)
+    assert np.array_equal(again.best_model, model.best_model) and again.getAction(np.ones((3, 1))).shape == (3,)
+    assert np.allclose(again.getActionProba(np.ones((2, 1))).sum(1), 1.0)
