@@ -599,7 +599,7 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
 // kernel does less total work per env once every SIMD has several wavefronts anyway.  SRLHIP_KUKA_KERNEL=group|lane forces one.
 static bool use_group_kernel(const Handle *h) {
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return false;        // the lane-group kernel has no two-button form
-    if (h->kuka->custom_model) return true;                              // only the lane-group kernel reads the runtime model table
+    if (h->kuka->custom_model) return true;                              // only the lane-group kernel reads the runtime model table (the override below cannot undo that)
     const char *v = getenv("SRLHIP_KUKA_KERNEL");                        // read per call: tests and probes flip it inside one process
     if (v && (v[0] == 'g' || v[0] == 'l')) return v[0] == 'g';
     return h->n <= kGroupKernelMaxEnvs;

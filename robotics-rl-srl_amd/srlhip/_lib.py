@@ -170,6 +170,12 @@ class Handle(object):
         self.action_dim = self._lib.srlhip_action_dim(self._h)
         self.num_actions = self._lib.srlhip_num_actions(self._h)
         self.reset_rand_count = self._lib.srlhip_reset_rand_count(self._h)
+        # SRLHIP_KUKA_SDF=<.../pybullet_data/kuka_iiwa/kuka_with_gripper2.sdf>: take the arm model from the file the
+        # reference loads (kuka.py:60) instead of the baked (recalled) table
+        sdf = os.environ.get("SRLHIP_KUKA_SDF")
+        if sdf and cfg.env_kind in (ENV_KUKA_BUTTON, ENV_KUKA_MOVING, ENV_KUKA_RAND):
+            from . import kuka_model
+            self.set_kuka_model(kuka_model.to_table(kuka_model.from_sdf(sdf)))
 
     def _check(self, rc, what):
         if rc:
