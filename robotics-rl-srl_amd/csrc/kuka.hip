@@ -14,39 +14,12 @@
 
 #include <type_traits>
 
-#include "internal.hpp"
-#include "kuka_env.hpp"
-#include "kuka_group.hpp"
+#include "kuka_device.hpp"
 
 namespace srl {
-
 using namespace kuka;
 
-constexpr int kWave = 64;
-constexpr int NDBL = 47, NINT = 9;
-constexpr int kGroupKernelMaxEnvs = 12288;     // batches up to this size are stepped by the lane-group kernel (measured crossover, profiles/r02_nsweep_kuka.jsonl)
-
-// SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
-enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42,
-       D_B2Q = 43, D_B2QD = 44, D_B2X = 45, D_B2Y = 46 };      // second button (Kuka2ButtonGymEnv)
-// SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
-enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6, I_GOAL = 7, I_NCONTACT2 = 8 };
-
-struct KukaState {
-    double *d;          // [NDBL][n]
-    int32_t *i;         // [NINT][n]
-    double *rows;       // [SC_ROWS_TOTAL][n]  generic constraint rows (global scratch, L2-resident)
-    double *objs;       // [30][n]  KukaRandButton distractor objects (x, y, present) x 10
-    double *settled;    // [kStartDoubles]
-    double *starts;     // [nstarts][kStartDoubles]
-    int32_t nstarts;
-    Model *model;       // runtime model table (device copy); the baked one unless srlhip_set_kuka_model() installed another
-    int32_t custom_model;
-};
-
 namespace {
-
-struct KukaParams { Cfg cfg; int32_t n; };
 
 template <int NB>
 __device__ __forceinline__ void load_env(const KukaState &s, int64_t n, int64_t e, Env &v) {
@@ -85,29 +58,6 @@ __device__ __forceinline__ void store_env(const KukaState &s, int64_t n, int64_t
     s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
     s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
     s.i[I_TERM * n + e] = v.terminated;
-}
-
-struct DevMt { Mt19937 m;
-    __device__ double double01() { return m.double01(); } __device__ double uniform(double a, double b) { return m.uniform(a, b); }
-    __device__ double normal(double a, double b) { return m.normal(a, b); } __device__ uint32_t bounded(uint32_t r) { return m.bounded(r); } };
-struct DevPhilox { Philox p;
-    __device__ double double01() { return p.double01(); } __device__ double uniform(double a, double b) { return p.uniform(a, b); }
-    __device__ double normal(double a, double b) { return p.normal(a, b); } __device__ uint32_t bounded(uint32_t r) { return p.bounded(r); } };
-template <int MODE> struct KRng;
-template <> struct KRng<SRLHIP_RNG_HOST> { using type = HostDraws; };
-template <> struct KRng<SRLHIP_RNG_PHILOX> { using type = DevPhilox; };
-template <> struct KRng<SRLHIP_RNG_MT19937> { using type = DevMt; };
-
-template <int MODE>
-__device__ __forceinline__ void krng_load(typename KRng<MODE>::type &r, const RngState &rs, int e, int n, const double *draws) {
-    if constexpr (MODE == SRLHIP_RNG_HOST) { r.v = draws; r.i = 0; }
-    else if constexpr (MODE == SRLHIP_RNG_PHILOX) { r.p.k0 = rs.key[e]; r.p.k1 = rs.key[n + e]; r.p.ctr = rs.ctr[e]; r.p.stream = 0; }
-    else r.m.load(rs.mt, e);
-}
-template <int MODE>
-__device__ __forceinline__ void krng_store(const typename KRng<MODE>::type &r, const RngState &rs, int e) {
-    if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = r.p.ctr;
-    else if constexpr (MODE == SRLHIP_RNG_MT19937) r.m.store(rs.mt, e);
 }
 
 extern __shared__ double kuka_lds[];
@@ -234,131 +184,6 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Lane-group rollout (kuka_group.hpp): 16 lanes = one DPP row per env, one wavefront (4 envs) per workgroup.  A 4096-env
-// batch is 1024 wavefronts — one per SIMD of the MI355X — instead of the 64 of kuka_rollout_k; same state planes, same
-// start-state table, same outputs.  KukaButton / MovingButton / RandButton (NB == 1).
-constexpr int kGroupBlock = 64;
-constexpr int kGroupEnvs = kGroupBlock / grp::GL;
-
-// GIVEN: the caller supplies the actions.  A compile-time switch because a possible action load inside the step loop makes
-// the compiler wait for vmcnt(0) every step — which on gfx9 also waits for the previous step's output STORES to retire
-// (loads and stores share the counter): the random-agent variant has no load in its loop and never waits on memory.
-// CM: a runtime model table is installed (srlhip_set_kuka_model): per-lane constants come from s.model, resets integrate
-// their init actions from the settled state instead of reading the start table.
-template <int MODE, bool JOINTS, bool GIVEN, bool CM>
-__global__ void __launch_bounds__(kGroupBlock)
-kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
-                     float *obs, float *rew, uint8_t *done_out, void *act_out) {
-    using namespace grp;
-    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
-    const int64_t n = p.n;
-    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
-    const bool valid = e_raw < p.n;
-    const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the DPP ops)
-    const Cfg &cfg = p.cfg;
-    double *scratch = scratch_all[threadIdx.x / GL];
-    Lane L;
-    lane_init<CM>(L, s.model);
-    const bool lead = L.l == 0 && valid;
-    // Philox mode: the lane-group stream adaptor (batched Gaussian draws); otherwise the generators of the lane-per-env kernel
-    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
-    Rng rng0;
-    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
-    else krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
-    // generators whose state lives in HBM (MT19937) are advanced by lane 0 only; counter-based / host streams are replayed by all
-    Lane0Rng<Rng> rng_l0{&rng0, lead};
-    Env v = {};
-    GState g;
-    {   // env scalars replicated on the row, the own joint per arm lane
-#pragma unroll
-        for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
-        v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
-        v.bz = s.d[D_BZ * n + e]; v.bspeed = s.d[D_BSPEED * n + e];
-        v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
-        v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
-        v.terminated = s.i[I_TERM * n + e];
-        const int j = L.arm ? L.l : 0;
-        g.q = s.d[(D_Q + j) * n + e]; g.qd = s.d[(D_QD + j) * n + e]; g.sq = s.d[(D_SQ + j) * n + e]; g.cq = s.d[(D_CQ + j) * n + e];
-        if (!L.arm) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
-        gfk<CM>(L, g);
-    }
-    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
-    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
-    GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
-    Philox &act = gact.p;
-    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
-    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
-    for (int t = 0; t < T; t++) {
-        const int64_t row = (int64_t)t * n + e;
-        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
-        if constexpr (GIVEN) {
-            if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
-            else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
-        } else {
-            if (cfg.is_discrete) a = gact.next(5);
-            else for (int j = 0; j < adim; j += 2) {
-                uint32_t o[4]; act.block(o);
-                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
-                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
-            }
-            if (act_out && lead) {
-                if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
-                else for (int j = 0; j < adim; j++) static_cast<float *>(act_out)[row * adim + j] = ca[j];
-            }
-        }
-        float ca_own = 0.f;
-#pragma unroll
-        for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
-        bool done;
-        double reward;
-        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = genv_step<CM>(v, g, L, cfg, scratch, rng_l0, a, ca, ca_own, &done);
-        else reward = genv_step<CM>(v, g, L, cfg, scratch, rng0, a, ca, ca_own, &done);
-        ep_ret += reward; ep_len += 1; last_reward = reward;
-        if (done) {
-            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
-            if (cfg.auto_reset) {
-                double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS, CM>(v, g, L, cfg, scratch, rng_l0, s.starts, s.settled, objs, n);
-                else genv_reset<JOINTS, CM>(v, g, L, cfg, scratch, rng0, s.starts, s.settled, objs, n);
-                // the start-state loads retire HERE: otherwise the wait for them lands at their first use in the next step, on
-                // every path, where vmcnt(0) also waits for the output stores of steps that did not reset
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            }
-        }
-        if (lead) {
-            if (obs) observe(v, cfg, obs + row * od, 1);
-            if (rew) rew[row] = (float)reward;
-            if (done_out) done_out[row] = (uint8_t)done;
-        }
-    }
-    // (the exit stores recompute their plane addresses from an opaque copy of the env index: otherwise the ~25 addresses
-    //  formed for the entry loads stay live across the whole rollout loop and push its working set into scratch)
-    int e_out = e;
-    asm volatile("" : "+v"(e_out));
-    const int e_in = e;
-    (void)e_in;
-#define e e_out
-    if (valid && L.arm) {
-        s.d[(D_Q + L.l) * n + e] = g.q; s.d[(D_QD + L.l) * n + e] = g.qd; s.d[(D_SQ + L.l) * n + e] = g.sq; s.d[(D_CQ + L.l) * n + e] = g.cq;
-    }
-    if (lead) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
-        s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
-        s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
-        s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
-        s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
-        s.i[I_TERM * n + e] = v.terminated;
-        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
-        else krng_store<MODE>(rng0, rs, e);
-        if constexpr (!GIVEN) rs.act_ctr[e] = act.ctr;
-        st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
-        st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
-    }
-#undef e
-}
-
 // after srlhip_set_state(KUKA_Q): refresh the cached sin/cos and the gripper position
 __global__ void kuka_refresh_k(KukaState s, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,137 +194,6 @@ __global__ void kuka_refresh_k(KukaState s, int n) {
     store_env<1>(s, n, e, v);
 }
 
-
-// srlhip_reset with a runtime model table installed: KukaButtonGymEnv.reset by lane groups (the start-state table of
-// kuka_reset_k belongs to the baked model).
-template <int MODE, bool JOINTS>
-__global__ void __launch_bounds__(kGroupBlock)
-kuka_group_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand, int rand_stride,
-                   float *obs) {
-    using namespace grp;
-    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
-    const int64_t n = p.n;
-    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
-    const bool valid = e_raw < p.n && !(mask && !mask[e_raw < p.n ? e_raw : 0]);
-    const int e = e_raw < p.n ? e_raw : p.n - 1;
-    Lane L; lane_init<true>(L, s.model);
-    const bool lead = L.l == 0 && valid;
-    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
-    Rng rng0;
-    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
-    else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
-    Lane0Rng<Rng> rng_l0{&rng0, lead};
-    Env v = {};
-    GState g;
-    double *objs = valid ? s.objs + e : nullptr;
-    if constexpr (MODE == SRLHIP_RNG_MT19937) genv_reset<JOINTS, true>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.starts, s.settled, objs, n);
-    else genv_reset<JOINTS, true>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.starts, s.settled, objs, n);
-    if (valid && L.arm) {
-        s.d[(D_Q + L.l) * n + e] = g.q; s.d[(D_QD + L.l) * n + e] = g.qd; s.d[(D_SQ + L.l) * n + e] = g.sq; s.d[(D_CQ + L.l) * n + e] = g.cq;
-    }
-    if (lead) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
-        s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
-        s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
-        s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
-        s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
-        s.i[I_TERM * n + e] = v.terminated;
-        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
-        else krng_store<MODE>(rng0, rs, e);
-        st.ep_return[e] = 0.0; st.ep_length[e] = 0;
-        if (obs) {
-            const int od = p.cfg.obs_mode == 1 ? 14 : p.cfg.obs_mode == 2 ? 17 : 3;
-            observe(v, p.cfg, obs + (int64_t)e * od, 1);
-        }
-    }
-}
-
-// Settled state of a runtime model table: 500 zero-action steps (kuka_button_gym_env.py:242-247) by the lane-group stepper
-// (every group of the wavefront integrates the same env; group 0 publishes, pack_start() layout).
-__global__ void __launch_bounds__(kGroupBlock) kuka_group_settle_k(KukaParams p, KukaState s) {
-    using namespace grp;
-    __shared__ double scratch_all[kGroupEnvs][kScratchDoubles];
-    Lane L; lane_init<true>(L, s.model);
-    Env e = {};
-    GState g;
-    g.q = L.arm ? L.q0 : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
-    e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z;
-    grefresh<true>(L, g, e);
-    const double zero[3] = {0, 0, 0};
-    for (int i = 0; i < kNSettleSteps; i++) gphysics_step<true>(e, g, L, p.cfg, scratch_all[threadIdx.x / GL], zero, p.cfg.action_joints != 0, L.q0);
-    if (threadIdx.x < GL) {
-        double *o = s.settled;
-        if (L.arm) { o[L.l] = g.q; o[7 + L.l] = g.qd; o[14 + L.l] = g.sq; o[21 + L.l] = g.cq; }
-        if (L.l == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { o[28 + k] = e.ee[k]; o[33 + k] = e.grip[k]; }
-            o[31] = e.bq; o[32] = e.bqd;
-        }
-    }
-}
-
-// Self-test of the lane-group primitives on the device (tests/test_gpu_group_primitives.py compares with what the host
-// emulation of the same source defines): one wavefront, out[k][lane].
-constexpr int kProbeRows = 40;
-__global__ void __launch_bounds__(64) kuka_group_probe_k(const double *q7, double *out) {
-    using namespace grp;
-    const int t = threadIdx.x;
-    Lane L; lane_init<false>(L, nullptr);
-    const double x = 1.5 * t + 0.25;
-    int k = 0;
-#define SRL_OUT(v) out[(k++) * 64 + t] = (v);
-    SRL_OUT((double)L.l)
-    SRL_OUT(bcast<3>(x)) SRL_OUT(bcast<15>(x))
-    SRL_OUT(shr<1>(x, -1.0)) SRL_OUT(shr<2>(x, -2.0)) SRL_OUT(shr<4>(x, -4.0))
-    SRL_OUT((double)ballot(t % 3 == 0)) SRL_OUT(gany(t == 37) ? 1.0 : 0.0) SRL_OUT(wany(t == 37) ? 1.0 : 0.0)
-    { double acc = (double)t; fmac_bcast<5>(acc, x, 2.0); SRL_OUT(acc) }
-    { double acc = 0.125 * t; const double tt = pgs_row<2>(acc, 0.125 * (t & 15) - 0.25, 0.5, t % 16 == 4 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
-    { double acc = 0.125 * t; const double tt = pgs_row2<1, 9>(acc, 0.25 * (t & 15) - 0.5, 0.5, t % 16 >= 8 ? 0.25 : 0.0, t % 16 == 0 ? 1.0 : 0.0); SRL_OUT(acc) SRL_OUT(tt) }
-    SRL_OUT(rcp(x + 1.0))
-    { Masks M; make_masks(L.l, M); SRL_OUT(masked_sum(x, M.le)) SRL_OUT(masked_sum(x, M.ge, 3.0)) }
-    {
-        double A[ND];
-#pragma unroll
-        for (int c = 0; c < ND; c++) A[c] = L.arm ? (c == L.l ? 4.0 + L.l : 1.0 / (1.0 + L.l + c)) : 0.0;      // SPD, row l on lane l
-        double b = L.arm ? 1.0 + L.l : 0.0, unused = 0.0, B[ND];
-#pragma unroll
-        for (int c = 0; c < ND; c++) B[c] = A[c];
-        gj_step<0, false>(L, B, b);
-        SRL_OUT(b)
-        gj_step<0, true>(L, A, unused);
-#pragma unroll
-        for (int c = 0; c < ND; c++) SRL_OUT(A[c])
-    }
-    {
-        GState g; Env e = {};
-        g.q = L.arm ? q7[L.l] : 0.0; g.qd = 0.0;
-        grefresh<false>(L, g, e);
-#pragma unroll
-        for (int c = 0; c < 9; c++) SRL_OUT(g.R[c])
-#pragma unroll
-        for (int c = 0; c < 3; c++) SRL_OUT(g.p[c])
-#pragma unroll
-        for (int c = 0; c < 3; c++) SRL_OUT(e.grip[c])
-    }
-#undef SRL_OUT
-}
-
-KukaParams params_of(const Handle *h) {
-    KukaParams p;
-    const srlhip_config &c = h->cfg;
-    p.cfg.random_target = c.random_target; p.cfg.force_down = c.force_down; p.cfg.shape_reward = c.shape_reward;
-    p.cfg.action_repeat = c.action_repeat; p.cfg.is_discrete = c.is_discrete; p.cfg.action_joints = c.action_joints;
-    p.cfg.obs_mode = c.obs_mode; p.cfg.auto_reset = c.auto_reset; p.cfg.max_distance = c.max_distance;
-    p.cfg.moving = c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0;
-    p.cfg.two = c.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
-    p.cfg.rand_objects = c.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
-    p.cfg.max_steps = p.cfg.moving ? 1500 : p.cfg.two ? kMaxSteps2Button : kMaxSteps;
-    p.n = h->n;
-    return p;
-}
 
 constexpr size_t kLdsBytes = (size_t)SC_TOTAL * kWave * sizeof(double);
 
@@ -561,19 +255,7 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
     float *obs = static_cast<float *>(d_obs);
     if (h->kuka->custom_model) {
         if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
-        dim3 ggrid((h->n + kGroupEnvs - 1) / kGroupEnvs), gblock(kGroupBlock);
-        const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
-#define SRL_GRESET(MODE)                                                                                                                       \
-        if (joints) hipLaunchKernelGGL((kuka_group_reset_k<MODE, true>), ggrid, gblock, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
-        else hipLaunchKernelGGL((kuka_group_reset_k<MODE, false>), ggrid, gblock, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs)
-        switch (h->cfg.rng_mode) {
-            case SRLHIP_RNG_HOST: SRL_GRESET(SRLHIP_RNG_HOST); break;
-            case SRLHIP_RNG_PHILOX: SRL_GRESET(SRLHIP_RNG_PHILOX); break;
-            default: SRL_GRESET(SRLHIP_RNG_MT19937);
-        }
-#undef SRL_GRESET
-        SRL_HIP_CHECK(h, hipGetLastError());
-        return 0;
+        return kuka_group_reset_table(h, p, d_mask, d_host_rand, stride, obs);
     }
     const bool two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
 #define SRL_RESET(MODE)                                                                                                          \
@@ -613,9 +295,7 @@ int kuka_set_model(Handle *h, const double *table138) {
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     s->custom_model = 1;
     KukaParams p = params_of(h);
-    hipLaunchKernelGGL(kuka_group_settle_k, dim3(1), dim3(kGroupBlock), 0, h->stream, p, *s);
-    SRL_HIP_CHECK(h, hipGetLastError());
-    return 0;
+    return kuka_group_settle_table(h, p);
 }
 void kuka_default_model(double *table138) { Model m; default_model(m); memcpy(table138, &m, sizeof m); }
 
@@ -623,28 +303,8 @@ int kuka_uses_group_kernel(const Handle *h) { return use_group_kernel(h) ? 1 : 0
 
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {
-    dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
-    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, cm = h->kuka->custom_model != 0;
-#define SRL_GROUP_GO(MODE, J, G, CM) hipLaunchKernelGGL((kuka_group_rollout_k<MODE, J, G, CM>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
-#define SRL_GROUP_CM(MODE, CM)                                                              \
-    if (cm == CM) {                                                                         \
-        if (joints && d_actions) SRL_GROUP_GO(MODE, true, true, CM);                        \
-        else if (joints) SRL_GROUP_GO(MODE, true, false, CM);                               \
-        else if (d_actions) SRL_GROUP_GO(MODE, false, true, CM);                            \
-        else SRL_GROUP_GO(MODE, false, false, CM);                                          \
-    }
-#define SRL_GROUP(MODE)                                                                                                             \
-    SRL_GROUP_CM(MODE, false) else SRL_GROUP_CM(MODE, true)
-    switch (h->cfg.rng_mode) {
-        case SRLHIP_RNG_PHILOX: SRL_GROUP(SRLHIP_RNG_PHILOX); break;
-        case SRLHIP_RNG_MT19937: SRL_GROUP(SRLHIP_RNG_MT19937); break;
-        default: SRL_GROUP(SRLHIP_RNG_HOST);
-    }
-#undef SRL_GROUP
-#undef SRL_GROUP_CM
-#undef SRL_GROUP_GO
-    SRL_HIP_CHECK(h, hipGetLastError());
-    return 0;
+    return h->kuka->custom_model ? kuka_group_launch_table(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+                                 : kuka_group_launch_baked(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
 }
 
 int kuka_rollout(Handle *h, int T, const void *d_actions, void *d_obs, float *d_rew, uint8_t *d_done, void *d_act_out) {
@@ -706,19 +366,6 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     v->b2q = s->d + D_B2Q * n; v->b2x = s->d + D_B2X * n; v->b2y = s->d + D_B2Y * n;
     v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
     v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
-}
-
-int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles) {
-    if (out_doubles < kProbeRows * 64) return SRLHIP_EINVAL;
-    double *dq = nullptr, *dout = nullptr;
-    if (hipMalloc(&dq, 7 * sizeof(double)) != hipSuccess || hipMalloc(&dout, kProbeRows * 64 * sizeof(double)) != hipSuccess) return SRLHIP_ENOMEM;
-    (void)hipMemcpy(dq, q7_host, 7 * sizeof(double), hipMemcpyHostToDevice);
-    (void)hipMemset(dout, 0, kProbeRows * 64 * sizeof(double));
-    hipLaunchKernelGGL(kuka_group_probe_k, dim3(1), dim3(64), 0, 0, dq, dout);
-    const hipError_t err = hipDeviceSynchronize();
-    (void)hipMemcpy(out_host, dout, kProbeRows * 64 * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(dq); (void)hipFree(dout);
-    return err == hipSuccess ? 0 : SRLHIP_EHIP;
 }
 
 int kuka_refresh(Handle *h) {
