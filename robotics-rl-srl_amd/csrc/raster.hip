@@ -74,15 +74,16 @@ __device__ __forceinline__ void set_prim(Prim &p, int type, float r, float g, fl
 }
 
 // ---- ray / primitive intersection: returns t (> 0) or -1, and the surface normal ----------------------
-__device__ __forceinline__ float hit_plane(const Prim &p, float oz, float dz, float &nx, float &ny, float &nz) {
+// The hit functions return t only, plus what the normal of THIS hit needs later (aux, code): normals are evaluated once, for
+// the nearest hit (prim_normal), not for every candidate — their divisions were a third of a capsule test.
+__device__ __forceinline__ float hit_plane(const Prim &p, float oz, float dz) {
     if (dz == 0.0f) return -1.0f;
     const float t = (p.az - oz) / dz;
-    nx = 0.0f; ny = 0.0f; nz = 1.0f;
     return t > 0.0f ? t : -1.0f;
 }
 
 __device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float &nx, float &ny, float &nz) {
+                                         float &aux, int &code) {
     // into the box frame (rotation about z by -yaw)
     const float px = ox - p.ax, py = oy - p.ay, pz = oz - p.az;
     const float lox = p.cs * px + p.sn * py, loy = p.cs * py - p.sn * px;
@@ -104,13 +105,12 @@ __device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, floa
         }
     }
     if (tmin > tmax || tmin <= 0.0f) return -1.0f;
-    const float lnx = axis == 0 ? sign : 0.0f, lny = axis == 1 ? sign : 0.0f;
-    nx = p.cs * lnx - p.sn * lny; ny = p.sn * lnx + p.cs * lny; nz = axis == 2 ? sign : 0.0f;
+    aux = sign; code = axis;
     return tmin;
 }
 
 __device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                              float &nx, float &ny, float &nz) {
+                                              float &aux, int &code) {
     const float R = p.bx, z0 = p.az, z1 = p.az + p.bz;
     const float px = ox - p.ax, py = oy - p.ay;
     float best = -1.0f;
@@ -121,10 +121,7 @@ __device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy,
         if (disc >= 0.0f) {
             const float t = (-b - sqrtf(disc)) / a;
             const float z = oz + t * dz;
-            if (t > 0.0f && z >= z0 && z <= z1) {
-                best = t;
-                nx = (px + t * dx) / R; ny = (py + t * dy) / R; nz = 0.0f;
-            }
+            if (t > 0.0f && z >= z0 && z <= z1) { best = t; code = 0; }
         }
     }
     if (dz != 0.0f) {       // caps (the top one is what a camera above ever sees)
@@ -132,14 +129,14 @@ __device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy,
         const float t = (zc - oz) / dz;
         if (t > 0.0f && (best < 0.0f || t < best)) {
             const float hx = px + t * dx, hy = py + t * dy;
-            if (hx * hx + hy * hy <= R * R) { best = t; nx = 0.0f; ny = 0.0f; nz = dz < 0.0f ? 1.0f : -1.0f; }
+            if (hx * hx + hy * hy <= R * R) { best = t; code = 1; }
         }
     }
     return best;
 }
 
 __device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             float &nx, float &ny, float &nz) {
+                                             float &aux, int &code) {
     const float bax = p.bx - p.ax, bay = p.by - p.ay, baz = p.bz - p.az;
     const float oax = ox - p.ax, oay = oy - p.ay, oaz = oz - p.az;
     const float baba = bax * bax + bay * bay + baz * baz;
@@ -169,9 +166,27 @@ __device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, 
         y = y <= 0.0f ? 0.0f : baba;
     }
     if (t <= 0.0f) return -1.0f;
-    const float k = y / baba;
-    nx = (oax + t * dx - bax * k) / p.rad; ny = (oay + t * dy - bay * k) / p.rad; nz = (oaz + t * dz - baz * k) / p.rad;
+    aux = y; code = 0;
     return t;
+}
+
+// normal of primitive p where the ray (eye o, unit direction d) hits it at parameter t; aux / code as left by its hit function
+__device__ __forceinline__ void prim_normal(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, float t, float aux,
+                                            int code, float &nx, float &ny, float &nz) {
+    if (p.type == PRIM_PLANE) { nx = 0.0f; ny = 0.0f; nz = 1.0f; }
+    else if (p.type == PRIM_BOX) {
+        const float lnx = code == 0 ? aux : 0.0f, lny = code == 1 ? aux : 0.0f;
+        nx = p.cs * lnx - p.sn * lny; ny = p.sn * lnx + p.cs * lny; nz = code == 2 ? aux : 0.0f;
+    } else if (p.type == PRIM_CYL) {
+        if (code == 0) { nx = (ox - p.ax + t * dx) / p.bx; ny = (oy - p.ay + t * dy) / p.bx; nz = 0.0f; }
+        else { nx = 0.0f; ny = 0.0f; nz = dz < 0.0f ? 1.0f : -1.0f; }
+    } else {
+        const float bax = p.bx - p.ax, bay = p.by - p.ay, baz = p.bz - p.az;
+        const float oax = ox - p.ax, oay = oy - p.ay, oaz = oz - p.az;
+        const float baba = bax * bax + bay * bay + baz * baz;
+        const float k = aux / baba;
+        nx = (oax + t * dx - bax * k) / p.rad; ny = (oay + t * dy - bay * k) / p.rad; nz = (oaz + t * dz - baz * k) / p.rad;
+    }
 }
 
 // ---- scenes ----------------------------------------------------------------------------------------------
@@ -265,27 +280,31 @@ __device__ __forceinline__ uint32_t finish_pixel(bool hit, float bnx, float bny,
 // z-test of the unit ray (dx, dy, dz) from the eye against the primitives in `mask` (wave-uniform), starting from `best`
 __device__ __forceinline__ bool trace(const Prim *prims, uint64_t mask, const Camera &c, float dx, float dy, float dz, float &best,
                                       float &bnx, float &bny, float &bnz, float &cr, float &cg, float &cb) {
-    bool hit = false;
+    int win = -1, wcode = 0;
+    float waux = 0.0f;
     while (mask) {                                   // wave-uniform list of the primitives that can touch this tile
         const int k = __builtin_ctzll(mask);
         mask &= mask - 1;
         const Prim &p = prims[k];
-        float nx, ny, nz, t;
-        if (p.type == PRIM_PLANE) t = hit_plane(p, c.ez, dz, nx, ny, nz);
-        else if (p.type == PRIM_BOX) t = hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
-        else if (p.type == PRIM_CYL) t = hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
-        else t = hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, nx, ny, nz);
-        if (t > 0.0f && t < best) {
-            best = t; bnx = nx; bny = ny; bnz = nz; cr = p.r; cg = p.g; cb = p.b; hit = true;
-            if (p.type == PRIM_PLANE) {
-                // plane.urdf's texture: 1 m blue/white checker aligned with the world axes (period, phase and the two
-                // colours measured on the reference's imgs/mobile_robot.gif: x in [0,1) x y in [0,1) is white)
-                const int par = (int)floorf(c.ex + t * dx) + (int)floorf(c.ey + t * dy);
-                if ((par & 1) == 0) { cr = 1.0f; cg = 1.0f; cb = 1.0f; }
-            }
-        }
+        float t, aux = 0.0f;
+        int code = 0;
+        if (p.type == PRIM_PLANE) t = hit_plane(p, c.ez, dz);
+        else if (p.type == PRIM_BOX) t = hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
+        else if (p.type == PRIM_CYL) t = hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
+        else t = hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
+        if (t > 0.0f && t < best) { best = t; win = k; waux = aux; wcode = code; }
     }
-    return hit;
+    if (win < 0) return false;
+    const Prim &p = prims[win];
+    prim_normal(p, c.ex, c.ey, c.ez, dx, dy, dz, best, waux, wcode, bnx, bny, bnz);
+    cr = p.r; cg = p.g; cb = p.b;
+    if (p.type == PRIM_PLANE) {
+        // plane.urdf's texture: 1 m blue/white checker aligned with the world axes (period, phase and the two
+        // colours measured on the reference's imgs/mobile_robot.gif: x in [0,1) x y in [0,1) is white)
+        const int par = (int)floorf(c.ex + best * dx) + (int)floorf(c.ey + best * dy);
+        if ((par & 1) == 0) { cr = 1.0f; cg = 1.0f; cb = 1.0f; }
+    }
+    return true;
 }
 
 __device__ __forceinline__ void pixel_ray(const Camera &c, float sx, float sy, float &dx, float &dy, float &dz) {
@@ -336,6 +355,7 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     __shared__ Prim prims[kMaxPrims];
     __shared__ float rects[kMaxPrims][4];
     __shared__ int nprims;
+    __shared__ uint32_t tile_masks[kTilePixels / 64];                     // per 8x8 tile of the current band: primitives whose rectangle overlaps it
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
     const int e = blockIdx.x, cam = blockIdx.y;
     Camera c = rp.cam[cam];
@@ -358,19 +378,26 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     for (int row0 = 0; row0 < rp.h; row0 += band_rows) {
         const int rows = min(band_rows, rp.h - row0), base = row0 * rp.w, count = rows * rp.w;
         const int ntiles = ((rows + 7) >> 3) * tiles_x;
-        int ty = wave / tiles_x, tx = wave - ty * tiles_x;                 // one division per band, not per tile
-        for (int t = wave; t < ntiles; t += kRasterBlock / 64, tx += kRasterBlock / 64) {
-            while (tx >= tiles_x) { tx -= tiles_x; ty++; }
-            const int col0 = tx * 8, r0 = row0 + ty * 8;
-            // tile rectangle in tangent space (pixel edges; y grows upwards while rows grow downwards)
-            // (culling only — the primitives' rectangles carry 1e-3 of slack — so reciprocals instead of divisions)
+        // tile -> primitive masks, one tile per lane (instead of one ballot per tile per wavefront): tile rectangle in
+        // tangent space (pixel edges; y grows upwards while rows grow downwards), culling only — the primitives' rectangles
+        // carry 1e-3 of slack — so reciprocals instead of divisions
+        for (int t = threadIdx.x; t < ntiles; t += kRasterBlock) {
+            const int tyy = t / tiles_x, txx = t - tyy * tiles_x, col0 = txx * 8, r0 = row0 + tyy * 8;
             const float tx0 = ((float)col0 * inv_w2 - 1.0f) * c.tan_half_fov;
             const float tx1 = ((float)(col0 + 8) * inv_w2 - 1.0f) * c.tan_half_fov;
             const float ty1 = (1.0f - (float)r0 * inv_h2) * c.tan_half_fov;
             const float ty0 = (1.0f - (float)(r0 + 8) * inv_h2) * c.tan_half_fov;
-            bool touch = false;
-            if (lane < np) touch = rects[lane][0] <= tx1 && rects[lane][1] >= tx0 && rects[lane][2] <= ty1 && rects[lane][3] >= ty0;
-            uint64_t mask = __ballot(touch);
+            uint32_t m = 0;
+            for (int k = 0; k < np; k++)
+                if (rects[k][0] <= tx1 && rects[k][1] >= tx0 && rects[k][2] <= ty1 && rects[k][3] >= ty0) m |= 1u << k;
+            tile_masks[t] = m;
+        }
+        __syncthreads();
+        int ty = wave / tiles_x, tx = wave - ty * tiles_x;                 // one division per band, not per tile
+        for (int t = wave; t < ntiles; t += kRasterBlock / 64, tx += kRasterBlock / 64) {
+            while (tx >= tiles_x) { tx -= tiles_x; ty++; }
+            const int col0 = tx * 8, r0 = row0 + ty * 8;
+            uint64_t mask = (uint64_t)__builtin_amdgcn_readfirstlane((int)tile_masks[t]) & 0xffffffffull;
             const int row = r0 + ly, col = col0 + lx;
             if (row < rp.h && col < rp.w) {
                 uint32_t rgb;
