@@ -8,20 +8,22 @@
 // camera model, object poses and colours, z-buffered, Lambert + ambient shading
 // (DESIGN.md §Rasteriser).
 //
-// Mapping: one 256-lane workgroup per (env, camera).  The env's scene — at most 16
+// Mapping: one 256-lane workgroup per (env, camera).  The env's scene — at most 28
 // analytic primitives (plane, z-rotated box, upright cylinder, capsule) — is built
 // once per workgroup into LDS from the SoA state (for the Kuka: float64 forward
-// kinematics from the cached joint sin/cos), then every lane ray-casts its pixels
-// against the MOVING primitives whose projected bounding box overlaps its wavefront's 8x8
-// tile (one ballot per tile; nearest hit = z-buffer in registers) and parks 3 bytes per
-// pixel in an LDS band buffer that is flushed with coalesced 16-byte stores:
-// the path's HBM traffic is the 12 288-byte image per env and nothing else.
+// kinematics from the cached joint sin/cos).
 // The cameras are fixed and the first primitives of a scene (floor plane, table / arena walls)
 // never move, so a per-handle setup kernel (raster_bg_k) stores for every pixel its unit ray,
-// the depth of the nearest static hit and the shaded static colour: a tile no moving primitive
-// can touch is a copy of that background, and the other tiles start their z-test from it —
-// same arithmetic per primitive, same bytes, without normalising the ray and re-hitting the
-// floor for every env.  (The MobileRobot fpv camera rides on the robot: it takes the full path.)
+// the depth of the nearest static hit and the shaded static colour.  raster_k then rasterises
+// only the MOVING primitives, in object order: each one's conservative screen footprint (for a
+// capsule: a slab around its projected axis, row by row) is cut into 64-pixel chunks shared
+// by the wavefronts; the exact ray test of that primitive runs for those pixels only and the
+// nearest hit is kept by a 64-bit atomic min in an LDS z-buffer that starts from the static
+// depth.  The hit pixels are then shaded from a dense list, every other pixel is a copy of the
+// cached background, and the band leaves with 12 bytes per lane: the path's HBM traffic is the
+// 12 288-byte image per env and nothing else.  Same arithmetic per (primitive, pixel) as a
+// full per-pixel z-test, same bytes — culling decides only which tests are skipped.
+// (The MobileRobot fpv camera rides on the robot: raster_tiles_k walks 8x8 tiles with the full test.)
 // float32 throughout, -ffp-contract=off so that the C oracle (oracle/raster_oracle.c)
 // reproduces the bytes.
 #include "internal.hpp"
@@ -61,6 +63,7 @@ struct Camera {
 struct RasterParams {
     int32_t kind, n, h, w, channels, ncam;
     int32_t fpv;           // mobile family, second camera: rides on the robot (cam[1] is stored relative to the robot position)
+    int32_t cam0;          // first camera this launch renders (blockIdx.y counts from it)
     int32_t nstatic;       // the first nstatic primitives of every env's scene are identical and never move
     const float4 *rays[2]; // per fixed camera: (unit ray, depth of the nearest static hit or 3e38) per pixel; null = full path
     const uint32_t *bg[2]; //                   shaded static colour per pixel (r | g << 8 | b << 16)
@@ -74,16 +77,16 @@ __device__ __forceinline__ void set_prim(Prim &p, int type, float r, float g, fl
 }
 
 // ---- ray / primitive intersection: returns t (> 0) or -1, and the surface normal ----------------------
-// The hit functions return t only, plus what the normal of THIS hit needs later (aux, code): normals are evaluated once, for
+// The hit functions return t only, plus a 3-bit `code` that says which face / part was hit: normals are evaluated once, for
 // the nearest hit (prim_normal), not for every candidate — their divisions were a third of a capsule test.
+//   box: axis | 4 when the face normal points along +axis;  cylinder: 0 side, 1 cap;  capsule: 0 body, 1 sphere at a, 2 sphere at b
 __device__ __forceinline__ float hit_plane(const Prim &p, float oz, float dz) {
     if (dz == 0.0f) return -1.0f;
     const float t = (p.az - oz) / dz;
     return t > 0.0f ? t : -1.0f;
 }
 
-__device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float &aux, int &code) {
+__device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, int &code) {
     // into the box frame (rotation about z by -yaw)
     const float px = ox - p.ax, py = oy - p.ay, pz = oz - p.az;
     const float lox = p.cs * px + p.sn * py, loy = p.cs * py - p.sn * px;
@@ -105,12 +108,11 @@ __device__ __forceinline__ float hit_box(const Prim &p, float ox, float oy, floa
         }
     }
     if (tmin > tmax || tmin <= 0.0f) return -1.0f;
-    aux = sign; code = axis;
+    code = axis | (sign > 0.0f ? 4 : 0);
     return tmin;
 }
 
-__device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                              float &aux, int &code) {
+__device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, int &code) {
     const float R = p.bx, z0 = p.az, z1 = p.az + p.bz;
     const float px = ox - p.ax, py = oy - p.ay;
     float best = -1.0f;
@@ -135,8 +137,7 @@ __device__ __forceinline__ float hit_cylinder(const Prim &p, float ox, float oy,
     return best;
 }
 
-__device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             float &aux, int &code) {
+__device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, int &code) {
     const float bax = p.bx - p.ax, bay = p.by - p.ay, baz = p.bz - p.az;
     const float oax = ox - p.ax, oay = oy - p.ay, oaz = oz - p.az;
     const float baba = bax * bax + bay * bay + baz * baz;
@@ -151,6 +152,7 @@ __device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, 
     if (h < 0.0f || baba == 0.0f) return -1.0f;
     float t = -1.0f, y = 0.0f;
     bool body = false;
+    code = 0;
     if (a > 0.0f) {
         t = (-b - sqrtf(h)) / a;
         y = baoa + t * bard;
@@ -163,20 +165,21 @@ __device__ __forceinline__ float hit_capsule(const Prim &p, float ox, float oy, 
         h = b * b - c;
         if (h < 0.0f) return -1.0f;
         t = -b - sqrtf(h);
-        y = y <= 0.0f ? 0.0f : baba;
+        code = y <= 0.0f ? 1 : 2;
     }
     if (t <= 0.0f) return -1.0f;
-    aux = y; code = 0;
     return t;
 }
 
-// normal of primitive p where the ray (eye o, unit direction d) hits it at parameter t; aux / code as left by its hit function
-__device__ __forceinline__ void prim_normal(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, float t, float aux,
-                                            int code, float &nx, float &ny, float &nz) {
+// normal of primitive p where the ray (eye o, unit direction d) hits it at parameter t; code as left by its hit function
+__device__ __forceinline__ void prim_normal(const Prim &p, float ox, float oy, float oz, float dx, float dy, float dz, float t, int code,
+                                            float &nx, float &ny, float &nz) {
     if (p.type == PRIM_PLANE) { nx = 0.0f; ny = 0.0f; nz = 1.0f; }
     else if (p.type == PRIM_BOX) {
-        const float lnx = code == 0 ? aux : 0.0f, lny = code == 1 ? aux : 0.0f;
-        nx = p.cs * lnx - p.sn * lny; ny = p.sn * lnx + p.cs * lny; nz = code == 2 ? aux : 0.0f;
+        const int axis = code & 3;
+        const float sign = (code & 4) ? 1.0f : -1.0f;
+        const float lnx = axis == 0 ? sign : 0.0f, lny = axis == 1 ? sign : 0.0f;
+        nx = p.cs * lnx - p.sn * lny; ny = p.sn * lnx + p.cs * lny; nz = axis == 2 ? sign : 0.0f;
     } else if (p.type == PRIM_CYL) {
         if (code == 0) { nx = (ox - p.ax + t * dx) / p.bx; ny = (oy - p.ay + t * dy) / p.bx; nz = 0.0f; }
         else { nx = 0.0f; ny = 0.0f; nz = dz < 0.0f ? 1.0f : -1.0f; }
@@ -184,10 +187,16 @@ __device__ __forceinline__ void prim_normal(const Prim &p, float ox, float oy, f
         const float bax = p.bx - p.ax, bay = p.by - p.ay, baz = p.bz - p.az;
         const float oax = ox - p.ax, oay = oy - p.ay, oaz = oz - p.az;
         const float baba = bax * bax + bay * bay + baz * baz;
-        const float k = aux / baba;
+        const float bard = bax * dx + bay * dy + baz * dz;
+        const float baoa = bax * oax + bay * oay + baz * oaz;
+        const float y = code == 0 ? baoa + t * bard : (code == 1 ? 0.0f : baba);      // where along the axis, as hit_capsule had it
+        const float k = y / baba;
         nx = (oax + t * dx - bax * k) / p.rad; ny = (oay + t * dy - bay * k) / p.rad; nz = (oaz + t * dz - baz * k) / p.rad;
     }
 }
+
+// colour of the hit (primitive p, parameter t, code) seen along the unit ray d from the eye: what the z-test winner becomes
+__device__ __forceinline__ uint32_t shade_hit(const Prim &p, const Camera &c, float dx, float dy, float dz, float t, int code);
 
 // ---- scenes ----------------------------------------------------------------------------------------------
 __device__ int build_mobile_scene(const RasterParams &rp, const RasterMobileView &v, int e, Prim *prims) {
@@ -277,33 +286,40 @@ __device__ __forceinline__ uint32_t finish_pixel(bool hit, float bnx, float bny,
     return r8 | (g8 << 8) | (b8 << 16);
 }
 
-// z-test of the unit ray (dx, dy, dz) from the eye against the primitives in `mask` (wave-uniform), starting from `best`
-__device__ __forceinline__ bool trace(const Prim *prims, uint64_t mask, const Camera &c, float dx, float dy, float dz, float &best,
-                                      float &bnx, float &bny, float &bnz, float &cr, float &cg, float &cb) {
-    int win = -1, wcode = 0;
-    float waux = 0.0f;
-    while (mask) {                                   // wave-uniform list of the primitives that can touch this tile
-        const int k = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const Prim &p = prims[k];
-        float t, aux = 0.0f;
-        int code = 0;
-        if (p.type == PRIM_PLANE) t = hit_plane(p, c.ez, dz);
-        else if (p.type == PRIM_BOX) t = hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
-        else if (p.type == PRIM_CYL) t = hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
-        else t = hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, aux, code);
-        if (t > 0.0f && t < best) { best = t; win = k; waux = aux; wcode = code; }
-    }
-    if (win < 0) return false;
-    const Prim &p = prims[win];
-    prim_normal(p, c.ex, c.ey, c.ez, dx, dy, dz, best, waux, wcode, bnx, bny, bnz);
-    cr = p.r; cg = p.g; cb = p.b;
+__device__ __forceinline__ uint32_t shade_hit(const Prim &p, const Camera &c, float dx, float dy, float dz, float t, int code) {
+    float nx, ny, nz, cr = p.r, cg = p.g, cb = p.b;
+    prim_normal(p, c.ex, c.ey, c.ez, dx, dy, dz, t, code, nx, ny, nz);
     if (p.type == PRIM_PLANE) {
         // plane.urdf's texture: 1 m blue/white checker aligned with the world axes (period, phase and the two
         // colours measured on the reference's imgs/mobile_robot.gif: x in [0,1) x y in [0,1) is white)
-        const int par = (int)floorf(c.ex + best * dx) + (int)floorf(c.ey + best * dy);
+        const int par = (int)floorf(c.ex + t * dx) + (int)floorf(c.ey + t * dy);
         if ((par & 1) == 0) { cr = 1.0f; cg = 1.0f; cb = 1.0f; }
     }
+    return finish_pixel(true, nx, ny, nz, cr, cg, cb);
+}
+
+__device__ __forceinline__ float hit_prim(const Prim &p, const Camera &c, float dx, float dy, float dz, int &code) {
+    code = 0;
+    if (p.type == PRIM_PLANE) return hit_plane(p, c.ez, dz);
+    if (p.type == PRIM_BOX) return hit_box(p, c.ex, c.ey, c.ez, dx, dy, dz, code);
+    if (p.type == PRIM_CYL) return hit_cylinder(p, c.ex, c.ey, c.ez, dx, dy, dz, code);
+    return hit_capsule(p, c.ex, c.ey, c.ez, dx, dy, dz, code);
+}
+
+// z-test of the unit ray (dx, dy, dz) from the eye against the primitives in `mask` (wave-uniform), starting from `best`;
+// false = nothing nearer than `best`, else rgb is the shaded winner
+__device__ __forceinline__ bool trace(const Prim *prims, uint64_t mask, const Camera &c, float dx, float dy, float dz, float best,
+                                      uint32_t &rgb) {
+    int win = -1, wcode = 0;
+    while (mask) {                                   // wave-uniform list of the primitives that can touch this tile
+        const int k = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        int code;
+        const float t = hit_prim(prims[k], c, dx, dy, dz, code);
+        if (t > 0.0f && t < best) { best = t; win = k; wcode = code; }
+    }
+    if (win < 0) return false;
+    rgb = shade_hit(prims[win], c, dx, dy, dz, best, wcode);
     return true;
 }
 
@@ -316,9 +332,9 @@ __device__ __forceinline__ void pixel_ray(const Camera &c, float sx, float sy, f
 __device__ __forceinline__ uint32_t shade_pixel(const Prim *prims, uint64_t mask, const Camera &c, float sx, float sy) {
     float dx, dy, dz;
     pixel_ray(c, sx, sy, dx, dy, dz);
-    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;     // background
-    const bool hit = trace(prims, mask, c, dx, dy, dz, best, bnx, bny, bnz, cr, cg, cb);
-    return finish_pixel(hit, bnx, bny, bnz, cr, cg, cb);
+    uint32_t rgb;
+    if (trace(prims, mask, c, dx, dy, dz, 3.0e38f, rgb)) return rgb;
+    return finish_pixel(false, 0.0f, 0.0f, 1.0f, 0.92f, 0.92f, 0.92f);                                   // background
 }
 
 // Conservative screen rectangle (tangent-space x = X/Z, y = Y/Z in the camera frame) of a primitive: the eight
@@ -350,14 +366,17 @@ __device__ void prim_screen_rect(const Prim &p, const Camera &c, float rect[4]) 
     rect[0] = x0 - eps; rect[1] = x1 + eps; rect[2] = y0 - eps; rect[3] = y1 + eps;
 }
 
+// Tile-order path: every wavefront walks 8x8 pixel tiles and z-tests, in registers, the primitives whose rectangle overlaps
+// the tile.  It serves the cameras without a cached background (the MobileRobot fpv camera, cam0 = 1), where every pixel
+// needs its own ray and the floor plane covers the screen anyway.
 __global__ void __launch_bounds__(kRasterBlock)
-raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) {
+raster_tiles_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) {
     __shared__ Prim prims[kMaxPrims];
     __shared__ float rects[kMaxPrims][4];
     __shared__ int nprims;
     __shared__ uint32_t tile_masks[kTilePixels / 64];                     // per 8x8 tile of the current band: primitives whose rectangle overlaps it
     __shared__ __attribute__((aligned(16))) uint8_t tile[kTilePixels * 3];
-    const int e = blockIdx.x, cam = blockIdx.y;
+    const int e = blockIdx.x, cam = rp.cam0 + blockIdx.y;
     Camera c = rp.cam[cam];
     if (rp.fpv && cam == 1) { c.ex += (float)mv.x[e]; c.ey += (float)mv.y[e]; }      // mobile_robot_env.py:315-323
     if (threadIdx.x == 0)
@@ -407,9 +426,7 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
                     rgb = bg[row * rp.w + col];
                     if (mask) {
                         const float4 ray = rays[row * rp.w + col];
-                        float best = ray.w, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-                        if (trace(prims, mask, c, ray.x, ray.y, ray.z, best, bnx, bny, bnz, cr, cg, cb))
-                            rgb = finish_pixel(true, bnx, bny, bnz, cr, cg, cb);
+                        trace(prims, mask, c, ray.x, ray.y, ray.z, ray.w, rgb);
                     }
                 } else {
                     const float sx = (((float)col + 0.5f) / (float)rp.w * 2.0f - 1.0f) * c.tan_half_fov;
@@ -436,6 +453,249 @@ raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) 
     }
 }
 
+// ---- object-order path (cameras with a cached background) ------------------------------------------------------------------
+// Screen footprint of one moving primitive in pixel units, conservative: rows r0..r1, columns c0..c1 and — for capsules — the
+// slab around the projected axis: in row r the columns within hw of xc0 + (r - r0) * kx.  W bounds the columns of any one row.
+struct Span {
+    int32_t r0, r1, c0, c1, W;
+    float xc0, kx, hw;
+    int32_t rpc, cch, inv_w;       // chunking: row spans per 64-lane chunk, chunks per row (W > 64), ceil(65536 / W)
+};
+
+// what hit_capsule derives from the capsule and the eye alone, evaluated once per (env, camera) with the same expressions
+struct CapsK { float bax, bay, baz, oax, oay, oaz, obx, oby, obz, baba, baoa, c, ca, cb; };
+
+__device__ void capsule_constants(const Prim &p, const Camera &cam, CapsK &k) {
+    k.bax = p.bx - p.ax; k.bay = p.by - p.ay; k.baz = p.bz - p.az;
+    k.oax = cam.ex - p.ax; k.oay = cam.ey - p.ay; k.oaz = cam.ez - p.az;
+    k.obx = cam.ex - p.bx; k.oby = cam.ey - p.by; k.obz = cam.ez - p.bz;
+    k.baba = k.bax * k.bax + k.bay * k.bay + k.baz * k.baz;
+    k.baoa = k.bax * k.oax + k.bay * k.oay + k.baz * k.oaz;
+    const float oaoa = k.oax * k.oax + k.oay * k.oay + k.oaz * k.oaz;
+    k.c = k.baba * oaoa - k.baoa * k.baoa - p.rad * p.rad * k.baba;
+    k.ca = k.oax * k.oax + k.oay * k.oay + k.oaz * k.oaz - p.rad * p.rad;
+    k.cb = k.obx * k.obx + k.oby * k.oby + k.obz * k.obz - p.rad * p.rad;
+}
+
+// hit_capsule with the per-capsule part taken from CapsK: same operations in the same order, so the same t
+__device__ __forceinline__ float hit_capsule_k(const CapsK &k, float dx, float dy, float dz, int &code) {
+    const float bard = k.bax * dx + k.bay * dy + k.baz * dz;
+    const float rdoa = dx * k.oax + dy * k.oay + dz * k.oaz;
+    const float a = k.baba - bard * bard;
+    float b = k.baba * rdoa - k.baoa * bard;
+    float h = b * b - a * k.c;
+    if (h < 0.0f || k.baba == 0.0f) return -1.0f;
+    float t = -1.0f, y = 0.0f;
+    bool body = false;
+    code = 0;
+    if (a > 0.0f) {
+        t = (-b - sqrtf(h)) / a;
+        y = k.baoa + t * bard;
+        body = y > 0.0f && y < k.baba;
+    }
+    if (!body) {            // one of the two end spheres
+        const bool at_a = y <= 0.0f;
+        b = dx * (at_a ? k.oax : k.obx) + dy * (at_a ? k.oay : k.oby) + dz * (at_a ? k.oaz : k.obz);
+        h = b * b - (at_a ? k.ca : k.cb);
+        if (h < 0.0f) return -1.0f;
+        t = -b - sqrtf(h);
+        code = at_a ? 1 : 2;
+    }
+    return t > 0.0f ? t : -1.0f;
+}
+
+// A capsule's surface point q = c + rad * n (c on the axis, |n| = 1) projects within rad * sqrt(1 + |c'|^2) / (Zc - rad) of
+// c' = (Xc, Yc) / Zc (Cauchy-Schwarz on Zc * n_xy - n_z * (Xc, Yc)); c' runs along the 2-D segment a'b', |c'|^2 is convex on
+// it and Zc is linear, so one radius R2 from the endpoints bounds the whole silhouette: a stadium around a'b'.
+__device__ void prim_span(const Prim &p, const Camera &c, int w, int h, Span &s) {
+    float rect[4];
+    prim_screen_rect(p, c, rect);
+    s.xc0 = 0.0f; s.kx = 0.0f; s.hw = 3.0e38f;
+    const float half_w = 0.5f * (float)w, half_h = 0.5f * (float)h, inv_tan = 1.0f / c.tan_half_fov;
+    bool slab = false;
+    float xa = 0.0f, ya = 0.0f, xb = 0.0f, yb = 0.0f, R2 = 0.0f;
+    if (p.type == PRIM_CAPSULE) {
+        const float wax = p.ax - c.ex, way = p.ay - c.ey, waz = p.az - c.ez, wbx = p.bx - c.ex, wby = p.by - c.ey, wbz = p.bz - c.ez;
+        const float za = wax * c.fx + way * c.fy + waz * c.fz, zb = wbx * c.fx + wby * c.fy + wbz * c.fz;
+        const float zmin = fminf(za, zb) - p.rad;
+        if (zmin > 0.05f) {
+            xa = (wax * c.rx + way * c.ry + waz * c.rz) / za; ya = (wax * c.ux + way * c.uy + waz * c.uz) / za;
+            xb = (wbx * c.rx + wby * c.ry + wbz * c.rz) / zb; yb = (wbx * c.ux + wby * c.uy + wbz * c.uz) / zb;
+            R2 = p.rad * sqrtf(1.0f + fmaxf(xa * xa + ya * ya, xb * xb + yb * yb)) / zmin * 1.001f + 1.0e-3f;
+            rect[0] = fmaxf(rect[0], fminf(xa, xb) - R2); rect[1] = fminf(rect[1], fmaxf(xa, xb) + R2);
+            rect[2] = fmaxf(rect[2], fminf(ya, yb) - R2); rect[3] = fminf(rect[3], fmaxf(ya, yb) + R2);
+            slab = true;
+        }
+    }
+    // tangent space -> pixel index of the pixel whose centre is there: col = (x / tan + 1) * w / 2 - 1/2, row = (1 - y / tan) * h / 2 - 1/2
+    const float cf0 = (rect[0] * inv_tan + 1.0f) * half_w - 0.5f, cf1 = (rect[1] * inv_tan + 1.0f) * half_w - 0.5f;
+    const float rf0 = (1.0f - rect[3] * inv_tan) * half_h - 0.5f, rf1 = (1.0f - rect[2] * inv_tan) * half_h - 0.5f;
+    s.c0 = (int)ceilf(fminf(fmaxf(cf0, 0.0f), (float)w)); s.c1 = (int)floorf(fminf(fmaxf(cf1, -1.0f), (float)(w - 1)));
+    s.r0 = (int)ceilf(fminf(fmaxf(rf0, 0.0f), (float)h)); s.r1 = (int)floorf(fminf(fmaxf(rf1, -1.0f), (float)(h - 1)));
+    s.W = max(s.c1 - s.c0 + 1, 0);
+    if (slab && s.W > 0 && s.r1 >= s.r0) {
+        const float dx = xb - xa, dy = yb - ya, len = sqrtf(dx * dx + dy * dy);
+        if (fabsf(dy) > 1.0e-4f * len && len > 0.0f) {
+            // the axis' column in row r: x = xa + (y_r - ya) * dx / dy with y_r = (1 - (r + 1/2) * 2 / h) * tan
+            const float slope = dx / dy, px = half_w * inv_tan;
+            const float y0 = (1.0f - ((float)s.r0 + 0.5f) / half_h) * c.tan_half_fov;
+            s.xc0 = ((xa + (y0 - ya) * slope) * inv_tan + 1.0f) * half_w - 0.5f;
+            s.kx = -slope * px * c.tan_half_fov / half_h;
+            s.hw = R2 * len / fabsf(dy) * px + 0.01f;
+            if (s.hw < 0.5f * (float)w) s.W = min(s.W, (int)floorf(2.0f * s.hw) + 2); else s.hw = 3.0e38f;
+        }
+    }
+    const int W = max(s.W, 1);
+    s.rpc = max(1, 64 / W); s.cch = (W + 63) >> 6; s.inv_w = W <= 64 ? (65536 + W - 1) / W : 0;
+}
+
+// One 256-lane workgroup per (env, cached camera).  The moving primitives are rasterised in object order: each one's footprint
+// (Span) is cut into 64-pixel chunks — several short row spans side by side — that the workgroup's wavefronts share; a lane
+// fetches its pixel's cached ray (the next chunk's load is in flight while this one is tested), runs the exact ray test of
+// that one primitive (type and constants wave-uniform) and, when it is nearer than the static depth, atomic-mins
+// (t, primitive, face) into a 64-bit LDS z-buffer — ties go to the lower primitive index, as in a sequential z-test.
+// Resolve: pixels without a hit take the cached background colour, the others are gathered into a dense list and shaded
+// (so the divergent normal code runs on full wavefronts); the colours replace the z-buffer words in place and the band is
+// flushed 4 pixels = 12 bytes per lane.  Pixels no footprint covers are never ray-tested.
+constexpr int kBandPixels = 2048;          // 16 KiB z-buffer + 4 KiB hit list: seven workgroups per CU
+constexpr uint32_t kNoHit = 0xffffffffu;
+
+struct Item { int k, row, col; bool valid; };
+
+__global__ void __launch_bounds__(kRasterBlock)
+raster_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, uint8_t *img) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ Prim prims[kMaxPrims];
+    __shared__ Span spans[kMaxPrims];
+    __shared__ CapsK capsk[kMaxPrims];
+    __shared__ int32_t chunks[kMaxPrims];
+    __shared__ int nprims, nhits;
+    __shared__ __attribute__((aligned(16))) unsigned long long zbuf[kBandPixels];
+    __shared__ uint16_t hits[kBandPixels];
+    const int e = blockIdx.x, cam = blockIdx.y;
+    const Camera c = rp.cam[cam];
+    if (threadIdx.x == 0)
+        nprims = rp.kind >= SRLHIP_ENV_KUKA_BUTTON ? build_kuka_scene(kv, e, prims) : build_mobile_scene(rp, mv, e, prims);
+    __syncthreads();
+    const int np = __builtin_amdgcn_readfirstlane(nprims), first = rp.nstatic, tid = threadIdx.x;
+    if (tid >= first && tid < np) {
+        prim_span(prims[tid], c, rp.w, rp.h, spans[tid]);
+        if (prims[tid].type == PRIM_CAPSULE) capsule_constants(prims[tid], c, capsk[tid]);
+    }
+    const int npix = rp.h * rp.w;
+    const float4 *__restrict__ rays = rp.rays[cam];
+    const uint32_t *__restrict__ bg = rp.bg[cam];
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t *out = img + (int64_t)e * npix * rp.channels;
+    // bands: whole rows, a multiple of 4 pixels (the resolve and the flush work on groups of 4)
+    const int band_rows = max(1, kBandPixels / rp.w);
+    const bool quads = (rp.w & 3) == 0 && rp.w <= kBandPixels;
+    const bool packed = quads && rp.channels == 3 && ((reinterpret_cast<uintptr_t>(out)) & 3) == 0;
+    for (int row0 = 0; row0 < rp.h; row0 += band_rows) {
+        const int rows = min(band_rows, rp.h - row0), base = row0 * rp.w, count = rows * rp.w, last_row = row0 + rows - 1;
+        for (int i = tid; i < (count + 1) / 2; i += kRasterBlock) reinterpret_cast<u32x4 *>(zbuf)[i] = u32x4{kNoHit, kNoHit, kNoHit, kNoHit};
+        if (tid == 0) nhits = 0;
+        __syncthreads();                                                   // spans written (first band) / previous band flushed
+        if (tid >= first && tid < np) {
+            const Span &s = spans[tid];
+            const int pr0 = max(s.r0, row0), pr1 = min(s.r1, last_row);
+            chunks[tid] = (pr1 >= pr0 && s.W > 0) ? ((pr1 - pr0 + s.rpc) / s.rpc) * s.cch : 0;
+        }
+        __syncthreads();
+        // ---- z-test, object order --------------------------------------------------------------------------------------
+        int k = first, kbase = 0;
+        int kcnt = k < np ? __builtin_amdgcn_readfirstlane(chunks[k]) : 0;
+        auto locate = [&](int q) {                                         // chunk q of the band -> this lane's (primitive, pixel)
+            Item it;
+            while (k < np && q >= kbase + kcnt) { kbase += kcnt; k++; kcnt = k < np ? __builtin_amdgcn_readfirstlane(chunks[k]) : 0; }
+            it.k = k; it.row = 0; it.col = 0; it.valid = false;
+            if (k >= np) return it;
+            const Span &s = spans[k];
+            const int W = s.W, qq = q - kbase;
+            int group = qq, cc = 0;
+            if (s.cch > 1) { group = qq / s.cch; cc = qq - group * s.cch; }
+            const int rr = (lane * s.inv_w) >> 16;                                      // lane / W (0 when W > 64)
+            const int i = cc * 64 + lane - rr * W;
+            it.row = max(s.r0, row0) + group * s.rpc + rr;
+            const float centre = s.xc0 + (float)(it.row - s.r0) * s.kx;
+            const int lo = s.hw < 1.0e30f ? max(s.c0, (int)ceilf(centre - s.hw)) : s.c0;
+            const int hi = s.hw < 1.0e30f ? min(s.c1, (int)floorf(centre + s.hw)) : s.c1;
+            it.col = lo + i;
+            it.valid = rr < s.rpc && i < W && it.row <= min(s.r1, last_row) && it.col <= hi;
+            return it;
+        };
+        Item cur = locate(wave);
+        float4 ray = rays[cur.valid ? cur.row * rp.w + cur.col : 0];
+        for (int q = wave; cur.k < np; q += kRasterBlock / 64) {
+            const Item nxt = locate(q + kRasterBlock / 64);
+            const float4 nray = rays[nxt.valid ? nxt.row * rp.w + nxt.col : 0];
+            if (cur.valid) {
+                int code;
+                const Prim &p = prims[cur.k];
+                const float t = p.type == PRIM_CAPSULE ? hit_capsule_k(capsk[cur.k], ray.x, ray.y, ray.z, code) : hit_prim(p, c, ray.x, ray.y, ray.z, code);
+                if (t > 0.0f && t < ray.w)
+                    atomicMin(&zbuf[(cur.row - row0) * rp.w + cur.col],
+                              ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((cur.k << 3) | code));
+            }
+            cur = nxt; ray = nray;
+        }
+        __syncthreads();
+        // ---- resolve: the pixels with a hit are gathered into a dense list and shaded; the colour goes to the low word ------
+        for (int i0 = 4 * tid; i0 < count; i0 += 4 * kRasterBlock) {
+            bool hit[4];
+            uint64_t m[4];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                hit[u] = i0 + u < count && (uint32_t)zbuf[i0 + u] != kNoHit;
+                m[u] = __ballot(hit[u]);
+                total += (int)__popcll(m[u]);
+            }
+            if (total) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&nhits, total);
+                at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (hit[u]) hits[at + (int)__popcll(m[u] & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + u);
+                    at += (int)__popcll(m[u]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < nhits; j += kRasterBlock) {
+            const int i = hits[j];
+            const unsigned long long key = zbuf[i];
+            const float4 r = rays[base + i];
+            reinterpret_cast<uint32_t *>(&zbuf[i])[0] =
+                shade_hit(prims[((uint32_t)key >> 3) & 31u], c, r.x, r.y, r.z, __uint_as_float((uint32_t)(key >> 32)), (int)((uint32_t)key & 7u));
+        }
+        __syncthreads();
+        // ---- flush: 4 pixels = 12 bytes per lane; entries still all-ones take the cached background colour ---------------------
+        if (packed) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(out + (int64_t)base * 3);
+            const u32x4 *bg4 = reinterpret_cast<const u32x4 *>(bg + base);
+            for (int j = tid; j < count / 4; j += kRasterBlock) {
+                const u32x4 z01 = reinterpret_cast<const u32x4 *>(zbuf)[2 * j], z23 = reinterpret_cast<const u32x4 *>(zbuf)[2 * j + 1];
+                const u32x4 b = bg4[j];
+                const uint32_t p0 = z01.y != kNoHit ? z01.x : b.x, p1 = z01.w != kNoHit ? z01.z : b.y;
+                const uint32_t p2 = z23.y != kNoHit ? z23.x : b.z, p3 = z23.w != kNoHit ? z23.z : b.w;
+                __builtin_nontemporal_store(p0 | (p1 << 24), dst + 3 * j);
+                __builtin_nontemporal_store((p1 >> 8) | (p2 << 16), dst + 3 * j + 1);
+                __builtin_nontemporal_store((p2 >> 16) | (p3 << 8), dst + 3 * j + 2);
+            }
+        } else {
+            for (int i = tid; i < count; i += kRasterBlock) {
+                const unsigned long long key = zbuf[i];
+                const uint32_t rgb = (uint32_t)(key >> 32) != kNoHit ? (uint32_t)key : bg[base + i];
+                uint8_t *d = out + (int64_t)(base + i) * rp.channels + 3 * cam;
+                d[0] = (uint8_t)rgb; d[1] = (uint8_t)(rgb >> 8); d[2] = (uint8_t)(rgb >> 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Per-handle setup: unit ray, nearest static depth and shaded static colour of every pixel of fixed camera `cam`.  The
 // static primitives are the first rp.nstatic ones of ANY env's scene (env 0 is used); same code path as raster_k's
 // full trace, so the bytes are the ones the full path would produce.
@@ -454,10 +714,16 @@ raster_bg_k(RasterParams rp, RasterKukaView kv, RasterMobileView mv, int cam, fl
     const float sy = (1.0f - ((float)row + 0.5f) / (float)rp.h * 2.0f) * c.tan_half_fov;
     float dx, dy, dz;
     pixel_ray(c, sx, sy, dx, dy, dz);
-    float best = 3.0e38f, bnx = 0.0f, bny = 0.0f, bnz = 1.0f, cr = 0.92f, cg = 0.92f, cb = 0.92f;
-    const bool hit = trace(prims, (1ull << rp.nstatic) - 1ull, c, dx, dy, dz, best, bnx, bny, bnz, cr, cg, cb);
+    // nearest static hit: the depth is kept beside the ray so that the per-env pass starts its z-test from it
+    float best = 3.0e38f;
+    int win = -1, wcode = 0;
+    for (int k = 0; k < rp.nstatic; k++) {
+        int code;
+        const float t = hit_prim(prims[k], c, dx, dy, dz, code);
+        if (t > 0.0f && t < best) { best = t; win = k; wcode = code; }
+    }
     rays[i] = make_float4(dx, dy, dz, best);
-    bg[i] = finish_pixel(hit, bnx, bny, bnz, cr, cg, cb);
+    bg[i] = win >= 0 ? shade_hit(prims[win], c, dx, dy, dz, best, wcode) : finish_pixel(false, 0.0f, 0.0f, 1.0f, 0.92f, 0.92f, 0.92f);
 }
 
 // pybullet computeViewMatrixFromYawPitchRoll (upAxisIndex = 2): eye = target + Rz(yaw) Ry(roll) Rx(pitch) (0,-d,0),
@@ -532,8 +798,14 @@ int raster_render(Handle *h, void *d_img) {
         rp.rays[cam] = h->raster_rays[cam];
         rp.bg[cam] = h->raster_bg[cam];
     }
-    hipLaunchKernelGGL(raster_k, dim3(h->n, rp.ncam), dim3(kRasterBlock), 0, h->stream, rp, kv, mv, static_cast<uint8_t *>(d_img));
+    rp.cam0 = 0;
+    hipLaunchKernelGGL(raster_k, dim3(h->n, ncached), dim3(kRasterBlock), 0, h->stream, rp, kv, mv, static_cast<uint8_t *>(d_img));
     SRL_HIP_CHECK(h, hipGetLastError());
+    if (ncached < rp.ncam) {
+        rp.cam0 = ncached;
+        hipLaunchKernelGGL(raster_tiles_k, dim3(h->n, rp.ncam - ncached), dim3(kRasterBlock), 0, h->stream, rp, kv, mv, static_cast<uint8_t *>(d_img));
+        SRL_HIP_CHECK(h, hipGetLastError());
+    }
     return 0;
 }
 
