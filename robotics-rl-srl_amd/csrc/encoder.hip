@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "../../include/srlhip.h"
+#include "encoder_general.hpp"
 
 namespace {
 
@@ -480,18 +481,9 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #undef ENC_STAMP
 
 // ---------------------------------------------------------------------------------------------- host side
-void split_f16(float v, _Float16 &hi, _Float16 &lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
-}
-// largest power of two that keeps max|w| * scale <= kWeightTop (lo parts then sit well inside f16's normal range)
-float pick_scale(double wmax) {
-    if (!(wmax > 0.0) || !std::isfinite(wmax)) return 1.f;
-    int e;
-    frexp((double)kWeightTop / wmax, &e);          // kWeightTop / wmax = f * 2^e, f in [0.5, 1)
-    e = e - 1 > 40 ? 40 : (e - 1 < -40 ? -40 : e - 1);
-    return (float)ldexp(1.0, e);
-}
+using srlenc::pack_layer3x3;
+using srlenc::pick_scale;
+using srlenc::split_f16;
 double layer1_weight(const float *w, const float *b, int o, int k) {
     const int ky = k / 32, kx = (k % 32) / 4, c4 = k % 4;
     double v = 0.0;
@@ -523,6 +515,21 @@ float pack_layer1(const float *w, const float *b, _Float16 *out) {
                 }
     return scale;
 }
+}  // namespace
+
+namespace srlenc {
+void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+// largest power of two that keeps max|w| * scale <= kWeightTop (lo parts then sit well inside f16's normal range)
+float pick_scale(double wmax) {
+    if (!(wmax > 0.0) || !std::isfinite(wmax)) return 1.f;
+    int e;
+    frexp((double)kWeightTop / wmax, &e);          // kWeightTop / wmax = f * 2^e, f in [0.5, 1)
+    e = e - 1 > 40 ? 40 : (e - 1 < -40 ? -40 : e - 1);
+    return (float)ldexp(1.0, e);
+}
 // conv_w [64][64][3][3] (torch OIHW, BatchNorm folded): k = (ky * 3 + kx) * 64 + c
 float pack_layer3x3(const float *w, _Float16 *out) {
     double wmax = 0.0;
@@ -540,7 +547,7 @@ float pack_layer3x3(const float *w, _Float16 *out) {
     return scale;
 }
 
-}  // namespace
+}  // namespace srlenc
 
 struct srlhip_encoder {
     int device_id, state_dim;
@@ -549,6 +556,8 @@ struct srlhip_encoder {
     int *d_status;
     int num_cus;
     int groups;            // wave groups along M: 2 = 4 waves per workgroup, 4 = 8 waves
+    srlenc::General *general;   // non-null: the layered path of encoder_general.hip serves this handle (any shape but 64x64x3)
+    int img_h, img_w, n_channels;
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 };
@@ -556,7 +565,11 @@ struct srlhip_encoder {
 namespace {
 thread_local std::string g_enc_create_error;
 
-bool supported_shape(int img_h, int img_w, int n_channels) { return img_h == kImg && img_w == kImg && n_channels == 3; }
+bool fused_shape(int img_h, int img_w, int n_channels) {
+    const char *g = getenv("SRLHIP_ENCODER_GENERAL");          // test knob: run 64x64x3 through the layered path too
+    return img_h == kImg && img_w == kImg && n_channels == 3 && !(g && atoi(g) == 1);
+}
+bool supported_shape(int img_h, int img_w, int n_channels) { return srlenc::geometry(img_h, img_w, n_channels).ok; }
 }  // namespace
 
 extern "C" {
@@ -583,8 +596,19 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     if (!out) return SRLHIP_EINVAL;
     *out = nullptr;
     if (!supported_shape(img_h, img_w, n_channels) || state_dim < 1 || !conv2_b || !conv3_b || !fc_w || !fc_b) {
-        g_enc_create_error = "srlhip_encoder_create: the fused encoder covers 64x64x3 frames (CustomCNN) and state_dim >= 1";
+        g_enc_create_error = "srlhip_encoder_create: CustomCNN frames are 8..1024 pixels a side with 3 or 6 channels, state_dim >= 1";
         return SRLHIP_ENOTSUP;
+    }
+    if (!fused_shape(img_h, img_w, n_channels)) {
+        srlhip_encoder *e = new (std::nothrow) srlhip_encoder();
+        if (!e) return SRLHIP_ENOMEM;
+        e->device_id = device_id; e->state_dim = state_dim; e->d_pack = nullptr; e->d_f32 = nullptr; e->d_status = nullptr; e->general = nullptr;
+        e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels;
+        const int rc = srlenc::general_create(device_id, srlenc::geometry(img_h, img_w, n_channels), state_dim, conv1_w, conv1_b, conv2_w, conv2_b,
+                                              conv3_w, conv3_b, fc_w, fc_b, &e->general, g_enc_create_error);
+        if (rc != SRLHIP_OK) { delete e; return rc; }
+        *out = e;
+        return SRLHIP_OK;
     }
     std::vector<char> pack(srlhip_encoder_pack_bytes());
     float scales[3];
@@ -594,7 +618,8 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     }
     srlhip_encoder *e = new (std::nothrow) srlhip_encoder();
     if (!e) return SRLHIP_ENOMEM;
-    e->device_id = device_id; e->state_dim = state_dim; e->d_pack = nullptr; e->d_f32 = nullptr; e->d_status = nullptr;
+    e->device_id = device_id; e->state_dim = state_dim; e->d_pack = nullptr; e->d_f32 = nullptr; e->d_status = nullptr; e->general = nullptr;
+    e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels;
 #define ENC_CHECK(expr)                                                                              \
     do {                                                                                             \
         hipError_t e__ = (expr);                                                                     \
@@ -642,6 +667,7 @@ int srlhip_encoder_forward(srlhip_encoder_handle e, const uint8_t *images_dev, i
     if (reinterpret_cast<uintptr_t>(images_dev) % 16) return e->fail(SRLHIP_EINVAL, "srlhip_encoder_forward: images must be 16-byte aligned");
     hipError_t rc = hipSetDevice(e->device_id);
     if (rc != hipSuccess) return e->fail(SRLHIP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(rc));
+    if (e->general) return srlenc::general_forward(e->general, images_dev, n, states_dev, static_cast<hipStream_t>(hip_stream), e->err);
     EncParams p;
     p.images = images_dev; p.n = n;
     p.b1 = e->d_pack; p.b2 = e->d_pack + kPack1Bytes; p.b3 = e->d_pack + kPack1Bytes + kPack2Bytes;
@@ -660,6 +686,7 @@ int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_d
                                 int64_t *cycles9) {
     if (!e || !cycles9) return SRLHIP_EINVAL;
     if (n < 1 || !images_dev || !states_dev) return e->fail(SRLHIP_EINVAL, "srlhip_encoder_phase_cycles: need n >= 1 and both buffers");
+    if (e->general) return e->fail(SRLHIP_ENOTSUP, "srlhip_encoder_phase_cycles: the phase stamps belong to the fused 64x64x3 kernel");
 #define ENC_RC(expr)                                                                                  \
     do {                                                                                              \
         hipError_t e__ = (expr);                                                                      \
@@ -713,7 +740,7 @@ int srlhip_encoder_overflow(srlhip_encoder_handle e, int32_t *flag) {
     hipError_t rc = hipSetDevice(e->device_id);
     if (rc == hipSuccess) rc = hipDeviceSynchronize();
     int v = 0;
-    if (rc == hipSuccess) rc = hipMemcpy(&v, e->d_status, sizeof(int), hipMemcpyDeviceToHost);
+    if (rc == hipSuccess) rc = hipMemcpy(&v, e->general ? srlenc::general_status(e->general) : e->d_status, sizeof(int), hipMemcpyDeviceToHost);
     if (rc != hipSuccess) return e->fail(SRLHIP_EHIP, std::string("srlhip_encoder_overflow: ") + hipGetErrorString(rc));
     *flag = v & 1;
     return SRLHIP_OK;
@@ -722,6 +749,7 @@ int srlhip_encoder_overflow(srlhip_encoder_handle e, int32_t *flag) {
 int srlhip_encoder_destroy(srlhip_encoder_handle e) {
     if (!e) return SRLHIP_OK;
     (void)hipSetDevice(e->device_id);
+    if (e->general) srlenc::general_destroy(e->general);
     if (e->d_pack) (void)hipFree(e->d_pack);
     if (e->d_f32) (void)hipFree(e->d_f32);
     if (e->d_status) (void)hipFree(e->d_status);

@@ -1,0 +1,378 @@
+// encoder_general.hip — layered SRL encoder forward (srl_zoo CustomCNN) for any frame shape, gfx950.
+//
+// The fused kernel of encoder.hip keeps a whole 64x64x3 frame in one CU's LDS.  The reference's real observation is
+// 224x224x3 (kuka_button_gym_env.py:21-22) or 6 channels with multi_view (:401-417): those maps do not fit a CU, so
+// this path runs the network layer by layer — same arithmetic (implicit GEMM on v_mfma_f32_32x32x16_f16 with every
+// operand split into f16 hi + lo so that the products accumulate to float32 accuracy, power-of-two weight pre-scale,
+// ImageNet normalisation and zero padding folded into layer 1 through a validity-mask channel), different tiling:
+//   * activations travel between layers as f16 hi / lo planes in HBM, [frame][row][column][64 channels];
+//   * one 128-lane workgroup (two wavefronts = the two halves of the 64 output channels) owns a band of R pooled rows
+//     by 15 pooled columns of one frame: it stages the input window it needs in LDS (rows and columns with their halo,
+//     zero outside the map), each wavefront accumulates the 2R+1 convolution rows x 32 columns of its tile in
+//     registers, and the 3x3/2 max-pool runs on those raw accumulators — vertically element-wise across the row
+//     tiles, horizontally after one lane^32 exchange — so a convolution output never touches memory; only the pooled
+//     quarter is rescaled, biased, rectified, split and stored;
+//   * layer-1 weights (B fragments) stay in registers while a workgroup walks several bands, layers 2-3 stream theirs
+//     from L2 through a register ring;
+//   * the fully connected layer is its own small kernel over the [frame][Hp3][Wp3][64] float32 features.
+// The network sees the frame with H and W swapped (models.py:185-188); all layers are symmetric in the two spatial
+// dims, so the kernels work on the frame as rasterised and the packers swap the kernel axes / the FC's flatten order.
+#include "encoder_general.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/srlhip.h"
+
+namespace srlenc {
+
+Geometry geometry(int img_h, int img_w, int n_channels) {
+    Geometry g;
+    g.H = img_h; g.W = img_w; g.C = n_channels;
+    int h = img_h, w = img_w;
+    const int k[3] = {7, 3, 3}, s[3] = {2, 1, 2}, pad[3] = {3, 1, 1}, ppad[3] = {1, 0, 0};
+    g.ok = (n_channels == 3 || n_channels == 6) && img_h >= 8 && img_w >= 8 && img_h <= 1024 && img_w <= 1024;
+    for (int l = 0; l < 3; l++) {
+        g.Hc[l] = (h + 2 * pad[l] - k[l]) / s[l] + 1; g.Wc[l] = (w + 2 * pad[l] - k[l]) / s[l] + 1;
+        g.Hp[l] = g.Hc[l] + 2 * ppad[l] >= 3 ? (g.Hc[l] + 2 * ppad[l] - 3) / 2 + 1 : 0;
+        g.Wp[l] = g.Wc[l] + 2 * ppad[l] >= 3 ? (g.Wc[l] + 2 * ppad[l] - 3) / 2 + 1 : 0;
+        if (g.Hp[l] < 1 || g.Wp[l] < 1) g.ok = false;
+        h = g.Hp[l]; w = g.Wp[l];
+    }
+    return g;
+}
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PX = 144;                 // LDS pixel pitch of a 64-channel f16 plane (128 B + 16 B skew)
+constexpr float kF16Max = 65504.f, kNegInf = -3.0e38f;
+constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
+constexpr int kNC1 = 70, kNC2 = 34, kNC3 = 65;          // staged input columns of a 32-column convolution tile
+constexpr int kR1 = 3, kR2 = 2, kR3 = 1;                 // pooled rows per band
+constexpr int kBandsPerWg1 = 4;                          // layer 1: bands walked with the weights resident
+
+struct LayerParams {
+    const uint8_t *img;              // layer 1: [n][H][W][C]
+    const _Float16 *in_hi, *in_lo;   // layers 2, 3: [n][Hin][Win][64]
+    _Float16 *out_hi, *out_lo;       // layers 1, 2: [n][Hp][Wp][64]
+    float *out_f32;                  // layer 3
+    const char *pack;                // B fragments [channel half][k-step][lane][8 hi | 8 lo] f16
+    const float *bias;               // [64], null for layer 1 (its bias rides on the mask channel)
+    float inv_scale;
+    int Hin, Win, Cimg, Hc, Wc, Hp, Wp, nbands, bands_per_wg;
+    int *status;
+};
+
+extern __shared__ __attribute__((aligned(16))) char lds[];
+
+__device__ __forceinline__ half8 lds16(int off) { return *reinterpret_cast<const half8 *>(lds + off); }
+__device__ __forceinline__ half8 glb16(const char *p) { return *reinterpret_cast<const half8 *>(p); }
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// LAYER 1: u8 frame -> conv7x7/2 p3 -> pool3/2 p1 (CPIX f16 per staged pixel: 4 = RGB + mask, 8 = 6 channels + mask + 0)
+// LAYER 2: planes -> conv3x3 p1 -> pool3/2      LAYER 3: planes -> conv3x3/2 p1 -> pool3/2 -> float32 features
+template <int LAYER, int CPIX, int R>
+__global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
+    constexpr int T = 2 * R + 1;                              // convolution rows of a band
+    constexpr int KS = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
+    constexpr int S = LAYER == 2 ? 1 : 2, PAD = LAYER == 1 ? 3 : 1, KW = LAYER == 1 ? 7 : 3, PPAD = LAYER == 1 ? 1 : 0;
+    constexpr int NR = S * (T - 1) + KW;                      // staged input rows
+    constexpr int NC = LAYER == 1 ? kNC1 : (LAYER == 2 ? kNC2 : kNC3);
+    constexpr int PIXB = LAYER == 1 ? CPIX * 2 : PX;          // staged bytes per pixel (and plane)
+    constexpr int PLANE = NR * NC * PIXB;
+    constexpr int AHEAD = 4;                                  // layers 2-3: B fragments requested this many k-steps early
+    const int tid = threadIdx.x, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int seg = blockIdx.x, img = blockIdx.z;
+    const int c0 = 30 * seg - PPAD, ix0 = S * c0 - PAD;
+    const char *bp = P.pack + ((size_t)nh * KS * 64 + lane) * 32;
+    half8 Bh1[LAYER == 1 ? KS : 1], Bl1[LAYER == 1 ? KS : 1];
+    if (LAYER == 1) {
+#pragma unroll
+        for (int s = 0; s < KS; s++) { Bh1[s] = glb16(bp + (size_t)s * 2048); Bl1[s] = glb16(bp + (size_t)s * 2048 + 16); }
+    }
+    const int ch = 32 * nh + m;
+    const float bias = P.bias ? P.bias[ch] : 0.f;
+    bool ovf = false;
+    const int band_end = min(P.nbands, ((int)blockIdx.y + 1) * P.bands_per_wg);
+    for (int band = blockIdx.y * P.bands_per_wg; band < band_end; band++) {
+        const int p0 = band * R, rr0 = 2 * p0 - PPAD, iy0 = S * rr0 - PAD;
+        __syncthreads();                                      // the previous band's fragments have been read
+        if (LAYER == 1) {
+            for (int pix = tid; pix < NR * NC; pix += 128) {
+                const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
+                const bool in = y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
+                const uint8_t *src = P.img + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * P.Cimg;
+                if (CPIX == 4) {
+                    half4v v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    if (in) { v[0] = (_Float16)(float)src[0]; v[1] = (_Float16)(float)src[1]; v[2] = (_Float16)(float)src[2]; v[3] = (_Float16)1.f; }
+                    *reinterpret_cast<half4v *>(lds + pix * 8) = v;
+                } else {
+                    half8 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    if (in) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) v[c] = (_Float16)(float)src[c];
+                        v[6] = (_Float16)1.f;
+                    }
+                    *reinterpret_cast<half8 *>(lds + pix * 16) = v;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < NR * NC * 16; idx += 128) {
+                const int pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
+                const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
+                    v = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
+                *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = v;
+            }
+        }
+        __syncthreads();
+        // ---- 2R+1 convolution rows x 32 columns x this wavefront's 32 channels: raw accumulators ----------------------------
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+        const int abase = LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16;
+        constexpr int ROWSTRIDE = S * NC * PIXB;
+        half8 rbh[AHEAD], rbl[AHEAD];
+        if (LAYER != 1) {
+#pragma unroll
+            for (int s = 0; s < AHEAD; s++) { rbh[s] = glb16(bp + (size_t)s * 2048); rbl[s] = glb16(bp + (size_t)s * 2048 + 16); }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int koff = LAYER == 1 ? (CPIX == 4 ? ((s >> 1) * NC + 4 * (s & 1)) * 8 : ((s >> 2) * NC + 2 * (s & 3)) * 16)
+                                        : (((s >> 2) / 3) * NC + (s >> 2) % 3) * PX + (s & 3) * 32;
+            half8 Bh, Bl;
+            if (LAYER == 1) { Bh = Bh1[s]; Bl = Bl1[s]; }
+            else { Bh = rbh[s % AHEAD]; Bl = rbl[s % AHEAD]; }
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const half8 ah = lds16(abase + t * ROWSTRIDE + koff);
+                acc[t] = mfma16(ah, Bh, acc[t]);
+                acc[t] = mfma16(ah, Bl, acc[t]);
+                if (LAYER != 1) acc[t] = mfma16(lds16(PLANE + abase + t * ROWSTRIDE + koff), Bh, acc[t]);
+            }
+            if (LAYER != 1 && s + AHEAD < KS) {
+                rbh[s % AHEAD] = glb16(bp + (size_t)(s + AHEAD) * 2048); rbl[s % AHEAD] = glb16(bp + (size_t)(s + AHEAD) * 2048 + 16);
+            }
+        }
+        // ---- 3x3/2 max-pool on the raw accumulators, then scale / bias / ReLU on the pooled values only --------------------------
+        // acc[t][i] of lane l: convolution row rr0 + t, column c0 + 8 (i / 4) + 4 (l / 32) + i % 4, channel ch
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int p = p0 + j;
+            if (p >= P.Hp) break;
+            const bool rv0 = rr0 + 2 * j >= 0 && rr0 + 2 * j < P.Hc, rv1 = rr0 + 2 * j + 1 < P.Hc, rv2 = rr0 + 2 * j + 2 < P.Hc;
+            float full[32];                                   // this channel's 32 columns of the vertically pooled row
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float v = max3(rv0 ? acc[2 * j][i] : kNegInf, rv1 ? acc[2 * j + 1][i] : kNegInf, rv2 ? acc[2 * j + 2][i] : kNegInf);
+                const float o = __shfl_xor(v, 32);
+                full[8 * (i >> 2) + (i & 3)] = h ? o : v;
+                full[8 * (i >> 2) + 4 + (i & 3)] = h ? v : o;
+            }
+#pragma unroll
+            for (int mm = 0; mm < 32; mm++)
+                if (c0 + mm < 0 || c0 + mm >= P.Wc) full[mm] = kNegInf;
+#pragma unroll
+            for (int jj = 0; jj < 15; jj++) {
+                const int q = 15 * seg + jj;
+                if (q < P.Wp && (jj & 1) == h) {
+                    const float x = fmaxf(max3(full[2 * jj], full[2 * jj + 1], full[2 * jj + 2]) * P.inv_scale + bias, 0.f);
+                    const size_t o = (((size_t)img * P.Hp + p) * P.Wp + q) * 64 + ch;
+                    if (LAYER == 3) P.out_f32[o] = x;
+                    else {
+                        ovf |= !(x < kF16Max);
+                        const _Float16 hi = (_Float16)x;
+                        P.out_hi[o] = hi;
+                        P.out_lo[o] = (_Float16)(x - (float)hi);
+                    }
+                }
+            }
+        }
+    }
+    if (ovf) atomicOr(P.status, 1);
+}
+
+// out[frame][s] = fcb[s] + sum_f feat[frame][f] * w[s][f]; one workgroup per frame, one output per wavefront at a time
+__global__ __launch_bounds__(256) void enc_fc_k(const float *feat, const float *w, const float *b, float *out, int F, int state_dim) {
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *x = feat + (size_t)img * F;
+    for (int s = wave; s < state_dim; s += 4) {
+        const float *ws = w + (size_t)s * F;
+        double a = 0.0;
+        for (int f = lane; f < F; f += 64) a += (double)x[f] * (double)ws[f];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+        if (lane == 0) out[(size_t)img * state_dim + s] = (float)(a + (double)b[s]);
+    }
+}
+
+// layer 1, normalisation folded: staged pixel = (c_0 .. c_{C-1}, mask [, 0]); k = (ky * 8 + kx) * CPIX + c with kx = 7 a zero slot.
+// The mask channel carries -sum_c w * mean_c / std_c per tap (zero padding stays exact in NORMALISED space) and the folded bias
+// on the centre tap.  The frame's axes are swapped with respect to torch's, so the tap at frame offset (ky, kx) is w[o][c][kx][ky].
+double layer1_weight(const float *w, const float *b, int C, int cpix, int o, int k) {
+    const int ky = k / (8 * cpix), kx = (k / cpix) % 8, c = k % cpix;
+    if (kx >= 7) return 0.0;
+    if (c < C) return (double)w[((o * C + c) * 7 + kx) * 7 + ky] / (255.0 * (double)kStd[c % 3]);
+    if (c > C) return 0.0;
+    double v = 0.0;
+    for (int cc = 0; cc < C; cc++) v -= (double)w[((o * C + cc) * 7 + kx) * 7 + ky] * (double)kMean[cc % 3] / (double)kStd[cc % 3];
+    if (ky == 3 && kx == 3) v += (double)b[o];
+    return v;
+}
+float pack_layer1(const float *w, const float *b, int C, _Float16 *out) {
+    const int cpix = C == 3 ? 4 : 8, ks = 7 * 8 * cpix / 16;
+    double wmax = 0.0;
+    for (int o = 0; o < 64; o++)
+        for (int k = 0; k < 16 * ks; k++) wmax = fmax(wmax, fabs(layer1_weight(w, b, C, cpix, o, k)));
+    const float scale = pick_scale(wmax);
+    for (int nh = 0; nh < 2; nh++)
+        for (int s = 0; s < ks; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 8; e++) {
+                    const int o = 32 * nh + (lane & 31), k = 16 * s + 8 * (lane >> 5) + e;
+                    _Float16 *dst = out + ((size_t)(nh * ks + s) * 64 + lane) * 16;
+                    split_f16((float)(layer1_weight(w, b, C, cpix, o, k) * (double)scale), dst[e], dst[8 + e]);
+                }
+    return scale;
+}
+
+}  // namespace
+
+struct General {
+    int device_id, state_dim, F;
+    Geometry g;
+    char *d_pack;          // layer 1 | layer 2 | layer 3 B fragments
+    size_t pack1_bytes;
+    float *d_f32;          // bias2[64] bias3[64] fcb[state_dim] fcw[state_dim][F]
+    float inv_scale[3];
+    int *d_status;
+    char *d_act;           // scratch for `cap` frames: a1 hi | a1 lo | a2 hi | a2 lo | features
+    int cap;
+};
+
+int *general_status(General *g) { return g->d_status; }
+
+void general_destroy(General *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device_id);
+    if (g->d_pack) (void)hipFree(g->d_pack);
+    if (g->d_f32) (void)hipFree(g->d_f32);
+    if (g->d_status) (void)hipFree(g->d_status);
+    if (g->d_act) (void)hipFree(g->d_act);
+    delete g;
+}
+
+int general_create(int device_id, const Geometry &geo, int state_dim, const float *conv1_w, const float *conv1_b, const float *conv2_w,
+                   const float *conv2_b, const float *conv3_w, const float *conv3_b, const float *fc_w, const float *fc_b,
+                   General **out, std::string &err) {
+    General *g = new (std::nothrow) General();
+    if (!g) return SRLHIP_ENOMEM;
+    g->device_id = device_id; g->state_dim = state_dim; g->g = geo; g->d_pack = nullptr; g->d_f32 = nullptr; g->d_status = nullptr;
+    g->d_act = nullptr; g->cap = 0;
+    const int F = 64 * geo.Hp[2] * geo.Wp[2];
+    g->F = F;
+    const int ks1 = geo.C == 3 ? 14 : 28;
+    g->pack1_bytes = (size_t)2 * ks1 * 64 * 32;
+    std::vector<char> pack(g->pack1_bytes + 2 * kPack3x3Bytes);
+    const float s1 = pack_layer1(conv1_w, conv1_b, geo.C, reinterpret_cast<_Float16 *>(pack.data()));
+    const float s2 = pack_layer3x3(conv2_w, reinterpret_cast<_Float16 *>(pack.data() + g->pack1_bytes));
+    const float s3 = pack_layer3x3(conv3_w, reinterpret_cast<_Float16 *>(pack.data() + g->pack1_bytes + kPack3x3Bytes));
+    g->inv_scale[0] = 1.f / s1; g->inv_scale[1] = 1.f / s2; g->inv_scale[2] = 1.f / s3;      // powers of two: exact
+    std::vector<float> f(128 + (size_t)state_dim * (1 + F));
+    memcpy(f.data(), conv2_b, 64 * sizeof(float));
+    memcpy(f.data() + 64, conv3_b, 64 * sizeof(float));
+    memcpy(f.data() + 128, fc_b, state_dim * sizeof(float));
+    // features are [frame row p][frame column q][channel]; torch flattens the transposed map as (channel, q, p)
+    const int Hp = geo.Hp[2], Wp = geo.Wp[2];
+    for (int s = 0; s < state_dim; s++)
+        for (int p = 0; p < Hp; p++)
+            for (int q = 0; q < Wp; q++)
+                for (int c = 0; c < 64; c++)
+                    f[128 + state_dim + (size_t)s * F + (p * Wp + q) * 64 + c] = fc_w[(size_t)s * F + (size_t)c * Wp * Hp + q * Hp + p];
+#define GEN_CHECK(expr)                                                              \
+    do {                                                                             \
+        hipError_t e__ = (expr);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            err = std::string(#expr ": ") + hipGetErrorString(e__);                  \
+            general_destroy(g);                                                      \
+            return SRLHIP_EHIP;                                                      \
+        }                                                                            \
+    } while (0)
+    GEN_CHECK(hipSetDevice(device_id));
+    GEN_CHECK(hipMalloc(reinterpret_cast<void **>(&g->d_pack), pack.size()));
+    GEN_CHECK(hipMalloc(reinterpret_cast<void **>(&g->d_f32), f.size() * sizeof(float)));
+    GEN_CHECK(hipMalloc(reinterpret_cast<void **>(&g->d_status), sizeof(int)));
+    GEN_CHECK(hipMemcpy(g->d_pack, pack.data(), pack.size(), hipMemcpyHostToDevice));
+    GEN_CHECK(hipMemcpy(g->d_f32, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    GEN_CHECK(hipMemset(g->d_status, 0, sizeof(int)));
+    constexpr int lds2 = 2 * (kR2 * 2 + 3) * kNC2 * PX, lds3 = 2 * (2 * (2 * kR3) + 3) * kNC3 * PX;
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<2, 4, kR2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+#undef GEN_CHECK
+    *out = g;
+    return SRLHIP_OK;
+}
+
+int general_forward(General *g, const uint8_t *images_dev, int n, float *states_dev, hipStream_t stream, std::string &err) {
+    const Geometry &geo = g->g;
+    const size_t a1 = (size_t)geo.Hp[0] * geo.Wp[0] * 64, a2 = (size_t)geo.Hp[1] * geo.Wp[1] * 64;      // halfs per frame and plane
+    const size_t per_frame = 2 * a1 * 2 + 2 * a2 * 2 + (size_t)g->F * 4;
+    if (n > g->cap) {
+        // grow-only scratch; a caller that captures the forward into a hipGraph warms the handle up with its batch size first
+        if (g->d_act) { (void)hipStreamSynchronize(stream); (void)hipFree(g->d_act); g->d_act = nullptr; g->cap = 0; }
+        hipError_t rc = hipMalloc(reinterpret_cast<void **>(&g->d_act), per_frame * (size_t)n + 256);
+        if (rc != hipSuccess) { err = std::string("encoder scratch hipMalloc: ") + hipGetErrorString(rc); return SRLHIP_ENOMEM; }
+        g->cap = n;
+    }
+    const size_t cap = (size_t)g->cap;
+    _Float16 *a1h = reinterpret_cast<_Float16 *>(g->d_act), *a1l = a1h + a1 * cap, *a2h = a1l + a1 * cap, *a2l = a2h + a2 * cap;
+    float *feat = reinterpret_cast<float *>(a2l + a2 * cap);
+    const char *pack2 = g->d_pack + g->pack1_bytes, *pack3 = pack2 + kPack3x3Bytes;
+    constexpr int kChunk = 32768;                            // frames per launch (grid.z)
+    for (int base = 0; base < n; base += kChunk) {
+        const int nn = n - base < kChunk ? n - base : kChunk;
+        LayerParams p = {};
+        p.status = g->d_status;
+        // layer 1
+        p.img = images_dev + (size_t)base * geo.H * geo.W * geo.C;
+        p.out_hi = a1h + a1 * base; p.out_lo = a1l + a1 * base; p.pack = g->d_pack; p.bias = nullptr; p.inv_scale = g->inv_scale[0];
+        p.Hin = geo.H; p.Win = geo.W; p.Cimg = geo.C; p.Hc = geo.Hc[0]; p.Wc = geo.Wc[0]; p.Hp = geo.Hp[0]; p.Wp = geo.Wp[0];
+        p.nbands = (p.Hp + kR1 - 1) / kR1; p.bands_per_wg = kBandsPerWg1;
+        dim3 grid1((p.Wp + 14) / 15, (p.nbands + kBandsPerWg1 - 1) / kBandsPerWg1, nn);
+        constexpr int nr1 = 2 * (2 * kR1) + 7;
+        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1>), grid1, dim3(128), nr1 * kNC1 * 8, stream, p);
+        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1>), grid1, dim3(128), nr1 * kNC1 * 16, stream, p);
+        // layer 2
+        p.img = nullptr; p.in_hi = a1h + a1 * base; p.in_lo = a1l + a1 * base; p.out_hi = a2h + a2 * base; p.out_lo = a2l + a2 * base;
+        p.pack = pack2; p.bias = g->d_f32; p.inv_scale = g->inv_scale[1];
+        p.Hin = geo.Hp[0]; p.Win = geo.Wp[0]; p.Hc = geo.Hc[1]; p.Wc = geo.Wc[1]; p.Hp = geo.Hp[1]; p.Wp = geo.Wp[1];
+        p.nbands = (p.Hp + kR2 - 1) / kR2; p.bands_per_wg = 1;
+        hipLaunchKernelGGL((enc_layer_k<2, 4, kR2>), dim3((p.Wp + 14) / 15, p.nbands, nn), dim3(128), 2 * (kR2 * 2 + 3) * kNC2 * PX, stream, p);
+        // layer 3
+        p.in_hi = a2h + a2 * base; p.in_lo = a2l + a2 * base; p.out_hi = nullptr; p.out_lo = nullptr; p.out_f32 = feat + (size_t)g->F * base;
+        p.pack = pack3; p.bias = g->d_f32 + 64; p.inv_scale = g->inv_scale[2];
+        p.Hin = geo.Hp[1]; p.Win = geo.Wp[1]; p.Hc = geo.Hc[2]; p.Wc = geo.Wc[2]; p.Hp = geo.Hp[2]; p.Wp = geo.Wp[2];
+        p.nbands = (p.Hp + kR3 - 1) / kR3; p.bands_per_wg = 1;
+        hipLaunchKernelGGL((enc_layer_k<3, 4, kR3>), dim3((p.Wp + 14) / 15, p.nbands, nn), dim3(128), 2 * (2 * (2 * kR3) + 3) * kNC3 * PX, stream, p);
+        hipLaunchKernelGGL(enc_fc_k, dim3(nn), dim3(256), 0, stream, feat + (size_t)g->F * base, g->d_f32 + 128 + g->state_dim, g->d_f32 + 128,
+                           states_dev + (size_t)base * g->state_dim, g->F, g->state_dim);
+    }
+    const hipError_t rc = hipGetLastError();
+    if (rc != hipSuccess) { err = std::string("encoder layer launch: ") + hipGetErrorString(rc); return SRLHIP_EHIP; }
+    return SRLHIP_OK;
+}
+
+}  // namespace srlenc

@@ -372,15 +372,17 @@ def encoder_pack(conv1_w, conv1_b, conv2_w, conv3_w):
 
 
 class Encoder(object):
-    """srlhip_encoder_handle: the fused CustomCNN forward on device-resident uint8 frames (csrc/encoder.hip).
-    Weights: float32 arrays in torch layout with the BatchNorms already folded (see include/srlhip.h)."""
+    """srlhip_encoder_handle: the CustomCNN forward on device-resident uint8 frames — one fused kernel for 64x64x3
+    (csrc/encoder.hip), the layered kernels of csrc/encoder_general.hip for any other shape.
+    Weights: float32 arrays in torch layout with the BatchNorms already folded (see include/srlhip.h); fc_w is
+    [state_dim][64 * pooled cells] in torch's flatten order."""
 
     def __init__(self, device_id, img_shape, n_channels, state_dim, conv1, conv2, conv3, fc):
         self._lib = load()
         self._e = ctypes.c_void_p()
         arrs = [_f32(a) for pair in (conv1, conv2, conv3, fc) for a in pair]
-        assert arrs[0].shape == (64, 3, 7, 7) and arrs[2].shape == (64, 64, 3, 3) and arrs[4].shape == (64, 64, 3, 3)
-        assert arrs[6].shape == (state_dim, 64) and arrs[7].shape == (state_dim,)
+        assert arrs[0].shape == (64, n_channels, 7, 7) and arrs[2].shape == (64, 64, 3, 3) and arrs[4].shape == (64, 64, 3, 3)
+        assert arrs[6].ndim == 2 and arrs[6].shape[0] == state_dim and arrs[6].shape[1] % 64 == 0 and arrs[7].shape == (state_dim,)
         rc = self._lib.srlhip_encoder_create(int(device_id), int(img_shape[0]), int(img_shape[1]), int(n_channels),
                                              int(state_dim), *[_ptr(a) for a in arrs], ctypes.byref(self._e))
         if rc:

@@ -98,8 +98,9 @@ class SRLNeuralNetwork(object):
         # 4096x64x64 batch); logical shapes, and therefore the flatten order in front of the FC, do not change
         self.memory_format = th.channels_last if self.device.type == "cuda" else th.contiguous_format
         self.fused_conv = self.fused_conv.to(memory_format=self.memory_format)
-        # Fused HIP forward (csrc/encoder.hip) for the shape it covers (64x64x3 frames on the GPU); every other
-        # shape keeps the PyTorch-ROCm forward above.  backend: "auto" | "hip" | "torch".
+        # HIP forward through the C-ABI: the fused single-kernel path for 64x64x3 frames (csrc/encoder.hip), the layered
+        # split-f16 MFMA path for every other shape — 224x224x3, 6-channel multi_view (csrc/encoder_general.hip).
+        # backend: "auto" | "hip" | "torch" (the PyTorch-ROCm forward above).
         self.hip = None
         self.backend = "torch"
         if backend not in ("auto", "hip", "torch"):
@@ -110,8 +111,9 @@ class SRLNeuralNetwork(object):
                 self.hip = _lib.Encoder(self.device.index or 0, img_shape, n_channels, state_dim, *self.folded_weights())
                 self.backend = "hip"
         if backend == "hip" and self.hip is None:
-            raise RuntimeError("the fused HIP encoder needs a GPU and 64x64x3 frames (got device {}, shape {}x{})".format(
-                self.device, img_shape, n_channels))
+            raise RuntimeError("the HIP encoder needs a GPU and 3- or 6-channel frames of 8..1024 pixels a side "
+                               "(got device {}, shape {}x{})".format(self.device, img_shape, n_channels))
+        self.img_shape, self.n_channels = tuple(img_shape), n_channels
 
     def folded_weights(self):
         """((conv1_w, conv1_b), (conv2_w, conv2_b), (conv3_w, conv3_b), (fc_w, fc_b)) as float32 numpy arrays in torch
@@ -141,7 +143,7 @@ class SRLNeuralNetwork(object):
         if isinstance(images_u8, np.ndarray):
             images_u8 = th.from_numpy(images_u8)
         images_u8 = images_u8.to(self.device).contiguous()
-        assert images_u8.dtype == th.uint8 and tuple(images_u8.shape[1:]) == (64, 64, 3), images_u8.shape
+        assert images_u8.dtype == th.uint8 and tuple(images_u8.shape[1:]) == self.img_shape + (self.n_channels,), images_u8.shape
         n = images_u8.shape[0]
         if out is None:
             out = th.empty((n, self.state_dim), dtype=th.float32, device=self.device)
