@@ -56,7 +56,7 @@ constexpr int PX = 144;                 // LDS pixel pitch of a 64-channel f16 p
 constexpr float kF16Max = 65504.f, kNegInf = -3.0e38f;
 constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
 constexpr int kNC1 = 70, kNC2 = 34, kNC3 = 65;          // staged input columns of a 32-column convolution tile
-constexpr int kR1 = 3, kR2 = 2, kR3 = 1;                 // pooled rows per band
+constexpr int kR1 = 3, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band (kR1x6: 6-channel frames hold twice the layer-1 weights)
 constexpr int kBandsPerWg1 = 4;                          // layer 1: bands walked with the weights resident
 
 struct LayerParams {
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     constexpr int NC = LAYER == 1 ? kNC1 : (LAYER == 2 ? kNC2 : kNC3);
     constexpr int PIXB = LAYER == 1 ? CPIX * 2 : PX;          // staged bytes per pixel (and plane)
     constexpr int PLANE = NR * NC * PIXB;
-    constexpr int AHEAD = 4;                                  // layers 2-3: B fragments requested this many k-steps early
     const int tid = threadIdx.x, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5;
     const int seg = blockIdx.x, img = blockIdx.z;
     const int c0 = 30 * seg - PPAD, ix0 = S * c0 - PAD;
@@ -106,33 +105,49 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     for (int band = blockIdx.y * P.bands_per_wg; band < band_end; band++) {
         const int p0 = band * R, rr0 = 2 * p0 - PPAD, iy0 = S * rr0 - PAD;
         __syncthreads();                                      // the previous band's fragments have been read
+        // every lane issues all of its loads before the first LDS store: the window arrives in one memory round trip
         if (LAYER == 1) {
-            for (int pix = tid; pix < NR * NC; pix += 128) {
-                const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
-                const bool in = y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
-                const uint8_t *src = P.img + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * P.Cimg;
-                if (CPIX == 4) {
-                    half4v v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                    if (in) { v[0] = (_Float16)(float)src[0]; v[1] = (_Float16)(float)src[1]; v[2] = (_Float16)(float)src[2]; v[3] = (_Float16)1.f; }
-                    *reinterpret_cast<half4v *>(lds + pix * 8) = v;
-                } else {
-                    half8 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                    if (in) {
+            constexpr int ITER = (NR * NC + 127) / 128;
+            uint32_t raw[ITER][2];
 #pragma unroll
-                        for (int c = 0; c < 6; c++) v[c] = (_Float16)(float)src[c];
-                        v[6] = (_Float16)1.f;
+            for (int it = 0; it < ITER; it++) {
+                const int pix = tid + 128 * it, yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
+                const bool in = pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
+                const uint8_t *src = P.img + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * P.Cimg;
+                raw[it][0] = in ? (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | 0x01000000u : 0u;   // byte 3: the mask
+                raw[it][1] = (in && CPIX == 8) ? (uint32_t)src[3] | ((uint32_t)src[4] << 8) | ((uint32_t)src[5] << 16) : 0u;
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int pix = tid + 128 * it;
+                if (pix < NR * NC) {
+                    const uint32_t a = raw[it][0], b = raw[it][1];
+                    if (CPIX == 4) {
+                        const half4v v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u), (_Float16)(float)(a >> 24)};
+                        *reinterpret_cast<half4v *>(lds + pix * 8) = v;
+                    } else {
+                        const half8 v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u),
+                                         (_Float16)(float)(b & 255u), (_Float16)(float)((b >> 8) & 255u), (_Float16)(float)((b >> 16) & 255u),
+                                         (_Float16)(float)(a >> 24), (_Float16)0.f};
+                        *reinterpret_cast<half8 *>(lds + pix * 16) = v;
                     }
-                    *reinterpret_cast<half8 *>(lds + pix * 16) = v;
                 }
             }
         } else {
-            for (int idx = tid; idx < NR * NC * 16; idx += 128) {
-                const int pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
+            constexpr int ITER = (NR * NC * 16 + 127) / 128;
+            u32x4 raw[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
                 const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
-                    v = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
-                *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = v;
+                raw[it] = u32x4{0u, 0u, 0u, 0u};
+                if (pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
+                    raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
+                if (pix < NR * NC) *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = raw[it];
             }
         }
         __syncthreads();
@@ -144,27 +159,39 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
             for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
         const int abase = LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16;
         constexpr int ROWSTRIDE = S * NC * PIXB;
-        half8 rbh[AHEAD], rbl[AHEAD];
-        if (LAYER != 1) {
+        if (LAYER == 1) {
 #pragma unroll
-            for (int s = 0; s < AHEAD; s++) { rbh[s] = glb16(bp + (size_t)s * 2048); rbl[s] = glb16(bp + (size_t)s * 2048 + 16); }
-        }
+            for (int s = 0; s < KS; s++) {
+                const int koff = CPIX == 4 ? ((s >> 1) * NC + 4 * (s & 1)) * 8 : ((s >> 2) * NC + 2 * (s & 3)) * 16;
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const int koff = LAYER == 1 ? (CPIX == 4 ? ((s >> 1) * NC + 4 * (s & 1)) * 8 : ((s >> 2) * NC + 2 * (s & 3)) * 16)
-                                        : (((s >> 2) / 3) * NC + (s >> 2) % 3) * PX + (s & 3) * 32;
-            half8 Bh, Bl;
-            if (LAYER == 1) { Bh = Bh1[s]; Bl = Bl1[s]; }
-            else { Bh = rbh[s % AHEAD]; Bl = rbl[s % AHEAD]; }
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const half8 ah = lds16(abase + t * ROWSTRIDE + koff);
-                acc[t] = mfma16(ah, Bh, acc[t]);
-                acc[t] = mfma16(ah, Bl, acc[t]);
-                if (LAYER != 1) acc[t] = mfma16(lds16(PLANE + abase + t * ROWSTRIDE + koff), Bh, acc[t]);
+                for (int t = 0; t < T; t++) {
+                    const half8 a = lds16(abase + t * ROWSTRIDE + koff);
+                    acc[t] = mfma16(a, Bh1[s], acc[t]);
+                    acc[t] = mfma16(a, Bl1[s], acc[t]);
+                }
             }
-            if (LAYER != 1 && s + AHEAD < KS) {
-                rbh[s % AHEAD] = glb16(bp + (size_t)(s + AHEAD) * 2048); rbl[s % AHEAD] = glb16(bp + (size_t)(s + AHEAD) * 2048 + 16);
+        } else {
+            // one trip per kernel tap (4 k-steps of 16 channels); the B ring is as deep as a trip, so its slots are static
+            half8 rbh[4], rbl[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { rbh[u] = glb16(bp + (size_t)u * 2048); rbl[u] = glb16(bp + (size_t)u * 2048 + 16); }
+#pragma unroll 1
+            for (int tap = 0; tap < 9; tap++) {
+                const int ky = tap / 3, kx = tap - 3 * ky, toff = abase + (ky * NC + kx) * PX;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const half8 Bh = rbh[u], Bl = rbl[u];
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        const half8 ah = lds16(toff + t * ROWSTRIDE + u * 32), al = lds16(PLANE + toff + t * ROWSTRIDE + u * 32);
+                        acc[t] = mfma16(ah, Bh, acc[t]);
+                        acc[t] = mfma16(ah, Bl, acc[t]);
+                        acc[t] = mfma16(al, Bh, acc[t]);
+                    }
+                    if (tap < 8) {
+                        rbh[u] = glb16(bp + (size_t)(4 * tap + 4 + u) * 2048); rbl[u] = glb16(bp + (size_t)(4 * tap + 4 + u) * 2048 + 16);
+                    }
+                }
             }
         }
         // ---- 3x3/2 max-pool on the raw accumulators, then scale / bias / ReLU on the pooled values only --------------------------
@@ -350,11 +377,11 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
         p.img = images_dev + (size_t)base * geo.H * geo.W * geo.C;
         p.out_hi = a1h + a1 * base; p.out_lo = a1l + a1 * base; p.pack = g->d_pack; p.bias = nullptr; p.inv_scale = g->inv_scale[0];
         p.Hin = geo.H; p.Win = geo.W; p.Cimg = geo.C; p.Hc = geo.Hc[0]; p.Wc = geo.Wc[0]; p.Hp = geo.Hp[0]; p.Wp = geo.Wp[0];
-        p.nbands = (p.Hp + kR1 - 1) / kR1; p.bands_per_wg = kBandsPerWg1;
+        const int r1 = geo.C == 3 ? kR1 : kR1x6;
+        p.nbands = (p.Hp + r1 - 1) / r1; p.bands_per_wg = kBandsPerWg1;
         dim3 grid1((p.Wp + 14) / 15, (p.nbands + kBandsPerWg1 - 1) / kBandsPerWg1, nn);
-        constexpr int nr1 = 2 * (2 * kR1) + 7;
-        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1>), grid1, dim3(128), nr1 * kNC1 * 8, stream, p);
-        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1>), grid1, dim3(128), nr1 * kNC1 * 16, stream, p);
+        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1>), grid1, dim3(128), (2 * (2 * kR1) + 7) * kNC1 * 8, stream, p);
+        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6>), grid1, dim3(128), (2 * (2 * kR1x6) + 7) * kNC1 * 16, stream, p);
         // layer 2
         p.img = nullptr; p.in_hi = a1h + a1 * base; p.in_lo = a1l + a1 * base; p.out_hi = a2h + a2 * base; p.out_lo = a2l + a2 * base;
         p.pack = pack2; p.bias = g->d_f32; p.inv_scale = g->inv_scale[1];
