@@ -20,6 +20,7 @@
 #include "encoder_general.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -56,6 +57,8 @@ constexpr int PX = 144;                 // LDS pixel pitch of a 64-channel f16 p
 constexpr float kF16Max = 65504.f, kNegInf = -3.0e38f;
 constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
 constexpr int kNC1 = 70, kNC2 = 34, kNC3 = 65;          // staged input columns of a 32-column convolution tile
+constexpr int kNC3Narrow = 33;                           // layer 3 when its map has at most 16 columns (224x224 frames: 14)
+constexpr int kLdsSlack3 = 2 * 32 * PX;                  // the masked columns of a narrow tile still read (finite garbage) behind the window
 constexpr int kR1 = 3, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band (kR1x6: 6-channel frames hold twice the layer-1 weights)
 constexpr int kBandsPerWg1 = 4;                          // layer 1: bands walked with the weights resident
 
@@ -80,13 +83,13 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 
 // LAYER 1: u8 frame -> conv7x7/2 p3 -> pool3/2 p1 (CPIX f16 per staged pixel: 4 = RGB + mask, 8 = 6 channels + mask + 0)
 // LAYER 2: planes -> conv3x3 p1 -> pool3/2      LAYER 3: planes -> conv3x3/2 p1 -> pool3/2 -> float32 features
-template <int LAYER, int CPIX, int R>
+// NC: staged input columns (kNC1 / kNC2 / kNC3, or kNC3Narrow when layer 3's map is at most 16 columns wide)
+template <int LAYER, int CPIX, int R, int NC>
 __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     constexpr int T = 2 * R + 1;                              // convolution rows of a band
     constexpr int KS = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
     constexpr int S = LAYER == 2 ? 1 : 2, PAD = LAYER == 1 ? 3 : 1, KW = LAYER == 1 ? 7 : 3, PPAD = LAYER == 1 ? 1 : 0;
     constexpr int NR = S * (T - 1) + KW;                      // staged input rows
-    constexpr int NC = LAYER == 1 ? kNC1 : (LAYER == 2 ? kNC2 : kNC3);
     constexpr int PIXB = LAYER == 1 ? CPIX * 2 : PX;          // staged bytes per pixel (and plane)
     constexpr int PLANE = NR * NC * PIXB;
     const int tid = threadIdx.x, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5;
@@ -102,26 +105,52 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     const float bias = P.bias ? P.bias[ch] : 0.f;
     bool ovf = false;
     const int band_end = min(P.nbands, ((int)blockIdx.y + 1) * P.bands_per_wg);
-    for (int band = blockIdx.y * P.bands_per_wg; band < band_end; band++) {
-        const int p0 = band * R, rr0 = 2 * p0 - PPAD, iy0 = S * rr0 - PAD;
-        __syncthreads();                                      // the previous band's fragments have been read
-        // every lane issues all of its loads before the first LDS store: the window arrives in one memory round trip
+    // Staging is split in two: `issue` sends every load of a band's input window (all of a lane's loads before anything else,
+    // so the window costs one memory round trip), `commit` converts / stores them to LDS.  Layer 1 issues the NEXT band's
+    // loads before this band's MFMAs and commits them after the pooled rows have been stored; layers 2-3 keep the registers
+    // for the weight ring instead (loads return in order: a window prefetch would also stall that ring).
+    constexpr int ITER = LAYER == 1 ? (NR * NC + 127) / 128 : (NR * NC * 16 + 127) / 128;
+    uint32_t raw1[LAYER == 1 ? ITER : 1][2];
+    u32x4 raw[LAYER == 1 ? 1 : ITER];
+    auto issue = [&](int band) {
+        const int iy0 = S * (2 * band * R - PPAD) - PAD;
         if (LAYER == 1) {
-            constexpr int ITER = (NR * NC + 127) / 128;
-            uint32_t raw[ITER][2];
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int pix = tid + 128 * it, yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
                 const bool in = pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
                 const uint8_t *src = P.img + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * P.Cimg;
-                raw[it][0] = in ? (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | 0x01000000u : 0u;   // byte 3: the mask
-                raw[it][1] = (in && CPIX == 8) ? (uint32_t)src[3] | ((uint32_t)src[4] << 8) | ((uint32_t)src[5] << 16) : 0u;
+                // one unaligned dword (two for 6 channels) per pixel; the frame batch's very last pixel is read byte by byte
+                const bool tail = img == (int)gridDim.z - 1 && y == P.Hin - 1 && x == P.Win - 1;
+                uint32_t w0 = 0u, w1 = 0u;
+                if (in && !tail) {
+                    __builtin_memcpy(&w0, src, 4);
+                    if (CPIX == 8) __builtin_memcpy(&w1, src + 4, 4);
+                } else if (in) {
+                    w0 = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16);
+                    if (CPIX == 8) { w0 |= (uint32_t)src[3] << 24; w1 = (uint32_t)src[4] | ((uint32_t)src[5] << 8); }
+                }
+                if (CPIX == 4) { raw1[it][0] = in ? (w0 & 0xffffffu) | 0x01000000u : 0u; raw1[it][1] = 0u; }     // byte 3: the mask
+                else { raw1[it][0] = in ? (w0 & 0xffffffu) | 0x01000000u : 0u; raw1[it][1] = in ? (w0 >> 24) | ((w1 & 0xffffu) << 8) : 0u; }
             }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
+                const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
+                raw[it] = u32x4{0u, 0u, 0u, 0u};
+                if (pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
+                    raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
+            }
+        }
+    };
+    auto commit = [&]() {
+        if (LAYER == 1) {
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int pix = tid + 128 * it;
                 if (pix < NR * NC) {
-                    const uint32_t a = raw[it][0], b = raw[it][1];
+                    const uint32_t a = raw1[it][0], b = raw1[it][1];
                     if (CPIX == 4) {
                         const half4v v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u), (_Float16)(float)(a >> 24)};
                         *reinterpret_cast<half4v *>(lds + pix * 8) = v;
@@ -134,22 +163,20 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
                 }
             }
         } else {
-            constexpr int ITER = (NR * NC * 16 + 127) / 128;
-            u32x4 raw[ITER];
-#pragma unroll
-            for (int it = 0; it < ITER; it++) {
-                const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
-                const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
-                raw[it] = u32x4{0u, 0u, 0u, 0u};
-                if (pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
-                    raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
-            }
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
                 if (pix < NR * NC) *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = raw[it];
             }
         }
+    };
+    const int band0 = blockIdx.y * P.bands_per_wg;
+    if (LAYER == 1 && band0 < band_end) issue(band0);
+    for (int band = band0; band < band_end; band++) {
+        const int p0 = band * R, rr0 = 2 * p0 - PPAD;
+        __syncthreads();                                      // the previous band's fragments have been read
+        if (LAYER != 1) issue(band);
+        commit();
         __syncthreads();
         // ---- 2R+1 convolution rows x 32 columns x this wavefront's 32 channels: raw accumulators ----------------------------
         f32x16 acc[T];
@@ -160,72 +187,110 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
         const int abase = LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16;
         constexpr int ROWSTRIDE = S * NC * PIXB;
         if (LAYER == 1) {
+            if (band + 1 < band_end) issue(band + 1);
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 const int koff = CPIX == 4 ? ((s >> 1) * NC + 4 * (s & 1)) * 8 : ((s >> 2) * NC + 2 * (s & 3)) * 16;
+                half8 a[T];                                   // consecutive MFMAs go to different accumulators
 #pragma unroll
-                for (int t = 0; t < T; t++) {
-                    const half8 a = lds16(abase + t * ROWSTRIDE + koff);
-                    acc[t] = mfma16(a, Bh1[s], acc[t]);
-                    acc[t] = mfma16(a, Bl1[s], acc[t]);
-                }
+                for (int t = 0; t < T; t++) a[t] = lds16(abase + t * ROWSTRIDE + koff);
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bh1[s], acc[t]);
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bl1[s], acc[t]);
             }
         } else {
-            // one trip per kernel tap (4 k-steps of 16 channels); the B ring is as deep as a trip, so its slots are static
-            half8 rbh[4], rbl[4];
+            // one trip per kernel tap (4 k-steps of 16 channels); the B ring holds two trips, so its slots are static
+            half8 rbh[8], rbl[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { rbh[u] = glb16(bp + (size_t)u * 2048); rbl[u] = glb16(bp + (size_t)u * 2048 + 16); }
+            for (int u = 0; u < 8; u++) { rbh[u] = glb16(bp + (size_t)u * 2048); rbl[u] = glb16(bp + (size_t)u * 2048 + 16); }
 #pragma unroll 1
-            for (int tap = 0; tap < 9; tap++) {
-                const int ky = tap / 3, kx = tap - 3 * ky, toff = abase + (ky * NC + kx) * PX;
+            for (int tap2 = 0; tap2 < 10; tap2 += 2) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const half8 Bh = rbh[u], Bl = rbl[u];
+                for (int v = 0; v < 8; v++) {
+                    const int tap = tap2 + (v >> 2), u = v & 3;
+                    if (tap < 9) {
+                        const int ky = tap / 3, kx = tap - 3 * ky, toff = abase + (ky * NC + kx) * PX;
+                        const half8 Bh = rbh[v], Bl = rbl[v];
+                        half8 ah[T], al[T];                   // consecutive MFMAs go to different accumulators
 #pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        const half8 ah = lds16(toff + t * ROWSTRIDE + u * 32), al = lds16(PLANE + toff + t * ROWSTRIDE + u * 32);
-                        acc[t] = mfma16(ah, Bh, acc[t]);
-                        acc[t] = mfma16(ah, Bl, acc[t]);
-                        acc[t] = mfma16(al, Bh, acc[t]);
-                    }
-                    if (tap < 8) {
-                        rbh[u] = glb16(bp + (size_t)(4 * tap + 4 + u) * 2048); rbl[u] = glb16(bp + (size_t)(4 * tap + 4 + u) * 2048 + 16);
+                        for (int t = 0; t < T; t++) { ah[t] = lds16(toff + t * ROWSTRIDE + u * 32); al[t] = lds16(PLANE + toff + t * ROWSTRIDE + u * 32); }
+#pragma unroll
+                        for (int t = 0; t < T; t++) acc[t] = mfma16(ah[t], Bh, acc[t]);
+#pragma unroll
+                        for (int t = 0; t < T; t++) acc[t] = mfma16(ah[t], Bl, acc[t]);
+#pragma unroll
+                        for (int t = 0; t < T; t++) acc[t] = mfma16(al[t], Bh, acc[t]);
+                        if (tap + 2 < 9) {
+                            rbh[v] = glb16(bp + (size_t)(4 * tap + 8 + u) * 2048); rbl[v] = glb16(bp + (size_t)(4 * tap + 8 + u) * 2048 + 16);
+                        }
                     }
                 }
             }
         }
         // ---- 3x3/2 max-pool on the raw accumulators, then scale / bias / ReLU on the pooled values only --------------------------
-        // acc[t][i] of lane l: convolution row rr0 + t, column c0 + 8 (i / 4) + 4 (l / 32) + i % 4, channel ch
+        // acc[t][i] of lane l: convolution row rr0 + t, column c0 + 8 (i / 4) + 4 (l / 32) + i % 4, channel ch.
+        // The pooled band is assembled in LDS (over the input window, which is dead by now) as [plane][row][column][64 channels]
+        // and leaves with 16-byte stores: one 128-byte line per pixel and plane.
+        __syncthreads();
+        constexpr int OPIX = R * 15, OPLANE = OPIX * 128;
 #pragma unroll
         for (int j = 0; j < R; j++) {
             const int p = p0 + j;
             if (p >= P.Hp) break;
             const bool rv0 = rr0 + 2 * j >= 0 && rr0 + 2 * j < P.Hc, rv1 = rr0 + 2 * j + 1 < P.Hc, rv2 = rr0 + 2 * j + 2 < P.Hc;
-            float full[32];                                   // this channel's 32 columns of the vertically pooled row
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float v = max3(rv0 ? acc[2 * j][i] : kNegInf, rv1 ? acc[2 * j + 1][i] : kNegInf, rv2 ? acc[2 * j + 2][i] : kNegInf);
-                const float o = __shfl_xor(v, 32);
-                full[8 * (i >> 2) + (i & 3)] = h ? o : v;
-                full[8 * (i >> 2) + 4 + (i & 3)] = h ? v : o;
-            }
-#pragma unroll
-            for (int mm = 0; mm < 32; mm++)
-                if (c0 + mm < 0 || c0 + mm >= P.Wc) full[mm] = kNegInf;
-#pragma unroll
-            for (int jj = 0; jj < 15; jj++) {
-                const int q = 15 * seg + jj;
-                if (q < P.Wp && (jj & 1) == h) {
-                    const float x = fmaxf(max3(full[2 * jj], full[2 * jj + 1], full[2 * jj + 2]) * P.inv_scale + bias, 0.f);
-                    const size_t o = (((size_t)img * P.Hp + p) * P.Wp + q) * 64 + ch;
-                    if (LAYER == 3) P.out_f32[o] = x;
+            // columns arrive eight at a time (accumulator quad g of both wavefront halves); a pooled column is emitted as soon as
+            // its three inputs exist, so only nine column values are live at once
+            auto emit = [&](int jj, float val) {
+                if ((jj & 1) == h) {
+                    const float x = fmaxf(val * P.inv_scale + bias, 0.f);
+                    if (LAYER == 3) *reinterpret_cast<float *>(lds + ((j * 15 + jj) * 64 + ch) * 4) = x;
                     else {
-                        ovf |= !(x < kF16Max);
+                        ovf |= !(x < kF16Max);                // columns beyond the map hold -inf -> 0 after the ReLU: never flagged
                         const _Float16 hi = (_Float16)x;
-                        P.out_hi[o] = hi;
-                        P.out_lo[o] = (_Float16)(x - (float)hi);
+                        *reinterpret_cast<_Float16 *>(lds + ((j * 15 + jj) * 64 + ch) * 2) = hi;
+                        *reinterpret_cast<_Float16 *>(lds + OPLANE + ((j * 15 + jj) * 64 + ch) * 2) = (_Float16)(x - (float)hi);
                     }
                 }
+            };
+            float prev6 = kNegInf, prev7 = kNegInf;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float c[8];
+#pragma unroll
+                for (int i4 = 0; i4 < 4; i4++) {
+                    const int i = 4 * g + i4;
+                    const float v = max3(rv0 ? acc[2 * j][i] : kNegInf, rv1 ? acc[2 * j + 1][i] : kNegInf, rv2 ? acc[2 * j + 2][i] : kNegInf);
+                    // v_permlane32_swap(v, v): first result = lanes 0-31's value in both halves (column 8g + i4), second = lanes 32-63's
+                    // (column 8g + 4 + i4): both halves of the wavefront see all 32 columns of their channel
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    c[i4] = __uint_as_float(sw[0]);
+                    c[4 + i4] = __uint_as_float(sw[1]);
+                }
+                if (c0 < 0 || c0 + 32 > P.Wc) {               // the map's edge runs through this tile
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (c0 + 8 * g + k < 0 || c0 + 8 * g + k >= P.Wc) c[k] = kNegInf;
+                }
+                if (g > 0) emit(4 * g - 1, max3(prev6, prev7, c[0]));
+                emit(4 * g, max3(c[0], c[1], c[2]));
+                emit(4 * g + 1, max3(c[2], c[3], c[4]));
+                emit(4 * g + 2, max3(c[4], c[5], c[6]));
+                prev6 = c[6]; prev7 = c[7];
+            }
+        }
+        __syncthreads();
+        constexpr int CPP = LAYER == 3 ? 16 : 8;              // 16-byte chunks per pixel (and plane)
+        constexpr int NCHUNK = OPIX * CPP * (LAYER == 3 ? 1 : 2);
+#pragma unroll
+        for (int it = 0; it < (NCHUNK + 127) / 128; it++) {
+            const int c = tid + 128 * it, pl = c / (OPIX * CPP), rem = c - pl * (OPIX * CPP), pix = rem / CPP, c8 = rem - pix * CPP;
+            const int j = pix / 15, jj = pix - 15 * j, p = p0 + j, q = 15 * seg + jj;
+            if (c < NCHUNK && p < P.Hp && q < P.Wp) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + c * 16);
+                const size_t o = (((size_t)img * P.Hp + p) * P.Wp + q) * 64;
+                if (LAYER == 3) *reinterpret_cast<u32x4 *>(P.out_f32 + o + c8 * 4) = v;
+                else *reinterpret_cast<u32x4 *>((pl ? P.out_lo : P.out_hi) + o + c8 * 8) = v;
             }
         }
     }
@@ -346,11 +411,23 @@ int general_create(int device_id, const Geometry &geo, int state_dim, const floa
     GEN_CHECK(hipMemcpy(g->d_f32, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     GEN_CHECK(hipMemset(g->d_status, 0, sizeof(int)));
     constexpr int lds2 = 2 * (kR2 * 2 + 3) * kNC2 * PX, lds3 = 2 * (2 * (2 * kR3) + 3) * kNC3 * PX;
-    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<2, 4, kR2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<2, 4, kR2, kNC2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3, kNC3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3, kNC3Narrow>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (2 * (2 * kR3) + 3) * kNC3Narrow * PX + kLdsSlack3));
 #undef GEN_CHECK
     *out = g;
     return SRLHIP_OK;
+}
+
+// bands a workgroup walks (its next window is fetched behind the current band's MFMAs): as many as leave >= 4096 workgroups
+// dynamic LDS of a layer kernel: the input window, or the pooled band that replaces it before the stores
+static int lds_bytes(int window, int r, bool f32) { const int band = r * 15 * (f32 ? 256 : 256); return window > band ? window : band; }
+
+static int bands_per_wg(int nbands, int nsegs, int frames) {
+    const long long wgs = (long long)nbands * nsegs * frames;
+    const long long b = wgs / 4096;
+    return (int)(b < 1 ? 1 : (b > nbands ? nbands : b));
 }
 
 int general_forward(General *g, const uint8_t *images_dev, int n, float *states_dev, hipStream_t stream, std::string &err) {
@@ -380,20 +457,25 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
         const int r1 = geo.C == 3 ? kR1 : kR1x6;
         p.nbands = (p.Hp + r1 - 1) / r1; p.bands_per_wg = kBandsPerWg1;
         dim3 grid1((p.Wp + 14) / 15, (p.nbands + kBandsPerWg1 - 1) / kBandsPerWg1, nn);
-        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1>), grid1, dim3(128), (2 * (2 * kR1) + 7) * kNC1 * 8, stream, p);
-        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6>), grid1, dim3(128), (2 * (2 * kR1x6) + 7) * kNC1 * 16, stream, p);
+        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1) + 7) * kNC1 * 8, kR1, false), stream, p);
+        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1x6) + 7) * kNC1 * 16, kR1x6, false), stream, p);
         // layer 2
         p.img = nullptr; p.in_hi = a1h + a1 * base; p.in_lo = a1l + a1 * base; p.out_hi = a2h + a2 * base; p.out_lo = a2l + a2 * base;
         p.pack = pack2; p.bias = g->d_f32; p.inv_scale = g->inv_scale[1];
         p.Hin = geo.Hp[0]; p.Win = geo.Wp[0]; p.Hc = geo.Hc[1]; p.Wc = geo.Wc[1]; p.Hp = geo.Hp[1]; p.Wp = geo.Wp[1];
-        p.nbands = (p.Hp + kR2 - 1) / kR2; p.bands_per_wg = 1;
-        hipLaunchKernelGGL((enc_layer_k<2, 4, kR2>), dim3((p.Wp + 14) / 15, p.nbands, nn), dim3(128), 2 * (kR2 * 2 + 3) * kNC2 * PX, stream, p);
+        p.nbands = (p.Hp + kR2 - 1) / kR2; p.bands_per_wg = bands_per_wg(p.nbands, (p.Wp + 14) / 15, nn);
+        hipLaunchKernelGGL((enc_layer_k<2, 4, kR2, kNC2>), dim3((p.Wp + 14) / 15, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn), dim3(128), 2 * (kR2 * 2 + 3) * kNC2 * PX, stream, p);
         // layer 3
         p.in_hi = a2h + a2 * base; p.in_lo = a2l + a2 * base; p.out_hi = nullptr; p.out_lo = nullptr; p.out_f32 = feat + (size_t)g->F * base;
         p.pack = pack3; p.bias = g->d_f32 + 64; p.inv_scale = g->inv_scale[2];
         p.Hin = geo.Hp[1]; p.Win = geo.Wp[1]; p.Hc = geo.Hc[2]; p.Wc = geo.Wc[2]; p.Hp = geo.Hp[2]; p.Wp = geo.Wp[2];
-        p.nbands = (p.Hp + kR3 - 1) / kR3; p.bands_per_wg = 1;
-        hipLaunchKernelGGL((enc_layer_k<3, 4, kR3>), dim3((p.Wp + 14) / 15, p.nbands, nn), dim3(128), 2 * (2 * (2 * kR3) + 3) * kNC3 * PX, stream, p);
+        p.nbands = (p.Hp + kR3 - 1) / kR3; p.bands_per_wg = bands_per_wg(p.nbands, (p.Wp + 14) / 15, nn);
+        if (p.Wc <= 16)
+            hipLaunchKernelGGL((enc_layer_k<3, 4, kR3, kNC3Narrow>), dim3(1, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn), dim3(128),
+                               2 * (2 * (2 * kR3) + 3) * kNC3Narrow * PX + kLdsSlack3, stream, p);
+        else
+            hipLaunchKernelGGL((enc_layer_k<3, 4, kR3, kNC3>), dim3((p.Wp + 14) / 15, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn), dim3(128),
+                               2 * (2 * (2 * kR3) + 3) * kNC3 * PX, stream, p);
         hipLaunchKernelGGL(enc_fc_k, dim3(nn), dim3(256), 0, stream, feat + (size_t)g->F * base, g->d_f32 + 128 + g->state_dim, g->d_f32 + 128,
                            states_dev + (size_t)base * g->state_dim, g->F, g->state_dim);
     }
