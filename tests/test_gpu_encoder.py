@@ -137,9 +137,10 @@ def test_vec_env_with_a_learned_srl_model(img_shape, tmp_path):
 def test_hip_encoder_rejects_what_it_does_not_cover():
     from srlhip import _lib
     with pytest.raises(RuntimeError):
-        SRLNeuralNetwork(2, cuda=True, img_shape=(224, 224), backend="hip")
-    net = SRLNeuralNetwork(2, cuda=True, img_shape=(224, 224))            # auto: falls to the PyTorch-ROCm forward, on the GPU
-    assert net.backend == "torch" and net.getStates(np.zeros((2, 224, 224, 3), np.uint8)).is_cuda
+        SRLNeuralNetwork(2, cuda=True, img_shape=(1040, 64), backend="hip")                   # beyond the C-ABI's 1024-pixel side
+    net = SRLNeuralNetwork(2, cuda=True, img_shape=(1040, 64))                # auto: falls to the PyTorch-ROCm forward, on the GPU
+    assert net.backend == "torch" and net.getStates(np.zeros((2, 1040, 64, 3), np.uint8)).is_cuda
+    assert SRLNeuralNetwork(2, cuda=True, img_shape=(224, 224)).backend == "hip"              # the reference's frame size: layered HIP path
     gpu, _ = make_net(2, 0, True)
     with pytest.raises(_lib.SrlHipError):
         gpu.hip.forward(0, 4, 0)                                           # null buffers
