@@ -254,17 +254,24 @@ int srlhip_abi_version(void);
 /* ---- SRL encoder (raw_pixels -> state) ----------------------------------------------------------------
  * Replaces SRLNeuralNetwork.getState (state_representation/models.py:178-193: preprocessImage, the H/W
  * transpose, one CustomCNN forward) and the one-image-at-a-time encoder server MultiprocessSRLModel._run
- * (rl_baselines/utils.py:181-191) for a whole DEVICE-resident batch of frames, in one fused HIP kernel
- * (csrc/encoder.hip).  Weights are plain float32 host arrays in torch layout with the BatchNorms already
- * folded into the preceding convolution (w' = w*gamma/sigma, b' = beta - mu*gamma/sigma):
- *   conv1_w [64][3][7][7] conv1_b [64]   conv2_w, conv3_w [64][64][3][3]   conv2_b, conv3_b [64]
- *   fc_w [state_dim][64]  fc_b [state_dim]
- * Covered shape: 64x64 frames with 3 channels (BASELINE configs 4-5); anything else -> SRLHIP_ENOTSUP
- * (srlhip_encoder_supported() tells beforehand) and the caller keeps the PyTorch-ROCm forward.
- * images_dev uint8 [n][64][64][3] and states_dev float [n][state_dim] are DEVICE pointers on device_id; the
- * call only enqueues on hip_stream (NULL = the default stream). */
+ * (rl_baselines/utils.py:181-191) for a whole DEVICE-resident batch of frames.  Weights are plain float32 host
+ * arrays in torch layout with the BatchNorms already folded into the preceding convolution
+ * (w' = w*gamma/sigma, b' = beta - mu*gamma/sigma):
+ *   conv1_w [64][C][7][7] conv1_b [64]   conv2_w, conv3_w [64][64][3][3]   conv2_b, conv3_b [64]
+ *   fc_w [state_dim][64 * cells]  fc_b [state_dim]      (cells = the last pooled map's size, torch flatten order)
+ * Covered shapes (srlhip_encoder_supported() tells beforehand, anything else -> SRLHIP_ENOTSUP and the caller keeps
+ * the PyTorch-ROCm forward): frames of 8..1024 pixels a side that survive the three conv + pool stages, with C = 3
+ * channels or C = 6 (multi_view / fpv: two cameras, kuka_button_gym_env.py:401-417).  64x64x3 (BASELINE configs 4-5)
+ * runs as ONE fused kernel (csrc/encoder.hip); every other shape — the reference's 224x224 RENDER size among them —
+ * runs layer by layer with f16 hi/lo activation planes in HBM (csrc/encoder_general.hip), same arithmetic.
+ * images_dev uint8 [n][H][W][C] and states_dev float [n][state_dim] are DEVICE pointers on device_id; the call only
+ * enqueues on hip_stream (NULL = the default stream).  The layered path keeps grow-only scratch planes per handle: a
+ * caller that captures the forward into a HIP graph calls it once with its batch size before capturing. */
 typedef struct srlhip_encoder *srlhip_encoder_handle;
 int srlhip_encoder_supported(int32_t img_h, int32_t img_w, int32_t n_channels);
+/* Host-only: inputs of the fully connected layer for this frame shape (64 channels x the last pooled map), 0 when the
+ * shape is not covered — the second dimension fc_w must have. */
+int32_t srlhip_encoder_feature_count(int32_t img_h, int32_t img_w, int32_t n_channels);
 int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32_t n_channels, int32_t state_dim,
                           const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv2_b,
                           const float *conv3_w, const float *conv3_b, const float *fc_w, const float *fc_b,

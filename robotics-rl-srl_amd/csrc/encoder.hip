@@ -589,6 +589,11 @@ int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float 
 
 int srlhip_encoder_supported(int32_t img_h, int32_t img_w, int32_t n_channels) { return supported_shape(img_h, img_w, n_channels) ? 1 : 0; }
 
+int32_t srlhip_encoder_feature_count(int32_t img_h, int32_t img_w, int32_t n_channels) {
+    const srlenc::Geometry g = srlenc::geometry(img_h, img_w, n_channels);
+    return g.ok ? 64 * g.Hp[2] * g.Wp[2] : 0;
+}
+
 int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32_t n_channels, int32_t state_dim,
                           const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv2_b,
                           const float *conv3_w, const float *conv3_b, const float *fc_w, const float *fc_b,

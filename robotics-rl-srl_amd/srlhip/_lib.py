@@ -39,7 +39,7 @@ EXPORTS = [
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
-    "srlhip_encoder_supported", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
+    "srlhip_encoder_supported", "srlhip_encoder_feature_count", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
     "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
 ]
@@ -121,6 +121,8 @@ def load():
     lib.srlhip_graph_launch.argtypes = [vp, vp]
     lib.srlhip_graph_destroy.argtypes = [vp]
     lib.srlhip_encoder_supported.argtypes = [i32, i32, i32]
+    lib.srlhip_encoder_feature_count.argtypes = [i32, i32, i32]
+    lib.srlhip_encoder_feature_count.restype = i32
     lib.srlhip_encoder_create.argtypes = [i32, i32, i32, i32, i32] + [vp] * 8 + [ctypes.POINTER(vp)]
     lib.srlhip_encoder_forward.argtypes = [vp, vp, i32, vp, vp]
     lib.srlhip_encoder_overflow.argtypes = [vp, ctypes.POINTER(i32)]
@@ -357,6 +359,11 @@ def encoder_supported(img_h, img_w, n_channels):
     return bool(load().srlhip_encoder_supported(int(img_h), int(img_w), int(n_channels)))
 
 
+def encoder_feature_count(img_h, img_w, n_channels):
+    """inputs of the encoder's fully connected layer for this frame shape, 0 when the shape is not covered"""
+    return int(load().srlhip_encoder_feature_count(int(img_h), int(img_w), int(n_channels)))
+
+
 def encoder_pack(conv1_w, conv1_b, conv2_w, conv3_w):
     """Host-only: (packed MFMA B-operand image as float16 words, the three per-layer power-of-two weight scales)
     exactly as srlhip_encoder_create uploads them."""
@@ -382,7 +389,7 @@ class Encoder(object):
         self._e = ctypes.c_void_p()
         arrs = [_f32(a) for pair in (conv1, conv2, conv3, fc) for a in pair]
         assert arrs[0].shape == (64, n_channels, 7, 7) and arrs[2].shape == (64, 64, 3, 3) and arrs[4].shape == (64, 64, 3, 3)
-        assert arrs[6].ndim == 2 and arrs[6].shape[0] == state_dim and arrs[6].shape[1] % 64 == 0 and arrs[7].shape == (state_dim,)
+        assert arrs[6].shape == (state_dim, encoder_feature_count(img_shape[0], img_shape[1], n_channels)) and arrs[7].shape == (state_dim,)
         rc = self._lib.srlhip_encoder_create(int(device_id), int(img_shape[0]), int(img_shape[1]), int(n_channels),
                                              int(state_dim), *[_ptr(a) for a in arrs], ctypes.byref(self._e))
         if rc:

@@ -90,3 +90,22 @@ def test_multi_view_frames_from_the_rasteriser():
     out = gpu.getStates(img).cpu().numpy()
     assert rel_err(out, cpu.getStates(img.cpu().numpy()).numpy()) < TOL
     h.close()
+
+
+@pytest.mark.parametrize("shape,multi_view,use_graph", [((224, 224), False, False), ((64, 64), True, True), ((112, 112), False, True)])
+def test_pixel_pipeline_on_the_layered_encoder(shape, multi_view, use_graph):
+    """stepper -> rasteriser -> layered encoder on one stream (PixelStateVecEnv), eager and replayed from a HIP graph:
+    the states are the CPU float32 forward of the frames the env holds."""
+    from srlhip.pixel_env import PixelStateVecEnv
+    ch = 6 if multi_view else 3
+    gpu, cpu = make_nets(5, 21, shape, ch)
+    env = PixelStateVecEnv("KukaButtonGymEnv-v0", 24, gpu, seed=5, img_shape=shape, env_kwargs={"multi_view": multi_view}, use_graph=use_graph)
+    states = env.reset()
+    torch.cuda.synchronize()
+    assert rel_err(states.cpu().numpy(), cpu.getStates(env.images.cpu().numpy()).numpy()) < TOL
+    for t in range(6):
+        states, rew, done = env.step()
+        torch.cuda.synchronize()
+        assert rel_err(states.cpu().numpy(), cpu.getStates(env.images.cpu().numpy()).numpy()) < TOL, t
+    assert (len(env._graphs) == 1) == use_graph
+    env.close()
