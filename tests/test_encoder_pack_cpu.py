@@ -106,7 +106,8 @@ def test_pack_rejects_short_buffers_and_encoder_needs_a_gpu():
     lib = _lib.load()
     z = np.zeros(16, np.float32)
     assert lib.srlhip_encoder_pack(_lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), _lib._ptr(z), 16, _lib._ptr(z)) == -22
-    assert not _lib.encoder_supported(224, 224, 3) and not _lib.encoder_supported(64, 64, 6)
+    assert _lib.encoder_supported(224, 224, 3) and _lib.encoder_supported(64, 64, 6)      # the layered path (encoder_general.hip)
+    assert not _lib.encoder_supported(64, 64, 4) and not _lib.encoder_supported(32, 32, 3)
     if not torch.cuda.is_available():
         net = SRLNeuralNetwork(2, img_shape=(64, 64))              # CPU device: PyTorch forward, never the HIP handle
         assert net.backend == "torch" and net.hip is None
