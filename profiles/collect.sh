@@ -12,6 +12,13 @@ for w in kuka mobile kuka_pixels; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -o $w -- python $R/bench.py --workload $w > $OUT/bench_$w.json 2>/dev/null
   cp $(find /tmp/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${w}_kernel_stats.csv
 done
+# the layered encoder (224x224x3 and 6-channel frames) and the rasteriser on their own
+timeout 300 python $R/profiles/encoder_general_microbench.py > $OUT/encoder_general_microbench.jsonl 2>/dev/null
+timeout 100 python $R/profiles/raster_microbench.py > $OUT/raster_microbench.txt 2>/dev/null
+rm -rf /tmp/prof_eg
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_eg -o eg -- python $R/profiles/probes/encoder_general_prof.py > /dev/null 2>&1
+cp $(find /tmp/prof_eg -name "*kernel_stats.csv" | head -1) $OUT/encoder_general_kernel_stats.csv
+[ -n "$SRLHIP_COLLECT_QUICK" ] && { ls -la $OUT; exit 0; }      # the PMC passes and the N-sweeps below only change with the steppers
 for w in kuka mobile; do
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
     tag=$(echo $pmc | cut -d" " -f1)

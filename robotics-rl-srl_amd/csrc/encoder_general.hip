@@ -59,8 +59,7 @@ constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 
 constexpr int kNC1 = 70, kNC2 = 34, kNC3 = 65;          // staged input columns of a 32-column convolution tile
 constexpr int kNC3Narrow = 33;                           // layer 3 when its map has at most 16 columns (224x224 frames: 14)
 constexpr int kLdsSlack3 = 2 * 32 * PX;                  // the masked columns of a narrow tile still read (finite garbage) behind the window
-constexpr int kR1 = 3, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band (kR1x6: 6-channel frames hold twice the layer-1 weights)
-constexpr int kBandsPerWg1 = 4;                          // layer 1: bands walked with the weights resident
+constexpr int kR1 = 4, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band (kR1x6: 6-channel frames hold twice the layer-1 weights)
 
 struct LayerParams {
     const uint8_t *img;              // layer 1: [n][H][W][C]
@@ -100,9 +99,14 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     if (LAYER == 1) {
 #pragma unroll
         for (int s = 0; s < KS; s++) { Bh1[s] = glb16(bp + (size_t)s * 2048); Bl1[s] = glb16(bp + (size_t)s * 2048 + 16); }
+        // opaque to the compiler from here on: otherwise it re-loads fragments inside the band loop instead of keeping them,
+        // and (loads return in order) every band waits for its window prefetch in front of the first MFMA
+#pragma unroll
+        for (int s = 0; s < KS; s++) { asm volatile("" : "+v"(Bh1[s])); asm volatile("" : "+v"(Bl1[s])); }
     }
     const int ch = 32 * nh + m;
-    const float bias = P.bias ? P.bias[ch] : 0.f;
+    float bias = P.bias ? P.bias[ch] : 0.f;
+    asm volatile("" : "+v"(bias));                         // waited for here, not at its first use behind the window prefetch
     bool ovf = false;
     const int band_end = min(P.nbands, ((int)blockIdx.y + 1) * P.bands_per_wg);
     // Staging is split in two: `issue` sends every load of a band's input window (all of a lane's loads before anything else,
@@ -112,26 +116,22 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     constexpr int ITER = LAYER == 1 ? (NR * NC + 127) / 128 : (NR * NC * 16 + 127) / 128;
     uint32_t raw1[LAYER == 1 ? ITER : 1][2];
     u32x4 raw[LAYER == 1 ? 1 : ITER];
+    uint32_t flags = 0u;                                      // layer 1, per staged pixel: bit 0 inside the frame, bit 1 the batch's last pixel
     auto issue = [&](int band) {
         const int iy0 = S * (2 * band * R - PPAD) - PAD;
         if (LAYER == 1) {
+            flags = 0u;
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int pix = tid + 128 * it, yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
                 const bool in = pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
                 const uint8_t *src = P.img + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * P.Cimg;
-                // one unaligned dword (two for 6 channels) per pixel; the frame batch's very last pixel is read byte by byte
+                // one unaligned dword (two for 6 channels) per pixel, branch-free and untouched until commit() so that all of a
+                // lane's loads are in flight together; the batch's very last pixel reads the dwords that END at its last byte
                 const bool tail = img == (int)gridDim.z - 1 && y == P.Hin - 1 && x == P.Win - 1;
-                uint32_t w0 = 0u, w1 = 0u;
-                if (in && !tail) {
-                    __builtin_memcpy(&w0, src, 4);
-                    if (CPIX == 8) __builtin_memcpy(&w1, src + 4, 4);
-                } else if (in) {
-                    w0 = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16);
-                    if (CPIX == 8) { w0 |= (uint32_t)src[3] << 24; w1 = (uint32_t)src[4] | ((uint32_t)src[5] << 8); }
-                }
-                if (CPIX == 4) { raw1[it][0] = in ? (w0 & 0xffffffu) | 0x01000000u : 0u; raw1[it][1] = 0u; }     // byte 3: the mask
-                else { raw1[it][0] = in ? (w0 & 0xffffffu) | 0x01000000u : 0u; raw1[it][1] = in ? (w0 >> 24) | ((w1 & 0xffffu) << 8) : 0u; }
+                __builtin_memcpy(&raw1[it][0], src - (tail ? (CPIX == 4 ? 1 : 2) : 0), 4);
+                if (CPIX == 8) __builtin_memcpy(&raw1[it][1], src + (tail ? 2 : 4), 4);
+                flags |= (in ? 1u : 0u) << (2 * it) | (tail ? 2u : 0u) << (2 * it);
             }
         } else {
 #pragma unroll
@@ -150,7 +150,16 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
             for (int it = 0; it < ITER; it++) {
                 const int pix = tid + 128 * it;
                 if (pix < NR * NC) {
-                    const uint32_t a = raw1[it][0], b = raw1[it][1];
+                    const bool in = (flags >> (2 * it)) & 1u, tail = (flags >> (2 * it)) & 2u;
+                    uint32_t a, b = 0u;
+                    if (CPIX == 4) a = tail ? raw1[it][0] >> 8 : raw1[it][0];
+                    else {
+                        const uint32_t w0 = raw1[it][0], w1 = raw1[it][1];
+                        const uint32_t lo = tail ? (w0 >> 16) | (w1 << 16) : w0, hi = tail ? w1 >> 16 : w1;      // channels 0..3 | 4, 5
+                        a = lo; b = (lo >> 24) | ((hi & 0xffffu) << 8);
+                    }
+                    a = in ? (a & 0xffffffu) | 0x01000000u : 0u;                           // byte 3: the mask
+                    b = in ? b : 0u;
                     if (CPIX == 4) {
                         const half4v v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u), (_Float16)(float)(a >> 24)};
                         *reinterpret_cast<half4v *>(lds + pix * 8) = v;
@@ -234,25 +243,32 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
         // and leaves with 16-byte stores: one 128-byte line per pixel and plane.
         __syncthreads();
         constexpr int OPIX = R * 15, OPLANE = OPIX * 128;
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int p = p0 + j;
-            if (p >= P.Hp) break;
-            const bool rv0 = rr0 + 2 * j >= 0 && rr0 + 2 * j < P.Hc, rv1 = rr0 + 2 * j + 1 < P.Hc, rv2 = rr0 + 2 * j + 2 < P.Hc;
-            // columns arrive eight at a time (accumulator quad g of both wavefront halves); a pooled column is emitted as soon as
-            // its three inputs exist, so only nine column values are live at once
-            auto emit = [&](int jj, float val) {
-                if ((jj & 1) == h) {
-                    const float x = fmaxf(val * P.inv_scale + bias, 0.f);
-                    if (LAYER == 3) *reinterpret_cast<float *>(lds + ((j * 15 + jj) * 64 + ch) * 4) = x;
-                    else {
-                        ovf |= !(x < kF16Max);                // columns beyond the map hold -inf -> 0 after the ReLU: never flagged
-                        const _Float16 hi = (_Float16)x;
-                        *reinterpret_cast<_Float16 *>(lds + ((j * 15 + jj) * 64 + ch) * 2) = hi;
-                        *reinterpret_cast<_Float16 *>(lds + OPLANE + ((j * 15 + jj) * 64 + ch) * 2) = (_Float16)(x - (float)hi);
-                    }
+        // pooled value `val` of row j, column jj of the band -> scale / bias / ReLU -> the LDS band (hi | lo planes, or float32)
+        auto emit = [&](int j, int jj, float val, bool on) {
+            const float x = fmaxf(val * P.inv_scale + bias, 0.f);
+            if (on) {
+                if (LAYER == 3) *reinterpret_cast<float *>(lds + ((j * 15 + jj) * 64 + ch) * 4) = x;
+                else {
+                    ovf |= !(x < kF16Max);                    // columns beyond the map hold -inf -> 0 after the ReLU: never flagged
+                    const _Float16 hi = (_Float16)x;
+                    *reinterpret_cast<_Float16 *>(lds + ((j * 15 + jj) * 64 + ch) * 2) = hi;
+                    *reinterpret_cast<_Float16 *>(lds + OPLANE + ((j * 15 + jj) * 64 + ch) * 2) = (_Float16)(x - (float)hi);
                 }
-            };
+            }
+        };
+        const bool edge = c0 < 0 || c0 + 32 > P.Wc;           // the map's left / right edge runs through this tile
+        // Rows in pairs: lanes 0-31 finish pooled row 2jp, lanes 32-63 row 2jp + 1.  Columns arrive eight at a time
+        // (accumulator quad g of both wavefront halves): v_permlane32_swap(va, vb) hands every lane its own row's value of the
+        // low quad (first result) and of the high quad (second result); a pooled column is emitted as soon as its three
+        // inputs exist, so only nine column values are live at once and no lane idles in a divergent branch.
+#pragma unroll
+        for (int jp = 0; jp < R / 2; jp++) {
+            const int ta = 4 * jp, jmy = 2 * jp + h;
+            if (p0 + 2 * jp >= P.Hp) break;
+            bool rv[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) rv[k] = rr0 + ta + k >= 0 && rr0 + ta + k < P.Hc;
+            const bool on = p0 + jmy < P.Hp;
             float prev6 = kNegInf, prev7 = kNegInf;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -260,23 +276,53 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
 #pragma unroll
                 for (int i4 = 0; i4 < 4; i4++) {
                     const int i = 4 * g + i4;
-                    const float v = max3(rv0 ? acc[2 * j][i] : kNegInf, rv1 ? acc[2 * j + 1][i] : kNegInf, rv2 ? acc[2 * j + 2][i] : kNegInf);
-                    // v_permlane32_swap(v, v): first result = lanes 0-31's value in both halves (column 8g + i4), second = lanes 32-63's
-                    // (column 8g + 4 + i4): both halves of the wavefront see all 32 columns of their channel
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    const float mid = rv[2] ? acc[ta + 2][i] : kNegInf;
+                    const float va = max3(rv[0] ? acc[ta][i] : kNegInf, rv[1] ? acc[ta + 1][i] : kNegInf, mid);
+                    const float vb = max3(mid, rv[3] ? acc[ta + 3][i] : kNegInf, rv[4] ? acc[ta + 4][i] : kNegInf);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
                     c[i4] = __uint_as_float(sw[0]);
                     c[4 + i4] = __uint_as_float(sw[1]);
                 }
-                if (c0 < 0 || c0 + 32 > P.Wc) {               // the map's edge runs through this tile
+                if (edge) {
 #pragma unroll
                     for (int k = 0; k < 8; k++)
                         if (c0 + 8 * g + k < 0 || c0 + 8 * g + k >= P.Wc) c[k] = kNegInf;
                 }
-                if (g > 0) emit(4 * g - 1, max3(prev6, prev7, c[0]));
-                emit(4 * g, max3(c[0], c[1], c[2]));
-                emit(4 * g + 1, max3(c[2], c[3], c[4]));
-                emit(4 * g + 2, max3(c[4], c[5], c[6]));
+                if (g > 0) emit(jmy, 4 * g - 1, max3(prev6, prev7, c[0]), on);
+                emit(jmy, 4 * g, max3(c[0], c[1], c[2]), on);
+                emit(jmy, 4 * g + 1, max3(c[2], c[3], c[4]), on);
+                emit(jmy, 4 * g + 2, max3(c[4], c[5], c[6]), on);
                 prev6 = c[6]; prev7 = c[7];
+            }
+        }
+        // an odd last row: both halves hold all 32 columns (v_permlane32_swap(v, v)) and share the pooled columns between them
+        if (R & 1) {
+            constexpr int j = R - 1;
+            if (p0 + j < P.Hp) {
+                const bool rv0 = rr0 + 2 * j >= 0 && rr0 + 2 * j < P.Hc, rv1 = rr0 + 2 * j + 1 < P.Hc, rv2 = rr0 + 2 * j + 2 < P.Hc;
+                float prev6 = kNegInf, prev7 = kNegInf;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float c[8];
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; i4++) {
+                        const int i = 4 * g + i4;
+                        const float v = max3(rv0 ? acc[2 * j][i] : kNegInf, rv1 ? acc[2 * j + 1][i] : kNegInf, rv2 ? acc[2 * j + 2][i] : kNegInf);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        c[i4] = __uint_as_float(sw[0]);
+                        c[4 + i4] = __uint_as_float(sw[1]);
+                    }
+                    if (edge) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (c0 + 8 * g + k < 0 || c0 + 8 * g + k >= P.Wc) c[k] = kNegInf;
+                    }
+                    if (g > 0) emit(j, 4 * g - 1, max3(prev6, prev7, c[0]), ((4 * g - 1) & 1) == h);
+                    emit(j, 4 * g, max3(c[0], c[1], c[2]), ((4 * g) & 1) == h);
+                    emit(j, 4 * g + 1, max3(c[2], c[3], c[4]), ((4 * g + 1) & 1) == h);
+                    emit(j, 4 * g + 2, max3(c[4], c[5], c[6]), ((4 * g + 2) & 1) == h);
+                    prev6 = c[6]; prev7 = c[7];
+                }
             }
         }
         __syncthreads();
@@ -455,8 +501,11 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
         p.out_hi = a1h + a1 * base; p.out_lo = a1l + a1 * base; p.pack = g->d_pack; p.bias = nullptr; p.inv_scale = g->inv_scale[0];
         p.Hin = geo.H; p.Win = geo.W; p.Cimg = geo.C; p.Hc = geo.Hc[0]; p.Wc = geo.Wc[0]; p.Hp = geo.Hp[0]; p.Wp = geo.Wp[0];
         const int r1 = geo.C == 3 ? kR1 : kR1x6;
-        p.nbands = (p.Hp + r1 - 1) / r1; p.bands_per_wg = kBandsPerWg1;
-        dim3 grid1((p.Wp + 14) / 15, (p.nbands + kBandsPerWg1 - 1) / kBandsPerWg1, nn);
+        // layer 1 walks 4..8 bands per workgroup with its weights resident: the count that leaves the last workgroup least idle
+        p.nbands = (p.Hp + r1 - 1) / r1; p.bands_per_wg = 4;
+        for (int b = 5; b <= 8; b++)
+            if ((p.nbands + b - 1) / b * b - p.nbands < (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg * p.bands_per_wg - p.nbands) p.bands_per_wg = b;
+        dim3 grid1((p.Wp + 14) / 15, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn);
         if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1) + 7) * kNC1 * 8, kR1, false), stream, p);
         else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1x6) + 7) * kNC1 * 16, kR1x6, false), stream, p);
         // layer 2
