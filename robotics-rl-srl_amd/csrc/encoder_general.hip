@@ -114,13 +114,19 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
     // loads before this band's MFMAs and commits them after the pooled rows have been stored; layers 2-3 keep the registers
     // for the weight ring instead (loads return in order: a window prefetch would also stall that ring).
     constexpr int ITER = LAYER == 1 ? (NR * NC + 127) / 128 : (NR * NC * 16 + 127) / 128;
+    static_assert(LAYER == 1 ? 2 * ITER <= 32 : ITER <= 64, "one flag word per lane");
     uint32_t raw1[LAYER == 1 ? ITER : 1][2];
     u32x4 raw[LAYER == 1 ? 1 : ITER];
     uint32_t flags = 0u;                                      // layer 1, per staged pixel: bit 0 inside the frame, bit 1 the batch's last pixel
+    uint64_t inside = 0u;                                     // layers 2-3, per staged 16-byte cell: inside the map
     auto issue = [&](int band) {
         const int iy0 = S * (2 * band * R - PPAD) - PAD;
         if (LAYER == 1) {
             flags = 0u;
+        } else {
+            inside = 0u;
+        }
+        if (LAYER == 1) {
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int pix = tid + 128 * it, yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
@@ -138,9 +144,10 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
             for (int it = 0; it < ITER; it++) {
                 const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
                 const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
-                raw[it] = u32x4{0u, 0u, 0u, 0u};
-                if (pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win)
-                    raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + y) * P.Win + x) * 64 + c8 * 8);
+                // branch-free: cells outside the map read the frame's first pixel and are zeroed in commit()
+                const bool in = pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
+                raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * 64 + c8 * 8);
+                inside |= (uint64_t)(in ? 1u : 0u) << it;
             }
         }
     };
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
-                if (pix < NR * NC) *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = raw[it];
+                if (pix < NR * NC) *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = ((inside >> it) & 1u) ? raw[it] : u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
