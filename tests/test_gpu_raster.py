@@ -28,7 +28,8 @@ def assert_images_equal(gpu, ora):
     assert frac == 0.0, "differing pixels: {:.5f}, max diff {}".format(frac, diff.max())
 
 
-@pytest.mark.parametrize("hw,multi_view", [((64, 64), 0), ((224, 224), 0), ((64, 64), 1), ((48, 80), 0)])
+# (50, 38): width not a multiple of 4 (byte stores); (16, 1024): the widest frame, two-row bands; (300, 12): tall and narrow, two cameras
+@pytest.mark.parametrize("hw,multi_view", [((64, 64), 0), ((224, 224), 0), ((64, 64), 1), ((48, 80), 0), ((50, 38), 0), ((16, 1024), 0), ((300, 12), 1)])
 def test_kuka_images_match_oracle(hw, multi_view):
     n = 64
     cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
