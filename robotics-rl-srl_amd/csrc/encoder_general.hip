@@ -12,8 +12,9 @@
 //     registers, and the 3x3/2 max-pool runs on those raw accumulators — vertically element-wise across the row
 //     tiles, horizontally after one lane^32 exchange — so a convolution output never touches memory; only the pooled
 //     quarter is rescaled, biased, rectified, split and stored;
-//   * layer-1 weights (B fragments) stay in registers while a workgroup walks several bands, layers 2-3 stream theirs
-//     from L2 through a register ring;
+//   * layer-1 weights (B fragments) stay on the CU while a workgroup walks several bands — in LDS, shared by the four
+//     wavefronts of a two-segment workgroup (3-channel frames: two workgroups = eight wavefronts per CU), or in registers
+//     (6-channel frames: twice the weights); layers 2-3 stream theirs from L2 through a register ring;
 //   * the fully connected layer is its own small kernel over the [frame][Hp3][Wp3][64] float32 features.
 // The network sees the frame with H and W swapped (models.py:185-188); all layers are symmetric in the two spatial
 // dims, so the kernels work on the frame as rasterised and the packers swap the kernel axes / the FC's flatten order.
@@ -59,7 +60,7 @@ constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 
 constexpr int kNC1 = 70, kNC2 = 34, kNC3 = 65;          // staged input columns of a 32-column convolution tile
 constexpr int kNC3Narrow = 33;                           // layer 3 when its map has at most 16 columns (224x224 frames: 14)
 constexpr int kLdsSlack3 = 2 * 32 * PX;                  // the masked columns of a narrow tile still read (finite garbage) behind the window
-constexpr int kR1 = 4, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band (kR1x6: 6-channel frames hold twice the layer-1 weights)
+constexpr int kR1 = 2, kR1x6 = 2, kR2 = 2, kR3 = 1;      // pooled rows per band
 
 struct LayerParams {
     const uint8_t *img;              // layer 1: [n][H][W][C]
@@ -83,20 +84,33 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // LAYER 1: u8 frame -> conv7x7/2 p3 -> pool3/2 p1 (CPIX f16 per staged pixel: 4 = RGB + mask, 8 = 6 channels + mask + 0)
 // LAYER 2: planes -> conv3x3 p1 -> pool3/2      LAYER 3: planes -> conv3x3/2 p1 -> pool3/2 -> float32 features
 // NC: staged input columns (kNC1 / kNC2 / kNC3, or kNC3Narrow when layer 3's map is at most 16 columns wide)
-template <int LAYER, int CPIX, int R, int NC>
-__global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
+// LDSB (layer 1, 3 channels): four wavefronts per workgroup — two column segments x two channel halves — with the layer's
+// weights in LDS (56 KiB, shared) instead of 112 registers per lane: under 256 registers two workgroups = eight wavefronts
+// fit a CU, and one wavefront's MFMAs overlap another's staging / pooling.
+template <int LAYER, int CPIX, int R, int NC, bool LDSB = false>
+__global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(LayerParams P) {
     constexpr int T = 2 * R + 1;                              // convolution rows of a band
     constexpr int KS = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
     constexpr int S = LAYER == 2 ? 1 : 2, PAD = LAYER == 1 ? 3 : 1, KW = LAYER == 1 ? 7 : 3, PPAD = LAYER == 1 ? 1 : 0;
     constexpr int NR = S * (T - 1) + KW;                      // staged input rows
     constexpr int PIXB = LAYER == 1 ? CPIX * 2 : PX;          // staged bytes per pixel (and plane)
     constexpr int PLANE = NR * NC * PIXB;
-    const int tid = threadIdx.x, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5;
-    const int seg = blockIdx.x, img = blockIdx.z;
+    // tid: thread within its wavefront PAIR (the unit that owns a window); sp: the pair (column segment) inside an LDSB workgroup
+    const int tid = threadIdx.x & 127, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5, sp = threadIdx.x >> 7;
+    const int seg = LDSB ? 2 * blockIdx.x + sp : blockIdx.x, img = blockIdx.z;
+    constexpr int KSB = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
+    constexpr int WGT_BYTES = LDSB ? 2 * KSB * 2048 : 0;      // LDSB: [channel half][k-step][lane][8 hi | 8 lo] at the start of LDS
+    constexpr int T_ = 2 * R + 1, NR_ = (LAYER == 2 ? 1 : 2) * (T_ - 1) + (LAYER == 1 ? 7 : 3);
+    constexpr int WIN_BYTES = LDSB ? (NR_ * NC * CPIX * 2 > R * 15 * 256 ? NR_ * NC * CPIX * 2 : R * 15 * 256) : 0;
+    char *const win = lds + WGT_BYTES + sp * WIN_BYTES;        // this pair's window, later its pooled band
+    const int woff = WGT_BYTES + sp * WIN_BYTES;
     const int c0 = 30 * seg - PPAD, ix0 = S * c0 - PAD;
     const char *bp = P.pack + ((size_t)nh * KS * 64 + lane) * 32;
-    half8 Bh1[LAYER == 1 ? KS : 1], Bl1[LAYER == 1 ? KS : 1];
-    if (LAYER == 1) {
+    half8 Bh1[LAYER == 1 && !LDSB ? KS : 1], Bl1[LAYER == 1 && !LDSB ? KS : 1];
+    if constexpr (LDSB) {
+        for (int c = threadIdx.x; c < WGT_BYTES / 16; c += 256)
+            *reinterpret_cast<u32x4 *>(lds + c * 16) = *reinterpret_cast<const u32x4 *>(P.pack + (size_t)c * 16);
+    } else if constexpr (LAYER == 1) {
 #pragma unroll
         for (int s = 0; s < KS; s++) { Bh1[s] = glb16(bp + (size_t)s * 2048); Bl1[s] = glb16(bp + (size_t)s * 2048 + 16); }
         // opaque to the compiler from here on: otherwise it re-loads fragments inside the band loop instead of keeping them,
@@ -169,12 +183,12 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
                     b = in ? b : 0u;
                     if (CPIX == 4) {
                         const half4v v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u), (_Float16)(float)(a >> 24)};
-                        *reinterpret_cast<half4v *>(lds + pix * 8) = v;
+                        *reinterpret_cast<half4v *>(win + pix * 8) = v;
                     } else {
                         const half8 v = {(_Float16)(float)(a & 255u), (_Float16)(float)((a >> 8) & 255u), (_Float16)(float)((a >> 16) & 255u),
                                          (_Float16)(float)(b & 255u), (_Float16)(float)((b >> 8) & 255u), (_Float16)(float)((b >> 16) & 255u),
                                          (_Float16)(float)(a >> 24), (_Float16)0.f};
-                        *reinterpret_cast<half8 *>(lds + pix * 16) = v;
+                        *reinterpret_cast<half8 *>(win + pix * 16) = v;
                     }
                 }
             }
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int idx = tid + 128 * it, pix = idx >> 4, pl = (idx >> 3) & 1, c8 = idx & 7;
-                if (pix < NR * NC) *reinterpret_cast<u32x4 *>(lds + pl * PLANE + pix * PX + c8 * 16) = ((inside >> it) & 1u) ? raw[it] : u32x4{0u, 0u, 0u, 0u};
+                if (pix < NR * NC) *reinterpret_cast<u32x4 *>(win + pl * PLANE + pix * PX + c8 * 16) = ((inside >> it) & 1u) ? raw[it] : u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
-        const int abase = LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16;
+        const int abase = woff + (LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16);
         constexpr int ROWSTRIDE = S * NC * PIXB;
         if (LAYER == 1) {
             if (band + 1 < band_end) issue(band + 1);
@@ -210,10 +224,12 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
                 half8 a[T];                                   // consecutive MFMAs go to different accumulators
 #pragma unroll
                 for (int t = 0; t < T; t++) a[t] = lds16(abase + t * ROWSTRIDE + koff);
+                const half8 Bh = LDSB ? lds16(((nh * KS + s) * 64 + lane) * 32) : Bh1[LDSB ? 0 : s];
+                const half8 Bl = LDSB ? lds16(((nh * KS + s) * 64 + lane) * 32 + 16) : Bl1[LDSB ? 0 : s];
 #pragma unroll
-                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bh1[s], acc[t]);
+                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bh, acc[t]);
 #pragma unroll
-                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bl1[s], acc[t]);
+                for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bl, acc[t]);
             }
         } else {
             // one trip per kernel tap (4 k-steps of 16 channels); the B ring holds two trips, so its slots are static
@@ -254,12 +270,12 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
         auto emit = [&](int j, int jj, float val, bool on) {
             const float x = fmaxf(val * P.inv_scale + bias, 0.f);
             if (on) {
-                if (LAYER == 3) *reinterpret_cast<float *>(lds + ((j * 15 + jj) * 64 + ch) * 4) = x;
+                if (LAYER == 3) *reinterpret_cast<float *>(win + ((j * 15 + jj) * 64 + ch) * 4) = x;
                 else {
                     ovf |= !(x < kF16Max);                    // columns beyond the map hold -inf -> 0 after the ReLU: never flagged
                     const _Float16 hi = (_Float16)x;
-                    *reinterpret_cast<_Float16 *>(lds + ((j * 15 + jj) * 64 + ch) * 2) = hi;
-                    *reinterpret_cast<_Float16 *>(lds + OPLANE + ((j * 15 + jj) * 64 + ch) * 2) = (_Float16)(x - (float)hi);
+                    *reinterpret_cast<_Float16 *>(win + ((j * 15 + jj) * 64 + ch) * 2) = hi;
+                    *reinterpret_cast<_Float16 *>(win + OPLANE + ((j * 15 + jj) * 64 + ch) * 2) = (_Float16)(x - (float)hi);
                 }
             }
         };
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(128) void enc_layer_k(LayerParams P) {
             const int c = tid + 128 * it, pl = c / (OPIX * CPP), rem = c - pl * (OPIX * CPP), pix = rem / CPP, c8 = rem - pix * CPP;
             const int j = pix / 15, jj = pix - 15 * j, p = p0 + j, q = 15 * seg + jj;
             if (c < NCHUNK && p < P.Hp && q < P.Wp) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + c * 16);
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(win + c * 16);
                 const size_t o = (((size_t)img * P.Hp + p) * P.Wp + q) * 64;
                 if (LAYER == 3) *reinterpret_cast<u32x4 *>(P.out_f32 + o + c8 * 4) = v;
                 else *reinterpret_cast<u32x4 *>((pl ? P.out_lo : P.out_hi) + o + c8 * 8) = v;
@@ -465,6 +481,7 @@ int general_create(int device_id, const Geometry &geo, int state_dim, const floa
     GEN_CHECK(hipMemset(g->d_status, 0, sizeof(int)));
     constexpr int lds2 = 2 * (kR2 * 2 + 3) * kNC2 * PX, lds3 = 2 * (2 * (2 * kR3) + 3) * kNC3 * PX;
     GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<2, 4, kR2, kNC2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<1, 4, kR1, kNC1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3, kNC3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
     GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<3, 4, kR3, kNC3Narrow>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * (2 * (2 * kR3) + 3) * kNC3Narrow * PX + kLdsSlack3));
@@ -473,10 +490,10 @@ int general_create(int device_id, const Geometry &geo, int state_dim, const floa
     return SRLHIP_OK;
 }
 
-// bands a workgroup walks (its next window is fetched behind the current band's MFMAs): as many as leave >= 4096 workgroups
 // dynamic LDS of a layer kernel: the input window, or the pooled band that replaces it before the stores
 static int lds_bytes(int window, int r, bool f32) { const int band = r * 15 * (f32 ? 256 : 256); return window > band ? window : band; }
 
+// layers 2-3: bands a workgroup walks — as many as leave >= 4096 workgroups
 static int bands_per_wg(int nbands, int nsegs, int frames) {
     const long long wgs = (long long)nbands * nsegs * frames;
     const long long b = wgs / 4096;
@@ -511,10 +528,16 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
         // layer 1 walks 4..8 bands per workgroup with its weights resident: the count that leaves the last workgroup least idle
         p.nbands = (p.Hp + r1 - 1) / r1; p.bands_per_wg = 4;
         for (int b = 5; b <= 8; b++)
-            if ((p.nbands + b - 1) / b * b - p.nbands < (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg * p.bands_per_wg - p.nbands) p.bands_per_wg = b;
+            if ((p.nbands + b - 1) / b * b - p.nbands <= (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg * p.bands_per_wg - p.nbands) p.bands_per_wg = b;
         dim3 grid1((p.Wp + 14) / 15, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn);
-        if (geo.C == 3) hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1) + 7) * kNC1 * 8, kR1, false), stream, p);
-        else hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1x6) + 7) * kNC1 * 16, kR1x6, false), stream, p);
+        if (geo.C == 3) {
+            // 3 channels: weights in LDS, four wavefronts per workgroup (two column segments), bands of kR1 pooled rows
+            constexpr int win = (2 * (2 * kR1) + 7) * kNC1 * 8, band = kR1 * 15 * 256;
+            hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1, true>), dim3((grid1.x + 1) / 2, grid1.y, nn), dim3(256),
+                               2 * 14 * 2048 + 2 * (win > band ? win : band), stream, p);
+        } else {
+            hipLaunchKernelGGL((enc_layer_k<1, 8, kR1x6, kNC1>), grid1, dim3(128), lds_bytes((2 * (2 * kR1x6) + 7) * kNC1 * 16, kR1x6, false), stream, p);
+        }
         // layer 2
         p.img = nullptr; p.in_hi = a1h + a1 * base; p.in_lo = a1l + a1 * base; p.out_hi = a2h + a2 * base; p.out_lo = a2l + a2 * base;
         p.pack = pack2; p.bias = g->d_f32; p.inv_scale = g->inv_scale[1];
