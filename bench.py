@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "kuka", "mobile", "kuka_pixels"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--inner-steps", type=int, default=None)
+    ap.add_argument("--img-size", type=int, default=64,
+                    help="kuka_pixels: frame side (64 = BASELINE config 4, fused encoder; 224 = the reference's RENDER size, layered encoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     return ap.parse_args()
@@ -137,13 +139,14 @@ def bench_pixels(args, rank, local_rank, world, dev):
     from srlhip import _lib, sharding
     from srlhip.pixel_env import PixelStateVecEnv
     from state_representation.models import SRLNeuralNetwork
-    n, inner = args.envs_per_gpu, args.inner_steps or 256     # >= 256 VecEnv steps per bench step
+    n, S = args.envs_per_gpu, args.img_size
+    inner = args.inner_steps or (256 if S == 64 else 32)       # >= 256 VecEnv steps per bench step at the BASELINE size
     K = args.steps if args.steps is not None else 8
     W = args.warmup if args.warmup is not None else 1
     torch.manual_seed(0)
-    enc = SRLNeuralNetwork(3, cuda=True, img_shape=(64, 64), device=dev)
+    enc = SRLNeuralNetwork(3, cuda=True, img_shape=(S, S), device=dev)
     first, _ = sharding.shard_range(world * n, world, rank)
-    env = PixelStateVecEnv("KukaButtonGymEnv-v0", n, enc, seed=0, img_shape=(64, 64), device_id=local_rank, first_env_id=first)
+    env = PixelStateVecEnv("KukaButtonGymEnv-v0", n, enc, seed=0, img_shape=(S, S), device_id=local_rank, first_env_id=first)
     env.reset()
     gathered = torch.zeros((world * n,), dtype=torch.float32, device=dev) if world > 1 else None
     ret = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -187,23 +190,25 @@ def bench_pixels(args, rank, local_rank, world, dev):
         enc_ms = env.h.timing_end() / reps
     value = world * n * inner * K / dt
     step_ms = dt * 1e3 / (K * inner)
-    raster_gbs = n * 64 * 64 * 3 / (raster_ms * 1e-3) / 1e9
+    raster_gbs = n * S * S * 3 / (raster_ms * 1e-3) / 1e9
     raster_roof = {"bound": "hbm", "kernel": "raster_k", "achieved": raster_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": raster_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": raster_ms,
-                   "alg_bytes_per_env_step": 12288, "env_steps_per_launch": n,
-                   "note": "image write only (12 288 B per env); the rasteriser is ray-cast ALU bound at 64x64"}
+                   "alg_bytes_per_env_step": S * S * 3, "env_steps_per_launch": n,
+                   "note": "image write only ({} B per env); the rasteriser is ray-cast ALU bound".format(S * S * 3)}
+    # CustomCNN map sizes for an S x S frame: conv7/2 p3 -> pool3/2 p1 -> conv3 p1 -> pool3/2 -> conv3/2 p1 -> pool3/2
+    c1 = (S + 6 - 7) // 2 + 1; p1 = (c1 + 2 - 3) // 2 + 1; c2 = p1; p2 = (c2 - 3) // 2 + 1; c3 = (p2 + 2 - 3) // 2 + 1; p3 = (c3 - 3) // 2 + 1
     if hip_encoder:
         # dominant kernel of this path: the fused encoder (csrc/encoder.hip).  Algorithmic work = the float32 network's
         # 2*K*N*M flops per frame (conv1 147x64x1024, conv2 576x64x256, conv3 576x64x16, FC); it is executed on the
         # f16 matrix pipe with split operands (2-3 MFMAs per algorithmic one, K padded 147 -> 224 in layer 1), so the
         # peak it is priced against is the dense f16 MFMA peak.
-        flops_frame = 2.0 * (147 * 64 * 1024 + 576 * 64 * 256 + 576 * 64 * 16 + 64 * enc.state_dim)
+        flops_frame = 2.0 * (147 * 64 * c1 * c1 + 576 * 64 * c2 * c2 + 576 * 64 * c3 * c3 + 64 * p3 * p3 * enc.state_dim)
         mfma_frame = 4 * (8.5 * 56 + 432 + 54) * 32768.0          # executed: 4 waves x MFMAs x 32x32x16x2
         tf = flops_frame * n / (enc_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "encoder_fwd_k", "achieved": tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / F16_MFMA_PEAK_TFLOPS, "traffic": n * 64 * 64 * 3, "avg_launch_ms": enc_ms,
+        roofline = {"bound": "mfma", "kernel": "encoder_fwd_k" if S == 64 else "enc_layer_k x3 + enc_fc_k (csrc/encoder_general.hip)", "achieved": tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / F16_MFMA_PEAK_TFLOPS, "traffic": n * S * S * 3 if S == 64 else None, "avg_launch_ms": enc_ms,
                     "alg_flops_per_env_step": flops_frame, "env_steps_per_launch": n,
-                    "executed_mfma_tflops": mfma_frame * n / (enc_ms * 1e-3) / 1e12,
+                    "executed_mfma_tflops": mfma_frame * n / (enc_ms * 1e-3) / 1e12 if S == 64 else None,
                     "f32_mfma_peak_tflops": F32_MFMA_PEAK_TFLOPS,
                     "traffic_source": "algorithmic = measured: one 12 288-byte frame read per env-step (profiles/ PMC FETCH_SIZE x2), "
                                       "state_dim floats written; weights (352 KiB) stay in L2",
@@ -217,15 +222,15 @@ def bench_pixels(args, rank, local_rank, world, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 dynamics, f32 raster, f32-accurate split-f16 MFMA encoder" if hip_encoder else "f64 dynamics, f32 raster/encoder",
             "data": "synthetic",
-            "config": {"workload": "KukaButtonGymEnv-v0 raw_pixels 64x64, {} envs per GPU, tile rasteriser + srl_zoo CustomCNN "
-                                   "forward (random init) on the same device, random-agent actions".format(n),
+            "config": {"workload": "KukaButtonGymEnv-v0 raw_pixels {}x{}, {} envs per GPU, rasteriser + srl_zoo CustomCNN "
+                                   "forward (random init) on the same device, random-agent actions".format(S, S, n),
                        "envs_per_gpu": n, "inner_steps": inner, "parallelism": "env-shard x{}".format(world),
                        "encoder_backend": enc.backend, "ms_per_vecenv_step": step_ms,
                        "kernel_ms": {"raster_k": raster_ms, "encoder_fwd_k": enc_ms,
                                      "stepper_and_launch_gaps": step_ms - raster_ms - (enc_ms or 0.0)},
                        "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
             "roofline": roofline}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 64:
         try:
             line["cpu_baseline"] = pixel_cpu_baseline(enc, env)
             line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
