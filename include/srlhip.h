@@ -291,6 +291,10 @@ int srlhip_encoder_destroy(srlhip_encoder_handle e);
 const char *srlhip_encoder_last_error(srlhip_encoder_handle e);
 /* Host-only: the MFMA B-operand image create() uploads (normalisation folded into layer 1, every weight split
  * into f16 hi/lo), srlhip_encoder_pack_bytes() bytes.  Exposed so the packing can be checked without a GPU. */
+/* Host-only, layered path: layer 1's B-operand image for 3- or 6-channel frames — [channel half][k-step][lane][8 hi | 8 lo]
+ * f16 with k = (ky * 8 + kx) * cpix + c (cpix = 4 or 8 staged f16 per pixel: the channels, the validity mask, zero fill; kx = 7
+ * is a zero slot), 2 * (7 * 8 * cpix / 16) * 2048 bytes; *scale = the power-of-two pre-scale. */
+int srlhip_encoder_pack_first_layer(int32_t n_channels, const float *conv1_w, const float *conv1_b, void *out, size_t out_bytes, float *scale);
 size_t srlhip_encoder_pack_bytes(void);
 int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv3_w,
                         void *out, size_t out_bytes, float *scales3 /* power-of-two pre-scale of layers 1..3 */);

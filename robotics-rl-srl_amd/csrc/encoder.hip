@@ -587,6 +587,12 @@ int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float 
     return SRLHIP_OK;
 }
 
+int srlhip_encoder_pack_first_layer(int32_t n_channels, const float *conv1_w, const float *conv1_b, void *out, size_t out_bytes, float *scale) {
+    if (!scale) return SRLHIP_EINVAL;
+    *scale = srlenc::pack_layer1_general(conv1_w, conv1_b, n_channels, out, out_bytes);
+    return *scale > 0.f ? SRLHIP_OK : SRLHIP_EINVAL;
+}
+
 int srlhip_encoder_supported(int32_t img_h, int32_t img_w, int32_t n_channels) { return supported_shape(img_h, img_w, n_channels) ? 1 : 0; }
 
 int32_t srlhip_encoder_feature_count(int32_t img_h, int32_t img_w, int32_t n_channels) {

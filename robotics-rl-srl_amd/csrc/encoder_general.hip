@@ -412,6 +412,13 @@ float pack_layer1(const float *w, const float *b, int C, _Float16 *out) {
 
 }  // namespace
 
+float pack_layer1_general(const float *w, const float *b, int n_channels, void *out, size_t out_bytes) {
+    if (!w || !b || !out || (n_channels != 3 && n_channels != 6)) return 0.f;
+    const size_t need = (size_t)2 * (n_channels == 3 ? 14 : 28) * 2048;
+    if (out_bytes < need) return 0.f;
+    return pack_layer1(w, b, n_channels, static_cast<_Float16 *>(out));
+}
+
 struct General {
     int device_id, state_dim, F;
     Geometry g;

@@ -29,6 +29,9 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
 int *general_status(General *g);
 void general_destroy(General *g);
 
+// layer 1 of the layered path, host-only (srlhip_encoder_pack_first_layer); returns the pre-scale, 0 on bad arguments
+float pack_layer1_general(const float *w, const float *b, int n_channels, void *out, size_t out_bytes);
+
 // shared with encoder.hip's packers
 void split_f16(float v, _Float16 &hi, _Float16 &lo);
 float pick_scale(double wmax);

@@ -41,7 +41,7 @@ EXPORTS = [
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_feature_count", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
-    "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack",
+    "srlhip_encoder_destroy", "srlhip_encoder_last_error", "srlhip_encoder_pack_bytes", "srlhip_encoder_pack", "srlhip_encoder_pack_first_layer",
 ]
 
 
@@ -133,6 +133,7 @@ def load():
     lib.srlhip_encoder_pack_bytes.restype = ctypes.c_size_t
     lib.srlhip_encoder_pack_bytes.argtypes = []
     lib.srlhip_encoder_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.srlhip_encoder_pack_first_layer.argtypes = [i32, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float)]
     _lib = lib
     return lib
 
@@ -357,6 +358,21 @@ def _f32(a):
 
 def encoder_supported(img_h, img_w, n_channels):
     return bool(load().srlhip_encoder_supported(int(img_h), int(img_w), int(n_channels)))
+
+
+def encoder_pack_first_layer(conv1_w, conv1_b):
+    """Host-only: (layer 1's packed MFMA B-operand image of the layered encoder as float16 words, its power-of-two pre-scale)
+    for 3- or 6-channel frames — csrc/encoder_general.hip's packer, as srlhip_encoder_create uploads it."""
+    lib = load()
+    w1, b1 = _f32(conv1_w), _f32(conv1_b)
+    c = w1.shape[1]
+    assert w1.shape == (64, c, 7, 7) and c in (3, 6) and b1.shape == (64,)
+    out = np.zeros(2 * (14 if c == 3 else 28) * 1024, np.float16)
+    scale = ctypes.c_float()
+    rc = lib.srlhip_encoder_pack_first_layer(c, _ptr(w1), _ptr(b1), _ptr(out), ctypes.c_size_t(out.nbytes), ctypes.byref(scale))
+    if rc:
+        raise SrlHipError("srlhip_encoder_pack_first_layer failed ({})".format(rc))
+    return out, float(scale.value)
 
 
 def encoder_feature_count(img_h, img_w, n_channels):

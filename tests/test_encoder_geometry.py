@@ -25,3 +25,52 @@ def test_uncovered_shapes():
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             CustomCNN(2, 3, (40, 40))
+
+
+@pytest.mark.parametrize("ch", [3, 6])
+def test_layered_layer1_pack_is_the_normalised_convolution(ch):
+    """The layered path's layer-1 B image (srlhip_encoder_pack_first_layer, csrc/encoder_general.hip) decoded with numpy and applied
+    to a padded (channels, mask[, 0]) uint8 frame the way the kernel indexes it — k = (ky * 8 + kx) * cpix + c, stride 2,
+    3-pixel ring with mask 0 — equals the BatchNorm-folded conv1 of the torch model on the reference's preprocessing
+    (scale to [0, 1], ImageNet mean / std per 3-channel group, H/W swapped): checks the folding, the mask channel that keeps
+    zero padding exact in normalised space, the axis swap and the k order for 3- and 6-channel frames, without a GPU."""
+    import numpy as np
+    from state_representation.models import SRLNeuralNetwork, preprocess
+    torch.manual_seed(4 + ch)
+    H, W = 22, 30                                           # not square: an axis mix-up cannot hide
+    net = SRLNeuralNetwork(3, img_shape=(64, 64), n_channels=ch, backend="torch")
+    for m in net.model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    net = SRLNeuralNetwork(3, img_shape=(64, 64), n_channels=ch, state_dict=net.model.state_dict(), backend="torch")
+    (w1, b1) = net.folded_weights()[0]
+    pack, scale = _lib.encoder_pack_first_layer(w1, b1)
+    assert scale > 0 and np.log2(scale) == np.round(np.log2(scale))
+    cpix, ks = (4, 14) if ch == 3 else (8, 28)
+    frag = pack.astype(np.float64).reshape(2, ks, 64, 16)       # [channel half][k-step][lane][8 hi | 8 lo]
+    eff = (frag[..., :8] + frag[..., 8:]) / scale
+    wk = np.zeros((64, ks * 16))
+    for nh in range(2):
+        for lane in range(64):
+            for s in range(ks):
+                wk[32 * nh + (lane & 31), 16 * s + 8 * (lane >> 5):16 * s + 8 * (lane >> 5) + 8] = eff[nh, s, lane]
+    assert np.all(wk.reshape(64, 7, 8, cpix)[:, :, 7, :] == 0)                         # pixel slot 7 carries no weight
+    if ch == 6:
+        assert np.all(wk.reshape(64, 7, 8, cpix)[..., 7] == 0)                         # nor does the fill channel
+    rs = np.random.RandomState(ch)
+    img = rs.randint(0, 256, size=(H, W, ch)).astype(np.uint8)
+    img[:, :7] = 0                                          # a flat border: the padding-mask path matters there
+    inp = np.zeros((H + 6, W + 8, cpix))
+    inp[3:3 + H, 3:3 + W, :ch] = img
+    inp[3:3 + H, 3:3 + W, ch] = 1.0
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = np.zeros((Hc, Wc, 64))
+    for oy in range(Hc):
+        for ox in range(Wc):
+            out[oy, ox] = wk @ inp[2 * oy:2 * oy + 7, 2 * ox:2 * ox + 8, :].reshape(-1)
+    conv1 = [m for m in net.fused_conv if isinstance(m, torch.nn.Conv2d)][0]
+    with torch.no_grad():
+        ref = conv1(preprocess(torch.from_numpy(img[None]))).numpy()[0]                # [64][W'][H']: the network sees W and H swapped
+    ref = np.transpose(ref, (2, 1, 0))                                                 # -> [frame row][frame column][channel]
+    assert ref.shape == out.shape
+    assert np.abs(out - ref).max() < 2e-5 * np.abs(ref).max()
