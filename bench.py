@@ -47,7 +47,31 @@ def parse():
                     help="kuka_pixels: frame side (64 = BASELINE config 4, fused encoder; 224 = the reference's RENDER size, layered encoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short BASELINE config 2 (mobile) and config 4 (kuka_pixels) runs nested under \"secondary\"")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
+    SURVEY 8e / rl_baselines/utils.py:213-220 "one worker per env" becomes "one rank per shard") by re-executing this file
+    under torch.distributed.run on the loopback address; rank 0's single JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("SRLHIP_SINGLE_DEVICE"):
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible (set SRLHIP_SINGLE_DEVICE=1 SRLHIP_DIST_BACKEND=gloo "
+                             "for a dry run of the N > 1 path on one device)".format(n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def measured_traffic(kernel, env_steps_per_launch):
@@ -73,17 +97,6 @@ def measured_traffic(kernel, env_steps_per_launch):
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
 
 
-def kuka_available():
-    from srlhip import _lib
-    try:
-        cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
-        cfg.num_envs = 1
-        _lib.Handle(cfg).close()
-        return True
-    except _lib.SrlHipError:
-        return False
-
-
 def cpu_baseline(workload, n_envs, budget_s=12.0):
     """Oracle ('port') timed on this box's host cores, rank 0, N=1 only."""
     from oracle import clib
@@ -103,14 +116,15 @@ def cpu_baseline(workload, n_envs, budget_s=12.0):
     return kuka_clib.cpu_baseline(10.0)
 
 
-def pixel_cpu_baseline(enc, env, budget_s=4.0):
+def pixel_cpu_baseline(enc, env, budget_s=3.0, phys=None):
     """Config 4 on the host cores ('port'): the C oracles step the physics (OpenMP) and ray-cast 64x64 frames (OpenMP), the
     same CustomCNN runs in float32 under PyTorch on the CPU; each stage timed on a bounded sample and combined per
     env-step (the stages are sequential in the reference: render inside env.step, then the encoder)."""
     from oracle import kuka_clib, raster_clib
     from state_representation.models import SRLNeuralNetwork
     from srlhip import _lib
-    phys = kuka_clib.cpu_baseline(budget_s, subproc=False)                    # env-steps/s, physics only
+    if phys is None or not phys.get("value"):
+        phys = kuka_clib.cpu_baseline(budget_s, subproc=False)                # env-steps/s, physics only
     n = 1024
     h = env.h
     state = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_BUTTON_Q)[0][:, None],
@@ -133,7 +147,7 @@ def pixel_cpu_baseline(enc, env, budget_s=4.0):
                       "sequential stages".format(budget_s, phys["value"], raster_rate, n, enc_rate)}
 
 
-def bench_pixels(args, rank, local_rank, world, dev):
+def bench_pixels(args, rank, local_rank, world, dev, K=None, W=None, cpu=True, phys_baseline=None):
     """BASELINE config 4/5: KukaButtonGymEnv raw_pixels 64x64 -> tile rasteriser -> SRL encoder forward
     (fused HIP kernel, csrc/encoder.hip) on the same device.  One bench step = `inner` VecEnv steps of this rank's shard."""
     from srlhip import _lib, sharding
@@ -141,8 +155,8 @@ def bench_pixels(args, rank, local_rank, world, dev):
     from state_representation.models import SRLNeuralNetwork
     n, S = args.envs_per_gpu, args.img_size
     inner = args.inner_steps or (256 if S == 64 else 32)       # >= 256 VecEnv steps per bench step at the BASELINE size
-    K = args.steps if args.steps is not None else 8
-    W = args.warmup if args.warmup is not None else 1
+    K = K if K is not None else (args.steps if args.steps is not None else 8)
+    W = W if W is not None else (args.warmup if args.warmup is not None else 1)
     torch.manual_seed(0)
     enc = SRLNeuralNetwork(3, cuda=True, img_shape=(S, S), device=dev)
     first, _ = sharding.shard_range(world * n, world, rank)
@@ -230,45 +244,44 @@ def bench_pixels(args, rank, local_rank, world, dev):
                                      "stepper_and_launch_gaps": step_ms - raster_ms - (enc_ms or 0.0)},
                        "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
             "roofline": roofline}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 64:
+    if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline and S == 64:
         try:
-            line["cpu_baseline"] = pixel_cpu_baseline(enc, env)
+            line["cpu_baseline"] = pixel_cpu_baseline(enc, env, phys=phys_baseline)
             line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
         except Exception as exc:      # the checker must never sink the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(exc)}
     env.close()
-    if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    return line
 
 
-def main():
-    args = parse()
-    from srlhip import _lib
+def pmc_issue_util(kernel, avg_launch_s, clock_hz=2.4e9):
+    """VALU issue utilisation of `kernel`: instructions per wavefront (newest committed PMC summary, SQ_INSTS_VALU / SQ_WAVES)
+    x 4 cycles per wave64 float64 instruction / cycles of one launch (live duration x 2.4 GHz).  None without a summary."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kuka_pmc_SQ_WAVES.csv")))
+    if not files:
+        return None
+    c = {}
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"] == kernel:
+            c[row["counter"]] = float(row["avg_per_dispatch"])
+    if "SQ_INSTS_VALU" not in c or not c.get("SQ_WAVES"):
+        return None
+    per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    return {"valu_insts_per_wavefront": per_wave, "waves_per_dispatch": c["SQ_WAVES"],
+            "issue_util": per_wave * 4.0 / (avg_launch_s * clock_hz), "source": os.path.basename(files[-1])}
 
-    from srlhip import sharding
-    rank, local_rank, world = sharding.dist_env()
-    backend = os.environ.get("SRLHIP_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI on ROCm
-    if os.environ.get("SRLHIP_SINGLE_DEVICE"):                # dry run of the N>1 path on a 1-GPU box (gloo)
-        local_rank = 0
-    if world > 1:
-        import torch.distributed as dist
-        sharding.init_process_group(backend, local_rank)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    workload = args.workload
-    if workload == "auto":
-        workload = "kuka" if kuka_available() else "mobile"
-    if workload == "kuka_pixels":
-        return bench_pixels(args, rank, local_rank, world, dev)
+def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, cpu=True, backend="nccl"):
+    """BASELINE configs 2 / 3: the ground-truth stepper alone.  Returns the bench line (dict)."""
+    from srlhip import _lib, sharding
     n = args.envs_per_gpu
     # SURVEY §8(d): one bench step = a T = 2048-step rollout of every env (each Kuka env crosses >= 2 auto-resets, each
     # MobileRobot env 8), after a warm-up of >= 256 steps (one 2048-step rollout by default)
     inner = args.inner_steps or 2048
-    K = args.steps if args.steps is not None else 20
-    W = args.warmup if args.warmup is not None else (5 if workload == "mobile" else 1)
+    K = K if K is not None else (args.steps if args.steps is not None else 20)
+    W = W if W is not None else (args.warmup if args.warmup is not None else (5 if workload == "mobile" else 1))
 
     kind = _lib.ENV_MOBILE if workload == "mobile" else _lib.ENV_KUKA_BUTTON
     cfg = _lib.default_config(kind)
@@ -276,7 +289,7 @@ def main():
     cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, local_rank, first_env_id, 0
     cfg.rng_mode = _lib.RNG_PHILOX if args.rng == "philox" else _lib.RNG_MT19937
     cfg.auto_reset, cfg.io_device = 1, 1
-    h = _lib.Handle(cfg)
+    h = _lib.Handle(cfg)                  # raises SrlHipError when the library / GPU is missing: no fallback workload
     od = h.obs_dim
     obs0 = torch.zeros((n, od), dtype=torch.float32, device=dev)
     obs = torch.zeros((inner, n, od), dtype=torch.float32, device=dev)
@@ -334,24 +347,46 @@ def main():
     steps_per_launch = n * inner
     avg_launch_s = kernel_ms * 1e-3 / K
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
-    roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "mobile_rollout_ep_k" if workload == "mobile" else ("kuka_group_rollout_k" if h.kuka_kernel() == "group" else "kuka_rollout_k"),
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch}
+    kernel = "mobile_rollout_ep_k" if workload == "mobile" else ("kuka_group_rollout_k" if h.kuka_kernel() == "group" else "kuka_rollout_k")
+    traffic = None
     if n == 4096 and inner == 2048:       # geometry the PMC passes were taken at
-        roofline["traffic"] = measured_traffic(roofline["kernel"], steps_per_launch)
-        roofline["traffic_source"] = "profiles/ PMC summaries (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
-    if workload == "kuka":
+        traffic = measured_traffic(kernel, steps_per_launch)
+    if workload == "mobile":
+        roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
+                    "avg_launch_ms": avg_launch_s * 1e3,
+                    "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch,
+                    "note": "frac = SURVEY 8(d) contract formula (73 algorithmic bytes per env-step of a step-at-a-time stepper); "
+                            "the fused rollout keeps the state in VGPRs, so the bytes that physically cross HBM are `traffic` "
+                            "-> physical_hbm_frac"}
+        if traffic is not None:
+            roofline["physical_hbm_gbs"] = traffic / avg_launch_s / 1e9
+            roofline["physical_hbm_frac"] = roofline["physical_hbm_gbs"] / HBM_PEAK_GBS
+    else:
         from srlhip import kuka_model
-        flops = kuka_model.FLOPS_PER_ENV_STEP
+        group = h.kuka_kernel() == "group"
+        flops = kuka_model.FLOPS_PER_ENV_STEP_GROUP if group else kuka_model.FLOPS_PER_ENV_STEP
         tf = flops * steps_per_launch / avg_launch_s / 1e12
-        roofline.update({"note": "Kuka stepper is FP64-VALU issue / dependency-latency bound, not HBM bound "
-                                 "(SURVEY §7 hard parts); HBM fraction reported because the north star asks for it",
-                         "launch_geometry": "16 lanes per env, 1 wavefront per workgroup: {} wavefronts".format((n + 3) // 4)
-                         if h.kuka_kernel() == "group" else "1 lane per env: {} wavefronts".format((n + 63) // 64),
-                         "valu_fp64_tflops": tf, "valu_fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                         "valu_frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_env_step": flops})
+        # the Kuka stepper is bounded by the float64 vector pipe (issue rate / dependency latency of the 150 Gauss-Seidel
+        # sweeps), so `frac` is the FP64-VALU fraction; the HBM fraction the north star asks for rides along
+        roofline = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": kernel,
+                    "avg_launch_ms": avg_launch_s * 1e3, "flops_per_env_step": flops,
+                    "flops_source": "srlhip/kuka_model.py: algorithmic float64 operations of the row set the {} kernel "
+                                    "integrates (FMA = 2)".format("lane-group" if group else "lane-per-env"),
+                    "hbm_achieved_gbs": achieved_gbs, "hbm_frac": achieved_gbs / HBM_PEAK_GBS,
+                    "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch,
+                    "launch_geometry": "16 lanes per env, 1 wavefront per workgroup: {} wavefronts".format((n + 3) // 4)
+                    if group else "1 lane per env: {} wavefronts".format((n + 63) // 64),
+                    "note": "FP64-VALU issue / dependency-latency bound, not HBM bound (SURVEY 7 hard parts); hbm_frac is "
+                            "reported because the north star asks for it"}
+        if n == 4096 and inner == 2048:
+            util = pmc_issue_util(kernel, avg_launch_s)
+            if util:
+                roofline.update(util)
+    if traffic is not None:
+        roofline["traffic_source"] = ("profiles/ PMC summaries of this command (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per "
+                                      "launch; committed, not re-measured in this run")
     line = {
         "metric": "env steps/sec (whole node), {} {} envs/GPU".format(
             "KukaButtonGymEnv" if workload == "kuka" else "MobileRobotGymEnv", n),
@@ -365,21 +400,71 @@ def main():
             "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
         "roofline": roofline,
     }
+    if workload == "kuka":
+        line["config"]["kuka_model"] = h.kuka_model_name() if hasattr(h, "kuka_model_name") else "lumped-gripper"
     if world > 1:
         torch.cuda.synchronize()
         line["config"]["episode_returns_allgathered"] = {"count": int(gathered.numel()), "mean": float(gathered.mean().item()),
                                                          "collective": "all_gather_into_tensor float32[{}] per rank, once per rollout ({})".format(n, backend)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(workload, n)
             line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
         except Exception as exc:      # the checker must never sink the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(exc)}
     h.close()
+    return line
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    from srlhip import sharding
+    rank, local_rank, world = sharding.dist_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus {} but the launcher started {} rank(s)".format(args.gpus, world))
+    backend = os.environ.get("SRLHIP_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI on ROCm
+    if os.environ.get("SRLHIP_SINGLE_DEVICE"):                # dry run of the N>1 path on a 1-GPU box (gloo)
+        local_rank = 0
+    if world > 1:
+        import torch.distributed as dist
+        sharding.init_process_group(backend, local_rank)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # "auto" = the configuration the metric is quoted on (BASELINE config 3).  No fallback: a missing library / GPU raises.
+    workload = "kuka" if args.workload == "auto" else args.workload
+    if workload == "kuka_pixels":
+        line = bench_pixels(args, rank, local_rank, world, dev)
+    else:
+        line = bench_stepper(args, workload, rank, local_rank, world, dev, backend=backend)
+    line["config"]["ranks_seen"] = world
+    line["config"]["dist_backend"] = ("{} (RCCL over xGMI)".format(backend) if backend == "nccl" else backend) if world > 1 else None
+    if args.workload == "auto" and world == 1 and not args.no_secondary and args.envs_per_gpu == 4096:
+        # BASELINE configs 2 and 4, briefly, in the same driver-run line (their own value / roofline / cpu_baseline)
+        sec = {}
+        saved = args.inner_steps
+        for name in ("mobile", "kuka_pixels"):
+            try:
+                args.inner_steps = None
+                if name == "mobile":
+                    sub = bench_stepper(args, "mobile", rank, local_rank, world, dev, K=20, W=5)
+                else:
+                    sub = bench_pixels(args, rank, local_rank, world, dev, K=4, W=1, phys_baseline=line.get("cpu_baseline"))
+                sec[name] = {k: sub[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline",
+                                                  "cpu_baseline") if k in sub}
+                sec[name]["workload"] = sub["config"]["workload"]
+                if "kernel_ms" in sub["config"]:
+                    sec[name]["kernel_ms"] = sub["config"]["kernel_ms"]
+            except Exception as exc:          # a secondary leg must never sink the headline measurement
+                sec[name] = {"value": None, "error": repr(exc)}
+        args.inner_steps = saved
+        line["secondary"] = sec
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -187,7 +187,9 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
         cfg->obs_mode != SRLHIP_OBS_RAW_PIXELS) {
         g_create_error = "create: MobileRobot envs support ground_truth / raw_pixels only"; return SRLHIP_EINVAL;
     }
-    if (cfg->obs_mode == SRLHIP_OBS_RAW_PIXELS && (cfg->img_h < 8 || cfg->img_w < 8 || cfg->img_h > 1024 || cfg->img_w > 1024)) {
+    // every obs_mode: srlhip_render() also serves ground-truth handles (dataset_generator --img-size), and the rasteriser's
+    // LDS band holds one image row of at most 2048 pixels
+    if (cfg->img_h < 8 || cfg->img_w < 8 || cfg->img_h > 1024 || cfg->img_w > 1024) {
         g_create_error = "create: img_h / img_w must be in [8, 1024]"; return SRLHIP_EINVAL;
     }
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {

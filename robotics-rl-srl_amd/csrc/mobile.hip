@@ -457,6 +457,15 @@ int mobile_alloc(Handle *h) {
         (rc = h->dalloc(&s.tgt_y, n)) || (rc = h->dalloc(&s.tgt2_x, n)) || (rc = h->dalloc(&s.tgt2_y, n)) ||
         (rc = h->dalloc(&s.counter, n)) || (rc = h->dalloc(&s.cur_target, n)))
         return rc;
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) {
+        // snapshot planes of the episode-parallel rollout (launch_rollout_ep): allocated with the handle, never lazily — a
+        // first rollout may sit inside srlhip_graph_begin / srlhip_graph_end, where hipMalloc is illegal
+        MobileState &d = h->mobile_snap;
+        if ((rc = h->dalloc(&d.pos_x, n)) || (rc = h->dalloc(&d.pos_y, n)) || (rc = h->dalloc(&d.tgt_x, n)) || (rc = h->dalloc(&d.tgt_y, n)) ||
+            (rc = h->dalloc(&d.tgt2_x, n)) || (rc = h->dalloc(&d.tgt2_y, n)) || (rc = h->dalloc(&d.counter, n)) || (rc = h->dalloc(&d.cur_target, n)) ||
+            (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)))
+            return rc;
+    }
     return 0;
 }
 
@@ -506,15 +515,6 @@ void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actio
 
 int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
                       uint8_t *d_done, int advance_actr) {
-    if (!h->snap_ctr) {
-        MobileState &d = h->mobile_snap;
-        const size_t n = (size_t)h->n;
-        int rc;
-        if ((rc = h->dalloc(&d.pos_x, n)) || (rc = h->dalloc(&d.pos_y, n)) || (rc = h->dalloc(&d.tgt_x, n)) || (rc = h->dalloc(&d.tgt_y, n)) ||
-            (rc = h->dalloc(&d.tgt2_x, n)) || (rc = h->dalloc(&d.tgt2_y, n)) || (rc = h->dalloc(&d.counter, n)) || (rc = h->dalloc(&d.cur_target, n)) ||
-            (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)))
-            return rc;
-    }
     hipLaunchKernelGGL(mobile_snapshot_k, dim3((h->n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->n, h->mobile, h->rng, h->stats,
                        h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length);
     const MobileSnap snap{h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length};

@@ -22,7 +22,7 @@ from .vec_env import RNG_MODES, default_rng_mode
 class DeviceVecEnv(object):
     def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode=None):
         kw = dict(env_kwargs or {})
-        rng_mode = rng_mode or default_rng_mode()
+        rng_mode = rng_mode or default_rng_mode("device")
         cfg = _lib.default_config(ENV_CLASSES[env_id].ENV_KIND)
         cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = int(num_envs), device_id, first_env_id, int(seed)
         for name in ("is_discrete", "random_target", "shape_reward", "force_down", "action_repeat", "action_joints"):

@@ -17,6 +17,19 @@ import numpy as np
 
 FLOPS_PER_ENV_STEP = 3.1e4
 
+# The lane-group kernel (csrc/kuka_group.hpp) integrates the same model with a different row set: impulse-space rows scaled
+# to [0, 1] (a row update = 1 add + clamp + one FMA into each of the OTHER coupled rows), M by CRBA and M^-1 by Gauss-Jordan
+# instead of seven ABA sweeps.  Algorithmic float64 operations per env-step (the work of ONE env, not of its 16 lanes; FMA = 2,
+# clamp = 2), lumped-gripper model, free path (no contact row):
+#   150 sweeps x (7 arm rows x (1 + 2 + 6 x 2) + 3 button rows x (1 + 2 + 2 x 2))                    = 18 900
+#   Gauss-Jordan inverse of the 7x7 mass matrix: 7 pivots x 7 rows x 7 columns x 2                     =    690
+#   CRBA: composite inertias (suffix sums), Ic S per link, 28 entries x 6-term dot products            =    620
+#   RNEA in world coordinates: per-link force ~150 x 7, prefix / suffix sums 27 quantities x 7 x 4 x 2 =  2 560
+#   FK (7 frame compositions x 63) + 7 sincos (~40 each)                                               =    720
+#   IK: Jacobian, J^T J (28 x 12), 7x7 Gauss-Jordan solve, orientation error                           =    990
+#   row setup, 6 sphere-cylinder candidates, env logic, Philox                                         =    530
+FLOPS_PER_ENV_STEP_GROUP = 2.5e4
+
 MODEL_DOUBLES = 138
 MODEL_FIELDS = (("joint_xyz", (7, 3)), ("joint_rpy", (7, 3)), ("joint_lower", (7,)), ("joint_upper", (7,)), ("joint_damping", ()),
                 ("mass", (7,)), ("com", (7, 3)), ("inertia", (7, 3)), ("ee_point", (3,)), ("gripper_point", (3,)), ("sphere", (6, 4)),

@@ -22,15 +22,18 @@ from . import _lib
 from .envs import ENV_CLASSES, OBS_MODES
 from .gym_compat import Box, Discrete
 
-# "philox" (default): counter-based per-env streams, the fast path of both steppers.  "mt19937": the reference's own
-# streams — every env draws from a device-resident numpy RandomState seeded like gym.utils.seeding.np_random(seed + rank)
-# (srl_env.py:71-78), so noise / reset draws are the reference's bit for bit; its 624-word regenerations make the Kuka
-# step ~1.5x slower.  SRLHIP_RNG_MODE overrides the default for code that does not pass rng_mode (rl_baselines.train).
+# "mt19937": the reference's own streams — every env draws from a device-resident numpy RandomState seeded like
+# gym.utils.seeding.np_random(seed + rank) (srl_env.py:71-78, environments/utils.py:52), so noise / reset draws are the
+# reference's bit for bit on identical seeds.  It is the default of the reference-surface entry points (HipVecEnv, i.e.
+# rl_baselines.utils.createEnvs / rl_baselines.train / dataset_generator): a drop-in reproduces the reference's draws with
+# no environment variable.  "philox": counter-based per-env streams, the fast path of both steppers (the MT19937
+# generators' 624-word regenerations cost the Kuka stepper ~15 %); default of the device-resident stack (DeviceVecEnv,
+# PixelStateVecEnv, bench.py), which has no reference stream to reproduce.  SRLHIP_RNG_MODE overrides both defaults.
 RNG_MODES = {"mt19937": _lib.RNG_MT19937, "philox": _lib.RNG_PHILOX}
 
 
-def default_rng_mode():
-    mode = os.environ.get("SRLHIP_RNG_MODE", "philox")
+def default_rng_mode(surface="reference"):
+    mode = os.environ.get("SRLHIP_RNG_MODE", "mt19937" if surface == "reference" else "philox")
     if mode not in RNG_MODES:
         raise ValueError("SRLHIP_RNG_MODE must be one of {}".format(sorted(RNG_MODES)))
     return mode
@@ -133,7 +136,8 @@ class HipVecEnv(object):
     def reset(self):
         # stable_baselines.bench.Monitor(allow_early_resets=False) refuses a reset() in the middle of an episode
         # (environments/utils.py:54, rl_baselines/utils.py:194): here that is a reset while some env's running episode has steps
-        if self._was_reset and not self.allow_early_resets and (self._h.get_state(_lib.F_EP_LENGTH) > 0).any():
+        # (checked first so that allow_early_resets costs no device read)
+        if not self.allow_early_resets and self._was_reset and (self._h.get_state(_lib.F_EP_LENGTH) > 0).any():
             raise RuntimeError("Tried to reset an environment before done. If you want to allow early resets, "
                                "wrap your env with Monitor(env, path, allow_early_resets=True)")
         self._was_reset = True
@@ -180,10 +184,17 @@ class HipVecEnv(object):
                 infos[i] = {"episode": ep}
                 self._dirty_infos.append(int(i))
                 if self._monitors is not None:
-                    with open(self._monitors[i], "at") as f:
-                        f.write("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
+                    # one unbuffered O_APPEND write per finished episode (no text-IO object per row: at 4096 envs in
+                    # lock-step MobileRobot episodes every env finishes on the same step)
+                    fd = os.open(self._monitors[i], os.O_WRONLY | os.O_APPEND)
+                    try:
+                        os.write(fd, "{},{},{}\n".format(ep["r"], ep["l"], ep["t"]).encode())
+                    finally:
+                        os.close(fd)
             self._n_finished = fin
-        return obs, rew, dones, infos
+        # a fresh list per step like SubprocVecEnv's tuple (callers may keep the previous step's infos); the per-env dicts of
+        # steps without an episode end are shared empties, replaced (never mutated) when an episode record appears
+        return obs, rew, dones, list(infos)
 
     def step(self, actions):
         self.step_async(actions)

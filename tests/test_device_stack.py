@@ -97,7 +97,7 @@ def test_device_env_steps_like_the_host_vec_env():
     n, T = 64, 300
     kw = {"srl_model": "ground_truth"}
     dev = DeviceVecEnv("MobileRobotGymEnv-v0", n, seed=5, env_kwargs=kw)
-    host = HipVecEnv("MobileRobotGymEnv-v0", n, seed=5, env_kwargs=kw)
+    host = HipVecEnv("MobileRobotGymEnv-v0", n, seed=5, env_kwargs=kw, rng_mode="philox")     # DeviceVecEnv's default stream family
     od, oh = dev.reset(), host.reset()
     assert od.is_cuda and np.array_equal(od.cpu().numpy(), oh)
     acts = np.random.RandomState(1).randint(-1, 4, size=(T, n)).astype(np.int32)
@@ -151,7 +151,7 @@ def test_device_normalize_statistics_round_trip(tmp_path):
     twin.load_running_average(str(tmp_path))
     assert torch.equal(twin.obs_rms.mean, env.obs_rms.mean) and torch.equal(twin.obs_rms.var, env.obs_rms.var)
     assert twin.obs_rms.count == env.obs_rms.count
-    host = VecNormalize(HipVecEnv("MobileRobotGymEnv-v0", 32, seed=1, env_kwargs=kw), norm_reward=False, training=False)
+    host = VecNormalize(HipVecEnv("MobileRobotGymEnv-v0", 32, seed=1, env_kwargs=kw, rng_mode="philox"), norm_reward=False, training=False)
     host.load_running_average(str(tmp_path))
     assert np.array_equal(host.obs_rms.mean, env.obs_rms.mean.cpu().numpy())
     o_dev, o_host = twin.reset(), host.reset()

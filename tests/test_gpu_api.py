@@ -92,6 +92,9 @@ def test_vec_env_semantics_none_actions_and_infos():
     for t in range(251):
         obs, rew, done, infos = env.step([None if i % 2 else 1 for i in range(8)])
     assert done.all() and all(info["episode"]["l"] == 251 for info in infos)
+    kept = infos
+    _, _, _, infos2 = env.step([1] * 8)                # SubprocVecEnv hands out a fresh tuple per step: a kept list is not mutated
+    assert infos2 is not kept and all("episode" in info for info in kept) and all(info == {} for info in infos2)
     ora = mobile_oracle.MobileOracleEnv(mobile_oracle.MOBILE)
     ora.seed(3 + 0)
     for _ in range(252):
