@@ -74,29 +74,63 @@ def set_model(model):
     clib.lib().raster_oracle_set_model(_p(t))
 
 
-def aba(q, qd, tau, gz=-10.0):
-    q, qd, tau = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, tau))
-    out = np.zeros(7)
-    _lib().kuka_oracle_aba(_p(q), _p(qd), _p(tau), gz, _p(out))
+def set_full(flag):
+    """False: gripper lumped rigidly into link_7 (7 DoF, the rounds 1-2 model).  True: the full kuka_with_gripper2 tree — 12 DoF
+    with every gripper joint motor of kuka.py:172-187, 16 collision spheres on links 5..11, one friction row per contact."""
+    clib.lib().kuka_oracle_set_full(int(bool(flag)))
+
+
+def is_full():
+    return bool(clib.lib().kuka_oracle_get_full())
+
+
+def ndof():
+    return 12 if is_full() else 7
+
+
+def get_tree_model():
+    """flat float64 image of the tree model table in use (layout of srlhip_kuka_tree_model)"""
+    t = np.zeros(clib.lib().kuka_oracle_tree_doubles())
+    clib.lib().kuka_oracle_get_tree_model(_p(t))
+    return t
+
+
+def set_tree_model(table):
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    assert t.shape == (clib.lib().kuka_oracle_tree_doubles(),)
+    clib.lib().kuka_oracle_set_tree_model(_p(t))
+
+
+def _pad(x):
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    out = np.zeros(12)
+    out[:len(x)] = x
     return out
 
 
+def aba(q, qd, tau, gz=-10.0):
+    q, qd, tau = (_pad(x) for x in (q, qd, tau))
+    out = np.zeros(12)
+    _lib().kuka_oracle_aba(_p(q), _p(qd), _p(tau), gz, _p(out))
+    return out[:ndof()]
+
+
 def minv(q):
-    q = np.ascontiguousarray(q, dtype=np.float64)
-    out = np.zeros((7, 7))
+    q, n = _pad(q), ndof()
+    out = np.zeros((n, n))
     _lib().kuka_oracle_minv(_p(q), _p(out))
     return out
 
 
 def fk(q):
-    q = np.ascontiguousarray(q, dtype=np.float64)
-    R, p = np.zeros((7, 3, 3)), np.zeros((7, 3))
+    q, n = _pad(q), ndof()
+    R, p = np.zeros((n, 3, 3)), np.zeros((n, 3))
     _lib().kuka_oracle_fk(_p(q), _p(R), _p(p))
     return R, p
 
 
 def ik(q, target):
-    q = np.ascontiguousarray(q, dtype=np.float64)
+    q = _pad(q)
     target = np.ascontiguousarray(target, dtype=np.float64)
     out = np.zeros(7)
     _lib().kuka_oracle_ik(_p(q), _p(target), _p(out))
@@ -111,7 +145,8 @@ def settled(random_target=False, action_joints=False):
 
 def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, random_target=False, force_down=True,
             shape_reward=False, action_repeat=1, max_distance=0.8, obs_mode=0, rng_mode=RNG_MT19937, auto_reset=True,
-            trace=True):
+            trace=True, aux=False):
+    """aux: also return q_all [T][n][12] (every DoF of the model in use) and rows [T][n][2] (contact-normal / friction rows)."""
     seeds = np.ascontiguousarray(seeds, dtype=np.int64)
     n = len(seeds)
     od = {0: 3, 1: 14, 2: 17}[obs_mode]
@@ -121,8 +156,12 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
         "obs0": np.zeros((n, od), np.float32), "obs": np.zeros((T, n, od), np.float32),
         "reward": np.zeros((T, n), np.float32), "reward64": np.zeros((T, n)), "done": np.zeros((T, n), np.uint8),
         "q": np.zeros((T, n, 7)) if trace else None, "gripper": np.zeros((T, n, 3)) if trace else None,
-        "final_state": np.zeros((n, 30)), "ep_stats": np.zeros((n, 3)),
+        "final_state": np.zeros((n, 40)), "ep_stats": np.zeros((n, 3)),
     }
+    if aux:
+        out["q_all"] = np.zeros((T, n, 12))
+        out["rows"] = np.zeros((T, n, 2), np.int32)
+        clib.lib().kuka_oracle_set_aux_trace(_p(out["q_all"]), _p(out["rows"]))
     act_out = None
     if actions is None:
         act_out = np.zeros((T, n), np.int32) if is_discrete else np.zeros((T, n, adim), np.float32)
@@ -135,6 +174,8 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
         _p(seeds), _p(keys), _p(lens), _p(actions), _p(out["obs0"]), _p(out["obs"]), _p(out["reward"]),
         _p(out["reward64"]), _p(out["done"]), _p(act_out), _p(out["q"]), _p(out["gripper"]),
         _p(out["final_state"]), _p(out["ep_stats"]))
+    if aux:
+        clib.lib().kuka_oracle_set_aux_trace(None, None)
     assert rc == 0
     out["actions"] = actions if actions is not None else act_out
     return out

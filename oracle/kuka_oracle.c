@@ -29,10 +29,11 @@
 #include <string.h>
 
 #include "kuka_model.h"
+#include "kuka_tree_model.h"
 #include "np_random.h"
 #include "philox.h"
 
-#define N KM_NDOF
+#define N KM_NDOF              /* arm joints (the IK / command surface) */
 #define MAX_ROWS 40
 #define MAX_GENERIC_ROWS 6   /* arm-limit + contact rows kept per step, first come first kept (solver row budget) */
 
@@ -86,44 +87,68 @@ static void crf_vec(const vec6 v, const vec6 f, vec6 o) {
     cross(v, f + 3, c); o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
 }
 
+/* ------------------------------------------------------------------ the model in use */
+/* One table for both variants (kuka_tree_model.h): g_m.nd = 7 (gripper lumped into link_7, rounds 1-2) or 12 (full gripper tree).
+ * kuka_oracle_set_full() switches; tests are single-threaded callers (OpenMP workers only read the table). */
+static tree_model g_m;
+static int g_m_ready = 0, g_full = 0;
+static void model_refresh(void) { if (g_full) tm_build_full(&g_m); else tm_build_lumped(&g_m); g_m_ready = 1; }
+static const tree_model *model(void) { if (!g_m_ready) model_refresh(); return &g_m; }
+#define ND (model()->nd)
+
 /* ------------------------------------------------------------------ kinematics */
+/* rotation about a unit axis (Rodrigues) */
+static void axis_rotation(const double a[3], double q, mat3 R) {
+    double c = cos(q), s = sin(q), v = 1.0 - c;
+    R[0][0] = c + a[0] * a[0] * v;        R[0][1] = a[0] * a[1] * v - a[2] * s; R[0][2] = a[0] * a[2] * v + a[1] * s;
+    R[1][0] = a[1] * a[0] * v + a[2] * s; R[1][1] = c + a[1] * a[1] * v;        R[1][2] = a[1] * a[2] * v - a[0] * s;
+    R[2][0] = a[2] * a[0] * v - a[1] * s; R[2][1] = a[2] * a[1] * v + a[0] * s; R[2][2] = c + a[2] * a[2] * v;
+}
 /* rotation of link i's frame in its parent's frame, and the motion transform X_i (parent -> link) */
 static void joint_rotation(int i, double q, mat3 Rpc) {
-    mat3 Rfix, Rz; double rz[3] = {0, 0, q};
-    rpy_to_mat(KM_JOINT_RPY[i], Rfix); rpy_to_mat(rz, Rz);
-    mat3_mul(Rfix, Rz, Rpc);
+    mat3 Rq; const tree_model *m = model();
+    if (m->axis[i][2] == 1.0) { double rz[3] = {0, 0, 0}; rz[2] = q; rpy_to_mat(rz, Rq); }     /* the arm's joints: exactly the rounds 1-2 arithmetic */
+    else axis_rotation(m->axis[i], q, Rq);
+    mat3_mul(m->Rj[i], Rq, Rpc);
 }
 static void motion_transform(int i, double q, mat6 X) {
     mat3 Rpc, E, rx, Erx; int a, b;
     joint_rotation(i, q, Rpc);
     for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) E[a][b] = Rpc[b][a];
-    skew(KM_JOINT_XYZ[i], rx);
+    skew(model()->xyz[i], rx);
     mat3_mul(E, rx, Erx);
     memset(X, 0, sizeof(mat6));
     for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) { X[a][b] = E[a][b]; X[a + 3][b + 3] = E[a][b]; X[a + 3][b] = -Erx[a][b]; }
 }
-/* world pose of every link frame */
-static void forward_kinematics(const double q[N], mat3 R[N], double p[N][3]) {
-    mat3 Rw = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, Rpc, Rn; double pw[3], t[3]; int i;
-    memcpy(pw, KM_BASE_POS, sizeof pw);
-    for (i = 0; i < N; i++) {
-        mat3_vec(Rw, KM_JOINT_XYZ[i], t);
-        pw[0] += t[0]; pw[1] += t[1]; pw[2] += t[2];
+/* world pose of every link frame (parents come before children) */
+static void forward_kinematics(const double q[TN], mat3 R[TN], double p[TN][3]) {
+    const tree_model *m = model(); int i;
+    for (i = 0; i < m->nd; i++) {
+        mat3 Rpc; double t[3]; const int par = m->parent[i];
         joint_rotation(i, q[i], Rpc);
-        mat3_mul(Rw, Rpc, Rn);
-        memcpy(Rw, Rn, sizeof(mat3));
-        memcpy(R[i], Rw, sizeof(mat3)); memcpy(p[i], pw, sizeof pw);
+        if (par < 0) {
+            static const mat3 I3 = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+            mat3_vec(I3, m->xyz[i], t);
+            p[i][0] = KM_BASE_POS[0] + t[0]; p[i][1] = KM_BASE_POS[1] + t[1]; p[i][2] = KM_BASE_POS[2] + t[2];
+            mat3_mul(I3, Rpc, R[i]);
+        } else {
+            mat3_vec(R[par], m->xyz[i], t);
+            p[i][0] = p[par][0] + t[0]; p[i][1] = p[par][1] + t[1]; p[i][2] = p[par][2] + t[2];
+            mat3_mul(R[par], Rpc, R[i]);
+        }
     }
 }
-static void link7_point(const mat3 R[N], const double p[N][3], const double local[3], double world[3]) {
-    double t[3]; mat3_vec(R[N - 1], local, t);
-    world[0] = p[N - 1][0] + t[0]; world[1] = p[N - 1][1] + t[1]; world[2] = p[N - 1][2] + t[2];
+static void link_point(const mat3 R[TN], const double p[TN][3], int link, const double local[3], double world[3]) {
+    double t[3]; mat3_vec(R[link], local, t);
+    world[0] = p[link][0] + t[0]; world[1] = p[link][1] + t[1]; world[2] = p[link][2] + t[2];
 }
-/* geometric Jacobian of a world point rigidly attached to link_7 */
-static void point_jacobian(const mat3 R[N], const double p[N][3], const double pt[3], double Jv[3][N], double Jw[3][N]) {
-    int j;
-    for (j = 0; j < N; j++) {
-        double z[3] = {R[j][0][2], R[j][1][2], R[j][2][2]}, d[3] = {pt[0] - p[j][0], pt[1] - p[j][1], pt[2] - p[j][2]}, c[3];
+/* geometric Jacobian of a world point rigidly attached to `link`: columns of the link's ancestors (and itself), zero elsewhere */
+static void point_jacobian(const mat3 R[TN], const double p[TN][3], int link, const double pt[3], double Jv[3][TN], double Jw[3][TN]) {
+    const tree_model *m = model(); int j, k;
+    for (j = 0; j < TN; j++) for (k = 0; k < 3; k++) { Jv[k][j] = 0.0; Jw[k][j] = 0.0; }
+    for (j = link; j >= 0; j = m->parent[j]) {
+        double z[3], d[3] = {pt[0] - p[j][0], pt[1] - p[j][1], pt[2] - p[j][2]}, c[3];
+        mat3_vec(R[j], m->axis[j], z);
         cross(z, d, c);
         Jv[0][j] = c[0]; Jv[1][j] = c[1]; Jv[2][j] = c[2];
         Jw[0][j] = z[0]; Jw[1][j] = z[1]; Jw[2][j] = z[2];
@@ -132,66 +157,70 @@ static void point_jacobian(const mat3 R[N], const double p[N][3], const double p
 
 /* ------------------------------------------------------------------ Featherstone ABA */
 static void spatial_inertia(int i, mat6 I) {
-    const double *c = KM_COM[i]; double m = KM_MASS[i]; mat3 cx; int a, b;
+    const tree_model *tm = model();
+    const double *c = tm->com[i], *in = tm->inertia[i]; double m = tm->mass[i]; mat3 cx; int a, b;
+    const double Ic[3][3] = {{in[0], in[1], in[2]}, {in[1], in[3], in[4]}, {in[2], in[4], in[5]}};
     double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
     skew(c, cx);
     memset(I, 0, sizeof(mat6));
     for (a = 0; a < 3; a++) for (b = 0; b < 3; b++) {
-        I[a][b] = (a == b ? KM_INERTIA[i][a] + m * cc : 0.0) - m * c[a] * c[b];
+        I[a][b] = (a == b ? Ic[a][a] + m * cc : Ic[a][b]) - m * c[a] * c[b];
         I[a][b + 3] = m * cx[a][b];
         I[a + 3][b] = -m * cx[a][b];
         I[a + 3][b + 3] = a == b ? m : 0.0;
     }
 }
-/* qdd = FD(q, qd, tau) with gravity (0, 0, gz) — RBDA Table 7.1, joint axis S = e_z(angular) */
-static void aba(const double q[N], const double qd[N], const double tau[N], double gz, double qdd[N]) {
-    static const vec6 S = {0, 0, 1, 0, 0, 0};
-    mat6 X[N], IA[N]; vec6 v[N], c[N], pA[N], U[N], a[N]; double d[N], u[N];
+/* qdd = FD(q, qd, tau) with gravity (0, 0, gz) — RBDA Table 7.1 on a kinematic tree, revolute joints S = [axis ; 0] */
+static void aba(const double q[TN], const double qd[TN], const double tau[TN], double gz, double qdd[TN]) {
+    const tree_model *m = model(); const int n = m->nd;
+    mat6 X[TN], IA[TN]; vec6 S[TN], v[TN], c[TN], pA[TN], U[TN], a[TN]; double d[TN], u[TN];
     int i, r, s, k;
-    for (i = 0; i < N; i++) {
-        vec6 vJ, Iv;
+    for (i = 0; i < n; i++) {
+        vec6 vJ, Iv; const int par = m->parent[i];
         motion_transform(i, q[i], X[i]);
-        for (k = 0; k < 6; k++) vJ[k] = S[k] * qd[i];
-        if (i == 0) memcpy(v[i], vJ, sizeof(vec6));
-        else { mat6_vec(X[i], v[i - 1], v[i]); for (k = 0; k < 6; k++) v[i][k] += vJ[k]; }
+        for (k = 0; k < 3; k++) { S[i][k] = m->axis[i][k]; S[i][3 + k] = 0.0; }
+        for (k = 0; k < 6; k++) vJ[k] = S[i][k] * qd[i];
+        if (par < 0) memcpy(v[i], vJ, sizeof(vec6));
+        else { mat6_vec(X[i], v[par], v[i]); for (k = 0; k < 6; k++) v[i][k] += vJ[k]; }
         crm_vec(v[i], vJ, c[i]);
         spatial_inertia(i, IA[i]);
         mat6_vec(IA[i], v[i], Iv);
         crf_vec(v[i], Iv, pA[i]);
     }
-    for (i = N - 1; i >= 0; i--) {
-        mat6_vec(IA[i], S, U[i]);
-        d[i] = U[i][2];
-        u[i] = tau[i] - pA[i][2];
-        if (i > 0) {
+    for (i = n - 1; i >= 0; i--) {
+        const int par = m->parent[i];
+        mat6_vec(IA[i], S[i], U[i]);
+        d[i] = 0.0; u[i] = tau[i];
+        for (k = 0; k < 6; k++) { d[i] += S[i][k] * U[i][k]; u[i] -= S[i][k] * pA[i][k]; }
+        if (par >= 0) {
             mat6 Ia, T; vec6 pa, Iac, t;
             for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) Ia[r][s] = IA[i][r][s] - U[i][r] * U[i][s] / d[i];
             mat6_vec(Ia, c[i], Iac);
             for (k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + U[i][k] * u[i] / d[i];
             /* IA[parent] += X^T Ia X ;  pA[parent] += X^T pa */
             for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += Ia[r][k] * X[i][k][s]; T[r][s] = acc; }
-            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += X[i][k][r] * T[k][s]; IA[i - 1][r][s] += acc; }
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += X[i][k][r] * T[k][s]; IA[par][r][s] += acc; }
             mat6T_vec(X[i], pa, t);
-            for (k = 0; k < 6; k++) pA[i - 1][k] += t[k];
+            for (k = 0; k < 6; k++) pA[par][k] += t[k];
         }
     }
-    for (i = 0; i < N; i++) {
-        vec6 ap; double Ua = 0;
-        if (i == 0) { vec6 a0 = {0, 0, 0, 0, 0, 0}; a0[5] = -gz; mat6_vec(X[i], a0, ap); }
-        else mat6_vec(X[i], a[i - 1], ap);
+    for (i = 0; i < n; i++) {
+        vec6 ap; double Ua = 0; const int par = m->parent[i];
+        if (par < 0) { vec6 a0 = {0, 0, 0, 0, 0, 0}; a0[5] = -gz; mat6_vec(X[i], a0, ap); }
+        else mat6_vec(X[i], a[par], ap);
         for (k = 0; k < 6; k++) ap[k] += c[i][k];
         for (k = 0; k < 6; k++) Ua += U[i][k] * ap[k];
         qdd[i] = (u[i] - Ua) / d[i];
-        for (k = 0; k < 6; k++) a[i][k] = ap[k] + S[k] * qdd[i];
+        for (k = 0; k < 6; k++) a[i][k] = ap[k] + S[i][k] * qdd[i];
     }
 }
 /* W = M(q)^-1, column j = response to a unit torque on joint j (no velocity, no gravity) */
-static void mass_matrix_inverse(const double q[N], double W[N][N]) {
-    double zero[N] = {0}, e[N], col[N]; int i, j;
-    for (j = 0; j < N; j++) {
+static void mass_matrix_inverse(const double q[TN], double W[TN][TN]) {
+    double zero[TN] = {0}, e[TN], col[TN]; int i, j; const int n = ND;
+    for (j = 0; j < n; j++) {
         memset(e, 0, sizeof e); e[j] = 1.0;
         aba(q, zero, e, 0.0, col);
-        for (i = 0; i < N; i++) W[i][j] = col[i];
+        for (i = 0; i < n; i++) W[i][j] = col[i];
     }
 }
 
@@ -226,16 +255,19 @@ static int solve_linear(double A[N][N], double b[N], double x[N]) {   /* Gaussia
     for (i = N - 1; i >= 0; i--) { double s = b[i]; for (j = i + 1; j < N; j++) s -= A[i][j] * x[j]; x[i] = s / A[i][i]; }
     return 0;
 }
-static void inverse_kinematics(const double q[N], const mat3 R[N], const double p[N][3], const double target[3], double damping, double q_des[N]) {
+/* The end effector (link 6) does not move with the gripper joints: their Jacobian columns are zero, so the 12-DoF damped
+ * least-squares step of the full model leaves them at exactly 0 and the 7x7 arm block is the whole solve. */
+static void inverse_kinematics(const double q[TN], const mat3 R[TN], const double p[TN][3], const double target[3], double damping, double q_des[N]) {
     /* target orientation p.getQuaternionFromEuler([0, -pi, 0]) = (0, sin(-pi/2), 0, cos(-pi/2)) */
     const double tq[4] = {0.0, sin(-KM_PI / 2), 0.0, cos(-KM_PI / 2)};
-    double ee[3], Jv[3][N], Jw[3][N], J[6][N], dS[6], cq[4], cinv[4], dq[4], A[N][N], b[N], dth[N];
+    const tree_model *m = model();
+    double ee[3], Jv[3][TN], Jw[3][TN], J[6][N], dS[6], cq[4], cinv[4], dq[4], A[N][N], b[N], dth[N];
     double angle, s2, axis[3], maxabs = 0; int i, j, k;
-    link7_point(R, p, KM_EE_POINT, ee);
-    point_jacobian(R, p, ee, Jv, Jw);
+    link_point(R, p, m->ee_link, m->ee_point, ee);
+    point_jacobian(R, p, m->ee_link, ee, Jv, Jw);
     for (j = 0; j < N; j++) for (k = 0; k < 3; k++) { J[k][j] = Jv[k][j]; J[k + 3][j] = Jw[k][j]; }
     for (k = 0; k < 3; k++) dS[k] = target[k] - ee[k];
-    quat_from_mat(R[N - 1], cq);
+    quat_from_mat(R[m->ee_link], cq);
     cinv[0] = -cq[0]; cinv[1] = -cq[1]; cinv[2] = -cq[2]; cinv[3] = cq[3];
     quat_mul(tq, cinv, dq);                                   /* deltaQ = endQ * startQ^-1 */
     /* btQuaternion::getAngle()/getAxis(): angle = 2 acos(w), axis = xyz / sqrt(1 - w^2).  Evaluated in the
@@ -261,7 +293,7 @@ static void inverse_kinematics(const double q[N], const mat3 R[N], const double 
 
 /* ------------------------------------------------------------------ env state */
 typedef struct {
-    double q[N], qd[N];            /* arm joints                                   */
+    double q[TN], qd[TN];          /* joints: arm 0..6; full model: 7 gripper_to_arm, 8/9 left finger / tip, 10/11 right finger / tip */
     double ee_target[3];           /* Kuka.end_effector_pos                        */
     double bq, bqd;                /* button glider position / velocity            */
     int button_motor_on;           /* 0: pybullet default velocity motor, 1: step2's position target */
@@ -300,30 +332,44 @@ static double sphere_cylinder(const double c[3], double rad, const double xy[2],
 }
 
 /* ------------------------------------------------------------------ one physics step */
-typedef struct { double J[N]; double Jb; double WJ[N]; double WJb; double Dinv, rhs, lo, hi, applied; int bsel; } row_t;
+/* A constraint row.  fric_of >= 0: friction row of contact-normal row `fric_of` (its bounds are +-mu * that row's applied impulse,
+ * re-evaluated every sweep: btMultiBodyConstraintSolver::solveSingleIteration). */
+typedef struct { double J[TN]; double Jb; double WJ[TN]; double WJb; double Dinv, rhs, lo, hi, applied, mu; int bsel, fric_of; } row_t;
 
-static void add_row(row_t *rows, int *nrows, const double J[N], double Jb, const double W[N][N], double Wb,
-                    double desired_vel, double pos_error_vel, const double qd[N], double bqd, double lo, double hi, int bsel) {
-    row_t *r = &rows[(*nrows)++]; int i, j; double D = 0, rel = 0;
+static row_t *add_row(row_t *rows, int *nrows, const double J[TN], double Jb, const double W[TN][TN], double Wb,
+                      double desired_vel, double pos_error_vel, const double qd[TN], double bqd, double lo, double hi, int bsel) {
+    row_t *r = &rows[(*nrows)++]; int i, j; double D = 0, rel = 0; const int n = ND;
     r->bsel = bsel;                       /* which button's glider the scalar Jb acts on (bqd = that glider's velocity) */
-    for (i = 0; i < N; i++) { double s = 0; for (j = 0; j < N; j++) s += W[i][j] * J[j]; r->WJ[i] = s; r->J[i] = J[i]; }
+    r->fric_of = -1; r->mu = 0.0;
+    for (i = 0; i < n; i++) { double s = 0; for (j = 0; j < n; j++) s += W[i][j] * J[j]; r->WJ[i] = s; r->J[i] = J[i]; }
     r->Jb = Jb; r->WJb = Wb * Jb;
-    for (i = 0; i < N; i++) { D += J[i] * r->WJ[i]; rel += J[i] * qd[i]; }
+    for (i = 0; i < n; i++) { D += J[i] * r->WJ[i]; rel += J[i] * qd[i]; }
     D += Jb * r->WJb; rel += Jb * bqd;
-    r->Dinv = 1.0 / D;
+    r->Dinv = D > 0.0 ? 1.0 / D : 0.0;       /* D = 0: a row no DoF can act on (inert) */
     r->rhs = (desired_vel - rel) * r->Dinv + pos_error_vel * r->Dinv;   /* velocityImpulse + penetrationImpulse */
     r->lo = lo; r->hi = hi; r->applied = 0.0;
+    return r;
 }
+/* btPlaneSpace1(n, p, q): the friction direction Bullet's multibody solver uses (first tangent) */
+static void plane_space1(const double n[3], double p[3]) {
+    if (fabs(n[2]) > 0.7071067811865475244008443621048490) { double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a); p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k; }
+    else { double a = n[0] * n[0] + n[1] * n[1], k = 1.0 / sqrt(a); p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0; }
+}
+
+/* optional per-step probe of the last physics step (tests / the model-gap report): contact rows created, friction rows */
+static int g_probe_rows[4];
+#pragma omp threadprivate(g_probe_rows)
 
 /* Kuka.applyAction (kuka.py:118-187) followed by p.stepSimulation() */
 static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets) {
-    mat3 R[N]; double p[N][3], q_des[N], tau[N], qdd[N], W[N][N], dv[N], dvb[2] = {0.0, 0.0};
+    const tree_model *m = model(); const int n = m->nd;
+    mat3 R[TN]; double p[TN][3], q_arm[N], q_des[TN], tau[TN] = {0}, qdd[TN], W[TN][TN], dv[TN], dvb[2] = {0.0, 0.0};
     const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
     const int nb = cfg->two ? 2 : 1;
     row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s, b;
     /* Kuka(small_constraints=False) for random_target and always for Kuka2Button (kuka_2button_gym_env.py:78) */
     const double (*box)[3] = KM_EE_BOX[(cfg->random_target || cfg->two) ? 0 : 1];
-    double zeroJ[N] = {0};
+    double zeroJ[TN] = {0};
     double *bq[2], *bqd[2]; const double *bxy[2];
     bq[0] = &e->bq; bqd[0] = &e->bqd; bxy[0] = e->button_xy; bq[1] = &e->b2q; bqd[1] = &e->b2qd; bxy[1] = e->button2_xy;
 
@@ -337,27 +383,32 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         /* kuka.py:147-156.  Kuka2Button sets use_null_space, but its ll/ul/jr/rp lists have 7 entries for a 12-DoF body:
          * pybullet drops null-space arguments whose length differs from the DoF count, and the call then carries no
          * jointDamping either -> plain DLS with the server's default damping 0.5 (KM_IK_DAMPING_DEFAULT). */
-        inverse_kinematics(e->q, R, p, e->ee_target, cfg->two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_des);
-    } else memcpy(q_des, joint_targets, sizeof q_des);           /* kuka.py:160-163 */
+        inverse_kinematics(e->q, R, p, e->ee_target, cfg->two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_arm);
+    } else memcpy(q_arm, joint_targets, sizeof q_arm);           /* kuka.py:160-163 */
     if (g_trace_ee) { memcpy(g_trace_ee + 3 * g_trace_n, e->ee_target, 3 * sizeof(double)); if (joint_targets) memcpy(g_trace_jt + N * g_trace_n, joint_targets, N * sizeof(double)); g_trace_n++; }
+    for (i = 0; i < N; i++) q_des[i] = q_arm[i];
+    /* gripper motor targets, kuka.py:177-187: joint 7 -> end_effector_angle (da = 0 in every env of the reference), fingers 8 / 11 ->
+     * -/+ finger_angle (motor_commands[4] = 0.0: closed), tips 10 / 13 -> 0 */
+    for (i = N; i < n; i++) { const int ji = m->joint_index[i]; q_des[i] = ji == 8 ? -motor[4] : ji == 11 ? motor[4] : 0.0; }
 
     /* -- collision detection at the current poses (start of stepSimulation) -- */
     e->contact_button = 0; e->contact_table = 0; e->contact_body[0] = 0; e->contact_body[1] = 0;
+    g_probe_rows[0] = g_probe_rows[1] = g_probe_rows[2] = g_probe_rows[3] = 0;
     {
         /* -- unconstrained velocities: ABA with joint damping torques and gravity -- */
-        for (i = 0; i < N; i++) tau[i] = -KM_JOINT_DAMPING * e->qd[i];
+        for (i = 0; i < n; i++) tau[i] = -m->damping[i] * e->qd[i];
         aba(e->q, e->qd, tau, KM_GRAVITY_Z, qdd);
-        for (i = 0; i < N; i++) e->qd[i] += dt * qdd[i];
+        for (i = 0; i < n; i++) e->qd[i] += dt * qdd[i];
         for (b = 0; b < nb; b++) *bqd[b] += dt * KM_GRAVITY_Z;
         mass_matrix_inverse(e->q, W);
 
-        /* -- constraint rows: motors, then joint limits, then contacts -- */
-        for (i = 0; i < N; i++) {                                   /* arm motors, kuka.py:167-170 */
-            double J[N] = {0}, target = KM_ARM_KP * (q_des[i] - e->q[i]) / dt;
-            if (target > KM_ARM_MAX_VEL) target = KM_ARM_MAX_VEL;
-            if (target < -KM_ARM_MAX_VEL) target = -KM_ARM_MAX_VEL;
+        /* -- constraint rows: motors, then joint limits, then contacts (normals, then their friction rows) -- */
+        for (i = 0; i < n; i++) {                                   /* joint motors, kuka.py:167-187 (btMultiBodyJointMotor) */
+            double J[TN] = {0}, target = m->kp[i] * (q_des[i] - e->q[i]) / dt;
+            if (target > m->max_vel[i]) target = m->max_vel[i];
+            if (target < -m->max_vel[i]) target = -m->max_vel[i];
             J[i] = 1.0;
-            add_row(rows, &nrows, J, 0.0, W, Wb, target, 0.0, e->qd, 0.0, -KM_ARM_MAX_FORCE * dt, KM_ARM_MAX_FORCE * dt, 0);
+            add_row(rows, &nrows, J, 0.0, W, Wb, target, 0.0, e->qd, 0.0, -m->max_force[i] * dt, m->max_force[i] * dt, 0);
         }
         for (b = 0; b < nb; b++) {
             if (e->button_motor_on)                                /* kuka_button_gym_env.py:347, kuka_2button_gym_env.py:118-119 */
@@ -369,60 +420,88 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         /* joint limits (btMultiBodyJointLimitConstraint): unilateral rows.  A row whose stop is still `pen`
          * away only forbids approaching faster than pen/dt, so it is created when pen/dt is within reach
          * (arm: KM_LIMIT_ACTIVATION_VEL, far above the 0.35 rad/s motor clamp; button: always). */
-        for (i = 0; i < N; i++) {
-            double J[N] = {0}, pen_lo = e->q[i] - KM_JOINT_LOWER[i], pen_hi = KM_JOINT_UPPER[i] - e->q[i];
-            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
-            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < MAX_GENERIC_ROWS) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+        for (i = 0; i < n; i++) {
+            double J[TN] = {0}, pen_lo = e->q[i] - m->lower[i], pen_hi = m->upper[i] - e->q[i];
+            if (m->lower[i] > m->upper[i]) continue;                /* no limit on this joint */
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
         }
         for (b = 0; b < nb; b++) {
           double pen_lo = *bq[b] - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - *bq[b];
           add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b);
           add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b); }
-        for (s = 0; s < KM_NSPHERE; s++) {                          /* gripper spheres vs cap, base (of every button), table */
-            double c[3], n[3], dist, pt[3], Jv[3][N], Jw[3][N], J[N]; int shape;
-            link7_point(R, p, KM_SPHERE[s], c);
-            if (c[2] - KM_SPHERE[s][3] - KM_TABLE_TOP_Z < KM_CONTACT_THRESHOLD) e->contact_table = 1;
-            for (shape = 0; shape < 2 * nb; shape++) {
-                double pos_err_vel, allow, cap_z0; const int is_cap = (shape & 1) == 0;
-                b = shape >> 1;
-                cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + *bq[b];
-                if (is_cap) dist = sphere_cylinder(c, KM_SPHERE[s][3], bxy[b], KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, n);
-                else dist = sphere_cylinder(c, KM_SPHERE[s][3], bxy[b], KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, n);
-                if (!(dist < KM_CONTACT_THRESHOLD)) continue;
-                if (is_cap && b == 0) e->contact_button = 1;
-                e->contact_body[b] = 1;
-                if (ngeneric >= MAX_GENERIC_ROWS) continue;
-                ngeneric++;
-                for (k = 0; k < 3; k++) pt[k] = c[k] - KM_SPHERE[s][3] * n[k];      /* contact point on the sphere */
-                point_jacobian(R, p, pt, Jv, Jw);
-                for (i = 0; i < N; i++) J[i] = n[0] * Jv[0][i] + n[1] * Jv[1][i] + n[2] * Jv[2][i];
-                /* separated: allow approach up to dist/dt; penetrating: push out with erp */
-                allow = dist > 0 ? -dist / dt : 0.0;
-                pos_err_vel = dist > 0 ? 0.0 : -dist * KM_ERP / dt;
-                add_row(rows, &nrows, J, is_cap ? -n[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, *bqd[b], 0.0, 1e10, b);
+        {
+            /* contact normals first; the friction rows are appended after ALL normals (Bullet solves normals, then frictions) */
+            struct { double J[TN], Jb, mu; int normal_row, bsel; } fr[MAX_ROWS]; int nfr = 0;
+            for (s = 0; s < m->nsphere; s++) {                      /* spheres on the arm / gripper links vs cap, base (of every button), table */
+                double c[3], nrm[3], dist, pt[3], Jv[3][TN], Jw[3][TN], J[TN]; int shape; const int link = m->sphere_link[s];
+                link_point(R, p, link, m->sphere[s], c);
+                if (c[2] - m->sphere[s][3] - m->table_top_z < KM_CONTACT_THRESHOLD) e->contact_table = 1;
+                for (shape = 0; shape < 2 * nb; shape++) {
+                    double pos_err_vel, allow, cap_z0; const int is_cap = (shape & 1) == 0;
+                    b = shape >> 1;
+                    cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + *bq[b];
+                    if (is_cap) dist = sphere_cylinder(c, m->sphere[s][3], bxy[b], KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, nrm);
+                    else dist = sphere_cylinder(c, m->sphere[s][3], bxy[b], KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, nrm);
+                    if (!(dist < KM_CONTACT_THRESHOLD)) continue;
+                    if (is_cap && b == 0) e->contact_button = 1;
+                    e->contact_body[b] = 1;
+                    if (ngeneric >= m->max_generic_rows) continue;
+                    ngeneric++;
+                    for (k = 0; k < 3; k++) pt[k] = c[k] - m->sphere[s][3] * nrm[k];      /* contact point on the sphere */
+                    point_jacobian(R, p, link, pt, Jv, Jw);
+                    for (i = 0; i < n; i++) J[i] = nrm[0] * Jv[0][i] + nrm[1] * Jv[1][i] + nrm[2] * Jv[2][i];
+                    /* separated: allow approach up to dist/dt; penetrating: push out with erp */
+                    allow = dist > 0 ? -dist / dt : 0.0;
+                    pos_err_vel = dist > 0 ? 0.0 : -dist * KM_ERP / dt;
+                    add_row(rows, &nrows, J, is_cap ? -nrm[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, *bqd[b], 0.0, 1e10, b);
+                    g_probe_rows[0]++;
+                    if (m->friction && m->sphere_mu[s] > 0.0) {
+                        double tdir[3];
+                        plane_space1(nrm, tdir);
+                        for (i = 0; i < n; i++) fr[nfr].J[i] = tdir[0] * Jv[0][i] + tdir[1] * Jv[1][i] + tdir[2] * Jv[2][i];
+                        /* the cap slides along z only: the z component of the tangent (side contacts) acts on the glider, like -n_z does for the normal */
+                        fr[nfr].Jb = is_cap ? -tdir[2] : 0.0;
+                        fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
+                        nfr++;
+                    }
+                }
+            }
+            for (k = 0; k < nfr; k++) {
+                /* friction: drive the tangential relative velocity to 0 within +-mu * (normal impulse); no positional term */
+                row_t *r = add_row(rows, &nrows, fr[k].J, fr[k].Jb, W, Wb, 0.0, 0.0, e->qd, *bqd[fr[k].bsel], 0.0, 0.0, fr[k].bsel);
+                r->fric_of = fr[k].normal_row; r->mu = fr[k].mu;
+                g_probe_rows[1]++;
             }
         }
     }
-    /* -- projected Gauss-Seidel, numSolverIterations = 150 -- */
+    /* -- projected Gauss-Seidel, numSolverIterations = 150: non-contact rows, contact normals, then friction rows whose bounds
+     *    follow the current normal impulse (skipped while that impulse is not positive) -- */
     memset(dv, 0, sizeof dv);
     for (it = 0; it < KM_SOLVER_ITERS; it++) {
         for (k = 0; k < nrows; k++) {
-            row_t *r = &rows[k]; double jdv = r->Jb * dvb[r->bsel], delta, sum;
-            for (i = 0; i < N; i++) jdv += r->J[i] * dv[i];
+            row_t *r = &rows[k]; double jdv, delta, sum;
+            if (r->fric_of >= 0) {
+                const double tot = rows[r->fric_of].applied;
+                if (!(tot > 0.0)) continue;
+                r->lo = -r->mu * tot; r->hi = r->mu * tot;
+            }
+            jdv = r->Jb * dvb[r->bsel];
+            for (i = 0; i < n; i++) jdv += r->J[i] * dv[i];
             delta = r->rhs - jdv * r->Dinv;
             sum = r->applied + delta;
             if (sum < r->lo) { delta = r->lo - r->applied; r->applied = r->lo; }
             else if (sum > r->hi) { delta = r->hi - r->applied; r->applied = r->hi; }
             else r->applied = sum;
-            for (i = 0; i < N; i++) dv[i] += delta * r->WJ[i];
+            for (i = 0; i < n; i++) dv[i] += delta * r->WJ[i];
             dvb[r->bsel] += delta * r->WJb;
         }
     }
     /* -- semi-implicit Euler -- */
-    for (i = 0; i < N; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
+    for (i = 0; i < n; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
     for (b = 0; b < nb; b++) { *bqd[b] += dvb[b]; *bq[b] += dt * *bqd[b]; }
     forward_kinematics(e->q, R, p);
-    link7_point(R, p, KM_GRIPPER_POINT, e->gripper);
+    link_point(R, p, m->grip_link, m->grip_point, e->gripper);
 }
 
 /* ------------------------------------------------------------------ env wrapper */
@@ -492,7 +571,7 @@ static uint32_t k_randint2(krng *r) { return r->mode == 2 ? np_rng_randint(&r->m
 static void settle(kenv *e, const kcfg *cfg) {
     const double zero[5] = {0, 0, 0, 0, 0}; int i;
     memset(e, 0, sizeof *e);
-    for (i = 0; i < N; i++) e->q[i] = KM_JOINT_POSITIONS[i];
+    for (i = 0; i < ND; i++) e->q[i] = KM_JOINT_POSITIONS[model()->joint_index[i]];       /* kuka.py:64-66: all 14 joints are reset */
     memcpy(e->ee_target, KM_EE_INIT, sizeof e->ee_target);
     e->button_xy[0] = KM_BUTTON_X; e->button_xy[1] = KM_BUTTON_Y; e->button_z = KM_BUTTON_BASE_Z;
     for (i = 0; i < KM_N_SETTLE_STEPS; i++) physics_step(e, cfg, zero, cfg->action_joints ? KM_JOINT_POSITIONS : NULL);
@@ -589,6 +668,17 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
 }
 
 static int g_moving = 0, g_two = 0, g_rand = 0;
+/* optional extra traces of the next kuka_oracle_rollout call: q_all [T][n][12] (every DoF), rows [T][n][2] (contact-normal and
+ * friction rows created by the step's last stepSimulation); NULL = off */
+static double *g_aux_q = NULL; static int32_t *g_aux_rows = NULL;
+void kuka_oracle_set_aux_trace(double *q_all, int32_t *rows) { g_aux_q = q_all; g_aux_rows = rows; }
+/* 0: gripper lumped rigidly into link_7 (7 DoF, rounds 1-2), 1: the full 12-DoF gripper tree with per-link contact spheres and
+ * friction rows (kuka_tree_model.h) */
+void kuka_oracle_set_full(int full) { g_full = full != 0; model_refresh(); }
+int kuka_oracle_get_full(void) { return g_full; }
+int kuka_oracle_tree_doubles(void) { return TM_DOUBLES; }
+void kuka_oracle_get_tree_model(double *t) { tm_to_table(model(), t); }
+void kuka_oracle_set_tree_model(const double *t) { tm_from_table(&g_m, t); g_m_ready = 1; g_full = g_m.nd > 7; }
 /* selects KukaMovingButtonGymEnv (1) / Kuka2ButtonGymEnv (2) / KukaRandButtonGymEnv (3) semantics for the following calls
  * (tests are single-threaded callers) */
 void kuka_oracle_set_moving(int moving) { g_moving = moving; g_two = 0; g_rand = 0; }
@@ -599,8 +689,8 @@ void kuka_oracle_set_variant(int variant) { g_moving = variant == 1; g_two = var
  * actions: int32 [T][n] (discrete, -1 = None) or float [T][n][adim]; NULL -> Philox random agent.
  * Outputs (any may be NULL): obs0 [n][od], obs [T][n][od] f32, rew f32 / rew64 f64 [T][n], done u8 [T][n],
  * q_trace [T][n][7] f64 (joint positions after each step, BEFORE a possible auto-reset),
- * grip_trace [T][n][3], final [n][30]: q7 qd7 ee3 bq bqd counter n_contacts n_outside terminated button_z,
- * b2q b2qd goal_id n_contacts2 b2x b2y (second button: Kuka2Button only). */
+ * grip_trace [T][n][3], final [n][40]: q7 qd7 ee3 bq bqd counter n_contacts n_outside terminated button_z,
+ * b2q b2qd goal_id n_contacts2 b2x b2y (second button: Kuka2Button only), then q[7..11] qd[7..11] (gripper DoFs, full model). */
 int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, int force_down, int shape_reward,
                         int action_repeat, double max_distance, int obs_mode, int rng_mode, int auto_reset, int n, int T,
                         const int64_t *seeds, const uint32_t *mt_keys, const int32_t *mt_key_len, const void *actions,
@@ -634,6 +724,8 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             }
             reward = env_step(&env, &cfg, r, a, ca, &done);
             if (q_trace) memcpy(q_trace + row * N, env.q, sizeof(double) * N);
+            if (g_aux_q) { memset(g_aux_q + row * TN, 0, sizeof(double) * TN); memcpy(g_aux_q + row * TN, env.q, sizeof(double) * ND); }
+            if (g_aux_rows) { g_aux_rows[2 * row] = g_probe_rows[0]; g_aux_rows[2 * row + 1] = g_probe_rows[1]; }
             if (grip_trace) memcpy(grip_trace + row * 3, env.gripper, sizeof(double) * 3);
             ep_ret += reward; ep_len += 1;
             if (done) {
@@ -646,7 +738,8 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             if (done_out) done_out[row] = (uint8_t)done;
         }
         if (final_state) {
-            double *f = final_state + 30 * (size_t)e; int j;
+            double *f = final_state + 40 * (size_t)e; int j;
+            for (j = 0; j < 5; j++) { f[30 + j] = N + j < ND ? env.q[N + j] : 0.0; f[35 + j] = N + j < ND ? env.qd[N + j] : 0.0; }
             for (j = 0; j < N; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
             f[14] = env.ee_target[0]; f[15] = env.ee_target[1]; f[16] = env.ee_target[2]; f[17] = env.bq; f[18] = env.bqd;
             f[19] = env.counter; f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.button_pos[2];
@@ -670,14 +763,14 @@ void kuka_oracle_settled(int random_target, int action_joints, double *out22) {
     out22[19] = s.gripper[0]; out22[20] = s.gripper[1]; out22[21] = s.gripper[2];
 }
 void kuka_oracle_aba(const double *q, const double *qd, const double *tau, double gz, double *qdd) { aba(q, qd, tau, gz, qdd); }
-void kuka_oracle_minv(const double *q, double *W49) { double W[N][N]; int i, j; mass_matrix_inverse(q, W); for (i = 0; i < N; i++) for (j = 0; j < N; j++) W49[i * N + j] = W[i][j]; }
+void kuka_oracle_minv(const double *q, double *Wnn) { double W[TN][TN]; int i, j; const int n = ND; mass_matrix_inverse(q, W); for (i = 0; i < n; i++) for (j = 0; j < n; j++) Wnn[i * n + j] = W[i][j]; }
 void kuka_oracle_fk(const double *q, double *R63, double *p21) {
-    mat3 R[N]; double p[N][3]; int i, a, b;
+    mat3 R[TN]; double p[TN][3]; int i, a, b;
     forward_kinematics(q, R, p);
-    for (i = 0; i < N; i++) { for (a = 0; a < 3; a++) { for (b = 0; b < 3; b++) R63[i * 9 + a * 3 + b] = R[i][a][b]; p21[i * 3 + a] = p[i][a]; } }
+    for (i = 0; i < ND; i++) { for (a = 0; a < 3; a++) { for (b = 0; b < 3; b++) R63[i * 9 + a * 3 + b] = R[i][a][b]; p21[i * 3 + a] = p[i][a]; } }
 }
 void kuka_oracle_ik(const double *q, const double *target, double *q_des) {
-    mat3 R[N]; double p[N][3]; forward_kinematics(q, R, p); inverse_kinematics(q, R, p, target, g_two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_des);
+    mat3 R[TN]; double p[TN][3]; forward_kinematics(q, R, p); inverse_kinematics(q, R, p, target, g_two ? KM_IK_DAMPING_DEFAULT : KM_IK_DAMPING, q_des);
 }
 /* scripted-wrapper probe: reward/termination logic on caller-supplied physics outputs */
 void kuka_oracle_wrapper_step(double *state8, const double *gripper, const double *button_pos, int contact_button, int contact_table,
@@ -772,5 +865,5 @@ double kuka_oracle_env_step(void *hv, int action, float *obs, int *done) {
 void kuka_oracle_env_free(void *hv) { free(hv); }
 
 /* runtime model table (oracle/kuka_model.h): this translation unit's copy */
-void kuka_oracle_set_model(const double *table138) { km_set_model(table138); }
+void kuka_oracle_set_model(const double *table138) { km_set_model(table138); model_refresh(); }
 void kuka_oracle_get_model(double *table138) { km_get_model(table138); }

@@ -121,7 +121,7 @@ void run_env(const Cfg &cfg, R &rng, Philox act, int T, int n, int e_idx, const 
         if (done_out) done_out[row] = (uint8_t)done;
     }
     if (final_state) {
-        double *f = final_state + 30 * (size_t)e_idx;
+        double *f = final_state + 40 * (size_t)e_idx;   // stride of oracle.kuka_clib.rollout (columns 30..39: gripper DoFs of the full model)
         for (int j = 0; j < ND; j++) { f[j] = env.q[j]; f[7 + j] = env.qd[j]; }
         f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
         f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
@@ -351,7 +351,7 @@ void group_env_body(GroupArgs &a, R &rng) {
         }
     }
     if (a.final_state) {
-        double *f = a.final_state + 30 * (size_t)e_idx;
+        double *f = a.final_state + 40 * (size_t)e_idx;
         if (L.arm) { f[L.l] = g.q; f[7 + L.l] = g.qd; }
         if (lead) {
             f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;

@@ -40,14 +40,17 @@ def test_eight_shards_equal_one_handle(monkeypatch):
     dev = torch.device("cuda", 0)
     enc = SRLNeuralNetwork(3, cuda=True, img_shape=(64, 64), device=dev)
     assert enc.backend == "hip"
-    # force_down random agents reach the table within the 64 steps: auto-resets and episode records are covered
     kw = {"random_target": True}
+    # the arm needs hundreds of steps to reach anything (0.35 rad/s joint speed limit), so the step counters are advanced to
+    # just below the 1001-step limit, staggered by global env id: every env ends an episode (and auto-resets) inside the window
+    counters = (1001 - 10 - (np.arange(G * PER) % 40)).astype(np.int32)
     full = PixelStateVecEnv("KukaButtonGymEnv-v0", G * PER, enc, seed=0, img_shape=(64, 64), env_kwargs=kw)
     assert full.h.kuka_kernel() == "group"
     rs = np.random.RandomState(7)
     actions = torch.from_numpy(rs.randint(6, size=(T, G * PER)).astype(np.int32)).to(dev)
     st0 = full.reset().clone()
     img0 = full.images.clone()
+    full.h.set_state(_lib.F_STEP_COUNT, counters)
     keep = [10, T - 1]                                        # full planes kept at two steps; checksums at every step
     ref = {"states": [], "rew": [], "done": [], "img_sum": [], "img": {}}
     for t in range(T):
@@ -63,7 +66,7 @@ def test_eight_shards_equal_one_handle(monkeypatch):
     full.h.episode_stats_device(last_return=ret_full.data_ptr(), last_length=len_full.data_ptr(), n_finished=fin_full.data_ptr())
     full.h.sync()
     full.close()
-    assert int(torch.stack(ref["done"]).sum()) > 0            # some episodes ended (table contact / button pressed)
+    assert int(torch.stack(ref["done"]).sum()) == G * PER     # every env crossed the step limit once
 
     shard_returns = []
     for g in range(G):
@@ -72,6 +75,7 @@ def test_eight_shards_equal_one_handle(monkeypatch):
         s = env.reset()
         torch.cuda.synchronize()
         assert torch.equal(s, st0[sl]) and torch.equal(env.images, img0[sl])
+        env.h.set_state(_lib.F_STEP_COUNT, counters[sl])
         for t in range(T):
             a = actions[t, sl].contiguous()
             s, r, d = env.step(a)
