@@ -21,6 +21,7 @@ static long g_clamp_cnt[2];
 #define SRL_GDBG_CLAMPS(cl) do { if (g_gdbg_on) { g_clamp_cnt[0]++; g_clamp_cnt[1] += (cl); } } while (0)
 #define SRL_GDBG_COUNTS(any, gl, gc, gb) do { if (g_gdbg_on) { g_gdbg[6][0] += 1; g_gdbg[6][1] += (any); g_gdbg[6][2] += (gl); g_gdbg[6][3] += (gc); g_gdbg[6][4] += (gb); } } while (0)
 #include "kuka_group.hpp"
+#include "kuka_tree.hpp"
 
 using namespace srl;
 using namespace srl::kuka;
@@ -440,3 +441,131 @@ extern "C" void hostcheck_kuka_set_model(const double *table138) {
     if (table138) memcpy(&g_model, table138, sizeof g_model);
 }
 extern "C" void hostcheck_kuka_default_model(double *table138) { Model m; default_model(m); memcpy(table138, &m, sizeof m); }
+
+
+// =====================================================================================================================
+// Full-model lane-group stepper (kuka_tree.hpp) under the same fiber harness.  Resets integrate their init actions from the
+// settled state (START = 2 / 1): the start-state table is a device-side shortcut for the same arithmetic.
+namespace {
+srl::kuka::TreeModel g_tree_model; bool g_tree_model_set = false;
+const srl::kuka::TreeModel *tree_model() {
+    if (!g_tree_model_set) { srl::kuka::default_tree_model(g_tree_model); g_tree_model_set = true; }
+    return &g_tree_model;
+}
+template <class R>
+void tree_env_body(GroupArgs &a, R &rng) {
+    using namespace tree;
+    const Cfg &cfg = a.cfg;
+    const int n = a.n, e_idx = a.e_idx, T = a.T;
+    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
+    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    TLane L; lane_init(L, tree_model());
+    const bool lead = L.l == 0;
+    Env env; memset(&env, 0, sizeof env);
+    GState g; memset(&g, 0, sizeof g);
+    const bool joints = !cfg.is_discrete && cfg.action_joints;
+    if (joints) tenv_reset<1>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    else tenv_reset<2>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
+    Philox act = a.act;
+    grp::GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
+    double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
+    for (int t = 0; t < T; t++) {
+        const size_t row = (size_t)t * n + e_idx;
+        int ac = 0; float ca[7] = {0}; bool done;
+        if (a.actions) {
+            if (cfg.is_discrete) ac = static_cast<const int32_t *>(a.actions)[row];
+            else memcpy(ca, static_cast<const float *>(a.actions) + row * adim, sizeof(float) * adim);
+        } else {
+            if (cfg.is_discrete) ac = gact.next(5);
+            else for (int j = 0; j < adim; j += 2) {
+                uint32_t o[4]; act.block(o);
+                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+            }
+            if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
+        }
+        const double reward = tenv_step(env, g, L, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
+        if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
+        ep_ret += reward; ep_len += 1;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
+            if (cfg.auto_reset) {
+                if (joints) tenv_reset<1>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                else tenv_reset<2>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+            }
+        }
+        if (lead) {
+            if (a.obs) observe(env, cfg, a.obs + row * od, 1);
+            if (a.rew) a.rew[row] = (float)reward;
+            if (a.rew64) a.rew64[row] = reward;
+            if (a.done_out) a.done_out[row] = (uint8_t)done;
+        }
+    }
+    if (a.final_state) {
+        double *f = a.final_state + 40 * (size_t)e_idx;
+        if (L.arm) { f[L.l] = g.q; f[7 + L.l] = g.qd; }
+        else if (L.jnt) { f[30 + L.l - ND] = g.q; f[35 + L.l - ND] = g.qd; }
+        if (lead) {
+            f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
+            f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
+        }
+    }
+    if (a.ep_stats && lead) { a.ep_stats[3 * (size_t)e_idx] = last_ret; a.ep_stats[3 * (size_t)e_idx + 1] = last_len; a.ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
+}
+void tree_fiber_body(void *p) {
+    GroupArgs &a = *static_cast<GroupArgs *>(p);
+    if (a.rng_mode == 2) { grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0}; tree_env_body(a, r); }
+    else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); tree_env_body(a, r); }
+}
+struct TreeSettleArgs { Cfg cfg; double *out; double *scratch; };
+void tree_settle_body(void *p) {
+    using namespace tree;
+    TreeSettleArgs &a = *static_cast<TreeSettleArgs *>(p);
+    TLane L; lane_init(L, tree_model());
+    Env e; memset(&e, 0, sizeof e);
+    GState g; memset(&g, 0, sizeof g);
+    tinitial(e, g, L);
+    const double zero[3] = {0, 0, 0};
+    for (int i = 0; i < kNSettleSteps; i++) tphysics_step(e, g, L, a.cfg, a.scratch, zero, a.cfg.action_joints != 0, L.q0, 0.0);
+    tpack_start(e, g, L, a.out);
+}
+}  // namespace
+
+extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, int random_target, int force_down,
+                                           int shape_reward, int action_repeat, double max_distance, int obs_mode,
+                                           int rng_mode, int auto_reset, int n, int T, const int64_t *seeds,
+                                           const uint32_t *mt_keys, const int32_t *mt_key_len, const void *actions,
+                                           float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out,
+                                           void *act_out, double *q_trace, double *grip_trace, double *final_state,
+                                           double *ep_stats) {
+    if (g_two) return -1;
+    GroupArgs a;
+    a.model = nullptr;
+    Cfg &cfg = a.cfg;
+    cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
+    cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
+    cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
+    cfg.moving = g_moving; cfg.two = 0; cfg.max_steps = g_moving ? 1500 : kMaxSteps; cfg.rand_objects = g_rand;
+    std::vector<double> settled(tree::kTreeStartDoubles, 0.0), starts, scratch(tree::kTreeScratchDoubles);
+    TreeSettleArgs sa{cfg, settled.data(), scratch.data()};
+    run_group(tree_settle_body, &sa);
+    a.rng_mode = rng_mode; a.T = T; a.n = n; a.actions = actions; a.settled = settled.data(); a.starts = starts.data();
+    a.obs0 = obs0; a.obs = obs; a.rew = rew; a.rew64 = rew64; a.done_out = done_out; a.act_out = act_out;
+    a.q_trace = q_trace; a.grip_trace = grip_trace; a.final_state = final_state; a.ep_stats = ep_stats; a.scratch = scratch.data();
+    for (int e = 0; e < n; e++) {
+        a.e_idx = e;
+        a.act.k0 = (uint32_t)(uint64_t)seeds[e]; a.act.k1 = (uint32_t)((uint64_t)seeds[e] >> 32); a.act.ctr = 0; a.act.stream = 1;
+        MtHost mt;
+        if (rng_mode == 2) mt.seed(mt_keys + 2 * (size_t)e, mt_key_len[e]);
+        a.mt = &mt;
+        run_group(tree_fiber_body, &a);
+    }
+    return 0;
+}
+extern "C" void hostcheck_kuka_tree_default_model(double *t506) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t506, &m, sizeof m); }
+extern "C" void hostcheck_kuka_tree_set_model(const double *t506) {
+    g_tree_model_set = t506 != nullptr;
+    if (t506) memcpy(&g_tree_model, t506, sizeof g_tree_model);
+}

@@ -1,0 +1,825 @@
+// kuka_tree.hpp — lane-group physics step for the FULL Kuka model (kuka_tree_model.hpp): the 12-DoF arm + gripper tree with every
+// joint motor of kuka.py:167-187, per-link contact spheres and one friction row per contact.  Same decomposition as
+// kuka_group.hpp (16 lanes = one DPP row per env, broadcast-accumulate for every cross-lane pattern), generalised from a chain to
+// a kinematic tree:
+//
+//   lane l < 12 owns DoF / link l and motor row l; lanes 12, 13, 14 own the button's scalar rows (motor, lower stop, upper stop);
+//   every lane owns one collision sphere (16) and — on the rare steps that carry them — one row of a second row bank "B":
+//   slots 0..7 joint-limit and contact-normal rows in creation order, slot 8 + g the friction row of contact-normal slot g.
+//
+//   * kinematics: local joint transforms composed by 4 levels of pointer jumping over the tree (lane l reads lane parent^(2^k)(l));
+//   * dynamics in WORLD coordinates about the world origin: link velocities / bias accelerations are sums over ANCESTORS, link
+//     forces / composite inertias sums over DESCENDANTS — masked row-broadcast FMAs with per-lane ancestor / descendant masks;
+//     M by CRBA (M_kl = S_k . Ic_l S_l for k an ancestor of l, 0 across branches), M^-1 by the lane-parallel Gauss-Jordan sweep;
+//   * IK: the end effector (link 6) does not move with the gripper joints, so the damped-least-squares step is the 7x7 arm block;
+//   * projected Gauss-Seidel in impulse space: bank-A rows (motors, button) scaled to [0, 1] and updated by the fused clamp /
+//     broadcast-FMA row of kuka_group.hpp; bank-B rows in impulse units with explicit bounds (a friction row's bounds follow its
+//     normal row's current impulse, btMultiBodyConstraintSolver::solveSingleIteration); their coupling coefficients live in LDS.
+//
+// The same source runs on the host under the fiber harness (csrc/kuka_hostcheck.cpp); the oracle it is compared with is
+// oracle/kuka_oracle.c in its full-model mode (link-frame ABA, dv-space Gauss-Seidel): ~1e-11 on joints, flags bit for bit.
+#pragma once
+#include "kuka_group.hpp"
+#include "kuka_tree_model.hpp"
+
+namespace srl {
+namespace kuka {
+namespace tree {
+using grp::GL;
+using grp::GState;
+using grp::bcast;
+using grp::ballot;
+using grp::clamp01;
+using grp::compose;
+using grp::fmac_bcast;
+using grp::gany;
+using grp::lane_id;
+using grp::pgs_row;
+using grp::pgs_row2;
+using grp::rcp;
+using grp::shfl;
+using grp::sync_scratch;
+using grp::wany;
+
+constexpr int NJ = 12;                          // joint lanes
+constexpr int NA = 7;                           // arm joints (IK, commands)
+constexpr int kBM = 12, kBLo = 13, kBHi = 14;   // lanes of the button's scalar rows
+constexpr int kNB = 16, kNGen = 8;              // bank-B slots; slots < kNGen: limits + contact normals, kNGen + g: friction of normal g
+constexpr int kTreeStartDoubles = 4 * NJ + 8;   // q12 qd12 sq12 cq12 ee3 bq bqd grip3
+// LDS scratch per env (doubles): row definitions J[16][12], W J [16][12], then three coupling planes [row j][lane i]:
+// nBA (lane i's B row <- A row j), nAB (lane i's A row <- B row j), nBB (lane i's B row <- B row j)
+// and the row scalars DEF[slot][8]: Jb, desired velocity, position-error velocity, upper bound, on, mu
+constexpr int kDefDoubles = 8;
+constexpr int SC_J = 0, SC_WJ = kNB * NJ, SC_NBA = 2 * kNB * NJ, SC_NAB = SC_NBA + GL * GL, SC_NBB = SC_NAB + GL * GL, SC_DEF = SC_NBB + GL * GL;
+constexpr int kTreeScratchDoubles = SC_DEF + kNB * kDefDoubles;
+
+// ------------------------------------------------------------------ per-lane constants
+struct TLane {
+    int l;
+    bool jnt, arm;            // l < 12, l < 7
+    double jm, am;            // 1.0 on joint / arm lanes
+    double e[NJ];             // e[j] = (l == j)
+    uint32_t anc, desc;       // bit k: DoF k is an ancestor-or-self / descendant-or-self of the own link
+    int src[4];               // lane parent^(1, 2, 4, 8)(l), -1 beyond the root
+    double mass, mcomp;       // link mass, mass of the own subtree
+    double com[3], in[6];     // centre of mass, inertia about it (xx xy xz yy yz zz) in link axes
+    double F[9], t[3], ax[3]; // fixed rotation (columns) and origin of the joint frame in the parent link, joint axis in the joint frame
+    double jlo, jhi;          // joint limits (jlo > jhi: none)
+    double damping, kp, bound, maxvel, q0;   // motor: gain, impulse bound force * dt, velocity clamp; kJointPositions of the joint
+    double tsel;              // gripper motor target = tsel * finger_angle (-1 joint 8, +1 joint 11, else 0)
+    int slink; uint32_t sanc; // own collision sphere: link, that link's ancestor mask; slink < 0: none
+    double sph[4], smu;
+    int ee_link, grip_link, max_gen;
+    bool friction;
+    double eept[3], grpt[3], table_z, base_z;
+};
+
+SRL_G void lane_init(TLane &L, const TreeModel *m) {
+    const int l = lane_id();
+    const int nd = (int)m->nd;
+    L.l = l; L.jnt = l < nd; L.arm = l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) L.e[j] = l == j ? 1.0 : 0.0;
+    const int i = L.jnt ? l : 0;
+    const TreeJoint &J = m->j[i];
+    // ancestors of the own link, descendants, pointer-jumping sources
+    L.anc = 0; L.desc = 0;
+    if (L.jnt) for (int k = l; k >= 0; k = (int)m->j[k].parent) L.anc |= 1u << k;
+    double mc = 0.0;
+    for (int k = 0; k < nd; k++) {
+        bool under = false;
+        for (int a = k; a >= 0; a = (int)m->j[a].parent) under = under || a == l;
+        if (under && L.jnt) { L.desc |= 1u << k; mc += m->j[k].mass; }
+    }
+    {
+        int a = L.jnt ? (int)J.parent : -1, hop = 1;
+        for (int lvl = 0; lvl < 4; lvl++) {
+            L.src[lvl] = a;
+            // the next source is 2 * hop links up from l
+            for (int s = 0; s < hop && a >= 0; s++) a = (int)m->j[a].parent;
+            hop *= 2;
+        }
+    }
+    L.mass = L.jnt ? J.mass : 0.0; L.mcomp = L.jnt ? mc : 0.0;
+    for (int k = 0; k < 3; k++) { L.com[k] = J.com[k]; L.t[k] = L.jnt ? J.xyz[k] + (J.parent < 0 ? kBasePos[k] : 0.0) : 0.0; L.ax[k] = J.axis[k]; }
+    for (int k = 0; k < 6; k++) L.in[k] = L.jnt ? J.inertia[k] : 0.0;
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) L.F[3 * c + r] = L.jnt ? J.Rj[3 * r + c] : (r == c ? 1.0 : 0.0);
+    L.jlo = L.jnt ? J.lower : 1.0; L.jhi = L.jnt ? J.upper : -1.0;
+    L.damping = L.jnt ? J.damping : 0.0; L.kp = J.kp; L.bound = L.jnt ? J.max_force * kDt : 0.0; L.maxvel = J.max_vel;
+    L.q0 = L.jnt ? kJointPositions[(int)J.joint_index] : 0.0;
+    L.tsel = !L.jnt ? 0.0 : (int)J.joint_index == 8 ? -1.0 : (int)J.joint_index == 11 ? 1.0 : 0.0;
+    const int ns = (int)m->nsphere;
+    const TreeSphere &S = m->s[l < ns ? l : 0];
+    L.slink = l < ns ? (int)S.link : -1;
+    L.sanc = 0;
+    if (L.slink >= 0) for (int k = L.slink; k >= 0; k = (int)m->j[k].parent) L.sanc |= 1u << k;
+    for (int k = 0; k < 3; k++) L.sph[k] = S.c[k];
+    L.sph[3] = S.r; L.smu = S.mu;
+    L.ee_link = (int)m->ee_link; L.grip_link = (int)m->grip_link; L.max_gen = (int)m->max_generic_rows; L.friction = m->friction != 0.0;
+    if (L.max_gen > kNGen) L.max_gen = kNGen;
+    for (int k = 0; k < 3; k++) { L.eept[k] = m->ee_point[k]; L.grpt[k] = m->grip_point[k]; }
+    L.table_z = m->table_top_z; L.base_z = m->button_base_z;
+}
+
+// ancestor / descendant masks as 0 / 1 weights, rebuilt per step (kept out of the rollout loop's live registers)
+struct TMasks { double le[NJ], ge[NJ]; };
+SRL_G void make_masks(uint32_t anc, uint32_t desc, TMasks &m) {
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(anc), "+v"(desc));
+#endif
+#pragma unroll
+    for (int k = 0; k < NJ; k++) { m.le[k] = (anc >> k) & 1u ? 1.0 : 0.0; m.ge[k] = (desc >> k) & 1u ? 1.0 : 0.0; }
+}
+
+// ------------------------------------------------------------------ kinematics
+// world frame of every link: local joint transform per lane, then pointer jumping (4 levels cover the depth-10 finger tips)
+SRL_G void tfk(const TLane &L, GState &g) {
+    const double s = g.sq, c = g.cq, v = 1.0 - c;         // lanes off the tree carry s = 0, c = 1: the identity
+    double Rq[9], R[9], p[3];
+    // Rodrigues, columns: Rq = c I + s [a]x + (1 - c) a a^T
+    const double ax = L.ax[0], ay = L.ax[1], az = L.ax[2];
+    Rq[0] = c + ax * ax * v;      Rq[1] = ay * ax * v + az * s; Rq[2] = az * ax * v - ay * s;
+    Rq[3] = ax * ay * v - az * s; Rq[4] = c + ay * ay * v;      Rq[5] = az * ay * v + ax * s;
+    Rq[6] = ax * az * v + ay * s; Rq[7] = ay * az * v - ax * s; Rq[8] = c + az * az * v;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) R[3 * j + k] = L.F[k] * Rq[3 * j] + L.F[3 + k] * Rq[3 * j + 1] + L.F[6 + k] * Rq[3 * j + 2];
+    p[0] = L.t[0]; p[1] = L.t[1]; p[2] = L.t[2];
+#pragma unroll
+    for (int lvl = 0; lvl < 4; lvl++) {
+        const int src = L.src[lvl];
+        const bool have = src >= 0;
+        const int from = have ? src : L.l;
+        double Ra[9], pa[3], Ro[9], po[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const double x = shfl(R[k], from); Ra[k] = have ? x : ((k % 4 == 0) ? 1.0 : 0.0); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double x = shfl(p[k], from); pa[k] = have ? x : 0.0; }
+        compose(Ra, pa, R, p, Ro, po);
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = Ro[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] = po[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) g.R[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) g.p[k] = p[k];
+}
+// world frame of link `link` (a per-lane index), fetched from its lane
+SRL_G void link_frame(const GState &g, int link, double Rt[9], double pt[3]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rt[k] = shfl(g.R[k], link);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pt[k] = shfl(g.p[k], link);
+}
+SRL_G void frame_point(const double R[9], const double p[3], const double local[3], double w[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) w[k] = p[k] + R[k] * local[0] + R[3 + k] * local[1] + R[6 + k] * local[2];
+}
+SRL_G void trefresh(const TLane &L, GState &g, Env &e) {
+    if (L.jnt) sincos(g.q, &g.sq, &g.cq); else { g.sq = 0.0; g.cq = 1.0; }
+    tfk(L, g);
+    double Rt[9], pt[3];
+    link_frame(g, L.grip_link, Rt, pt);
+    frame_point(Rt, pt, L.grpt, e.grip);
+}
+
+// ------------------------------------------------------------------ row-broadcast helpers for 12 joint lanes
+template <int K> SRL_G void msum_step(double &acc, double x, const double m[NJ]) {
+    fmac_bcast<K>(acc, x, m[K]);
+    if constexpr (K + 1 < NJ) msum_step<K + 1>(acc, x, m);
+}
+SRL_G double msum(double x, const double m[NJ], double base = 0.0) { double acc = base; msum_step<0>(acc, x, m); return acc; }
+template <int K, int N> SRL_G void ball_step(double x, double *out) {
+    out[K] = bcast<K>(x);
+    if constexpr (K + 1 < N) ball_step<K + 1, N>(x, out);
+}
+template <int K, int N> SRL_G void dot6_step(const double a[6], const double b[6], double *out) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) fmac_bcast<K>(acc, b[c], a[c]);
+    out[K] = acc;
+    if constexpr (K + 1 < N) dot6_step<K + 1, N>(a, b, out);
+}
+template <int K> SRL_G void transpose_step(const TLane &L, const double low[NJ], double M[NJ]) {
+#pragma unroll
+    for (int j = 0; j < K; j++) fmac_bcast<K>(M[K], low[j], L.e[j]);
+    if constexpr (K + 1 < NJ) transpose_step<K + 1>(L, low, M);
+}
+template <int K, int N> SRL_G void rdot_step(double &acc, const double *row, double x) {
+    fmac_bcast<K>(acc, x, row[K]);
+    if constexpr (K + 1 < N) rdot_step<K + 1, N>(acc, row, x);
+}
+// In-place Gauss-Jordan on an N x N SPD matrix, row i on lane i (lanes >= N carry zero rows).  INV: A <- A^-1, else A x = b -> b.
+template <int K, int N, bool INV> SRL_G void gj_step(const TLane &L, double *A, double &b) {
+    const double r = rcp(bcast<K>(A[K]));
+    const double g = -((A[K] - L.e[K]) * r);
+    if constexpr (INV) {
+        A[K] = L.e[K];
+#pragma unroll
+        for (int c = 0; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
+    } else {
+#pragma unroll
+        for (int c = K + 1; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
+        fmac_bcast<K>(b, b, g);
+    }
+    if constexpr (K + 1 < N) gj_step<K + 1, N, INV>(L, A, b);
+}
+
+// ------------------------------------------------------------------ PGS, bank A only (no limit / contact row in the wavefront)
+struct TRows {
+    double acc0, cs;
+    double n[GL];              // scaled couplings of the own bank-A row to bank-A rows (n[own] = 0)
+    double diag, lo, S, jb;
+};
+// One sweep: 12 motor rows; the button's three rows are decoupled from them here and ride on rows 0..2.
+SRL_G void sweep_free(const TLane &L, const TRows &r, double &acc, double e0, double e1, double e2, double ep_first) {
+    pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], ep_first);
+    pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);
+    pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);
+    pgs_row<3>(acc, r.cs, r.n[3], e2);        pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);  pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);
+    pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);    pgs_row<7>(acc, r.cs, r.n[7], L.e[6]);  pgs_row<8>(acc, r.cs, r.n[8], L.e[7]);
+    pgs_row<9>(acc, r.cs, r.n[9], L.e[8]);    pgs_row<10>(acc, r.cs, r.n[10], L.e[9]); pgs_row<11>(acc, r.cs, r.n[11], L.e[10]);
+}
+SRL_G double sweeps_free(const TLane &L, const TRows &r) {
+    double acc = r.acc0, u = 0.0, t;
+    const double e0 = L.e[0] + (L.l == kBM ? 1.0 : 0.0), e1 = L.e[1] + (L.l == kBLo ? 1.0 : 0.0), e2 = L.e[2] + (L.l == kBHi ? 1.0 : 0.0);
+    sweep_free(L, r, acc, e0, e1, e2, 0.0);
+    for (int it = 1; it < kSolverIters - 1; it++) sweep_free(L, r, acc, e0, e1, e2, L.e[11]);
+    t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], L.e[11]);  u = fma(e0, t, u);
+    t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);      u = fma(e1, t, u);
+    t = pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);      u = fma(e2, t, u);
+    t = pgs_row<3>(acc, r.cs, r.n[3], e2);         u = fma(L.e[3], t, u);
+    t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);     u = fma(L.e[4], t, u);
+    t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);     u = fma(L.e[5], t, u);
+    t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);     u = fma(L.e[6], t, u);
+    t = pgs_row<7>(acc, r.cs, r.n[7], L.e[6]);     u = fma(L.e[7], t, u);
+    t = pgs_row<8>(acc, r.cs, r.n[8], L.e[7]);     u = fma(L.e[8], t, u);
+    t = pgs_row<9>(acc, r.cs, r.n[9], L.e[8]);     u = fma(L.e[9], t, u);
+    t = pgs_row<10>(acc, r.cs, r.n[10], L.e[9]);   u = fma(L.e[10], t, u);
+    t = pgs_row<11>(acc, r.cs, r.n[11], L.e[10]);  u = fma(L.e[11], t, u);
+    return u;
+}
+
+// ------------------------------------------------------------------ PGS, general path: bank A + bank B
+struct BRow { double cs, lo, hi, mu, lam, jb, inv_diag; int normal; bool on, fric; };   // own bank-B row (slot == lane)
+// bank-A row J: u = clamp01(cs + accA) on lane J, broadcast to both accumulators of every lane.  (The general path resets the
+// own accumulator explicitly instead of in the shadow of the next row: bank-B rows interleave with bank A.)
+template <int J> SRL_G void gen_rowA(const TLane &L, const TRows &r, const double *sc, double &accA, double &accB, double &uA) {
+    const double t = clamp01(r.cs + accA);
+    const double tb = bcast<J>(t);
+    if (L.l == J) { accA = 0.0; uA = t; }
+    accA = fma(r.n[J], tb, accA);
+    accB = fma(sc[SC_NBA + J * GL + L.l], tb, accB);
+}
+// bank-B slot s (a wave-uniform loop index): lambda = clamp(cs + accB, lo, hi) on lane s.  A friction row's bounds are +-mu times
+// the CURRENT impulse of its normal row, and the row keeps its value while that is not positive (it still hands the value round:
+// every row contributes exactly once per sweep to the others' accumulators).  part: this env's slot s belongs to the phase being
+// swept (uniform over the env's 16 lanes) — otherwise nothing of this env changes.
+SRL_G void gen_rowB(const TLane &L, const double *sc, int s, BRow &b, double &accA, double &accB, bool part) {
+    double lo = b.lo, hi = b.hi;
+    const double tot = shfl(b.lam, b.normal);               // friction rows: the normal row's impulse
+    const bool skip = b.fric && !(tot > 0.0);
+    if (b.fric) { lo = -b.mu * tot; hi = b.mu * tot; }
+    double t = b.cs + accB;
+    t = t < lo ? lo : (t > hi ? hi : t);
+    if (skip) t = b.lam;
+    const double tb = shfl(t, s);
+    const double nA = fma(sc[SC_NAB + s * GL + L.l], tb, accA);
+    const double nB = fma(sc[SC_NBB + s * GL + L.l], tb, L.l == s ? 0.0 : accB);
+    if (part) { accA = nA; accB = nB; if (L.l == s) b.lam = t; }
+}
+
+// ------------------------------------------------------------------ one physics step
+// Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
+// lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
+// finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
+SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
+                         double finger_angle) {
+    const double dt = kDt, inv_dt = 1.0 / kDt;
+    // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
+    double S[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) S[k] = (g.R[k] * L.ax[0] + g.R[3 + k] * L.ax[1] + g.R[6 + k] * L.ax[2]) * L.jm;
+    cross3(g.p, S, S + 3);
+    // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
+    double qdes = L.arm ? jt_own : L.tsel * finger_angle;
+    if (!joint_mode) {
+        const int b = (cfg.random_target || cfg.two) ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double v = e.ee[k] + motor[k];
+            v = v < kEeBox[b][0][k] ? kEeBox[b][0][k] : v;
+            v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
+            e.ee[k] = v;
+        }
+        double Rt[9], pt[3], ee[3], dS[6], J[6];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rt[k] = bcast<NA - 1>(g.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pt[k] = bcast<NA - 1>(g.p[k]);
+        frame_point(Rt, pt, L.eept, ee);
+        {
+            double d[3], Sa[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { d[k] = ee[k] - g.p[k]; Sa[k] = S[k] * L.am; }
+            cross3(Sa, d, J);
+#pragma unroll
+            for (int k = 0; k < 3; k++) J[3 + k] = Sa[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
+        {   // orientation error towards quat(euler(0, -pi, 0)), replicated (same construction as kuka_group.hpp)
+            const double *R = Rt;
+            double qx, qy, qz, qw;
+            const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+            const double tr = m00 + m11 + m22;
+            if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
+            else if (m00 > m11 && m00 > m22) { double s = sqrt(1.0 + m00 - m11 - m22) * 2; qw = (m21 - m12) / s; qx = 0.25 * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
+            else if (m11 > m22) { double s = sqrt(1.0 + m11 - m00 - m22) * 2; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25 * s; qz = (m12 + m21) / s; }
+            else { double s = sqrt(1.0 + m22 - m00 - m11) * 2; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25 * s; }
+            const double tx = 0.0, ty = -1.0, tz = 0.0, tw = 6.123233995736766e-17;
+            const double ix = -qx, iy = -qy, iz = -qz, iw = qw;
+            const double dw = tw * iw - tx * ix - ty * iy - tz * iz;
+            const double dx = tw * ix + tx * iw + ty * iz - tz * iy;
+            const double dy = tw * iy - tx * iz + ty * iw + tz * ix;
+            const double dz = tw * iz + tx * iy - ty * ix + tz * iw;
+            const double sv = sqrt(dx * dx + dy * dy + dz * dz);
+            double angle = 2.0 * atan2(sv, dw), ax, ay, az;
+            if (sv * sv < 10.0 * 2.2204460492503131e-16) { ax = 1; ay = 0; az = 0; }
+            else { ax = dx / sv; ay = dy / sv; az = dz / sv; }
+            if (angle > kPi) angle -= 2 * kPi;
+            dS[3] = angle * ax; dS[4] = angle * ay; dS[5] = angle * az;
+        }
+        double A[NA], bb = 0.0;
+        dot6_step<0, NA>(J, J, A);
+        const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
+#pragma unroll
+        for (int k = 0; k < NA; k++) A[k] = fma(damping, L.e[k], A[k]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
+        gj_step<0, NA, false>(L, A, bb);
+        bb *= L.am;
+        double all[NA], maxabs = 0.0;
+        ball_step<0, NA>(bb, all);
+#pragma unroll
+        for (int k = 0; k < NA; k++) maxabs = fmax(maxabs, fabs(all[k]));
+        if (L.arm) qdes = g.q + bb;
+        if (wany(maxabs > kIkMaxAngle)) {
+            const double scale = kIkMaxAngle / maxabs;
+            if (maxabs > kIkMaxAngle && L.arm) qdes = g.q + bb * scale;
+        }
+    }
+    // ---- collision detection at the current poses: every lane owns one sphere of the model
+    double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30;
+    const bool sphere = L.slink >= 0;
+    {
+        double Rs[9], ps[3];
+        link_frame(g, sphere ? L.slink : 0, Rs, ps);
+        frame_point(Rs, ps, L.sph, cc);
+    }
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
+    {
+        const double reach = L.sph[3] + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
+        const double rmax = kBaseRadius + reach;
+        const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
+        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+        if (wany(sphere && !far)) {
+            if (sphere) {
+                d_cap = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+                d_base = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+            }
+        }
+    }
+    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    e.contact_table = gany(sphere && (cc[2] - L.sph[3] - L.table_z < kContactThreshold)) ? 1 : 0;
+    e.contact_button = gany(c_cap) ? 1 : 0;
+    // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
+    double target = L.kp * (qdes - g.q) * inv_dt;
+    target = target > L.maxvel ? L.maxvel : target;
+    target = target < -L.maxvel ? -L.maxvel : target;
+    // ---- dynamics in world coordinates
+    const double qd = g.qd * L.jm;
+    double W[NJ], tau;
+    {
+        TMasks M;
+        make_masks(L.anc, L.desc, M);
+        double w[3], vo[3], aw[3], av[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, M.le); vo[k] = msum(S[3 + k] * qd, M.le); }
+        {
+            double t0[3], t1[3], t2[3];
+            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                aw[k] = msum(t0[k] * qd, M.le);
+                av[k] = msum((t1[k] + t2[k]) * qd, M.le, k == 2 ? -kGravityZ : 0.0);
+            }
+        }
+        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
+        double Io[6], h[3];
+        {
+            const double *R = g.R;
+            double cw[3], T[9];
+            frame_point(R, g.p, L.com, cw);
+            // T = R * Ilink (columns of T), Io = T * R^T + m (|c|^2 1 - c c^T)
+            const double I00 = L.in[0], I01 = L.in[1], I02 = L.in[2], I11 = L.in[3], I12 = L.in[4], I22 = L.in[5];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                T[k] = R[k] * I00 + R[3 + k] * I01 + R[6 + k] * I02;
+                T[3 + k] = R[k] * I01 + R[3 + k] * I11 + R[6 + k] * I12;
+                T[6 + k] = R[k] * I02 + R[3 + k] * I12 + R[6 + k] * I22;
+            }
+            const double m = L.mass, ccs = dot3(cw, cw);
+            Io[0] = T[0] * R[0] + T[3] * R[3] + T[6] * R[6] + m * (ccs - cw[0] * cw[0]);
+            Io[1] = T[0] * R[1] + T[3] * R[4] + T[6] * R[7] - m * cw[0] * cw[1];
+            Io[2] = T[0] * R[2] + T[3] * R[5] + T[6] * R[8] - m * cw[0] * cw[2];
+            Io[3] = T[1] * R[1] + T[4] * R[4] + T[7] * R[7] + m * (ccs - cw[1] * cw[1]);
+            Io[4] = T[1] * R[2] + T[4] * R[5] + T[7] * R[8] - m * cw[1] * cw[2];
+            Io[5] = T[2] * R[2] + T[5] * R[5] + T[8] * R[8] + m * (ccs - cw[2] * cw[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
+        }
+        double Fn[3], Ff[3], Ioc[6], hc[3];
+        {
+            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
+            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass * av[k] - t1[k]; }
+            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass * vo[k] - t1[k]; }
+            cross3(w, n, t0); cross3(vo, f, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
+            cross3(w, f, t0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) ff[k] += t0[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], M.ge); Ff[k] = msum(ff[k], M.ge); hc[k] = msum(h[k], M.ge); }
+#pragma unroll
+            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], M.ge);
+        }
+        tau = -L.damping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
+        double Fc[6], t0[3], t1[3], low[NJ];
+        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp * S[3 + k] - t1[k]; }
+        dot6_step<0, NJ>(Fc, S, low);
+#pragma unroll
+        for (int k = 0; k < NJ; k++) { low[k] *= M.le[k] * L.jm; W[k] = low[k]; }
+        transpose_step<1>(L, low, W);
+        double unused = 0.0;
+        gj_step<0, NJ, true>(L, W, unused);
+    }
+    double qdd = 0.0;
+    rdot_step<0, NJ>(qdd, W, tau);
+#pragma unroll
+    for (int k = 0; k < NJ; k++) SRL_GDBG(0, L.l * NJ + k, W[k]);
+    SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
+    const double qd_new = qd + dt * qdd;
+    e.bqd += dt * kGravityZ;
+    // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
+    const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
+    const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
+    const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
+    TRows r;
+    double rhs = 0.0, off = 0.0;
+#pragma unroll
+    for (int k = 0; k < GL; k++) r.n[k] = 0.0;
+    r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
+    double a_own[GL];                              // unscaled couplings of the own bank-A row to every bank-A row
+#pragma unroll
+    for (int k = 0; k < GL; k++) a_own[k] = 0.0;
+    if (L.jnt) {
+#pragma unroll
+        for (int k = 0; k < NJ; k++) { r.diag = fma(L.e[k], W[k], r.diag); a_own[k] = W[k] * (1.0 - L.e[k]); }
+        rhs = target - qd_new; r.lo = -L.bound; r.S = 2.0 * L.bound;
+    } else if (is_bm) {
+        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - e.bqd;
+        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
+        a_own[kBLo] = wb; a_own[kBHi] = -wb;
+    } else if (is_blo) {
+        const double pen = e.bq - kGliderLower;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        r.S = blim; r.jb = 1.0; r.diag = wb;
+        a_own[kBM] = wb; a_own[kBHi] = -wb;
+    } else if (is_bhi) {
+        const double pen = kGliderUpper - e.bq;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        r.S = blim; r.jb = -1.0; r.diag = wb;
+        a_own[kBM] = -wb; a_own[kBLo] = -wb;
+    }
+    // bounds of every bank-A row, replicated: S_k and lo_k
+    double Sall[GL], loall[GL];
+    ball_step<0, GL>(r.S, Sall);
+    ball_step<0, GL>(r.lo, loall);
+#pragma unroll
+    for (int k = 0; k < GL; k++) off = fma(a_own[k], loall[k], off);
+    // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
+    const bool has_lim = L.jnt && L.jlo <= L.jhi;
+    const double pen_lo = g.q - L.jlo, pen_hi = L.jhi - g.q;
+    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
+    BRow b;
+    b.cs = 0.0; b.lo = 0.0; b.hi = 0.0; b.mu = 0.0; b.lam = 0.0; b.jb = 0.0; b.inv_diag = 0.0; b.normal = L.l; b.on = false; b.fric = false;
+    int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
+    bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
+    if (any_generic) {
+        double *sc = scratch;
+        // slot of a candidate = number of candidates before it in creation order: limits (joint 0 lower, joint 0 upper, joint 1
+        // lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first max_gen are kept
+        const uint32_t b_lo = ballot(lim_lo), b_hi = ballot(lim_hi), b_cap = ballot(c_cap), b_base = ballot(c_base);
+        const uint32_t below = (1u << L.l) - 1u;
+        nlim = __builtin_popcount(b_lo) + __builtin_popcount(b_hi);
+        const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base);
+        const int s_lo = __builtin_popcount(b_lo & below) + __builtin_popcount(b_hi & below), s_hi = s_lo + (lim_lo ? 1 : 0);
+        const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
+        if (nlim > L.max_gen) nlim = L.max_gen;
+        ngen = nlim + ncon; if (ngen > L.max_gen) ngen = L.max_gen;
+        // every joint's spatial axis on every lane (contact Jacobians): only here, off the common path
+        double Sw[NJ][3], Sv[NJ][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double tw[NJ], tv[NJ];
+            ball_step<0, NJ>(S[k], tw); ball_step<0, NJ>(S[3 + k], tv);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) { Sw[j][k] = tw[j]; Sv[j][k] = tv[j]; }
+        }
+        // ---- row definitions -> LDS.  Slot s < kNGen: J[12] + (Jb, desired, position error, upper bound, on); its friction row at
+        // slot kNGen + s: J[12] + (Jb, -, -, -, on, mu).  Every lane first clears the definition of its own slot.
+        {
+            double *d = sc + SC_DEF + L.l * kDefDoubles;
+#pragma unroll
+            for (int k = 0; k < kDefDoubles; k++) d[k] = 0.0;
+        }
+        sync_scratch();
+        auto put_limit = [&](int slot, double sign, double pen) {
+            if (slot < L.max_gen) {
+                double *o = sc + SC_J + slot * NJ, *d = sc + SC_DEF + slot * kDefDoubles;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) o[j] = sign * L.e[j];
+                d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * kErp * inv_dt; d[3] = blim; d[4] = 1.0;
+            }
+        };
+        auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap) {
+            if (slot < L.max_gen) {
+                double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (kNGen + slot) * NJ;
+                double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (kNGen + slot) * kDefDoubles;
+                double pt3[3], tdir[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) pt3[k] = cc[k] - L.sph[3] * nrm[k];
+                // btPlaneSpace1: first tangent of the contact normal (the one friction direction of Bullet's multibody solver)
+                if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); tdir[0] = 0.0; tdir[1] = -nrm[2] * kk; tdir[2] = nrm[1] * kk; }
+                else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    double c3[3];
+                    cross3(Sw[j], pt3, c3);                               // w_j x pt + v_j = velocity of the contact point per unit qd_j
+                    const double on = (L.sanc >> j) & 1u ? 1.0 : 0.0;     // only the joints the sphere's link hangs on
+                    o[j] = on * (dot3(nrm, c3) + dot3(nrm, Sv[j]));
+                    of[j] = on * (dot3(tdir, c3) + dot3(tdir, Sv[j]));
+                }
+                d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
+                df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction && L.smu > 0.0) ? 1.0 : 0.0; df[5] = L.smu;
+            }
+        };
+        if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
+        if (lim_hi) put_limit(s_hi, -1.0, pen_hi);
+        if (c_cap) put_contact(s_cap, n_cap, d_cap, true);
+        if (c_base) put_contact(s_base, n_base, d_base, false);
+        sync_scratch();
+        nlim_w = 0; ngen_w = 0;
+        for (int k = 0; k < kNGen; k++) { if (wany(k < nlim)) nlim_w = k + 1; if (wany(k < ngen)) ngen_w = k + 1; }
+        // ---- the own bank-B row (slot == lane): scalars
+        const double *myd = sc + SC_DEF + L.l * kDefDoubles;
+        const bool own_on = myd[4] != 0.0;
+        const bool mine_f = own_on && L.l >= kNGen;
+        const double own_jb = own_on ? myd[0] : 0.0;
+        // ---- W J of every active slot: joint lane k computes (W J_s)_k = its coupling a_{k,s}; button lanes jb wb Jb_s
+        double aAB[kNB];                                // unscaled couplings of the own bank-A row to the bank-B rows
+#pragma unroll
+        for (int s = 0; s < kNB; s++) {
+            const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+            double wjk = 0.0;
+            if (used) {
+                const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
+                const double act = ds[4], jbs = ds[0];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) wjk = fma(W[j], Js[j] * act, wjk);
+                if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
+                else wjk = is_button ? r.jb * wb * jbs * act : 0.0;
+            }
+            aAB[s] = wjk;
+        }
+        sync_scratch();
+        double qall[NJ];
+        ball_step<0, NJ>(qd_new, qall);
+        b.on = own_on; b.fric = mine_f; b.jb = own_jb; b.mu = mine_f ? myd[5] : 0.0;
+        b.normal = mine_f ? L.l - kNGen : L.l;
+        b.lo = 0.0; b.hi = (own_on && !mine_f) ? myd[3] : 0.0;
+        {
+            const double *Jr = sc + SC_J + L.l * NJ, *wjr = sc + SC_WJ + L.l * NJ;
+            double diag = own_jb * own_jb * wb, jv = own_jb * e.bqd, offb = own_jb * wb * (-bound_bm);
+            double wjo[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const double Jj = own_on ? Jr[j] : 0.0;
+                wjo[j] = own_on ? wjr[j] : 0.0;
+                diag = fma(Jj, wjo[j], diag); jv = fma(Jj, qall[j], jv); offb = fma(wjo[j], loall[j], offb);
+            }
+            const bool live = own_on && diag > 0.0;
+            b.inv_diag = live ? 1.0 / diag : 0.0;
+            if (!live) b.on = false;
+            // (desired - J v + position term) / a_rr, minus what the bank-A rows contribute at their lower bounds
+            const double des = (own_on && !mine_f) ? myd[1] : 0.0, perr = (own_on && !mine_f) ? myd[2] : 0.0;
+            b.cs = ((des - jv) + perr - offb) * b.inv_diag;
+            // couplings of the own bank-B row to the bank-A rows j (in u units: a_rj S_j) and to the bank-B rows s
+#pragma unroll
+            for (int j = 0; j < GL; j++) {
+                double a = 0.0;
+                if (j < NJ) a = wjo[j < NJ ? j : 0];
+                else if (j == kBM || j == kBLo) a = own_jb * wb;
+                else if (j == kBHi) a = -own_jb * wb;
+                sc[SC_NBA + j * GL + L.l] = -a * Sall[j] * b.inv_diag;
+            }
+#pragma unroll
+            for (int s = 0; s < kNB; s++) {
+                const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+                double a = 0.0;
+                if (used && s != L.l) {
+                    const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
+                    a = own_jb * wb * ds[0] * ds[4];
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ws[j], a);
+                }
+                sc[SC_NBB + s * GL + L.l] = -a * b.inv_diag;
+            }
+        }
+        // scaled couplings of the own bank-A row to bank B: -a / (a_rr S_r)
+        {
+            const bool liveA = r.S > 0.0 && r.diag > 0.0;
+            const double invA = liveA ? 1.0 / (r.diag * r.S) : 0.0;
+#pragma unroll
+            for (int s = 0; s < kNB; s++) sc[SC_NAB + s * GL + L.l] = -aAB[s] * invA;
+        }
+        on_lim = b.on && L.l < nlim; on_con = b.on && !on_lim;
+        sync_scratch();
+    }
+    // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
+    {
+        const bool live = r.S > 0.0 && r.diag > 0.0;
+        const double inv = live ? rcp(r.diag * r.S) : 0.0;
+        r.cs = live ? (rhs - off) * inv + ((L.jnt || is_bm) ? 0.5 : 0.0) : 0.0;
+#pragma unroll
+        for (int k = 0; k < GL; k++) r.n[k] = -(a_own[k] * Sall[k]) * inv;
+        // lambda starts at 0, i.e. u_k = -lo_k / S_k = 1/2 for the symmetric rows: what motor row l sees of the motor rows behind it
+        // during the first sweep (the button motor couples to no row that comes before it)
+        r.acc0 = 0.0;
+        if (L.jnt) {
+#pragma unroll
+            for (int k = 0; k < NJ; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
+        }
+    }
+    double u;
+    if (!any_generic) u = sweeps_free(L, r);
+    else {
+        // general path, Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
+        // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept
+        // before any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
+        const double *sc = scratch;
+        double accA = 0.0, accB = 0.0, uA = 0.0;
+#pragma unroll
+        for (int k = 0; k < GL; k++) {
+            const double u0 = Sall[k] > 0.0 ? -loall[k] / Sall[k] : 0.0;
+            accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
+        }
+        for (int it = 0; it < kSolverIters; it++) {
+            gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
+            gen_rowA<3>(L, r, sc, accA, accB, uA);  gen_rowA<4>(L, r, sc, accA, accB, uA);  gen_rowA<5>(L, r, sc, accA, accB, uA);
+            gen_rowA<6>(L, r, sc, accA, accB, uA);  gen_rowA<7>(L, r, sc, accA, accB, uA);  gen_rowA<8>(L, r, sc, accA, accB, uA);
+            gen_rowA<9>(L, r, sc, accA, accB, uA);  gen_rowA<10>(L, r, sc, accA, accB, uA); gen_rowA<11>(L, r, sc, accA, accB, uA);
+            gen_rowA<kBM>(L, r, sc, accA, accB, uA);
+            // a slot index is a limit row in one env of the wavefront and a contact row in another: `part` keeps every row in its phase
+            for (int s = 0; s < nlim_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_lim ? 1.0 : 0.0, s) != 0.0);
+            gen_rowA<kBLo>(L, r, sc, accA, accB, uA); gen_rowA<kBHi>(L, r, sc, accA, accB, uA);
+            for (int s = 0; s < ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
+            for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
+        }
+        u = uA;
+    }
+    const double lam = r.lo + r.S * u;
+    SRL_GDBG(5, L.l, lam);
+    // ---- velocity change: joint lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
+    double dv = 0.0, dvb = 0.0;
+    {
+        const double v = r.S > 0.0 ? lam / r.S : 0.0, pb = r.jb * lam * wb;
+        double acc = 0.0;
+#define SRL_ACC(K) fmac_bcast<K>(acc, v, r.n[K]);
+        SRL_ACC(0) SRL_ACC(1) SRL_ACC(2) SRL_ACC(3) SRL_ACC(4) SRL_ACC(5) SRL_ACC(6) SRL_ACC(7) SRL_ACC(8) SRL_ACC(9) SRL_ACC(10) SRL_ACC(11)
+#undef SRL_ACC
+        dvb = bcast<kBM>(pb) + bcast<kBLo>(pb) + bcast<kBHi>(pb);
+        if (any_generic) {
+            const double *sc = scratch;
+            const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
+            for (int s = 0; s < kNB; s++) {
+                const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
+                if (!used) continue;
+                acc = fma(sc[SC_NAB + s * GL + L.l], shfl(b.on ? b.lam : 0.0, s), acc);
+                dvb += shfl(pbb, s);
+            }
+            sync_scratch();                          // scratch is reused by the next step
+        }
+        dv = r.diag * (lam - r.S * acc);
+    }
+    // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position
+    if (L.jnt) { g.qd = qd_new + dv; g.q += dt * g.qd; }
+    e.bqd += dvb;
+    e.bq += dt * e.bqd;
+    trefresh(L, g, e);
+}
+
+// ------------------------------------------------------------------ env level (mirrors kuka_group.hpp / kuka_env.hpp)
+// packed start state: q12 qd12 sq12 cq12 ee3 bq bqd grip3
+SRL_G void tunpack_start(Env &e, GState &g, const TLane &L, const double *o) {
+    if (L.jnt) { g.q = o[L.l]; g.qd = o[NJ + L.l]; g.sq = o[2 * NJ + L.l]; g.cq = o[3 * NJ + L.l]; }
+    else { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = o[4 * NJ + k]; e.grip[k] = o[4 * NJ + 5 + k]; }
+    e.bq = o[4 * NJ + 3]; e.bqd = o[4 * NJ + 4];
+}
+SRL_G void tpack_start(const Env &e, const GState &g, const TLane &L, double *o) {
+    if (L.jnt) { o[L.l] = g.q; o[NJ + L.l] = g.qd; o[2 * NJ + L.l] = g.sq; o[3 * NJ + L.l] = g.cq; }
+    if (L.l == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[4 * NJ + k] = e.ee[k]; o[4 * NJ + 5 + k] = e.grip[k]; }
+        o[4 * NJ + 3] = e.bq; o[4 * NJ + 4] = e.bqd;
+    }
+}
+// state right after loadSDF / resetJointState (kuka.py:56-73): all joints at joint_positions, IK target at its initial value
+SRL_G void tinitial(Env &e, GState &g, const TLane &L) {
+    g.q = L.jnt ? L.q0 : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
+    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z; e.bspeed = 0.0;
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0; e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    trefresh(L, g, e);
+}
+
+// KukaButtonGymEnv.reset for one lane group: the reference's draws in its order (reset_draw), then the episode's start state.
+// START = 0: from the start-state table (Cartesian action modes: the 500 settle steps are RNG- and contact-free and each of the
+// five init actions is one of 6 (2) noise-free moves, so an episode starts from one of 6^5 (2^5) states, integrated once per
+// handle); START = 1: joint-space actions — the five init actions are integrated here from the settled state; START = 2: Cartesian
+// modes without a table (the CPU harness): the same five moves integrated from the settled state.
+template <int START, class R>
+SRL_G void tenv_reset(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
+                      double *objs, int64_t objs_stride) {
+#pragma clang fp contract(off)
+    ResetDraw d;
+    reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
+    tunpack_start(e, g, L, START ? settled : starts + (int64_t)d.idx * kTreeStartDoubles);
+    e.bx = d.bx; e.by = d.by; e.bz = L.base_z;
+    tfk(L, g);
+    if constexpr (START == 1) {
+        const double motor[3] = {0, 0, 0};
+        for (int k = 0; k < kNInitActions; k++) {
+            const double jt = L.q0 + kDeltaTheta * d.g[k];
+            tphysics_step(e, g, L, cfg, scratch, motor, true, jt, 0.0);
+        }
+    } else if constexpr (START == 2) {
+        const int base = cfg.is_discrete ? 6 : 2;
+        int rem = d.idx;
+        double motor[3];
+        for (int k = 0; k < kNInitActions; k++) {
+            init_action_motor(cfg, rem % base, motor);
+            tphysics_step(e, g, L, cfg, scratch, motor, false, L.q0, 0.0);
+            rem /= base;
+        }
+    }
+    reset_finish<1>(e, d, L.base_z);
+}
+
+// KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
+// finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
+template <class R>
+SRL_G double tenv_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done) {
+    StepCmd c;
+    step_command(e, cfg, rng, action, ca3, c);
+    const double jt = joint_target(c, ca_own, L.q0);
+    for (int rep = 0; rep < cfg.action_repeat; rep++) {
+        tphysics_step(e, g, L, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
+        if (termination(e, cfg)) break;
+        e.counter += 1;
+    }
+    const double reward = reward_fn(e, cfg);
+    *done = termination(e, cfg);
+    return reward;
+}
+
+}  // namespace tree
+}  // namespace kuka
+}  // namespace srl

@@ -70,3 +70,24 @@ def default_model():
     t = np.zeros(kuka_clib.MODEL_DOUBLES)
     lib().hostcheck_kuka_default_model(t.ctypes.data_as(ctypes.c_void_p))
     return kuka_clib.model_to_dict(t)
+
+
+def tree_rollout(seeds, T, actions=None, **kw):
+    """Same, computed by the FULL-model lane-group stepper (csrc/kuka_tree.hpp: 12-DoF gripper tree, contact spheres per link,
+    friction rows) under the fiber harness; compare with oracle.kuka_clib.rollout after kuka_clib.set_full(True)."""
+    l = lib()
+    l.hostcheck_kuka_tree_rollout.argtypes = l.hostcheck_kuka_rollout.argtypes
+    fake = types.SimpleNamespace(kuka_oracle_rollout=l.hostcheck_kuka_tree_rollout)
+    real = kuka_clib._lib
+    kuka_clib._lib = lambda: fake
+    try:
+        return kuka_clib.rollout(seeds, T, actions=actions, **kw)
+    finally:
+        kuka_clib._lib = real
+
+
+def tree_default_model():
+    import numpy as np
+    t = np.zeros(506)
+    lib().hostcheck_kuka_tree_default_model(t.ctypes.data_as(ctypes.c_void_p))
+    return t
