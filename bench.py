@@ -47,6 +47,8 @@ def parse():
                     help="kuka_pixels: frame side (64 = BASELINE config 4, fused encoder; 224 = the reference's RENDER size, layered encoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
+    ap.add_argument("--kuka-model", default="full", choices=["full", "lumped"],
+                    help="full = the 12-DoF arm + gripper tree of kuka_with_gripper2.sdf (library default); lumped = the rounds 1-2 approximation")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short BASELINE config 2 (mobile) and config 4 (kuka_pixels) runs nested under \"secondary\"")
     return ap.parse_args()
@@ -97,7 +99,7 @@ def measured_traffic(kernel, env_steps_per_launch):
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
 
 
-def cpu_baseline(workload, n_envs, budget_s=12.0):
+def cpu_baseline(workload, n_envs, budget_s=12.0, full=True):
     """Oracle ('port') timed on this box's host cores, rank 0, N=1 only."""
     from oracle import clib
     if workload == "mobile":
@@ -113,7 +115,7 @@ def cpu_baseline(workload, n_envs, budget_s=12.0):
         base["c_port_1_thread_env_steps_per_s"] = reps * T * n_envs / (time.perf_counter() - t0)
         return base
     from oracle import kuka_clib
-    return kuka_clib.cpu_baseline(10.0)
+    return kuka_clib.cpu_baseline(10.0, full=full)
 
 
 def pixel_cpu_baseline(enc, env, budget_s=3.0, phys=None):
@@ -260,6 +262,7 @@ def pmc_issue_util(kernel, avg_launch_s, clock_hz=2.4e9):
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kuka_pmc_SQ_WAVES.csv")))
+    files = [f for f in files if any(row["kernel"] == kernel for row in csv.DictReader(open(f)))]      # a summary that saw THIS kernel
     if not files:
         return None
     c = {}
@@ -289,6 +292,8 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, local_rank, first_env_id, 0
     cfg.rng_mode = _lib.RNG_PHILOX if args.rng == "philox" else _lib.RNG_MT19937
     cfg.auto_reset, cfg.io_device = 1, 1
+    if workload == "kuka":
+        cfg.kuka_model = _lib.KUKA_MODEL_FULL if args.kuka_model == "full" else _lib.KUKA_MODEL_LUMPED
     h = _lib.Handle(cfg)                  # raises SrlHipError when the library / GPU is missing: no fallback workload
     od = h.obs_dim
     obs0 = torch.zeros((n, od), dtype=torch.float32, device=dev)
@@ -347,7 +352,7 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     steps_per_launch = n * inner
     avg_launch_s = kernel_ms * 1e-3 / K
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
-    kernel = "mobile_rollout_ep_k" if workload == "mobile" else ("kuka_group_rollout_k" if h.kuka_kernel() == "group" else "kuka_rollout_k")
+    kernel = "mobile_rollout_ep_k" if workload == "mobile" else {"tree": "kuka_tree_rollout_k", "group": "kuka_group_rollout_k", "lane": "kuka_rollout_k"}[h.kuka_kernel()]
     traffic = None
     if n == 4096 and inner == 2048:       # geometry the PMC passes were taken at
         traffic = measured_traffic(kernel, steps_per_launch)
@@ -364,8 +369,9 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
             roofline["physical_hbm_frac"] = roofline["physical_hbm_gbs"] / HBM_PEAK_GBS
     else:
         from srlhip import kuka_model
-        group = h.kuka_kernel() == "group"
-        flops = kuka_model.FLOPS_PER_ENV_STEP_GROUP if group else kuka_model.FLOPS_PER_ENV_STEP
+        kk = h.kuka_kernel()
+        group = kk != "lane"
+        flops = {"tree": kuka_model.FLOPS_PER_ENV_STEP_TREE, "group": kuka_model.FLOPS_PER_ENV_STEP_GROUP, "lane": kuka_model.FLOPS_PER_ENV_STEP}[kk]
         tf = flops * steps_per_launch / avg_launch_s / 1e12
         # the Kuka stepper is bounded by the float64 vector pipe (issue rate / dependency latency of the 150 Gauss-Seidel
         # sweeps), so `frac` is the FP64-VALU fraction; the HBM fraction the north star asks for rides along
@@ -373,7 +379,7 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
                     "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": kernel,
                     "avg_launch_ms": avg_launch_s * 1e3, "flops_per_env_step": flops,
                     "flops_source": "srlhip/kuka_model.py: algorithmic float64 operations of the row set the {} kernel "
-                                    "integrates (FMA = 2)".format("lane-group" if group else "lane-per-env"),
+                                    "integrates (FMA = 2)".format({"tree": "tree lane-group (full 12-DoF model)", "group": "lane-group", "lane": "lane-per-env"}[kk]),
                     "hbm_achieved_gbs": achieved_gbs, "hbm_frac": achieved_gbs / HBM_PEAK_GBS,
                     "alg_bytes_per_env_step": ALG_BYTES[workload], "env_steps_per_launch": steps_per_launch,
                     "launch_geometry": "16 lanes per env, 1 wavefront per workgroup: {} wavefronts".format((n + 3) // 4)
@@ -401,14 +407,14 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
         "roofline": roofline,
     }
     if workload == "kuka":
-        line["config"]["kuka_model"] = h.kuka_model_name() if hasattr(h, "kuka_model_name") else "lumped-gripper"
+        line["config"]["kuka_model"] = h.kuka_model_name()
     if world > 1:
         torch.cuda.synchronize()
         line["config"]["episode_returns_allgathered"] = {"count": int(gathered.numel()), "mean": float(gathered.mean().item()),
                                                          "collective": "all_gather_into_tensor float32[{}] per rank, once per rollout ({})".format(n, backend)}
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(workload, n)
+            line["cpu_baseline"] = cpu_baseline(workload, n, full=args.kuka_model == "full")
             line["cpu_baseline"]["host"] = "{} logical cores".format(os.cpu_count())
         except Exception as exc:      # the checker must never sink the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(exc)}

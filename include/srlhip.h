@@ -63,6 +63,17 @@ extern "C" {
 #define SRLHIP_OBS_JOINTS_POSITION  2  /* Kuka only: 3 + 14                      */
 #define SRLHIP_OBS_RAW_PIXELS       3  /* u8[H,W,3(6)] from the tile rasteriser  */
 
+/* ---- Kuka body model: what loadSDF("kuka_iiwa/kuka_with_gripper2.sdf") (kuka.py:60) becomes ------------------
+ * FULL   : the 12-DoF tree — arm J0..J6, gripper_to_arm, two fingers, two finger tips — every joint driven by the
+ *          POSITION_CONTROL motor the reference commands each step (kuka.py:167-187: arm 200 N·m / 0.35 rad/s, joint 7
+ *          200, fingers 2 / 2.5, tips 2), contact spheres on links 5..11, one friction row per contact.  Stepped by the
+ *          tree lane-group kernel (csrc/kuka_tree.hpp) at every batch size.  KukaButton / MovingButton / RandButton.
+ * LUMPED : rounds 1-2 — the gripper welded to link_7 (7 DoF), six gripper spheres, frictionless contacts.  Kept for
+ *          Kuka2ButtonGymEnv (not yet ported to the tree kernel) and as the cheaper approximation (profiles/r03_kuka_model_gap.json
+ *          measures what it costs: 0.02 rad on the arm joints, different reward / done planes). */
+#define SRLHIP_KUKA_MODEL_LUMPED 0
+#define SRLHIP_KUKA_MODEL_FULL   1
+
 /* ---- random-number modes ------------------------------------------------- */
 #define SRLHIP_RNG_HOST     0  /* caller supplies every random draw (parity harness)        */
 #define SRLHIP_RNG_PHILOX   1  /* device Philox4x32-10 keyed (seed, global env id): throughput */
@@ -93,6 +104,8 @@ typedef struct srlhip_config {
                                  observation of the next episode (SB VecEnv semantics,
                                  rl_baselines/utils.py:216-220); needs rng_mode != HOST     */
     int32_t io_device;        /* 0 host pointers, 1 device pointers (see Conventions)      */
+    int32_t kuka_model;       /* SRLHIP_KUKA_MODEL_* (Kuka envs; srlhip_default_config picks FULL where it exists) */
+    int32_t reserved0;        /* 0                                                         */
     int64_t seed0;            /* base seed: env i is seeded seed0 + first_env_id + i       */
     double  max_distance;     /* ctor kwarg max_distance                                   */
 } srlhip_config;
@@ -176,6 +189,8 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_KUKA_BUTTON2_XY 25 /* f64[2]  Kuka2Button: second button base position */
 #define SRLHIP_F_KUKA_GOAL      26  /* i32[2]  Kuka2Button: goal_id, n_contacts[1] (n_contacts[0] is COUNTERS[0]) */
 #define SRLHIP_F_KUKA_OBJECTS   27  /* f64[30] KukaRandButton: (x, y, present) of the ten distractor objects */
+#define SRLHIP_F_KUKA_GRIPPER_Q 28  /* f64[5]  full model: joints 7, 8, 10, 11, 13 (gripper_to_arm, left finger, left tip, right finger, right tip) */
+#define SRLHIP_F_KUKA_GRIPPER_QD 29 /* f64[5]  their velocities */
 int srlhip_get_state(srlhip_handle h, int32_t field, void *out);
 int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
 /* Zero-copy hand-off of a field's device array (e.g. to torch via
@@ -236,7 +251,32 @@ typedef struct srlhip_kuka_model {
 int srlhip_kuka_default_model(srlhip_kuka_model *m);
 int srlhip_set_kuka_model(srlhip_handle h, const srlhip_kuka_model *m);
 
-/* Which kernel steps this Kuka handle's batch: 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 12288
+/* The full model as data (SRLHIP_KUKA_MODEL_FULL): a kinematic tree of up to 12 revolute DoFs, parents before children.
+ * Integer-valued fields are stored as doubles so that the struct is a flat table of 506 doubles.  Per DoF: parent (-1 = the fixed
+ * base at kuka.py:63's pose), joint frame in the parent link (origin, fixed rotation Rj row-major: child = Rj * Rot(axis, q)),
+ * unit axis in the joint frame, limits (lower > upper = none), damping, link mass / centre of mass / inertia about it in link axes
+ * (xx xy xz yy yz zz; fixed-joint children are merged in exactly), the joint's POSITION_CONTROL motor (positionGain, force,
+ * maxVelocity; velocityGain is 1), the pybullet joint index.  Then the IK end-effector link / point (kuka_end_effector_index 6),
+ * the getArmPos() link / point (kuka_gripper_index 8: its COM), up to 16 collision spheres (link, centre, radius, combined lateral
+ * friction), table / button-base heights, the per-step budget of limit + contact-normal rows (<= 8) and the friction switch.
+ * The arm part is in-tree or pinned elsewhere (srlhip_kuka_model); the gripper part is RECALLED from kuka_with_gripper2.sdf
+ * [UNVERIFIED-MEMORY] — tests/golden/make_kuka_pybullet_golden.py overwrites it from pybullet_data when PyBullet is importable. */
+typedef struct srlhip_kuka_tree_joint {
+    double parent, xyz[3], Rj[9], axis[3], lower, upper, damping, mass, com[3], inertia[6], kp, max_force, max_vel, joint_index;
+} srlhip_kuka_tree_joint;
+typedef struct srlhip_kuka_tree_sphere { double link, c[3], r, mu; } srlhip_kuka_tree_sphere;
+typedef struct srlhip_kuka_tree_model {
+    double nd;
+    srlhip_kuka_tree_joint j[12];
+    double ee_link, ee_point[3], grip_link, grip_point[3], nsphere;
+    srlhip_kuka_tree_sphere s[16];
+    double table_top_z, button_base_z, max_generic_rows, friction;
+} srlhip_kuka_tree_model;
+int srlhip_kuka_tree_default_model(srlhip_kuka_tree_model *m);                   /* host only, no GPU needed */
+/* Install a table on a SRLHIP_KUKA_MODEL_FULL handle: settled state and start-state table are re-integrated; reset afterwards. */
+int srlhip_set_kuka_tree_model(srlhip_handle h, const srlhip_kuka_tree_model *m);
+
+/* Which kernel steps this Kuka handle's batch: 2 = tree lane-group (full model, kuka_tree_rollout_k: every batch size), 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 12288
  * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and Kuka2ButtonGymEnv); the environment variable
  * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs
  * (to ~1e-11 on joint positions; discrete flags identical). */

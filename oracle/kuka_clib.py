@@ -281,7 +281,18 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(budget_s=10.0, n_envs=None, subproc=True):
+def cpu_baseline(budget_s=10.0, n_envs=None, subproc=True, full=True):
+    was_full = is_full()
+    set_full(full)           # the model the GPU path integrates by default (forked subproc workers inherit it)
+    try:
+        res = _cpu_baseline(budget_s, n_envs, subproc)
+        res["kuka_model"] = "full 12-DoF gripper tree" if full else "lumped gripper (7 DoF)"
+        return res
+    finally:
+        set_full(was_full)
+
+
+def _cpu_baseline(budget_s=10.0, n_envs=None, subproc=True):
     """bench.py's cpu_baseline leg (rank 0, N=1): the oracle timed on the host cores, two ways.
     value   = OpenMP over envs, T = 2048 steps per env with auto-reset inside (SURVEY 8(d) rollout length); the 500 RNG-free
               settle steps are integrated once per pass and cached, a reset then costs its 5 init-action steps — the most

@@ -154,6 +154,9 @@ int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
     cfg->auto_reset = 1;
     cfg->max_distance = env_kind >= SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
     if (env_kind == SRLHIP_ENV_KUKA_2BUTTON) { cfg->max_distance = 2.0; cfg->force_down = 0; }   // kuka_2button_gym_env.py:29
+    // the full gripper model wherever the tree kernel steps the env (Kuka2Button still runs on the lane-per-env kernel: lumped)
+    cfg->kuka_model = (env_kind == SRLHIP_ENV_KUKA_BUTTON || env_kind == SRLHIP_ENV_KUKA_MOVING || env_kind == SRLHIP_ENV_KUKA_RAND)
+                          ? SRLHIP_KUKA_MODEL_FULL : SRLHIP_KUKA_MODEL_LUMPED;
     return 0;
 }
 
@@ -191,6 +194,13 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     // LDS band holds one image row of at most 2048 pixels
     if (cfg->img_h < 8 || cfg->img_w < 8 || cfg->img_h > 1024 || cfg->img_w > 1024) {
         g_create_error = "create: img_h / img_w must be in [8, 1024]"; return SRLHIP_EINVAL;
+    }
+    if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->kuka_model != SRLHIP_KUKA_MODEL_LUMPED && cfg->kuka_model != SRLHIP_KUKA_MODEL_FULL) {
+        g_create_error = "create: unknown kuka_model"; return SRLHIP_EINVAL;
+    }
+    if (cfg->env_kind == SRLHIP_ENV_KUKA_2BUTTON && cfg->kuka_model == SRLHIP_KUKA_MODEL_FULL) {
+        g_create_error = "create: Kuka2ButtonGymEnv is stepped with the lumped-gripper model only (kuka_model = SRLHIP_KUKA_MODEL_LUMPED)";
+        return SRLHIP_ENOTSUP;
     }
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
         g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;
@@ -448,7 +458,7 @@ int srlhip_set_state(srlhip_handle hh, int32_t field, const void *in) {
     if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     SRL_HIP_CHECK(h, hipMemcpy(d, in, elem * count * (size_t)h->n, hipMemcpyHostToDevice));
-    if (field == SRLHIP_F_KUKA_Q) return kuka_refresh(h);        // derived planes: sin/cos of q, gripper position
+    if (field == SRLHIP_F_KUKA_Q || field == SRLHIP_F_KUKA_GRIPPER_Q) return kuka_refresh(h);        // derived planes: sin/cos of q, gripper position
     return 0;
 }
 
@@ -515,6 +525,32 @@ int srlhip_set_kuka_model(srlhip_handle hh, const srlhip_kuka_model *m) {
         if (!(m->mass[i] > 0.0) || !(m->inertia[i][0] > 0.0) || !(m->inertia[i][1] > 0.0) || !(m->inertia[i][2] > 0.0) || !(m->joint_lower[i] < m->joint_upper[i]))
             return h->fail(SRLHIP_EINVAL, "set_kuka_model: masses and principal inertias must be positive, joint_lower < joint_upper");
     return kuka_set_model(h, reinterpret_cast<const double *>(m));
+}
+
+int srlhip_kuka_tree_default_model(srlhip_kuka_tree_model *m) {
+    if (!m) return SRLHIP_EINVAL;
+    kuka_default_tree_model(reinterpret_cast<double *>(m));
+    return 0;
+}
+
+int srlhip_set_kuka_tree_model(srlhip_handle hh, const srlhip_kuka_tree_model *m) {
+    if (!hh || !m) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: not a Kuka handle");
+    if (h->cfg.kuka_model != SRLHIP_KUKA_MODEL_FULL) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: the handle was created with the lumped model");
+    const int nd = (int)m->nd, ns = (int)m->nsphere;
+    if (nd < 7 || nd > 12 || ns < 0 || ns > 16 || (int)m->ee_link != 6 || (int)m->grip_link < 0 || (int)m->grip_link >= nd)
+        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: 7..12 DoFs, <= 16 spheres, end effector = link 6");
+    for (int i = 0; i < nd; i++) {
+        const srlhip_kuka_tree_joint &J = m->j[i];
+        const double a2 = J.axis[0] * J.axis[0] + J.axis[1] * J.axis[1] + J.axis[2] * J.axis[2];
+        if (!((int)J.parent < i && (int)J.parent >= -1) || !(J.mass > 0) || !(J.inertia[0] > 0 && J.inertia[3] > 0 && J.inertia[5] > 0) ||
+            !(a2 > 0.999999 && a2 < 1.000001) || !(J.max_force > 0) || !(J.kp > 0))
+            return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: parents before children, positive masses / inertias / motor gains, unit axes");
+        if (i < 7 && ((int)J.parent != i - 1)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: DoFs 0..6 must be the serial arm");
+    }
+    for (int k = 0; k < ns; k++) if ((int)m->s[k].link < 0 || (int)m->s[k].link >= nd || !(m->s[k].r > 0)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: bad sphere");
+    return kuka_set_tree_model(h, reinterpret_cast<const double *>(m));
 }
 
 int srlhip_kuka_kernel(srlhip_handle hh) {

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "kuka_device.hpp"
+#include "kuka_tree.hpp"
 
 namespace srl {
 using namespace kuka;
@@ -228,6 +229,18 @@ int kuka_alloc(Handle *h) {
         SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
     s->custom_model = 0;
+    s->full = h->cfg.kuka_model == SRLHIP_KUKA_MODEL_FULL ? 1 : 0;
+    s->tmodel = nullptr; s->tsettled = nullptr; s->tstarts = nullptr;
+    if (s->full) {
+        // the full model has its own table, settled state and start-state table; the lane-per-env kernels below are not used
+        if ((rc = h->dalloc(&s->tmodel, 1)) || (rc = h->dalloc(&s->tsettled, tree::kTreeStartDoubles)) ||
+            (rc = h->dalloc(&s->tstarts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * tree::kTreeStartDoubles)))
+            return rc;
+        TreeModel tm; default_tree_model(tm);
+        SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, &tm, sizeof tm, hipMemcpyHostToDevice, h->stream));
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        return kuka_tree_settle(h, params_of(h));
+    }
     if ((rc = allow_lds(h, kuka_settle_k)) || (rc = allow_lds(h, kuka_starts_k))) return rc;
 #define SRL_ALLOW(NB)                                                                                                     \
     if ((rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_HOST, NB>)) || (rc = allow_lds(h, kuka_reset_k<SRLHIP_RNG_PHILOX, NB>)) ||     \
@@ -253,6 +266,10 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
     dim3 grid((h->n + kWave - 1) / kWave), block(kWave);
     const int stride = kuka_reset_rand_count(h->cfg);
     float *obs = static_cast<float *>(d_obs);
+    if (h->kuka->full) {
+        if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
+        return kuka_tree_reset(h, p, d_mask, d_host_rand, stride, obs);
+    }
     if (h->kuka->custom_model) {
         if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !d_host_rand) return h->fail(SRLHIP_EINVAL, "reset: RNG_HOST needs host_rand");
         return kuka_group_reset_table(h, p, d_mask, d_host_rand, stride, obs);
@@ -280,6 +297,7 @@ int kuka_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, void
 // Which kernel steps a batch: the lane-group kernel fills the chip at small batches (16 lanes per env), the lane-per-env
 // kernel does less total work per env once every SIMD has several wavefronts anyway.  SRLHIP_KUKA_KERNEL=group|lane forces one.
 static bool use_group_kernel(const Handle *h) {
+    if (h->kuka->full) return true;                                      // the tree lane-group kernel, every batch size
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return false;        // the lane-group kernel has no two-button form
     if (h->kuka->custom_model) return true;                              // only the lane-group kernel reads the runtime model table (the override below cannot undo that)
     const char *v = getenv("SRLHIP_KUKA_KERNEL");                        // read per call: tests and probes flip it inside one process
@@ -289,6 +307,7 @@ static bool use_group_kernel(const Handle *h) {
 
 // srlhip_set_kuka_model: install a runtime model table; the settled state is re-integrated with it.  Envs must be reset afterwards.
 int kuka_set_model(Handle *h, const double *table138) {
+    if (h->kuka->full) return h->fail(SRLHIP_EINVAL, "set_kuka_model: this handle integrates the full model (srlhip_set_kuka_tree_model)");
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return h->fail(SRLHIP_ENOTSUP, "set_kuka_model: Kuka2ButtonGymEnv is stepped by the lane-per-env kernel, which is specialised for the baked model");
     KukaState *s = h->kuka;
     SRL_HIP_CHECK(h, hipMemcpyAsync(s->model, table138, sizeof(Model), hipMemcpyHostToDevice, h->stream));
@@ -299,10 +318,20 @@ int kuka_set_model(Handle *h, const double *table138) {
 }
 void kuka_default_model(double *table138) { Model m; default_model(m); memcpy(table138, &m, sizeof m); }
 
-int kuka_uses_group_kernel(const Handle *h) { return use_group_kernel(h) ? 1 : 0; }
+int kuka_uses_group_kernel(const Handle *h) { return h->kuka->full ? 2 : use_group_kernel(h) ? 1 : 0; }
+
+// srlhip_set_kuka_tree_model: install a full-model table; settled state and start table are re-integrated.  Envs must be reset afterwards.
+int kuka_set_tree_model(Handle *h, const double *table506) {
+    KukaState *s = h->kuka;
+    SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, table506, sizeof(TreeModel), hipMemcpyHostToDevice, h->stream));
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return kuka_tree_settle(h, params_of(h));
+}
+void kuka_default_tree_model(double *table506) { TreeModel m; default_tree_model(m); memcpy(table506, &m, sizeof m); }
 
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {
+    if (h->kuka->full) return kuka_tree_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
     return h->kuka->custom_model ? kuka_group_launch_table(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
                                  : kuka_group_launch_baked(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
 }
@@ -369,6 +398,12 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
 }
 
 int kuka_refresh(Handle *h) {
+    if (h->kuka->full) {
+        int rc = kuka_tree_refresh(h, params_of(h));
+        if (rc) return rc;
+        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
     hipLaunchKernelGGL(kuka_refresh_k, dim3((h->n + 63) / 64), dim3(64), 0, h->stream, *h->kuka, h->n);
     SRL_HIP_CHECK(h, hipGetLastError());
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -393,6 +428,8 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_BUTTON2_XY: *dptr = s->d + D_B2X * n; *count = 2; return 0;
         case SRLHIP_F_KUKA_GOAL: *dptr = s->i + I_GOAL * n; *elem = 4; *count = 2; return 0;
         case SRLHIP_F_KUKA_OBJECTS: *dptr = s->objs; *count = 30; return 0;
+        case SRLHIP_F_KUKA_GRIPPER_Q: *dptr = s->d + D_GQ * n; *count = 5; return 0;
+        case SRLHIP_F_KUKA_GRIPPER_QD: *dptr = s->d + D_GQD * n; *count = 5; return 0;
     }
     return h->fail(SRLHIP_EINVAL, "unknown field for KukaButtonGymEnv");
 }

@@ -9,6 +9,7 @@
 
 #include "internal.hpp"
 #include "kuka_env.hpp"
+#include "kuka_tree_model.hpp"
 
 namespace srl {
 
@@ -16,12 +17,15 @@ namespace srl {
 using namespace kuka;
 
 constexpr int kWave = 64;
-constexpr int NDBL = 47, NINT = 9;
+constexpr int NDBL = 67, NINT = 9;
 constexpr int kGroupKernelMaxEnvs = 12288;     // batches up to this size are stepped by the lane-group kernel (measured crossover, profiles/r02_nsweep_kuka.jsonl)
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
 enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32, D_BX = 33, D_BY = 34, D_BPOS = 35, D_GRIP = 38, D_BZ = 41, D_BSPEED = 42,
-       D_B2Q = 43, D_B2QD = 44, D_B2X = 45, D_B2Y = 46 };      // second button (Kuka2ButtonGymEnv)
+       D_B2Q = 43, D_B2QD = 44, D_B2X = 45, D_B2Y = 46,        // second button (Kuka2ButtonGymEnv)
+       D_GQ = 47, D_GQD = 52, D_GSQ = 57, D_GCQ = 62 };        // full model: gripper DoFs 7..11 (q, qd, sin, cos)
+// plane of joint lane l of the full model: arm joints in the q7 planes, gripper joints behind them
+__host__ __device__ inline int tree_plane(int base_arm, int base_gripper, int l) { return l < ND ? base_arm + l : base_gripper + (l - ND); }
 // SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
 enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6, I_GOAL = 7, I_NCONTACT2 = 8 };
 
@@ -35,6 +39,11 @@ struct KukaState {
     int32_t nstarts;
     Model *model;       // runtime model table (device copy); the baked one unless srlhip_set_kuka_model() installed another
     int32_t custom_model;
+    // full model (cfg.kuka_model = SRLHIP_KUKA_MODEL_FULL, kuka_tree.hpp): its own table and start states
+    int32_t full;
+    TreeModel *tmodel;
+    double *tsettled;   // [kTreeStartDoubles]
+    double *tstarts;    // [nstarts][kTreeStartDoubles]
 };
 
 
@@ -89,5 +98,11 @@ int kuka_group_launch_table(Handle *h, const KukaParams &p, int T, const void *d
                             uint8_t *d_done, void *d_act_out);
 int kuka_group_reset_table(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
 int kuka_group_settle_table(Handle *h, const KukaParams &p);
+// full-model lane-group kernels (kuka_tree.hip)
+int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
+                     uint8_t *d_done, void *d_act_out);
+int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
+int kuka_tree_settle(Handle *h, const KukaParams &p);     // settled state + start-state table of the installed tree model
+int kuka_tree_refresh(Handle *h, const KukaParams &p);
 
 }  // namespace srl

@@ -19,7 +19,8 @@ F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REW
 F_TARGET2_X, F_TARGET2_Y = 9, 10
 F_LAST_RETURN, F_LAST_LENGTH, F_N_FINISHED = 11, 12, 13
 F_KUKA_Q, F_KUKA_QD, F_KUKA_EE_TARGET, F_KUKA_BUTTON_Q, F_KUKA_BUTTON_POS, F_KUKA_GRIPPER, F_KUKA_COUNTERS = range(16, 23)
-F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS = range(23, 28)
+F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS, F_KUKA_GRIPPER_Q, F_KUKA_GRIPPER_QD = range(23, 30)
+KUKA_MODEL_LUMPED, KUKA_MODEL_FULL = 0, 1          # srlhip_config.kuka_model
 
 _FIELD_SHAPES = {
     F_POS_X: (np.float64, 1), F_POS_Y: (np.float64, 1), F_TARGET_X: (np.float64, 1), F_TARGET_Y: (np.float64, 1),
@@ -30,6 +31,7 @@ _FIELD_SHAPES = {
     F_KUKA_BUTTON_Q: (np.float64, 2), F_KUKA_BUTTON_POS: (np.float64, 3), F_KUKA_GRIPPER: (np.float64, 3),
     F_KUKA_COUNTERS: (np.int32, 3), F_KUKA_BUTTON_XY: (np.float64, 2), F_KUKA_BUTTON2_Q: (np.float64, 2),
     F_KUKA_BUTTON2_XY: (np.float64, 2), F_KUKA_GOAL: (np.int32, 2), F_KUKA_OBJECTS: (np.float64, 30),
+    F_KUKA_GRIPPER_Q: (np.float64, 5), F_KUKA_GRIPPER_QD: (np.float64, 5),
 }
 
 EXPORTS = [
@@ -37,7 +39,7 @@ EXPORTS = [
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
-    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model",
+    "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model", "srlhip_kuka_tree_default_model", "srlhip_set_kuka_tree_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_feature_count", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
     "srlhip_encoder_phase_cycles",
@@ -46,6 +48,15 @@ EXPORTS = [
 
 
 KUKA_MODEL_DOUBLES = 138
+KUKA_TREE_MODEL_DOUBLES = 506
+
+
+def kuka_tree_default_model():
+    """The baked srlhip_kuka_tree_model (full 12-DoF gripper tree) as a flat float64[506] (no GPU needed)."""
+    t = np.zeros(KUKA_TREE_MODEL_DOUBLES)
+    rc = load().srlhip_kuka_tree_default_model(t.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return t
 
 
 def kuka_default_model():
@@ -65,6 +76,7 @@ class Config(ctypes.Structure):
         ("action_repeat", ctypes.c_int32), ("action_joints", ctypes.c_int32), ("obs_mode", ctypes.c_int32),
         ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32), ("multi_view", ctypes.c_int32),
         ("rng_mode", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("io_device", ctypes.c_int32),
+        ("kuka_model", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("seed0", ctypes.c_int64), ("max_distance", ctypes.c_double),
     ]
 
@@ -113,6 +125,8 @@ def load():
     lib.srlhip_kuka_kernel.argtypes = [vp]
     lib.srlhip_kuka_default_model.argtypes = [vp]
     lib.srlhip_set_kuka_model.argtypes = [vp, vp]
+    lib.srlhip_kuka_tree_default_model.argtypes = [vp]
+    lib.srlhip_set_kuka_tree_model.argtypes = [vp, vp]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -300,12 +314,22 @@ class Handle(object):
         assert t.shape == (KUKA_MODEL_DOUBLES,)
         self._check(self._lib.srlhip_set_kuka_model(self._h, _ptr(t)), "srlhip_set_kuka_model")
 
+    def set_kuka_tree_model(self, table):
+        """Install a full-model table (srlhip_kuka_tree_model: 506 float64) on a KUKA_MODEL_FULL handle — reset() afterwards."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        assert t.shape == (KUKA_TREE_MODEL_DOUBLES,)
+        self._check(self._lib.srlhip_set_kuka_tree_model(self._h, _ptr(t)), "srlhip_set_kuka_tree_model")
+
     def kuka_kernel(self):
-        """'group' (16 lanes per env) or 'lane' (one lane per env): the kernel that steps this Kuka batch."""
+        """'tree' (full model, 16 lanes per env), 'group' (lumped model, 16 lanes per env) or 'lane' (lumped, one lane per env):
+        the kernel that steps this Kuka batch."""
         rc = self._lib.srlhip_kuka_kernel(self._h)
         if rc < 0:
             raise SrlHipError("srlhip_kuka_kernel: not a Kuka handle")
-        return "group" if rc else "lane"
+        return {0: "lane", 1: "group", 2: "tree"}[rc]
+
+    def kuka_model_name(self):
+        return "full 12-DoF gripper tree" if self.cfg.kuka_model == KUKA_MODEL_FULL else "lumped gripper (7 DoF)"
 
     def episode_stats_device(self, last_return=0, last_length=0, n_finished=0):
         """Enqueue-only: float32 returns / int32 lengths / counts of the last finished episodes into DEVICE buffers

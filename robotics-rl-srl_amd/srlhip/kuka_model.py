@@ -149,3 +149,15 @@ def from_sdf(sdf_path, base=None):
         model["mass"][6], model["com"][6], model["inertia"][6] = m_tot, c, np.diag(I)      # off-diagonal terms dropped
     del base_T
     return model
+
+# The tree lane-group kernel (csrc/kuka_tree.hpp) integrates the FULL model: 12 DoFs (arm + gripper_to_arm + two fingers + two
+# tips), 12 motor rows.  Algorithmic float64 operations per env-step, free path (no limit / contact / friction row):
+#   150 sweeps x (12 motor rows x (1 + 2 + 11 x 2) + 3 button rows x (1 + 2 + 2 x 2))                = 48 150
+#   Gauss-Jordan inverse of the 12x12 mass matrix: 12 pivots x 12 rows x 12 columns x 2               =  3 460
+#   CRBA: composite inertias over the tree, Ic S per link, 48 ancestor pairs x 6-term dot products    =  1 400
+#   RNEA in world coordinates: per-link force ~190 x 12 (full inertia tensors), ancestor / descendant
+#   sums 27 quantities x 12 lanes x ~5 terms x 2                                                      =  5 500
+#   FK (12 frame compositions x 63 + 12 Rodrigues rotations x 45) + 12 sincos (~40 each)              =  1 780
+#   IK on the arm block (as above)                                                                    =    990
+#   row setup, 16 sphere-cylinder candidates, env logic, Philox                                       =    900
+FLOPS_PER_ENV_STEP_TREE = 6.2e4

@@ -12,10 +12,16 @@ def run():
     actions = np.random.RandomState(0).randint(6, size=(T, n)).astype(np.int32)
     obs0 = h.reset()
     out = h.rollout(T, actions=actions)
-    ora = kuka_clib.rollout(1 + np.arange(n), T, actions=actions, trace=False)
+    kuka_clib.set_full(cfg.kuka_model == _lib.KUKA_MODEL_FULL)       # the oracle integrates the model the handle integrates (default: full gripper)
+    try:
+        ora = kuka_clib.rollout(1 + np.arange(n), T, actions=actions, trace=False)
+    finally:
+        kuka_clib.set_full(False)
     q_err = np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, :7]).max()
     assert np.abs(obs0 - ora["obs0"]).max() <= 1e-4 and np.abs(out["obs"] - ora["obs"]).max() <= 1e-4
     assert q_err <= 1e-4, q_err
     assert np.array_equal(out["reward"], ora["reward"]) and np.array_equal(out["done"], ora["done"])
+    h_name, kernel = h.kuka_model_name(), h.kuka_kernel()
     h.close()
-    print("smoke: KukaButtonGymEnv-v0 x{} envs x{} steps: max|q-q_oracle|={:.2e}, reward/done bit-exact".format(n, T, q_err))
+    print("smoke: KukaButtonGymEnv-v0 ({}, kernel {}) x{} envs x{} steps: max|q-q_oracle|={:.2e}, reward/done bit-exact".format(
+        h_name, kernel, n, T, q_err))

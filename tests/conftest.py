@@ -14,6 +14,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lumped_kuka: GPU test of the lumped-gripper Kuka kernels (the oracle stays in its lumped mode)")
 
 
 def _has_gpu():
@@ -36,3 +37,19 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _kuka_oracle_model(request):
+    """The Kuka oracle integrates the model the product integrates by default: GPU tests run against the FULL 12-DoF gripper model
+    (srlhip_default_config: kuka_model = FULL for KukaButton / Moving / RandButton); a GPU test that steps the rounds 1-2
+    lumped-gripper kernels says so with @pytest.mark.lumped_kuka (or calls lumped_kuka() itself).  CPU tests keep the oracle's
+    default (lumped) unless they switch it themselves."""
+    full = "gpu" in request.keywords and "lumped_kuka" not in request.keywords
+    if full:
+        from oracle import kuka_clib
+        kuka_clib.set_full(True)
+    yield
+    if full:
+        from oracle import kuka_clib
+        kuka_clib.set_full(False)

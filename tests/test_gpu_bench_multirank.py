@@ -35,7 +35,7 @@ def test_kuka_bench_two_ranks_gather_episode_returns():
     g = line["config"]["episode_returns_allgathered"]
     assert g["count"] == 2 * 4096
     assert -1.0 <= g["mean"] <= 5.0 and g["mean"] != 0.0             # sparse Kuka returns: -1 (table / out of reach) ... +5 (button pressed)
-    assert line["value"] > 0 and line["roofline"]["kernel"] == "kuka_group_rollout_k"
+    assert line["value"] > 0 and line["roofline"]["kernel"] == "kuka_tree_rollout_k"
 
 
 def test_mobile_bench_two_ranks_under_torchrun():

@@ -4,8 +4,7 @@ simulated shards on 1)"; SURVEY 8e: seeds are seed0 + global id, so trajectories
 
 Frames, encoder states, rewards, dones and the device-side episode statistics must be bit-equal; the path's one collective
 (all-gather of per-env episode returns) is run over 8 simulated ranks with gloo on CPU tensors and must reproduce the single
-handle's plane.  Both sides are pinned to the lane-group Kuka kernel: the library would step a 32 768-env batch with the
-lane-per-env kernel, which associates its float64 sums differently (1e-11 on joints, tests/test_gpu_kuka.py)."""
+handle's plane.  Both sides run the full-model tree lane-group kernel (it steps every batch size), so bit-equality is meaningful."""
 import os
 import socket
 
@@ -34,8 +33,7 @@ def _gather_worker(rank, world, port, shards, out):
     dist.destroy_process_group()
 
 
-def test_eight_shards_equal_one_handle(monkeypatch):
-    monkeypatch.setenv("SRLHIP_KUKA_KERNEL", "group")
+def test_eight_shards_equal_one_handle():
     torch.manual_seed(0)
     dev = torch.device("cuda", 0)
     enc = SRLNeuralNetwork(3, cuda=True, img_shape=(64, 64), device=dev)
@@ -45,7 +43,7 @@ def test_eight_shards_equal_one_handle(monkeypatch):
     # just below the 1001-step limit, staggered by global env id: every env ends an episode (and auto-resets) inside the window
     counters = (1001 - 10 - (np.arange(G * PER) % 40)).astype(np.int32)
     full = PixelStateVecEnv("KukaButtonGymEnv-v0", G * PER, enc, seed=0, img_shape=(64, 64), env_kwargs=kw)
-    assert full.h.kuka_kernel() == "group"
+    assert full.h.kuka_kernel() == "tree"
     rs = np.random.RandomState(7)
     actions = torch.from_numpy(rs.randint(6, size=(T, G * PER)).astype(np.int32)).to(dev)
     st0 = full.reset().clone()

@@ -12,7 +12,7 @@ TOL = 1e-4
 
 
 def make(n, rng_mode=_lib.RNG_MT19937, auto_reset=1, seed0=0, first=0, **kw):
-    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)           # kuka_model = FULL: the tree lane-group kernel (conftest puts the oracle in the same mode)
     cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0, cfg.first_env_id = n, rng_mode, auto_reset, seed0, first
     for k, v in kw.items():
         setattr(cfg, k, v)
@@ -224,6 +224,7 @@ def test_moving_button_env():
     env.close()
 
 
+@pytest.mark.lumped_kuka
 def test_two_button_env():
     """Kuka2ButtonGymEnv-v0 on the GPU (NB = 2 kernels: second button body, goal switching) vs the oracle, whose wrapper
     logic is pinned to the reference source (tests/test_kuka_2button_golden.py).  Env 0 presses both buttons in order."""
@@ -298,14 +299,16 @@ def test_rand_button_env():
     h.close()
 
 
+@pytest.mark.lumped_kuka
 @pytest.mark.parametrize("kernel", ["lane", "group"])
 def test_both_kernels_at_the_headline_size(kernel, monkeypatch):
-    """The library picks the lane-group kernel (16 lanes per env, kuka_group.hpp) for batches up to 12288 envs and the
-    lane-per-env kernel (kuka_core.hpp) above; SRLHIP_KUKA_KERNEL forces one.  Both against the oracle at 4096 envs, in
-    the throughput mode (Philox streams, device-sampled actions), through two auto-resets per env."""
+    """Lumped-gripper model: the library picks the lane-group kernel (16 lanes per env, kuka_group.hpp) for batches up to 12288
+    envs and the lane-per-env kernel (kuka_core.hpp) above; SRLHIP_KUKA_KERNEL forces one.  Both against the oracle at 4096
+    envs, in the throughput mode (Philox streams, device-sampled actions), through two auto-resets per env."""
     monkeypatch.setenv("SRLHIP_KUKA_KERNEL", kernel)
     n, T = 4096, 1100
-    h = make(n, rng_mode=_lib.RNG_PHILOX, seed0=11)
+    h = make(n, rng_mode=_lib.RNG_PHILOX, seed0=11, kuka_model=_lib.KUKA_MODEL_LUMPED)
+    assert h.kuka_kernel() == kernel
     obs0 = h.reset()
     out = h.rollout(T)
     ora = kuka_clib.rollout(11 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False)
@@ -317,15 +320,16 @@ def test_both_kernels_at_the_headline_size(kernel, monkeypatch):
     h.close()
 
 
+@pytest.mark.lumped_kuka
 def test_kernels_agree_on_state_handover():
-    """A rollout may be continued by the other kernel: both read and write the same state planes."""
+    """Lumped model: a rollout may be continued by the other kernel — both read and write the same state planes."""
     import os
     n, T = 512, 300
     actions = np.random.RandomState(21).randint(6, size=(2 * T, n)).astype(np.int32)
     actions[np.random.RandomState(22).rand(2 * T, n) < 0.3] = 4
     outs = []
     for first, second in (("group", "lane"), ("lane", "group")):
-        h = make(n, seed0=5)
+        h = make(n, seed0=5, kuka_model=_lib.KUKA_MODEL_LUMPED)
         h.reset()
         os.environ["SRLHIP_KUKA_KERNEL"] = first
         a = h.rollout(T, actions=actions[:T])
@@ -342,8 +346,9 @@ def test_kernels_agree_on_state_handover():
         assert np.abs(q.T - ora["final_state"][:, :7]).max() <= TOL
 
 
+@pytest.mark.lumped_kuka
 def test_runtime_model_table_on_the_device():
-    """srlhip_set_kuka_model: another arm (masses, centres of mass, inertias, link lengths, joint frames, damping, gripper
+    """srlhip_set_kuka_model (lumped model): another arm (masses, centres of mass, inertias, link lengths, joint frames, damping, gripper
     geometry) installed as DATA — the lane-group kernel integrates it, the oracle with the same table agrees; the baked table
     sent through the same entry point reproduces the baked model."""
     from srlhip import kuka_model
@@ -360,7 +365,7 @@ def test_runtime_model_table_on_the_device():
     base = kuka_clib.rollout(7 + np.arange(n), T, actions=actions, trace=False)
     try:
         for table, ref in ((m0, base), (m, None)):
-            h = make(n, seed0=7)
+            h = make(n, seed0=7, kuka_model=_lib.KUKA_MODEL_LUMPED)
             h.set_kuka_model(kuka_model.to_table(table))
             assert h.kuka_kernel() == "group"
             obs0 = h.reset()
@@ -381,3 +386,72 @@ def test_runtime_model_table_on_the_device():
     with pytest.raises(_lib.SrlHipError):
         h.set_kuka_model(kuka_model.to_table(m0))
     h.close()
+
+
+def test_full_model_is_the_default_and_gripper_state_matches_the_oracle():
+    """KukaButtonGymEnv handles integrate the full 12-DoF gripper tree by default (tree lane-group kernel, every batch size):
+    arm AND gripper joints against the oracle's full mode, contact / friction steps included; set_state(GRIPPER_Q) round trip."""
+    n, T = 512, 700
+    actions = np.random.RandomState(41).randint(6, size=(T, n)).astype(np.int32)
+    actions[np.random.RandomState(42).rand(T, n) < 0.25] = 4            # press down often: contacts with friction rows
+    h = make(n, seed0=9, random_target=1)
+    assert h.cfg.kuka_model == _lib.KUKA_MODEL_FULL and h.kuka_kernel() == "tree" and kuka_clib.is_full()
+    obs0 = h.reset()
+    gq0 = h.get_state(_lib.F_KUKA_GRIPPER_Q)
+    assert np.abs(gq0[1]).max() < 0.05 and np.abs(gq0[3]).max() < 0.05      # fingers closed by the 500 settle steps (they start at -+0.3)
+    out = h.rollout(T, actions=actions)
+    ora = kuka_clib.rollout(9 + np.arange(n), T, actions=actions, random_target=True, aux=True, trace=False)
+    check_planes(ora, obs0, out)
+    assert ora["rows"][:, :, 0].sum() > 50 and ora["rows"][:, :, 1].sum() > 50          # contact normals and friction rows were exercised
+    fs = ora["final_state"]
+    assert np.abs(h.get_state(_lib.F_KUKA_Q).T - fs[:, :7]).max() <= TOL
+    assert np.abs(h.get_state(_lib.F_KUKA_GRIPPER_Q).T - fs[:, 30:35]).max() <= TOL
+    assert np.abs(h.get_state(_lib.F_KUKA_GRIPPER_QD).T - fs[:, 35:40]).max() <= 1e-3
+    g = h.get_state(_lib.F_KUKA_GRIPPER_Q).copy()
+    grip_before = h.get_state(_lib.F_KUKA_GRIPPER).copy()
+    g[1] += 0.2                                                          # open the left finger: getArmPos() is that finger's COM
+    h.set_state(_lib.F_KUKA_GRIPPER_Q, g)
+    assert np.abs(h.get_state(_lib.F_KUKA_GRIPPER) - grip_before).max() > 1e-3
+    h.close()
+    # a lumped handle of the same env: the rounds 1-2 kernels, a different trajectory
+    h2 = make(64, seed0=9, random_target=1, kuka_model=_lib.KUKA_MODEL_LUMPED)
+    assert h2.kuka_kernel() == "group"
+    h2.reset()
+    out2 = h2.rollout(100, actions=actions[:100, :64])
+    assert np.abs(out2["obs"] - out["obs"][:100, :64]).max() > 1e-3
+    h2.close()
+    cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
+    assert cfg.kuka_model == _lib.KUKA_MODEL_LUMPED
+    cfg.kuka_model = _lib.KUKA_MODEL_FULL
+    with pytest.raises(_lib.SrlHipError):
+        _lib.Handle(cfg)
+
+
+def test_full_model_runtime_table():
+    """srlhip_set_kuka_tree_model: a perturbed gripper (masses, finger motor forces, sphere radii, friction) installed as data is
+    integrated identically by the device and by the oracle with the same table."""
+    n, T = 128, 500
+    actions = np.random.RandomState(51).randint(6, size=(T, n)).astype(np.int32)
+    actions[np.random.RandomState(52).rand(T, n) < 0.3] = 4
+    t0 = _lib.kuka_tree_default_model()
+    assert np.abs(t0 - kuka_clib.get_tree_model()).max() < 1e-15         # product table == oracle table
+    t = t0.copy()
+    J = 1 + 33 * np.arange(12)                                            # first double of each joint record
+    t[J[8:] + 19] *= 1.5                                                  # masses of the finger / tip bodies
+    t[J[8] + 30] = 3.0; t[J[10] + 30] = 1.5                               # finger motor forces
+    S = 1 + 33 * 12 + 9 + 6 * np.arange(16)
+    t[S + 4] *= 1.1; t[S + 5] *= 0.5                                      # sphere radii, friction coefficients
+    try:
+        h = make(n, seed0=13)
+        h.set_kuka_tree_model(t)
+        obs0 = h.reset()
+        out = h.rollout(T, actions=actions)
+        base = kuka_clib.rollout(13 + np.arange(n), T, actions=actions, trace=False)
+        kuka_clib.set_tree_model(t)
+        ref = kuka_clib.rollout(13 + np.arange(n), T, actions=actions, trace=False)
+        assert np.abs(ref["obs"] - base["obs"]).max() > 1e-4              # it IS a different gripper
+        check_planes(ref, obs0, out)
+        assert np.abs(h.get_state(_lib.F_KUKA_GRIPPER_Q).T - ref["final_state"][:, 30:35]).max() <= TOL
+        h.close()
+    finally:
+        kuka_clib.set_full(True)                                          # rebuilds the default table
