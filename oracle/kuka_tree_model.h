@@ -148,7 +148,7 @@ static void tm_build_full(tree_model *m) {
     const tm_sdf_link *fing[2] = {&TM_L_FINGER, &TM_R_FINGER}, *fbase[2] = {&TM_L_FBASE, &TM_R_FBASE}, *tip[2] = {&TM_L_TIP, &TM_R_TIP};
     int i, k, side;
     tm_build_lumped(m);                                 /* arm joints 0..6 (frames, limits, damping, motors) */
-    m->nd = 12; m->nsphere = 0; m->max_generic_rows = 8; m->friction = 1;
+    m->nd = 12; m->nsphere = 0; m->max_generic_rows = 6; m->friction = 1;
     for (i = 0; i < TN; i++) m->joint_index[i] = jidx[i];
     tm_set_body(m, 6, &TM_LINK7, NULL);                 /* link_7 without the lumped gripper */
     /* DoF 7: gripper_to_arm (continuous, axis z), child base_link */

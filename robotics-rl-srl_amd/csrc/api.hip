@@ -539,8 +539,8 @@ int srlhip_set_kuka_tree_model(srlhip_handle hh, const srlhip_kuka_tree_model *m
     if (is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: not a Kuka handle");
     if (h->cfg.kuka_model != SRLHIP_KUKA_MODEL_FULL) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: the handle was created with the lumped model");
     const int nd = (int)m->nd, ns = (int)m->nsphere;
-    if (nd < 7 || nd > 12 || ns < 0 || ns > 16 || (int)m->ee_link != 6 || (int)m->grip_link < 0 || (int)m->grip_link >= nd)
-        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: 7..12 DoFs, <= 16 spheres, end effector = link 6");
+    if (nd != 12 || ns < 0 || ns > 16 || (int)m->max_generic_rows < 0 || (int)m->ee_link != 6 || (int)m->grip_link < 0 || (int)m->grip_link >= nd)
+        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: 12 DoFs, <= 16 spheres, end effector = link 6");
     for (int i = 0; i < nd; i++) {
         const srlhip_kuka_tree_joint &J = m->j[i];
         const double a2 = J.axis[0] * J.axis[0] + J.axis[1] * J.axis[1] + J.axis[2] * J.axis[2];

@@ -460,12 +460,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
     TLane L; lane_init(L, tree_model());
+    static double tab[kLaneTableDoubles];          // the wavefront's lane-constant table (LDS on the device): shared by the 16 fibers
+    lane_store(L, tab);
+    grp::sync_scratch();
     const bool lead = L.l == 0;
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
     const bool joints = !cfg.is_discrete && cfg.action_joints;
-    if (joints) tenv_reset<1>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-    else tenv_reset<2>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (joints) tenv_reset<1>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    else tenv_reset<2>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     grp::GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
@@ -485,15 +488,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
             }
             if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = tenv_step(env, g, L, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        const double reward = tenv_step(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
             if (cfg.auto_reset) {
-                if (joints) tenv_reset<1>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-                else tenv_reset<2>(env, g, L, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                if (joints) tenv_reset<1>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                else tenv_reset<2>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
             }
         }
         if (lead) {
@@ -524,11 +527,14 @@ void tree_settle_body(void *p) {
     using namespace tree;
     TreeSettleArgs &a = *static_cast<TreeSettleArgs *>(p);
     TLane L; lane_init(L, tree_model());
+    static double tab[kLaneTableDoubles];
+    lane_store(L, tab);
+    grp::sync_scratch();
     Env e; memset(&e, 0, sizeof e);
     GState g; memset(&g, 0, sizeof g);
-    tinitial(e, g, L);
+    tinitial(e, g, tab);
     const double zero[3] = {0, 0, 0};
-    for (int i = 0; i < kNSettleSteps; i++) tphysics_step(e, g, L, a.cfg, a.scratch, zero, a.cfg.action_joints != 0, L.q0, 0.0);
+    for (int i = 0; i < kNSettleSteps; i++) tphysics_step(e, g, tab, a.cfg, a.scratch, zero, a.cfg.action_joints != 0, L.q0, 0.0);
     tpack_start(e, g, L, a.out);
 }
 }  // namespace

@@ -13,6 +13,13 @@ using tree::TLane;
 using tree::NJ;
 constexpr int kTS = tree::kTreeScratchDoubles, kTStart = tree::kTreeStartDoubles;
 
+// the wavefront's lane-constant table in LDS (kuka_tree.hpp: lane_store / lane_load): built once per launch from the model table
+__device__ __forceinline__ void build_lane_table(TLane &L, const TreeModel *m, double *tab) {
+    tree::lane_init(L, m);
+    if (threadIdx.x < grp::GL) tree::lane_store(L, tab);      // the four rows of the wavefront hold identical constants: row 0 writes
+    __syncthreads();
+}
+
 // env scalars replicated on the row, the own joint per joint lane
 __device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const TLane &L, Env &v, grp::GState &g) {
 #pragma unroll
@@ -56,9 +63,10 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     const bool valid = e_raw < p.n;
     const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the cross-lane ops)
     const Cfg &cfg = p.cfg;
+    __shared__ double tab[tree::kLaneTableDoubles];
     double *scratch = scratch_all[threadIdx.x / GL];
     TLane L;
-    tree::lane_init(L, s.tmodel);
+    build_lane_table(L, s.tmodel, tab);
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
     Rng rng0;
@@ -98,15 +106,15 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
         bool done;
         double reward;
-        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = tree::tenv_step(v, g, L, cfg, scratch, rng_l0, a, ca, ca_own, &done);
-        else reward = tree::tenv_step(v, g, L, cfg, scratch, rng0, a, ca, ca_own, &done);
+        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = tree::tenv_step(v, g, tab, cfg, scratch, rng_l0, a, ca, ca_own, &done);
+        else reward = tree::tenv_step(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
                 double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, L, cfg, scratch, rng_l0, s.tstarts, s.tsettled, objs, n);
-                else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, L, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
+                if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, cfg, scratch, rng_l0, s.tstarts, s.tsettled, objs, n);
+                else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
                 // the start-state loads retire HERE, not at their first use in the next step (where vmcnt(0) would also wait for
                 // the output stores of steps that did not reset)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -140,7 +148,8 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
     const bool valid = e_raw < p.n && !(mask && !mask[e_raw < p.n ? e_raw : 0]);
     const int e = e_raw < p.n ? e_raw : p.n - 1;
-    TLane L; tree::lane_init(L, s.tmodel);
+    __shared__ double tab[tree::kLaneTableDoubles];
+    TLane L; build_lane_table(L, s.tmodel, tab);
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
     Rng rng0;
@@ -150,8 +159,8 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     Env v = {};
     GState g;
     double *objs = valid ? s.objs + e : nullptr;
-    if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.tstarts, s.tsettled, objs, n);
-    else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, L, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
+    if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.tstarts, s.tsettled, objs, n);
+    else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
     tstore(s, n, e, L, v, g, valid);
     if (lead) {
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
@@ -168,12 +177,13 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
 __global__ void __launch_bounds__(kGroupBlock) kuka_tree_settle_k(KukaParams p, KukaState s) {
     using namespace grp;
     __shared__ double scratch_all[kGroupEnvs][kTS];
-    TLane L; tree::lane_init(L, s.tmodel);
+    __shared__ double tab[tree::kLaneTableDoubles];
+    TLane L; build_lane_table(L, s.tmodel, tab);
     Env e = {};
     GState g;
-    tree::tinitial(e, g, L);
+    tree::tinitial(e, g, tab);
     const double zero[3] = {0, 0, 0};
-    for (int i = 0; i < kNSettleSteps; i++) tree::tphysics_step(e, g, L, p.cfg, scratch_all[threadIdx.x / GL], zero, p.cfg.action_joints != 0, L.q0, 0.0);
+    for (int i = 0; i < kNSettleSteps; i++) tree::tphysics_step(e, g, tab, p.cfg, scratch_all[threadIdx.x / GL], zero, p.cfg.action_joints != 0, L.q0, 0.0);
     if (threadIdx.x < GL) tree::tpack_start(e, g, L, s.tsettled);
 }
 // table of the 6^5 (2^5) possible episode start states: one lane group per state
@@ -183,7 +193,8 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, 
     const int idx_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
     const bool valid = idx_raw < s.nstarts;
     const int idx = valid ? idx_raw : s.nstarts - 1;
-    TLane L; tree::lane_init(L, s.tmodel);
+    __shared__ double tab[tree::kLaneTableDoubles];
+    TLane L; build_lane_table(L, s.tmodel, tab);
     Env e = {};
     GState g;
     tree::tunpack_start(e, g, L, s.tsettled);
@@ -194,7 +205,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, 
     double motor[3];
     for (int k = 0; k < kNInitActions; k++) {
         init_action_motor(p.cfg, rem % base, motor);
-        tree::tphysics_step(e, g, L, p.cfg, scratch_all[threadIdx.x / GL], motor, false, L.q0, 0.0);
+        tree::tphysics_step(e, g, tab, p.cfg, scratch_all[threadIdx.x / GL], motor, false, L.q0, 0.0);
         rem /= base;
     }
     if (valid) tree::tpack_start(e, g, L, s.tstarts + (int64_t)idx * kTStart);

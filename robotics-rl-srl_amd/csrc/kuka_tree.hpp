@@ -44,14 +44,16 @@ using grp::wany;
 constexpr int NJ = 12;                          // joint lanes
 constexpr int NA = 7;                           // arm joints (IK, commands)
 constexpr int kBM = 12, kBLo = 13, kBHi = 14;   // lanes of the button's scalar rows
-constexpr int kNB = 16, kNGen = 8;              // bank-B slots; slots < kNGen: limits + contact normals, kNGen + g: friction of normal g
+constexpr int kNGen = 6, kNB = 2 * kNGen;       // bank-B slots; slots < kNGen: limits + contact normals, kNGen + g: friction of normal g
+constexpr int kNArows = 15;                     // bank-A rows: 12 motors + the button's three
 constexpr int kTreeStartDoubles = 4 * NJ + 8;   // q12 qd12 sq12 cq12 ee3 bq bqd grip3
 // LDS scratch per env (doubles): row definitions J[16][12], W J [16][12], then three coupling planes [row j][lane i]:
 // nBA (lane i's B row <- A row j), nAB (lane i's A row <- B row j), nBB (lane i's B row <- B row j)
 // and the row scalars DEF[slot][8]: Jb, desired velocity, position-error velocity, upper bound, on, mu
 constexpr int kDefDoubles = 8;
-constexpr int SC_J = 0, SC_WJ = kNB * NJ, SC_NBA = 2 * kNB * NJ, SC_NAB = SC_NBA + GL * GL, SC_NBB = SC_NAB + GL * GL, SC_DEF = SC_NBB + GL * GL;
-constexpr int kTreeScratchDoubles = SC_DEF + kNB * kDefDoubles;
+constexpr int SC_J = 0, SC_WJ = kNB * NJ, SC_NBA = 2 * kNB * NJ, SC_NAB = SC_NBA + kNArows * GL, SC_NBB = SC_NAB + kNB * GL, SC_DEF = SC_NBB + kNB * GL,
+              SC_S = SC_DEF + kNB * kDefDoubles;                 // + the joints' spatial axes S[12][6] (contact Jacobians)
+constexpr int kTreeScratchDoubles = SC_S + NJ * 6;               // 1056 doubles = 8.25 KiB per env
 
 // ------------------------------------------------------------------ per-lane constants
 struct TLane {
@@ -121,14 +123,76 @@ SRL_G void lane_init(TLane &L, const TreeModel *m) {
     L.table_z = m->table_top_z; L.base_z = m->button_base_z;
 }
 
-// ancestor / descendant masks as 0 / 1 weights, rebuilt per step (kept out of the rollout loop's live registers)
-struct TMasks { double le[NJ], ge[NJ]; };
-SRL_G void make_masks(uint32_t anc, uint32_t desc, TMasks &m) {
+// The per-lane constants live in LDS for the whole launch ([field][16 lanes], one table per wavefront: its envs share the model)
+// and are re-read by every physics step: kept in registers across the rollout loop (~75 doubles per lane) they pushed the loop
+// into scratch, and any scratch reload inside the step loop waits for the previous step's output stores (gfx9 counts loads and
+// stores in one in-order counter).  LDS reads count on lgkmcnt and cost ~80 ds_read_b64 per step.
+enum { LT_MASS = 0, LT_MCOMP, LT_COM, LT_IN = LT_COM + 3, LT_F = LT_IN + 6, LT_T = LT_F + 9, LT_AX = LT_T + 3, LT_JLO = LT_AX + 3, LT_JHI, LT_DAMP, LT_KP,
+       LT_BOUND, LT_MAXVEL, LT_Q0, LT_TSEL, LT_SPH, LT_SMU = LT_SPH + 4, LT_ANC, LT_DESC, LT_SRC, LT_SLINK = LT_SRC + 4, LT_SANC, LT_COUNT };
+// behind the per-lane fields: the model's scalars, stored once
+enum { LS_EEPT = 0, LS_GRPT = 3, LS_TABLEZ = 6, LS_BASEZ, LS_EELINK, LS_GRIPLINK, LS_MAXGEN, LS_FRICTION, LS_COUNT };
+constexpr int kLaneTableDoubles = LT_COUNT * GL + LS_COUNT;
+SRL_G void lane_store(const TLane &L, double *tab) {
+    double *t = tab + L.l;
+#define SRL_PUT(F, v) t[(F) * GL] = (double)(v);
+    SRL_PUT(LT_MASS, L.mass) SRL_PUT(LT_MCOMP, L.mcomp)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { SRL_PUT(LT_COM + k, L.com[k]) SRL_PUT(LT_T + k, L.t[k]) SRL_PUT(LT_AX + k, L.ax[k]) }
+#pragma unroll
+    for (int k = 0; k < 6; k++) SRL_PUT(LT_IN + k, L.in[k])
+#pragma unroll
+    for (int k = 0; k < 9; k++) SRL_PUT(LT_F + k, L.F[k])
+#pragma unroll
+    for (int k = 0; k < 4; k++) { SRL_PUT(LT_SPH + k, L.sph[k]) SRL_PUT(LT_SRC + k, L.src[k]) }
+    SRL_PUT(LT_JLO, L.jlo) SRL_PUT(LT_JHI, L.jhi) SRL_PUT(LT_DAMP, L.damping) SRL_PUT(LT_KP, L.kp) SRL_PUT(LT_BOUND, L.bound) SRL_PUT(LT_MAXVEL, L.maxvel)
+    SRL_PUT(LT_Q0, L.q0) SRL_PUT(LT_TSEL, L.tsel) SRL_PUT(LT_SMU, L.smu)
+    SRL_PUT(LT_ANC, L.anc) SRL_PUT(LT_DESC, L.desc) SRL_PUT(LT_SLINK, L.slink) SRL_PUT(LT_SANC, L.sanc)
+#undef SRL_PUT
+    if (L.l == 0) {
+        double *sc = tab + LT_COUNT * GL;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sc[LS_EEPT + k] = L.eept[k]; sc[LS_GRPT + k] = L.grpt[k]; }
+        sc[LS_TABLEZ] = L.table_z; sc[LS_BASEZ] = L.base_z; sc[LS_EELINK] = L.ee_link; sc[LS_GRIPLINK] = L.grip_link;
+        sc[LS_MAXGEN] = L.max_gen; sc[LS_FRICTION] = L.friction ? 1.0 : 0.0;
+    }
+}
+// rebuild the lane's constants from the table; `tab` is laundered so that the reads are not hoisted out of the rollout loop
+SRL_G void lane_load(TLane &L, const double *tab) {
 #if SRL_G_DEVICE
-    asm volatile("" : "+v"(anc), "+v"(desc));
+    asm volatile("" : "+v"(tab));
+#endif
+    const int l = lane_id();
+    const double *t = tab + l;
+    L.l = l; L.jnt = l < NJ; L.arm = l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) L.e[j] = l == j ? 1.0 : 0.0;
+#define SRL_GET(F) t[(F) * GL]
+    L.mass = SRL_GET(LT_MASS); L.mcomp = SRL_GET(LT_MCOMP);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.com[k] = SRL_GET(LT_COM + k); L.t[k] = SRL_GET(LT_T + k); L.ax[k] = SRL_GET(LT_AX + k); }
+    const double *sc = tab + LT_COUNT * GL;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.eept[k] = sc[LS_EEPT + k]; L.grpt[k] = sc[LS_GRPT + k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) L.in[k] = SRL_GET(LT_IN + k);
+#pragma unroll
+    for (int k = 0; k < 9; k++) L.F[k] = SRL_GET(LT_F + k);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { L.sph[k] = SRL_GET(LT_SPH + k); L.src[k] = (int)SRL_GET(LT_SRC + k); }
+    L.jlo = SRL_GET(LT_JLO); L.jhi = SRL_GET(LT_JHI); L.damping = SRL_GET(LT_DAMP); L.kp = SRL_GET(LT_KP); L.bound = SRL_GET(LT_BOUND); L.maxvel = SRL_GET(LT_MAXVEL);
+    L.q0 = SRL_GET(LT_Q0); L.tsel = SRL_GET(LT_TSEL); L.smu = SRL_GET(LT_SMU); L.table_z = sc[LS_TABLEZ]; L.base_z = sc[LS_BASEZ];
+    L.anc = (uint32_t)SRL_GET(LT_ANC); L.desc = (uint32_t)SRL_GET(LT_DESC); L.slink = (int)SRL_GET(LT_SLINK); L.sanc = (uint32_t)SRL_GET(LT_SANC);
+    L.ee_link = (int)sc[LS_EELINK]; L.grip_link = (int)sc[LS_GRIPLINK]; L.max_gen = (int)sc[LS_MAXGEN]; L.friction = sc[LS_FRICTION] != 0.0;
+#undef SRL_GET
+}
+
+// ancestor / descendant masks as 0 / 1 weights, rebuilt per step (kept out of the rollout loop's live registers)
+SRL_G void make_mask(uint32_t bits, double m[NJ]) {      // one of the two at a time: 24 registers instead of 48
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(bits));
 #endif
 #pragma unroll
-    for (int k = 0; k < NJ; k++) { m.le[k] = (anc >> k) & 1u ? 1.0 : 0.0; m.ge[k] = (desc >> k) & 1u ? 1.0 : 0.0; }
+    for (int k = 0; k < NJ; k++) m[k] = (bits >> k) & 1u ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------ kinematics
@@ -235,19 +299,51 @@ struct TRows {
     double diag, lo, S, jb;
 };
 // One sweep: 12 motor rows; the button's three rows are decoupled from them here and ride on rows 0..2.
-SRL_G void sweep_free(const TLane &L, const TRows &r, double &acc, double e0, double e1, double e2, double ep_first) {
+// A whole sweep is TWO asm statements (an asm statement takes at most 30 operands; the compiler pads every asm boundary with wait
+// states): rows 0..5 with the button rows riding on 0..2, rows 6..11.  39 VALU instructions per sweep.
+struct TEs { double e[NJ]; };          // e[j] = (lane == j), plus the button lanes on 0..2: who restarts its accumulator after row j
+SRL_G void sweep_free(const TEs &E, const TRows &r, double &acc, double ep_first) {
+#if SRL_G_DEVICE
+    double t;
+#define SRL_ROW(J, NJ_, EP) "v_add_f64 %1, %2, %0 clamp\n\tv_fma_f64 %0, -%" #EP ", %0, %0\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %" #NJ_ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define SRL_ROWB(J, NJ_) "v_fmac_f64_dpp %0, %1, %" #NJ_ " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile(SRL_ROW(0, 3, 12) SRL_ROWB(12, 9) SRL_ROW(1, 4, 13) SRL_ROWB(13, 10) SRL_ROW(2, 5, 14) SRL_ROWB(14, 11)
+                 SRL_ROW(3, 6, 15) SRL_ROW(4, 7, 16) SRL_ROW(5, 8, 17)
+                 : "+v"(acc), "=&v"(t)
+                 : "v"(r.cs), "v"(r.n[0]), "v"(r.n[1]), "v"(r.n[2]), "v"(r.n[3]), "v"(r.n[4]), "v"(r.n[5]),          // %2 .. %8
+                   "v"(r.n[kBM]), "v"(r.n[kBLo]), "v"(r.n[kBHi]),                                                     // %9 .. %11
+                   "v"(ep_first), "v"(E.e[0]), "v"(E.e[1]), "v"(E.e[2]), "v"(E.e[3]), "v"(E.e[4]));                   // %12 .. %17
+    asm volatile(SRL_ROW(6, 3, 9) SRL_ROW(7, 4, 10) SRL_ROW(8, 5, 11) SRL_ROW(9, 6, 12) SRL_ROW(10, 7, 13) SRL_ROW(11, 8, 14)
+                 : "+v"(acc), "=&v"(t)
+                 : "v"(r.cs), "v"(r.n[6]), "v"(r.n[7]), "v"(r.n[8]), "v"(r.n[9]), "v"(r.n[10]), "v"(r.n[11]),        // %2 .. %8
+                   "v"(E.e[5]), "v"(E.e[6]), "v"(E.e[7]), "v"(E.e[8]), "v"(E.e[9]), "v"(E.e[10]));                     // %9 .. %14
+#undef SRL_ROW
+#undef SRL_ROWB
+#else
     pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], ep_first);
-    pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);
-    pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);
-    pgs_row<3>(acc, r.cs, r.n[3], e2);        pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);  pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);
-    pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);    pgs_row<7>(acc, r.cs, r.n[7], L.e[6]);  pgs_row<8>(acc, r.cs, r.n[8], L.e[7]);
-    pgs_row<9>(acc, r.cs, r.n[9], L.e[8]);    pgs_row<10>(acc, r.cs, r.n[10], L.e[9]); pgs_row<11>(acc, r.cs, r.n[11], L.e[10]);
+    pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], E.e[0]);
+    pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], E.e[1]);
+    pgs_row<3>(acc, r.cs, r.n[3], E.e[2]);    pgs_row<4>(acc, r.cs, r.n[4], E.e[3]);  pgs_row<5>(acc, r.cs, r.n[5], E.e[4]);
+    pgs_row<6>(acc, r.cs, r.n[6], E.e[5]);    pgs_row<7>(acc, r.cs, r.n[7], E.e[6]);  pgs_row<8>(acc, r.cs, r.n[8], E.e[7]);
+    pgs_row<9>(acc, r.cs, r.n[9], E.e[8]);    pgs_row<10>(acc, r.cs, r.n[10], E.e[9]); pgs_row<11>(acc, r.cs, r.n[11], E.e[10]);
+#endif
 }
-SRL_G double sweeps_free(const TLane &L, const TRows &r) {
+SRL_G double sweeps_free(const TRows &r) {
     double acc = r.acc0, u = 0.0, t;
-    const double e0 = L.e[0] + (L.l == kBM ? 1.0 : 0.0), e1 = L.e[1] + (L.l == kBLo ? 1.0 : 0.0), e2 = L.e[2] + (L.l == kBHi ? 1.0 : 0.0);
-    sweep_free(L, r, acc, e0, e1, e2, 0.0);
-    for (int it = 1; it < kSolverIters - 1; it++) sweep_free(L, r, acc, e0, e1, e2, L.e[11]);
+    int l = lane_id();
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(l));          // the e's are rebuilt here: nothing of them is live outside the solver
+#endif
+    TEs E;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) E.e[j] = l == j ? 1.0 : 0.0;
+    E.e[0] += l == kBM ? 1.0 : 0.0; E.e[1] += l == kBLo ? 1.0 : 0.0; E.e[2] += l == kBHi ? 1.0 : 0.0;
+    const double e0 = E.e[0], e1 = E.e[1], e2 = E.e[2];
+    struct { double e[NJ]; } L; 
+#pragma unroll
+    for (int j = 0; j < NJ; j++) L.e[j] = E.e[j];
+    sweep_free(E, r, acc, 0.0);
+    for (int it = 1; it < kSolverIters - 1; it++) sweep_free(E, r, acc, E.e[11]);
     t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], L.e[11]);  u = fma(e0, t, u);
     t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);      u = fma(e1, t, u);
     t = pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);      u = fma(e2, t, u);
@@ -296,9 +392,11 @@ SRL_G void gen_rowB(const TLane &L, const double *sc, int s, BRow &b, double &ac
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
+SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
                          double finger_angle) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
+    TLane L;
+    lane_load(L, tab);                     // this step's copy of the lane constants (dead before the solver loop)
     // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
     double S[6];
 #pragma unroll
@@ -404,18 +502,18 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
     const double qd = g.qd * L.jm;
     double W[NJ], tau;
     {
-        TMasks M;
-        make_masks(L.anc, L.desc, M);
         double w[3], vo[3], aw[3], av[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, M.le); vo[k] = msum(S[3 + k] * qd, M.le); }
         {
+            double le[NJ];                        // ancestors-or-self of the own link
+            make_mask(L.anc, le);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, le); vo[k] = msum(S[3 + k] * qd, le); }
             double t0[3], t1[3], t2[3];
             cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                aw[k] = msum(t0[k] * qd, M.le);
-                av[k] = msum((t1[k] + t2[k]) * qd, M.le, k == 2 ? -kGravityZ : 0.0);
+                aw[k] = msum(t0[k] * qd, le);
+                av[k] = msum((t1[k] + t2[k]) * qd, le, k == 2 ? -kGravityZ : 0.0);
             }
         }
         // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
@@ -457,10 +555,12 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
             cross3(w, f, t0);
 #pragma unroll
             for (int k = 0; k < 3; k++) ff[k] += t0[k];
+            double ge[NJ];                        // descendants-or-self
+            make_mask(L.desc, ge);
 #pragma unroll
-            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], M.ge); Ff[k] = msum(ff[k], M.ge); hc[k] = msum(h[k], M.ge); }
+            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], ge); Ff[k] = msum(ff[k], ge); hc[k] = msum(h[k], ge); }
 #pragma unroll
-            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], M.ge);
+            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], ge);
         }
         tau = -L.damping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
         // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
@@ -469,8 +569,12 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
 #pragma unroll
         for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp * S[3 + k] - t1[k]; }
         dot6_step<0, NJ>(Fc, S, low);
+        {
+            double le[NJ];
+            make_mask(L.anc, le);
 #pragma unroll
-        for (int k = 0; k < NJ; k++) { low[k] *= M.le[k] * L.jm; W[k] = low[k]; }
+            for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
+        }
         transpose_step<1>(L, low, W);
         double unused = 0.0;
         gj_step<0, NJ, true>(L, W, unused);
@@ -491,34 +595,36 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
 #pragma unroll
     for (int k = 0; k < GL; k++) r.n[k] = 0.0;
     r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
-    double a_own[GL];                              // unscaled couplings of the own bank-A row to every bank-A row
-#pragma unroll
-    for (int k = 0; k < GL; k++) a_own[k] = 0.0;
+    // bounds of every bank-A row are known on every lane without communication: motor row k has lo = -bound_k, S = 2 bound_k (the
+    // lane table), the button motor -+bound_bm, the button stops [0, blim]
+    auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
+    auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
+    // unscaled coupling of the own bank-A row to bank-A row k
+    auto a_of = [&](int k) -> double {
+        if (k < NJ) return L.jnt ? W[k] * (1.0 - L.e[k]) : 0.0;
+        if (k == kBM) return is_blo ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBLo) return is_bm ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBHi) return (is_bm || is_blo) ? -wb : 0.0;
+        return 0.0;
+    };
     if (L.jnt) {
 #pragma unroll
-        for (int k = 0; k < NJ; k++) { r.diag = fma(L.e[k], W[k], r.diag); a_own[k] = W[k] * (1.0 - L.e[k]); }
+        for (int k = 0; k < NJ; k++) r.diag = fma(L.e[k], W[k], r.diag);
         rhs = target - qd_new; r.lo = -L.bound; r.S = 2.0 * L.bound;
     } else if (is_bm) {
         rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - e.bqd;
         r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
-        a_own[kBLo] = wb; a_own[kBHi] = -wb;
     } else if (is_blo) {
         const double pen = e.bq - kGliderLower;
         rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
         r.S = blim; r.jb = 1.0; r.diag = wb;
-        a_own[kBM] = wb; a_own[kBHi] = -wb;
     } else if (is_bhi) {
         const double pen = kGliderUpper - e.bq;
         rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
         r.S = blim; r.jb = -1.0; r.diag = wb;
-        a_own[kBM] = -wb; a_own[kBLo] = -wb;
     }
-    // bounds of every bank-A row, replicated: S_k and lo_k
-    double Sall[GL], loall[GL];
-    ball_step<0, GL>(r.S, Sall);
-    ball_step<0, GL>(r.lo, loall);
 #pragma unroll
-    for (int k = 0; k < GL; k++) off = fma(a_own[k], loall[k], off);
+    for (int k = 0; k < kNArows; k++) off = fma(a_of(k), lo_of(k), off);
     // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
     const bool has_lim = L.jnt && L.jlo <= L.jhi;
     const double pen_lo = g.q - L.jlo, pen_hi = L.jhi - g.q;
@@ -540,18 +646,14 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
         if (nlim > L.max_gen) nlim = L.max_gen;
         ngen = nlim + ncon; if (ngen > L.max_gen) ngen = L.max_gen;
-        // every joint's spatial axis on every lane (contact Jacobians): only here, off the common path
-        double Sw[NJ][3], Sv[NJ][3];
+        // every joint's spatial axis goes to LDS (contact Jacobians read them): only here, off the common path
+        if (L.jnt) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double tw[NJ], tv[NJ];
-            ball_step<0, NJ>(S[k], tw); ball_step<0, NJ>(S[3 + k], tv);
-#pragma unroll
-            for (int j = 0; j < NJ; j++) { Sw[j][k] = tw[j]; Sv[j][k] = tv[j]; }
+            for (int k = 0; k < 6; k++) sc[SC_S + L.l * 6 + k] = S[k];
         }
         // ---- row definitions -> LDS.  Slot s < kNGen: J[12] + (Jb, desired, position error, upper bound, on); its friction row at
         // slot kNGen + s: J[12] + (Jb, -, -, -, on, mu).  Every lane first clears the definition of its own slot.
-        {
+        if (L.l < kNB) {
             double *d = sc + SC_DEF + L.l * kDefDoubles;
 #pragma unroll
             for (int k = 0; k < kDefDoubles; k++) d[k] = 0.0;
@@ -577,11 +679,13 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
                 else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
+                    const double *Sj = sc + SC_S + j * 6;
+                    const double Swj[3] = {Sj[0], Sj[1], Sj[2]}, Svj[3] = {Sj[3], Sj[4], Sj[5]};
                     double c3[3];
-                    cross3(Sw[j], pt3, c3);                               // w_j x pt + v_j = velocity of the contact point per unit qd_j
+                    cross3(Swj, pt3, c3);                                 // w_j x pt + v_j = velocity of the contact point per unit qd_j
                     const double on = (L.sanc >> j) & 1u ? 1.0 : 0.0;     // only the joints the sphere's link hangs on
-                    o[j] = on * (dot3(nrm, c3) + dot3(nrm, Sv[j]));
-                    of[j] = on * (dot3(tdir, c3) + dot3(tdir, Sv[j]));
+                    o[j] = on * (dot3(nrm, c3) + dot3(nrm, Svj));
+                    of[j] = on * (dot3(tdir, c3) + dot3(tdir, Svj));
                 }
                 d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
                 df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction && L.smu > 0.0) ? 1.0 : 0.0; df[5] = L.smu;
@@ -595,8 +699,9 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         nlim_w = 0; ngen_w = 0;
         for (int k = 0; k < kNGen; k++) { if (wany(k < nlim)) nlim_w = k + 1; if (wany(k < ngen)) ngen_w = k + 1; }
         // ---- the own bank-B row (slot == lane): scalars
-        const double *myd = sc + SC_DEF + L.l * kDefDoubles;
-        const bool own_on = myd[4] != 0.0;
+        const int own_slot = L.l < kNB ? L.l : 0;                       // lanes >= kNB own no bank-B row
+        const double *myd = sc + SC_DEF + own_slot * kDefDoubles;
+        const bool own_on = L.l < kNB && myd[4] != 0.0;
         const bool mine_f = own_on && L.l >= kNGen;
         const double own_jb = own_on ? myd[0] : 0.0;
         // ---- W J of every active slot: joint lane k computes (W J_s)_k = its coupling a_{k,s}; button lanes jb wb Jb_s
@@ -622,14 +727,14 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         b.normal = mine_f ? L.l - kNGen : L.l;
         b.lo = 0.0; b.hi = (own_on && !mine_f) ? myd[3] : 0.0;
         {
-            const double *Jr = sc + SC_J + L.l * NJ, *wjr = sc + SC_WJ + L.l * NJ;
+            const double *Jr = sc + SC_J + own_slot * NJ, *wjr = sc + SC_WJ + own_slot * NJ;
             double diag = own_jb * own_jb * wb, jv = own_jb * e.bqd, offb = own_jb * wb * (-bound_bm);
             double wjo[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 const double Jj = own_on ? Jr[j] : 0.0;
                 wjo[j] = own_on ? wjr[j] : 0.0;
-                diag = fma(Jj, wjo[j], diag); jv = fma(Jj, qall[j], jv); offb = fma(wjo[j], loall[j], offb);
+                diag = fma(Jj, wjo[j], diag); jv = fma(Jj, qall[j], jv); offb = fma(wjo[j], lo_of(j), offb);
             }
             const bool live = own_on && diag > 0.0;
             b.inv_diag = live ? 1.0 / diag : 0.0;
@@ -639,12 +744,12 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
             b.cs = ((des - jv) + perr - offb) * b.inv_diag;
             // couplings of the own bank-B row to the bank-A rows j (in u units: a_rj S_j) and to the bank-B rows s
 #pragma unroll
-            for (int j = 0; j < GL; j++) {
+            for (int j = 0; j < kNArows; j++) {
                 double a = 0.0;
                 if (j < NJ) a = wjo[j < NJ ? j : 0];
                 else if (j == kBM || j == kBLo) a = own_jb * wb;
                 else if (j == kBHi) a = -own_jb * wb;
-                sc[SC_NBA + j * GL + L.l] = -a * Sall[j] * b.inv_diag;
+                sc[SC_NBA + j * GL + L.l] = -a * S_of(j) * b.inv_diag;
             }
 #pragma unroll
             for (int s = 0; s < kNB; s++) {
@@ -675,7 +780,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         const double inv = live ? rcp(r.diag * r.S) : 0.0;
         r.cs = live ? (rhs - off) * inv + ((L.jnt || is_bm) ? 0.5 : 0.0) : 0.0;
 #pragma unroll
-        for (int k = 0; k < GL; k++) r.n[k] = -(a_own[k] * Sall[k]) * inv;
+        for (int k = 0; k < kNArows; k++) r.n[k] = -(a_of(k) * S_of(k)) * inv;
         // lambda starts at 0, i.e. u_k = -lo_k / S_k = 1/2 for the symmetric rows: what motor row l sees of the motor rows behind it
         // during the first sweep (the button motor couples to no row that comes before it)
         r.acc0 = 0.0;
@@ -685,7 +790,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         }
     }
     double u;
-    if (!any_generic) u = sweeps_free(L, r);
+    if (!any_generic) u = sweeps_free(r);
     else {
         // general path, Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
         // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept
@@ -693,8 +798,8 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         const double *sc = scratch;
         double accA = 0.0, accB = 0.0, uA = 0.0;
 #pragma unroll
-        for (int k = 0; k < GL; k++) {
-            const double u0 = Sall[k] > 0.0 ? -loall[k] / Sall[k] : 0.0;
+        for (int k = 0; k < kNArows; k++) {
+            const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
             accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
         }
         for (int it = 0; it < kSolverIters; it++) {
@@ -712,7 +817,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
         u = uA;
     }
     const double lam = r.lo + r.S * u;
-    SRL_GDBG(5, L.l, lam);
+    SRL_GDBG(5, lane_id(), lam);
     // ---- velocity change: joint lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
     double dv = 0.0, dvb = 0.0;
     {
@@ -728,18 +833,21 @@ SRL_G void tphysics_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, doub
             for (int s = 0; s < kNB; s++) {
                 const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
                 if (!used) continue;
-                acc = fma(sc[SC_NAB + s * GL + L.l], shfl(b.on ? b.lam : 0.0, s), acc);
+                acc = fma(sc[SC_NAB + s * GL + lane_id()], shfl(b.on ? b.lam : 0.0, s), acc);
                 dvb += shfl(pbb, s);
             }
             sync_scratch();                          // scratch is reused by the next step
         }
         dv = r.diag * (lam - r.S * acc);
     }
-    // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position
-    if (L.jnt) { g.qd = qd_new + dv; g.q += dt * g.qd; }
+    // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position (a fresh copy of the lane constants: the one loaded
+    //      at the top of the step is not kept live across the solver loop)
+    if (lane_id() < NJ) { g.qd = qd_new + dv; g.q += dt * g.qd; }
     e.bqd += dvb;
     e.bq += dt * e.bqd;
-    trefresh(L, g, e);
+    TLane L3;
+    lane_load(L3, tab);
+    trefresh(L3, g, e);
 }
 
 // ------------------------------------------------------------------ env level (mirrors kuka_group.hpp / kuka_env.hpp)
@@ -760,7 +868,9 @@ SRL_G void tpack_start(const Env &e, const GState &g, const TLane &L, double *o)
     }
 }
 // state right after loadSDF / resetJointState (kuka.py:56-73): all joints at joint_positions, IK target at its initial value
-SRL_G void tinitial(Env &e, GState &g, const TLane &L) {
+SRL_G void tinitial(Env &e, GState &g, const double *tab) {
+    TLane L;
+    lane_load(L, tab);
     g.q = L.jnt ? L.q0 : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
@@ -775,9 +885,11 @@ SRL_G void tinitial(Env &e, GState &g, const TLane &L) {
 // handle); START = 1: joint-space actions — the five init actions are integrated here from the settled state; START = 2: Cartesian
 // modes without a table (the CPU harness): the same five moves integrated from the settled state.
 template <int START, class R>
-SRL_G void tenv_reset(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
+SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
                       double *objs, int64_t objs_stride) {
 #pragma clang fp contract(off)
+    TLane L;
+    lane_load(L, tab);
     ResetDraw d;
     reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
@@ -788,7 +900,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const TLane &L, const Cfg &cfg, double 
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0 + kDeltaTheta * d.g[k];
-            tphysics_step(e, g, L, cfg, scratch, motor, true, jt, 0.0);
+            tphysics_step(e, g, tab, cfg, scratch, motor, true, jt, 0.0);
         }
     } else if constexpr (START == 2) {
         const int base = cfg.is_discrete ? 6 : 2;
@@ -796,7 +908,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const TLane &L, const Cfg &cfg, double 
         double motor[3];
         for (int k = 0; k < kNInitActions; k++) {
             init_action_motor(cfg, rem % base, motor);
-            tphysics_step(e, g, L, cfg, scratch, motor, false, L.q0, 0.0);
+            tphysics_step(e, g, tab, cfg, scratch, motor, false, L.q0, 0.0);
             rem /= base;
         }
     }
@@ -806,12 +918,12 @@ SRL_G void tenv_reset(Env &e, GState &g, const TLane &L, const Cfg &cfg, double 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
 template <class R>
-SRL_G double tenv_step(Env &e, GState &g, const TLane &L, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done) {
+SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done) {
     StepCmd c;
     step_command(e, cfg, rng, action, ca3, c);
-    const double jt = joint_target(c, ca_own, L.q0);
+    const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step(e, g, L, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
+        tphysics_step(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

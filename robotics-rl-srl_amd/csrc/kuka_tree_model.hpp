@@ -141,7 +141,7 @@ inline void default_tree_model(TreeModel &m) {
         add_sphere(m, t, nullptr, nullptr, 0, 0, 0.012, 0.010, kMuFinger);
         add_sphere(m, t, nullptr, nullptr, 0, 0, 0.032, 0.010, kMuFinger);
     }
-    m.table_top_z = kTableTopZ; m.button_base_z = kButtonBaseZ; m.max_generic_rows = 8; m.friction = 1;
+    m.table_top_z = kTableTopZ; m.button_base_z = kButtonBaseZ; m.max_generic_rows = 6; m.friction = 1;
 }
 
 }  // namespace kuka
