@@ -535,7 +535,7 @@ void tree_settle_body(void *p) {
     tinitial(e, g, tab);
     const double zero[3] = {0, 0, 0};
     for (int i = 0; i < kNSettleSteps; i++) tphysics_step(e, g, tab, a.cfg, a.scratch, zero, a.cfg.action_joints != 0, L.q0, 0.0);
-    tpack_start(e, g, L, a.out);
+    tpack_start(e, g, a.out);
 }
 }  // namespace
 

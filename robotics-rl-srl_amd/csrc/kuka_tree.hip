@@ -76,7 +76,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     Env v = {};
     GState g;
     tload(s, n, e, L, v, g);
-    tree::tfk(L, g);
+    tree::tfk(tree::lane_view(tab), g);
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
     GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_settle_k(KukaParams p, 
     tree::tinitial(e, g, tab);
     const double zero[3] = {0, 0, 0};
     for (int i = 0; i < kNSettleSteps; i++) tree::tphysics_step(e, g, tab, p.cfg, scratch_all[threadIdx.x / GL], zero, p.cfg.action_joints != 0, L.q0, 0.0);
-    if (threadIdx.x < GL) tree::tpack_start(e, g, L, s.tsettled);
+    if (threadIdx.x < GL) tree::tpack_start(e, g, s.tsettled);
 }
 // table of the 6^5 (2^5) possible episode start states: one lane group per state
 __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, KukaState s) {
@@ -197,9 +197,9 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, 
     TLane L; build_lane_table(L, s.tmodel, tab);
     Env e = {};
     GState g;
-    tree::tunpack_start(e, g, L, s.tsettled);
+    tree::tunpack_start(e, g, s.tsettled);
     e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z;
-    tree::tfk(L, g);
+    tree::tfk(tree::lane_view(tab), g);
     const int base = p.cfg.is_discrete ? 6 : 2;
     int rem = idx;
     double motor[3];
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, 
         tree::tphysics_step(e, g, tab, p.cfg, scratch_all[threadIdx.x / GL], motor, false, L.q0, 0.0);
         rem /= base;
     }
-    if (valid) tree::tpack_start(e, g, L, s.tstarts + (int64_t)idx * kTStart);
+    if (valid) tree::tpack_start(e, g, s.tstarts + (int64_t)idx * kTStart);
 }
 // after srlhip_set_state(KUKA_Q / GRIPPER_Q): refresh the cached sin / cos and the gripper position
 __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p, KukaState s) {
@@ -217,11 +217,12 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
     const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
     const bool valid = e_raw < p.n;
     const int e = valid ? e_raw : p.n - 1;
-    TLane L; tree::lane_init(L, s.tmodel);
+    __shared__ double tab[tree::kLaneTableDoubles];
+    TLane L; build_lane_table(L, s.tmodel, tab);
     Env v = {};
     GState g;
     tload(s, n, e, L, v, g);
-    tree::trefresh(L, g, v);
+    tree::trefresh(tree::lane_view(tab), g, v);
     tstore(s, n, e, L, v, g, valid);
 }
 

@@ -187,6 +187,57 @@ SRL_G void lane_load(TLane &L, const double *tab) {
 }
 
 // ancestor / descendant masks as 0 / 1 weights, rebuilt per step (kept out of the rollout loop's live registers)
+// Lazy view of the lane table: every field is read from LDS where it is used (loading all ~45 of them at the top of a step kept
+// ~100 registers live through the dynamics).  The pointer is laundered per view, so nothing is hoisted out of the rollout loop.
+struct TL {
+    const double *p;          // table + own lane
+    const double *sc;         // the model's scalars behind the per-lane fields
+    int l;
+    bool jnt, arm;
+    double jm, am;
+    SRL_G double f(int F) const { return p[F * GL]; }
+    SRL_G double e(int j) const { return l == j ? 1.0 : 0.0; }
+    SRL_G double mass() const { return f(LT_MASS); }
+    SRL_G double mcomp() const { return f(LT_MCOMP); }
+    SRL_G double com(int k) const { return f(LT_COM + k); }
+    SRL_G double in(int k) const { return f(LT_IN + k); }
+    SRL_G double F(int k) const { return f(LT_F + k); }
+    SRL_G double t(int k) const { return f(LT_T + k); }
+    SRL_G double ax(int k) const { return f(LT_AX + k); }
+    SRL_G double jlo() const { return f(LT_JLO); }
+    SRL_G double jhi() const { return f(LT_JHI); }
+    SRL_G double damping() const { return f(LT_DAMP); }
+    SRL_G double kp() const { return f(LT_KP); }
+    SRL_G double bound() const { return f(LT_BOUND); }
+    SRL_G double maxvel() const { return f(LT_MAXVEL); }
+    SRL_G double q0() const { return f(LT_Q0); }
+    SRL_G double tsel() const { return f(LT_TSEL); }
+    SRL_G double sph(int k) const { return f(LT_SPH + k); }
+    SRL_G double smu() const { return f(LT_SMU); }
+    SRL_G uint32_t anc() const { return (uint32_t)f(LT_ANC); }
+    SRL_G uint32_t desc() const { return (uint32_t)f(LT_DESC); }
+    SRL_G int src(int k) const { return (int)f(LT_SRC + k); }
+    SRL_G int slink() const { return (int)f(LT_SLINK); }
+    SRL_G uint32_t sanc() const { return (uint32_t)f(LT_SANC); }
+    SRL_G double eept(int k) const { return sc[LS_EEPT + k]; }
+    SRL_G double grpt(int k) const { return sc[LS_GRPT + k]; }
+    SRL_G double table_z() const { return sc[LS_TABLEZ]; }
+    SRL_G double base_z() const { return sc[LS_BASEZ]; }
+    SRL_G int ee_link() const { return (int)sc[LS_EELINK]; }
+    SRL_G int grip_link() const { return (int)sc[LS_GRIPLINK]; }
+    SRL_G int max_gen() const { return (int)sc[LS_MAXGEN]; }
+    SRL_G bool friction() const { return sc[LS_FRICTION] != 0.0; }
+};
+SRL_G TL lane_view(const double *tab) {
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(tab));
+#endif
+    TL L;
+    L.l = lane_id(); L.p = tab + L.l; L.sc = tab + LT_COUNT * GL;
+    L.jnt = L.l < NJ; L.arm = L.l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
+    return L;
+}
+
 SRL_G void make_mask(uint32_t bits, double m[NJ]) {      // one of the two at a time: 24 registers instead of 48
 #if SRL_G_DEVICE
     asm volatile("" : "+v"(bits));
@@ -197,22 +248,22 @@ SRL_G void make_mask(uint32_t bits, double m[NJ]) {      // one of the two at a 
 
 // ------------------------------------------------------------------ kinematics
 // world frame of every link: local joint transform per lane, then pointer jumping (4 levels cover the depth-10 finger tips)
-SRL_G void tfk(const TLane &L, GState &g) {
+SRL_G void tfk(const TL &L, GState &g) {
     const double s = g.sq, c = g.cq, v = 1.0 - c;         // lanes off the tree carry s = 0, c = 1: the identity
     double Rq[9], R[9], p[3];
     // Rodrigues, columns: Rq = c I + s [a]x + (1 - c) a a^T
-    const double ax = L.ax[0], ay = L.ax[1], az = L.ax[2];
+    const double ax = L.ax(0), ay = L.ax(1), az = L.ax(2);
     Rq[0] = c + ax * ax * v;      Rq[1] = ay * ax * v + az * s; Rq[2] = az * ax * v - ay * s;
     Rq[3] = ax * ay * v - az * s; Rq[4] = c + ay * ay * v;      Rq[5] = az * ay * v + ax * s;
     Rq[6] = ax * az * v + ay * s; Rq[7] = ay * az * v - ax * s; Rq[8] = c + az * az * v;
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) R[3 * j + k] = L.F[k] * Rq[3 * j] + L.F[3 + k] * Rq[3 * j + 1] + L.F[6 + k] * Rq[3 * j + 2];
-    p[0] = L.t[0]; p[1] = L.t[1]; p[2] = L.t[2];
+        for (int k = 0; k < 3; k++) R[3 * j + k] = L.F(k) * Rq[3 * j] + L.F(3 + k) * Rq[3 * j + 1] + L.F(6 + k) * Rq[3 * j + 2];
+    p[0] = L.t(0); p[1] = L.t(1); p[2] = L.t(2);
 #pragma unroll
     for (int lvl = 0; lvl < 4; lvl++) {
-        const int src = L.src[lvl];
+        const int src = L.src(lvl);
         const bool have = src >= 0;
         const int from = have ? src : L.l;
         double Ra[9], pa[3], Ro[9], po[3];
@@ -242,12 +293,13 @@ SRL_G void frame_point(const double R[9], const double p[3], const double local[
 #pragma unroll
     for (int k = 0; k < 3; k++) w[k] = p[k] + R[k] * local[0] + R[3 + k] * local[1] + R[6 + k] * local[2];
 }
-SRL_G void trefresh(const TLane &L, GState &g, Env &e) {
+SRL_G void trefresh(const TL &L, GState &g, Env &e) {
     if (L.jnt) sincos(g.q, &g.sq, &g.cq); else { g.sq = 0.0; g.cq = 1.0; }
     tfk(L, g);
     double Rt[9], pt[3];
-    link_frame(g, L.grip_link, Rt, pt);
-    frame_point(Rt, pt, L.grpt, e.grip);
+    link_frame(g, L.grip_link(), Rt, pt);
+    const double grpt[3] = {L.grpt(0), L.grpt(1), L.grpt(2)};
+    frame_point(Rt, pt, grpt, e.grip);
 }
 
 // ------------------------------------------------------------------ row-broadcast helpers for 12 joint lanes
@@ -267,9 +319,9 @@ template <int K, int N> SRL_G void dot6_step(const double a[6], const double b[6
     out[K] = acc;
     if constexpr (K + 1 < N) dot6_step<K + 1, N>(a, b, out);
 }
-template <int K> SRL_G void transpose_step(const TLane &L, const double low[NJ], double M[NJ]) {
+template <int K> SRL_G void transpose_step(const TL &L, const double low[NJ], double M[NJ]) {
 #pragma unroll
-    for (int j = 0; j < K; j++) fmac_bcast<K>(M[K], low[j], L.e[j]);
+    for (int j = 0; j < K; j++) fmac_bcast<K>(M[K], low[j], L.e(j));
     if constexpr (K + 1 < NJ) transpose_step<K + 1>(L, low, M);
 }
 template <int K, int N> SRL_G void rdot_step(double &acc, const double *row, double x) {
@@ -277,11 +329,11 @@ template <int K, int N> SRL_G void rdot_step(double &acc, const double *row, dou
     if constexpr (K + 1 < N) rdot_step<K + 1, N>(acc, row, x);
 }
 // In-place Gauss-Jordan on an N x N SPD matrix, row i on lane i (lanes >= N carry zero rows).  INV: A <- A^-1, else A x = b -> b.
-template <int K, int N, bool INV> SRL_G void gj_step(const TLane &L, double *A, double &b) {
+template <int K, int N, bool INV> SRL_G void gj_step(const TL &L, double *A, double &b) {
     const double r = rcp(bcast<K>(A[K]));
-    const double g = -((A[K] - L.e[K]) * r);
+    const double g = -((A[K] - L.e(K)) * r);
     if constexpr (INV) {
-        A[K] = L.e[K];
+        A[K] = L.e(K);
 #pragma unroll
         for (int c = 0; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
     } else {
@@ -339,23 +391,20 @@ SRL_G double sweeps_free(const TRows &r) {
     for (int j = 0; j < NJ; j++) E.e[j] = l == j ? 1.0 : 0.0;
     E.e[0] += l == kBM ? 1.0 : 0.0; E.e[1] += l == kBLo ? 1.0 : 0.0; E.e[2] += l == kBHi ? 1.0 : 0.0;
     const double e0 = E.e[0], e1 = E.e[1], e2 = E.e[2];
-    struct { double e[NJ]; } L; 
-#pragma unroll
-    for (int j = 0; j < NJ; j++) L.e[j] = E.e[j];
     sweep_free(E, r, acc, 0.0);
     for (int it = 1; it < kSolverIters - 1; it++) sweep_free(E, r, acc, E.e[11]);
-    t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], L.e[11]);  u = fma(e0, t, u);
+    t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], E.e[11]);  u = fma(e0, t, u);
     t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);      u = fma(e1, t, u);
     t = pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);      u = fma(e2, t, u);
-    t = pgs_row<3>(acc, r.cs, r.n[3], e2);         u = fma(L.e[3], t, u);
-    t = pgs_row<4>(acc, r.cs, r.n[4], L.e[3]);     u = fma(L.e[4], t, u);
-    t = pgs_row<5>(acc, r.cs, r.n[5], L.e[4]);     u = fma(L.e[5], t, u);
-    t = pgs_row<6>(acc, r.cs, r.n[6], L.e[5]);     u = fma(L.e[6], t, u);
-    t = pgs_row<7>(acc, r.cs, r.n[7], L.e[6]);     u = fma(L.e[7], t, u);
-    t = pgs_row<8>(acc, r.cs, r.n[8], L.e[7]);     u = fma(L.e[8], t, u);
-    t = pgs_row<9>(acc, r.cs, r.n[9], L.e[8]);     u = fma(L.e[9], t, u);
-    t = pgs_row<10>(acc, r.cs, r.n[10], L.e[9]);   u = fma(L.e[10], t, u);
-    t = pgs_row<11>(acc, r.cs, r.n[11], L.e[10]);  u = fma(L.e[11], t, u);
+    t = pgs_row<3>(acc, r.cs, r.n[3], e2);         u = fma(E.e[3], t, u);
+    t = pgs_row<4>(acc, r.cs, r.n[4], E.e[3]);     u = fma(E.e[4], t, u);
+    t = pgs_row<5>(acc, r.cs, r.n[5], E.e[4]);     u = fma(E.e[5], t, u);
+    t = pgs_row<6>(acc, r.cs, r.n[6], E.e[5]);     u = fma(E.e[6], t, u);
+    t = pgs_row<7>(acc, r.cs, r.n[7], E.e[6]);     u = fma(E.e[7], t, u);
+    t = pgs_row<8>(acc, r.cs, r.n[8], E.e[7]);     u = fma(E.e[8], t, u);
+    t = pgs_row<9>(acc, r.cs, r.n[9], E.e[8]);     u = fma(E.e[9], t, u);
+    t = pgs_row<10>(acc, r.cs, r.n[10], E.e[9]);   u = fma(E.e[10], t, u);
+    t = pgs_row<11>(acc, r.cs, r.n[11], E.e[10]);  u = fma(E.e[11], t, u);
     return u;
 }
 
@@ -363,7 +412,7 @@ SRL_G double sweeps_free(const TRows &r) {
 struct BRow { double cs, lo, hi, mu, lam, jb, inv_diag; int normal; bool on, fric; };   // own bank-B row (slot == lane)
 // bank-A row J: u = clamp01(cs + accA) on lane J, broadcast to both accumulators of every lane.  (The general path resets the
 // own accumulator explicitly instead of in the shadow of the next row: bank-B rows interleave with bank A.)
-template <int J> SRL_G void gen_rowA(const TLane &L, const TRows &r, const double *sc, double &accA, double &accB, double &uA) {
+template <int J> SRL_G void gen_rowA(const TL &L, const TRows &r, const double *sc, double &accA, double &accB, double &uA) {
     const double t = clamp01(r.cs + accA);
     const double tb = bcast<J>(t);
     if (L.l == J) { accA = 0.0; uA = t; }
@@ -374,7 +423,7 @@ template <int J> SRL_G void gen_rowA(const TLane &L, const TRows &r, const doubl
 // the CURRENT impulse of its normal row, and the row keeps its value while that is not positive (it still hands the value round:
 // every row contributes exactly once per sweep to the others' accumulators).  part: this env's slot s belongs to the phase being
 // swept (uniform over the env's 16 lanes) — otherwise nothing of this env changes.
-SRL_G void gen_rowB(const TLane &L, const double *sc, int s, BRow &b, double &accA, double &accB, bool part) {
+SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA, double &accB, bool part) {
     double lo = b.lo, hi = b.hi;
     const double tot = shfl(b.lam, b.normal);               // friction rows: the normal row's impulse
     const bool skip = b.fric && !(tot > 0.0);
@@ -388,253 +437,39 @@ SRL_G void gen_rowB(const TLane &L, const double *sc, int s, BRow &b, double &ac
     if (part) { accA = nA; accB = nB; if (L.l == s) b.lam = t; }
 }
 
-// ------------------------------------------------------------------ one physics step
-// Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
-// lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
-// finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
-                         double finger_angle) {
+// ------------------------------------------------------------------ the general path as ONE non-inlined function
+// Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps), but their code — row
+// definitions, couplings through LDS, the two-bank sweeps — needs far more registers than the common step.  Inlined, it pushed
+// the whole rollout loop into scratch (every scratch reload in the step loop waits for the previous step's output stores); as a
+// function with its own frame it costs the common path nothing.  Everything goes in and out by value (copy-in / copy-out keeps
+// the caller's row data in registers).
+struct GenIn {
+    const double *tab; double *scratch;
+    TRows r;                      // the scaled bank-A row of this lane
+    double S[6], W[NJ], cc[3], n_cap[3], n_base[3];
+    double d_cap, d_base, pen_lo, pen_hi, qd_new, bqd, bound_bm, q;
+    bool c_cap, c_base, lim_lo, lim_hi;
+};
+struct GenOut { double u, acc_b, dvb_b; };     // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows
+__host__ __device__ __attribute__((noinline)) inline GenOut general_path(const GenIn in) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
-    TLane L;
-    lane_load(L, tab);                     // this step's copy of the lane constants (dead before the solver loop)
-    // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
-    double S[6];
-#pragma unroll
-    for (int k = 0; k < 3; k++) S[k] = (g.R[k] * L.ax[0] + g.R[3 + k] * L.ax[1] + g.R[6 + k] * L.ax[2]) * L.jm;
-    cross3(g.p, S, S + 3);
-    // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
-    double qdes = L.arm ? jt_own : L.tsel * finger_angle;
-    if (!joint_mode) {
-        const int b = (cfg.random_target || cfg.two) ? 0 : 1;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double v = e.ee[k] + motor[k];
-            v = v < kEeBox[b][0][k] ? kEeBox[b][0][k] : v;
-            v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
-            e.ee[k] = v;
-        }
-        double Rt[9], pt[3], ee[3], dS[6], J[6];
-#pragma unroll
-        for (int k = 0; k < 9; k++) Rt[k] = bcast<NA - 1>(g.R[k]);
-#pragma unroll
-        for (int k = 0; k < 3; k++) pt[k] = bcast<NA - 1>(g.p[k]);
-        frame_point(Rt, pt, L.eept, ee);
-        {
-            double d[3], Sa[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { d[k] = ee[k] - g.p[k]; Sa[k] = S[k] * L.am; }
-            cross3(Sa, d, J);
-#pragma unroll
-            for (int k = 0; k < 3; k++) J[3 + k] = Sa[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
-        {   // orientation error towards quat(euler(0, -pi, 0)), replicated (same construction as kuka_group.hpp)
-            const double *R = Rt;
-            double qx, qy, qz, qw;
-            const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
-            const double tr = m00 + m11 + m22;
-            if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
-            else if (m00 > m11 && m00 > m22) { double s = sqrt(1.0 + m00 - m11 - m22) * 2; qw = (m21 - m12) / s; qx = 0.25 * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
-            else if (m11 > m22) { double s = sqrt(1.0 + m11 - m00 - m22) * 2; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25 * s; qz = (m12 + m21) / s; }
-            else { double s = sqrt(1.0 + m22 - m00 - m11) * 2; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25 * s; }
-            const double tx = 0.0, ty = -1.0, tz = 0.0, tw = 6.123233995736766e-17;
-            const double ix = -qx, iy = -qy, iz = -qz, iw = qw;
-            const double dw = tw * iw - tx * ix - ty * iy - tz * iz;
-            const double dx = tw * ix + tx * iw + ty * iz - tz * iy;
-            const double dy = tw * iy - tx * iz + ty * iw + tz * ix;
-            const double dz = tw * iz + tx * iy - ty * ix + tz * iw;
-            const double sv = sqrt(dx * dx + dy * dy + dz * dz);
-            double angle = 2.0 * atan2(sv, dw), ax, ay, az;
-            if (sv * sv < 10.0 * 2.2204460492503131e-16) { ax = 1; ay = 0; az = 0; }
-            else { ax = dx / sv; ay = dy / sv; az = dz / sv; }
-            if (angle > kPi) angle -= 2 * kPi;
-            dS[3] = angle * ax; dS[4] = angle * ay; dS[5] = angle * az;
-        }
-        double A[NA], bb = 0.0;
-        dot6_step<0, NA>(J, J, A);
-        const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
-#pragma unroll
-        for (int k = 0; k < NA; k++) A[k] = fma(damping, L.e[k], A[k]);
-#pragma unroll
-        for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
-        gj_step<0, NA, false>(L, A, bb);
-        bb *= L.am;
-        double all[NA], maxabs = 0.0;
-        ball_step<0, NA>(bb, all);
-#pragma unroll
-        for (int k = 0; k < NA; k++) maxabs = fmax(maxabs, fabs(all[k]));
-        if (L.arm) qdes = g.q + bb;
-        if (wany(maxabs > kIkMaxAngle)) {
-            const double scale = kIkMaxAngle / maxabs;
-            if (maxabs > kIkMaxAngle && L.arm) qdes = g.q + bb * scale;
-        }
-    }
-    // ---- collision detection at the current poses: every lane owns one sphere of the model
-    double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30;
-    const bool sphere = L.slink >= 0;
-    {
-        double Rs[9], ps[3];
-        link_frame(g, sphere ? L.slink : 0, Rs, ps);
-        frame_point(Rs, ps, L.sph, cc);
-    }
-    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
-    {
-        const double reach = L.sph[3] + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
-        const double rmax = kBaseRadius + reach;
-        const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
-        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
-        if (wany(sphere && !far)) {
-            if (sphere) {
-                d_cap = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
-                d_base = sphere_cylinder(cc, L.sph[3], e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
-            }
-        }
-    }
-    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
-    e.contact_table = gany(sphere && (cc[2] - L.sph[3] - L.table_z < kContactThreshold)) ? 1 : 0;
-    e.contact_button = gany(c_cap) ? 1 : 0;
-    // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
-    double target = L.kp * (qdes - g.q) * inv_dt;
-    target = target > L.maxvel ? L.maxvel : target;
-    target = target < -L.maxvel ? -L.maxvel : target;
-    // ---- dynamics in world coordinates
-    const double qd = g.qd * L.jm;
-    double W[NJ], tau;
-    {
-        double w[3], vo[3], aw[3], av[3];
-        {
-            double le[NJ];                        // ancestors-or-self of the own link
-            make_mask(L.anc, le);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, le); vo[k] = msum(S[3 + k] * qd, le); }
-            double t0[3], t1[3], t2[3];
-            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                aw[k] = msum(t0[k] * qd, le);
-                av[k] = msum((t1[k] + t2[k]) * qd, le, k == 2 ? -kGravityZ : 0.0);
-            }
-        }
-        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
-        double Io[6], h[3];
-        {
-            const double *R = g.R;
-            double cw[3], T[9];
-            frame_point(R, g.p, L.com, cw);
-            // T = R * Ilink (columns of T), Io = T * R^T + m (|c|^2 1 - c c^T)
-            const double I00 = L.in[0], I01 = L.in[1], I02 = L.in[2], I11 = L.in[3], I12 = L.in[4], I22 = L.in[5];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                T[k] = R[k] * I00 + R[3 + k] * I01 + R[6 + k] * I02;
-                T[3 + k] = R[k] * I01 + R[3 + k] * I11 + R[6 + k] * I12;
-                T[6 + k] = R[k] * I02 + R[3 + k] * I12 + R[6 + k] * I22;
-            }
-            const double m = L.mass, ccs = dot3(cw, cw);
-            Io[0] = T[0] * R[0] + T[3] * R[3] + T[6] * R[6] + m * (ccs - cw[0] * cw[0]);
-            Io[1] = T[0] * R[1] + T[3] * R[4] + T[6] * R[7] - m * cw[0] * cw[1];
-            Io[2] = T[0] * R[2] + T[3] * R[5] + T[6] * R[8] - m * cw[0] * cw[2];
-            Io[3] = T[1] * R[1] + T[4] * R[4] + T[7] * R[7] + m * (ccs - cw[1] * cw[1]);
-            Io[4] = T[1] * R[2] + T[4] * R[5] + T[7] * R[8] - m * cw[1] * cw[2];
-            Io[5] = T[2] * R[2] + T[5] * R[5] + T[8] * R[8] + m * (ccs - cw[2] * cw[2]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
-        }
-        double Fn[3], Ff[3], Ioc[6], hc[3];
-        {
-            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
-            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass * av[k] - t1[k]; }
-            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass * vo[k] - t1[k]; }
-            cross3(w, n, t0); cross3(vo, f, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
-            cross3(w, f, t0);
-#pragma unroll
-            for (int k = 0; k < 3; k++) ff[k] += t0[k];
-            double ge[NJ];                        // descendants-or-self
-            make_mask(L.desc, ge);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], ge); Ff[k] = msum(ff[k], ge); hc[k] = msum(h[k], ge); }
-#pragma unroll
-            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], ge);
-        }
-        tau = -L.damping * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
-        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
-        double Fc[6], t0[3], t1[3], low[NJ];
-        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp * S[3 + k] - t1[k]; }
-        dot6_step<0, NJ>(Fc, S, low);
-        {
-            double le[NJ];
-            make_mask(L.anc, le);
-#pragma unroll
-            for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
-        }
-        transpose_step<1>(L, low, W);
-        double unused = 0.0;
-        gj_step<0, NJ, true>(L, W, unused);
-    }
-    double qdd = 0.0;
-    rdot_step<0, NJ>(qdd, W, tau);
-#pragma unroll
-    for (int k = 0; k < NJ; k++) SRL_GDBG(0, L.l * NJ + k, W[k]);
-    SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
-    const double qd_new = qd + dt * qdd;
-    e.bqd += dt * kGravityZ;
-    // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
+    const double *tab = in.tab;
+    double *scratch = in.scratch;
+    const TL L = lane_view(tab);
+    const TRows &r = in.r;
+    const double *S = in.S, *W = in.W, *cc = in.cc, *n_cap = in.n_cap, *n_base = in.n_base;
+    const double d_cap = in.d_cap, d_base = in.d_base, pen_lo = in.pen_lo, pen_hi = in.pen_hi, qd_new = in.qd_new, bound_bm = in.bound_bm;
+    const bool c_cap = in.c_cap, c_base = in.c_base, lim_lo = in.lim_lo, lim_hi = in.lim_hi;
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
-    const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
     const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
-    TRows r;
-    double rhs = 0.0, off = 0.0;
-#pragma unroll
-    for (int k = 0; k < GL; k++) r.n[k] = 0.0;
-    r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
-    // bounds of every bank-A row are known on every lane without communication: motor row k has lo = -bound_k, S = 2 bound_k (the
-    // lane table), the button motor -+bound_bm, the button stops [0, blim]
+    struct { double bqd; } e = {in.bqd};
     auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
     auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
-    // unscaled coupling of the own bank-A row to bank-A row k
-    auto a_of = [&](int k) -> double {
-        if (k < NJ) return L.jnt ? W[k] * (1.0 - L.e[k]) : 0.0;
-        if (k == kBM) return is_blo ? wb : is_bhi ? -wb : 0.0;
-        if (k == kBLo) return is_bm ? wb : is_bhi ? -wb : 0.0;
-        if (k == kBHi) return (is_bm || is_blo) ? -wb : 0.0;
-        return 0.0;
-    };
-    if (L.jnt) {
-#pragma unroll
-        for (int k = 0; k < NJ; k++) r.diag = fma(L.e[k], W[k], r.diag);
-        rhs = target - qd_new; r.lo = -L.bound; r.S = 2.0 * L.bound;
-    } else if (is_bm) {
-        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - e.bqd;
-        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
-    } else if (is_blo) {
-        const double pen = e.bq - kGliderLower;
-        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
-        r.S = blim; r.jb = 1.0; r.diag = wb;
-    } else if (is_bhi) {
-        const double pen = kGliderUpper - e.bq;
-        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
-        r.S = blim; r.jb = -1.0; r.diag = wb;
-    }
-#pragma unroll
-    for (int k = 0; k < kNArows; k++) off = fma(a_of(k), lo_of(k), off);
-    // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
-    const bool has_lim = L.jnt && L.jlo <= L.jhi;
-    const double pen_lo = g.q - L.jlo, pen_hi = L.jhi - g.q;
-    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
-    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
     BRow b;
     b.cs = 0.0; b.lo = 0.0; b.hi = 0.0; b.mu = 0.0; b.lam = 0.0; b.jb = 0.0; b.inv_diag = 0.0; b.normal = L.l; b.on = false; b.fric = false;
     int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
-    if (any_generic) {
+    {
         double *sc = scratch;
         // slot of a candidate = number of candidates before it in creation order: limits (joint 0 lower, joint 0 upper, joint 1
         // lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first max_gen are kept
@@ -644,8 +479,8 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base);
         const int s_lo = __builtin_popcount(b_lo & below) + __builtin_popcount(b_hi & below), s_hi = s_lo + (lim_lo ? 1 : 0);
         const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
-        if (nlim > L.max_gen) nlim = L.max_gen;
-        ngen = nlim + ncon; if (ngen > L.max_gen) ngen = L.max_gen;
+        if (nlim > L.max_gen()) nlim = L.max_gen();
+        ngen = nlim + ncon; if (ngen > L.max_gen()) ngen = L.max_gen();
         // every joint's spatial axis goes to LDS (contact Jacobians read them): only here, off the common path
         if (L.jnt) {
 #pragma unroll
@@ -660,20 +495,20 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         }
         sync_scratch();
         auto put_limit = [&](int slot, double sign, double pen) {
-            if (slot < L.max_gen) {
+            if (slot < L.max_gen()) {
                 double *o = sc + SC_J + slot * NJ, *d = sc + SC_DEF + slot * kDefDoubles;
 #pragma unroll
-                for (int j = 0; j < NJ; j++) o[j] = sign * L.e[j];
+                for (int j = 0; j < NJ; j++) o[j] = sign * L.e(j);
                 d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * kErp * inv_dt; d[3] = blim; d[4] = 1.0;
             }
         };
         auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap) {
-            if (slot < L.max_gen) {
+            if (slot < L.max_gen()) {
                 double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (kNGen + slot) * NJ;
                 double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (kNGen + slot) * kDefDoubles;
                 double pt3[3], tdir[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) pt3[k] = cc[k] - L.sph[3] * nrm[k];
+                for (int k = 0; k < 3; k++) pt3[k] = cc[k] - L.sph(3) * nrm[k];
                 // btPlaneSpace1: first tangent of the contact normal (the one friction direction of Bullet's multibody solver)
                 if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); tdir[0] = 0.0; tdir[1] = -nrm[2] * kk; tdir[2] = nrm[1] * kk; }
                 else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
@@ -683,12 +518,12 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
                     const double Swj[3] = {Sj[0], Sj[1], Sj[2]}, Svj[3] = {Sj[3], Sj[4], Sj[5]};
                     double c3[3];
                     cross3(Swj, pt3, c3);                                 // w_j x pt + v_j = velocity of the contact point per unit qd_j
-                    const double on = (L.sanc >> j) & 1u ? 1.0 : 0.0;     // only the joints the sphere's link hangs on
+                    const double on = (L.sanc() >> j) & 1u ? 1.0 : 0.0;     // only the joints the sphere's link hangs on
                     o[j] = on * (dot3(nrm, c3) + dot3(nrm, Svj));
                     of[j] = on * (dot3(tdir, c3) + dot3(tdir, Svj));
                 }
                 d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
-                df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction && L.smu > 0.0) ? 1.0 : 0.0; df[5] = L.smu;
+                df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && L.smu() > 0.0) ? 1.0 : 0.0; df[5] = L.smu();
             }
         };
         if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
@@ -774,6 +609,285 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         on_lim = b.on && L.l < nlim; on_con = b.on && !on_lim;
         sync_scratch();
     }
+    // ---- Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
+    // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept before
+    // any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
+    const double *sc = scratch;
+    double accA = 0.0, accB = 0.0, uA = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNArows; k++) {
+        const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
+        accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
+    }
+    for (int it = 0; it < kSolverIters; it++) {
+        gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
+        gen_rowA<3>(L, r, sc, accA, accB, uA);  gen_rowA<4>(L, r, sc, accA, accB, uA);  gen_rowA<5>(L, r, sc, accA, accB, uA);
+        gen_rowA<6>(L, r, sc, accA, accB, uA);  gen_rowA<7>(L, r, sc, accA, accB, uA);  gen_rowA<8>(L, r, sc, accA, accB, uA);
+        gen_rowA<9>(L, r, sc, accA, accB, uA);  gen_rowA<10>(L, r, sc, accA, accB, uA); gen_rowA<11>(L, r, sc, accA, accB, uA);
+        gen_rowA<kBM>(L, r, sc, accA, accB, uA);
+        // a slot index is a limit row in one env of the wavefront and a contact row in another: `part` keeps every row in its phase
+        for (int s = 0; s < nlim_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_lim ? 1.0 : 0.0, s) != 0.0);
+        gen_rowA<kBLo>(L, r, sc, accA, accB, uA); gen_rowA<kBHi>(L, r, sc, accA, accB, uA);
+        for (int s = 0; s < ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
+        for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
+    }
+    GenOut out;
+    out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0;
+    const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
+    for (int s = 0; s < kNB; s++) {
+        const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
+        if (!used) continue;
+        out.acc_b = fma(sc[SC_NAB + s * GL + L.l], shfl(b.on ? b.lam : 0.0, s), out.acc_b);
+        out.dvb_b += shfl(pbb, s);
+    }
+    sync_scratch();                          // scratch is reused by the next step
+    return out;
+}
+
+// ------------------------------------------------------------------ one physics step
+// Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
+// lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
+// finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
+SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
+                         double finger_angle) {
+    const double dt = kDt, inv_dt = 1.0 / kDt;
+    const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
+    // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
+    double S[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) S[k] = (g.R[k] * L.ax(0) + g.R[3 + k] * L.ax(1) + g.R[6 + k] * L.ax(2)) * L.jm;
+    cross3(g.p, S, S + 3);
+    // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
+    double qdes = L.arm ? jt_own : L.tsel() * finger_angle;
+    if (!joint_mode) {
+        const int b = (cfg.random_target || cfg.two) ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double v = e.ee[k] + motor[k];
+            v = v < kEeBox[b][0][k] ? kEeBox[b][0][k] : v;
+            v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
+            e.ee[k] = v;
+        }
+        double Rt[9], pt[3], ee[3], dS[6], J[6];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rt[k] = bcast<NA - 1>(g.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pt[k] = bcast<NA - 1>(g.p[k]);
+        const double eept[3] = {L.eept(0), L.eept(1), L.eept(2)};
+        frame_point(Rt, pt, eept, ee);
+        {
+            double d[3], Sa[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { d[k] = ee[k] - g.p[k]; Sa[k] = S[k] * L.am; }
+            cross3(Sa, d, J);
+#pragma unroll
+            for (int k = 0; k < 3; k++) J[3 + k] = Sa[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
+        {   // orientation error towards quat(euler(0, -pi, 0)), replicated (same construction as kuka_group.hpp)
+            const double *R = Rt;
+            double qx, qy, qz, qw;
+            const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+            const double tr = m00 + m11 + m22;
+            if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
+            else if (m00 > m11 && m00 > m22) { double s = sqrt(1.0 + m00 - m11 - m22) * 2; qw = (m21 - m12) / s; qx = 0.25 * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
+            else if (m11 > m22) { double s = sqrt(1.0 + m11 - m00 - m22) * 2; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25 * s; qz = (m12 + m21) / s; }
+            else { double s = sqrt(1.0 + m22 - m00 - m11) * 2; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25 * s; }
+            const double tx = 0.0, ty = -1.0, tz = 0.0, tw = 6.123233995736766e-17;
+            const double ix = -qx, iy = -qy, iz = -qz, iw = qw;
+            const double dw = tw * iw - tx * ix - ty * iy - tz * iz;
+            const double dx = tw * ix + tx * iw + ty * iz - tz * iy;
+            const double dy = tw * iy - tx * iz + ty * iw + tz * ix;
+            const double dz = tw * iz + tx * iy - ty * ix + tz * iw;
+            const double sv = sqrt(dx * dx + dy * dy + dz * dz);
+            double angle = 2.0 * atan2(sv, dw), ax, ay, az;
+            if (sv * sv < 10.0 * 2.2204460492503131e-16) { ax = 1; ay = 0; az = 0; }
+            else { ax = dx / sv; ay = dy / sv; az = dz / sv; }
+            if (angle > kPi) angle -= 2 * kPi;
+            dS[3] = angle * ax; dS[4] = angle * ay; dS[5] = angle * az;
+        }
+        double A[NA], bb = 0.0;
+        dot6_step<0, NA>(J, J, A);
+        const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
+#pragma unroll
+        for (int k = 0; k < NA; k++) A[k] = fma(damping, L.e(k), A[k]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
+        gj_step<0, NA, false>(L, A, bb);
+        bb *= L.am;
+        double all[NA], maxabs = 0.0;
+        ball_step<0, NA>(bb, all);
+#pragma unroll
+        for (int k = 0; k < NA; k++) maxabs = fmax(maxabs, fabs(all[k]));
+        if (L.arm) qdes = g.q + bb;
+        if (wany(maxabs > kIkMaxAngle)) {
+            const double scale = kIkMaxAngle / maxabs;
+            if (maxabs > kIkMaxAngle && L.arm) qdes = g.q + bb * scale;
+        }
+    }
+    // ---- collision detection at the current poses: every lane owns one sphere of the model
+    double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30;
+    const bool sphere = L.slink() >= 0;
+    {
+        double Rs[9], ps[3];
+        link_frame(g, sphere ? L.slink() : 0, Rs, ps);
+        const double sph3[3] = {L.sph(0), L.sph(1), L.sph(2)};
+        frame_point(Rs, ps, sph3, cc);
+    }
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
+    {
+        const double reach = L.sph(3) + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
+        const double rmax = kBaseRadius + reach;
+        const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
+        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+        if (wany(sphere && !far)) {
+            if (sphere) {
+                d_cap = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+                d_base = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+            }
+        }
+    }
+    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    e.contact_table = gany(sphere && (cc[2] - L.sph(3) - L.table_z() < kContactThreshold)) ? 1 : 0;
+    e.contact_button = gany(c_cap) ? 1 : 0;
+    // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
+    double target = L.kp() * (qdes - g.q) * inv_dt;
+    target = target > L.maxvel() ? L.maxvel() : target;
+    target = target < -L.maxvel() ? -L.maxvel() : target;
+    // ---- dynamics in world coordinates
+    const double qd = g.qd * L.jm;
+    double W[NJ], tau;
+    {
+        double w[3], vo[3], aw[3], av[3];
+        {
+            double le[NJ];                        // ancestors-or-self of the own link
+            make_mask(L.anc(), le);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, le); vo[k] = msum(S[3 + k] * qd, le); }
+            double t0[3], t1[3], t2[3];
+            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                aw[k] = msum(t0[k] * qd, le);
+                av[k] = msum((t1[k] + t2[k]) * qd, le, k == 2 ? -kGravityZ : 0.0);
+            }
+        }
+        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
+        double Io[6], h[3];
+        {
+            const double *R = g.R;
+            double cw[3], T[9];
+            const double com3[3] = {L.com(0), L.com(1), L.com(2)};
+            frame_point(R, g.p, com3, cw);
+            // T = R * Ilink (columns of T), Io = T * R^T + m (|c|^2 1 - c c^T)
+            const double I00 = L.in(0), I01 = L.in(1), I02 = L.in(2), I11 = L.in(3), I12 = L.in(4), I22 = L.in(5);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                T[k] = R[k] * I00 + R[3 + k] * I01 + R[6 + k] * I02;
+                T[3 + k] = R[k] * I01 + R[3 + k] * I11 + R[6 + k] * I12;
+                T[6 + k] = R[k] * I02 + R[3 + k] * I12 + R[6 + k] * I22;
+            }
+            const double m = L.mass(), ccs = dot3(cw, cw);
+            Io[0] = T[0] * R[0] + T[3] * R[3] + T[6] * R[6] + m * (ccs - cw[0] * cw[0]);
+            Io[1] = T[0] * R[1] + T[3] * R[4] + T[6] * R[7] - m * cw[0] * cw[1];
+            Io[2] = T[0] * R[2] + T[3] * R[5] + T[6] * R[8] - m * cw[0] * cw[2];
+            Io[3] = T[1] * R[1] + T[4] * R[4] + T[7] * R[7] + m * (ccs - cw[1] * cw[1]);
+            Io[4] = T[1] * R[2] + T[4] * R[5] + T[7] * R[8] - m * cw[1] * cw[2];
+            Io[5] = T[2] * R[2] + T[5] * R[5] + T[8] * R[8] + m * (ccs - cw[2] * cw[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
+        }
+        double Fn[3], Ff[3], Ioc[6], hc[3];
+        {
+            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
+            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass() * av[k] - t1[k]; }
+            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass() * vo[k] - t1[k]; }
+            cross3(w, n, t0); cross3(vo, f, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
+            cross3(w, f, t0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) ff[k] += t0[k];
+            double ge[NJ];                        // descendants-or-self
+            make_mask(L.desc(), ge);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], ge); Ff[k] = msum(ff[k], ge); hc[k] = msum(h[k], ge); }
+#pragma unroll
+            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], ge);
+        }
+        tau = -L.damping() * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
+        double Fc[6], t0[3], t1[3], low[NJ];
+        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp() * S[3 + k] - t1[k]; }
+        dot6_step<0, NJ>(Fc, S, low);
+        {
+            double le[NJ];
+            make_mask(L.anc(), le);
+#pragma unroll
+            for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
+        }
+        transpose_step<1>(L, low, W);
+        double unused = 0.0;
+        gj_step<0, NJ, true>(L, W, unused);
+    }
+    double qdd = 0.0;
+    rdot_step<0, NJ>(qdd, W, tau);
+#pragma unroll
+    for (int k = 0; k < NJ; k++) SRL_GDBG(0, L.l * NJ + k, W[k]);
+    SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
+    const double qd_new = qd + dt * qdd;
+    e.bqd += dt * kGravityZ;
+    // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
+    const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
+    const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
+    const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
+    TRows r;
+    double rhs = 0.0, off = 0.0;
+#pragma unroll
+    for (int k = 0; k < GL; k++) r.n[k] = 0.0;
+    r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
+    // bounds of every bank-A row are known on every lane without communication: motor row k has lo = -bound_k, S = 2 bound_k (the
+    // lane table), the button motor -+bound_bm, the button stops [0, blim]
+    auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
+    auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
+    // unscaled coupling of the own bank-A row to bank-A row k
+    auto a_of = [&](int k) -> double {
+        if (k < NJ) return L.jnt ? W[k] * (1.0 - L.e(k)) : 0.0;
+        if (k == kBM) return is_blo ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBLo) return is_bm ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBHi) return (is_bm || is_blo) ? -wb : 0.0;
+        return 0.0;
+    };
+    if (L.jnt) {
+#pragma unroll
+        for (int k = 0; k < NJ; k++) r.diag = fma(L.e(k), W[k], r.diag);
+        rhs = target - qd_new; r.lo = -L.bound(); r.S = 2.0 * L.bound();
+    } else if (is_bm) {
+        rhs = (e.motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - e.bqd;
+        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
+    } else if (is_blo) {
+        const double pen = e.bq - kGliderLower;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        r.S = blim; r.jb = 1.0; r.diag = wb;
+    } else if (is_bhi) {
+        const double pen = kGliderUpper - e.bq;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        r.S = blim; r.jb = -1.0; r.diag = wb;
+    }
+#pragma unroll
+    for (int k = 0; k < kNArows; k++) off = fma(a_of(k), lo_of(k), off);
+    // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
+    const bool has_lim = L.jnt && L.jlo() <= L.jhi();
+    const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
+    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
     // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
         const bool live = r.S > 0.0 && r.diag > 0.0;
@@ -789,32 +903,21 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             for (int k = 0; k < NJ; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
         }
     }
-    double u;
+    double u, acc_b = 0.0, dvb_b = 0.0;
     if (!any_generic) u = sweeps_free(r);
     else {
-        // general path, Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
-        // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept
-        // before any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
-        const double *sc = scratch;
-        double accA = 0.0, accB = 0.0, uA = 0.0;
+        GenIn in;
+        in.tab = tab; in.scratch = scratch; in.r = r;
 #pragma unroll
-        for (int k = 0; k < kNArows; k++) {
-            const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
-            accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
-        }
-        for (int it = 0; it < kSolverIters; it++) {
-            gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
-            gen_rowA<3>(L, r, sc, accA, accB, uA);  gen_rowA<4>(L, r, sc, accA, accB, uA);  gen_rowA<5>(L, r, sc, accA, accB, uA);
-            gen_rowA<6>(L, r, sc, accA, accB, uA);  gen_rowA<7>(L, r, sc, accA, accB, uA);  gen_rowA<8>(L, r, sc, accA, accB, uA);
-            gen_rowA<9>(L, r, sc, accA, accB, uA);  gen_rowA<10>(L, r, sc, accA, accB, uA); gen_rowA<11>(L, r, sc, accA, accB, uA);
-            gen_rowA<kBM>(L, r, sc, accA, accB, uA);
-            // a slot index is a limit row in one env of the wavefront and a contact row in another: `part` keeps every row in its phase
-            for (int s = 0; s < nlim_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_lim ? 1.0 : 0.0, s) != 0.0);
-            gen_rowA<kBLo>(L, r, sc, accA, accB, uA); gen_rowA<kBHi>(L, r, sc, accA, accB, uA);
-            for (int s = 0; s < ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
-            for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
-        }
-        u = uA;
+        for (int k = 0; k < 6; k++) in.S[k] = S[k];
+#pragma unroll
+        for (int k = 0; k < NJ; k++) in.W[k] = W[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { in.cc[k] = cc[k]; in.n_cap[k] = n_cap[k]; in.n_base[k] = n_base[k]; }
+        in.d_cap = d_cap; in.d_base = d_base; in.pen_lo = pen_lo; in.pen_hi = pen_hi; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm; in.q = g.q;
+        in.c_cap = c_cap; in.c_base = c_base; in.lim_lo = lim_lo; in.lim_hi = lim_hi;
+        const GenOut out = general_path(in);
+        u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
     }
     const double lam = r.lo + r.S * u;
     SRL_GDBG(5, lane_id(), lam);
@@ -827,17 +930,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         SRL_ACC(0) SRL_ACC(1) SRL_ACC(2) SRL_ACC(3) SRL_ACC(4) SRL_ACC(5) SRL_ACC(6) SRL_ACC(7) SRL_ACC(8) SRL_ACC(9) SRL_ACC(10) SRL_ACC(11)
 #undef SRL_ACC
         dvb = bcast<kBM>(pb) + bcast<kBLo>(pb) + bcast<kBHi>(pb);
-        if (any_generic) {
-            const double *sc = scratch;
-            const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
-            for (int s = 0; s < kNB; s++) {
-                const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
-                if (!used) continue;
-                acc = fma(sc[SC_NAB + s * GL + lane_id()], shfl(b.on ? b.lam : 0.0, s), acc);
-                dvb += shfl(pbb, s);
-            }
-            sync_scratch();                          // scratch is reused by the next step
-        }
+        acc += acc_b; dvb += dvb_b;
         dv = r.diag * (lam - r.S * acc);
     }
     // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position (a fresh copy of the lane constants: the one loaded
@@ -845,23 +938,24 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     if (lane_id() < NJ) { g.qd = qd_new + dv; g.q += dt * g.qd; }
     e.bqd += dvb;
     e.bq += dt * e.bqd;
-    TLane L3;
-    lane_load(L3, tab);
+    const TL L3 = lane_view(tab);
     trefresh(L3, g, e);
 }
 
 // ------------------------------------------------------------------ env level (mirrors kuka_group.hpp / kuka_env.hpp)
 // packed start state: q12 qd12 sq12 cq12 ee3 bq bqd grip3
-SRL_G void tunpack_start(Env &e, GState &g, const TLane &L, const double *o) {
-    if (L.jnt) { g.q = o[L.l]; g.qd = o[NJ + L.l]; g.sq = o[2 * NJ + L.l]; g.cq = o[3 * NJ + L.l]; }
+SRL_G void tunpack_start(Env &e, GState &g, const double *o) {
+    const int l = lane_id();
+    if (l < NJ) { g.q = o[l]; g.qd = o[NJ + l]; g.sq = o[2 * NJ + l]; g.cq = o[3 * NJ + l]; }
     else { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
 #pragma unroll
     for (int k = 0; k < 3; k++) { e.ee[k] = o[4 * NJ + k]; e.grip[k] = o[4 * NJ + 5 + k]; }
     e.bq = o[4 * NJ + 3]; e.bqd = o[4 * NJ + 4];
 }
-SRL_G void tpack_start(const Env &e, const GState &g, const TLane &L, double *o) {
-    if (L.jnt) { o[L.l] = g.q; o[NJ + L.l] = g.qd; o[2 * NJ + L.l] = g.sq; o[3 * NJ + L.l] = g.cq; }
-    if (L.l == 0) {
+SRL_G void tpack_start(const Env &e, const GState &g, double *o) {
+    const int l = lane_id();
+    if (l < NJ) { o[l] = g.q; o[NJ + l] = g.qd; o[2 * NJ + l] = g.sq; o[3 * NJ + l] = g.cq; }
+    if (l == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { o[4 * NJ + k] = e.ee[k]; o[4 * NJ + 5 + k] = e.grip[k]; }
         o[4 * NJ + 3] = e.bq; o[4 * NJ + 4] = e.bqd;
@@ -869,12 +963,11 @@ SRL_G void tpack_start(const Env &e, const GState &g, const TLane &L, double *o)
 }
 // state right after loadSDF / resetJointState (kuka.py:56-73): all joints at joint_positions, IK target at its initial value
 SRL_G void tinitial(Env &e, GState &g, const double *tab) {
-    TLane L;
-    lane_load(L, tab);
-    g.q = L.jnt ? L.q0 : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
+    const TL L = lane_view(tab);
+    g.q = L.jnt ? L.q0() : 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
-    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z; e.bspeed = 0.0;
+    e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z(); e.bspeed = 0.0;
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0; e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
     trefresh(L, g, e);
 }
@@ -888,18 +981,17 @@ template <int START, class R>
 SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
                       double *objs, int64_t objs_stride) {
 #pragma clang fp contract(off)
-    TLane L;
-    lane_load(L, tab);
+    const TL L = lane_view(tab);
     ResetDraw d;
     reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
-    tunpack_start(e, g, L, START ? settled : starts + (int64_t)d.idx * kTreeStartDoubles);
-    e.bx = d.bx; e.by = d.by; e.bz = L.base_z;
+    tunpack_start(e, g, START ? settled : starts + (int64_t)d.idx * kTreeStartDoubles);
+    e.bx = d.bx; e.by = d.by; e.bz = L.base_z();
     tfk(L, g);
     if constexpr (START == 1) {
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
-            const double jt = L.q0 + kDeltaTheta * d.g[k];
+            const double jt = L.q0() + kDeltaTheta * d.g[k];
             tphysics_step(e, g, tab, cfg, scratch, motor, true, jt, 0.0);
         }
     } else if constexpr (START == 2) {
@@ -908,11 +1000,11 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         double motor[3];
         for (int k = 0; k < kNInitActions; k++) {
             init_action_motor(cfg, rem % base, motor);
-            tphysics_step(e, g, tab, cfg, scratch, motor, false, L.q0, 0.0);
+            tphysics_step(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0);
             rem /= base;
         }
     }
-    reset_finish<1>(e, d, L.base_z);
+    reset_finish<1>(e, d, L.base_z());
 }
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
