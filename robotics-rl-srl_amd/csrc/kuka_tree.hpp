@@ -438,11 +438,9 @@ SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA,
 }
 
 // ------------------------------------------------------------------ the general path as ONE non-inlined function
-// Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps), but their code — row
-// definitions, couplings through LDS, the two-bank sweeps — needs far more registers than the common step.  Inlined, it pushed
-// the whole rollout loop into scratch (every scratch reload in the step loop waits for the previous step's output stores); as a
-// function with its own frame it costs the common path nothing.  Everything goes in and out by value (copy-in / copy-out keeps
-// the caller's row data in registers).
+// Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps): row definitions,
+// couplings through LDS, the two-bank sweeps.  (Tried as a real call with its own frame, -mllvm -amdgpu-function-calls: the call
+// site saves ~150 live registers to scratch, the throughput did not change, and one GPU parity test failed — inlined again.)
 struct GenIn {
     const double *tab; double *scratch;
     TRows r;                      // the scaled bank-A row of this lane
@@ -451,7 +449,7 @@ struct GenIn {
     bool c_cap, c_base, lim_lo, lim_hi;
 };
 struct GenOut { double u, acc_b, dvb_b; };     // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows
-__host__ __device__ __attribute__((noinline)) inline GenOut general_path(const GenIn in) {
+SRL_G GenOut general_path(const GenIn &in) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const double *tab = in.tab;
     double *scratch = in.scratch;

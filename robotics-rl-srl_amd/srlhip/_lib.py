@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsrlhip.so")
+LIB_PATH = os.environ.get("SRLHIP_LIB") or os.path.join(HERE, "libsrlhip.so")      # SRLHIP_LIB: experiment builds (profiles/probes)
 
 # ---- constants mirrored from include/srlhip.h --------------------------------
 ENV_MOBILE, ENV_MOBILE_1D, ENV_MOBILE_2TARGET, ENV_MOBILE_LINE, ENV_KUKA_BUTTON, ENV_KUKA_MOVING, ENV_KUKA_2BUTTON, ENV_KUKA_RAND = range(8)
