@@ -4,8 +4,7 @@ OUT=$R/gpurun_out/pmc_tree
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
-           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS"; do
+for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
   rm -rf /tmp/pmc_g
   timeout 300 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_g -o pmc -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 1 --inner-steps 256 > /dev/null 2>/tmp/pmc_err.log

@@ -437,17 +437,74 @@ SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA,
     if (part) { accA = nA; accB = nB; if (L.l == s) b.lam = t; }
 }
 
-// ------------------------------------------------------------------ the general path as ONE non-inlined function
+// The common contact case — no joint-limit row in the wavefront, at most two contact normals per env (slots 0, 1: lanes 0, 1) and
+// their friction rows (slots kNGen, kNGen + 1) — with every coupling in registers and every broadcast a DPP row_newbcast: no LDS
+// access and no ds_bpermute inside the 150 sweeps (the general loop below pays ~100 cycles of LDS latency per row).
+template <int J> SRL_G void c2_rowA(const TRows &r, double nBA_J, double eJ, double &accA, double &accB, double &uA) {
+    const double t = clamp01(r.cs + accA);
+    accA = fma(-eJ, accA, accA);                    // the own accumulator restarts
+    uA = fma(eJ, t - uA, uA);                       // lane J keeps its value
+    fmac_bcast<J>(accA, t, r.n[J]);
+    fmac_bcast<J>(accB, t, nBA_J);
+}
+// bank-B slot S on lane S; NRM: the lane of its normal row (friction rows), -1 for a normal row
+template <int S, int NRM> SRL_G void c2_rowB(BRow &b, double nAB_S, double nBB_S, double eS, double &accA, double &accB) {
+    double lo = b.lo, hi = b.hi, t = b.cs + accB;
+    bool keep = !b.on;                              // a slot this env does not use hands round 0 (its lambda stays 0)
+    if constexpr (NRM >= 0) {
+        const double tot = bcast<NRM>(b.lam);       // the normal row's CURRENT impulse
+        lo = -b.mu * tot; hi = b.mu * tot;
+        keep = keep || !(tot > 0.0);                // friction rows wait for a positive normal impulse
+    }
+    t = t < lo ? lo : (t > hi ? hi : t);
+    t = keep ? b.lam : t;
+    b.lam = fma(eS, t - b.lam, b.lam);
+    accB = fma(-eS, accB, accB);
+    fmac_bcast<S>(accA, t, nAB_S);
+    fmac_bcast<S>(accB, t, nBB_S);
+}
+SRL_G double sweeps_contact2(const TRows &r, BRow &b, const double *sc, double accA, bool two) {
+    int l = lane_id();
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(l));
+#endif
+    double nBA[kNArows], eA[kNArows];
+#pragma unroll
+    for (int j = 0; j < kNArows; j++) { nBA[j] = sc[SC_NBA + j * GL + l]; eA[j] = l == j ? 1.0 : 0.0; }
+    const double nAB0 = sc[SC_NAB + 0 * GL + l], nAB1 = sc[SC_NAB + 1 * GL + l], nABf0 = sc[SC_NAB + kNGen * GL + l], nABf1 = sc[SC_NAB + (kNGen + 1) * GL + l];
+    const double nBB0 = sc[SC_NBB + 0 * GL + l], nBB1 = sc[SC_NBB + 1 * GL + l], nBBf0 = sc[SC_NBB + kNGen * GL + l], nBBf1 = sc[SC_NBB + (kNGen + 1) * GL + l];
+    const double e0 = eA[0], e1 = eA[1], ef0 = l == kNGen ? 1.0 : 0.0, ef1 = l == kNGen + 1 ? 1.0 : 0.0;
+    double accB = 0.0, uA = 0.0;
+    for (int it = 0; it < kSolverIters; it++) {
+        c2_rowA<0>(r, nBA[0], eA[0], accA, accB, uA);   c2_rowA<1>(r, nBA[1], eA[1], accA, accB, uA);   c2_rowA<2>(r, nBA[2], eA[2], accA, accB, uA);
+        c2_rowA<3>(r, nBA[3], eA[3], accA, accB, uA);   c2_rowA<4>(r, nBA[4], eA[4], accA, accB, uA);   c2_rowA<5>(r, nBA[5], eA[5], accA, accB, uA);
+        c2_rowA<6>(r, nBA[6], eA[6], accA, accB, uA);   c2_rowA<7>(r, nBA[7], eA[7], accA, accB, uA);   c2_rowA<8>(r, nBA[8], eA[8], accA, accB, uA);
+        c2_rowA<9>(r, nBA[9], eA[9], accA, accB, uA);   c2_rowA<10>(r, nBA[10], eA[10], accA, accB, uA); c2_rowA<11>(r, nBA[11], eA[11], accA, accB, uA);
+        c2_rowA<kBM>(r, nBA[kBM], eA[kBM], accA, accB, uA); c2_rowA<kBLo>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); c2_rowA<kBHi>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);
+        c2_rowB<0, -1>(b, nAB0, nBB0, e0, accA, accB);
+        if (two) c2_rowB<1, -1>(b, nAB1, nBB1, e1, accA, accB);
+        c2_rowB<kNGen, 0>(b, nABf0, nBBf0, ef0, accA, accB);
+        if (two) c2_rowB<kNGen + 1, 1>(b, nABf1, nBBf1, ef1, accA, accB);
+    }
+    return uA;
+}
+
+// ------------------------------------------------------------------ the general path
 // Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps): row definitions,
 // couplings through LDS, the two-bank sweeps.  (Tried as a real call with its own frame, -mllvm -amdgpu-function-calls: the call
 // site saves ~150 live registers to scratch, the throughput did not change, and one GPU parity test failed — inlined again.)
 struct GenIn {
     const double *tab; double *scratch;
     TRows r;                      // the scaled bank-A row of this lane
-    double S[6], W[NJ], cc[3], n_cap[3], n_base[3];
-    double d_cap, d_base, pen_lo, pen_hi, qd_new, bqd, bound_bm, q;
-    bool c_cap, c_base, lim_lo, lim_hi;
+    double qd_new, bqd, bound_bm;
 };
+// What the general path needs of the step's intermediate results is parked in LDS when it is computed (planes the general path
+// only overwrites at the end of its setup), so that nothing of it stays in registers on the common path:
+//   W (the own row of M^-1) in the NBA plane [k][lane], S in its own plane, and MISC[13][lane] in the NAB / NBB planes:
+//   sphere centre cc[3], n_cap[3], n_base[3], d_cap, d_base, pen_lo, pen_hi
+constexpr int SC_STASH_W = SC_NBA, SC_STASH_MISC = SC_NAB;
+enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM_PENHI, SM_COUNT };
+static_assert(NJ * GL <= kNArows * GL && SM_COUNT * GL <= 2 * kNB * GL, "stash planes");
 struct GenOut { double u, acc_b, dvb_b; };     // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows
 SRL_G GenOut general_path(const GenIn &in) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
@@ -455,9 +512,20 @@ SRL_G GenOut general_path(const GenIn &in) {
     double *scratch = in.scratch;
     const TL L = lane_view(tab);
     const TRows &r = in.r;
-    const double *S = in.S, *W = in.W, *cc = in.cc, *n_cap = in.n_cap, *n_base = in.n_base;
-    const double d_cap = in.d_cap, d_base = in.d_base, pen_lo = in.pen_lo, pen_hi = in.pen_hi, qd_new = in.qd_new, bound_bm = in.bound_bm;
-    const bool c_cap = in.c_cap, c_base = in.c_base, lim_lo = in.lim_lo, lim_hi = in.lim_hi;
+    double S[6], W[NJ], cc[3], n_cap[3], n_base[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) S[k] = L.jnt ? scratch[SC_S + L.l * 6 + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NJ; k++) W[k] = scratch[SC_STASH_W + k * GL + L.l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cc[k] = scratch[SC_STASH_MISC + (SM_CC + k) * GL + L.l]; n_cap[k] = scratch[SC_STASH_MISC + (SM_NCAP + k) * GL + L.l]; n_base[k] = scratch[SC_STASH_MISC + (SM_NBASE + k) * GL + L.l]; }
+    const double d_cap = scratch[SC_STASH_MISC + SM_DCAP * GL + L.l], d_base = scratch[SC_STASH_MISC + SM_DBASE * GL + L.l];
+    const double pen_lo = scratch[SC_STASH_MISC + SM_PENLO * GL + L.l], pen_hi = scratch[SC_STASH_MISC + SM_PENHI * GL + L.l];
+    const double qd_new = in.qd_new, bound_bm = in.bound_bm;
+    const bool sphere = L.slink() >= 0, has_lim = L.jnt && L.jlo() <= L.jhi();
+    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
+    sync_scratch();                       // every lane has its stash in registers before the planes are reused
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
     const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
     struct { double bqd; } e = {in.bqd};
@@ -479,11 +547,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
         if (nlim > L.max_gen()) nlim = L.max_gen();
         ngen = nlim + ncon; if (ngen > L.max_gen()) ngen = L.max_gen();
-        // every joint's spatial axis goes to LDS (contact Jacobians read them): only here, off the common path
-        if (L.jnt) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) sc[SC_S + L.l * 6 + k] = S[k];
-        }
+        // (every joint's spatial axis is already in LDS: the contact Jacobians read them there)
         // ---- row definitions -> LDS.  Slot s < kNGen: J[12] + (Jb, desired, position error, upper bound, on); its friction row at
         // slot kNGen + s: J[12] + (Jb, -, -, -, on, mu).  Every lane first clears the definition of its own slot.
         if (L.l < kNB) {
@@ -617,6 +681,8 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
         accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
     }
+    if (nlim_w == 0 && ngen_w <= 2) uA = sweeps_contact2(r, b, sc, accA, ngen_w == 2);
+    else
     for (int it = 0; it < kSolverIters; it++) {
         gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
         gen_rowA<3>(L, r, sc, accA, accB, uA);  gen_rowA<4>(L, r, sc, accA, accB, uA);  gen_rowA<5>(L, r, sc, accA, accB, uA);
@@ -655,6 +721,10 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
 #pragma unroll
     for (int k = 0; k < 3; k++) S[k] = (g.R[k] * L.ax(0) + g.R[3 + k] * L.ax(1) + g.R[6 + k] * L.ax(2)) * L.jm;
     cross3(g.p, S, S + 3);
+    if (L.jnt) {                            // parked for the (rare) general path, see GenIn
+#pragma unroll
+        for (int k = 0; k < 6; k++) scratch[SC_S + L.l * 6 + k] = S[k];
+    }
     // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
     double qdes = L.arm ? jt_own : L.tsel() * finger_angle;
     if (!joint_mode) {
@@ -747,6 +817,12 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         }
     }
     const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    {
+        double *m = scratch + SC_STASH_MISC + L.l;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m[(SM_CC + k) * GL] = cc[k]; m[(SM_NCAP + k) * GL] = n_cap[k]; m[(SM_NBASE + k) * GL] = n_base[k]; }
+        m[SM_DCAP * GL] = d_cap; m[SM_DBASE * GL] = d_base;
+    }
     e.contact_table = gany(sphere && (cc[2] - L.sph(3) - L.table_z() < kContactThreshold)) ? 1 : 0;
     e.contact_button = gany(c_cap) ? 1 : 0;
     // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
@@ -834,6 +910,8 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         transpose_step<1>(L, low, W);
         double unused = 0.0;
         gj_step<0, NJ, true>(L, W, unused);
+#pragma unroll
+        for (int k = 0; k < NJ; k++) scratch[SC_STASH_W + k * GL + L.l] = W[k];
     }
     double qdd = 0.0;
     rdot_step<0, NJ>(qdd, W, tau);
@@ -885,6 +963,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     const bool has_lim = L.jnt && L.jlo() <= L.jhi();
     const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
     const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
+    scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi;
     const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
     // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
@@ -905,15 +984,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     if (!any_generic) u = sweeps_free(r);
     else {
         GenIn in;
-        in.tab = tab; in.scratch = scratch; in.r = r;
-#pragma unroll
-        for (int k = 0; k < 6; k++) in.S[k] = S[k];
-#pragma unroll
-        for (int k = 0; k < NJ; k++) in.W[k] = W[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { in.cc[k] = cc[k]; in.n_cap[k] = n_cap[k]; in.n_base[k] = n_base[k]; }
-        in.d_cap = d_cap; in.d_base = d_base; in.pen_lo = pen_lo; in.pen_hi = pen_hi; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm; in.q = g.q;
-        in.c_cap = c_cap; in.c_base = c_base; in.lim_lo = lim_lo; in.lim_hi = lim_hi;
+        in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
         const GenOut out = general_path(in);
         u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
     }
