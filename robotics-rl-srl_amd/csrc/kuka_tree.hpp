@@ -507,28 +507,16 @@ enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM
 static_assert(NJ * GL <= kNArows * GL && SM_COUNT * GL <= 2 * kNB * GL, "stash planes");
 struct GenOut { double u, acc_b, dvb_b; };     // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows
 SRL_G GenOut general_path(const GenIn &in) {
+    // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
+    // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const double *tab = in.tab;
-    double *scratch = in.scratch;
+    double *sc = in.scratch;
     const TL L = lane_view(tab);
     const TRows &r = in.r;
-    double S[6], W[NJ], cc[3], n_cap[3], n_base[3];
-#pragma unroll
-    for (int k = 0; k < 6; k++) S[k] = L.jnt ? scratch[SC_S + L.l * 6 + k] : 0.0;
-#pragma unroll
-    for (int k = 0; k < NJ; k++) W[k] = scratch[SC_STASH_W + k * GL + L.l];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { cc[k] = scratch[SC_STASH_MISC + (SM_CC + k) * GL + L.l]; n_cap[k] = scratch[SC_STASH_MISC + (SM_NCAP + k) * GL + L.l]; n_base[k] = scratch[SC_STASH_MISC + (SM_NBASE + k) * GL + L.l]; }
-    const double d_cap = scratch[SC_STASH_MISC + SM_DCAP * GL + L.l], d_base = scratch[SC_STASH_MISC + SM_DBASE * GL + L.l];
-    const double pen_lo = scratch[SC_STASH_MISC + SM_PENLO * GL + L.l], pen_hi = scratch[SC_STASH_MISC + SM_PENHI * GL + L.l];
-    const double qd_new = in.qd_new, bound_bm = in.bound_bm;
-    const bool sphere = L.slink() >= 0, has_lim = L.jnt && L.jlo() <= L.jhi();
-    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
-    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
-    sync_scratch();                       // every lane has its stash in registers before the planes are reused
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
-    const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
-    struct { double bqd; } e = {in.bqd};
+    const double qd_new = in.qd_new, bound_bm = in.bound_bm, bqd = in.bqd;
+    const bool is_button = L.l == kBM || L.l == kBLo || L.l == kBHi;
     auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
     auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
     BRow b;
@@ -536,56 +524,66 @@ SRL_G GenOut general_path(const GenIn &in) {
     int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
     {
-        double *sc = scratch;
+        // ---- the parked inputs of this lane (the MISC plane is reused for the NAB couplings below)
+        double cc[3], n_cap[3], n_base[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cc[k] = sc[SC_STASH_MISC + (SM_CC + k) * GL + L.l]; n_cap[k] = sc[SC_STASH_MISC + (SM_NCAP + k) * GL + L.l]; n_base[k] = sc[SC_STASH_MISC + (SM_NBASE + k) * GL + L.l]; }
+        const double d_cap = sc[SC_STASH_MISC + SM_DCAP * GL + L.l], d_base = sc[SC_STASH_MISC + SM_DBASE * GL + L.l];
+        const double pen_lo = sc[SC_STASH_MISC + SM_PENLO * GL + L.l], pen_hi = sc[SC_STASH_MISC + SM_PENHI * GL + L.l];
+        const bool sphere = L.slink() >= 0, has_lim = L.jnt && L.jlo() <= L.jhi();
+        const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+        const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
         // slot of a candidate = number of candidates before it in creation order: limits (joint 0 lower, joint 0 upper, joint 1
         // lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first max_gen are kept
         const uint32_t b_lo = ballot(lim_lo), b_hi = ballot(lim_hi), b_cap = ballot(c_cap), b_base = ballot(c_base);
         const uint32_t below = (1u << L.l) - 1u;
+        const int max_gen = L.max_gen();
         nlim = __builtin_popcount(b_lo) + __builtin_popcount(b_hi);
         const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base);
         const int s_lo = __builtin_popcount(b_lo & below) + __builtin_popcount(b_hi & below), s_hi = s_lo + (lim_lo ? 1 : 0);
         const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
-        if (nlim > L.max_gen()) nlim = L.max_gen();
-        ngen = nlim + ncon; if (ngen > L.max_gen()) ngen = L.max_gen();
-        // (every joint's spatial axis is already in LDS: the contact Jacobians read them there)
+        if (nlim > max_gen) nlim = max_gen;
+        ngen = nlim + ncon; if (ngen > max_gen) ngen = max_gen;
         // ---- row definitions -> LDS.  Slot s < kNGen: J[12] + (Jb, desired, position error, upper bound, on); its friction row at
         // slot kNGen + s: J[12] + (Jb, -, -, -, on, mu).  Every lane first clears the definition of its own slot.
         if (L.l < kNB) {
             double *d = sc + SC_DEF + L.l * kDefDoubles;
-#pragma unroll
+#pragma nounroll
             for (int k = 0; k < kDefDoubles; k++) d[k] = 0.0;
         }
-        sync_scratch();
+        sync_scratch();                    // (also: every lane has read its parked MISC values)
         auto put_limit = [&](int slot, double sign, double pen) {
-            if (slot < L.max_gen()) {
+            if (slot < max_gen) {
                 double *o = sc + SC_J + slot * NJ, *d = sc + SC_DEF + slot * kDefDoubles;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) o[j] = sign * L.e(j);
+#pragma nounroll
+                for (int j = 0; j < NJ; j++) o[j] = j == L.l ? sign : 0.0;
                 d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * kErp * inv_dt; d[3] = blim; d[4] = 1.0;
             }
         };
         auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap) {
-            if (slot < L.max_gen()) {
+            if (slot < max_gen) {
                 double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (kNGen + slot) * NJ;
                 double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (kNGen + slot) * kDefDoubles;
                 double pt3[3], tdir[3];
+                const double rad = L.sph(3), smu = L.smu();
+                const uint32_t sanc = L.sanc();
 #pragma unroll
-                for (int k = 0; k < 3; k++) pt3[k] = cc[k] - L.sph(3) * nrm[k];
+                for (int k = 0; k < 3; k++) pt3[k] = cc[k] - rad * nrm[k];
                 // btPlaneSpace1: first tangent of the contact normal (the one friction direction of Bullet's multibody solver)
                 if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); tdir[0] = 0.0; tdir[1] = -nrm[2] * kk; tdir[2] = nrm[1] * kk; }
                 else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
-#pragma unroll
+#pragma nounroll
                 for (int j = 0; j < NJ; j++) {
                     const double *Sj = sc + SC_S + j * 6;
                     const double Swj[3] = {Sj[0], Sj[1], Sj[2]}, Svj[3] = {Sj[3], Sj[4], Sj[5]};
                     double c3[3];
                     cross3(Swj, pt3, c3);                                 // w_j x pt + v_j = velocity of the contact point per unit qd_j
-                    const double on = (L.sanc() >> j) & 1u ? 1.0 : 0.0;     // only the joints the sphere's link hangs on
+                    const double on = (sanc >> j) & 1u ? 1.0 : 0.0;       // only the joints the sphere's link hangs on
                     o[j] = on * (dot3(nrm, c3) + dot3(nrm, Svj));
                     of[j] = on * (dot3(tdir, c3) + dot3(tdir, Svj));
                 }
                 d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
-                df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && L.smu() > 0.0) ? 1.0 : 0.0; df[5] = L.smu();
+                df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && smu > 0.0) ? 1.0 : 0.0; df[5] = smu;
             }
         };
         if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
@@ -593,88 +591,82 @@ SRL_G GenOut general_path(const GenIn &in) {
         if (c_cap) put_contact(s_cap, n_cap, d_cap, true);
         if (c_base) put_contact(s_base, n_base, d_base, false);
         sync_scratch();
-        nlim_w = 0; ngen_w = 0;
-        for (int k = 0; k < kNGen; k++) { if (wany(k < nlim)) nlim_w = k + 1; if (wany(k < ngen)) ngen_w = k + 1; }
-        // ---- the own bank-B row (slot == lane): scalars
-        const int own_slot = L.l < kNB ? L.l : 0;                       // lanes >= kNB own no bank-B row
-        const double *myd = sc + SC_DEF + own_slot * kDefDoubles;
-        const bool own_on = L.l < kNB && myd[4] != 0.0;
-        const bool mine_f = own_on && L.l >= kNGen;
-        const double own_jb = own_on ? myd[0] : 0.0;
-        // ---- W J of every active slot: joint lane k computes (W J_s)_k = its coupling a_{k,s}; button lanes jb wb Jb_s
-        double aAB[kNB];                                // unscaled couplings of the own bank-A row to the bank-B rows
-#pragma unroll
+    }
+    nlim_w = 0; ngen_w = 0;
+#pragma nounroll
+    for (int k = 0; k < kNGen; k++) { if (wany(k < nlim)) nlim_w = k + 1; if (wany(k < ngen)) ngen_w = k + 1; }
+    // ---- W J of every active slot: joint lane k computes (W J_s)_k = its coupling a_{k,s} (W: the parked row of M^-1 in the NBA
+    //      plane); button lanes: jb wb Jb_s.  The own bank-A row's scaled couplings -a / (a_rr S_r) go straight to the NAB plane.
+    {
+        const bool liveA = r.S > 0.0 && r.diag > 0.0;
+        const double invA = liveA ? 1.0 / (r.diag * r.S) : 0.0;
+#pragma nounroll
         for (int s = 0; s < kNB; s++) {
             const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
             double wjk = 0.0;
             if (used) {
                 const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
                 const double act = ds[4], jbs = ds[0];
-#pragma unroll
-                for (int j = 0; j < NJ; j++) wjk = fma(W[j], Js[j] * act, wjk);
+#pragma nounroll
+                for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], Js[j] * act, wjk);
                 if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
                 else wjk = is_button ? r.jb * wb * jbs * act : 0.0;
             }
-            aAB[s] = wjk;
+            sc[SC_NAB + s * GL + L.l] = -wjk * invA;
         }
-        sync_scratch();
-        double qall[NJ];
-        ball_step<0, NJ>(qd_new, qall);
+    }
+    sync_scratch();                        // W J complete; the parked W rows (NBA plane) are dead from here on
+    {
+        // ---- the own bank-B row (slot == lane): scalars, diagonal, couplings to bank A and to bank B
+        const int own_slot = L.l < kNB ? L.l : 0;                       // lanes >= kNB own no bank-B row
+        const double *myd = sc + SC_DEF + own_slot * kDefDoubles;
+        const bool own_on = L.l < kNB && myd[4] != 0.0;
+        const bool mine_f = own_on && L.l >= kNGen;
+        const double own_jb = own_on ? myd[0] : 0.0;
         b.on = own_on; b.fric = mine_f; b.jb = own_jb; b.mu = mine_f ? myd[5] : 0.0;
         b.normal = mine_f ? L.l - kNGen : L.l;
         b.lo = 0.0; b.hi = (own_on && !mine_f) ? myd[3] : 0.0;
-        {
-            const double *Jr = sc + SC_J + own_slot * NJ, *wjr = sc + SC_WJ + own_slot * NJ;
-            double diag = own_jb * own_jb * wb, jv = own_jb * e.bqd, offb = own_jb * wb * (-bound_bm);
-            double wjo[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const double Jj = own_on ? Jr[j] : 0.0;
-                wjo[j] = own_on ? wjr[j] : 0.0;
-                diag = fma(Jj, wjo[j], diag); jv = fma(Jj, qall[j], jv); offb = fma(wjo[j], lo_of(j), offb);
-            }
-            const bool live = own_on && diag > 0.0;
-            b.inv_diag = live ? 1.0 / diag : 0.0;
-            if (!live) b.on = false;
-            // (desired - J v + position term) / a_rr, minus what the bank-A rows contribute at their lower bounds
-            const double des = (own_on && !mine_f) ? myd[1] : 0.0, perr = (own_on && !mine_f) ? myd[2] : 0.0;
-            b.cs = ((des - jv) + perr - offb) * b.inv_diag;
-            // couplings of the own bank-B row to the bank-A rows j (in u units: a_rj S_j) and to the bank-B rows s
-#pragma unroll
-            for (int j = 0; j < kNArows; j++) {
-                double a = 0.0;
-                if (j < NJ) a = wjo[j < NJ ? j : 0];
-                else if (j == kBM || j == kBLo) a = own_jb * wb;
-                else if (j == kBHi) a = -own_jb * wb;
-                sc[SC_NBA + j * GL + L.l] = -a * S_of(j) * b.inv_diag;
-            }
-#pragma unroll
-            for (int s = 0; s < kNB; s++) {
-                const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
-                double a = 0.0;
-                if (used && s != L.l) {
-                    const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
-                    a = own_jb * wb * ds[0] * ds[4];
-#pragma unroll
-                    for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ws[j], a);
-                }
-                sc[SC_NBB + s * GL + L.l] = -a * b.inv_diag;
-            }
+        const double *Jr = sc + SC_J + own_slot * NJ, *wjr = sc + SC_WJ + own_slot * NJ;
+        double diag = own_jb * own_jb * wb, jv = own_jb * bqd, offb = own_jb * wb * (-bound_bm);
+#pragma nounroll
+        for (int j = 0; j < NJ; j++) {
+            const double Jj = own_on ? Jr[j] : 0.0, wj = own_on ? wjr[j] : 0.0;
+            const double qj = shfl(qd_new, j);                           // the unconstrained velocity of joint j
+            diag = fma(Jj, wj, diag); jv = fma(Jj, qj, jv); offb = fma(wj, lo_of(j), offb);
         }
-        // scaled couplings of the own bank-A row to bank B: -a / (a_rr S_r)
-        {
-            const bool liveA = r.S > 0.0 && r.diag > 0.0;
-            const double invA = liveA ? 1.0 / (r.diag * r.S) : 0.0;
-#pragma unroll
-            for (int s = 0; s < kNB; s++) sc[SC_NAB + s * GL + L.l] = -aAB[s] * invA;
+        const bool live = own_on && diag > 0.0;
+        b.inv_diag = live ? 1.0 / diag : 0.0;
+        if (!live) b.on = false;
+        // (desired - J v + position term) / a_rr, minus what the bank-A rows contribute at their lower bounds
+        const double des = (own_on && !mine_f) ? myd[1] : 0.0, perr = (own_on && !mine_f) ? myd[2] : 0.0;
+        b.cs = ((des - jv) + perr - offb) * b.inv_diag;
+        // couplings of the own bank-B row to the bank-A rows j (in u units: a_rj S_j) and to the bank-B rows s
+#pragma nounroll
+        for (int j = 0; j < kNArows; j++) {
+            double a = 0.0;
+            if (j < NJ) a = own_on ? wjr[j] : 0.0;
+            else if (j == kBM || j == kBLo) a = own_jb * wb;
+            else if (j == kBHi) a = -own_jb * wb;
+            sc[SC_NBA + j * GL + L.l] = -a * S_of(j) * b.inv_diag;
+        }
+#pragma nounroll
+        for (int s = 0; s < kNB; s++) {
+            const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+            double a = 0.0;
+            if (used && s != L.l) {
+                const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
+                a = own_jb * wb * ds[0] * ds[4];
+#pragma nounroll
+                for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ws[j], a);
+            }
+            sc[SC_NBB + s * GL + L.l] = -a * b.inv_diag;
         }
         on_lim = b.on && L.l < nlim; on_con = b.on && !on_lim;
-        sync_scratch();
     }
+    sync_scratch();
     // ---- Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
     // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept before
     // any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
-    const double *sc = scratch;
     double accA = 0.0, accB = 0.0, uA = 0.0;
 #pragma unroll
     for (int k = 0; k < kNArows; k++) {
