@@ -158,10 +158,10 @@ SRL_G void lane_store(const TLane &L, double *tab) {
 }
 // rebuild the lane's constants from the table; `tab` is laundered so that the reads are not hoisted out of the rollout loop
 SRL_G void lane_load(TLane &L, const double *tab) {
+    int l = lane_id();
 #if SRL_G_DEVICE
-    asm volatile("" : "+v"(tab));
+    asm volatile("" : "+v"(l));
 #endif
-    const int l = lane_id();
     const double *t = tab + l;
     L.l = l; L.jnt = l < NJ; L.arm = l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
 #pragma unroll
@@ -229,11 +229,14 @@ struct TL {
     SRL_G bool friction() const { return sc[LS_FRICTION] != 0.0; }
 };
 SRL_G TL lane_view(const double *tab) {
+    // (the OFFSETS are laundered, not the pointer: an opaque pointer loses its LDS address space and every read becomes a flat
+    //  load — vector-memory instructions that wait on vmcnt, i.e. on the previous step's output stores)
+    int l = lane_id(), off = LT_COUNT * GL;
 #if SRL_G_DEVICE
-    asm volatile("" : "+v"(tab));
+    asm volatile("" : "+v"(l), "+v"(off));
 #endif
     TL L;
-    L.l = lane_id(); L.p = tab + L.l; L.sc = tab + LT_COUNT * GL;
+    L.l = l; L.p = tab + l; L.sc = tab + off;
     L.jnt = L.l < NJ; L.arm = L.l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
     return L;
 }
