@@ -61,6 +61,7 @@ def test_eight_shards_equal_one_handle():
     ret_full = torch.zeros(G * PER, dtype=torch.float32, device=dev)
     len_full = torch.zeros(G * PER, dtype=torch.int32, device=dev)
     fin_full = torch.zeros(G * PER, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                                   # the zero fills run on torch's stream, the statistics kernel on the stepper's
     full.h.episode_stats_device(last_return=ret_full.data_ptr(), last_length=len_full.data_ptr(), n_finished=fin_full.data_ptr())
     full.h.sync()
     full.close()
@@ -86,6 +87,7 @@ def test_eight_shards_equal_one_handle():
         ret = torch.zeros(PER, dtype=torch.float32, device=dev)
         ln = torch.zeros(PER, dtype=torch.int32, device=dev)
         fin = torch.zeros(PER, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         env.h.episode_stats_device(last_return=ret.data_ptr(), last_length=ln.data_ptr(), n_finished=fin.data_ptr())
         env.h.sync()
         assert torch.equal(ret, ret_full[sl]) and torch.equal(ln, len_full[sl]) and torch.equal(fin, fin_full[sl])
