@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <limits>
 #include <vector>
 
 // row-count instrumentation: ngen (limit + contact rows) of every env step, for the path statistics in DESIGN.md
@@ -554,7 +555,9 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
     cfg.moving = g_moving; cfg.two = 0; cfg.max_steps = g_moving ? 1500 : kMaxSteps; cfg.rand_objects = g_rand;
-    std::vector<double> settled(tree::kTreeStartDoubles, 0.0), starts, scratch(tree::kTreeScratchDoubles);
+    // LDS is not cleared between launches on the device: poison the emulated scratch so that any read of a slot this env never
+    // wrote (0 * stale = NaN) shows up here and not as a flaky GPU test
+    std::vector<double> settled(tree::kTreeStartDoubles, 0.0), starts, scratch(tree::kTreeScratchDoubles, std::numeric_limits<double>::quiet_NaN());
     TreeSettleArgs sa{cfg, settled.data(), scratch.data()};
     run_group(tree_settle_body, &sa);
     a.rng_mode = rng_mode; a.T = T; a.n = n; a.actions = actions; a.settled = settled.data(); a.starts = starts.data();

@@ -611,9 +611,9 @@ SRL_G GenOut general_path(const GenIn &in) {
                 const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
                 const double act = ds[4], jbs = ds[0];
 #pragma nounroll
-                for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], Js[j] * act, wjk);
+                for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], act != 0.0 ? Js[j] : 0.0, wjk);   // (a slot this env does not use holds stale LDS: select, never multiply by 0)
                 if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
-                else wjk = is_button ? r.jb * wb * jbs * act : 0.0;
+                else wjk = (is_button && act != 0.0) ? r.jb * wb * jbs : 0.0;
             }
             sc[SC_NAB + s * GL + L.l] = -wjk * invA;
         }
@@ -658,9 +658,9 @@ SRL_G GenOut general_path(const GenIn &in) {
             double a = 0.0;
             if (used && s != L.l) {
                 const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
-                a = own_jb * wb * ds[0] * ds[4];
+                a = ds[4] != 0.0 ? own_jb * wb * ds[0] : 0.0;
 #pragma nounroll
-                for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ws[j], a);
+                for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ds[4] != 0.0 ? ws[j] : 0.0, a);
             }
             sc[SC_NBB + s * GL + L.l] = -a * b.inv_diag;
         }
