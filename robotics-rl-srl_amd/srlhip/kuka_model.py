@@ -161,3 +161,134 @@ def from_sdf(sdf_path, base=None):
 #   IK on the arm block (as above)                                                                    =    990
 #   row setup, 16 sphere-cylinder candidates, env logic, Philox                                       =    900
 FLOPS_PER_ENV_STEP_TREE = 6.2e4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The full model (`srlhip_kuka_tree_model`, 506 doubles): the 12-DoF arm + gripper tree.
+TREE_MODEL_DOUBLES = 506
+TREE_JOINT_FIELDS = (("parent", 1), ("xyz", 3), ("Rj", 9), ("axis", 3), ("lower", 1), ("upper", 1), ("damping", 1), ("mass", 1), ("com", 3),
+                     ("inertia", 6), ("kp", 1), ("max_force", 1), ("max_vel", 1), ("joint_index", 1))          # 33 doubles per DoF
+
+
+def tree_to_dict(table):
+    """flat float64[506] -> {"nd", "joints": [dict x 12], "ee_link", "ee_point", "grip_link", "grip_point", "nsphere",
+    "spheres": [dict(link, c, r, mu) x 16], "table_top_z", "button_base_z", "max_generic_rows", "friction"}"""
+    t = np.asarray(table, dtype=np.float64).reshape(-1)
+    assert t.shape == (TREE_MODEL_DOUBLES,)
+    k = 1
+    joints = []
+    for _ in range(12):
+        j = {}
+        for name, n in TREE_JOINT_FIELDS:
+            j[name] = t[k:k + n].copy() if n > 1 else float(t[k])
+            k += n
+        joints.append(j)
+    out = {"nd": int(t[0]), "joints": joints, "ee_link": int(t[k]), "ee_point": t[k + 1:k + 4].copy(), "grip_link": int(t[k + 4]),
+           "grip_point": t[k + 5:k + 8].copy(), "nsphere": int(t[k + 8])}
+    k += 9
+    out["spheres"] = [{"link": int(t[k + 6 * i]), "c": t[k + 6 * i + 1:k + 6 * i + 4].copy(), "r": float(t[k + 6 * i + 4]), "mu": float(t[k + 6 * i + 5])} for i in range(16)]
+    k += 96
+    out["table_top_z"], out["button_base_z"], out["max_generic_rows"], out["friction"] = float(t[k]), float(t[k + 1]), int(t[k + 2]), int(t[k + 3])
+    return out
+
+
+def tree_to_table(m):
+    t = [float(m["nd"])]
+    for j in m["joints"]:
+        for name, n in TREE_JOINT_FIELDS:
+            t.extend(np.asarray(j[name], dtype=np.float64).reshape(-1).tolist())
+    t.append(float(m["ee_link"])); t.extend(np.asarray(m["ee_point"], dtype=np.float64).tolist())
+    t.append(float(m["grip_link"])); t.extend(np.asarray(m["grip_point"], dtype=np.float64).tolist())
+    t.append(float(m["nsphere"]))
+    for s in m["spheres"]:
+        t.append(float(s["link"])); t.extend(np.asarray(s["c"], dtype=np.float64).tolist()); t.extend([float(s["r"]), float(s["mu"])])
+    t.extend([float(m["table_top_z"]), float(m["button_base_z"]), float(m["max_generic_rows"]), float(m["friction"])])
+    t = np.asarray(t, dtype=np.float64)
+    assert t.shape == (TREE_MODEL_DOUBLES,)
+    return t
+
+
+def tree_default():
+    from . import _lib
+    return tree_to_dict(_lib.kuka_tree_default_model())
+
+
+def _quat_matrix(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def tree_from_pybullet(p, uid, base=None):
+    """The full-model table read from a LOADED body through PyBullet's own introspection (p = the pybullet module, uid = the body
+    kuka.py:60 loads): joint tree, joint frames, axes, limits, damping from getJointInfo; link masses, inertial frames and
+    inertias from getDynamicsInfo; link frames at q = 0 from getLinkState.  Fixed joints (9 and 12 of kuka_with_gripper2.sdf) are
+    merged into their parent bodies exactly.  What PyBullet does not carry per joint — the motors the reference commands every
+    step (kuka.py:167-187) — and the collision spheres come from `base` (default: the baked table); sphere friction is
+    recomputed from the links' lateral friction (x 0.5 for the button / table)."""
+    base = base or tree_default()
+    nj = p.getNumJoints(uid)
+    saved = [p.getJointState(uid, j)[0] for j in range(nj)]
+    for j in range(nj):
+        p.resetJointState(uid, j, 0.0)
+    try:
+        bpos, born = p.getBasePositionAndOrientation(uid)
+        Tb = np.eye(4); Tb[:3, :3] = _quat_matrix(born); Tb[:3, 3] = bpos
+        info = [p.getJointInfo(uid, j) for j in range(nj)]
+        frames, inert = {-1: Tb}, {}
+        for j in range(nj):
+            ls = p.getLinkState(uid, j, computeForwardKinematics=True)
+            T = np.eye(4); T[:3, :3] = _quat_matrix(ls[5]); T[:3, 3] = ls[4]                 # URDF link frame in the world
+            frames[j] = T
+            dyn = p.getDynamicsInfo(uid, j)
+            Rin = _quat_matrix(dyn[4])
+            inert[j] = {"mass": dyn[0], "c": np.array(dyn[3]), "I": Rin @ np.diag(dyn[2]) @ Rin.T, "mu": dyn[1]}
+        movable = [j for j in range(nj) if info[j][2] != p.JOINT_FIXED]
+        assert len(movable) == 12, "expected 12 movable joints, found {}".format(len(movable))
+        dof_of = {j: i for i, j in enumerate(movable)}
+
+        def body_of(link):                       # the DoF whose body a link belongs to (fixed links hang on their parent's)
+            while link not in dof_of:
+                link = info[link][16]
+            return dof_of[link]
+
+        m = {k: v for k, v in base.items()}
+        m["joints"] = [dict(j) for j in base["joints"]]
+        parts = {i: [] for i in range(12)}
+        for j in range(nj):
+            i = body_of(j)
+            Trel = np.linalg.inv(frames[movable[i]]) @ frames[j]                              # identity for the DoF's own link
+            parts[i].append((inert[j]["mass"], Trel[:3, :3] @ inert[j]["c"] + Trel[:3, 3], Trel[:3, :3] @ inert[j]["I"] @ Trel[:3, :3].T))
+        for i, j in enumerate(movable):
+            J = m["joints"][i]
+            par = info[j][16]
+            Tpar = frames[movable[body_of(par)]] if par >= 0 else Tb
+            rel = np.linalg.inv(Tpar) @ frames[j]
+            J["parent"] = float(body_of(par)) if par >= 0 else -1.0
+            # the library places the arm's base at Kuka.reset's base position itself (kuka.py:63): DoF 0 is relative to the base link
+            J["xyz"], J["Rj"] = rel[:3, 3].copy(), rel[:3, :3].reshape(-1).copy()
+            J["axis"] = np.array(info[j][13], dtype=np.float64)
+            J["lower"], J["upper"] = float(info[j][8]), float(info[j][9])
+            if abs(J["lower"]) > 9.0 and abs(J["upper"]) > 9.0 or info[j][8] > info[j][9]:     # +-10 rad "limits" of the gripper joints never act
+                J["lower"], J["upper"] = 1.0, -1.0
+            J["damping"] = float(info[j][6])
+            mt = sum(q[0] for q in parts[i])
+            c = sum(q[0] * q[1] for q in parts[i]) / mt
+            I = np.zeros((3, 3))
+            for mass, ci, Ii in parts[i]:
+                r = ci - c
+                I += Ii + mass * (np.dot(r, r) * np.eye(3) - np.outer(r, r))
+            J["mass"], J["com"] = float(mt), c
+            J["inertia"] = np.array([I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]])
+            J["joint_index"] = float(j)
+        ee = movable[int(base["ee_link"])]
+        m["ee_point"] = inert[ee]["c"].copy()                                                 # IK end effector = the link's inertial frame
+        gl = movable[int(base["grip_link"])]
+        m["grip_point"] = inert[gl]["c"].copy()                                               # getLinkState(.., 8)[0]: COM of that link alone
+        for s in m["spheres"][:int(m["nsphere"])]:
+            s["mu"] = float(inert[movable[int(s["link"])]]["mu"]) * 0.5
+        return m
+    finally:
+        for j in range(nj):
+            p.resetJointState(uid, j, saved[j])

@@ -9,14 +9,16 @@ the reference is available:
 It drives the REFERENCE's own KukaButtonGymEnv (environments/kuka_gym/kuka_button_gym_env.py + kuka.py, unmodified; gym is
 stubbed by tests/golden/_reference_stubs.py when it is not installed, with the restated gym==0.11.0 seeding) on the real
 PyBullet, and records for seeds {0, 1, 2} x 2 episodes of RandomState(1234) discrete actions, per step:
-arm joint positions / velocities (7), button glider position / velocity, gripper position (getArmPos), button_pos, the two
-contact predicates of _reward (button link <-> arm, table <-> arm), reward, done, Kuka.end_effector_pos and the observation.
-It also extracts the model table (`srlhip_kuka_model`, 138 doubles) from pybullet_data's kuka_iiwa/kuka_with_gripper2.sdf
-and from the loaded scene (table top / settled button base height).
+joint positions / velocities of all 14 joints (7 arm + gripper), button glider position / velocity, gripper position (getArmPos),
+button_pos, the two contact predicates of _reward (button link <-> arm, table <-> arm), reward, done, Kuka.end_effector_pos and
+the observation.  It also extracts the FULL model table (`srlhip_kuka_tree_model`, 506 doubles: the 12-DoF arm + gripper tree)
+from the loaded body through PyBullet's own introspection (srlhip.kuka_model.tree_from_pybullet: getJointInfo / getDynamicsInfo
+/ getLinkState at q = 0) and the scene heights (table top / settled button base), plus the rounds 1-2 lumped table
+(`srlhip_kuka_model`, 138 doubles) from the sdf file.
 
-tests/test_kuka_pybullet_pin.py then installs that table in the oracle (oracle.kuka_clib.set_model) and in the HIP stepper
-(Handle.set_kuka_model), replays the same seeds / actions and compares: joint positions within 1e-4, reward / done flags
-bit-exact — the north-star bar.  Until this script has been run somewhere, that test SKIPS with "PARITY UNPINNED".
+tests/test_kuka_pybullet_pin.py then installs the full table in the oracle (oracle.kuka_clib.set_tree_model) and in the HIP
+stepper (Handle.set_kuka_tree_model), replays the same seeds / actions and compares: joint positions within 1e-4, reward / done
+flags bit-exact — the north-star bar.  Until this script has been run somewhere, that test SKIPS with "PARITY UNPINNED".
 
 This container has no PyBullet: the script exits with status 2 and says so."""
 import argparse
@@ -59,7 +61,8 @@ def main():
     sdf = os.path.join(pybullet_data.getDataPath(), "kuka_iiwa", "kuka_with_gripper2.sdf")
     model = kuka_model.from_sdf(sdf)
 
-    records = {k: [] for k in ("seed", "episode", "action", "q", "qd", "glider", "gripper", "button_pos", "contact_button",
+    tree = None
+    records = {k: [] for k in ("seed", "episode", "action", "q", "qd", "q14", "qd14", "glider", "gripper", "button_pos", "contact_button",
                                "contact_table", "reward", "done", "ee_target", "obs", "obs0")}
     arng = np.random.RandomState(1234)
     for seed in (0, 1, 2):
@@ -77,6 +80,8 @@ def main():
                 p7 = np.array(ls[4])
                 model["ee_point"] = R7.T @ (np.array(ls[0]) - p7)                                # its inertial frame = IK end effector
                 model["gripper_point"] = R7.T @ (np.array(env.getArmPos()) - p7)
+                tree = kuka_model.tree_from_pybullet(p, env._kuka.kuka_uid)
+                tree["table_top_z"], tree["button_base_z"] = model["table_top_z"], model["button_base_z"]
             done = False
             while not done:
                 a = int(arng.randint(6))
@@ -85,6 +90,8 @@ def main():
                 gl = p.getJointState(env.button_uid, ref.BUTTON_GLIDER_IDX)
                 records["seed"].append(seed); records["episode"].append(episode); records["action"].append(a)
                 records["q"].append([s[0] for s in js]); records["qd"].append([s[1] for s in js])
+                js14 = [p.getJointState(env._kuka.kuka_uid, j) for j in range(14)]
+                records["q14"].append([s[0] for s in js14]); records["qd14"].append([s[1] for s in js14])
                 records["glider"].append([gl[0], gl[1]])
                 records["gripper"].append(list(env.getArmPos())); records["button_pos"].append(list(env.button_pos))
                 records["contact_button"].append(int(len(p.getContactPoints(env.button_uid, env._kuka.kuka_uid, ref.BUTTON_LINK_IDX)) > 0))
@@ -94,6 +101,7 @@ def main():
         env.close()
     out = {k: np.asarray(v) for k, v in records.items()}
     out["model_table"] = kuka_model.to_table(model)
+    out["tree_model_table"] = kuka_model.tree_to_table(tree)
     out["pybullet_version"] = np.array(str(getattr(p, "getAPIVersion", lambda: "?")()))
     np.savez_compressed(args.out, **out)
     print("wrote {}: {} steps, model table from {}".format(args.out, len(out["action"]), sdf))

@@ -3,9 +3,9 @@ reward / done flags bit-exact).  The fixture tests/golden/kuka_pybullet_referenc
 tests/golden/make_kuka_pybullet_golden.py on a machine with pybullet==1.8.6 (this repo's build container has none): until
 it exists these tests SKIP — "PARITY UNPINNED" — and the dynamics parity claim stays GPU == oracle only.
 
-When the fixture exists: its model table (link frames, inertial parameters, limits, heights extracted from pybullet_data)
-is installed in the oracle and in the HIP stepper, the recorded seeds / actions are replayed, and every recorded step is
-compared."""
+When the fixture exists: its FULL model table (srlhip_kuka_tree_model: the 12-DoF arm + gripper tree — link frames, inertial
+parameters, limits, friction read from the loaded PyBullet body, scene heights) is installed in the oracle and in the HIP
+stepper, the recorded seeds / actions are replayed, and every recorded step is compared (arm AND gripper joints)."""
 import os
 
 import numpy as np
@@ -31,25 +31,30 @@ def episodes_of(fx):
         yield int(seed), fx["action"][idx].astype(np.int32), idx
 
 
-def compare(fx, idx, q, reward, done):
+GRIPPER_JOINTS = [7, 8, 10, 11, 13]             # the movable gripper joints of kuka_with_gripper2.sdf (9 and 12 are fixed)
+
+
+def compare(fx, idx, q, reward, done, gq=None):
     assert np.array_equal(done.astype(int), fx["done"][idx]), "done flags differ from PyBullet"
     assert np.array_equal(reward, fx["reward"][idx].astype(reward.dtype)), "rewards differ from PyBullet"
     live = fx["done"][idx] == 0                     # the state after a terminal step already belongs to the next episode
     err = np.abs(q[live] - fx["q"][idx][live]).max()
     assert err <= TOL, "max |q - q_pybullet| = {:.3e}".format(err)
+    if gq is not None:
+        gerr = np.abs(gq[live] - fx["q14"][idx][live][:, GRIPPER_JOINTS]).max()
+        assert gerr <= TOL, "max |q_gripper - q_pybullet| = {:.3e}".format(gerr)
     return err
 
 
 def test_oracle_matches_pybullet():
     fx = load_fixture()
-    saved = kuka_clib.get_model()
     try:
-        kuka_clib.set_model(fx["model_table"])
+        kuka_clib.set_tree_model(fx["tree_model_table"])          # switches the oracle to the full model with PyBullet's own numbers
         for seed, actions, idx in episodes_of(fx):
-            out = kuka_clib.rollout([seed], len(actions), actions=actions[:, None])
-            compare(fx, idx, out["q"][:, 0], out["reward64"][:, 0], out["done"][:, 0])
+            out = kuka_clib.rollout([seed], len(actions), actions=actions[:, None], aux=True)
+            compare(fx, idx, out["q"][:, 0], out["reward64"][:, 0], out["done"][:, 0], gq=out["q_all"][:, 0, 7:12])
     finally:
-        kuka_clib.set_model(saved)
+        kuka_clib.set_full(False)
 
 
 @pytest.mark.gpu
@@ -59,12 +64,14 @@ def test_hip_stepper_matches_pybullet():
     for seed, actions, idx in episodes_of(fx):
         cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
         cfg.num_envs, cfg.seed0, cfg.rng_mode, cfg.auto_reset = 1, seed, _lib.RNG_MT19937, 1
+        assert cfg.kuka_model == _lib.KUKA_MODEL_FULL
         h = _lib.Handle(cfg)
-        h.set_kuka_model(fx["model_table"])
+        h.set_kuka_tree_model(fx["tree_model_table"])
         h.reset()
-        q, rew, done = [], [], []
+        q, gq, rew, done = [], [], [], []
         for a in actions:
             o, r, d = h.step(np.array([a], np.int32))
-            q.append(h.get_state(_lib.F_KUKA_Q)[:, 0].copy()); rew.append(float(r[0])); done.append(int(d[0]))
-        compare(fx, idx, np.array(q), np.array(rew), np.array(done))
+            q.append(h.get_state(_lib.F_KUKA_Q)[:, 0].copy()); gq.append(h.get_state(_lib.F_KUKA_GRIPPER_Q)[:, 0].copy())
+            rew.append(float(r[0])); done.append(int(d[0]))
+        compare(fx, idx, np.array(q), np.array(rew), np.array(done), gq=np.array(gq))
         h.close()
