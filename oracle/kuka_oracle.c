@@ -92,7 +92,8 @@ static void crf_vec(const vec6 v, const vec6 f, vec6 o) {
  * kuka_oracle_set_full() switches; tests are single-threaded callers (OpenMP workers only read the table). */
 static tree_model g_m;
 static int g_m_ready = 0, g_full = 0;
-static void model_refresh(void) { if (g_full) tm_build_full(&g_m); else tm_build_lumped(&g_m); g_m_ready = 1; }
+static void inertia_refresh(void);
+static void model_refresh(void) { if (g_full) tm_build_full(&g_m); else tm_build_lumped(&g_m); g_m_ready = 1; inertia_refresh(); }
 static const tree_model *model(void) { if (!g_m_ready) model_refresh(); return &g_m; }
 #define ND (model()->nd)
 
@@ -170,59 +171,84 @@ static void spatial_inertia(int i, mat6 I) {
         I[a + 3][b + 3] = a == b ? m : 0.0;
     }
 }
-/* qdd = FD(q, qd, tau) with gravity (0, 0, gz) — RBDA Table 7.1 on a kinematic tree, revolute joints S = [axis ; 0] */
-static void aba(const double q[TN], const double qd[TN], const double tau[TN], double gz, double qdd[TN]) {
+static mat6 g_I6[TN];
+static void inertia_refresh(void) { int i; for (i = 0; i < g_m.nd; i++) spatial_inertia(i, g_I6[i]); }
+/* Featherstone ABA (RBDA Table 7.1) on a kinematic tree, revolute joints S = [axis ; 0], split in two so that the thirteen
+ * solves of one physics step (the step itself + one unit torque per DoF for M^-1) share what depends on q only:
+ *   aba_factor : motion transforms, articulated inertias IA, U = IA S, d = S.U          (the 6x6 congruence transforms)
+ *   aba_solve  : velocities / bias forces, backward vector pass, forward accelerations   (6-vectors only)
+ * Same arithmetic, in the same order, as the single-pass form of rounds 1-2. */
+typedef struct { mat6 X[TN], IA[TN], Ia[TN]; vec6 S[TN], U[TN]; double d[TN]; } aba_fac;
+static void aba_factor(const double q[TN], aba_fac *f) {
+    const tree_model *m = model(); const int n = m->nd; int i, r, s, k;
+    for (i = 0; i < n; i++) {
+        motion_transform(i, q[i], f->X[i]);
+        for (k = 0; k < 3; k++) { f->S[i][k] = m->axis[i][k]; f->S[i][3 + k] = 0.0; }
+        memcpy(f->IA[i], g_I6[i], sizeof(mat6));
+    }
+    for (i = n - 1; i >= 0; i--) {
+        const int par = m->parent[i];
+        mat6_vec(f->IA[i], f->S[i], f->U[i]);
+        f->d[i] = 0.0;
+        for (k = 0; k < 6; k++) f->d[i] += f->S[i][k] * f->U[i][k];
+        if (par >= 0) {
+            mat6 T;
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) f->Ia[i][r][s] = f->IA[i][r][s] - f->U[i][r] * f->U[i][s] / f->d[i];
+            /* IA[parent] += X^T Ia X */
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += f->Ia[i][r][k] * f->X[i][k][s]; T[r][s] = acc; }
+            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += f->X[i][k][r] * T[k][s]; f->IA[par][r][s] += acc; }
+        }
+    }
+}
+static void aba_solve(const aba_fac *f, const double qd[TN], const double tau[TN], double gz, double qdd[TN]) {
     const tree_model *m = model(); const int n = m->nd;
-    mat6 X[TN], IA[TN]; vec6 S[TN], v[TN], c[TN], pA[TN], U[TN], a[TN]; double d[TN], u[TN];
-    int i, r, s, k;
+    vec6 v[TN], c[TN], pA[TN], a[TN]; double u[TN];
+    int i, k;
     for (i = 0; i < n; i++) {
         vec6 vJ, Iv; const int par = m->parent[i];
-        motion_transform(i, q[i], X[i]);
-        for (k = 0; k < 3; k++) { S[i][k] = m->axis[i][k]; S[i][3 + k] = 0.0; }
-        for (k = 0; k < 6; k++) vJ[k] = S[i][k] * qd[i];
+        for (k = 0; k < 6; k++) vJ[k] = f->S[i][k] * qd[i];
         if (par < 0) memcpy(v[i], vJ, sizeof(vec6));
-        else { mat6_vec(X[i], v[par], v[i]); for (k = 0; k < 6; k++) v[i][k] += vJ[k]; }
+        else { mat6_vec(f->X[i], v[par], v[i]); for (k = 0; k < 6; k++) v[i][k] += vJ[k]; }
         crm_vec(v[i], vJ, c[i]);
-        spatial_inertia(i, IA[i]);
-        mat6_vec(IA[i], v[i], Iv);
+        mat6_vec(g_I6[i], v[i], Iv);
         crf_vec(v[i], Iv, pA[i]);
     }
     for (i = n - 1; i >= 0; i--) {
         const int par = m->parent[i];
-        mat6_vec(IA[i], S[i], U[i]);
-        d[i] = 0.0; u[i] = tau[i];
-        for (k = 0; k < 6; k++) { d[i] += S[i][k] * U[i][k]; u[i] -= S[i][k] * pA[i][k]; }
+        u[i] = tau[i];
+        for (k = 0; k < 6; k++) u[i] -= f->S[i][k] * pA[i][k];
         if (par >= 0) {
-            mat6 Ia, T; vec6 pa, Iac, t;
-            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) Ia[r][s] = IA[i][r][s] - U[i][r] * U[i][s] / d[i];
-            mat6_vec(Ia, c[i], Iac);
-            for (k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + U[i][k] * u[i] / d[i];
-            /* IA[parent] += X^T Ia X ;  pA[parent] += X^T pa */
-            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += Ia[r][k] * X[i][k][s]; T[r][s] = acc; }
-            for (r = 0; r < 6; r++) for (s = 0; s < 6; s++) { double acc = 0; for (k = 0; k < 6; k++) acc += X[i][k][r] * T[k][s]; IA[par][r][s] += acc; }
-            mat6T_vec(X[i], pa, t);
+            vec6 pa, Iac, t;
+            mat6_vec(f->Ia[i], c[i], Iac);
+            for (k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + f->U[i][k] * u[i] / f->d[i];
+            mat6T_vec(f->X[i], pa, t);                              /* pA[parent] += X^T pa */
             for (k = 0; k < 6; k++) pA[par][k] += t[k];
         }
     }
     for (i = 0; i < n; i++) {
         vec6 ap; double Ua = 0; const int par = m->parent[i];
-        if (par < 0) { vec6 a0 = {0, 0, 0, 0, 0, 0}; a0[5] = -gz; mat6_vec(X[i], a0, ap); }
-        else mat6_vec(X[i], a[par], ap);
+        if (par < 0) { vec6 a0 = {0, 0, 0, 0, 0, 0}; a0[5] = -gz; mat6_vec(f->X[i], a0, ap); }
+        else mat6_vec(f->X[i], a[par], ap);
         for (k = 0; k < 6; k++) ap[k] += c[i][k];
-        for (k = 0; k < 6; k++) Ua += U[i][k] * ap[k];
-        qdd[i] = (u[i] - Ua) / d[i];
-        for (k = 0; k < 6; k++) a[i][k] = ap[k] + S[i][k] * qdd[i];
+        for (k = 0; k < 6; k++) Ua += f->U[i][k] * ap[k];
+        qdd[i] = (u[i] - Ua) / f->d[i];
+        for (k = 0; k < 6; k++) a[i][k] = ap[k] + f->S[i][k] * qdd[i];
     }
 }
+/* qdd = FD(q, qd, tau) with gravity (0, 0, gz) */
+static void aba(const double q[TN], const double qd[TN], const double tau[TN], double gz, double qdd[TN]) {
+    aba_fac f; aba_factor(q, &f); aba_solve(&f, qd, tau, gz, qdd);
+}
 /* W = M(q)^-1, column j = response to a unit torque on joint j (no velocity, no gravity) */
-static void mass_matrix_inverse(const double q[TN], double W[TN][TN]) {
+static void mass_matrix_inverse_f(const aba_fac *f, double W[TN][TN]) {
     double zero[TN] = {0}, e[TN], col[TN]; int i, j; const int n = ND;
     for (j = 0; j < n; j++) {
         memset(e, 0, sizeof e); e[j] = 1.0;
-        aba(q, zero, e, 0.0, col);
+        aba_solve(f, zero, e, 0.0, col);
         for (i = 0; i < n; i++) W[i][j] = col[i];
     }
 }
+static void mass_matrix_inverse(const double q[TN], double W[TN][TN]) { aba_fac f; aba_factor(q, &f); mass_matrix_inverse_f(&f, W); }
 
 /* ------------------------------------------------------------------ inverse kinematics */
 /* one damped-least-squares step towards (target position, orientation = quat(euler(0,-pi,0))) */
@@ -397,10 +423,14 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     {
         /* -- unconstrained velocities: ABA with joint damping torques and gravity -- */
         for (i = 0; i < n; i++) tau[i] = -m->damping[i] * e->qd[i];
-        aba(e->q, e->qd, tau, KM_GRAVITY_Z, qdd);
+        {
+            aba_fac fac;
+            aba_factor(e->q, &fac);
+            aba_solve(&fac, e->qd, tau, KM_GRAVITY_Z, qdd);
+            mass_matrix_inverse_f(&fac, W);
+        }
         for (i = 0; i < n; i++) e->qd[i] += dt * qdd[i];
         for (b = 0; b < nb; b++) *bqd[b] += dt * KM_GRAVITY_Z;
-        mass_matrix_inverse(e->q, W);
 
         /* -- constraint rows: motors, then joint limits, then contacts (normals, then their friction rows) -- */
         for (i = 0; i < n; i++) {                                   /* joint motors, kuka.py:167-187 (btMultiBodyJointMotor) */
@@ -678,7 +708,7 @@ void kuka_oracle_set_full(int full) { g_full = full != 0; model_refresh(); }
 int kuka_oracle_get_full(void) { return g_full; }
 int kuka_oracle_tree_doubles(void) { return TM_DOUBLES; }
 void kuka_oracle_get_tree_model(double *t) { tm_to_table(model(), t); }
-void kuka_oracle_set_tree_model(const double *t) { tm_from_table(&g_m, t); g_m_ready = 1; g_full = g_m.nd > 7; }
+void kuka_oracle_set_tree_model(const double *t) { tm_from_table(&g_m, t); g_m_ready = 1; g_full = g_m.nd > 7; inertia_refresh(); }
 /* selects KukaMovingButtonGymEnv (1) / Kuka2ButtonGymEnv (2) / KukaRandButtonGymEnv (3) semantics for the following calls
  * (tests are single-threaded callers) */
 void kuka_oracle_set_moving(int moving) { g_moving = moving; g_two = 0; g_rand = 0; }

@@ -1,0 +1,62 @@
+"""CPU: the FULL-model Kuka stepper's own source (csrc/kuka_tree.hpp: 16-lane groups, pointer-jumping kinematics, masked broadcast
+sums over the gripper tree, two-bank projected Gauss-Seidel with friction rows) executed on the host — the 16 lanes of a group
+are 16 lockstep fibers (csrc/kuka_hostcheck.cpp), the LDS scratch is poisoned with NaN — against the oracle in its full-model
+mode (link-frame ABA, dv-space Gauss-Seidel).  Bar: 1e-9 on every joint (north star: 1e-4), discrete flags bit for bit."""
+import numpy as np
+import pytest
+
+import hostcheck
+from oracle import kuka_clib
+
+TOL = 1e-9
+
+
+@pytest.fixture(autouse=True)
+def full_oracle():
+    kuka_clib.set_full(True)
+    yield
+    kuka_clib.set_full(False)
+
+
+def run(n, T, seed0, variant=0, **kw):
+    rs = np.random.RandomState(seed0)
+    if kw.get("is_discrete", True):
+        actions = rs.randint(6, size=(T, n)).astype(np.int32)
+        actions[rs.rand(T, n) < 0.2] = 4                                  # press down: button contacts, friction rows
+    else:
+        actions = rs.uniform(-1, 1, size=(T, n, 7 if kw.get("action_joints") else 3)).astype(np.float32)
+    kuka_clib.set_variant(variant); hostcheck.set_variant(variant)
+    try:
+        a = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions, aux=True, **kw)
+        b = hostcheck.tree_rollout(seed0 + np.arange(n), T, actions=actions, **kw)
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
+    assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
+    assert np.abs(a["reward64"] - b["reward64"]).max() <= TOL
+    assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["gripper"] - b["gripper"]).max() <= TOL
+    assert np.abs(a["obs"] - b["obs"]).max() <= 1e-6 and np.abs(a["obs0"] - b["obs0"]).max() <= 1e-6
+    assert np.abs(a["final_state"][:, 30:35] - b["final_state"][:, 30:35]).max() <= TOL           # gripper joints
+    assert np.array_equal(a["ep_stats"], b["ep_stats"])
+    return a
+
+
+def test_model_tables_of_product_and_oracle_agree():
+    assert np.abs(kuka_clib.get_tree_model() - hostcheck.tree_default_model()).max() < 1e-15
+
+
+def test_discrete_actions_with_contacts_and_friction_rows():
+    a = run(6, 900, 5, rng_mode=kuka_clib.RNG_MT19937, random_target=True)
+    assert a["rows"][:, :, 0].sum() > 10 and a["rows"][:, :, 1].sum() > 10 and a["done"].sum() >= 4
+    # the fingers start open (-+0.3 rad, kuka.py:65-66) and are closed by their 2 / 2.5 N m motors during the 500 settle steps
+    assert np.abs(a["q_all"][0, :, [8, 10]]).max() < 0.05
+
+
+@pytest.mark.parametrize("kw,variant", [
+    (dict(rng_mode=kuka_clib.RNG_PHILOX, force_down=False, shape_reward=True), 0),
+    (dict(rng_mode=kuka_clib.RNG_MT19937, is_discrete=False), 0),
+    (dict(rng_mode=kuka_clib.RNG_MT19937, is_discrete=False, action_joints=True), 0),
+    (dict(rng_mode=kuka_clib.RNG_PHILOX, shape_reward=True), 1),
+    (dict(rng_mode=kuka_clib.RNG_MT19937, random_target=True, action_repeat=2), 3),
+])
+def test_options_and_variants(kw, variant):
+    run(4, 350, 31, variant=variant, **kw)
