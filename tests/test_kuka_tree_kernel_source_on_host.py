@@ -36,7 +36,7 @@ def run(n, T, seed0, variant=0, **kw):
     assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["gripper"] - b["gripper"]).max() <= TOL
     assert np.abs(a["obs"] - b["obs"]).max() <= 1e-6 and np.abs(a["obs0"] - b["obs0"]).max() <= 1e-6
     assert np.abs(a["final_state"][:, 30:35] - b["final_state"][:, 30:35]).max() <= TOL           # gripper joints
-    assert np.array_equal(a["ep_stats"], b["ep_stats"])
+    assert np.array_equal(a["ep_stats"][:, 1:], b["ep_stats"][:, 1:]) and np.abs(a["ep_stats"][:, 0] - b["ep_stats"][:, 0]).max() <= 1e-6   # shaped returns are float sums
     return a
 
 
