@@ -6,9 +6,17 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_k
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o kuka -- python $R/bench.py > $OUT/bench_default.json 2>/dev/null
-cp $(find /tmp/prof_k -name "*kernel_stats.csv" | head -1) $OUT/default_kernel_stats.csv
+# (1) the default command exactly as the driver runs it: headline + secondary legs + cpu baselines, one JSON line
+timeout 900 python $R/bench.py > $OUT/bench_default.json 2>/dev/null
+# (2) kernel stats per workload, each traced alone so that a kernel's average launch duration is that of ONE launch shape
+#     (the default command mixes 2048-step rollouts and single steps of the same kernel)
+for w in kuka mobile kuka_pixels; do
+  rm -rf /tmp/prof_$w
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --no-secondary > $OUT/bench_$w.json 2>/dev/null
+  cp $(find /tmp/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${w}_kernel_stats.csv
+done
+# the reference-exact MT19937 streams on the same workload
+timeout 300 python $R/bench.py --rng mt19937 --no-cpu-baseline --no-secondary --steps 5 > $OUT/bench_kuka_mt19937.json 2>/dev/null
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM"; do
   tag=$(echo $pmc | cut -d" " -f1)
   rm -rf /tmp/pmc_k

@@ -230,10 +230,10 @@ int kuka_alloc(Handle *h) {
     }
     s->custom_model = 0;
     s->full = h->cfg.kuka_model == SRLHIP_KUKA_MODEL_FULL ? 1 : 0;
-    s->tmodel = nullptr; s->tsettled = nullptr; s->tstarts = nullptr;
+    s->tmodel = nullptr; s->ttable = nullptr; s->tsettled = nullptr; s->tstarts = nullptr;
     if (s->full) {
         // the full model has its own table, settled state and start-state table; the lane-per-env kernels below are not used
-        if ((rc = h->dalloc(&s->tmodel, 1)) || (rc = h->dalloc(&s->tsettled, tree::kTreeStartDoubles)) ||
+        if ((rc = h->dalloc(&s->tmodel, 1)) || (rc = h->dalloc(&s->ttable, tree::kLaneTableDoubles)) || (rc = h->dalloc(&s->tsettled, tree::kTreeStartDoubles)) ||
             (rc = h->dalloc(&s->tstarts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * tree::kTreeStartDoubles)))
             return rc;
         TreeModel tm; default_tree_model(tm);

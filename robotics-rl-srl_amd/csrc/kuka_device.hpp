@@ -42,6 +42,7 @@ struct KukaState {
     // full model (cfg.kuka_model = SRLHIP_KUKA_MODEL_FULL, kuka_tree.hpp): its own table and start states
     int32_t full;
     TreeModel *tmodel;
+    double *ttable;     // [tree::kLaneTableDoubles] per-lane constants derived from tmodel (kuka_tree_table_k)
     double *tsettled;   // [kTreeStartDoubles]
     double *tstarts;    // [nstarts][kTreeStartDoubles]
 };

@@ -13,15 +13,24 @@ using tree::TLane;
 using tree::NJ;
 constexpr int kTS = tree::kTreeScratchDoubles, kTStart = tree::kTreeStartDoubles;
 
-// the wavefront's lane-constant table in LDS (kuka_tree.hpp: lane_store / lane_load): built once per launch from the model table
-__device__ __forceinline__ void build_lane_table(TLane &L, const TreeModel *m, double *tab) {
-    tree::lane_init(L, m);
-    if (threadIdx.x < grp::GL) tree::lane_store(L, tab);      // the four rows of the wavefront hold identical constants: row 0 writes
+// the wavefront's lane-constant table in LDS (kuka_tree.hpp: lane_store / lane_view).  It is derived from the model table ONCE per
+// model (kuka_tree_table_k -> KukaState::ttable in HBM: the ancestor / descendant walks cost ~0.1 ms, far too much for the
+// single-step launches of the per-step API); a launch only copies its 5.6 KB.
+struct LaneId { int l; bool jnt; double q0, base_z; };
+__device__ __forceinline__ void build_lane_table(LaneId &L, const double *ttable, double *tab) {
+    for (int i = threadIdx.x; i < tree::kLaneTableDoubles; i += kGroupBlock) tab[i] = ttable[i];
     __syncthreads();
+    L.l = (int)(threadIdx.x & (grp::GL - 1)); L.jnt = L.l < NJ;
+    L.q0 = tab[tree::LT_Q0 * grp::GL + L.l]; L.base_z = tab[tree::LT_COUNT * grp::GL + tree::LS_BASEZ];
+}
+__global__ void __launch_bounds__(kGroupBlock) kuka_tree_table_k(const TreeModel *m, double *ttable) {
+    TLane L;
+    tree::lane_init(L, m);
+    if (threadIdx.x < grp::GL) tree::lane_store(L, ttable);
 }
 
 // env scalars replicated on the row, the own joint per joint lane
-__device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const TLane &L, Env &v, grp::GState &g) {
+__device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const LaneId &L, Env &v, grp::GState &g) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
     v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
@@ -34,7 +43,7 @@ __device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, cons
     g.sq = s.d[tree_plane(D_SQ, D_GSQ, j) * n + e]; g.cq = s.d[tree_plane(D_CQ, D_GCQ, j) * n + e];
     if (!L.jnt) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
 }
-__device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, const TLane &L, const Env &v, const grp::GState &g, bool valid) {
+__device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, const LaneId &L, const Env &v, const grp::GState &g, bool valid) {
     if (valid && L.jnt) {
         s.d[tree_plane(D_Q, D_GQ, L.l) * n + e] = g.q; s.d[tree_plane(D_QD, D_GQD, L.l) * n + e] = g.qd;
         s.d[tree_plane(D_SQ, D_GSQ, L.l) * n + e] = g.sq; s.d[tree_plane(D_CQ, D_GCQ, L.l) * n + e] = g.cq;
@@ -65,8 +74,8 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     const Cfg &cfg = p.cfg;
     __shared__ double tab[tree::kLaneTableDoubles];
     double *scratch = scratch_all[threadIdx.x / GL];
-    TLane L;
-    build_lane_table(L, s.tmodel, tab);
+    LaneId L;
+    build_lane_table(L, s.ttable, tab);
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
     Rng rng0;
@@ -149,7 +158,7 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     const bool valid = e_raw < p.n && !(mask && !mask[e_raw < p.n ? e_raw : 0]);
     const int e = e_raw < p.n ? e_raw : p.n - 1;
     __shared__ double tab[tree::kLaneTableDoubles];
-    TLane L; build_lane_table(L, s.tmodel, tab);
+    LaneId L; build_lane_table(L, s.ttable, tab);
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
     Rng rng0;
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_settle_k(KukaParams p, 
     using namespace grp;
     __shared__ double scratch_all[kGroupEnvs][kTS];
     __shared__ double tab[tree::kLaneTableDoubles];
-    TLane L; build_lane_table(L, s.tmodel, tab);
+    LaneId L; build_lane_table(L, s.ttable, tab);
     Env e = {};
     GState g;
     tree::tinitial(e, g, tab);
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_starts_k(KukaParams p, 
     const bool valid = idx_raw < s.nstarts;
     const int idx = valid ? idx_raw : s.nstarts - 1;
     __shared__ double tab[tree::kLaneTableDoubles];
-    TLane L; build_lane_table(L, s.tmodel, tab);
+    LaneId L; build_lane_table(L, s.ttable, tab);
     Env e = {};
     GState g;
     tree::tunpack_start(e, g, s.tsettled);
@@ -218,7 +227,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
     const bool valid = e_raw < p.n;
     const int e = valid ? e_raw : p.n - 1;
     __shared__ double tab[tree::kLaneTableDoubles];
-    TLane L; build_lane_table(L, s.tmodel, tab);
+    LaneId L; build_lane_table(L, s.ttable, tab);
     Env v = {};
     GState g;
     tload(s, n, e, L, v, g);
@@ -264,6 +273,8 @@ int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const
 }
 
 int kuka_tree_settle(Handle *h, const KukaParams &p) {
+    hipLaunchKernelGGL(kuka_tree_table_k, dim3(1), dim3(kGroupBlock), 0, h->stream, h->kuka->tmodel, h->kuka->ttable);
+    SRL_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(kuka_tree_settle_k, dim3(1), dim3(kGroupBlock), 0, h->stream, p, *h->kuka);
     SRL_HIP_CHECK(h, hipGetLastError());
     if (h->kuka->nstarts > 0) {
