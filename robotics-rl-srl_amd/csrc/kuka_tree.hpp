@@ -440,55 +440,72 @@ SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA,
     if (part) { accA = nA; accB = nB; if (L.l == s) b.lam = t; }
 }
 
-// The common contact case — no joint-limit row in the wavefront, at most two contact normals per env (slots 0, 1: lanes 0, 1) and
-// their friction rows (slots kNGen, kNGen + 1) — with every coupling in registers and every broadcast a DPP row_newbcast: no LDS
-// access and no ds_bpermute inside the 150 sweeps (the general loop below pays ~100 cycles of LDS latency per row).
-template <int J> SRL_G void c2_rowA(const TRows &r, double nBA_J, double eJ, double &accA, double &accB, double &uA) {
+// Contact steps without a joint-limit row in the wavefront (every contact case a random agent produces: two finger tips with two
+// spheres each on the cap, plus the base): all couplings in registers and every broadcast a DPP row_newbcast — no LDS access and
+// no ds_bpermute inside the 150 sweeps (the general loop below pays ~100 cycles of LDS latency per row: measured 300+ us per
+// step with four contacts).  Slots: contact normals g = 0..kNGen-1 on lanes g, their friction rows on lanes kNGen + g; slots a
+// wavefront does not use (g >= ngen_w, wave-uniform) are skipped, slots an ENV does not use have zero coefficients.
+template <int J> SRL_G void cn_rowA(const TRows &r, double nBA_J, double eJ, double &accA, double &accB, double &uA) {
     const double t = clamp01(r.cs + accA);
     accA = fma(-eJ, accA, accA);                    // the own accumulator restarts
     uA = fma(eJ, t - uA, uA);                       // lane J keeps its value
     fmac_bcast<J>(accA, t, r.n[J]);
     fmac_bcast<J>(accB, t, nBA_J);
 }
-// bank-B slot S on lane S; NRM: the lane of its normal row (friction rows), -1 for a normal row
-template <int S, int NRM> SRL_G void c2_rowB(BRow &b, double nAB_S, double nBB_S, double eS, double &accA, double &accB) {
-    double lo = b.lo, hi = b.hi, t = b.cs + accB;
-    bool keep = !b.on;                              // a slot this env does not use hands round 0 (its lambda stays 0)
-    if constexpr (NRM >= 0) {
-        const double tot = bcast<NRM>(b.lam);       // the normal row's CURRENT impulse
-        lo = -b.mu * tot; hi = b.mu * tot;
-        keep = keep || !(tot > 0.0);                // friction rows wait for a positive normal impulse
-    }
-    t = t < lo ? lo : (t > hi ? hi : t);
-    t = keep ? b.lam : t;
-    b.lam = fma(eS, t - b.lam, b.lam);
+// contact-normal slot G on lane G: lambda = clamp(cs + accB, 0, hi)
+template <int G> SRL_G void cn_rowN(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB) {
+    double t = b.cs + accB;
+    t = t < 0.0 ? 0.0 : (t > b.hi ? b.hi : t);      // (an unused slot has cs = 0, zero couplings and hi = 0: t = 0)
+    lam = fma(eS, t - lam, lam);
     accB = fma(-eS, accB, accB);
-    fmac_bcast<S>(accA, t, nAB_S);
-    fmac_bcast<S>(accB, t, nBB_S);
+    fmac_bcast<G>(accA, t, nAB);
+    fmac_bcast<G>(accB, t, nBB);
 }
-SRL_G double sweeps_contact2(const TRows &r, BRow &b, const double *sc, double accA, bool two) {
+// friction slot kNGen + G: bounds +-mu * (current impulse of normal slot G); the row keeps its value while that is not positive
+template <int G> SRL_G void cn_rowF(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB) {
+    const double tot = bcast<G>(lam);               // lane G's lambda: the normal row's CURRENT impulse
+    const double hi = b.mu * tot;
+    double t = b.cs + accB;
+    t = t < -hi ? -hi : (t > hi ? hi : t);
+    t = (b.fric && tot > 0.0) ? t : lam;            // (on lanes that do not own an active friction row lam is 0 and stays 0)
+    lam = fma(eS, t - lam, lam);
+    accB = fma(-eS, accB, accB);
+    fmac_bcast<kNGen + G>(accA, t, nAB);
+    fmac_bcast<kNGen + G>(accB, t, nBB);
+}
+template <int G> SRL_G void cn_normals(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
+    if (G < ngen_w) cn_rowN<G>(b, lam, nAB[G], nBB[G], eB[G], accA, accB);
+    if constexpr (G + 1 < kNGen) cn_normals<G + 1>(b, lam, nAB, nBB, eB, accA, accB, ngen_w);
+}
+template <int G> SRL_G void cn_frictions(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
+    if (G < ngen_w) cn_rowF<G>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB);
+    if constexpr (G + 1 < kNGen) cn_frictions<G + 1>(b, lam, nAB, nBB, eB, accA, accB, ngen_w);
+}
+SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double accA, int ngen_w) {
     int l = lane_id();
 #if SRL_G_DEVICE
     asm volatile("" : "+v"(l));
 #endif
-    double nBA[kNArows], eA[kNArows];
+    double nBA[kNArows], eA[kNArows], nAB[kNB], nBB[kNB], eB[kNB];
 #pragma unroll
     for (int j = 0; j < kNArows; j++) { nBA[j] = sc[SC_NBA + j * GL + l]; eA[j] = l == j ? 1.0 : 0.0; }
-    const double nAB0 = sc[SC_NAB + 0 * GL + l], nAB1 = sc[SC_NAB + 1 * GL + l], nABf0 = sc[SC_NAB + kNGen * GL + l], nABf1 = sc[SC_NAB + (kNGen + 1) * GL + l];
-    const double nBB0 = sc[SC_NBB + 0 * GL + l], nBB1 = sc[SC_NBB + 1 * GL + l], nBBf0 = sc[SC_NBB + kNGen * GL + l], nBBf1 = sc[SC_NBB + (kNGen + 1) * GL + l];
-    const double e0 = eA[0], e1 = eA[1], ef0 = l == kNGen ? 1.0 : 0.0, ef1 = l == kNGen + 1 ? 1.0 : 0.0;
-    double accB = 0.0, uA = 0.0;
+#pragma unroll
+    for (int s = 0; s < kNB; s++) { nAB[s] = sc[SC_NAB + s * GL + l]; nBB[s] = sc[SC_NBB + s * GL + l]; eB[s] = l == s ? 1.0 : 0.0; }
+    // a lane that owns no active normal row must hand round 0: hi = 0 does that (cs and the couplings of such a row are 0 anyway)
+    BRow bb = b;
+    if (!(bb.on && !bb.fric)) bb.hi = 0.0;
+    if (!bb.on) bb.cs = 0.0;
+    double lam = 0.0, accB = 0.0, uA = 0.0;
     for (int it = 0; it < kSolverIters; it++) {
-        c2_rowA<0>(r, nBA[0], eA[0], accA, accB, uA);   c2_rowA<1>(r, nBA[1], eA[1], accA, accB, uA);   c2_rowA<2>(r, nBA[2], eA[2], accA, accB, uA);
-        c2_rowA<3>(r, nBA[3], eA[3], accA, accB, uA);   c2_rowA<4>(r, nBA[4], eA[4], accA, accB, uA);   c2_rowA<5>(r, nBA[5], eA[5], accA, accB, uA);
-        c2_rowA<6>(r, nBA[6], eA[6], accA, accB, uA);   c2_rowA<7>(r, nBA[7], eA[7], accA, accB, uA);   c2_rowA<8>(r, nBA[8], eA[8], accA, accB, uA);
-        c2_rowA<9>(r, nBA[9], eA[9], accA, accB, uA);   c2_rowA<10>(r, nBA[10], eA[10], accA, accB, uA); c2_rowA<11>(r, nBA[11], eA[11], accA, accB, uA);
-        c2_rowA<kBM>(r, nBA[kBM], eA[kBM], accA, accB, uA); c2_rowA<kBLo>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); c2_rowA<kBHi>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);
-        c2_rowB<0, -1>(b, nAB0, nBB0, e0, accA, accB);
-        if (two) c2_rowB<1, -1>(b, nAB1, nBB1, e1, accA, accB);
-        c2_rowB<kNGen, 0>(b, nABf0, nBBf0, ef0, accA, accB);
-        if (two) c2_rowB<kNGen + 1, 1>(b, nABf1, nBBf1, ef1, accA, accB);
+        cn_rowA<0>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2>(r, nBA[2], eA[2], accA, accB, uA);
+        cn_rowA<3>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5>(r, nBA[5], eA[5], accA, accB, uA);
+        cn_rowA<6>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8>(r, nBA[8], eA[8], accA, accB, uA);
+        cn_rowA<9>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11>(r, nBA[11], eA[11], accA, accB, uA);
+        cn_rowA<kBM>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowA<kBLo>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);
+        cn_normals<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
+        cn_frictions<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
     }
+    b.lam = lam;
     return uA;
 }
 
@@ -676,7 +693,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
         accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
     }
-    if (nlim_w == 0 && ngen_w <= 2) uA = sweeps_contact2(r, b, sc, accA, ngen_w == 2);
+    if (nlim_w == 0) uA = sweeps_contacts(r, b, sc, accA, ngen_w);
     else
     for (int it = 0; it < kSolverIters; it++) {
         gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
