@@ -453,8 +453,8 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         for (i = 0; i < n; i++) {
             double J[TN] = {0}, pen_lo = e->q[i] - m->lower[i], pen_hi = m->upper[i] - e->q[i];
             if (m->lower[i] > m->upper[i]) continue;                /* no limit on this joint */
-            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
-            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; g_probe_rows[2]++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; g_probe_rows[2]++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
         }
         for (b = 0; b < nb; b++) {
           double pen_lo = *bq[b] - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - *bq[b];
@@ -755,7 +755,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             reward = env_step(&env, &cfg, r, a, ca, &done);
             if (q_trace) memcpy(q_trace + row * N, env.q, sizeof(double) * N);
             if (g_aux_q) { memset(g_aux_q + row * TN, 0, sizeof(double) * TN); memcpy(g_aux_q + row * TN, env.q, sizeof(double) * ND); }
-            if (g_aux_rows) { g_aux_rows[2 * row] = g_probe_rows[0]; g_aux_rows[2 * row + 1] = g_probe_rows[1]; }
+            if (g_aux_rows) { g_aux_rows[2 * row] = g_probe_rows[0]; g_aux_rows[2 * row + 1] = g_probe_rows[1] + 1000 * g_probe_rows[2]; }
             if (grip_trace) memcpy(grip_trace + row * 3, env.gripper, sizeof(double) * 3);
             ep_ret += reward; ep_len += 1;
             if (done) {

@@ -445,12 +445,21 @@ SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA,
 // no ds_bpermute inside the 150 sweeps (the general loop below pays ~100 cycles of LDS latency per row: measured 300+ us per
 // step with four contacts).  Slots: contact normals g = 0..kNGen-1 on lanes g, their friction rows on lanes kNGen + g; slots a
 // wavefront does not use (g >= ngen_w, wave-uniform) are skipped, slots an ENV does not use have zero coefficients.
-template <int J> SRL_G void cn_rowA(const TRows &r, double nBA_J, double eJ, double &accA, double &accB, double &uA) {
+template <int J, bool LAST> SRL_G void cn_rowA(const TRows &r, double nBA_J, double eJ, double &accA, double &accB, double &uA) {
+#if SRL_G_DEVICE
+    double t;
+    // t = clamp01(cs + accA); the own accumulator restarts; both banks take n * bcast_J(t)  (one statement: nothing is scheduled into it)
+    asm volatile("v_add_f64 %2, %3, %0 clamp\n\tv_fma_f64 %0, -%6, %0, %0\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                 : "+v"(accA), "+v"(accB), "=&v"(t) : "v"(r.cs), "v"(r.n[J]), "v"(nBA_J), "v"(eJ), "n"(J));
+#else
     const double t = clamp01(r.cs + accA);
     accA = fma(-eJ, accA, accA);                    // the own accumulator restarts
-    uA = fma(eJ, t - uA, uA);                       // lane J keeps its value
-    fmac_bcast<J>(accA, t, r.n[J]);
-    fmac_bcast<J>(accB, t, nBA_J);
+    accA = fma(grp::host_exchange(t, J), r.n[J], accA);
+    accB = fma(grp::host_exchange(t, J), nBA_J, accB);
+#endif
+    if (LAST) uA = fma(eJ, t - uA, uA);             // lane J keeps its value (last sweep only)
 }
 // contact-normal slot G on lane G: lambda = clamp(cs + accB, 0, hi)
 template <int G> SRL_G void cn_rowN(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB) {
@@ -496,15 +505,17 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     if (!(bb.on && !bb.fric)) bb.hi = 0.0;
     if (!bb.on) bb.cs = 0.0;
     double lam = 0.0, accB = 0.0, uA = 0.0;
-    for (int it = 0; it < kSolverIters; it++) {
-        cn_rowA<0>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2>(r, nBA[2], eA[2], accA, accB, uA);
-        cn_rowA<3>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5>(r, nBA[5], eA[5], accA, accB, uA);
-        cn_rowA<6>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8>(r, nBA[8], eA[8], accA, accB, uA);
-        cn_rowA<9>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11>(r, nBA[11], eA[11], accA, accB, uA);
-        cn_rowA<kBM>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowA<kBLo>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);
-        cn_normals<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
-        cn_frictions<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
-    }
+#define SRL_CN_SWEEP(LAST)                                                                                                                     \
+    cn_rowA<0, LAST>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1, LAST>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2, LAST>(r, nBA[2], eA[2], accA, accB, uA);   \
+    cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
+    cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
+    cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
+    cn_rowA<kBM, LAST>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowA<kBLo, LAST>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi, LAST>(r, nBA[kBHi], eA[kBHi], accA, accB, uA); \
+    cn_normals<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);                                                                                  \
+    cn_frictions<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
+    for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
+    { SRL_CN_SWEEP(true) }
+#undef SRL_CN_SWEEP
     b.lam = lam;
     return uA;
 }
@@ -627,7 +638,7 @@ SRL_G GenOut general_path(const GenIn &in) {
             if (used) {
                 const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
                 const double act = ds[4], jbs = ds[0];
-#pragma nounroll
+#pragma unroll
                 for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], act != 0.0 ? Js[j] : 0.0, wjk);   // (a slot this env does not use holds stale LDS: select, never multiply by 0)
                 if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
                 else wjk = (is_button && act != 0.0) ? r.jb * wb * jbs : 0.0;
@@ -676,7 +687,7 @@ SRL_G GenOut general_path(const GenIn &in) {
             if (used && s != L.l) {
                 const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
                 a = ds[4] != 0.0 ? own_jb * wb * ds[0] : 0.0;
-#pragma nounroll
+#pragma unroll
                 for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ds[4] != 0.0 ? ws[j] : 0.0, a);
             }
             sc[SC_NBB + s * GL + L.l] = -a * b.inv_diag;
