@@ -311,9 +311,45 @@ template <int K> SRL_G void msum_step(double &acc, double x, const double m[NJ])
     if constexpr (K + 1 < NJ) msum_step<K + 1>(acc, x, m);
 }
 SRL_G double msum(double x, const double m[NJ], double base = 0.0) { double acc = base; msum_step<0>(acc, x, m); return acc; }
+// three masked sums at once: a serial chain of 12 dependent v_fmac_f64_dpp costs ~9 cycles per term (+ the DPP hazard nop); with
+// three independent chains interleaved in one statement per source lane every instruction issues back to back
+template <int K> SRL_G void msum3_step(double &a0, double &a1, double &a2, double x0, double x1, double x2, const double m[NJ]) {
+#if SRL_G_DEVICE
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(m[K]), "n"(K));
+#else
+    a0 = fma(grp::host_exchange(x0, K), m[K], a0); a1 = fma(grp::host_exchange(x1, K), m[K], a1); a2 = fma(grp::host_exchange(x2, K), m[K], a2);
+#endif
+    if constexpr (K + 1 < NJ) msum3_step<K + 1>(a0, a1, a2, x0, x1, x2, m);
+}
+SRL_G void msum3(const double x[3], const double m[NJ], double out[3], double base2 = 0.0) {
+    double a0 = 0.0, a1 = 0.0, a2 = base2;
+    msum3_step<0>(a0, a1, a2, x[0], x[1], x[2], m);
+    out[0] = a0; out[1] = a1; out[2] = a2;
+}
 template <int K, int N> SRL_G void ball_step(double x, double *out) {
     out[K] = bcast<K>(x);
     if constexpr (K + 1 < N) ball_step<K + 1, N>(x, out);
+}
+// out[K] = sum_c a[c] * bcast_K(b[c]) for K = 0..11, accumulated column by column: twelve independent chains per statement
+SRL_G void dot6_all12(const double a[6], const double b[6], double out[NJ]) {
+#pragma unroll
+    for (int k = 0; k < NJ; k++) out[k] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#if SRL_G_DEVICE
+#define SRL_F(K) "v_fmac_f64_dpp %" #K ", %12, %13 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+        asm("s_nop 1\n\t" SRL_F(0) SRL_F(1) SRL_F(2) SRL_F(3) SRL_F(4) SRL_F(5) SRL_F(6) SRL_F(7) SRL_F(8) SRL_F(9) SRL_F(10) SRL_F(11)
+            : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4]), "+v"(out[5]), "+v"(out[6]), "+v"(out[7]), "+v"(out[8]),
+              "+v"(out[9]), "+v"(out[10]), "+v"(out[11])
+            : "v"(b[c]), "v"(a[c]));
+#undef SRL_F
+#else
+        for (int k = 0; k < NJ; k++) out[k] = fma(grp::host_exchange(b[c], k), a[c], out[k]);
+#endif
+    }
 }
 template <int K, int N> SRL_G void dot6_step(const double a[6], const double b[6], double *out) {
     double acc = 0.0;
@@ -322,10 +358,15 @@ template <int K, int N> SRL_G void dot6_step(const double a[6], const double b[6
     out[K] = acc;
     if constexpr (K + 1 < N) dot6_step<K + 1, N>(a, b, out);
 }
-template <int K> SRL_G void transpose_step(const TL &L, const double low[NJ], double M[NJ]) {
-#pragma unroll
-    for (int j = 0; j < K; j++) fmac_bcast<K>(M[K], low[j], L.e(j));
-    if constexpr (K + 1 < NJ) transpose_step<K + 1>(L, low, M);
+// M[K] on lane j < K takes lane K's low[j] (the mirrored half of the mass matrix).  Ordered by j, then K: the targets M[K] of
+// consecutive instructions are independent (ordered by K, every M[K] was a serial chain of K dependent DPP FMAs).
+template <int J, int K> SRL_G void transpose_inner(const TL &L, const double low[NJ], double M[NJ]) {
+    fmac_bcast<K>(M[K], low[J], L.e(J));
+    if constexpr (K + 1 < NJ) transpose_inner<J, K + 1>(L, low, M);
+}
+template <int J> SRL_G void transpose_step(const TL &L, const double low[NJ], double M[NJ]) {
+    transpose_inner<J, J + 1>(L, low, M);
+    if constexpr (J + 2 < NJ) transpose_step<J + 1>(L, low, M);
 }
 template <int K, int N> SRL_G void rdot_step(double &acc, const double *row, double x) {
     fmac_bcast<K>(acc, x, row[K]);
@@ -337,8 +378,21 @@ template <int K, int N, bool INV> SRL_G void gj_step(const TL &L, double *A, dou
     const double g = -((A[K] - L.e(K)) * r);
     if constexpr (INV) {
         A[K] = L.e(K);
+#if SRL_G_DEVICE
+        if constexpr (N == NJ) {
+            // the twelve column updates of a pivot are independent: one statement, one hazard nop
+#define SRL_F(C) "v_fmac_f64_dpp %" #C ", %" #C ", %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+            asm("s_nop 1\n\t" SRL_F(0) SRL_F(1) SRL_F(2) SRL_F(3) SRL_F(4) SRL_F(5) SRL_F(6) SRL_F(7) SRL_F(8) SRL_F(9) SRL_F(10) SRL_F(11)
+                : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]), "+v"(A[9]),
+                  "+v"(A[10]), "+v"(A[11])
+                : "v"(g), "n"(K));
+#undef SRL_F
+        } else
+#endif
+        {
 #pragma unroll
-        for (int c = 0; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
+            for (int c = 0; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
+        }
     } else {
 #pragma unroll
         for (int c = K + 1; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
@@ -860,14 +914,19 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         {
             double le[NJ];                        // ancestors-or-self of the own link
             make_mask(L.anc(), le);
+            {
+                double xw[3], xv[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) { w[k] = msum(S[k] * qd, le); vo[k] = msum(S[3 + k] * qd, le); }
+                for (int k = 0; k < 3; k++) { xw[k] = S[k] * qd; xv[k] = S[3 + k] * qd; }
+                msum3(xw, le, w); msum3(xv, le, vo);
+            }
             double t0[3], t1[3], t2[3];
             cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
+            {
+                double xw[3], xv[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                aw[k] = msum(t0[k] * qd, le);
-                av[k] = msum((t1[k] + t2[k]) * qd, le, k == 2 ? -kGravityZ : 0.0);
+                for (int k = 0; k < 3; k++) { xw[k] = t0[k] * qd; xv[k] = (t1[k] + t2[k]) * qd; }
+                msum3(xw, le, aw); msum3(xv, le, av, -kGravityZ);
             }
         }
         // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
@@ -912,10 +971,8 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             for (int k = 0; k < 3; k++) ff[k] += t0[k];
             double ge[NJ];                        // descendants-or-self
             make_mask(L.desc(), ge);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { Fn[k] = msum(fn[k], ge); Ff[k] = msum(ff[k], ge); hc[k] = msum(h[k], ge); }
-#pragma unroll
-            for (int k = 0; k < 6; k++) Ioc[k] = msum(Io[k], ge);
+            msum3(fn, ge, Fn); msum3(ff, ge, Ff); msum3(h, ge, hc);
+            msum3(Io, ge, Ioc); msum3(Io + 3, ge, Ioc + 3);
         }
         tau = -L.damping() * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
         // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
@@ -923,14 +980,14 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
 #pragma unroll
         for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp() * S[3 + k] - t1[k]; }
-        dot6_step<0, NJ>(Fc, S, low);
+        dot6_all12(Fc, S, low);
         {
             double le[NJ];
             make_mask(L.anc(), le);
 #pragma unroll
             for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
         }
-        transpose_step<1>(L, low, W);
+        transpose_step<0>(L, low, W);
         double unused = 0.0;
         gj_step<0, NJ, true>(L, W, unused);
 #pragma unroll
