@@ -62,7 +62,7 @@ struct TLane {
     double jm, am;            // 1.0 on joint / arm lanes
     double e[NJ];             // e[j] = (l == j)
     uint32_t anc, desc;       // bit k: DoF k is an ancestor-or-self / descendant-or-self of the own link
-    int src[4];               // lane parent^(1, 2, 4, 8)(l), -1 beyond the root
+    int src[4];               // lane parent^(1, 2, 4, 8)(l); beyond the root: lane 15 (identity)
     double mass, mcomp;       // link mass, mass of the own subtree
     double com[3], in[6];     // centre of mass, inertia about it (xx xy xz yy yz zz) in link axes
     double F[9], t[3], ax[3]; // fixed rotation (columns) and origin of the joint frame in the parent link, joint axis in the joint frame
@@ -96,7 +96,7 @@ SRL_G void lane_init(TLane &L, const TreeModel *m) {
     {
         int a = L.jnt ? (int)J.parent : -1, hop = 1;
         for (int lvl = 0; lvl < 4; lvl++) {
-            L.src[lvl] = a;
+            L.src[lvl] = a >= 0 ? a : GL - 1;      // beyond the root: lane 15, which never owns a joint and carries the identity
             // the next source is 2 * hop links up from l
             for (int s = 0; s < hop && a >= 0; s++) a = (int)m->j[a].parent;
             hop *= 2;
@@ -266,14 +266,12 @@ SRL_G void tfk(const TL &L, GState &g) {
     p[0] = L.t(0); p[1] = L.t(1); p[2] = L.t(2);
 #pragma unroll
     for (int lvl = 0; lvl < 4; lvl++) {
-        const int src = L.src(lvl);
-        const bool have = src >= 0;
-        const int from = have ? src : L.l;
+        const int from = L.src(lvl);                   // parent^(2^lvl), or the identity lane 15 beyond the root
         double Ra[9], pa[3], Ro[9], po[3];
 #pragma unroll
-        for (int k = 0; k < 9; k++) { const double x = shfl(R[k], from); Ra[k] = have ? x : ((k % 4 == 0) ? 1.0 : 0.0); }
+        for (int k = 0; k < 9; k++) Ra[k] = shfl(R[k], from);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const double x = shfl(p[k], from); pa[k] = have ? x : 0.0; }
+        for (int k = 0; k < 3; k++) pa[k] = shfl(p[k], from);
         compose(Ra, pa, R, p, Ro, po);
 #pragma unroll
         for (int k = 0; k < 9; k++) R[k] = Ro[k];
