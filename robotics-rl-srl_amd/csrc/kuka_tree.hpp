@@ -124,9 +124,9 @@ SRL_G void lane_init(TLane &L, const TreeModel *m) {
 }
 
 // The per-lane constants live in LDS for the whole launch ([field][16 lanes], one table per wavefront: its envs share the model)
-// and are re-read by every physics step: kept in registers across the rollout loop (~75 doubles per lane) they pushed the loop
-// into scratch, and any scratch reload inside the step loop waits for the previous step's output stores (gfx9 counts loads and
-// stores in one in-order counter).  LDS reads count on lgkmcnt and cost ~80 ds_read_b64 per step.
+// and are read where a physics step uses them (TL below): kept in registers across the rollout loop (~75 doubles per lane) they
+// pushed the loop into scratch, and any scratch reload inside the step loop waits for the previous step's output stores (gfx9
+// counts loads and stores in one in-order counter).  LDS reads count on lgkmcnt: ~140 ds_read_b64 per step.
 enum { LT_MASS = 0, LT_MCOMP, LT_COM, LT_IN = LT_COM + 3, LT_F = LT_IN + 6, LT_T = LT_F + 9, LT_AX = LT_T + 3, LT_JLO = LT_AX + 3, LT_JHI, LT_DAMP, LT_KP,
        LT_BOUND, LT_MAXVEL, LT_Q0, LT_TSEL, LT_SPH, LT_SMU = LT_SPH + 4, LT_ANC, LT_DESC, LT_SRC, LT_SLINK = LT_SRC + 4, LT_SANC, LT_COUNT };
 // behind the per-lane fields: the model's scalars, stored once
@@ -156,37 +156,6 @@ SRL_G void lane_store(const TLane &L, double *tab) {
         sc[LS_MAXGEN] = L.max_gen; sc[LS_FRICTION] = L.friction ? 1.0 : 0.0;
     }
 }
-// rebuild the lane's constants from the table; `tab` is laundered so that the reads are not hoisted out of the rollout loop
-SRL_G void lane_load(TLane &L, const double *tab) {
-    int l = lane_id();
-#if SRL_G_DEVICE
-    asm volatile("" : "+v"(l));
-#endif
-    const double *t = tab + l;
-    L.l = l; L.jnt = l < NJ; L.arm = l < NA; L.jm = L.jnt ? 1.0 : 0.0; L.am = L.arm ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) L.e[j] = l == j ? 1.0 : 0.0;
-#define SRL_GET(F) t[(F) * GL]
-    L.mass = SRL_GET(LT_MASS); L.mcomp = SRL_GET(LT_MCOMP);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { L.com[k] = SRL_GET(LT_COM + k); L.t[k] = SRL_GET(LT_T + k); L.ax[k] = SRL_GET(LT_AX + k); }
-    const double *sc = tab + LT_COUNT * GL;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { L.eept[k] = sc[LS_EEPT + k]; L.grpt[k] = sc[LS_GRPT + k]; }
-#pragma unroll
-    for (int k = 0; k < 6; k++) L.in[k] = SRL_GET(LT_IN + k);
-#pragma unroll
-    for (int k = 0; k < 9; k++) L.F[k] = SRL_GET(LT_F + k);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { L.sph[k] = SRL_GET(LT_SPH + k); L.src[k] = (int)SRL_GET(LT_SRC + k); }
-    L.jlo = SRL_GET(LT_JLO); L.jhi = SRL_GET(LT_JHI); L.damping = SRL_GET(LT_DAMP); L.kp = SRL_GET(LT_KP); L.bound = SRL_GET(LT_BOUND); L.maxvel = SRL_GET(LT_MAXVEL);
-    L.q0 = SRL_GET(LT_Q0); L.tsel = SRL_GET(LT_TSEL); L.smu = SRL_GET(LT_SMU); L.table_z = sc[LS_TABLEZ]; L.base_z = sc[LS_BASEZ];
-    L.anc = (uint32_t)SRL_GET(LT_ANC); L.desc = (uint32_t)SRL_GET(LT_DESC); L.slink = (int)SRL_GET(LT_SLINK); L.sanc = (uint32_t)SRL_GET(LT_SANC);
-    L.ee_link = (int)sc[LS_EELINK]; L.grip_link = (int)sc[LS_GRIPLINK]; L.max_gen = (int)sc[LS_MAXGEN]; L.friction = sc[LS_FRICTION] != 0.0;
-#undef SRL_GET
-}
-
-// ancestor / descendant masks as 0 / 1 weights, rebuilt per step (kept out of the rollout loop's live registers)
 // Lazy view of the lane table: every field is read from LDS where it is used (loading all ~45 of them at the top of a step kept
 // ~100 registers live through the dynamics).  The pointer is laundered per view, so nothing is hoisted out of the rollout loop.
 struct TL {
