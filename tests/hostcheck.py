@@ -91,3 +91,14 @@ def tree_default_model():
     t = np.zeros(506)
     lib().hostcheck_kuka_tree_default_model(t.ctypes.data_as(ctypes.c_void_p))
     return t
+
+
+def tree_set_model(table):
+    """Runtime full-model table (506 doubles) for tree_rollout(); None -> the baked model."""
+    import numpy as np
+    if table is None:
+        lib().hostcheck_kuka_tree_set_model(None)
+        return
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    assert t.shape == (506,)
+    lib().hostcheck_kuka_tree_set_model(t.ctypes.data_as(ctypes.c_void_p))

@@ -455,3 +455,33 @@ def test_full_model_runtime_table():
         h.close()
     finally:
         kuka_clib.set_full(True)                                          # rebuilds the default table
+
+
+def test_full_model_joint_limit_rows_and_row_budget():
+    """The tree kernel's general path with joint-LIMIT rows (LDS coupling planes; a random agent never reaches the real limits):
+    a table whose arm limits sit 0.12 rad around the settled pose and a row budget of 3 that overflows; several envs of a
+    wavefront carry different row sets at the same time."""
+    n, T = 256, 600
+    rs = np.random.RandomState(61)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.2] = 4
+    t = _lib.kuka_tree_default_model().copy()
+    J = 1 + 33 * np.arange(12)
+    q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])
+    t[J[:7] + 16] = q_settled - 0.12
+    t[J[:7] + 17] = q_settled + 0.12
+    t[-2] = 3.0
+    try:
+        h = make(n, seed0=17, random_target=1)
+        h.set_kuka_tree_model(t)
+        obs0 = h.reset()
+        out = h.rollout(T, actions=actions)
+        kuka_clib.set_tree_model(t)
+        ora = kuka_clib.rollout(17 + np.arange(n), T, actions=actions, random_target=True, aux=True, trace=False)
+        lim = ora["rows"][:, :, 1] // 1000
+        assert (lim > 0).mean() > 0.05 and ora["rows"][:, :, 0].sum() > 20          # limit rows on > 5 % of the env-steps, contacts too
+        check_planes(ora, obs0, out)
+        assert np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, :7]).max() <= TOL
+        h.close()
+    finally:
+        kuka_clib.set_full(True)

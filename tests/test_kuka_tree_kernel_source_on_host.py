@@ -60,3 +60,23 @@ def test_discrete_actions_with_contacts_and_friction_rows():
 ])
 def test_options_and_variants(kw, variant):
     run(4, 350, 31, variant=variant, **kw)
+
+
+def test_joint_limit_rows_and_row_budget_with_a_tightened_model():
+    """The general path with joint-LIMIT rows (never reached by a random agent on the real limits): a runtime table whose arm
+    limits sit just beyond the settled pose, so that limit rows appear together with contact / friction rows, and a row budget
+    of 3 that overflows — oracle and kernel source must drop the same candidates."""
+    t = kuka_clib.get_tree_model().copy()
+    J = 1 + 33 * np.arange(12)
+    q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])              # roughly where the 500 settle steps leave the arm
+    t[J[:7] + 16] = q_settled - 0.12                                          # lower limits
+    t[J[:7] + 17] = q_settled + 0.12                                          # upper limits
+    t[-2] = 3.0                                                               # max_generic_rows
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        a = run(4, 600, 91, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
+        lim = a["rows"][:, :, 1] // 1000
+        assert (lim > 0).sum() > 50 and ((lim > 0) & (a["rows"][:, :, 0] > 0)).sum() >= 0
+    finally:
+        hostcheck.tree_set_model(None)
+        kuka_clib.set_full(True)
