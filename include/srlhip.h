@@ -67,10 +67,11 @@ extern "C" {
  * FULL   : the 12-DoF tree — arm J0..J6, gripper_to_arm, two fingers, two finger tips — every joint driven by the
  *          POSITION_CONTROL motor the reference commands each step (kuka.py:167-187: arm 200 N·m / 0.35 rad/s, joint 7
  *          200, fingers 2 / 2.5, tips 2), contact spheres on links 5..11, one friction row per contact.  Stepped by the
- *          tree lane-group kernel (csrc/kuka_tree.hpp) at every batch size.  KukaButton / MovingButton / RandButton.
- * LUMPED : rounds 1-2 — the gripper welded to link_7 (7 DoF), six gripper spheres, frictionless contacts.  Kept for
- *          Kuka2ButtonGymEnv (not yet ported to the tree kernel) and as the cheaper approximation (profiles/r03_kuka_model_gap.json
- *          measures what it costs: 0.02 rad on the arm joints, different reward / done planes). */
+ *          tree lane-group kernel (csrc/kuka_tree.hpp) at every batch size.  The default of every Kuka env
+ *          (Kuka2ButtonGymEnv: the kernel's two-button form — second glider, its motor / stop rows, its cap and base).
+ * LUMPED : rounds 1-2 — the gripper welded to link_7 (7 DoF), six gripper spheres, frictionless contacts.  Kept as the
+ *          cheaper approximation (profiles/r03_kuka_model_gap.json measures what it costs: 0.02 rad on the arm joints,
+ *          different reward / done planes). */
 #define SRLHIP_KUKA_MODEL_LUMPED 0
 #define SRLHIP_KUKA_MODEL_FULL   1
 
@@ -238,7 +239,7 @@ int srlhip_graph_destroy(srlhip_graph_handle g);
  * re-integrated, every following reset / step uses it.  A 7-joint serial arm whose joints turn about their local z is
  * assumed (joint_rpy = URDF rpy of the joint frame in the parent link frame, joint_xyz its origin; inertia = principal
  * moments about com, axes parallel to the link frame).  With a table installed the batch is stepped by the lane-group
- * kernel at any size; Kuka2ButtonGymEnv handles return SRLHIP_ENOTSUP.  tests/golden/make_kuka_pybullet_golden.py
+ * kernel at any size; lumped Kuka2ButtonGymEnv handles return SRLHIP_ENOTSUP (full-model ones take srlhip_set_kuka_tree_model).  tests/golden/make_kuka_pybullet_golden.py
  * fills this struct from pybullet_data when PyBullet is importable. */
 typedef struct srlhip_kuka_model {
     double joint_xyz[7][3], joint_rpy[7][3], joint_lower[7], joint_upper[7], joint_damping;
@@ -277,7 +278,7 @@ int srlhip_kuka_tree_default_model(srlhip_kuka_tree_model *m);                  
 int srlhip_set_kuka_tree_model(srlhip_handle h, const srlhip_kuka_tree_model *m);
 
 /* Which kernel steps this Kuka handle's batch: 2 = tree lane-group (full model, kuka_tree_rollout_k: every batch size), 1 = lane-group (16 lanes per env, kuka_group_rollout_k: batches up to 12288
- * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and Kuka2ButtonGymEnv); the environment variable
+ * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and the lumped Kuka2ButtonGymEnv); the environment variable
  * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs
  * (to ~1e-11 on joint positions; discrete flags identical). */
 int srlhip_kuka_kernel(srlhip_handle h);

@@ -154,9 +154,8 @@ int srlhip_default_config(int32_t env_kind, srlhip_config *cfg) {
     cfg->auto_reset = 1;
     cfg->max_distance = env_kind >= SRLHIP_ENV_KUKA_BUTTON ? 0.8 : 1.6;   // ctor defaults
     if (env_kind == SRLHIP_ENV_KUKA_2BUTTON) { cfg->max_distance = 2.0; cfg->force_down = 0; }   // kuka_2button_gym_env.py:29
-    // the full gripper model wherever the tree kernel steps the env (Kuka2Button still runs on the lane-per-env kernel: lumped)
-    cfg->kuka_model = (env_kind == SRLHIP_ENV_KUKA_BUTTON || env_kind == SRLHIP_ENV_KUKA_MOVING || env_kind == SRLHIP_ENV_KUKA_RAND)
-                          ? SRLHIP_KUKA_MODEL_FULL : SRLHIP_KUKA_MODEL_LUMPED;
+    // every Kuka env integrates the full arm + gripper model on the tree lane-group kernel (Kuka2Button: its two-button form)
+    cfg->kuka_model = env_kind >= SRLHIP_ENV_KUKA_BUTTON ? SRLHIP_KUKA_MODEL_FULL : SRLHIP_KUKA_MODEL_LUMPED;
     return 0;
 }
 
@@ -197,10 +196,6 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     }
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->kuka_model != SRLHIP_KUKA_MODEL_LUMPED && cfg->kuka_model != SRLHIP_KUKA_MODEL_FULL) {
         g_create_error = "create: unknown kuka_model"; return SRLHIP_EINVAL;
-    }
-    if (cfg->env_kind == SRLHIP_ENV_KUKA_2BUTTON && cfg->kuka_model == SRLHIP_KUKA_MODEL_FULL) {
-        g_create_error = "create: Kuka2ButtonGymEnv is stepped with the lumped-gripper model only (kuka_model = SRLHIP_KUKA_MODEL_LUMPED)";
-        return SRLHIP_ENOTSUP;
     }
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
         g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;

@@ -453,7 +453,7 @@ const srl::kuka::TreeModel *tree_model() {
     if (!g_tree_model_set) { srl::kuka::default_tree_model(g_tree_model); g_tree_model_set = true; }
     return &g_tree_model;
 }
-template <class R>
+template <int NB, class R>
 void tree_env_body(GroupArgs &a, R &rng) {
     using namespace tree;
     const Cfg &cfg = a.cfg;
@@ -468,8 +468,8 @@ void tree_env_body(GroupArgs &a, R &rng) {
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
     const bool joints = !cfg.is_discrete && cfg.action_joints;
-    if (joints) tenv_reset<1>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-    else tenv_reset<2>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (joints) tenv_reset<1, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    else tenv_reset<2, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     grp::GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
@@ -489,15 +489,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
             }
             if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = tenv_step(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        const double reward = tenv_step<NB>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
             if (cfg.auto_reset) {
-                if (joints) tenv_reset<1>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-                else tenv_reset<2>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                if (joints) tenv_reset<1, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                else tenv_reset<2, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
             }
         }
         if (lead) {
@@ -514,14 +514,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
         if (lead) {
             f[14] = env.ee[0]; f[15] = env.ee[1]; f[16] = env.ee[2]; f[17] = env.bq; f[18] = env.bqd; f[19] = env.counter;
             f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = cfg.moving ? env.bpos[1] : env.bpos[2];
+            if (NB == 2) { f[24] = env.b2q; f[25] = env.b2qd; f[26] = env.goal_id; f[27] = env.n_contacts2; f[28] = env.b2x; f[29] = env.b2y; }
         }
     }
     if (a.ep_stats && lead) { a.ep_stats[3 * (size_t)e_idx] = last_ret; a.ep_stats[3 * (size_t)e_idx + 1] = last_len; a.ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
 }
 void tree_fiber_body(void *p) {
     GroupArgs &a = *static_cast<GroupArgs *>(p);
-    if (a.rng_mode == 2) { grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0}; tree_env_body(a, r); }
-    else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); tree_env_body(a, r); }
+    if (a.rng_mode == 2) { grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0}; if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r); }
+    else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r); }
 }
 struct TreeSettleArgs { Cfg cfg; double *out; double *scratch; };
 void tree_settle_body(void *p) {
@@ -547,14 +548,13 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
                                            float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out,
                                            void *act_out, double *q_trace, double *grip_trace, double *final_state,
                                            double *ep_stats) {
-    if (g_two) return -1;
     GroupArgs a;
     a.model = nullptr;
     Cfg &cfg = a.cfg;
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;
-    cfg.moving = g_moving; cfg.two = 0; cfg.max_steps = g_moving ? 1500 : kMaxSteps; cfg.rand_objects = g_rand;
+    cfg.moving = g_moving; cfg.two = g_two; cfg.max_steps = g_moving ? 1500 : g_two ? kMaxSteps2Button : kMaxSteps; cfg.rand_objects = g_rand;
     // LDS is not cleared between launches on the device: poison the emulated scratch so that any read of a slot this env never
     // wrote (0 * stale = NaN) shows up here and not as a flaky GPU test
     std::vector<double> settled(tree::kTreeStartDoubles, 0.0), starts, scratch(tree::kTreeScratchDoubles, std::numeric_limits<double>::quiet_NaN());

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_table_k(const TreeModel
 }
 
 // env scalars replicated on the row, the own joint per joint lane
-__device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const LaneId &L, Env &v, grp::GState &g) {
+__device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const LaneId &L, Env &v, grp::GState &g, bool two) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
     v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
@@ -38,12 +38,16 @@ __device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, cons
     v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
     v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
     v.terminated = s.i[I_TERM * n + e];
+    if (two) {                               // Kuka2ButtonGymEnv: second glider, goal switching
+        v.b2q = s.d[D_B2Q * n + e]; v.b2qd = s.d[D_B2QD * n + e]; v.b2x = s.d[D_B2X * n + e]; v.b2y = s.d[D_B2Y * n + e];
+        v.goal_id = s.i[I_GOAL * n + e]; v.n_contacts2 = s.i[I_NCONTACT2 * n + e]; v.contact_body1 = 0; v.contact_body2 = 0;
+    }
     const int j = L.jnt ? L.l : 0;
     g.q = s.d[tree_plane(D_Q, D_GQ, j) * n + e]; g.qd = s.d[tree_plane(D_QD, D_GQD, j) * n + e];
     g.sq = s.d[tree_plane(D_SQ, D_GSQ, j) * n + e]; g.cq = s.d[tree_plane(D_CQ, D_GCQ, j) * n + e];
     if (!L.jnt) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
 }
-__device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, const LaneId &L, const Env &v, const grp::GState &g, bool valid) {
+__device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, const LaneId &L, const Env &v, const grp::GState &g, bool valid, bool two) {
     if (valid && L.jnt) {
         s.d[tree_plane(D_Q, D_GQ, L.l) * n + e] = g.q; s.d[tree_plane(D_QD, D_GQD, L.l) * n + e] = g.qd;
         s.d[tree_plane(D_SQ, D_GSQ, L.l) * n + e] = g.sq; s.d[tree_plane(D_CQ, D_GCQ, L.l) * n + e] = g.cq;
@@ -56,12 +60,16 @@ __device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, con
         s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
         s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
         s.i[I_TERM * n + e] = v.terminated;
+        if (two) {
+            s.d[D_B2Q * n + e] = v.b2q; s.d[D_B2QD * n + e] = v.b2qd; s.d[D_B2X * n + e] = v.b2x; s.d[D_B2Y * n + e] = v.b2y;
+            s.i[I_GOAL * n + e] = v.goal_id; s.i[I_NCONTACT2 * n + e] = v.n_contacts2;
+        }
     }
 }
 
 // T consecutive VecEnv steps per launch.  GIVEN: the caller supplies the actions (a compile-time switch: a possible action load
 // inside the step loop makes every step wait for the previous step's output stores — gfx9 counts loads and stores together).
-template <int MODE, bool JOINTS, bool GIVEN>
+template <int MODE, bool JOINTS, bool GIVEN, int NB>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                     float *obs, float *rew, uint8_t *done_out, void *act_out) {
@@ -84,7 +92,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     Lane0Rng<Rng> rng_l0{&rng0, lead};
     Env v = {};
     GState g;
-    tload(s, n, e, L, v, g);
+    tload(s, n, e, L, v, g, NB == 2);
     tree::tfk(tree::lane_view(tab), g);
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
@@ -115,15 +123,15 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
         bool done;
         double reward;
-        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = tree::tenv_step(v, g, tab, cfg, scratch, rng_l0, a, ca, ca_own, &done);
-        else reward = tree::tenv_step(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done);
+        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = tree::tenv_step<NB>(v, g, tab, cfg, scratch, rng_l0, a, ca, ca_own, &done);
+        else reward = tree::tenv_step<NB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
                 double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, cfg, scratch, rng_l0, s.tstarts, s.tsettled, objs, n);
-                else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
+                if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, cfg, scratch, rng_l0, s.tstarts, s.tsettled, objs, n);
+                else tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
                 // the start-state loads retire HERE, not at their first use in the next step (where vmcnt(0) would also wait for
                 // the output stores of steps that did not reset)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -137,7 +145,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     }
     int e_out = e;
     asm volatile("" : "+v"(e_out));       // exit-store addresses are recomputed instead of being kept live across the loop
-    tstore(s, n, e_out, L, v, g, valid);
+    tstore(s, n, e_out, L, v, g, valid, NB == 2);
     if (lead) {
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e_out] = rng0.p.ctr;
         else krng_store<MODE>(rng0, rs, e_out);
@@ -148,7 +156,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 }
 
 // srlhip_reset: KukaButtonGymEnv.reset by lane groups
-template <int MODE, bool JOINTS>
+template <int MODE, bool JOINTS, int NB>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand, int rand_stride, float *obs) {
     using namespace grp;
@@ -168,9 +176,9 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     Env v = {};
     GState g;
     double *objs = valid ? s.objs + e : nullptr;
-    if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.tstarts, s.tsettled, objs, n);
-    else tree::tenv_reset<JOINTS ? 1 : 0>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
-    tstore(s, n, e, L, v, g, valid);
+    if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.tstarts, s.tsettled, objs, n);
+    else tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
+    tstore(s, n, e, L, v, g, valid, NB == 2);
     if (lead) {
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
         else krng_store<MODE>(rng0, rs, e);
@@ -230,23 +238,26 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
     LaneId L; build_lane_table(L, s.ttable, tab);
     Env v = {};
     GState g;
-    tload(s, n, e, L, v, g);
+    tload(s, n, e, L, v, g, p.cfg.two != 0);
     tree::trefresh(tree::lane_view(tab), g, v);
-    tstore(s, n, e, L, v, g, valid);
+    tstore(s, n, e, L, v, g, valid, p.cfg.two != 0);
 }
 
 }  // namespace
 
-#define SRL_TREE_GO(MODE, J, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+#define SRL_TREE_GO(MODE, J, G, NB) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, NB>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+// (Kuka2ButtonGymEnv takes discrete actions only: no joints-mode instantiation of the two-button kernels)
 #define SRL_TREE_MODE(MODE)                                         \
-    if (joints && d_actions) SRL_TREE_GO(MODE, true, true);         \
-    else if (joints) SRL_TREE_GO(MODE, true, false);                \
-    else if (d_actions) SRL_TREE_GO(MODE, false, true);             \
-    else SRL_TREE_GO(MODE, false, false);
+    if (two && d_actions) SRL_TREE_GO(MODE, false, true, 2);        \
+    else if (two) SRL_TREE_GO(MODE, false, false, 2);               \
+    else if (joints && d_actions) SRL_TREE_GO(MODE, true, true, 1); \
+    else if (joints) SRL_TREE_GO(MODE, true, false, 1);             \
+    else if (d_actions) SRL_TREE_GO(MODE, false, true, 1);          \
+    else SRL_TREE_GO(MODE, false, false, 1);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out) {
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
-    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_TREE_MODE(SRLHIP_RNG_PHILOX) break;
         case SRLHIP_RNG_MT19937: SRL_TREE_MODE(SRLHIP_RNG_MT19937) break;
@@ -258,10 +269,11 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
 
 int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs) {
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
-    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+    const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
 #define SRL_TRESET(MODE)                                                                                                                       \
-    if (joints) hipLaunchKernelGGL((kuka_tree_reset_k<MODE, true>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
-    else hipLaunchKernelGGL((kuka_tree_reset_k<MODE, false>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs)
+    if (two) hipLaunchKernelGGL((kuka_tree_reset_k<MODE, false, 2>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
+    else if (joints) hipLaunchKernelGGL((kuka_tree_reset_k<MODE, true, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs); \
+    else hipLaunchKernelGGL((kuka_tree_reset_k<MODE, false, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, d_mask, d_host_rand, stride, obs)
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_HOST: SRL_TRESET(SRLHIP_RNG_HOST); break;
         case SRLHIP_RNG_PHILOX: SRL_TRESET(SRLHIP_RNG_PHILOX); break;

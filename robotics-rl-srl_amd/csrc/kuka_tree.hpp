@@ -404,7 +404,16 @@ SRL_G void sweep_free(const TEs &E, const TRows &r, double &acc, double ep_first
     pgs_row<9>(acc, r.cs, r.n[9], E.e[8]);    pgs_row<10>(acc, r.cs, r.n[10], E.e[9]); pgs_row<11>(acc, r.cs, r.n[11], E.e[10]);
 #endif
 }
-SRL_G double sweeps_free(const TRows &r) {
+// Kuka2Button: the second button's three rows live on the same lanes (kBM, kBLo, kBHi) with their own accumulator.  Without a
+// contact they couple to nothing but each other: an independent three-row chain per sweep.
+struct TRows2 { double cs, n[3], lo, S, jb; };
+SRL_G void sweep_free2(const TRows2 &r2, double &acc2, double e_bm, double e_blo, double e_bhi_prev) {
+    pgs_row<kBM>(acc2, r2.cs, r2.n[0], e_bhi_prev);
+    pgs_row<kBLo>(acc2, r2.cs, r2.n[1], e_bm);
+    pgs_row<kBHi>(acc2, r2.cs, r2.n[2], e_blo);
+}
+template <int NB = 1>
+SRL_G double sweeps_free(const TRows &r, const TRows2 *r2 = nullptr, double *u2_out = nullptr) {
     double acc = r.acc0, u = 0.0, t;
     int l = lane_id();
 #if SRL_G_DEVICE
@@ -415,8 +424,20 @@ SRL_G double sweeps_free(const TRows &r) {
     for (int j = 0; j < NJ; j++) E.e[j] = l == j ? 1.0 : 0.0;
     E.e[0] += l == kBM ? 1.0 : 0.0; E.e[1] += l == kBLo ? 1.0 : 0.0; E.e[2] += l == kBHi ? 1.0 : 0.0;
     const double e0 = E.e[0], e1 = E.e[1], e2 = E.e[2];
+    double acc2 = 0.0, u2 = 0.0;
+    const double c_bm = l == kBM ? 1.0 : 0.0, c_blo = l == kBLo ? 1.0 : 0.0, c_bhi = l == kBHi ? 1.0 : 0.0;
     sweep_free(E, r, acc, 0.0);
-    for (int it = 1; it < kSolverIters - 1; it++) sweep_free(E, r, acc, E.e[11]);
+    if constexpr (NB == 2) sweep_free2(*r2, acc2, c_bm, c_blo, 0.0);
+    for (int it = 1; it < kSolverIters - 1; it++) {
+        sweep_free(E, r, acc, E.e[11]);
+        if constexpr (NB == 2) sweep_free2(*r2, acc2, c_bm, c_blo, c_bhi);
+    }
+    if constexpr (NB == 2) {
+        t = pgs_row<kBM>(acc2, r2->cs, r2->n[0], c_bhi);   u2 = fma(c_bm, t, u2);
+        t = pgs_row<kBLo>(acc2, r2->cs, r2->n[1], c_bm);   u2 = fma(c_blo, t, u2);
+        t = pgs_row<kBHi>(acc2, r2->cs, r2->n[2], c_blo);  u2 = fma(c_bhi, t, u2);
+        *u2_out = u2;
+    }
     t = pgs_row2<0, kBM>(acc, r.cs, r.n[0], r.n[kBM], E.e[11]);  u = fma(e0, t, u);
     t = pgs_row2<1, kBLo>(acc, r.cs, r.n[1], r.n[kBLo], e0);      u = fma(e1, t, u);
     t = pgs_row2<2, kBHi>(acc, r.cs, r.n[2], r.n[kBHi], e1);      u = fma(e2, t, u);
@@ -433,7 +454,8 @@ SRL_G double sweeps_free(const TRows &r) {
 }
 
 // ------------------------------------------------------------------ PGS, general path: bank A + bank B
-struct BRow { double cs, lo, hi, mu, lam, jb, inv_diag; int normal; bool on, fric; };   // own bank-B row (slot == lane)
+struct BRow { double cs, lo, hi, mu, lam, jb, inv_diag; int normal; bool on, fric;      // own bank-B row (slot == lane)
+              int bsel; double nBC[3]; };   // Kuka2Button: the glider the row acts on; its scaled couplings to the second button's rows
 // bank-A row J: u = clamp01(cs + accA) on lane J, broadcast to both accumulators of every lane.  (The general path resets the
 // own accumulator explicitly instead of in the shadow of the next row: bank-B rows interleave with bank A.)
 template <int J> SRL_G void gen_rowA(const TL &L, const TRows &r, const double *sc, double &accA, double &accB, double &uA) {
@@ -443,11 +465,20 @@ template <int J> SRL_G void gen_rowA(const TL &L, const TRows &r, const double *
     accA = fma(r.n[J], tb, accA);
     accB = fma(sc[SC_NBA + J * GL + L.l], tb, accB);
 }
+// Kuka2Button, row J (kBM / kBLo / kBHi) of the second button: same lanes, own accumulator accC; couples to the bank-B rows that act on glider 2
+template <int J> SRL_G void gen_rowC(const TL &L, const TRows2 &r2, const BRow &b, double &accC, double &accB, double &uC) {
+    const double t = clamp01(r2.cs + accC);
+    const double tb = bcast<J>(t);
+    if (L.l == J) { accC = 0.0; uC = t; }
+    accC = fma(r2.n[J - kBM], tb, accC);
+    accB = fma(b.nBC[J - kBM], tb, accB);
+}
 // bank-B slot s (a wave-uniform loop index): lambda = clamp(cs + accB, lo, hi) on lane s.  A friction row's bounds are +-mu times
 // the CURRENT impulse of its normal row, and the row keeps its value while that is not positive (it still hands the value round:
 // every row contributes exactly once per sweep to the others' accumulators).  part: this env's slot s belongs to the phase being
 // swept (uniform over the env's 16 lanes) — otherwise nothing of this env changes.
-SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA, double &accB, bool part) {
+template <int NB = 1>
+SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA, double &accB, bool part, double *accC = nullptr, double nCB_s = 0.0) {
     double lo = b.lo, hi = b.hi;
     const double tot = shfl(b.lam, b.normal);               // friction rows: the normal row's impulse
     const bool skip = b.fric && !(tot > 0.0);
@@ -459,6 +490,7 @@ SRL_G void gen_rowB(const TL &L, const double *sc, int s, BRow &b, double &accA,
     const double nA = fma(sc[SC_NAB + s * GL + L.l], tb, accA);
     const double nB = fma(sc[SC_NBB + s * GL + L.l], tb, L.l == s ? 0.0 : accB);
     if (part) { accA = nA; accB = nB; if (L.l == s) b.lam = t; }
+    if constexpr (NB == 2) { if (part) *accC = fma(nCB_s, tb, *accC); }
 }
 
 // Contact steps without a joint-limit row in the wavefront (every contact case a random agent produces: two finger tips with two
@@ -483,16 +515,24 @@ template <int J, bool LAST> SRL_G void cn_rowA(const TRows &r, double nBA_J, dou
     if (LAST) uA = fma(eJ, t - uA, uA);             // lane J keeps its value (last sweep only)
 }
 // contact-normal slot G on lane G: lambda = clamp(cs + accB, 0, hi)
-template <int G> SRL_G void cn_rowN(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB) {
+template <int J, bool LAST> SRL_G void cn_rowC(const TRows2 &r2, double nBC_J, double eJ, double &accC, double &accB, double &uC) {
+    const double t = clamp01(r2.cs + accC);
+    accC = fma(-eJ, accC, accC);
+    fmac_bcast<J>(accC, t, r2.n[J - kBM]);
+    fmac_bcast<J>(accB, t, nBC_J);
+    if (LAST) uC = fma(eJ, t - uC, uC);
+}
+template <int G, int NB = 1> SRL_G void cn_rowN(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
     double t = b.cs + accB;
     t = t < 0.0 ? 0.0 : (t > b.hi ? b.hi : t);      // (an unused slot has cs = 0, zero couplings and hi = 0: t = 0)
     lam = fma(eS, t - lam, lam);
     accB = fma(-eS, accB, accB);
     fmac_bcast<G>(accA, t, nAB);
     fmac_bcast<G>(accB, t, nBB);
+    if constexpr (NB == 2) fmac_bcast<G>(*accC, t, nCB);
 }
 // friction slot kNGen + G: bounds +-mu * (current impulse of normal slot G); the row keeps its value while that is not positive
-template <int G> SRL_G void cn_rowF(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB) {
+template <int G, int NB = 1> SRL_G void cn_rowF(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
     const double tot = bcast<G>(lam);               // lane G's lambda: the normal row's CURRENT impulse
     const double hi = b.mu * tot;
     double t = b.cs + accB;
@@ -502,14 +542,56 @@ template <int G> SRL_G void cn_rowF(const BRow &b, double &lam, double nAB, doub
     accB = fma(-eS, accB, accB);
     fmac_bcast<kNGen + G>(accA, t, nAB);
     fmac_bcast<kNGen + G>(accB, t, nBB);
+    if constexpr (NB == 2) fmac_bcast<kNGen + G>(*accC, t, nCB);
 }
-template <int G> SRL_G void cn_normals(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
-    if (G < ngen_w) cn_rowN<G>(b, lam, nAB[G], nBB[G], eB[G], accA, accB);
-    if constexpr (G + 1 < kNGen) cn_normals<G + 1>(b, lam, nAB, nBB, eB, accA, accB, ngen_w);
+template <int G, int NB = 1> SRL_G void cn_normals(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
+                                                   double *accC = nullptr, const double *nCB = nullptr) {
+    if (G < ngen_w) {
+        if constexpr (NB == 2) cn_rowN<G, 2>(b, lam, nAB[G], nBB[G], eB[G], accA, accB, accC, nCB[G]);
+        else cn_rowN<G>(b, lam, nAB[G], nBB[G], eB[G], accA, accB);
+    }
+    if constexpr (G + 1 < kNGen) cn_normals<G + 1, NB>(b, lam, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
 }
-template <int G> SRL_G void cn_frictions(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
-    if (G < ngen_w) cn_rowF<G>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB);
-    if constexpr (G + 1 < kNGen) cn_frictions<G + 1>(b, lam, nAB, nBB, eB, accA, accB, ngen_w);
+template <int G, int NB = 1> SRL_G void cn_frictions(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
+                                                     double *accC = nullptr, const double *nCB = nullptr) {
+    if (G < ngen_w) {
+        if constexpr (NB == 2) cn_rowF<G, 2>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB, accC, nCB[kNGen + G]);
+        else cn_rowF<G>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB);
+    }
+    if constexpr (G + 1 < kNGen) cn_frictions<G + 1, NB>(b, lam, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
+}
+// Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
+// stops, normals, frictions).  nCB: the second button's rows' couplings to the bank-B slots (per lane, zero off the button lanes).
+SRL_G double sweeps_contacts2(const TRows &r, const TRows2 &r2, BRow &b, const double *sc, double accA, int ngen_w, const double *nCB, double *u2_out) {
+    int l = lane_id();
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(l));
+#endif
+    double nBA[kNArows], eA[kNArows], nAB[kNB], nBB[kNB], eB[kNB];
+#pragma unroll
+    for (int j = 0; j < kNArows; j++) { nBA[j] = sc[SC_NBA + j * GL + l]; eA[j] = l == j ? 1.0 : 0.0; }
+#pragma unroll
+    for (int s = 0; s < kNB; s++) { nAB[s] = sc[SC_NAB + s * GL + l]; nBB[s] = sc[SC_NBB + s * GL + l]; eB[s] = l == s ? 1.0 : 0.0; }
+    BRow bb = b;
+    if (!(bb.on && !bb.fric)) bb.hi = 0.0;
+    if (!bb.on) bb.cs = 0.0;
+    double lam = 0.0, accB = 0.0, uA = 0.0, accC = 0.0, uC = 0.0;
+#define SRL_CN_SWEEP(LAST)                                                                                                                     \
+    cn_rowA<0, LAST>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1, LAST>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2, LAST>(r, nBA[2], eA[2], accA, accB, uA);   \
+    cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
+    cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
+    cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
+    cn_rowA<kBM, LAST>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowC<kBM, LAST>(r2, bb.nBC[0], eA[kBM], accC, accB, uC);                      \
+    cn_rowA<kBLo, LAST>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi, LAST>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);                  \
+    cn_rowC<kBLo, LAST>(r2, bb.nBC[1], eA[kBLo], accC, accB, uC); cn_rowC<kBHi, LAST>(r2, bb.nBC[2], eA[kBHi], accC, accB, uC);                \
+    cn_normals<0, 2>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);                                                                   \
+    cn_frictions<0, 2>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);
+    for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
+    { SRL_CN_SWEEP(true) }
+#undef SRL_CN_SWEEP
+    b.lam = lam;
+    *u2_out = uC;
+    return uA;
 }
 SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double accA, int ngen_w) {
     int l = lane_id();
@@ -549,15 +631,18 @@ struct GenIn {
     const double *tab; double *scratch;
     TRows r;                      // the scaled bank-A row of this lane
     double qd_new, bqd, bound_bm;
+    TRows2 r2; double bqd2;       // Kuka2Button: the second button's rows (same lanes), its glider velocity
 };
 // What the general path needs of the step's intermediate results is parked in LDS when it is computed (planes the general path
 // only overwrites at the end of its setup), so that nothing of it stays in registers on the common path:
 //   W (the own row of M^-1) in the NBA plane [k][lane], S in its own plane, and MISC[13][lane] in the NAB / NBB planes:
 //   sphere centre cc[3], n_cap[3], n_base[3], d_cap, d_base, pen_lo, pen_hi
 constexpr int SC_STASH_W = SC_NBA, SC_STASH_MISC = SC_NAB;
-enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM_PENHI, SM_COUNT };
-static_assert(NJ * GL <= kNArows * GL && SM_COUNT * GL <= 2 * kNB * GL, "stash planes");
-struct GenOut { double u, acc_b, dvb_b; };     // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows
+enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM_PENHI, SM_COUNT,
+       SM_NCAP2 = SM_COUNT, SM_NBASE2 = SM_NCAP2 + 3, SM_DCAP2 = SM_NBASE2 + 3, SM_DBASE2, SM_COUNT2 };     // Kuka2Button: the second button's shapes
+static_assert(NJ * GL <= kNArows * GL && SM_COUNT2 * GL <= 2 * kNB * GL, "stash planes");
+struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; };   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
+template <int NB = 1>
 SRL_G GenOut general_path(const GenIn &in) {
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
     // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
@@ -573,6 +658,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
     BRow b;
     b.cs = 0.0; b.lo = 0.0; b.hi = 0.0; b.mu = 0.0; b.lam = 0.0; b.jb = 0.0; b.inv_diag = 0.0; b.normal = L.l; b.on = false; b.fric = false;
+    b.bsel = 0; b.nBC[0] = 0.0; b.nBC[1] = 0.0; b.nBC[2] = 0.0;
     int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
     {
@@ -584,16 +670,25 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double pen_lo = sc[SC_STASH_MISC + SM_PENLO * GL + L.l], pen_hi = sc[SC_STASH_MISC + SM_PENHI * GL + L.l];
         const bool sphere = L.slink() >= 0, has_lim = L.jnt && L.jlo() <= L.jhi();
         const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+        double n_cap2[3] = {0, 0, 1}, n_base2[3] = {0, 0, 1}, d_cap2 = 1e30, d_base2 = 1e30;
+        if constexpr (NB == 2) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { n_cap2[k] = sc[SC_STASH_MISC + (SM_NCAP2 + k) * GL + L.l]; n_base2[k] = sc[SC_STASH_MISC + (SM_NBASE2 + k) * GL + L.l]; }
+            d_cap2 = sc[SC_STASH_MISC + SM_DCAP2 * GL + L.l]; d_base2 = sc[SC_STASH_MISC + SM_DBASE2 * GL + L.l];
+        }
+        const bool c_cap2 = NB == 2 && sphere && d_cap2 < kContactThreshold, c_base2 = NB == 2 && sphere && d_base2 < kContactThreshold;
         const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
         // slot of a candidate = number of candidates before it in creation order: limits (joint 0 lower, joint 0 upper, joint 1
-        // lower, ...), then contacts (sphere 0 cap, sphere 0 base, sphere 1 cap, ...); the first max_gen are kept
+        // lower, ...), then contacts (sphere 0 cap, sphere 0 base, [sphere 0 cap 2, sphere 0 base 2,] sphere 1 cap, ...); the first max_gen are kept
         const uint32_t b_lo = ballot(lim_lo), b_hi = ballot(lim_hi), b_cap = ballot(c_cap), b_base = ballot(c_base);
+        const uint32_t b_cap2 = NB == 2 ? ballot(c_cap2) : 0u, b_base2 = NB == 2 ? ballot(c_base2) : 0u;
         const uint32_t below = (1u << L.l) - 1u;
         const int max_gen = L.max_gen();
         nlim = __builtin_popcount(b_lo) + __builtin_popcount(b_hi);
-        const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base);
+        const int ncon = __builtin_popcount(b_cap) + __builtin_popcount(b_base) + __builtin_popcount(b_cap2) + __builtin_popcount(b_base2);
         const int s_lo = __builtin_popcount(b_lo & below) + __builtin_popcount(b_hi & below), s_hi = s_lo + (lim_lo ? 1 : 0);
-        const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below), s_base = s_cap + (c_cap ? 1 : 0);
+        const int s_cap = nlim + __builtin_popcount(b_cap & below) + __builtin_popcount(b_base & below) + __builtin_popcount(b_cap2 & below) + __builtin_popcount(b_base2 & below);
+        const int s_base = s_cap + (c_cap ? 1 : 0), s_cap2 = s_base + (c_base ? 1 : 0), s_base2 = s_cap2 + (c_cap2 ? 1 : 0);
         if (nlim > max_gen) nlim = max_gen;
         ngen = nlim + ncon; if (ngen > max_gen) ngen = max_gen;
         // ---- row definitions -> LDS.  Slot s < kNGen: J[12] + (Jb, desired, position error, upper bound, on); its friction row at
@@ -612,7 +707,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * kErp * inv_dt; d[3] = blim; d[4] = 1.0;
             }
         };
-        auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap) {
+        auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap, int bsel) {
             if (slot < max_gen) {
                 double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (kNGen + slot) * NJ;
                 double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (kNGen + slot) * kDefDoubles;
@@ -636,12 +731,17 @@ SRL_G GenOut general_path(const GenIn &in) {
                 }
                 d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
                 df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && smu > 0.0) ? 1.0 : 0.0; df[5] = smu;
+                d[6] = (double)bsel; df[6] = (double)bsel;
             }
         };
         if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
         if (lim_hi) put_limit(s_hi, -1.0, pen_hi);
-        if (c_cap) put_contact(s_cap, n_cap, d_cap, true);
-        if (c_base) put_contact(s_base, n_base, d_base, false);
+        if (c_cap) put_contact(s_cap, n_cap, d_cap, true, 0);
+        if (c_base) put_contact(s_base, n_base, d_base, false, 0);
+        if constexpr (NB == 2) {
+            if (c_cap2) put_contact(s_cap2, n_cap2, d_cap2, true, 1);
+            if (c_base2) put_contact(s_base2, n_base2, d_base2, false, 1);
+        }
         sync_scratch();
     }
     nlim_w = 0; ngen_w = 0;
@@ -662,7 +762,7 @@ SRL_G GenOut general_path(const GenIn &in) {
 #pragma unroll
                 for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], act != 0.0 ? Js[j] : 0.0, wjk);   // (a slot this env does not use holds stale LDS: select, never multiply by 0)
                 if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
-                else wjk = (is_button && act != 0.0) ? r.jb * wb * jbs : 0.0;
+                else wjk = (is_button && act != 0.0 && (NB == 1 || ds[6] == 0.0)) ? r.jb * wb * jbs : 0.0;
             }
             sc[SC_NAB + s * GL + L.l] = -wjk * invA;
         }
@@ -678,8 +778,10 @@ SRL_G GenOut general_path(const GenIn &in) {
         b.on = own_on; b.fric = mine_f; b.jb = own_jb; b.mu = mine_f ? myd[5] : 0.0;
         b.normal = mine_f ? L.l - kNGen : L.l;
         b.lo = 0.0; b.hi = (own_on && !mine_f) ? myd[3] : 0.0;
+        const int own_bsel = (NB == 2 && own_on && myd[6] != 0.0) ? 1 : 0;
+        b.bsel = own_bsel;
         const double *Jr = sc + SC_J + own_slot * NJ, *wjr = sc + SC_WJ + own_slot * NJ;
-        double diag = own_jb * own_jb * wb, jv = own_jb * bqd, offb = own_jb * wb * (-bound_bm);
+        double diag = own_jb * own_jb * wb, jv = own_jb * (own_bsel ? in.bqd2 : bqd), offb = own_jb * wb * (-bound_bm);
 #pragma nounroll
         for (int j = 0; j < NJ; j++) {
             const double Jj = own_on ? Jr[j] : 0.0, wj = own_on ? wjr[j] : 0.0;
@@ -699,7 +801,12 @@ SRL_G GenOut general_path(const GenIn &in) {
             if (j < NJ) a = own_on ? wjr[j] : 0.0;
             else if (j == kBM || j == kBLo) a = own_jb * wb;
             else if (j == kBHi) a = -own_jb * wb;
+            if (NB == 2 && j >= NJ && own_bsel) a = 0.0;        // the row acts on ONE glider: its couplings go to that button's rows
             sc[SC_NBA + j * GL + L.l] = -a * S_of(j) * b.inv_diag;
+        }
+        if constexpr (NB == 2) {
+            const double ab = own_bsel ? own_jb * wb * b.inv_diag : 0.0;
+            b.nBC[0] = -ab * S_of(kBM); b.nBC[1] = -ab * S_of(kBLo); b.nBC[2] = ab * S_of(kBHi);
         }
 #pragma nounroll
         for (int s = 0; s < kNB; s++) {
@@ -707,7 +814,7 @@ SRL_G GenOut general_path(const GenIn &in) {
             double a = 0.0;
             if (used && s != L.l) {
                 const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
-                a = ds[4] != 0.0 ? own_jb * wb * ds[0] : 0.0;
+                a = (ds[4] != 0.0 && (NB == 1 || (ds[6] != 0.0) == (own_bsel != 0))) ? own_jb * wb * ds[0] : 0.0;
 #pragma unroll
                 for (int j = 0; j < NJ; j++) a = fma(own_on ? Jr[j] : 0.0, ds[4] != 0.0 ? ws[j] : 0.0, a);
             }
@@ -725,28 +832,46 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double Sk = S_of(k), u0 = Sk > 0.0 ? -lo_of(k) / Sk : 0.0;
         accA = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), u0, accA);
     }
-    if (nlim_w == 0) uA = sweeps_contacts(r, b, sc, accA, ngen_w);
-    else
+    double accC = 0.0, uC = 0.0;
+    // Kuka2Button: the second button's rows' scaled couplings to the bank-B slots that act on glider 2 (the form the first button's have in the NAB plane)
+    const bool liveC = NB == 2 && is_button && in.r2.S > 0.0;
+    const double invC = liveC ? 1.0 / (wb * in.r2.S) : 0.0;
+    auto nCB_of = [&](int s) -> double {
+        const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+        const double *ds = sc + SC_DEF + s * kDefDoubles;
+        return (used && liveC && ds[4] != 0.0 && ds[6] != 0.0) ? -(in.r2.jb * wb * ds[0]) * invC : 0.0;
+    };
+    if (nlim_w == 0) {
+        if constexpr (NB == 2) {
+            double nCB[kNB];
+#pragma unroll
+            for (int s = 0; s < kNB; s++) nCB[s] = nCB_of(s);
+            uA = sweeps_contacts2(r, in.r2, b, sc, accA, ngen_w, nCB, &uC);
+        } else uA = sweeps_contacts(r, b, sc, accA, ngen_w);
+    } else
     for (int it = 0; it < kSolverIters; it++) {
         gen_rowA<0>(L, r, sc, accA, accB, uA);  gen_rowA<1>(L, r, sc, accA, accB, uA);  gen_rowA<2>(L, r, sc, accA, accB, uA);
         gen_rowA<3>(L, r, sc, accA, accB, uA);  gen_rowA<4>(L, r, sc, accA, accB, uA);  gen_rowA<5>(L, r, sc, accA, accB, uA);
         gen_rowA<6>(L, r, sc, accA, accB, uA);  gen_rowA<7>(L, r, sc, accA, accB, uA);  gen_rowA<8>(L, r, sc, accA, accB, uA);
         gen_rowA<9>(L, r, sc, accA, accB, uA);  gen_rowA<10>(L, r, sc, accA, accB, uA); gen_rowA<11>(L, r, sc, accA, accB, uA);
         gen_rowA<kBM>(L, r, sc, accA, accB, uA);
+        if constexpr (NB == 2) gen_rowC<kBM>(L, in.r2, b, accC, accB, uC);
         // a slot index is a limit row in one env of the wavefront and a contact row in another: `part` keeps every row in its phase
-        for (int s = 0; s < nlim_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_lim ? 1.0 : 0.0, s) != 0.0);
+        for (int s = 0; s < nlim_w; s++) gen_rowB<NB>(L, sc, s, b, accA, accB, shfl(on_lim ? 1.0 : 0.0, s) != 0.0, &accC, NB == 2 ? nCB_of(s) : 0.0);
         gen_rowA<kBLo>(L, r, sc, accA, accB, uA); gen_rowA<kBHi>(L, r, sc, accA, accB, uA);
-        for (int s = 0; s < ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
-        for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0);
+        if constexpr (NB == 2) { gen_rowC<kBLo>(L, in.r2, b, accC, accB, uC); gen_rowC<kBHi>(L, in.r2, b, accC, accB, uC); }
+        for (int s = 0; s < ngen_w; s++) gen_rowB<NB>(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0, &accC, NB == 2 ? nCB_of(s) : 0.0);
+        for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB<NB>(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0, &accC, NB == 2 ? nCB_of(s) : 0.0);
     }
     GenOut out;
-    out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0;
+    out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0; out.u2 = uC; out.dvb_b2 = 0.0;
     const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
     for (int s = 0; s < kNB; s++) {
         const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
         if (!used) continue;
         out.acc_b = fma(sc[SC_NAB + s * GL + L.l], shfl(b.on ? b.lam : 0.0, s), out.acc_b);
-        out.dvb_b += shfl(pbb, s);
+        out.dvb_b += shfl(b.bsel ? 0.0 : pbb, s);
+        if constexpr (NB == 2) out.dvb_b2 += shfl(b.bsel ? pbb : 0.0, s);
     }
     sync_scratch();                          // scratch is reused by the next step
     return out;
@@ -756,6 +881,7 @@ SRL_G GenOut general_path(const GenIn &in) {
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
+template <int NB = 1>
 SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
                          double finger_angle) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
@@ -867,6 +993,28 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         for (int k = 0; k < 3; k++) { m[(SM_CC + k) * GL] = cc[k]; m[(SM_NCAP + k) * GL] = n_cap[k]; m[(SM_NBASE + k) * GL] = n_base[k]; }
         m[SM_DCAP * GL] = d_cap; m[SM_DBASE * GL] = d_base;
     }
+    bool c_any2 = false;
+    if constexpr (NB == 2) {                // Kuka2Button: the second button's cap and base (same urdf, kuka_2button_gym_env.py:62-70)
+        double n_cap2[3] = {0, 0, 1}, n_base2[3] = {0, 0, 1}, d_cap2 = 1e30, d_base2 = 1e30;
+        const double cap2_z0 = e.bz + kGliderOriginZ + e.b2q;
+        const double reach = L.sph(3) + kContactThreshold + 1e-9, dx = cc[0] - e.b2x, dy = cc[1] - e.b2y, rho2 = dx * dx + dy * dy;
+        const double rmax = kBaseRadius + reach;
+        const double top = fmax(cap2_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap2_z0, e.bz);
+        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+        if (wany(sphere && !far)) {
+            if (sphere) {
+                d_cap2 = sphere_cylinder(cc, L.sph(3), e.b2x, e.b2y, kCapRadius, cap2_z0, cap2_z0 + kCapHeight, n_cap2);
+                d_base2 = sphere_cylinder(cc, L.sph(3), e.b2x, e.b2y, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base2);
+            }
+        }
+        double *m = scratch + SC_STASH_MISC + L.l;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m[(SM_NCAP2 + k) * GL] = n_cap2[k]; m[(SM_NBASE2 + k) * GL] = n_base2[k]; }
+        m[SM_DCAP2 * GL] = d_cap2; m[SM_DBASE2 * GL] = d_base2;
+        c_any2 = sphere && (d_cap2 < kContactThreshold || d_base2 < kContactThreshold);
+        e.contact_body1 = gany(c_cap || c_base) ? 1 : 0;            // getContactPoints(button_uid, kuka_uid): any link of that button
+        e.contact_body2 = gany(c_any2) ? 1 : 0;
+    }
     e.contact_table = gany(sphere && (cc[2] - L.sph(3) - L.table_z() < kContactThreshold)) ? 1 : 0;
     e.contact_button = gany(c_cap) ? 1 : 0;
     // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
@@ -967,6 +1115,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
     const double qd_new = qd + dt * qdd;
     e.bqd += dt * kGravityZ;
+    if constexpr (NB == 2) e.b2qd += dt * kGravityZ;
     // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
     const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
@@ -1006,12 +1155,29 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     }
 #pragma unroll
     for (int k = 0; k < kNArows; k++) off = fma(a_of(k), lo_of(k), off);
+    // ---- Kuka2Button: the second button's motor and stops, on the same three lanes
+    TRows2 r2;
+    r2.cs = 0.0; r2.n[0] = 0.0; r2.n[1] = 0.0; r2.n[2] = 0.0; r2.lo = 0.0; r2.S = 0.0; r2.jb = 0.0;
+    if constexpr (NB == 2) {
+        double rhs2 = 0.0, off2 = 0.0;
+        if (is_bm) rhs2 = (e.motor_on ? kButtonKp * (kButtonTarget - e.b2q) * inv_dt : 0.0) - e.b2qd;
+        else if (is_blo) { const double pen = e.b2q - kGliderLower; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) - e.b2qd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt); }
+        else if (is_bhi) { const double pen = kGliderUpper - e.b2q; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) + e.b2qd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt); }
+        if (is_button) { r2.lo = r.lo; r2.S = r.S; r2.jb = r.jb; }
+#pragma unroll
+        for (int k = kBM; k <= kBHi; k++) off2 = fma(a_of(k), lo_of(k), off2);
+        const bool live2 = is_button && r2.S > 0.0;
+        const double inv2 = live2 ? rcp(wb * r2.S) : 0.0;
+        r2.cs = live2 ? (rhs2 - off2) * inv2 + (is_bm ? 0.5 : 0.0) : 0.0;
+#pragma unroll
+        for (int k = kBM; k <= kBHi; k++) r2.n[k - kBM] = -(a_of(k) * S_of(k)) * inv2;
+    }
     // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
     const bool has_lim = L.jnt && L.jlo() <= L.jhi();
     const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
     const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
     scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi;
-    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base || c_any2);
     // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
         const bool live = r.S > 0.0 && r.diag > 0.0;
@@ -1027,13 +1193,14 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             for (int k = 0; k < NJ; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
         }
     }
-    double u, acc_b = 0.0, dvb_b = 0.0;
-    if (!any_generic) u = sweeps_free(r);
+    double u, acc_b = 0.0, dvb_b = 0.0, u2 = 0.0, dvb_b2 = 0.0;
+    if (!any_generic) u = sweeps_free<NB>(r, &r2, &u2);
     else {
         GenIn in;
         in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
-        const GenOut out = general_path(in);
-        u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
+        in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0;
+        const GenOut out = general_path<NB>(in);
+        u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b; u2 = out.u2; dvb_b2 = out.dvb_b2;
     }
     const double lam = r.lo + r.S * u;
     SRL_GDBG(5, lane_id(), lam);
@@ -1054,6 +1221,11 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     if (lane_id() < NJ) { g.qd = qd_new + dv; g.q += dt * g.qd; }
     e.bqd += dvb;
     e.bq += dt * e.bqd;
+    if constexpr (NB == 2) {
+        const double pb2 = r2.jb * (r2.lo + r2.S * u2) * wb;
+        e.b2qd += bcast<kBM>(pb2) + bcast<kBLo>(pb2) + bcast<kBHi>(pb2) + dvb_b2;
+        e.b2q += dt * e.b2qd;
+    }
     const TL L3 = lane_view(tab);
     trefresh(L3, g, e);
 }
@@ -1085,6 +1257,7 @@ SRL_G void tinitial(Env &e, GState &g, const double *tab) {
     for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
     e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z(); e.bspeed = 0.0;
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0; e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    e.b2q = 0.0; e.b2qd = 0.0; e.b2x = kButtonX; e.b2y = kButton2Y2B; e.contact_body1 = 0; e.contact_body2 = 0; e.goal_id = 0; e.n_contacts2 = 0;
     trefresh(L, g, e);
 }
 
@@ -1093,22 +1266,23 @@ SRL_G void tinitial(Env &e, GState &g, const double *tab) {
 // five init actions is one of 6 (2) noise-free moves, so an episode starts from one of 6^5 (2^5) states, integrated once per
 // handle); START = 1: joint-space actions — the five init actions are integrated here from the settled state; START = 2: Cartesian
 // modes without a table (the CPU harness): the same five moves integrated from the settled state.
-template <int START, class R>
+template <int START, int NB = 1, class R>
 SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
                       double *objs, int64_t objs_stride) {
 #pragma clang fp contract(off)
     const TL L = lane_view(tab);
     ResetDraw d;
-    reset_draw<1>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
+    reset_draw<NB>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     tunpack_start(e, g, START ? settled : starts + (int64_t)d.idx * kTreeStartDoubles);
     e.bx = d.bx; e.by = d.by; e.bz = L.base_z();
+    if constexpr (NB == 2) { e.b2x = d.b2x; e.b2y = d.b2y; e.b2q = e.bq; e.b2qd = e.bqd; }    // same urdf, same free steps
     tfk(L, g);
     if constexpr (START == 1) {
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0() + kDeltaTheta * d.g[k];
-            tphysics_step(e, g, tab, cfg, scratch, motor, true, jt, 0.0);
+            tphysics_step<NB>(e, g, tab, cfg, scratch, motor, true, jt, 0.0);
         }
     } else if constexpr (START == 2) {
         const int base = cfg.is_discrete ? 6 : 2;
@@ -1116,26 +1290,26 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         double motor[3];
         for (int k = 0; k < kNInitActions; k++) {
             init_action_motor(cfg, rem % base, motor);
-            tphysics_step(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0);
+            tphysics_step<NB>(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0);
             rem /= base;
         }
     }
-    reset_finish<1>(e, d, L.base_z());
+    reset_finish<NB>(e, d, L.base_z());
 }
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-template <class R>
+template <int NB = 1, class R>
 SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done) {
     StepCmd c;
     step_command(e, cfg, rng, action, ca3, c);
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
+        tphysics_step<NB>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }
-    const double reward = reward_fn(e, cfg);
+    const double reward = NB == 2 ? reward_two(e, cfg) : reward_fn(e, cfg);
     *done = termination(e, cfg);
     return reward;
 }

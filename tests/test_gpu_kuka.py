@@ -224,20 +224,23 @@ def test_moving_button_env():
     env.close()
 
 
-@pytest.mark.lumped_kuka
-def test_two_button_env():
+def two_button_env(full):
     """Kuka2ButtonGymEnv-v0 on the GPU (NB = 2 kernels: second button body, goal switching) vs the oracle, whose wrapper
     logic is pinned to the reference source (tests/test_kuka_2button_golden.py).  Env 0 presses both buttons in order."""
     from test_kuka_kernel_source_on_host import two_button_actions
+    from test_kuka_tree_kernel_source_on_host import two_button_actions_full
     n, T = 128, 1600
-    actions = two_button_actions(n, T)
+    actions = two_button_actions_full(n, T) if full else two_button_actions(n, T)
     for kw in (dict(), dict(shape_reward=1, random_target=1)):
         cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
-        assert cfg.max_distance == 2.0 and cfg.force_down == 0
+        assert cfg.max_distance == 2.0 and cfg.force_down == 0 and cfg.kuka_model == _lib.KUKA_MODEL_FULL
         cfg.num_envs, cfg.seed0 = n, 60
+        if not full:
+            cfg.kuka_model = _lib.KUKA_MODEL_LUMPED
         for k, v in kw.items():
             setattr(cfg, k, v)
         h = _lib.Handle(cfg)
+        assert h.kuka_kernel() == ("tree" if full else "lane") and kuka_clib.is_full() == full
         obs0 = h.reset()
         b2_xy0 = h.get_state(_lib.F_KUKA_BUTTON2_XY).copy()
         out = h.rollout(T, actions=actions)
@@ -261,6 +264,11 @@ def test_two_button_env():
             assert out["done"][first, 0] and out["reward"][first, 0] == 1.0 and out["reward"][:first, 0].sum() == 4
             assert length[1] == 1501                                                          # idle env: counter > 1500
         h.close()
+
+
+def test_two_button_env():
+    """the default: the full arm + gripper model on the tree lane-group kernel's two-button form"""
+    two_button_env(True)
     from environments.registry import registered_env
     env = registered_env["Kuka2ButtonGymEnv-v0"][0](srl_model="ground_truth")
     env.seed(1)
@@ -269,6 +277,12 @@ def test_two_button_env():
     assert np.allclose(env.button_all_pos[0], [0.5, 0.125, 0.08]) and np.allclose(env.button_all_pos[1], [0.5, -0.125, 0.08])
     assert np.array_equal(env.getTargetPos(), env.button_all_pos[0])
     env.close()
+
+
+@pytest.mark.lumped_kuka
+def test_two_button_env_lumped_model():
+    """rounds 1-2: the lumped-gripper model on the lane-per-env kernel (kuka_model = LUMPED)"""
+    two_button_env(False)
 
 
 def test_rand_button_env():
@@ -379,10 +393,11 @@ def test_runtime_model_table_on_the_device():
             h.close()
     finally:
         kuka_clib.set_model(m0)
-    # Kuka2Button handles are stepped by the lane-per-env kernel (baked model only): they refuse a table
+    # lumped Kuka2Button handles are stepped by the lane-per-env kernel (baked model only): they refuse a table
     cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
-    cfg.num_envs = 4
+    cfg.num_envs, cfg.kuka_model = 4, _lib.KUKA_MODEL_LUMPED
     h = _lib.Handle(cfg)
+    assert h.kuka_kernel() == "lane"
     with pytest.raises(_lib.SrlHipError):
         h.set_kuka_model(kuka_model.to_table(m0))
     h.close()
@@ -420,11 +435,8 @@ def test_full_model_is_the_default_and_gripper_state_matches_the_oracle():
     out2 = h2.rollout(100, actions=actions[:100, :64])
     assert np.abs(out2["obs"] - out["obs"][:100, :64]).max() > 1e-3
     h2.close()
-    cfg = _lib.default_config(_lib.ENV_KUKA_2BUTTON)
-    assert cfg.kuka_model == _lib.KUKA_MODEL_LUMPED
-    cfg.kuka_model = _lib.KUKA_MODEL_FULL
-    with pytest.raises(_lib.SrlHipError):
-        _lib.Handle(cfg)
+    for kind in (_lib.ENV_KUKA_BUTTON, _lib.ENV_KUKA_MOVING, _lib.ENV_KUKA_2BUTTON, _lib.ENV_KUKA_RAND):
+        assert _lib.default_config(kind).kuka_model == _lib.KUKA_MODEL_FULL          # every Kuka env
 
 
 def test_full_model_runtime_table():
@@ -459,17 +471,18 @@ def test_full_model_runtime_table():
 
 def test_full_model_joint_limit_rows_and_row_budget():
     """The tree kernel's general path with joint-LIMIT rows (LDS coupling planes; a random agent never reaches the real limits):
-    a table whose arm limits sit 0.12 rad around the settled pose and a row budget of 3 that overflows; several envs of a
-    wavefront carry different row sets at the same time."""
+    a table whose limits of joints 3 and 5 sit 0.3 rad around the settled pose and a row budget of 3 that fills up; limit rows,
+    contact rows and both at once, several envs of a wavefront carrying different row sets at the same time."""
     n, T = 256, 600
     rs = np.random.RandomState(61)
     actions = rs.randint(6, size=(T, n)).astype(np.int32)
-    actions[rs.rand(T, n) < 0.2] = 4
+    actions[rs.rand(T, n) < 0.3] = 4
     t = _lib.kuka_tree_default_model().copy()
     J = 1 + 33 * np.arange(12)
     q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])
-    t[J[:7] + 16] = q_settled - 0.12
-    t[J[:7] + 17] = q_settled + 0.12
+    jj = np.array([3, 5])
+    t[J[jj] + 16] = q_settled[jj] - 0.3
+    t[J[jj] + 17] = q_settled[jj] + 0.3
     t[-2] = 3.0
     try:
         h = make(n, seed0=17, random_target=1)
@@ -478,8 +491,9 @@ def test_full_model_joint_limit_rows_and_row_budget():
         out = h.rollout(T, actions=actions)
         kuka_clib.set_tree_model(t)
         ora = kuka_clib.rollout(17 + np.arange(n), T, actions=actions, random_target=True, aux=True, trace=False)
-        lim = ora["rows"][:, :, 1] // 1000
-        assert (lim > 0).mean() > 0.05 and ora["rows"][:, :, 0].sum() > 20          # limit rows on > 5 % of the env-steps, contacts too
+        lim, normals = ora["rows"][:, :, 1] // 1000, ora["rows"][:, :, 0]
+        # limit rows on > 5 % of the env-steps, contact rows beside them, and the budget of 3 reached
+        assert (lim > 0).mean() > 0.05 and ((lim > 0) & (normals > 0)).sum() > 20 and ((lim + normals) >= 3).sum() > 5
         check_planes(ora, obs0, out)
         assert np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, :7]).max() <= TOL
         h.close()

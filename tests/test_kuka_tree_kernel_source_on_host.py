@@ -80,3 +80,45 @@ def test_joint_limit_rows_and_row_budget_with_a_tightened_model():
     finally:
         hostcheck.tree_set_model(None)
         kuka_clib.set_full(True)
+
+
+def two_button_actions_full(n, T, seed=5):
+    """Kuka2Button with the full model: random walks, env 0 scripted to press button 1 (y = +0.125) five times, rise, move over and
+    press button 2 (open loop, found with the oracle: the default-damping IK of this env tracks its target loosely), env 1 idles
+    into the 1500-step limit, env 2 goes for the second button first."""
+    actions = np.random.RandomState(seed).randint(6, size=(T, n)).astype(np.int32)
+    script = [3] * 4 + [0] * 4 + [4] * 17 + [-1] * 400 + [5] * 8 + [-1] * 120 + [2] * 8 + [-1] * 280 + [4] * 20
+    actions[:len(script), 0] = script
+    actions[len(script):, 0] = -1
+    actions[:, 1] = -1
+    script2 = [2] * 4 + [4] * 50
+    actions[:len(script2), 2] = script2
+    return actions
+
+
+def test_two_button_variant():
+    """Kuka2ButtonGymEnv on the tree kernel's source (NB = 2: the second button's motor / stop rows on the same three lanes, its
+    cap and base as contact shapes, rows that act on glider 1 or 2, goal switching) against the full-model oracle."""
+    n, T = 4, 1600
+    actions = two_button_actions_full(n, T)
+    try:
+        kuka_clib.set_variant(2); hostcheck.set_variant(2)
+        for kw in (dict(force_down=False, max_distance=2.0), dict(force_down=False, max_distance=2.0, shape_reward=True, random_target=True)):
+            a = kuka_clib.rollout(60 + np.arange(n), T, actions=actions, aux=True, **kw)
+            b = hostcheck.tree_rollout(60 + np.arange(n), T, actions=actions, **kw)
+            assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
+            assert np.abs(a["reward64"] - b["reward64"]).max() <= TOL
+            assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["gripper"] - b["gripper"]).max() <= TOL
+            assert np.abs(a["final_state"][:, 30:35] - b["final_state"][:, 30:35]).max() <= TOL           # gripper joints
+            assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])                 # goal_id, n_contacts[1]
+            assert np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL           # second glider
+            assert np.array_equal(a["final_state"][:, 28:30], b["final_state"][:, 28:30])                 # second button position
+            assert np.array_equal(a["ep_stats"][:, 1:], b["ep_stats"][:, 1:])
+            if not kw.get("random_target"):
+                first = np.argmax(a["done"][:, 0])
+                assert a["done"][first, 0] and 900 < first < 1400 and a["reward"][first, 0] == 1.0     # both buttons pressed in order
+                assert a["reward"][:first, 0].sum() == 4 and (a["reward"][:first, 0] != 0).sum() == 4   # sparse: last button only
+                assert a["rows"][:, :, 0].sum() > 100 and a["rows"][:, 2, 0].sum() > 10                 # contact rows, also on button 2 first
+        assert a["ep_stats"][:, 1].max() == 1501
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
