@@ -122,3 +122,33 @@ def test_two_button_variant():
         assert a["ep_stats"][:, 1].max() == 1501
     finally:
         kuka_clib.set_variant(0); hostcheck.set_variant(0)
+
+
+def test_two_button_variant_with_joint_limit_rows():
+    """NB = 2 on the general path's LDS loop (joint-limit rows in the wavefront): limits of joints 3 and 5 tightened to 0.3 rad
+    around the settled pose, row budget 3 — limit rows, contact rows on either button and the second button's rows interleave."""
+    t = kuka_clib.get_tree_model().copy()
+    J = 1 + 33 * np.arange(12)
+    q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])
+    jj = np.array([3, 5])
+    t[J[jj] + 16] = q_settled[jj] - 0.3
+    t[J[jj] + 17] = q_settled[jj] + 0.3
+    t[-2] = 3.0
+    n, T = 6, 700
+    rs = np.random.RandomState(9)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.35] = 4
+    kw = dict(force_down=False, max_distance=2.0, random_target=True)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        kuka_clib.set_variant(2); hostcheck.set_variant(2)
+        a = kuka_clib.rollout(20 + np.arange(n), T, actions=actions, aux=True, **kw)
+        b = hostcheck.tree_rollout(20 + np.arange(n), T, actions=actions, **kw)
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    lim, normals = a["rows"][:, :, 1] // 1000, a["rows"][:, :, 0]
+    assert (lim > 0).mean() > 0.3 and ((lim > 0) & (normals > 0)).sum() > 50
+    assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
+    assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL
+    assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])
