@@ -938,6 +938,52 @@ template <class R> struct Lane0Rng {
     SRL_G uint32_t bounded(uint32_t m) { double v = 0.0; if (own) v = (double)r->bounded(m); return (uint32_t)bcast<0>(v); }
 };
 
+// numpy RandomState (MT19937, state words in HBM: rng.hpp Mt19937View) for a lane group.  The index and the cached Gaussian are
+// replicated on the 16 lanes and every draw is computed by all of them (no broadcast of results).  Raw state words are fetched
+// SIXTEEN AT A TIME — one load instruction, lane l takes word idx + l — and handed out by a row shuffle: a per-word load inside the
+// step loop would wait for the previous steps' output stores on every draw (gfx9 counts loads and stores in one in-order
+// counter).  The twist regenerates the 624 words in 39 blocks of 16, word b + l on lane l (3 loads + 1 store per lane and block
+// instead of lane 0's 33 + 16): same blocks, same read-before-write order as Mt19937::twist, so the stream is the sequential
+// generator's bit for bit.  (Memory operations of one wavefront are performed in order: the wavefront-scope fences of
+// sync_scratch() order the blocks; on the host harness they are the fibers' lockstep points.)
+struct GroupMt {
+    Mt19937 m;
+    uint32_t win;            // raw (untempered) word m.idx - pos + lane
+    int pos, cnt;            // words of the window handed out / fetched
+    SRL_G void load(const Mt19937View &v, int64_t env) { m.load(v, env); win = 0u; pos = 0; cnt = 0; }
+    SRL_G void store(const Mt19937View &v, int64_t env) const { m.store(v, env); }      // (one lane of a valid env)
+    SRL_G void twist() {
+        const int l = lane_id();
+        for (int b = 0; b < MT_N; b += GL) {                      // 624 = 39 x 16
+            const int k = b + l, k1 = k + 1 >= MT_N ? k + 1 - MT_N : k + 1, km = k + MT_M >= MT_N ? k + MT_M - MT_N : k + MT_M;
+            const uint32_t a0 = m.at(k), a1 = m.at(k1), mm = m.at(km);
+            sync_scratch();
+            const uint32_t y = (a0 & 0x80000000u) | (a1 & 0x7fffffffu);
+            uint32_t v = mm ^ (y >> 1);
+            if (y & 1u) v ^= 0x9908b0dfu;
+            m.at(k) = v;
+            sync_scratch();
+        }
+        m.idx = 0;
+    }
+    SRL_G uint32_t u32() {
+        if (pos >= cnt) {
+            if (m.idx >= MT_N) twist();
+            const int l = lane_id();
+            cnt = MT_N - m.idx < GL ? MT_N - m.idx : GL;
+            win = l < cnt ? m.at(m.idx + l) : 0u;
+            pos = 0;
+        }
+        const uint32_t y = (uint32_t)shfl((double)win, pos);      // (a uint32 is exact in a double)
+        pos++; m.idx++;
+        return mt_temper(y);
+    }
+    SRL_G double double01() { return mt_double01(*this); }
+    SRL_G double normal(double loc, double scale) { return mt_normal(*this, m.has_g, m.g, loc, scale); }
+    SRL_G double uniform(double low, double high) { return mt_uniform(*this, low, high); }
+    SRL_G uint32_t bounded(uint32_t rng) { return mt_bounded(*this, rng); }
+};
+
 // Counter-based env stream (Philox) for a lane group.  Every lane holds the same key / counter; the expensive draw — the
 // per-step Gaussian noise (log, sqrt, cos in float64) — is produced 16 counters at a time, one per lane, and handed out by a
 // row shuffle, so its cost is shared by 16 steps instead of being replayed on all 16 lanes every step.  Values are the

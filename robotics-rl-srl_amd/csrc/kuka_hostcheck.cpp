@@ -521,7 +521,10 @@ void tree_env_body(GroupArgs &a, R &rng) {
 }
 void tree_fiber_body(void *p) {
     GroupArgs &a = *static_cast<GroupArgs *>(p);
-    if (a.rng_mode == 2) { grp::Lane0Rng<MtHost> r{a.mt, grp::lane_id() == 0}; if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r); }
+    if (a.rng_mode == 2) {            // the lane-group MT19937 of the device kernels over the env's host-side state words (every fiber: its own replica)
+        grp::GroupMt r; r.m = a.mt->m; r.win = 0u; r.pos = 0; r.cnt = 0;
+        if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r);
+    }
     else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r); }
 }
 struct TreeSettleArgs { Cfg cfg; double *out; double *scratch; };

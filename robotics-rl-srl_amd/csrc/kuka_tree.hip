@@ -85,11 +85,11 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     LaneId L;
     build_lane_table(L, s.ttable, tab);
     const bool lead = L.l == 0 && valid;
-    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
     Rng rng0;
     if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
     else krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
-    Lane0Rng<Rng> rng_l0{&rng0, lead};
     Env v = {};
     GState g;
     tload(s, n, e, L, v, g, NB == 2);
@@ -123,15 +123,13 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
         bool done;
         double reward;
-        if constexpr (MODE == SRLHIP_RNG_MT19937) reward = tree::tenv_step<NB>(v, g, tab, cfg, scratch, rng_l0, a, ca, ca_own, &done);
-        else reward = tree::tenv_step<NB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done);
+        reward = tree::tenv_step<NB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
                 double *objs = valid ? s.objs + e : nullptr;
-                if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, cfg, scratch, rng_l0, s.tstarts, s.tsettled, objs, n);
-                else tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
+                tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n);
                 // the start-state loads retire HERE, not at their first use in the next step (where vmcnt(0) would also wait for
                 // the output stores of steps that did not reset)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -148,6 +146,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     tstore(s, n, e_out, L, v, g, valid, NB == 2);
     if (lead) {
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e_out] = rng0.p.ctr;
+        else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.store(rs.mt, e_out);
         else krng_store<MODE>(rng0, rs, e_out);
         if constexpr (!GIVEN) rs.act_ctr[e_out] = act.ctr;
         st.ep_return[e_out] = ep_ret; st.ep_length[e_out] = ep_len; st.last_return[e_out] = last_ret; st.last_length[e_out] = last_len;
@@ -168,19 +167,19 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     __shared__ double tab[tree::kLaneTableDoubles];
     LaneId L; build_lane_table(L, s.ttable, tab);
     const bool lead = L.l == 0 && valid;
-    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, typename KRng<MODE>::type>;
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
     Rng rng0;
     if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
     else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
-    Lane0Rng<Rng> rng_l0{&rng0, lead};
     Env v = {};
     GState g;
     double *objs = valid ? s.objs + e : nullptr;
-    if constexpr (MODE == SRLHIP_RNG_MT19937) tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng_l0, s.tstarts, s.tsettled, objs, n);
-    else tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
+    tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
     tstore(s, n, e, L, v, g, valid, NB == 2);
     if (lead) {
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
+        else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.store(rs.mt, e);
         else krng_store<MODE>(rng0, rs, e);
         st.ep_return[e] = 0.0; st.ep_length[e] = 0;
         if (obs) {

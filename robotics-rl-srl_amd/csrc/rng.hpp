@@ -21,6 +21,52 @@ namespace srl {
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 
+// numpy's derived draws on top of any source of tempered 32-bit words (G::u32()): shared by the per-env generator below and by
+// the lane-group generator of the Kuka kernels (kuka_group.hpp: GroupMt), so that both produce the same stream bit for bit.
+// numpy rk_double / random_sample: 53-bit double in [0, 1)
+template <class G> SRL_HD double mt_double01(G &gen) {
+    uint32_t a = gen.u32() >> 5, b = gen.u32() >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+// legacy_gauss (polar Box-Muller, caches the second deviate)
+template <class G> SRL_HD double mt_std_normal(G &gen, int32_t &has_g, double &g) {
+#pragma clang fp contract(off)
+    if (has_g) { double t = g; g = 0.0; has_g = 0; return t; }
+    double x1, x2, r2;
+    do {
+        x1 = 2.0 * mt_double01(gen) - 1.0;
+        x2 = 2.0 * mt_double01(gen) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    double f = sqrt(-2.0 * log(r2) / r2);
+    g = f * x1; has_g = 1;
+    return f * x2;
+}
+template <class G> SRL_HD double mt_normal(G &gen, int32_t &has_g, double &g, double loc, double scale) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+    return loc + scale * mt_std_normal(gen, has_g, g);
+}
+template <class G> SRL_HD double mt_uniform(G &gen, double low, double high) {
+#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
+    return low + (high - low) * mt_double01(gen);
+}
+// RandomState.randint(0, rng+1): masked rejection on 32-bit draws (rng < 2^32)
+template <class G> SRL_HD uint32_t mt_bounded(G &gen, uint32_t rng) {
+    if (rng == 0) return 0;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = (gen.u32() & mask)) > rng) {}
+    return v;
+}
+SRL_HD uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
 struct Mt19937View {
     uint32_t *mt;        // [MT_N][stride]
     int32_t *mti;        // [stride]
@@ -99,49 +145,13 @@ struct Mt19937 {
 
     SRL_HD uint32_t u32() {
         if (idx >= MT_N) twist();
-        uint32_t y = at(idx++);
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        return mt_temper(at(idx++));
     }
-    // numpy rk_double / random_sample: 53-bit double in [0, 1)
-    SRL_HD double double01() {
-        uint32_t a = u32() >> 5, b = u32() >> 6;
-        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-    }
-    // legacy_gauss (polar Box-Muller, caches the second deviate)
-    SRL_HD double std_normal() {
-#pragma clang fp contract(off)
-        if (has_g) { double t = g; g = 0.0; has_g = 0; return t; }
-        double x1, x2, r2;
-        do {
-            x1 = 2.0 * double01() - 1.0;
-            x2 = 2.0 * double01() - 1.0;
-            r2 = x1 * x1 + x2 * x2;
-        } while (r2 >= 1.0 || r2 == 0.0);
-        double f = sqrt(-2.0 * log(r2) / r2);
-        g = f * x1; has_g = 1;
-        return f * x2;
-    }
-    SRL_HD double normal(double loc, double scale) {
-#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
-        return loc + scale * std_normal();
-    }
-    SRL_HD double uniform(double low, double high) {
-#pragma clang fp contract(off)   // numpy computes these unfused; keep them bit-identical under -ffp-contract=fast
-        return low + (high - low) * double01();
-    }
-    // RandomState.randint(0, rng+1): masked rejection on 32-bit draws (rng < 2^32)
-    SRL_HD uint32_t bounded(uint32_t rng) {
-        if (rng == 0) return 0;
-        uint32_t mask = rng;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        uint32_t v;
-        while ((v = (u32() & mask)) > rng) {}
-        return v;
-    }
+    SRL_HD double double01() { return mt_double01(*this); }
+    SRL_HD double std_normal() { return mt_std_normal(*this, has_g, g); }
+    SRL_HD double normal(double loc, double scale) { return mt_normal(*this, has_g, g, loc, scale); }
+    SRL_HD double uniform(double low, double high) { return mt_uniform(*this, low, high); }
+    SRL_HD uint32_t bounded(uint32_t rng) { return mt_bounded(*this, rng); }
 };
 
 // ------------------------------------------------------------- Philox4x32-10
