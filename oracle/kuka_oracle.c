@@ -40,6 +40,12 @@
 /* optional trace of the commands handed to the arm (wrapper pinning tests) */
 static double *g_trace_ee = NULL, *g_trace_jt = NULL;
 static int g_trace_n = 0;
+/* Sensitivity probe (profiles/probes/kuka_bullet_detail_sensitivity.py), NOT part of the parity definition: variants of solver
+ * details of Bullet's btMultiBodyConstraintSolver that are recalled, not read (the source is absent here).  bit 0: the non-contact
+ * rows are swept backwards on even iterations (`iteration & 1 ? j : size - 1 - j`); bit 1: non-contact rows in body-creation
+ * order (button loaded before the arm, kuka_button_gym_env.py:233-238; per body: joint-limit rows, then its motors). */
+static int g_detail = 0;
+void kuka_oracle_set_detail(int mask) { g_detail = mask; }
 #pragma omp threadprivate(g_trace_ee, g_trace_jt, g_trace_n)
 
 /* ------------------------------------------------------------------ small algebra */
@@ -508,9 +514,21 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     /* -- projected Gauss-Seidel, numSolverIterations = 150: non-contact rows, contact normals, then friction rows whose bounds
      *    follow the current normal impulse (skipped while that impulse is not positive) -- */
     memset(dv, 0, sizeof dv);
+    {
+    int order[MAX_ROWS], nnc = 0, jj;
+    for (k = 0; k < nrows; k++) order[k] = k;
+    while (nnc < nrows && rows[nnc].fric_of < 0 && rows[nnc].hi < 1e9) nnc++;     /* non-contact rows: everything before the first normal (hi = 1e10) */
+    if (g_detail & 2) {            /* [button stops, button motors, arm limits, arm motors] */
+        int w = 0, nlim_arm = nnc - n - 3 * nb;
+        for (b = 0; b < nb; b++) { order[w++] = n + nb + nlim_arm + 2 * b; order[w++] = n + nb + nlim_arm + 2 * b + 1; order[w++] = n + b; }
+        for (k = 0; k < nlim_arm; k++) order[w++] = n + nb + k;
+        for (k = 0; k < n; k++) order[w++] = k;
+    }
     for (it = 0; it < KM_SOLVER_ITERS; it++) {
-        for (k = 0; k < nrows; k++) {
-            row_t *r = &rows[k]; double jdv, delta, sum;
+        for (jj = 0; jj < nrows; jj++) {
+            row_t *r; double jdv, delta, sum;
+            k = jj < nnc ? order[(g_detail & 1) ? ((it & 1) ? jj : nnc - 1 - jj) : jj] : jj;
+            r = &rows[k];
             if (r->fric_of >= 0) {
                 const double tot = rows[r->fric_of].applied;
                 if (!(tot > 0.0)) continue;
@@ -526,6 +544,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             for (i = 0; i < n; i++) dv[i] += delta * r->WJ[i];
             dvb[r->bsel] += delta * r->WJb;
         }
+    }
     }
     /* -- semi-implicit Euler -- */
     for (i = 0; i < n; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
