@@ -408,6 +408,10 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     }
     if workload == "kuka":
         line["config"]["kuka_model"] = h.kuka_model_name()
+        if args.kuka_model == "full":
+            # rounds 1-2 reported this metric for the lumped-gripper model (2.4e8): a different, cheaper simulation
+            line["config"]["model_note"] = ("the full arm + gripper model since round 3; the rounds 1-2 lumped-gripper model "
+                                            "(gripper welded to link 7, 7 DoF) is `--kuka-model lumped`")
     if world > 1:
         torch.cuda.synchronize()
         line["config"]["episode_returns_allgathered"] = {"count": int(gathered.numel()), "mean": float(gathered.mean().item()),
