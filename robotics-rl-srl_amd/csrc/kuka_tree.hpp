@@ -522,43 +522,59 @@ template <int J, bool LAST> SRL_G void cn_rowC(const TRows2 &r2, double nBC_J, d
     fmac_bcast<J>(accB, t, nBC_J);
     if (LAST) uC = fma(eJ, t - uC, uC);
 }
-template <int G, int NB = 1> SRL_G void cn_rowN(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
-    double t = b.cs + accB;
-    t = t < 0.0 ? 0.0 : (t > b.hi ? b.hi : t);      // (an unused slot has cs = 0, zero couplings and hi = 0: t = 0)
-    lam = fma(eS, t - lam, lam);
-    accB = fma(-eS, accB, accB);
-    fmac_bcast<G>(accA, t, nAB);
-    fmac_bcast<G>(accB, t, nBB);
-    if constexpr (NB == 2) fmac_bcast<G>(*accC, t, nCB);
+// Bank-B rows of the contact path.  Only the OWNING lane's value of a row is ever consumed (through a row broadcast), so a row's
+// impulse is simply the register `t` of its last update on every lane — no masked bookkeeping: tN[G] / tF[G] are the impulses of
+// normal slot G (lane G) and of its friction row (lane kNGen + G).  One asm statement per row for the DPP part (one hazard nop).
+template <int S, int NB> SRL_G void cn_spread(double t, double nAB, double nBB, double nCB, double &accA, double &accB, double *accC) {
+#if SRL_G_DEVICE
+    if constexpr (NB == 2)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+            : "+v"(accA), "+v"(accB), "+v"(*accC) : "v"(t), "v"(nAB), "v"(nBB), "v"(nCB), "n"(S));
+    else
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+            : "+v"(accA), "+v"(accB) : "v"(t), "v"(nAB), "v"(nBB), "n"(S));
+#else
+    const double tb = grp::host_exchange(t, S);
+    accA = fma(tb, nAB, accA); accB = fma(tb, nBB, accB);
+    if constexpr (NB == 2) *accC = fma(tb, nCB, *accC);
+#endif
+}
+// contact-normal slot G on lane G: lambda = clamp(cs + accB, 0, hi)   (an unused slot has cs = 0, zero couplings and hi = 0: 0)
+template <int G, int NB = 1> SRL_G void cn_rowN(const BRow &b, double &tN, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
+    const double t = fmin(fmax(b.cs + accB, 0.0), b.hi);
+    accB = fma(-eS, accB, accB);                    // the own accumulator restarts
+    tN = t;
+    cn_spread<G, NB>(t, nAB, nBB, nCB, accA, accB, accC);
 }
 // friction slot kNGen + G: bounds +-mu * (current impulse of normal slot G); the row keeps its value while that is not positive
-template <int G, int NB = 1> SRL_G void cn_rowF(const BRow &b, double &lam, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
-    const double tot = bcast<G>(lam);               // lane G's lambda: the normal row's CURRENT impulse
-    const double hi = b.mu * tot;
-    double t = b.cs + accB;
-    t = t < -hi ? -hi : (t > hi ? hi : t);
-    t = (b.fric && tot > 0.0) ? t : lam;            // (on lanes that do not own an active friction row lam is 0 and stays 0)
-    lam = fma(eS, t - lam, lam);
+// (mu > 0 on a lane that owns an active friction row, 0 elsewhere: hi > 0 says both)
+template <int G, int NB = 1> SRL_G void cn_rowF(const BRow &b, double tN, double &tF, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
+    const double hi = b.mu * bcast<G>(tN);
+    double t = fmin(fmax(b.cs + accB, -hi), hi);
+    t = hi > 0.0 ? t : tF;
     accB = fma(-eS, accB, accB);
-    fmac_bcast<kNGen + G>(accA, t, nAB);
-    fmac_bcast<kNGen + G>(accB, t, nBB);
-    if constexpr (NB == 2) fmac_bcast<kNGen + G>(*accC, t, nCB);
+    tF = t;
+    cn_spread<kNGen + G, NB>(t, nAB, nBB, nCB, accA, accB, accC);
 }
-template <int G, int NB = 1> SRL_G void cn_normals(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
+template <int G, int NB = 1> SRL_G void cn_normals(const BRow &b, double *tN, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
                                                    double *accC = nullptr, const double *nCB = nullptr) {
-    if (G < ngen_w) {
-        if constexpr (NB == 2) cn_rowN<G, 2>(b, lam, nAB[G], nBB[G], eB[G], accA, accB, accC, nCB[G]);
-        else cn_rowN<G>(b, lam, nAB[G], nBB[G], eB[G], accA, accB);
-    }
-    if constexpr (G + 1 < kNGen) cn_normals<G + 1, NB>(b, lam, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
+    if (G < ngen_w) cn_rowN<G, NB>(b, tN[G], nAB[G], nBB[G], eB[G], accA, accB, accC, NB == 2 ? nCB[G] : 0.0);
+    if constexpr (G + 1 < kNGen) cn_normals<G + 1, NB>(b, tN, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
 }
-template <int G, int NB = 1> SRL_G void cn_frictions(const BRow &b, double &lam, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
+template <int G, int NB = 1> SRL_G void cn_frictions(const BRow &b, const double *tN, double *tF, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w,
                                                      double *accC = nullptr, const double *nCB = nullptr) {
-    if (G < ngen_w) {
-        if constexpr (NB == 2) cn_rowF<G, 2>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB, accC, nCB[kNGen + G]);
-        else cn_rowF<G>(b, lam, nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB);
-    }
-    if constexpr (G + 1 < kNGen) cn_frictions<G + 1, NB>(b, lam, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
+    if (G < ngen_w) cn_rowF<G, NB>(b, tN[G], tF[G], nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB, accC, NB == 2 ? nCB[kNGen + G] : 0.0);
+    if constexpr (G + 1 < kNGen) cn_frictions<G + 1, NB>(b, tN, tF, nAB, nBB, eB, accA, accB, ngen_w, accC, nCB);
+}
+// the own row's impulse after the last sweep: lane l < kNGen owns normal slot l, lane kNGen + g the friction row of slot g
+SRL_G double cn_own_lambda(const double *tN, const double *tF, int l) {
+    double lam = 0.0;
+#pragma unroll
+    for (int g = 0; g < kNGen; g++) { lam = l == g ? tN[g] : lam; lam = l == kNGen + g ? tF[g] : lam; }
+    return lam;
 }
 // Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
 // stops, normals, frictions).  nCB: the second button's rows' couplings to the bank-B slots (per lane, zero off the button lanes).
@@ -575,7 +591,9 @@ SRL_G double sweeps_contacts2(const TRows &r, const TRows2 &r2, BRow &b, const d
     BRow bb = b;
     if (!(bb.on && !bb.fric)) bb.hi = 0.0;
     if (!bb.on) bb.cs = 0.0;
-    double lam = 0.0, accB = 0.0, uA = 0.0, accC = 0.0, uC = 0.0;
+    double accB = 0.0, uA = 0.0, accC = 0.0, uC = 0.0, tN[kNGen], tF[kNGen];
+#pragma unroll
+    for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
 #define SRL_CN_SWEEP(LAST)                                                                                                                     \
     cn_rowA<0, LAST>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1, LAST>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2, LAST>(r, nBA[2], eA[2], accA, accB, uA);   \
     cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
@@ -584,12 +602,12 @@ SRL_G double sweeps_contacts2(const TRows &r, const TRows2 &r2, BRow &b, const d
     cn_rowA<kBM, LAST>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowC<kBM, LAST>(r2, bb.nBC[0], eA[kBM], accC, accB, uC);                      \
     cn_rowA<kBLo, LAST>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi, LAST>(r, nBA[kBHi], eA[kBHi], accA, accB, uA);                  \
     cn_rowC<kBLo, LAST>(r2, bb.nBC[1], eA[kBLo], accC, accB, uC); cn_rowC<kBHi, LAST>(r2, bb.nBC[2], eA[kBHi], accC, accB, uC);                \
-    cn_normals<0, 2>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);                                                                   \
-    cn_frictions<0, 2>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);
+    cn_normals<0, 2>(bb, tN, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);                                                                    \
+    cn_frictions<0, 2>(bb, tN, tF, nAB, nBB, eB, accA, accB, ngen_w, &accC, nCB);
     for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
     { SRL_CN_SWEEP(true) }
 #undef SRL_CN_SWEEP
-    b.lam = lam;
+    b.lam = cn_own_lambda(tN, tF, l);
     *u2_out = uC;
     return uA;
 }
@@ -607,19 +625,21 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     BRow bb = b;
     if (!(bb.on && !bb.fric)) bb.hi = 0.0;
     if (!bb.on) bb.cs = 0.0;
-    double lam = 0.0, accB = 0.0, uA = 0.0;
+    double accB = 0.0, uA = 0.0, tN[kNGen], tF[kNGen];
+#pragma unroll
+    for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
 #define SRL_CN_SWEEP(LAST)                                                                                                                     \
     cn_rowA<0, LAST>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1, LAST>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2, LAST>(r, nBA[2], eA[2], accA, accB, uA);   \
     cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
     cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
     cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
     cn_rowA<kBM, LAST>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowA<kBLo, LAST>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi, LAST>(r, nBA[kBHi], eA[kBHi], accA, accB, uA); \
-    cn_normals<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);                                                                                  \
-    cn_frictions<0>(bb, lam, nAB, nBB, eB, accA, accB, ngen_w);
+    cn_normals<0>(bb, tN, nAB, nBB, eB, accA, accB, ngen_w);                                                                                   \
+    cn_frictions<0>(bb, tN, tF, nAB, nBB, eB, accA, accB, ngen_w);
     for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
     { SRL_CN_SWEEP(true) }
 #undef SRL_CN_SWEEP
-    b.lam = lam;
+    b.lam = cn_own_lambda(tN, tF, l);
     return uA;
 }
 
