@@ -499,3 +499,19 @@ def test_full_model_joint_limit_rows_and_row_budget():
         h.close()
     finally:
         kuka_clib.set_full(True)
+
+
+@pytest.mark.parametrize("n", [1, 5, 7, 130])
+def test_ragged_env_counts_with_mt19937_streams(n):
+    """env counts that do not fill the last wavefront (its spare lane groups shadow the last env, MT19937 state words included:
+    the lane-group generator fetches and twists them across the 16 lanes) through several episodes and twists"""
+    T = 1300
+    actions = np.random.RandomState(3).randint(6, size=(T, n)).astype(np.int32)
+    h = make(n, seed0=21, random_target=1)
+    assert h.cfg.rng_mode == _lib.RNG_MT19937
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    ora = kuka_clib.rollout(21 + np.arange(n), T, actions=actions, random_target=True, trace=False)
+    check_planes(ora, obs0, out)
+    assert ora["done"].sum() >= 2
+    h.close()
