@@ -96,3 +96,32 @@ def test_full_model_settled_gripper_is_closed_and_arm_on_target(full_model):
     out = kuka_clib.rollout([0], 1, actions=np.array([[-1]], np.int32), aux=True)
     qa = out["q_all"][0, 0]
     assert np.abs(qa[7]) < 1e-4 and np.abs(qa[[8, 10]]).max() < 0.02 and np.abs(qa[[9, 11]]).max() < 0.02
+
+
+def test_solver_is_not_converged_after_150_sweeps_so_row_order_matters():
+    """profiles/probes/kuka_bullet_detail_sensitivity.py in small: the oracle's sensitivity bits (NOT part of the parity definition)
+    change the joints by far more than the 1e-4 bar within a few hundred contact-free steps — the reason DESIGN 4.2 lists Bullet's
+    recalled sweep order as the first thing the PyBullet pin has to settle."""
+    import ctypes
+    lib = kuka_clib._lib()
+    lib.kuka_oracle_set_detail.argtypes = [ctypes.c_int]
+    T = 150
+    actions = np.random.RandomState(1234).randint(6, size=(T, 1)).astype(np.int32)
+    try:
+        kuka_clib.set_full(True)
+        base = kuka_clib.rollout([0], T, actions=actions, aux=True)
+        lib.kuka_oracle_set_detail(1)                     # alternating sweep direction of the non-contact rows
+        alt = kuka_clib.rollout([0], T, actions=actions, aux=True)
+    finally:
+        lib.kuka_oracle_set_detail(0)
+        kuka_clib.set_full(False)
+    assert base["rows"][:, :, 0].sum() == 0               # contact-free
+    d = np.abs(alt["q_all"] - base["q_all"]).max()
+    assert 1e-4 < d < 0.2
+    again = None
+    try:
+        kuka_clib.set_full(True)
+        again = kuka_clib.rollout([0], T, actions=actions, aux=True)
+    finally:
+        kuka_clib.set_full(False)
+    assert np.array_equal(again["q_all"], base["q_all"])   # the bits are off again
