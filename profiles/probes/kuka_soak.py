@@ -1,5 +1,6 @@
-"""One-off soak (run on the GPU box): KukaButtonGymEnv, 4096 envs x 3000 steps, Philox random agent with auto-reset,
-HIP stepper vs the C oracle: actions / reward / done bit-exact, observations and final joints within 1e-4."""
+"""Soak (run on the GPU box): the full-model tree kernel against the C oracle, Philox random agent with auto-reset —
+KukaButtonGymEnv 8192 envs x 4000 steps and Kuka2ButtonGymEnv 2048 envs x 3200 steps: actions / reward / done bit-exact,
+observations and final joints within 1e-4."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "robotics-rl-srl_amd")); sys.path.insert(0, R)
@@ -7,16 +8,25 @@ import numpy as np
 import torch  # noqa: F401
 from oracle import kuka_clib
 from srlhip import _lib
-n, T = 4096, 3000
-cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
-cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0 = n, _lib.RNG_PHILOX, 1, 7
-h = _lib.Handle(cfg)
-obs0 = h.reset()
-t0 = time.perf_counter(); out = h.rollout(T); t1 = time.perf_counter()
-ora = kuka_clib.rollout(7 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False); t2 = time.perf_counter()
-print("gpu %.2f s (host-pointer planes), oracle %.1f s" % (t1 - t0, t2 - t1))
-print("actions equal:", np.array_equal(ora["actions"], out["actions"]), " reward equal:", np.array_equal(ora["reward"], out["reward"]),
-      " done equal:", np.array_equal(ora["done"], out["done"]), " episodes finished per env: min %d max %d" % (ora["ep_stats"][:, 2].min(), ora["ep_stats"][:, 2].max()))
-print("max |obs - obs_oracle| = %.3e, max |q_final - q_oracle| = %.3e" % (np.abs(ora["obs"] - out["obs"]).max(), np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, 0:7]).max()))
-ret, length, fin = h.episode_stats()
-print("episode stats equal:", np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32)), np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)), np.array_equal(ret, ora["ep_stats"][:, 0]))
+kuka_clib.set_full(True)
+for kind, variant, n, T, kw in ((_lib.ENV_KUKA_BUTTON, 0, 8192, 4000, dict(random_target=True)),
+                                (_lib.ENV_KUKA_2BUTTON, 2, 2048, 3200, dict(random_target=True, force_down=False, max_distance=2.0))):
+    cfg = _lib.default_config(kind)
+    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0, cfg.random_target = n, _lib.RNG_PHILOX, 1, 7, 1
+    h = _lib.Handle(cfg)
+    assert h.kuka_kernel() == "tree"
+    obs0 = h.reset()
+    t0 = time.perf_counter(); out = h.rollout(T); t1 = time.perf_counter()
+    kuka_clib.set_variant(variant)
+    try:
+        ora = kuka_clib.rollout(7 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False, **kw)
+    finally:
+        kuka_clib.set_variant(0)
+    t2 = time.perf_counter()
+    print("kind %d: %d envs x %d steps: gpu %.2f s (host-pointer planes), oracle %.1f s" % (kind, n, T, t1 - t0, t2 - t1))
+    print("  actions equal:", np.array_equal(ora["actions"], out["actions"]), " reward equal:", np.array_equal(ora["reward"], out["reward"]),
+          " done equal:", np.array_equal(ora["done"], out["done"]), " episodes finished per env: min %d max %d" % (ora["ep_stats"][:, 2].min(), ora["ep_stats"][:, 2].max()))
+    print("  max |obs - obs_oracle| = %.3e, max |q_final - q_oracle| = %.3e, NaN in obs: %s" % (np.abs(ora["obs"] - out["obs"]).max(), np.abs(h.get_state(_lib.F_KUKA_Q).T - ora["final_state"][:, 0:7]).max(), bool(np.isnan(out["obs"]).any())))
+    ret, length, fin = h.episode_stats()
+    print("  episode stats equal:", np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32)), np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)), np.abs(ret - ora["ep_stats"][:, 0]).max() <= 1e-6)
+    h.close()
