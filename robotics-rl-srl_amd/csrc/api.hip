@@ -252,6 +252,7 @@ int srlhip_destroy(srlhip_handle hh) {
     for (void *p : h->allocs) (void)hipFree(p);
     void *st[] = {h->st_actions, h->st_noise, h->st_obs, h->st_rew, h->st_done, h->st_mask, h->st_rand};
     for (void *p : st) if (p) (void)hipFree(p);
+    for (void *p : h->act_plane) if (p) (void)hipFree(p);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
@@ -276,6 +277,7 @@ int srlhip_seed(srlhip_handle hh, const uint8_t *mask, const int64_t *seeds) {
     if (!hh || !seeds) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
+    h->prefetch_valid = false;                  // the action-stream counters restart
     return rc ? rc : seed_impl(h, mask, seeds);
 }
 

@@ -95,6 +95,13 @@ struct Handle {
     uint64_t *snap_ctr = nullptr;
     double *snap_ep_return = nullptr;
     int32_t *snap_ep_length = nullptr;
+    // synthetic-agent rollouts of the MobileRobot family: the [T][N] action plane of the NEXT rollout is drawn by spare workgroups
+    // of the current rollout's launch (mobile_rollout_ep_k), from the action-stream counters in the snapshot; two planes in turn
+    uint64_t *snap_actr = nullptr;
+    void *act_plane[2] = {nullptr, nullptr};
+    size_t act_plane_sz[2] = {0, 0};
+    bool prefetch_valid = false;
+    int prefetch_T = 0, prefetch_buf = 0;
     KukaState *kuka;
     std::vector<void *> allocs;      // everything hipMalloc'ed for this handle
     // staging buffers for io_device == 0

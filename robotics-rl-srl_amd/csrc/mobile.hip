@@ -241,16 +241,21 @@ __device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0
 }
 
 // All T x N synthetic actions of a rollout at once: thread (t, e) draws block act_ctr[e] + t of env e's action stream.
+// entry i = t * N + e of a [T][N] action plane whose first row is block base[e] + offset of env e's action stream
+__device__ __forceinline__ void sample_plane_entry(const MobileParams &p, const uint32_t *key, const uint64_t *base, uint64_t offset, int64_t i,
+                                                   void *__restrict__ act) {
+    const int e = (int)(i % p.n);
+    const int64_t t = i / p.n;
+    int a = 0; float a0 = 0.f, a1 = 0.f;
+    sample_action(p, key[e], key[p.n + e], base[e] + offset + (uint64_t)t, a, a0, a1);
+    if (p.is_discrete) static_cast<int32_t *>(act)[i] = a;
+    else static_cast<float2 *>(act)[i] = make_float2(a0, a1);
+}
 __global__ void __launch_bounds__(kBlock)
 mobile_sample_actions_k(MobileParams p, RngState rs, int T, void *__restrict__ act) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= (int64_t)T * p.n) return;
-    const int e = (int)(i % p.n);
-    const int64_t t = i / p.n;
-    int a = 0; float a0 = 0.f, a1 = 0.f;
-    sample_action(p, rs.key[e], rs.key[p.n + e], rs.act_ctr[e] + (uint64_t)t, a, a0, a1);
-    if (p.is_discrete) static_cast<int32_t *>(act)[i] = a;
-    else static_cast<float2 *>(act)[i] = make_float2(a0, a1);
+    sample_plane_entry(p, rs.key, rs.act_ctr, 0, i, act);
 }
 
 // One launch == T consecutive VecEnv steps; T == 1 with plain stores is the per-step entry point, T > 1 the fused
@@ -337,11 +342,16 @@ constexpr int kEpisodeSteps = 251;
 // overwrites its state: the segments therefore read this snapshot, taken by mobile_snapshot_k in stream order right
 // before the launch, and only write the live state.
 struct MobileSnap { MobileState s; const uint64_t *ctr; const double *ep_return; const int32_t *ep_length; };
+// The synthetic agent's NEXT action plane, drawn by the workgroups of a rollout launch beyond its segment lanes (the rollout itself
+// is a latency-bound recurrence on 10 x N lanes: the chip has room) so that the following rollout starts without a sampler launch:
+// block base[e] + T + t of env e's action stream (base = the counters in the snapshot: the live ones move when the rollout ends).
+struct NextPlane { void *act; const uint64_t *base; int ep_blocks; };
 
 __global__ void __launch_bounds__(kBlock)
-mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileState d, uint64_t *ctr, double *ep_return, int32_t *ep_length) {
+mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileState d, uint64_t *ctr, double *ep_return, int32_t *ep_length, uint64_t *actr) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= n) return;
+    actr[e] = rs.act_ctr[e];
     d.pos_x[e] = s.pos_x[e]; d.pos_y[e] = s.pos_y[e]; d.tgt_x[e] = s.tgt_x[e]; d.tgt_y[e] = s.tgt_y[e];
     d.tgt2_x[e] = s.tgt2_x[e]; d.tgt2_y[e] = s.tgt2_y[e]; d.counter[e] = s.counter[e]; d.cur_target[e] = s.cur_target[e];
     ctr[e] = rs.ctr[e]; ep_return[e] = st.ep_return[e]; ep_length[e] = st.ep_length[e];
@@ -351,11 +361,16 @@ template <int KIND, int DISC>
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
                     const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
-                    uint8_t *__restrict__ done_out, int advance_actr) {
+                    uint8_t *__restrict__ done_out, int advance_actr, NextPlane next, void *__restrict__ act_out) {
+    p.kind = KIND; p.is_discrete = DISC;                                   // compile-time constants from here on
+    if ((int)blockIdx.x >= next.ep_blocks) {                               // spare workgroups: the next rollout's action plane
+        const int64_t i = ((int64_t)blockIdx.x - next.ep_blocks) * kBlock + threadIdx.x;
+        if (i < (int64_t)T * p.n) sample_plane_entry(p, rs.key, next.base, (uint64_t)T, i, next.act);
+        return;
+    }
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(gid % p.n), j = (int)(gid / p.n);
     if (j >= smax) return;
-    p.kind = KIND; p.is_discrete = DISC;                                   // compile-time constants from here on
     const int c0 = snap.s.counter[e];
     const int L0 = c0 <= kEpisodeSteps - 1 ? kEpisodeSteps - c0 : 1;       // steps until the running episode ends
     const int t_lo = j == 0 ? 0 : L0 + kEpisodeSteps * (j - 1);
@@ -396,6 +411,10 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
                 const int64_t row = (int64_t)t * p.n + e;
                 const int a = p.is_discrete ? ai[k] : 0;
                 const float a0 = p.is_discrete ? 0.f : af[k].x, a1 = p.is_discrete ? 0.f : af[k].y;
+                if (act_out) {                                             // the plane is internal: hand the actions taken to the caller
+                    if (p.is_discrete) __builtin_nontemporal_store(a, static_cast<int32_t *>(act_out) + row);
+                    else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+                }
                 const double dv = 0.1 + rng.normal(0.0, 0.0);              // DELTA_POS + N(0, NOISE_STD = 0): draws nothing
                 double reward; bool done;
                 step_env<KIND, DISC>(p, m, a, a0, a1, dv, reward, done);
@@ -463,7 +482,8 @@ int mobile_alloc(Handle *h) {
         MobileState &d = h->mobile_snap;
         if ((rc = h->dalloc(&d.pos_x, n)) || (rc = h->dalloc(&d.pos_y, n)) || (rc = h->dalloc(&d.tgt_x, n)) || (rc = h->dalloc(&d.tgt_y, n)) ||
             (rc = h->dalloc(&d.tgt2_x, n)) || (rc = h->dalloc(&d.tgt2_y, n)) || (rc = h->dalloc(&d.counter, n)) || (rc = h->dalloc(&d.cur_target, n)) ||
-            (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)))
+            (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)) ||
+            (rc = h->dalloc(&h->snap_actr, n)))
             return rc;
     }
     return 0;
@@ -513,18 +533,23 @@ void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actio
 #undef SRL_GO
 }
 
+// next_plane: where the spare workgroups put the following rollout's actions (null: none); act_out: the caller's action plane
+// when `d_actions` is an internal one
 int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
-                      uint8_t *d_done, int advance_actr) {
+                      uint8_t *d_done, int advance_actr, void *next_plane, void *act_out) {
     hipLaunchKernelGGL(mobile_snapshot_k, dim3((h->n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->n, h->mobile, h->rng, h->stats,
-                       h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length);
+                       h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length, h->snap_actr);
     const MobileSnap snap{h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length};
     const int smax = 1 + (T - 1 + kEpisodeSteps - 1) / kEpisodeSteps;     // first segment of one step + whole episodes
     const int64_t lanes = (int64_t)smax * h->n;
-    dim3 grid((unsigned)((lanes + kBlock - 1) / kBlock)), block(kBlock);
+    const int ep_blocks = (int)((lanes + kBlock - 1) / kBlock);
+    const int64_t extra = next_plane ? ((int64_t)T * h->n + kBlock - 1) / kBlock : 0;
+    const NextPlane next{next_plane, h->snap_actr, ep_blocks};
+    dim3 grid((unsigned)(ep_blocks + extra)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
 #define SRL_GO(KIND, DISC)                                                                                              \
     hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
-                       draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr)
+                       draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr, next, act_out)
 #define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
     switch (p.kind) {
         case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
@@ -545,7 +570,39 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
     if (h->cfg.rng_mode != SRLHIP_RNG_PHILOX && h->cfg.rng_mode != SRLHIP_RNG_MT19937)
         return h->fail(SRLHIP_EINVAL, "rollout: needs a device RNG mode (PHILOX or MT19937)");
     int advance = 0;
+    const bool ep_path = h->cfg.rng_mode == SRLHIP_RNG_PHILOX && p.auto_reset && T >= 32;
+    if (!d_actions && ep_path && !getenv("SRLHIP_NO_ACTION_PREFETCH")) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(h->stream, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            // synthetic agent, episode-parallel rollout: two internal action planes in turn.  This rollout reads the plane the
+            // previous launch's spare workgroups filled (or fills one now), its own spare workgroups fill the other one.
+            const size_t bytes = (size_t)T * h->n * (p.is_discrete ? 4 : 8);
+            for (int b = 0; b < 2; b++)
+                if (h->act_plane_sz[b] < bytes) {
+                    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+                    if (h->act_plane[b]) (void)hipFree(h->act_plane[b]);
+                    h->act_plane[b] = nullptr; h->act_plane_sz[b] = 0; h->prefetch_valid = false;
+                    SRL_HIP_CHECK(h, hipMalloc(&h->act_plane[b], bytes));
+                    h->act_plane_sz[b] = bytes;
+                }
+            int cur = 0;
+            if (h->prefetch_valid && h->prefetch_T == T) cur = h->prefetch_buf;
+            else {
+                const int64_t total = (int64_t)T * h->n;
+                hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                                   p, h->rng, T, h->act_plane[0]);
+                SRL_HIP_CHECK(h, hipGetLastError());
+            }
+            int rc = launch_rollout_ep(h, p, T, h->act_plane[cur], d_obs, d_rew, d_done, 1, h->act_plane[cur ^ 1], d_act_out);
+            if (rc) return rc;
+            SRL_HIP_CHECK(h, hipGetLastError());
+            h->prefetch_valid = true; h->prefetch_T = T; h->prefetch_buf = cur ^ 1;
+            return 0;
+        }
+    }
     if (!d_actions) {
+        h->prefetch_valid = false;              // this rollout moves the action-stream counters past what was drawn ahead
         // synthetic agent: draw the whole [T][N] action plane in parallel, into the caller's plane when there is one
         const size_t bytes = (size_t)T * h->n * (p.is_discrete ? 4 : 8);
         void *plane = d_act_out;
@@ -566,7 +623,7 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
         advance = 1;
     }
     // counter-based streams + fixed-length episodes: segments of the rollout run in parallel (mobile_rollout_ep_k)
-    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX && p.auto_reset && T >= 32) { int rc = launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance); if (rc) return rc; }
+    if (ep_path) { int rc = launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance, nullptr, nullptr); if (rc) return rc; }
     else if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     else launch_rollout<SRLHIP_RNG_MT19937>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     SRL_HIP_CHECK(h, hipGetLastError());

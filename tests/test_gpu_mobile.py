@@ -289,3 +289,40 @@ def test_episode_parallel_rollout_beyond_resident_lanes(T):
     a.sync(); b.sync()
     assert torch.equal(planes[0][0][:40], planes[1][0][:40])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind,is_discrete", [(_lib.ENV_MOBILE, 1), (_lib.ENV_MOBILE, 0), (_lib.ENV_MOBILE_2TARGET, 1)])
+def test_synthetic_agent_action_plane_drawn_ahead(kind, is_discrete):
+    """Rollouts without caller actions: the NEXT rollout's action plane is drawn by spare workgroups of the current launch.  Same
+    planes, observations, rewards and dones as with the standalone sampler (SRLHIP_NO_ACTION_PREFETCH=1), also across a change of
+    T (the plane drawn ahead is dropped), a re-seed and a rollout with caller actions in between."""
+    n = 512
+
+    def run(prefetch):
+        if prefetch:
+            os.environ.pop("SRLHIP_NO_ACTION_PREFETCH", None)
+        else:
+            os.environ["SRLHIP_NO_ACTION_PREFETCH"] = "1"
+        try:
+            cfg = _lib.default_config(kind)
+            cfg.num_envs, cfg.seed0, cfg.rng_mode, cfg.is_discrete, cfg.random_target = n, 3, _lib.RNG_PHILOX, is_discrete, 1
+            h = _lib.Handle(cfg)
+            h.reset()
+            outs = [h.rollout(T) for T in (300, 300, 300, 100, 300)]
+            given = outs[0]["actions"][:64].copy()
+            outs.append(h.rollout(64, actions=given))                  # caller actions: the stream counters do not move
+            outs.append(h.rollout(300))
+            h.seed(np.arange(n, dtype=np.int64) + 77)
+            h.reset()
+            outs.append(h.rollout(300))
+            outs.append(h.rollout(300))
+            h.close()
+            return outs
+        finally:
+            os.environ.pop("SRLHIP_NO_ACTION_PREFETCH", None)
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for k in ("obs", "reward", "done", "actions"):
+            if k in x and x[k] is not None:
+                assert np.array_equal(x[k], y[k]), k
+    assert not np.array_equal(a[0]["actions"], a[1]["actions"])         # consecutive planes continue the stream
