@@ -23,6 +23,12 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WA
   timeout 400 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_k -o pmc -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 1 > /dev/null 2>&1
   python $R/profiles/summarize_pmc.py $(find /tmp/pmc_k -name "*counter_collection.csv" | head -1) $OUT/kuka_pmc_${tag}.csv
 done
+# MobileRobot: HBM traffic of the episode-parallel rollout (its spare workgroups now also write the next action plane)
+for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/pmc_m
+  timeout 300 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_m -o pmc -- python $R/bench.py --workload mobile --no-cpu-baseline --no-secondary --steps 4 --warmup 2 > /dev/null 2>&1
+  python $R/profiles/summarize_pmc.py $(find /tmp/pmc_m -name "*counter_collection.csv" | head -1) $OUT/mobile_pmc_${pmc}.csv
+done
 # the lumped-gripper model (rounds 1-2) on its kernels, for the before / after comparison
 timeout 300 python $R/bench.py --kuka-model lumped --no-cpu-baseline --no-secondary --steps 5 > $OUT/bench_kuka_lumped.json 2>/dev/null
 # N-sweep of the Kuka stepper (full model: the tree lane-group kernel at every size)
