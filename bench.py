@@ -91,9 +91,13 @@ def measured_traffic(kernel, env_steps_per_launch):
         files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_{}_pmc_{}.csv".format(wl, counter))))
         if not files:
             return None
-        for row in csv.DictReader(open(files[-1])):
-            if row["kernel"] in kernels and row["counter"] == counter:
-                out[counter] = out.get(counter, 0.0) + float(row["avg_per_dispatch"])
+        rows = [row for row in csv.DictReader(open(files[-1])) if row["kernel"] in kernels and row["counter"] == counter]
+        launches = [float(row["dispatches"]) for row in rows if row["kernel"] == kernel]
+        if not launches:
+            return None
+        # per launch of `kernel`: its own average plus the other kernels' totals spread over its launches (the standalone
+        # action sampler only runs when no plane was drawn ahead: once per bench run)
+        out[counter] = sum(float(row["sum"]) for row in rows) / launches[0]
     if len(out) != 2:
         return None
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
