@@ -51,6 +51,8 @@ def parse():
                     help="full = the 12-DoF arm + gripper tree of kuka_with_gripper2.sdf (library default); lumped = the rounds 1-2 approximation")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short BASELINE config 2 (mobile) and config 4 (kuka_pixels) runs nested under \"secondary\"")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="roofline.traffic / issue_util from the committed profiles/ summaries only (no rocprofv3 --pmc child passes)")
     return ap.parse_args()
 
 
@@ -74,6 +76,67 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+_LIVE_PMC = {}      # workload -> {kernel: {counter: (sum, dispatches)}} measured by child passes of this run
+
+
+def live_pmc(args, workload):
+    """HBM traffic and instruction counters of THIS run's kernels: the same command (short: 1 warm-up + 2 steps) re-run as child
+    processes under `rocprofv3 --pmc`, one pass per counter set and no tracing options (MI355X_MICROARCH.md, HBM / rocprofv3
+    section), aggregated per kernel like profiles/summarize_pmc.py.  Rank 0 of an N = 1 run only; None (-> the committed
+    summaries) when rocprofv3 is missing, a pass fails, or we ARE such a child."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if workload in _LIVE_PMC:
+        return _LIVE_PMC[workload]
+    _LIVE_PMC[workload] = None
+    if args.no_live_pmc or os.environ.get("SRLHIP_BENCH_CHILD") or shutil.which("rocprofv3") is None:
+        return None
+    sets = ["FETCH_SIZE", "WRITE_SIZE"] + (["SQ_WAVES SQ_INSTS_VALU"] if workload == "kuka" else [])
+    agg = {}
+    env = dict(os.environ, SRLHIP_BENCH_CHILD="1", TMPDIR="/tmp")
+    try:
+        for pmc in sets:
+            out = tempfile.mkdtemp(prefix="srlhip_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc"] + pmc.split() + ["--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", workload, "--no-cpu-baseline", "--no-secondary", "--steps", "2", "--warmup", "1",
+                   "--envs-per-gpu", str(args.envs_per_gpu), "--rng", args.rng, "--kuka-model", args.kuka_model]
+            if args.inner_steps is not None:
+                cmd += ["--inner-steps", str(args.inner_steps)]
+            rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240).returncode
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if rc != 0 or not found:
+                shutil.rmtree(out, ignore_errors=True)
+                return None
+            disp = {}
+            for r in csv.DictReader(open(found[0])):
+                m = re.search(r"(\w+_k)\b", r["Kernel_Name"])
+                name = m.group(1) if m else r["Kernel_Name"].split("<")[0].split("(")[0][-40:]
+                k = agg.setdefault(name, {})
+                k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                disp.setdefault((name, r["Counter_Name"]), set()).add(r["Dispatch_Id"])
+            for (name, c), ids in disp.items():
+                agg[name][c] = (agg[name][c], len(ids))
+            shutil.rmtree(out, ignore_errors=True)
+    except Exception:
+        return None
+    _LIVE_PMC[workload] = agg
+    return agg
+
+
+def live_traffic(args, workload, kernel):
+    """bytes per launch of `kernel` from this run's child PMC passes (helper kernels spread over its launches), or None"""
+    agg = live_pmc(args, workload)
+    if not agg or kernel not in agg or "FETCH_SIZE" not in agg[kernel] or "WRITE_SIZE" not in agg[kernel]:
+        return None
+    kernels = [kernel] + (["mobile_sample_actions_k"] if workload == "mobile" else [])
+    launches = agg[kernel]["FETCH_SIZE"][1]
+    tot = {c: sum(agg[k][c][0] for k in kernels if k in agg and c in agg[k]) / launches for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 
 
 def measured_traffic(kernel, env_steps_per_launch):
@@ -357,8 +420,11 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     avg_launch_s = kernel_ms * 1e-3 / K
     achieved_gbs = ALG_BYTES[workload] * steps_per_launch / avg_launch_s / 1e9
     kernel = "mobile_rollout_ep_k" if workload == "mobile" else {"tree": "kuka_tree_rollout_k", "group": "kuka_group_rollout_k", "lane": "kuka_rollout_k"}[h.kuka_kernel()]
-    traffic = None
-    if n == 4096 and inner == 2048:       # geometry the PMC passes were taken at
+    traffic, traffic_live = None, False
+    if world == 1 and rank == 0:
+        traffic = live_traffic(args, workload, kernel)          # re-measured now: child passes under rocprofv3 --pmc
+        traffic_live = traffic is not None
+    if traffic is None and n == 4096 and inner == 2048:       # geometry the committed PMC passes were taken at
         traffic = measured_traffic(kernel, steps_per_launch)
     if workload == "mobile":
         roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -390,12 +456,25 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
                     if group else "1 lane per env: {} wavefronts".format((n + 63) // 64),
                     "note": "FP64-VALU issue / dependency-latency bound, not HBM bound (SURVEY 7 hard parts); hbm_frac is "
                             "reported because the north star asks for it"}
-        if n == 4096 and inner == 2048:
+        util = None
+        agg = live_pmc(args, workload) if (world == 1 and rank == 0) else None
+        if agg and kernel in agg and "SQ_INSTS_VALU" in agg[kernel] and "SQ_WAVES" in agg[kernel]:
+            # wavefronts per launch from the launch geometry (SQ_WAVES is reported beside it: the counter has been seen to absorb
+            # the previous dispatch's wavefronts once in a while)
+            waves = float((n + 3) // 4 if group else (n + 63) // 64)
+            per_wave = agg[kernel]["SQ_INSTS_VALU"][0] / agg[kernel]["SQ_INSTS_VALU"][1] / waves
+            util = {"valu_insts_per_wavefront": per_wave, "waves_per_dispatch": waves,
+                    "sq_waves_per_dispatch": agg[kernel]["SQ_WAVES"][0] / agg[kernel]["SQ_WAVES"][1],
+                    "issue_util": per_wave * 4.0 / (avg_launch_s * 2.4e9), "source": "rocprofv3 --pmc child pass of this run"}
+        elif n == 4096 and inner == 2048:
             util = pmc_issue_util(kernel, avg_launch_s)
-            if util:
-                roofline.update(util)
+        if util:
+            roofline.update(util)
     if traffic is not None:
-        roofline["traffic_source"] = ("profiles/ PMC summaries of this command (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per "
+        roofline["traffic_source"] = ("measured in this run: the same command re-run as child processes under rocprofv3 --pmc "
+                                      "(separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
+                                      if traffic_live else
+                                      "profiles/ PMC summaries of this command (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per "
                                       "launch; committed, not re-measured in this run")
     line = {
         "metric": "env steps/sec (whole node), {} {} envs/GPU".format(
@@ -463,7 +542,11 @@ def main():
             try:
                 args.inner_steps = None
                 if name == "mobile":
-                    sub = bench_stepper(args, "mobile", rank, local_rank, world, dev, K=20, W=5)
+                    # (a rollout of this family lasts 0.1 ms: 300 of them, so that the GPU clocks are up and the timed region is not
+                    #  2 ms; the headline's CPU baseline has just torn down 256 worker processes and a 256-thread OpenMP team: give
+                    #  the host two seconds, this leg issues a launch every 50 us)
+                    time.sleep(2.0)
+                    sub = bench_stepper(args, "mobile", rank, local_rank, world, dev, K=200, W=100)
                 else:
                     sub = bench_pixels(args, rank, local_rank, world, dev, K=4, W=1, phys_baseline=line.get("cpu_baseline"))
                 sec[name] = {k: sub[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline",
