@@ -43,7 +43,8 @@ static int g_trace_n = 0;
 /* Sensitivity probe (profiles/probes/kuka_bullet_detail_sensitivity.py), NOT part of the parity definition: variants of solver
  * details of Bullet's btMultiBodyConstraintSolver that are recalled, not read (the source is absent here).  bit 0: the non-contact
  * rows are swept backwards on even iterations (`iteration & 1 ? j : size - 1 - j`); bit 1: non-contact rows in body-creation
- * order (button loaded before the arm, kuka_button_gym_env.py:233-238; per body: joint-limit rows, then its motors). */
+ * order (button loaded before the arm, kuka_button_gym_env.py:233-238; per body: joint-limit rows, then its motors); bit 2: a second
+ * friction row per contact along n x t1 (SOLVER_USE_2_FRICTION_DIRECTIONS), each row boxed by mu * normal impulse. */
 static int g_detail = 0;
 void kuka_oracle_set_detail(int mask) { g_detail = mask; }
 #pragma omp threadprivate(g_trace_ee, g_trace_jt, g_trace_n)
@@ -500,6 +501,14 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                         fr[nfr].Jb = is_cap ? -tdir[2] : 0.0;
                         fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
                         nfr++;
+                        if (g_detail & 4) {
+                            double t2[3];
+                            t2[0] = nrm[1] * tdir[2] - nrm[2] * tdir[1]; t2[1] = nrm[2] * tdir[0] - nrm[0] * tdir[2]; t2[2] = nrm[0] * tdir[1] - nrm[1] * tdir[0];
+                            for (i = 0; i < n; i++) fr[nfr].J[i] = t2[0] * Jv[0][i] + t2[1] * Jv[1][i] + t2[2] * Jv[2][i];
+                            fr[nfr].Jb = is_cap ? -t2[2] : 0.0;
+                            fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
+                            nfr++;
+                        }
                     }
                 }
             }
