@@ -536,8 +536,8 @@ int srlhip_set_kuka_tree_model(srlhip_handle hh, const srlhip_kuka_tree_model *m
     if (is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: not a Kuka handle");
     if (h->cfg.kuka_model != SRLHIP_KUKA_MODEL_FULL) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: the handle was created with the lumped model");
     const int nd = (int)m->nd, ns = (int)m->nsphere;
-    if (nd != 12 || ns < 0 || ns > 16 || (int)m->max_generic_rows < 0 || (int)m->ee_link != 6 || (int)m->grip_link < 0 || (int)m->grip_link >= nd)
-        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: 12 DoFs, <= 16 spheres, end effector = link 6");
+    if (nd != 12 || ns < 0 || ns > 16 || (int)m->max_generic_rows < 0 || (int)m->max_generic_rows > 6 || (int)m->ee_link != 6 || (int)m->grip_link < 0 || (int)m->grip_link >= nd)
+        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: 12 DoFs, <= 16 spheres, end effector = link 6, max_generic_rows <= 6 (the lane group's row bank)");
     for (int i = 0; i < nd; i++) {
         const srlhip_kuka_tree_joint &J = m->j[i];
         const double a2 = J.axis[0] * J.axis[0] + J.axis[1] * J.axis[1] + J.axis[2] * J.axis[2];
@@ -586,6 +586,7 @@ int srlhip_graph_begin(srlhip_handle hh) {
     if (!h->cfg.io_device) return h->fail(SRLHIP_EINVAL, "graph capture needs io_device = 1 (host-pointer calls synchronise)");
     int rc = set_device(h);
     if (rc) return rc;
+    h->prefetch_valid = false;             // a captured synthetic-agent rollout moves the action-stream counters on the device at every replay
     SRL_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     return 0;
 }
@@ -612,6 +613,7 @@ int srlhip_graph_end(srlhip_handle hh, srlhip_graph_handle *out) {
 int srlhip_graph_launch(srlhip_handle hh, srlhip_graph_handle g) {
     if (!hh || !g) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
+    h->prefetch_valid = false;             // (see srlhip_graph_begin: the action plane drawn ahead belongs to counters the replay has consumed)
     SRL_HIP_CHECK(h, hipGraphLaunch(g->exec, h->stream));
     return 0;
 }

@@ -428,8 +428,11 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_BUTTON2_XY: *dptr = s->d + D_B2X * n; *count = 2; return 0;
         case SRLHIP_F_KUKA_GOAL: *dptr = s->i + I_GOAL * n; *elem = 4; *count = 2; return 0;
         case SRLHIP_F_KUKA_OBJECTS: *dptr = s->objs; *count = 30; return 0;
-        case SRLHIP_F_KUKA_GRIPPER_Q: *dptr = s->d + D_GQ * n; *count = 5; return 0;
-        case SRLHIP_F_KUKA_GRIPPER_QD: *dptr = s->d + D_GQD * n; *count = 5; return 0;
+        case SRLHIP_F_KUKA_GRIPPER_Q:
+        case SRLHIP_F_KUKA_GRIPPER_QD:
+            // the lumped model has no gripper DoFs: its kernels never write these planes
+            if (!s->full) return h->fail(SRLHIP_EINVAL, "KUKA_GRIPPER_Q / KUKA_GRIPPER_QD exist on full-model handles only (cfg.kuka_model = SRLHIP_KUKA_MODEL_FULL)");
+            *dptr = s->d + (field == SRLHIP_F_KUKA_GRIPPER_Q ? D_GQ : D_GQD) * n; *count = 5; return 0;
     }
     return h->fail(SRLHIP_EINVAL, "unknown field for KukaButtonGymEnv");
 }

@@ -168,13 +168,18 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     LaneId L; build_lane_table(L, s.ttable, tab);
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
+    // A masked-out env (and the shadow rows of a tail group) must not draw: GroupMt's twist() rewrites the env's 624 state words in
+    // HBM in place while its index is only stored by the lead lane of a VALID env — a masked draw across a twist boundary would
+    // leave the running env with a regenerated block and a stale index.  `valid` is uniform over the 16-lane row, and every
+    // cross-lane operation of the reset is row-local (the rollout kernel already runs tenv_reset under row divergence).
+    if (!valid) return;
     Rng rng0;
     if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
     else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
     else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
     Env v = {};
     GState g;
-    double *objs = valid ? s.objs + e : nullptr;
+    double *objs = s.objs + e;
     tree::tenv_reset<JOINTS ? 1 : 0, NB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n);
     tstore(s, n, e, L, v, g, valid, NB == 2);
     if (lead) {

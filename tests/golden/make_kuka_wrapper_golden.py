@@ -12,6 +12,11 @@ What this pins (everything the reference itself computes on the Kuka path):
   * the motor-command list of joint-space mode (kuka.py:160-163);
   * _reward / _termination bookkeeping (n_contacts, n_steps_outside, terminated,
     shaped rewards) on scripted gripper positions and contact flags.
+  * EVERY p.setJointMotorControl2 call with all of its arguments (round 4: the `motorlog|...` arrays): the 14 position motors
+    of Kuka.reset() (kuka.py:69-71), the seven arm motors + five gripper / tip motors of every applyAction (kuka.py:167-187)
+    and the button motor of step2 (kuka_button_gym_env.py:347), as rows
+        [body, joint, controlMode, targetPosition, targetVelocity, force, maxVelocity, positionGain, velocityGain]
+    with NaN where the reference does not pass the argument (pybullet then uses its own default).
 What it cannot pin: the physics inside pybullet (IK solution, dynamics, contacts).
 
 Run in the build container only:  python tests/golden/make_kuka_wrapper_golden.py
@@ -40,6 +45,7 @@ class Script(object):
         self.ik_targets = []
         self.motor_targets = []
         self.button_motor_calls = 0
+        self.motor_log = None            # a list: every setJointMotorControl2 call is appended as a 9-vector
 
     def idx(self):
         return max(self.n_sim - 1, 0)
@@ -79,6 +85,14 @@ def make_scripted_pybullet():
     def setJointMotorControl2(*a, **k):
         body = k.get("bodyUniqueId", a[0] if a else None)
         joint = k.get("jointIndex", a[1] if len(a) > 1 else None)
+        if SCRIPT.motor_log is not None:
+            mode = k.get("controlMode", a[2] if len(a) > 2 else np.nan)
+            known = {"bodyUniqueId", "jointIndex", "controlMode", "targetPosition", "targetVelocity", "force", "maxVelocity",
+                     "positionGain", "velocityGain"}
+            assert set(k) <= known and len(a) <= 3, (a, k)      # nothing the log would drop
+            SCRIPT.motor_log.append([float(body), float(joint), float(mode)] +
+                                    [float(k.get(name, np.nan)) for name in ("targetPosition", "targetVelocity", "force", "maxVelocity",
+                                                                             "positionGain", "velocityGain")])
         if body == BUTTON:
             SCRIPT.button_motor_calls += 1
         elif body == KUKA and joint is not None and joint <= 6 and "maxVelocity" in k:
@@ -221,8 +235,41 @@ def moving_case(seed, shape_reward, random_target):
     return out
 
 
+def motorlog_case(mode):
+    """Every setJointMotorControl2 call of one reset() and of two step() calls, all arguments (module docstring)."""
+    kw = dict(srl_model="ground_truth")
+    if mode == "discrete":
+        kw["is_discrete"] = True
+    elif mode == "continuous":
+        kw["is_discrete"] = False
+    else:
+        kw.update(is_discrete=False, action_joints=True)
+    env = KukaButtonGymEnv(**kw)
+    env.seed(0)
+    SCRIPT.reset(None, None, None)
+    SCRIPT.motor_log = []
+    env.reset()
+    log_reset = np.array(SCRIPT.motor_log)
+    n_reset_sim = SCRIPT.n_sim
+    out = {"reset": log_reset, "n_reset_sim": n_reset_sim}
+    for t in range(2):
+        SCRIPT.motor_log = []
+        if mode == "discrete":
+            env.step(t + 2)
+        elif mode == "continuous":
+            env.step(np.array([0.25, -0.5, 0.75], dtype=np.float32).astype(np.float64))
+        else:
+            env.step(np.linspace(-1, 1, 7).astype(np.float32))
+        out["step{}".format(t)] = np.array(SCRIPT.motor_log)
+    SCRIPT.motor_log = None
+    return out
+
+
 def main():
     out = {}
+    for mode in ("discrete", "continuous", "joints"):
+        for k, v in motorlog_case(mode).items():
+            out["motorlog|{}|{}".format(mode, k)] = v
     for seed in (0, 1, 2, 3):
         for shape_reward in (False, True):
             tag = "mov|s{}|sr{}|rt{}".format(seed, int(shape_reward), seed % 2)

@@ -151,6 +151,30 @@ def test_host_rng_mode_no_auto_reset():
     h.close()
 
 
+def test_masked_resets_under_mt19937_do_not_touch_running_streams():
+    """environments/dataset_generator.py's pattern (rng_mode MT19937, auto_reset off, srlhip_reset(mask) for the finished envs) over
+    enough steps that every env's generator twists at least twice: a masked-out env must neither draw nor regenerate its state block
+    (round-3 advisor finding: kuka_tree_reset_k used to run the reset draws of masked-out rows, and GroupMt's in-place twist then left
+    a running env with a fresh block and a stale index)."""
+    n, T = 37, 900                      # ragged: the last wavefront carries shadow rows too
+    actions = np.random.RandomState(21).randint(6, size=(T, n)).astype(np.int32)
+    actions[np.random.RandomState(22).rand(T, n) < 0.3] = 4
+    h = make(n, auto_reset=0, seed0=700)
+    obs = h.reset()
+    ora = kuka_clib.rollout(700 + np.arange(n), T, actions=actions)
+    assert np.abs(obs - ora["obs0"]).max() <= TOL
+    n_masked = 0
+    for t in range(T):
+        o, r_, d = h.step(actions[t])
+        assert np.array_equal(d, ora["done"][t]) and np.array_equal(r_, ora["reward"][t]), t
+        if d.any():
+            n_masked += 1
+            o = h.reset(mask=d, obs_out=o.copy())
+        assert np.abs(o - ora["obs"][t]).max() <= TOL, t
+    assert n_masked >= 20 and ora["ep_stats"][:, 2].min() >= 1
+    h.close()
+
+
 def test_sharding_invariance():
     n, T = 256, 300
     actions = np.random.RandomState(13).randint(6, size=(T, n)).astype(np.int32)
