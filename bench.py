@@ -256,7 +256,9 @@ def bench_pixels(args, rank, local_rank, world, dev, K=None, W=None, cpu=True, p
     for _ in range(K):
         one_step()
     fence()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, device=dev)
+    dt_own = time.perf_counter() - t0
+    dt_ranks = sharding.per_rank(dt_own, device=dev)
+    dt = sharding.max_over_ranks(dt_own, device=dev)
     # per-kernel shares, each timed alone with HIP events on the stepper's own stream (the stream all three run on)
     env.h.sync()
     reps = 50
@@ -313,6 +315,8 @@ def bench_pixels(args, rank, local_rank, world, dev, K=None, W=None, cpu=True, p
                                      "stepper_and_launch_gaps": step_ms - raster_ms - (enc_ms or 0.0)},
                        "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
             "roofline": roofline}
+    if world > 1:      # stragglers: every rank's own time for the K steps (value uses the maximum)
+        line["config"]["ms_per_step_ranks"] = {"min": min(dt_ranks) * 1e3 / K, "max": max(dt_ranks) * 1e3 / K, "all": [x * 1e3 / K for x in dt_ranks]}
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline and S == 64:
         try:
             line["cpu_baseline"] = pixel_cpu_baseline(enc, env, phys=phys_baseline)
@@ -323,7 +327,7 @@ def bench_pixels(args, rank, local_rank, world, dev, K=None, W=None, cpu=True, p
     return line
 
 
-def pmc_issue_util(kernel, avg_launch_s, clock_hz=2.4e9):
+def pmc_issue_util(kernel, avg_launch_s, clock_hz=2.35e9):      # (the PMC pass's GRBM_GUI_ACTIVE says 2.35 GHz under this load)
     """VALU issue utilisation of `kernel`: instructions per wavefront (newest committed PMC summary, SQ_INSTS_VALU / SQ_WAVES)
     x 4 cycles per wave64 float64 instruction / cycles of one launch (live duration x 2.4 GHz).  None without a summary."""
     import csv
@@ -412,6 +416,7 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     kernel_ms = h.timing_end()          # HIP events on the stepper's own stream
     fence()
     dt = time.perf_counter() - t0
+    dt_ranks = sharding.per_rank(dt, device=dev)
     dt = sharding.max_over_ranks(dt, device=dev)
 
     total_env_steps = world * n * inner * K
@@ -465,7 +470,7 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
             per_wave = agg[kernel]["SQ_INSTS_VALU"][0] / agg[kernel]["SQ_INSTS_VALU"][1] / waves
             util = {"valu_insts_per_wavefront": per_wave, "waves_per_dispatch": waves,
                     "sq_waves_per_dispatch": agg[kernel]["SQ_WAVES"][0] / agg[kernel]["SQ_WAVES"][1],
-                    "issue_util": per_wave * 4.0 / (avg_launch_s * 2.4e9), "source": "rocprofv3 --pmc child pass of this run"}
+                    "issue_util": per_wave * 4.0 / (avg_launch_s * 2.35e9), "source": "rocprofv3 --pmc child pass of this run"}
         elif n == 4096 and inner == 2048:
             util = pmc_issue_util(kernel, avg_launch_s)
         if util:
@@ -497,6 +502,8 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
                                             "(gripper welded to link 7, 7 DoF) is `--kuka-model lumped`")
     if world > 1:
         torch.cuda.synchronize()
+        # stragglers: every rank's own time for the K steps (value uses the maximum)
+        line["config"]["ms_per_step_ranks"] = {"min": min(dt_ranks) * 1e3 / K, "max": max(dt_ranks) * 1e3 / K, "all": [x * 1e3 / K for x in dt_ranks]}
         line["config"]["episode_returns_allgathered"] = {"count": int(gathered.numel()), "mean": float(gathered.mean().item()),
                                                          "collective": "all_gather_into_tensor float32[{}] per rank, once per rollout ({})".format(n, backend)}
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:

@@ -253,13 +253,14 @@ int srlhip_kuka_default_model(srlhip_kuka_model *m);
 int srlhip_set_kuka_model(srlhip_handle h, const srlhip_kuka_model *m);
 
 /* The full model as data (SRLHIP_KUKA_MODEL_FULL): a kinematic tree of up to 12 revolute DoFs, parents before children.
- * Integer-valued fields are stored as doubles so that the struct is a flat table of 506 doubles.  Per DoF: parent (-1 = the fixed
+ * Integer-valued fields are stored as doubles so that the struct is a flat table of 510 doubles.  Per DoF: parent (-1 = the fixed
  * base at kuka.py:63's pose), joint frame in the parent link (origin, fixed rotation Rj row-major: child = Rj * Rot(axis, q)),
  * unit axis in the joint frame, limits (lower > upper = none), damping, link mass / centre of mass / inertia about it in link axes
  * (xx xy xz yy yz zz; fixed-joint children are merged in exactly), the joint's POSITION_CONTROL motor (positionGain, force,
  * maxVelocity; velocityGain is 1), the pybullet joint index.  Then the IK end-effector link / point (kuka_end_effector_index 6),
  * the getArmPos() link / point (kuka_gripper_index 8: its COM), up to 16 collision spheres (link, centre, radius, combined lateral
- * friction), table / button-base heights, the per-step budget of limit + contact-normal rows (<= 8) and the friction switch.
+ * friction), table / button-base heights, the per-step budget of limit + contact-normal rows (<= 6: the lane group's second row bank; values above are rejected) and the
+ * friction switch, then the SOLVER DETAILS below.
  * The arm part is in-tree or pinned elsewhere (srlhip_kuka_model); the gripper part is RECALLED from kuka_with_gripper2.sdf
  * [UNVERIFIED-MEMORY] — tests/golden/make_kuka_pybullet_golden.py overwrites it from pybullet_data when PyBullet is importable. */
 typedef struct srlhip_kuka_tree_joint {
@@ -272,7 +273,19 @@ typedef struct srlhip_kuka_tree_model {
     double ee_link, ee_point[3], grip_link, grip_point[3], nsphere;
     srlhip_kuka_tree_sphere s[16];
     double table_top_z, button_base_z, max_generic_rows, friction;
+    /* Details of the dependency's constraint solver (Bullet 2.87 btMultiBodyConstraintSolver as driven by pybullet 1.8.6:
+     * kuka_button_gym_env.py:219-220 sets 150 iterations, :351 steps it) that this repo RECALLS and cannot read — kept as data so
+     * that the day a PyBullet fixture exists, matching it is a choice of table values (tests/golden/fit_kuka_pin.py searches them on
+     * the oracle), not a kernel change.  Defaults (0, 0.2, 0.2, 0) = the behaviour of rounds 1-3.
+     *   solver_detail   bit mask of SRLHIP_KUKA_DETAIL_*
+     *   contact_erp     error reduction of penetrating contact rows (Bullet m_erp2; pybullet's server is recalled to use 0.08)
+     *   limit_erp       the same for joint-limit rows, the button's two stops included (Bullet m_erp)
+     *   linear_slop     a contact row sees penetration = distance + linear_slop (Bullet m_linearSlop; recalled server value 1e-5) */
+    double solver_detail, contact_erp, limit_erp, linear_slop;
 } srlhip_kuka_tree_model;
+#define SRLHIP_KUKA_DETAIL_ALT_SWEEP  1  /* the non-contact rows (motors, limits, button rows) are swept backwards on even iterations */
+#define SRLHIP_KUKA_DETAIL_BODY_ORDER 2  /* non-contact rows in body-creation order: button (stops, motor) before the arm (limits, motors) */
+#define SRLHIP_KUKA_DETAIL_FRICTION2  4  /* second friction row per contact along n x t1; the row budget becomes min(max_generic_rows, 4) */
 int srlhip_kuka_tree_default_model(srlhip_kuka_tree_model *m);                   /* host only, no GPU needed */
 /* Install a table on a SRLHIP_KUKA_MODEL_FULL handle: settled state and start-state table are re-integrated; reset afterwards. */
 int srlhip_set_kuka_tree_model(srlhip_handle h, const srlhip_kuka_tree_model *m);

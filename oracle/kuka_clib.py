@@ -101,6 +101,19 @@ def set_tree_model(table):
     clib.lib().kuka_oracle_set_tree_model(_p(t))
 
 
+def margins_reset():
+    """Start a new flag-margin record (oracle/kuka_oracle.c: margin probe); rollout() calls accumulate into it."""
+    clib.lib().kuka_oracle_margins_reset()
+
+
+def margins():
+    """{"contact_button", "contact_table", "max_distance", "any_contact"}: the smallest |value - threshold| the quantities behind the
+    discrete reward / done outputs reached in the rollouts since margins_reset()."""
+    out = np.zeros(4)
+    clib.lib().kuka_oracle_margins_get(_p(out))
+    return dict(zip(("contact_button", "contact_table", "max_distance", "any_contact"), out))
+
+
 def _pad(x):
     x = np.asarray(x, dtype=np.float64).reshape(-1)
     out = np.zeros(12)

@@ -35,18 +35,14 @@
 
 #define N KM_NDOF              /* arm joints (the IK / command surface) */
 #define MAX_ROWS 40
-#define MAX_GENERIC_ROWS 6   /* arm-limit + contact rows kept per step, first come first kept (solver row budget) */
 
 /* optional trace of the commands handed to the arm (wrapper pinning tests) */
 static double *g_trace_ee = NULL, *g_trace_jt = NULL;
 static int g_trace_n = 0;
-/* Sensitivity probe (profiles/probes/kuka_bullet_detail_sensitivity.py), NOT part of the parity definition: variants of solver
- * details of Bullet's btMultiBodyConstraintSolver that are recalled, not read (the source is absent here).  bit 0: the non-contact
- * rows are swept backwards on even iterations (`iteration & 1 ? j : size - 1 - j`); bit 1: non-contact rows in body-creation
- * order (button loaded before the arm, kuka_button_gym_env.py:233-238; per body: joint-limit rows, then its motors); bit 2: a second
- * friction row per contact along n x t1 (SOLVER_USE_2_FRICTION_DIRECTIONS), each row boxed by mu * normal impulse. */
-static int g_detail = 0;
-void kuka_oracle_set_detail(int mask) { g_detail = mask; }
+/* Solver details of Bullet's btMultiBodyConstraintSolver that are recalled, not read (the source is absent here): they live in the
+ * model table (kuka_tree_model.h: solver_detail bits, contact_erp, limit_erp, linear_slop) so that the PyBullet pin can decide them
+ * as DATA; the product's tree kernel takes the same table.  kuka_oracle_set_detail() edits the bit mask of the table in use (a
+ * kuka_oracle_set_full() / set_model() call rebuilds the table and clears it). */
 #pragma omp threadprivate(g_trace_ee, g_trace_jt, g_trace_n)
 
 /* ------------------------------------------------------------------ small algebra */
@@ -103,6 +99,8 @@ static void inertia_refresh(void);
 static void model_refresh(void) { if (g_full) tm_build_full(&g_m); else tm_build_lumped(&g_m); g_m_ready = 1; inertia_refresh(); }
 static const tree_model *model(void) { if (!g_m_ready) model_refresh(); return &g_m; }
 #define ND (model()->nd)
+void kuka_oracle_set_detail(int mask) { (void)model(); g_m.solver_detail = mask; }
+int kuka_oracle_get_detail(void) { return model()->solver_detail; }
 
 /* ------------------------------------------------------------------ kinematics */
 /* rotation about a unit axis (Rodrigues) */
@@ -392,13 +390,29 @@ static void plane_space1(const double n[3], double p[3]) {
 /* optional per-step probe of the last physics step (tests / the model-gap report): contact rows created, friction rows */
 static int g_probe_rows[4];
 #pragma omp threadprivate(g_probe_rows)
+/* Flag-margin probe: how close the quantities behind the DISCRETE outputs came to their thresholds over a rollout —
+ * [0] min |d(sphere, cap of button 0) - threshold| (contact_button), [1] min |sphere-table gap - threshold| (contact_table),
+ * [2] min |distance(gripper, target) - max_distance| (the -1 reward / n_outside counter), [3] min |d(any button shape) - threshold|
+ * (contact_body / row creation).  The HIP stepper's values differ from these by ~1e-11 (different association of the same sums),
+ * so its flags can only differ where a margin is that small: tests assert the margins of the runs they compare. */
+static double t_margin[4] = {1e30, 1e30, 1e30, 1e30}, g_margin[4] = {1e30, 1e30, 1e30, 1e30};
+#pragma omp threadprivate(t_margin)
+static void margin_note(int k, double v) { v = fabs(v); if (v < t_margin[k]) t_margin[k] = v; }
+static void margin_merge(void) {
+    int k;
+#pragma omp critical(kuka_margin)
+    for (k = 0; k < 4; k++) { if (t_margin[k] < g_margin[k]) g_margin[k] = t_margin[k]; }
+    for (k = 0; k < 4; k++) t_margin[k] = 1e30;
+}
+void kuka_oracle_margins_reset(void) { int k; for (k = 0; k < 4; k++) g_margin[k] = 1e30; }
+void kuka_oracle_margins_get(double *out4) { memcpy(out4, g_margin, sizeof g_margin); }
 
 /* Kuka.applyAction (kuka.py:118-187) followed by p.stepSimulation() */
 static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets) {
     const tree_model *m = model(); const int n = m->nd;
     mat3 R[TN]; double p[TN][3], q_arm[N], q_des[TN], tau[TN] = {0}, qdd[TN], W[TN][TN], dv[TN], dvb[2] = {0.0, 0.0};
     const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
-    const int nb = cfg->two ? 2 : 1;
+    const int nb = cfg->two ? 2 : 1, budget = tm_row_budget(m);
     row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s, b;
     /* Kuka(small_constraints=False) for random_target and always for Kuka2Button (kuka_2button_gym_env.py:78) */
     const double (*box)[3] = KM_EE_BOX[(cfg->random_target || cfg->two) ? 0 : 1];
@@ -460,37 +474,41 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         for (i = 0; i < n; i++) {
             double J[TN] = {0}, pen_lo = e->q[i] - m->lower[i], pen_hi = m->upper[i] - e->q[i];
             if (m->lower[i] > m->upper[i]) continue;                /* no limit on this joint */
-            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; g_probe_rows[2]++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
-            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < m->max_generic_rows) { ngeneric++; g_probe_rows[2]++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_lo <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < budget) { ngeneric++; g_probe_rows[2]++; J[i] = 1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * m->limit_erp / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
+            if (pen_hi <= KM_LIMIT_ACTIVATION_VEL * dt && ngeneric < budget) { ngeneric++; g_probe_rows[2]++; J[i] = -1.0; add_row(rows, &nrows, J, 0.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * m->limit_erp / dt, e->qd, 0.0, 0.0, KM_LIMIT_MAX_IMPULSE, 0); }
         }
         for (b = 0; b < nb; b++) {
           double pen_lo = *bq[b] - KM_GLIDER_LOWER, pen_hi = KM_GLIDER_UPPER - *bq[b];
-          add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b);
-          add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * KM_ERP / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b); }
+          add_row(rows, &nrows, zeroJ, 1.0, W, Wb, pen_lo > 0 ? -pen_lo / dt : 0.0, pen_lo > 0 ? 0.0 : -pen_lo * m->limit_erp / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b);
+          add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * m->limit_erp / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b); }
         {
             /* contact normals first; the friction rows are appended after ALL normals (Bullet solves normals, then frictions) */
             struct { double J[TN], Jb, mu; int normal_row, bsel; } fr[MAX_ROWS]; int nfr = 0;
             for (s = 0; s < m->nsphere; s++) {                      /* spheres on the arm / gripper links vs cap, base (of every button), table */
                 double c[3], nrm[3], dist, pt[3], Jv[3][TN], Jw[3][TN], J[TN]; int shape; const int link = m->sphere_link[s];
                 link_point(R, p, link, m->sphere[s], c);
+                margin_note(1, c[2] - m->sphere[s][3] - m->table_top_z - KM_CONTACT_THRESHOLD);
                 if (c[2] - m->sphere[s][3] - m->table_top_z < KM_CONTACT_THRESHOLD) e->contact_table = 1;
                 for (shape = 0; shape < 2 * nb; shape++) {
-                    double pos_err_vel, allow, cap_z0; const int is_cap = (shape & 1) == 0;
+                    double pos_err_vel, allow, cap_z0, pen; const int is_cap = (shape & 1) == 0;
                     b = shape >> 1;
                     cap_z0 = e->button_z + KM_GLIDER_ORIGIN_Z + *bq[b];
                     if (is_cap) dist = sphere_cylinder(c, m->sphere[s][3], bxy[b], KM_CAP_RADIUS, cap_z0, cap_z0 + KM_CAP_HEIGHT, nrm);
                     else dist = sphere_cylinder(c, m->sphere[s][3], bxy[b], KM_BASE_RADIUS, e->button_z, e->button_z + KM_BASE_HEIGHT, nrm);
+                    margin_note(3, dist - KM_CONTACT_THRESHOLD);
+                    if (is_cap && b == 0) margin_note(0, dist - KM_CONTACT_THRESHOLD);
                     if (!(dist < KM_CONTACT_THRESHOLD)) continue;
                     if (is_cap && b == 0) e->contact_button = 1;
                     e->contact_body[b] = 1;
-                    if (ngeneric >= m->max_generic_rows) continue;
+                    if (ngeneric >= budget) continue;
                     ngeneric++;
                     for (k = 0; k < 3; k++) pt[k] = c[k] - m->sphere[s][3] * nrm[k];      /* contact point on the sphere */
                     point_jacobian(R, p, link, pt, Jv, Jw);
                     for (i = 0; i < n; i++) J[i] = nrm[0] * Jv[0][i] + nrm[1] * Jv[1][i] + nrm[2] * Jv[2][i];
                     /* separated: allow approach up to dist/dt; penetrating: push out with erp */
-                    allow = dist > 0 ? -dist / dt : 0.0;
-                    pos_err_vel = dist > 0 ? 0.0 : -dist * KM_ERP / dt;
+                    pen = dist + m->linear_slop;                       /* Bullet: penetration = distance + m_linearSlop */
+                    allow = pen > 0 ? -pen / dt : 0.0;
+                    pos_err_vel = pen > 0 ? 0.0 : -pen * m->contact_erp / dt;
                     add_row(rows, &nrows, J, is_cap ? -nrm[2] : 0.0, W, Wb, allow, pos_err_vel, e->qd, *bqd[b], 0.0, 1e10, b);
                     g_probe_rows[0]++;
                     if (m->friction && m->sphere_mu[s] > 0.0) {
@@ -501,7 +519,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                         fr[nfr].Jb = is_cap ? -tdir[2] : 0.0;
                         fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
                         nfr++;
-                        if (g_detail & 4) {
+                        if (m->solver_detail & TM_DETAIL_FRICTION2) {
                             double t2[3];
                             t2[0] = nrm[1] * tdir[2] - nrm[2] * tdir[1]; t2[1] = nrm[2] * tdir[0] - nrm[0] * tdir[2]; t2[2] = nrm[0] * tdir[1] - nrm[1] * tdir[0];
                             for (i = 0; i < n; i++) fr[nfr].J[i] = t2[0] * Jv[0][i] + t2[1] * Jv[1][i] + t2[2] * Jv[2][i];
@@ -527,7 +545,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     int order[MAX_ROWS], nnc = 0, jj;
     for (k = 0; k < nrows; k++) order[k] = k;
     while (nnc < nrows && rows[nnc].fric_of < 0 && rows[nnc].hi < 1e9) nnc++;     /* non-contact rows: everything before the first normal (hi = 1e10) */
-    if (g_detail & 2) {            /* [button stops, button motors, arm limits, arm motors] */
+    if (m->solver_detail & TM_DETAIL_BODY_ORDER) {            /* [button stops, button motors, arm limits, arm motors] */
         int w = 0, nlim_arm = nnc - n - 3 * nb;
         for (b = 0; b < nb; b++) { order[w++] = n + nb + nlim_arm + 2 * b; order[w++] = n + nb + nlim_arm + 2 * b + 1; order[w++] = n + b; }
         for (k = 0; k < nlim_arm; k++) order[w++] = n + nb + k;
@@ -536,7 +554,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     for (it = 0; it < KM_SOLVER_ITERS; it++) {
         for (jj = 0; jj < nrows; jj++) {
             row_t *r; double jdv, delta, sum;
-            k = jj < nnc ? order[(g_detail & 1) ? ((it & 1) ? jj : nnc - 1 - jj) : jj] : jj;
+            k = jj < nnc ? order[(m->solver_detail & TM_DETAIL_ALT_SWEEP) ? ((it & 1) ? jj : nnc - 1 - jj) : jj] : jj;
             r = &rows[k];
             if (r->fric_of >= 0) {
                 const double tot = rows[r->fric_of].applied;
@@ -575,6 +593,7 @@ static int termination_cfg(const kenv *e, const kcfg *cfg) {      /* :422-426 */
 /* Kuka2ButtonGymEnv._reward (kuka_2button_gym_env.py:141-200) */
 static double reward_two(kenv *e, const kcfg *cfg) {
     double distance = norm3(e->all_pos[e->goal_id], e->gripper);
+    margin_note(2, distance - cfg->max_distance);
     int reward = 0, contact = e->contact_body[e->goal_id];   /* getContactPoints(button_uid[goal_id], kuka): any link of that button */
     int *nc[2]; nc[0] = &e->n_contacts; nc[1] = &e->n_contacts2;
     *nc[e->goal_id] += contact;
@@ -602,6 +621,7 @@ static double reward_fn(kenv *e, const kcfg *cfg) {              /* :428-463 */
     double distance;
     if (cfg->two) return reward_two(e, cfg);
     distance = norm3(e->button_pos, e->gripper);
+    margin_note(2, distance - cfg->max_distance);
     int reward = e->contact_button ? 1 : 0;
     e->n_contacts += reward;
     if (distance > cfg->max_distance || e->contact_table) { reward = -1; e->n_outside += 1; }
@@ -805,6 +825,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             f[24] = env.b2q; f[25] = env.b2qd; f[26] = env.goal_id; f[27] = env.n_contacts2; f[28] = env.button2_xy[0]; f[29] = env.button2_xy[1];
         }
         if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
+        margin_merge();
         free(r);
     }
     return 0;

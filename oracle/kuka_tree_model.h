@@ -36,7 +36,23 @@ typedef struct {
     double table_top_z, button_base_z;
     int max_generic_rows;                 /* joint-limit + contact-normal rows kept per step (each contact normal adds one friction row in the full model) */
     int friction;                         /* 1: one friction row per contact (Bullet multibody default: a single direction from btPlaneSpace1) */
+    /* Solver details of the dependency (Bullet 2.87 btMultiBodyConstraintSolver / pybullet's server defaults) that are RECALLED, not
+     * read, and that the PyBullet pin decides (tests/golden/fit_kuka_pin.py): a bit mask and three scalars, runtime data like the
+     * rest of the table.  Defaults = rounds 1-3 behaviour.
+     *   bit 0 (TM_DETAIL_ALT_SWEEP)  non-contact rows are swept backwards on even iterations (`iteration & 1 ? j : size - 1 - j`)
+     *   bit 1 (TM_DETAIL_BODY_ORDER) non-contact rows in body-creation order: button before arm (kuka_button_gym_env.py:233-238), per
+     *                                body its joint-limit rows, then its motors
+     *   bit 2 (TM_DETAIL_FRICTION2)  a second friction row per contact along n x t1 (SOLVER_USE_2_FRICTION_DIRECTIONS), each boxed by
+     *                                mu x the normal impulse; the row budget becomes min(max_generic_rows, 4) (4 + 4 + 4 bank-B slots) */
+    int solver_detail;
+    double contact_erp, limit_erp;        /* error reduction of contact rows (Bullet: m_erp2) / joint-limit rows, button stops included */
+    double linear_slop;                   /* contact rows see penetration = distance + linear_slop (Bullet: m_linearSlop) */
 } tree_model;
+#define TM_DETAIL_ALT_SWEEP 1
+#define TM_DETAIL_BODY_ORDER 2
+#define TM_DETAIL_FRICTION2 4
+/* row budget in force: the lane group's second row bank holds 12 rows — 6 normals / limits + 6 friction rows, or 4 + 4 + 4 */
+static int tm_row_budget(const tree_model *m) { const int cap = (m->solver_detail & TM_DETAIL_FRICTION2) ? 4 : 6; return m->max_generic_rows < cap ? m->max_generic_rows : cap; }
 
 static void tm_rpy_to_mat(const double rpy[3], double R[3][3]) {
     double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
@@ -66,6 +82,7 @@ static void tm_build_lumped(tree_model *m) {
     for (i = 0; i < KM_NSPHERE; i++) { m->sphere_link[i] = 6; for (k = 0; k < 4; k++) m->sphere[i][k] = KM_SPHERE[i][k]; m->sphere_mu[i] = 0.0; }
     m->table_top_z = KM_TABLE_TOP_Z; m->button_base_z = KM_BUTTON_BASE_Z;
     m->max_generic_rows = 6; m->friction = 0;
+    m->solver_detail = 0; m->contact_erp = KM_ERP; m->limit_erp = KM_ERP; m->linear_slop = 0.0;
 }
 
 /* ---- kuka_with_gripper2.sdf, gripper part [UNVERIFIED-MEMORY]: link poses in the model frame at q = 0 (xyz, rpy), inertial
@@ -187,7 +204,7 @@ static void tm_build_full(tree_model *m) {
 }
 
 /* flat float64 image of a tree_model (the layout of include/srlhip.h `srlhip_kuka_tree_model`), ints stored as doubles */
-#define TM_DOUBLES (1 + TN * (1 + 3 + 9 + 3 + 2 + 1 + 1 + 3 + 6 + 3 + 1) + (1 + 3) + (1 + 3) + 1 + TNS * (1 + 4 + 1) + 2 + 2)
+#define TM_DOUBLES (1 + TN * (1 + 3 + 9 + 3 + 2 + 1 + 1 + 3 + 6 + 3 + 1) + (1 + 3) + (1 + 3) + 1 + TNS * (1 + 4 + 1) + 2 + 2 + 4)
 static void tm_to_table(const tree_model *m, double *t) {
     int k = 0, i, j;
     t[k++] = m->nd;
@@ -207,6 +224,7 @@ static void tm_to_table(const tree_model *m, double *t) {
     t[k++] = m->nsphere;
     for (i = 0; i < TNS; i++) { t[k++] = m->sphere_link[i]; for (j = 0; j < 4; j++) t[k++] = m->sphere[i][j]; t[k++] = m->sphere_mu[i]; }
     t[k++] = m->table_top_z; t[k++] = m->button_base_z; t[k++] = m->max_generic_rows; t[k++] = m->friction;
+    t[k++] = m->solver_detail; t[k++] = m->contact_erp; t[k++] = m->limit_erp; t[k++] = m->linear_slop;
 }
 static void tm_from_table(tree_model *m, const double *t) {
     int k = 0, i, j;
@@ -227,5 +245,6 @@ static void tm_from_table(tree_model *m, const double *t) {
     m->nsphere = (int)t[k++];
     for (i = 0; i < TNS; i++) { m->sphere_link[i] = (int)t[k++]; for (j = 0; j < 4; j++) m->sphere[i][j] = t[k++]; m->sphere_mu[i] = t[k++]; }
     m->table_top_z = t[k++]; m->button_base_z = t[k++]; m->max_generic_rows = (int)t[k++]; m->friction = (int)t[k++];
+    m->solver_detail = (int)t[k++]; m->contact_erp = t[k++]; m->limit_erp = t[k++]; m->linear_slop = t[k++];
 }
 #endif

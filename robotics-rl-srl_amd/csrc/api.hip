@@ -546,6 +546,10 @@ int srlhip_set_kuka_tree_model(srlhip_handle hh, const srlhip_kuka_tree_model *m
             return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: parents before children, positive masses / inertias / motor gains, unit axes");
         if (i < 7 && ((int)J.parent != i - 1)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: DoFs 0..6 must be the serial arm");
     }
+    const int detail = (int)m->solver_detail;
+    if (m->solver_detail != (double)detail || detail < 0 || detail > (SRLHIP_KUKA_DETAIL_ALT_SWEEP | SRLHIP_KUKA_DETAIL_BODY_ORDER | SRLHIP_KUKA_DETAIL_FRICTION2) ||
+        !(m->contact_erp >= 0.0 && m->contact_erp <= 1.0) || !(m->limit_erp >= 0.0 && m->limit_erp <= 1.0) || !(m->linear_slop >= 0.0 && m->linear_slop <= 0.01))
+        return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: solver_detail is a mask of SRLHIP_KUKA_DETAIL_* bits, erp values in [0, 1], linear_slop in [0, 0.01]");
     for (int k = 0; k < ns; k++) if ((int)m->s[k].link < 0 || (int)m->s[k].link >= nd || !(m->s[k].r > 0)) return h->fail(SRLHIP_EINVAL, "set_kuka_tree_model: bad sphere");
     return kuka_set_tree_model(h, reinterpret_cast<const double *>(m));
 }

@@ -71,8 +71,8 @@ int kuka_refresh(Handle *h);
 int kuka_uses_group_kernel(const Handle *h);
 int kuka_set_model(Handle *h, const double *table138);
 void kuka_default_model(double *table138);
-int kuka_set_tree_model(Handle *h, const double *table506);
-void kuka_default_tree_model(double *table506);
+int kuka_set_tree_model(Handle *h, const double *table510);
+void kuka_default_tree_model(double *table510);
 int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
 
 // raster.hip

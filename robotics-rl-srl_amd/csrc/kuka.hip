@@ -321,13 +321,13 @@ void kuka_default_model(double *table138) { Model m; default_model(m); memcpy(ta
 int kuka_uses_group_kernel(const Handle *h) { return h->kuka->full ? 2 : use_group_kernel(h) ? 1 : 0; }
 
 // srlhip_set_kuka_tree_model: install a full-model table; settled state and start table are re-integrated.  Envs must be reset afterwards.
-int kuka_set_tree_model(Handle *h, const double *table506) {
+int kuka_set_tree_model(Handle *h, const double *table510) {
     KukaState *s = h->kuka;
-    SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, table506, sizeof(TreeModel), hipMemcpyHostToDevice, h->stream));
+    SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, table510, sizeof(TreeModel), hipMemcpyHostToDevice, h->stream));
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return kuka_tree_settle(h, params_of(h));
 }
-void kuka_default_tree_model(double *table506) { TreeModel m; default_tree_model(m); memcpy(table506, &m, sizeof m); }
+void kuka_default_tree_model(double *table510) { TreeModel m; default_tree_model(m); memcpy(table510, &m, sizeof m); }
 
 static int kuka_group_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                              uint8_t *d_done, void *d_act_out) {

@@ -537,6 +537,11 @@ SRL_HD void aba_forward_and_minv(const Env &e, const Scratch &sc, double qdd[ND]
 // ---------------------------------------------------------------- contacts
 SRL_HD double sphere_cylinder(const double c[3], double rad, double bx, double by, double Rc, double z0, double z1,
                               double n[3]) {
+    // The distance that is compared with kContactThreshold decides reward / done flags: evaluated UNFUSED, operation for operation as
+    // oracle/kuka_oracle.c::sphere_cylinder does (-ffp-contract=off there), whatever the translation unit's contraction setting is.
+    // (Its input, the sphere centre, still comes out of differently associated kinematics: flags are bit-exact as long as no
+    // distance comes within ~1e-10 of the threshold — the oracle's margin probe reports how close the tested runs get.)
+#pragma clang fp contract(off)
     const double dx = c[0] - bx, dy = c[1] - by, rho = sqrt(dx * dx + dy * dy);
     const double er = rho - Rc, ez_top = c[2] - z1, ez_bot = z0 - c[2];
     const double ez = ez_top > ez_bot ? ez_top : ez_bot;

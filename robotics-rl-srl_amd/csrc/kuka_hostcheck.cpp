@@ -576,8 +576,8 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
     }
     return 0;
 }
-extern "C" void hostcheck_kuka_tree_default_model(double *t506) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t506, &m, sizeof m); }
-extern "C" void hostcheck_kuka_tree_set_model(const double *t506) {
-    g_tree_model_set = t506 != nullptr;
-    if (t506) memcpy(&g_tree_model, t506, sizeof g_tree_model);
+extern "C" void hostcheck_kuka_tree_default_model(double *t510) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t510, &m, sizeof m); }
+extern "C" void hostcheck_kuka_tree_set_model(const double *t510) {
+    g_tree_model_set = t510 != nullptr;
+    if (t510) memcpy(&g_tree_model, t510, sizeof g_tree_model);
 }

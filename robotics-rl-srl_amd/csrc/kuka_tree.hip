@@ -84,6 +84,9 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     double *scratch = scratch_all[threadIdx.x / GL];
     LaneId L;
     build_lane_table(L, s.ttable, tab);
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0) { unsigned long long *pp = tree::tprof_buf(); for (int i = 0; i < tree::kProfSlots; i++) pp[i] = 0; pp[tree::kProfSlots] = __builtin_amdgcn_s_memtime(); }
+#endif
     const bool lead = L.l == 0 && valid;
     using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
     Rng rng0;
@@ -141,6 +144,12 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             if (done_out) done_out[row] = (uint8_t)done;
         }
     }
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 511)) {
+        const unsigned long long *pp = tree::tprof_buf();
+        for (int i = 0; i < tree::kProfSlots; i++) printf("tprof block %d T %d phase %d cycles %llu\n", (int)blockIdx.x, T, i, pp[i]);
+    }
+#endif
     int e_out = e;
     asm volatile("" : "+v"(e_out));       // exit-store addresses are recomputed instead of being kept live across the loop
     tstore(s, n, e_out, L, v, g, valid, NB == 2);

@@ -41,10 +41,22 @@ using grp::shfl;
 using grp::sync_scratch;
 using grp::wany;
 
+// ---- phase stamps of the PROFILING build (make prof: -DSRL_TREE_PROF, profiles/probes/kuka_tree_phases.py): shader-clock cycles
+// between consecutive stamps, accumulated per phase by lane 0 of the workgroup in LDS, printed by workgroup 0 when the kernel ends.
+// The product build compiles them away.
+#if defined(SRL_TREE_PROF) && SRL_G_DEVICE
+constexpr int kProfSlots = 12;
+SRL_G unsigned long long *tprof_buf() { __shared__ unsigned long long p[kProfSlots + 1]; return p; }
+#define SRL_TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long *p_ = tprof_buf(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p_[i] += t_ - p_[kProfSlots]; p_[kProfSlots] = t_; } } while (0)
+#else
+#define SRL_TSTAMP(i)
+#endif
+
 constexpr int NJ = 12;                          // joint lanes
 constexpr int NA = 7;                           // arm joints (IK, commands)
 constexpr int kBM = 12, kBLo = 13, kBHi = 14;   // lanes of the button's scalar rows
 constexpr int kNGen = 6, kNB = 2 * kNGen;       // bank-B slots; slots < kNGen: limits + contact normals, kNGen + g: friction of normal g
+constexpr int kNGen2 = 4;                       // SRLHIP_KUKA_DETAIL_FRICTION2: the same 12 slots as 4 normals / limits + 4 + 4 friction rows (slot ng + g, 2 ng + g)
 constexpr int kNArows = 15;                     // bank-A rows: 12 motors + the button's three
 constexpr int kTreeStartDoubles = 4 * NJ + 8;   // q12 qd12 sq12 cq12 ee3 bq bqd grip3
 // LDS scratch per env (doubles): row definitions J[16][12], W J [16][12], then three coupling planes [row j][lane i]:
@@ -74,6 +86,8 @@ struct TLane {
     int ee_link, grip_link, max_gen;
     bool friction;
     double eept[3], grpt[3], table_z, base_z;
+    int detail, ng;           // solver_detail bits; normal / limit slots of bank B in force (6, or 4 with two friction directions)
+    double cerp, lerp, slop;  // contact_erp, limit_erp, linear_slop
 };
 
 SRL_G void lane_init(TLane &L, const TreeModel *m) {
@@ -118,7 +132,9 @@ SRL_G void lane_init(TLane &L, const TreeModel *m) {
     for (int k = 0; k < 3; k++) L.sph[k] = S.c[k];
     L.sph[3] = S.r; L.smu = S.mu;
     L.ee_link = (int)m->ee_link; L.grip_link = (int)m->grip_link; L.max_gen = (int)m->max_generic_rows; L.friction = m->friction != 0.0;
-    if (L.max_gen > kNGen) L.max_gen = kNGen;
+    L.detail = (int)m->solver_detail; L.ng = (L.detail & kDetailFriction2) ? kNGen2 : kNGen;
+    if (L.max_gen > L.ng) L.max_gen = L.ng;
+    L.cerp = m->contact_erp; L.lerp = m->limit_erp; L.slop = m->linear_slop;
     for (int k = 0; k < 3; k++) { L.eept[k] = m->ee_point[k]; L.grpt[k] = m->grip_point[k]; }
     L.table_z = m->table_top_z; L.base_z = m->button_base_z;
 }
@@ -130,7 +146,7 @@ SRL_G void lane_init(TLane &L, const TreeModel *m) {
 enum { LT_MASS = 0, LT_MCOMP, LT_COM, LT_IN = LT_COM + 3, LT_F = LT_IN + 6, LT_T = LT_F + 9, LT_AX = LT_T + 3, LT_JLO = LT_AX + 3, LT_JHI, LT_DAMP, LT_KP,
        LT_BOUND, LT_MAXVEL, LT_Q0, LT_TSEL, LT_SPH, LT_SMU = LT_SPH + 4, LT_ANC, LT_DESC, LT_SRC, LT_SLINK = LT_SRC + 4, LT_SANC, LT_COUNT };
 // behind the per-lane fields: the model's scalars, stored once
-enum { LS_EEPT = 0, LS_GRPT = 3, LS_TABLEZ = 6, LS_BASEZ, LS_EELINK, LS_GRIPLINK, LS_MAXGEN, LS_FRICTION, LS_COUNT };
+enum { LS_EEPT = 0, LS_GRPT = 3, LS_TABLEZ = 6, LS_BASEZ, LS_EELINK, LS_GRIPLINK, LS_MAXGEN, LS_FRICTION, LS_DETAIL, LS_NG, LS_CERP, LS_LERP, LS_SLOP, LS_COUNT };
 constexpr int kLaneTableDoubles = LT_COUNT * GL + LS_COUNT;
 SRL_G void lane_store(const TLane &L, double *tab) {
     double *t = tab + L.l;
@@ -154,6 +170,7 @@ SRL_G void lane_store(const TLane &L, double *tab) {
         for (int k = 0; k < 3; k++) { sc[LS_EEPT + k] = L.eept[k]; sc[LS_GRPT + k] = L.grpt[k]; }
         sc[LS_TABLEZ] = L.table_z; sc[LS_BASEZ] = L.base_z; sc[LS_EELINK] = L.ee_link; sc[LS_GRIPLINK] = L.grip_link;
         sc[LS_MAXGEN] = L.max_gen; sc[LS_FRICTION] = L.friction ? 1.0 : 0.0;
+        sc[LS_DETAIL] = L.detail; sc[LS_NG] = L.ng; sc[LS_CERP] = L.cerp; sc[LS_LERP] = L.lerp; sc[LS_SLOP] = L.slop;
     }
 }
 // Lazy view of the lane table: every field is read from LDS where it is used (loading all ~45 of them at the top of a step kept
@@ -196,6 +213,11 @@ struct TL {
     SRL_G int grip_link() const { return (int)sc[LS_GRIPLINK]; }
     SRL_G int max_gen() const { return (int)sc[LS_MAXGEN]; }
     SRL_G bool friction() const { return sc[LS_FRICTION] != 0.0; }
+    SRL_G int detail() const { return (int)sc[LS_DETAIL]; }
+    SRL_G int ng() const { return (int)sc[LS_NG]; }
+    SRL_G double contact_erp() const { return sc[LS_CERP]; }
+    SRL_G double limit_erp() const { return sc[LS_LERP]; }
+    SRL_G double linear_slop() const { return sc[LS_SLOP]; }
 };
 SRL_G TL lane_view(const double *tab) {
     // (the OFFSETS are laundered, not the pointer: an opaque pointer loses its LDS address space and every read becomes a flat
@@ -643,6 +665,115 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     return uA;
 }
 
+// ------------------------------------------------------------------ PGS under the model's solver details (srlhip_kuka_tree_model.solver_detail)
+// Any row ORDER — alternating sweep direction, body-creation order — and the second friction direction in ONE formulation: every
+// lane keeps the TOTAL coupling sum of its rows over the current values of all other rows, tot_r = sum_k n_rk u_k, and a row update
+// hands round its CHANGE:  t = clamp(cs_r + tot_r);  d = t - u_r;  u_r = t;  tot_i += n_ir d on every lane i.  (The default path's
+// accumulators restart at the own row, which is only right when every other row is visited exactly once between two visits of a
+// row: an alternating order breaks that.)  Three dependent float64 operations per row instead of two, the same rows, bounds and
+// start values (lambda = 0, i.e. u = 1/2 on the symmetric rows); with solver_detail = 0 none of this code runs.
+struct DState { double totA, uA, totB, totC, uC; };
+template <int J, bool GEN> SRL_G void d_rowA(const TRows &r, const double *sc, int l, DState &st) {
+    const double t = clamp01(r.cs + st.totA);
+    const double d = t - st.uA;
+    if (l == J) st.uA = t;
+    fmac_bcast<J>(st.totA, d, r.n[J]);
+    if constexpr (GEN) fmac_bcast<J>(st.totB, d, sc[SC_NBA + J * GL + l]);
+}
+// Kuka2Button: row J (kBM / kBLo / kBHi) of the second button, same lanes, own sums
+template <int J, bool GEN> SRL_G void d_rowC(const TRows2 &r2, const double nBC[3], int l, DState &st) {
+    const double t = clamp01(r2.cs + st.totC);
+    const double d = t - st.uC;
+    if (l == J) st.uC = t;
+    fmac_bcast<J>(st.totC, d, r2.n[J - kBM]);
+    if constexpr (GEN) fmac_bcast<J>(st.totB, d, nBC[J - kBM]);
+}
+// bank-B slot s (a wave-uniform index): see gen_rowB for the friction bounds and `part`
+template <int NB> SRL_G void d_rowB(const double *sc, int l, int s, BRow &b, DState &st, bool part, double nCB_s) {
+    double lo = b.lo, hi = b.hi;
+    const double tot = shfl(b.lam, b.normal);
+    const bool skip = b.fric && !(tot > 0.0);
+    if (b.fric) { lo = -b.mu * tot; hi = b.mu * tot; }
+    double t = b.cs + st.totB;
+    t = t < lo ? lo : (t > hi ? hi : t);
+    if (skip) t = b.lam;
+    const double db = shfl(part ? t - b.lam : 0.0, s);
+    st.totA = fma(sc[SC_NAB + s * GL + l], db, st.totA);
+    st.totB = fma(sc[SC_NBB + s * GL + l], db, st.totB);     // (the plane holds 0 at [s][s])
+    if (part && l == s) b.lam = t;
+    if constexpr (NB == 2) st.totC = fma(nCB_s, db, st.totC);
+}
+// The non-contact rows of one sweep in the order the details ask for.  Creation order of the solver (detail bit 1 clear): motors 0..11,
+// button motor(s), joint limits, button stops (b = 0: lower, upper; b = 1: ...).  Body order (bit 1): per button its stops, then its
+// motor; the arm's limits; the arm's motors.  REV: the same list backwards.  LIM(FWD) sweeps the limit slots.
+#define SRL_D_ARM_FWD  d_rowA<0, GEN>(r, sc, l, st); d_rowA<1, GEN>(r, sc, l, st); d_rowA<2, GEN>(r, sc, l, st); d_rowA<3, GEN>(r, sc, l, st);   \
+                       d_rowA<4, GEN>(r, sc, l, st); d_rowA<5, GEN>(r, sc, l, st); d_rowA<6, GEN>(r, sc, l, st); d_rowA<7, GEN>(r, sc, l, st);   \
+                       d_rowA<8, GEN>(r, sc, l, st); d_rowA<9, GEN>(r, sc, l, st); d_rowA<10, GEN>(r, sc, l, st); d_rowA<11, GEN>(r, sc, l, st);
+#define SRL_D_ARM_REV  d_rowA<11, GEN>(r, sc, l, st); d_rowA<10, GEN>(r, sc, l, st); d_rowA<9, GEN>(r, sc, l, st); d_rowA<8, GEN>(r, sc, l, st); \
+                       d_rowA<7, GEN>(r, sc, l, st); d_rowA<6, GEN>(r, sc, l, st); d_rowA<5, GEN>(r, sc, l, st); d_rowA<4, GEN>(r, sc, l, st);   \
+                       d_rowA<3, GEN>(r, sc, l, st); d_rowA<2, GEN>(r, sc, l, st); d_rowA<1, GEN>(r, sc, l, st); d_rowA<0, GEN>(r, sc, l, st);
+template <int NB, bool GEN, class LIM>
+SRL_G void d_noncontact(const TRows &r, const TRows2 &r2, const double nBC[3], const double *sc, int l, DState &st, bool body_order, bool rev, LIM lim) {
+    if (!body_order) {
+        if (!rev) {
+            SRL_D_ARM_FWD
+            d_rowA<kBM, GEN>(r, sc, l, st);
+            if constexpr (NB == 2) d_rowC<kBM, GEN>(r2, nBC, l, st);
+            if constexpr (GEN) lim(true);
+            d_rowA<kBLo, GEN>(r, sc, l, st); d_rowA<kBHi, GEN>(r, sc, l, st);
+            if constexpr (NB == 2) { d_rowC<kBLo, GEN>(r2, nBC, l, st); d_rowC<kBHi, GEN>(r2, nBC, l, st); }
+        } else {
+            if constexpr (NB == 2) { d_rowC<kBHi, GEN>(r2, nBC, l, st); d_rowC<kBLo, GEN>(r2, nBC, l, st); }
+            d_rowA<kBHi, GEN>(r, sc, l, st); d_rowA<kBLo, GEN>(r, sc, l, st);
+            if constexpr (GEN) lim(false);
+            if constexpr (NB == 2) d_rowC<kBM, GEN>(r2, nBC, l, st);
+            d_rowA<kBM, GEN>(r, sc, l, st);
+            SRL_D_ARM_REV
+        }
+    } else {
+        if (!rev) {
+            d_rowA<kBLo, GEN>(r, sc, l, st); d_rowA<kBHi, GEN>(r, sc, l, st); d_rowA<kBM, GEN>(r, sc, l, st);
+            if constexpr (NB == 2) { d_rowC<kBLo, GEN>(r2, nBC, l, st); d_rowC<kBHi, GEN>(r2, nBC, l, st); d_rowC<kBM, GEN>(r2, nBC, l, st); }
+            if constexpr (GEN) lim(true);
+            SRL_D_ARM_FWD
+        } else {
+            SRL_D_ARM_REV
+            if constexpr (GEN) lim(false);
+            if constexpr (NB == 2) { d_rowC<kBM, GEN>(r2, nBC, l, st); d_rowC<kBHi, GEN>(r2, nBC, l, st); d_rowC<kBLo, GEN>(r2, nBC, l, st); }
+            d_rowA<kBM, GEN>(r, sc, l, st); d_rowA<kBHi, GEN>(r, sc, l, st); d_rowA<kBLo, GEN>(r, sc, l, st);
+        }
+    }
+}
+#undef SRL_D_ARM_FWD
+#undef SRL_D_ARM_REV
+// start values: every impulse 0, i.e. u_k = -lo_k / S_k (1/2 on the symmetric rows, 0 on the unilateral ones)
+template <class SOF, class LOF> SRL_G double d_u0(int k, SOF S_of, LOF lo_of) { const double Sk = S_of(k); return Sk > 0.0 ? -lo_of(k) / Sk : 0.0; }
+// steps without generic rows: bank A (and the second button's rows) only
+template <int NB, class SOF, class LOF>
+SRL_G double sweeps_free_detail(const TRows &r, const TRows2 &r2, int detail, SOF S_of, LOF lo_of, double *u2_out) {
+    int l = lane_id();
+#if SRL_G_DEVICE
+    asm volatile("" : "+v"(l));
+#endif
+    DState st;
+    st.totA = 0.0; st.totB = 0.0; st.totC = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNArows; k++) st.totA = fma(r.n[k], d_u0(k, S_of, lo_of), st.totA);
+    st.uA = l < kNArows ? d_u0(l, S_of, lo_of) : 0.0;
+    st.uC = 0.0;
+    if constexpr (NB == 2) {
+#pragma unroll
+        for (int k = kBM; k <= kBHi; k++) st.totC = fma(r2.n[k - kBM], d_u0(k, S_of, lo_of), st.totC);
+        st.uC = (l >= kBM && l <= kBHi) ? d_u0(l, S_of, lo_of) : 0.0;
+    }
+    const double nBC[3] = {0.0, 0.0, 0.0};
+    const bool body_order = (detail & kDetailBodyOrder) != 0, alt = (detail & kDetailAltSweep) != 0;
+    for (int it = 0; it < kSolverIters; it++)
+        d_noncontact<NB, false>(r, r2, nBC, nullptr, l, st, body_order, alt && !(it & 1), [](bool) {});
+    if constexpr (NB == 2) *u2_out = st.uC;
+    return st.uA;
+}
+
 // ------------------------------------------------------------------ the general path
 // Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps): row definitions,
 // couplings through LDS, the two-bank sweeps.  (Tried as a real call with its own frame, -mllvm -amdgpu-function-calls: the call
@@ -674,6 +805,10 @@ SRL_G GenOut general_path(const GenIn &in) {
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
     const double qd_new = in.qd_new, bound_bm = in.bound_bm, bqd = in.bqd;
     const bool is_button = L.l == kBM || L.l == kBLo || L.l == kBHi;
+    // bank-B slot layout: normals / limits 0..ng-1, friction rows ng + g [, second friction direction 2 ng + g] — 6 + 6, or 4 + 4 + 4
+    const int detail = L.detail(), ng = L.ng(), nfd = (detail & kDetailFriction2) ? 2 : 1, nslots = (1 + nfd) * ng;
+    const double lerp = L.limit_erp(), cerp = L.contact_erp(), slop = L.linear_slop();
+    auto used_slot = [&](int s_, int ngw) -> bool { return s_ < nslots && (s_ >= 2 * ng ? s_ - 2 * ng : s_ >= ng ? s_ - ng : s_) < ngw; };
     auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
     auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
     BRow b;
@@ -724,14 +859,16 @@ SRL_G GenOut general_path(const GenIn &in) {
                 double *o = sc + SC_J + slot * NJ, *d = sc + SC_DEF + slot * kDefDoubles;
 #pragma nounroll
                 for (int j = 0; j < NJ; j++) o[j] = j == L.l ? sign : 0.0;
-                d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * kErp * inv_dt; d[3] = blim; d[4] = 1.0;
+                d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * lerp * inv_dt; d[3] = blim; d[4] = 1.0;
             }
         };
         auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap, int bsel) {
             if (slot < max_gen) {
-                double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (kNGen + slot) * NJ;
-                double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (kNGen + slot) * kDefDoubles;
-                double pt3[3], tdir[3];
+                double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (ng + slot) * NJ;
+                double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (ng + slot) * kDefDoubles;
+                double *of2 = sc + SC_J + (nfd == 2 ? 2 * ng + slot : ng + slot) * NJ, *df2 = sc + SC_DEF + (nfd == 2 ? 2 * ng + slot : ng + slot) * kDefDoubles;
+                double pt3[3], tdir[3], tdir2[3];
+                const double pen = dist + slop;                           // Bullet: penetration = distance + m_linearSlop
                 const double rad = L.sph(3), smu = L.smu();
                 const uint32_t sanc = L.sanc();
 #pragma unroll
@@ -739,6 +876,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 // btPlaneSpace1: first tangent of the contact normal (the one friction direction of Bullet's multibody solver)
                 if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); tdir[0] = 0.0; tdir[1] = -nrm[2] * kk; tdir[2] = nrm[1] * kk; }
                 else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
+                cross3(nrm, tdir, tdir2);                                 // the second friction direction (SOLVER_USE_2_FRICTION_DIRECTIONS)
 #pragma nounroll
                 for (int j = 0; j < NJ; j++) {
                     const double *Sj = sc + SC_S + j * 6;
@@ -748,10 +886,12 @@ SRL_G GenOut general_path(const GenIn &in) {
                     const double on = (sanc >> j) & 1u ? 1.0 : 0.0;       // only the joints the sphere's link hangs on
                     o[j] = on * (dot3(nrm, c3) + dot3(nrm, Svj));
                     of[j] = on * (dot3(tdir, c3) + dot3(tdir, Svj));
+                    if (nfd == 2) of2[j] = on * (dot3(tdir2, c3) + dot3(tdir2, Svj));
                 }
-                d[0] = cap ? -nrm[2] : 0.0; d[1] = dist > 0 ? -dist * inv_dt : 0.0; d[2] = dist > 0 ? 0.0 : -dist * kErp * inv_dt; d[3] = 1e10; d[4] = 1.0;
+                d[0] = cap ? -nrm[2] : 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * cerp * inv_dt; d[3] = 1e10; d[4] = 1.0;
                 df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && smu > 0.0) ? 1.0 : 0.0; df[5] = smu;
                 d[6] = (double)bsel; df[6] = (double)bsel;
+                if (nfd == 2) { df2[0] = cap ? -tdir2[2] : 0.0; df2[4] = df[4]; df2[5] = smu; df2[6] = (double)bsel; }
             }
         };
         if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
@@ -774,7 +914,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double invA = liveA ? 1.0 / (r.diag * r.S) : 0.0;
 #pragma nounroll
         for (int s = 0; s < kNB; s++) {
-            const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+            const bool used = used_slot(s, ngen_w);
             double wjk = 0.0;
             if (used) {
                 const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
@@ -793,10 +933,10 @@ SRL_G GenOut general_path(const GenIn &in) {
         const int own_slot = L.l < kNB ? L.l : 0;                       // lanes >= kNB own no bank-B row
         const double *myd = sc + SC_DEF + own_slot * kDefDoubles;
         const bool own_on = L.l < kNB && myd[4] != 0.0;
-        const bool mine_f = own_on && L.l >= kNGen;
+        const bool mine_f = own_on && L.l >= ng;
         const double own_jb = own_on ? myd[0] : 0.0;
         b.on = own_on; b.fric = mine_f; b.jb = own_jb; b.mu = mine_f ? myd[5] : 0.0;
-        b.normal = mine_f ? L.l - kNGen : L.l;
+        b.normal = mine_f ? (L.l >= 2 * ng ? L.l - 2 * ng : L.l - ng) : L.l;
         b.lo = 0.0; b.hi = (own_on && !mine_f) ? myd[3] : 0.0;
         const int own_bsel = (NB == 2 && own_on && myd[6] != 0.0) ? 1 : 0;
         b.bsel = own_bsel;
@@ -830,7 +970,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         }
 #pragma nounroll
         for (int s = 0; s < kNB; s++) {
-            const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+            const bool used = used_slot(s, ngen_w);
             double a = 0.0;
             if (used && s != L.l) {
                 const double *ws = sc + SC_WJ + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
@@ -857,11 +997,38 @@ SRL_G GenOut general_path(const GenIn &in) {
     const bool liveC = NB == 2 && is_button && in.r2.S > 0.0;
     const double invC = liveC ? 1.0 / (wb * in.r2.S) : 0.0;
     auto nCB_of = [&](int s) -> double {
-        const bool used = (s < kNGen ? s : s - kNGen) < ngen_w;
+        const bool used = used_slot(s, ngen_w);
         const double *ds = sc + SC_DEF + s * kDefDoubles;
         return (used && liveC && ds[4] != 0.0 && ds[6] != 0.0) ? -(in.r2.jb * wb * ds[0]) * invC : 0.0;
     };
-    if (nlim_w == 0) {
+    if (detail != 0) {
+        // the model's solver details: total-sum formulation (d_rowA / d_rowB above), rows in the order the bits ask for
+        DState st;
+        st.totA = 0.0; st.totB = 0.0; st.totC = 0.0; st.uC = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNArows; k++) {
+            const double u0 = d_u0(k, S_of, lo_of);
+            st.totA = fma(r.n[k], u0, st.totA);
+            st.totB = fma(sc[SC_NBA + k * GL + L.l], u0, st.totB);
+        }
+        st.uA = L.l < kNArows ? d_u0(L.l, S_of, lo_of) : 0.0;
+        if constexpr (NB == 2) {
+#pragma unroll
+            for (int k = kBM; k <= kBHi; k++) { const double u0 = d_u0(k, S_of, lo_of); st.totC = fma(in.r2.n[k - kBM], u0, st.totC); st.totB = fma(b.nBC[k - kBM], u0, st.totB); }
+            st.uC = is_button ? d_u0(L.l, S_of, lo_of) : 0.0;
+        }
+        const bool body_order = (detail & kDetailBodyOrder) != 0, alt = (detail & kDetailAltSweep) != 0;
+        const int l = L.l;
+        for (int it = 0; it < kSolverIters; it++) {
+            d_noncontact<NB, true>(r, in.r2, b.nBC, sc, l, st, body_order, alt && !(it & 1), [&](bool fwd) {
+                for (int k = 0; k < nlim_w; k++) { const int s = fwd ? k : nlim_w - 1 - k; d_rowB<NB>(sc, l, s, b, st, shfl(on_lim ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0); }
+            });
+            for (int s = 0; s < ngen_w; s++) d_rowB<NB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0);
+            for (int g = 0; g < ngen_w; g++)
+                for (int f = 1; f <= nfd; f++) { const int s = f * ng + g; d_rowB<NB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0); }
+        }
+        uA = st.uA; uC = st.uC;
+    } else if (nlim_w == 0) {
         if constexpr (NB == 2) {
             double nCB[kNB];
 #pragma unroll
@@ -887,8 +1054,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0; out.u2 = uC; out.dvb_b2 = 0.0;
     const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
     for (int s = 0; s < kNB; s++) {
-        const bool used = s < kNGen ? s < ngen_w : s - kNGen < ngen_w;
-        if (!used) continue;
+        if (!used_slot(s, ngen_w)) continue;
         out.acc_b = fma(sc[SC_NAB + s * GL + L.l], shfl(b.on ? b.lam : 0.0, s), out.acc_b);
         out.dvb_b += shfl(b.bsel ? 0.0 : pbb, s);
         if constexpr (NB == 2) out.dvb_b2 += shfl(b.bsel ? pbb : 0.0, s);
@@ -906,6 +1072,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
                          double finger_angle) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
+    SRL_TSTAMP(0);                          // (everything between two physics steps: env logic, outputs, action sampling)
     // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
     double S[6];
 #pragma unroll
@@ -984,6 +1151,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             if (maxabs > kIkMaxAngle && L.arm) qdes = g.q + bb * scale;
         }
     }
+    SRL_TSTAMP(1);                          // IK
     // ---- collision detection at the current poses: every lane owns one sphere of the model
     double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30;
     const bool sphere = L.slink() >= 0;
@@ -1041,6 +1209,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     double target = L.kp() * (qdes - g.q) * inv_dt;
     target = target > L.maxvel() ? L.maxvel() : target;
     target = target < -L.maxvel() ? -L.maxvel() : target;
+    SRL_TSTAMP(2);                          // collision detection, motor targets
     // ---- dynamics in world coordinates
     const double qd = g.qd * L.jm;
     double W[NJ], tau;
@@ -1110,6 +1279,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             msum3(Io, ge, Ioc); msum3(Io + 3, ge, Ioc + 3);
         }
         tau = -L.damping() * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        SRL_TSTAMP(3);                      // velocities, bias forces, composite inertias (the masked sums)
         // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
         double Fc[6], t0[3], t1[3], low[NJ];
         sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
@@ -1123,8 +1293,10 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
         }
         transpose_step<0>(L, low, W);
+        SRL_TSTAMP(4);                      // mass matrix (CRBA)
         double unused = 0.0;
         gj_step<0, NJ, true>(L, W, unused);
+        SRL_TSTAMP(5);                      // its inverse (Gauss-Jordan)
 #pragma unroll
         for (int k = 0; k < NJ; k++) scratch[SC_STASH_W + k * GL + L.l] = W[k];
     }
@@ -1140,6 +1312,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
     const double bound_bm = e.motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
     const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi, is_button = is_bm || is_blo || is_bhi;
+    const double lerp = L.limit_erp();
     TRows r;
     double rhs = 0.0, off = 0.0;
 #pragma unroll
@@ -1166,11 +1339,11 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
     } else if (is_blo) {
         const double pen = e.bq - kGliderLower;
-        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - e.bqd) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt);
         r.S = blim; r.jb = 1.0; r.diag = wb;
     } else if (is_bhi) {
         const double pen = kGliderUpper - e.bq;
-        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt);
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + e.bqd) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt);
         r.S = blim; r.jb = -1.0; r.diag = wb;
     }
 #pragma unroll
@@ -1181,8 +1354,8 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     if constexpr (NB == 2) {
         double rhs2 = 0.0, off2 = 0.0;
         if (is_bm) rhs2 = (e.motor_on ? kButtonKp * (kButtonTarget - e.b2q) * inv_dt : 0.0) - e.b2qd;
-        else if (is_blo) { const double pen = e.b2q - kGliderLower; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) - e.b2qd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt); }
-        else if (is_bhi) { const double pen = kGliderUpper - e.b2q; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) + e.b2qd) + (pen > 0 ? 0.0 : -pen * kErp * inv_dt); }
+        else if (is_blo) { const double pen = e.b2q - kGliderLower; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) - e.b2qd) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt); }
+        else if (is_bhi) { const double pen = kGliderUpper - e.b2q; rhs2 = ((pen > 0 ? -pen * inv_dt : 0.0) + e.b2qd) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt); }
         if (is_button) { r2.lo = r.lo; r2.S = r.S; r2.jb = r.jb; }
 #pragma unroll
         for (int k = kBM; k <= kBHi; k++) off2 = fma(a_of(k), lo_of(k), off2);
@@ -1214,7 +1387,9 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         }
     }
     double u, acc_b = 0.0, dvb_b = 0.0, u2 = 0.0, dvb_b2 = 0.0;
-    if (!any_generic) u = sweeps_free<NB>(r, &r2, &u2);
+    const int detail = L.detail();
+    SRL_TSTAMP(6);                          // row setup
+    if (!any_generic) u = detail != 0 ? sweeps_free_detail<NB>(r, r2, detail, S_of, lo_of, &u2) : sweeps_free<NB>(r, &r2, &u2);
     else {
         GenIn in;
         in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
@@ -1222,6 +1397,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         const GenOut out = general_path<NB>(in);
         u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b; u2 = out.u2; dvb_b2 = out.dvb_b2;
     }
+    if (any_generic) { SRL_TSTAMP(8); } else { SRL_TSTAMP(7); }      // the 150 sweeps: free path / steps with generic rows (setup included)
     const double lam = r.lo + r.S * u;
     SRL_GDBG(5, lane_id(), lam);
     // ---- velocity change: joint lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
@@ -1248,6 +1424,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     }
     const TL L3 = lane_view(tab);
     trefresh(L3, g, e);
+    SRL_TSTAMP(9);                          // velocity update, integration, sin / cos, forward kinematics
 }
 
 // ------------------------------------------------------------------ env level (mirrors kuka_group.hpp / kuka_env.hpp)

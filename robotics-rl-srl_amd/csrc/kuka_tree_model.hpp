@@ -4,7 +4,7 @@
 //   DoF 8, 9   base_left_finger_joint (8) -> left_base_tip_joint (10); the fixed joint 9 (left_finger -> left_finger_base) is merged
 //   DoF 10, 11 base_right_finger_joint (11) -> right_base_tip_joint (13); fixed joint 12 merged
 // with the POSITION_CONTROL motor the reference commands on every joint each step (kuka.py:167-187), 16 collision spheres on links
-// 5..11 and one friction direction per contact.  `srlhip_kuka_tree_model` of include/srlhip.h has this layout (506 doubles, integer
+// 5..11 and one friction direction per contact.  `srlhip_kuka_tree_model` of include/srlhip.h has this layout (510 doubles, integer
 // fields stored as doubles).  The arm part repeats kuka_core.hpp's table; the gripper part is RECALLED from the SDF file
 // [UNVERIFIED-MEMORY] (pybullet_data is absent here: PARITY UNPINNED) — which is why it is a runtime table:
 // tests/golden/make_kuka_pybullet_golden.py fills it from the real files.
@@ -29,8 +29,11 @@ struct TreeModel {
     double ee_link, ee_point[3], grip_link, grip_point[3], nsphere;
     TreeSphere s[TNS];
     double table_top_z, button_base_z, max_generic_rows, friction;
+    // solver details of the dependency that are recalled, not read — the PyBullet pin decides them as data (include/srlhip.h)
+    double solver_detail, contact_erp, limit_erp, linear_slop;
 };
-constexpr int kTreeModelDoubles = 506;
+constexpr int kTreeModelDoubles = 510;
+constexpr int kDetailAltSweep = 1, kDetailBodyOrder = 2, kDetailFriction2 = 4;       // SRLHIP_KUKA_DETAIL_*
 static_assert(sizeof(TreeModel) == kTreeModelDoubles * sizeof(double), "srlhip_kuka_tree_model layout");
 
 namespace tree_build {
@@ -142,6 +145,7 @@ inline void default_tree_model(TreeModel &m) {
         add_sphere(m, t, nullptr, nullptr, 0, 0, 0.032, 0.010, kMuFinger);
     }
     m.table_top_z = kTableTopZ; m.button_base_z = kButtonBaseZ; m.max_generic_rows = 6; m.friction = 1;
+    m.solver_detail = 0; m.contact_erp = kErp; m.limit_erp = kErp; m.linear_slop = 0.0;
 }
 
 }  // namespace kuka

@@ -48,11 +48,12 @@ EXPORTS = [
 
 
 KUKA_MODEL_DOUBLES = 138
-KUKA_TREE_MODEL_DOUBLES = 506
+KUKA_TREE_MODEL_DOUBLES = 510
+KUKA_DETAIL_ALT_SWEEP, KUKA_DETAIL_BODY_ORDER, KUKA_DETAIL_FRICTION2 = 1, 2, 4
 
 
 def kuka_tree_default_model():
-    """The baked srlhip_kuka_tree_model (full 12-DoF gripper tree) as a flat float64[506] (no GPU needed)."""
+    """The baked srlhip_kuka_tree_model (full 12-DoF gripper tree) as a flat float64[510] (no GPU needed)."""
     t = np.zeros(KUKA_TREE_MODEL_DOUBLES)
     rc = load().srlhip_kuka_tree_default_model(t.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
@@ -315,7 +316,7 @@ class Handle(object):
         self._check(self._lib.srlhip_set_kuka_model(self._h, _ptr(t)), "srlhip_set_kuka_model")
 
     def set_kuka_tree_model(self, table):
-        """Install a full-model table (srlhip_kuka_tree_model: 506 float64) on a KUKA_MODEL_FULL handle — reset() afterwards."""
+        """Install a full-model table (srlhip_kuka_tree_model: 510 float64) on a KUKA_MODEL_FULL handle — reset() afterwards."""
         t = np.ascontiguousarray(table, dtype=np.float64)
         assert t.shape == (KUKA_TREE_MODEL_DOUBLES,)
         self._check(self._lib.srlhip_set_kuka_tree_model(self._h, _ptr(t)), "srlhip_set_kuka_tree_model")

@@ -164,15 +164,19 @@ FLOPS_PER_ENV_STEP_TREE = 6.2e4
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The full model (`srlhip_kuka_tree_model`, 506 doubles): the 12-DoF arm + gripper tree.
-TREE_MODEL_DOUBLES = 506
+# The full model (`srlhip_kuka_tree_model`, 510 doubles): the 12-DoF arm + gripper tree.
+TREE_MODEL_DOUBLES = 510
+# named offsets into the flat table (tests edit single entries)
+TREE_JOINT0, TREE_JOINT_STRIDE, TREE_LOWER, TREE_UPPER = 1, 33, 16, 17
+TREE_MAX_GENERIC_ROWS, TREE_FRICTION, TREE_SOLVER_DETAIL, TREE_CONTACT_ERP, TREE_LIMIT_ERP, TREE_LINEAR_SLOP = 504, 505, 506, 507, 508, 509
 TREE_JOINT_FIELDS = (("parent", 1), ("xyz", 3), ("Rj", 9), ("axis", 3), ("lower", 1), ("upper", 1), ("damping", 1), ("mass", 1), ("com", 3),
                      ("inertia", 6), ("kp", 1), ("max_force", 1), ("max_vel", 1), ("joint_index", 1))          # 33 doubles per DoF
 
 
 def tree_to_dict(table):
-    """flat float64[506] -> {"nd", "joints": [dict x 12], "ee_link", "ee_point", "grip_link", "grip_point", "nsphere",
-    "spheres": [dict(link, c, r, mu) x 16], "table_top_z", "button_base_z", "max_generic_rows", "friction"}"""
+    """flat float64[510] -> {"nd", "joints": [dict x 12], "ee_link", "ee_point", "grip_link", "grip_point", "nsphere",
+    "spheres": [dict(link, c, r, mu) x 16], "table_top_z", "button_base_z", "max_generic_rows", "friction", "solver_detail", "contact_erp",
+    "limit_erp", "linear_slop"}"""
     t = np.asarray(table, dtype=np.float64).reshape(-1)
     assert t.shape == (TREE_MODEL_DOUBLES,)
     k = 1
@@ -189,6 +193,7 @@ def tree_to_dict(table):
     out["spheres"] = [{"link": int(t[k + 6 * i]), "c": t[k + 6 * i + 1:k + 6 * i + 4].copy(), "r": float(t[k + 6 * i + 4]), "mu": float(t[k + 6 * i + 5])} for i in range(16)]
     k += 96
     out["table_top_z"], out["button_base_z"], out["max_generic_rows"], out["friction"] = float(t[k]), float(t[k + 1]), int(t[k + 2]), int(t[k + 3])
+    out["solver_detail"], out["contact_erp"], out["limit_erp"], out["linear_slop"] = int(t[k + 4]), float(t[k + 5]), float(t[k + 6]), float(t[k + 7])
     return out
 
 
@@ -203,6 +208,7 @@ def tree_to_table(m):
     for s in m["spheres"]:
         t.append(float(s["link"])); t.extend(np.asarray(s["c"], dtype=np.float64).tolist()); t.extend([float(s["r"]), float(s["mu"])])
     t.extend([float(m["table_top_z"]), float(m["button_base_z"]), float(m["max_generic_rows"]), float(m["friction"])])
+    t.extend([float(m["solver_detail"]), float(m["contact_erp"]), float(m["limit_erp"]), float(m["linear_slop"])])
     t = np.asarray(t, dtype=np.float64)
     assert t.shape == (TREE_MODEL_DOUBLES,)
     return t

@@ -63,3 +63,16 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=None if _via_cpu() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def per_rank(seconds, device=None):
+    """Every rank's value of `seconds`, in rank order (one all-gather of a float64): bench.py reports the per-rank step times next to
+    their maximum so that a multi-GPU record shows stragglers."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(seconds)]
+    t = torch.tensor([seconds], dtype=torch.float64, device=None if _via_cpu() else device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -16,6 +16,17 @@ from the loaded body through PyBullet's own introspection (srlhip.kuka_model.tre
 / getLinkState at q = 0) and the scene heights (table top / settled button base), plus the rounds 1-2 lumped table
 (`srlhip_kuka_model`, 138 doubles) from the sdf file.
 
+Round 4 — what decides the recalled SOLVER DETAILS (srlhip_kuka_tree_model.solver_detail / contact_erp / limit_erp / linear_slop;
+tests/golden/fit_kuka_pin.py searches them on the oracle against this fixture) is recorded as well:
+  * `settle_q14` / `settle_qd14` [seed][SETTLE_PROBE][14]: joint positions AND velocities after each of the first SETTLE_PROBE
+    stepSimulation calls of every reset() — contact-free, RNG-free steps right after resetJointState: the cleanest trace of the
+    sweep ORDER of the motor rows (an alternating sweep moves the arm joints by 2e-4 rad in the very first step);
+  * `physics_engine_parameters`: p.getPhysicsEngineParameters() as JSON (erp, contactERP / erp2, linear slop, iterations ...);
+  * per recorded step, for up to MAX_CONTACTS button <-> arm contact points: `contact_normal` [.][K][3], `contact_distance`,
+    `contact_normal_force`, `contact_fric1` / `contact_fric2` (lateral friction impulses) and `contact_fric_dir1` / `contact_fric_dir2`
+    — a non-zero second direction says SOLVER_USE_2_FRICTION_DIRECTIONS is in force (NaN where the installed pybullet's
+    getContactPoints does not return the field).
+
 tests/test_kuka_pybullet_pin.py then installs the full table in the oracle (oracle.kuka_clib.set_tree_model) and in the HIP
 stepper (Handle.set_kuka_tree_model), replays the same seeds / actions and compares: joint positions within 1e-4, reward / done
 flags bit-exact — the north-star bar.  Until this script has been run somewhere, that test SKIPS with "PARITY UNPINNED".
@@ -29,6 +40,54 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
+SETTLE_PROBE, MAX_CONTACTS = 10, 6
+
+
+def engine_parameters(p):
+    """p.getPhysicsEngineParameters() as a JSON string ("{}" when the call does not exist in this pybullet)."""
+    import json
+    try:
+        d = p.getPhysicsEngineParameters()
+    except Exception as exc:                     # noqa: BLE001  (older builds: no such call)
+        return json.dumps({"error": str(exc)})
+    return json.dumps({str(k): (v if isinstance(v, (int, float, str)) else str(v)) for k, v in dict(d).items()}, sort_keys=True)
+
+
+def contact_record(p, body_a, body_b, link_a=None):
+    """Up to MAX_CONTACTS contact points as fixed-size arrays: normal[K][3], distance[K], normal_force[K], fric1[K], dir1[K][3],
+    fric2[K], dir2[K][3]; NaN-padded.  getContactPoints tuples: [7] contactNormalOnB, [8] contactDistance, [9] normalForce and,
+    where the build returns them, [10] lateralFriction1, [11] lateralFrictionDir1, [12] lateralFriction2, [13] lateralFrictionDir2."""
+    pts = p.getContactPoints(body_a, body_b, link_a) if link_a is not None else p.getContactPoints(body_a, body_b)
+    K = MAX_CONTACTS
+    rec = {"normal": np.full((K, 3), np.nan), "distance": np.full(K, np.nan), "normal_force": np.full(K, np.nan),
+           "fric1": np.full(K, np.nan), "fric_dir1": np.full((K, 3), np.nan), "fric2": np.full(K, np.nan), "fric_dir2": np.full((K, 3), np.nan)}
+    for i, c in enumerate(list(pts)[:K]):
+        rec["normal"][i] = c[7]; rec["distance"][i] = c[8]; rec["normal_force"][i] = c[9]
+        if len(c) > 13:
+            rec["fric1"][i] = c[10]; rec["fric_dir1"][i] = c[11]; rec["fric2"][i] = c[12]; rec["fric_dir2"][i] = c[13]
+    return rec, len(pts)
+
+
+class SettleProbe(object):
+    """Wraps p.stepSimulation for the duration of a reset(): joint states of `uid_of()` after each of the first SETTLE_PROBE calls."""
+
+    def __init__(self, p, uid_of):
+        self.p, self.uid_of, self.real = p, uid_of, p.stepSimulation
+        self.q, self.qd = [], []
+
+    def __enter__(self):
+        def step(*a, **k):
+            out = self.real(*a, **k)
+            if len(self.q) < SETTLE_PROBE:
+                js = [self.p.getJointState(self.uid_of(), j) for j in range(14)]
+                self.q.append([s[0] for s in js]); self.qd.append([s[1] for s in js])
+            return out
+        self.p.stepSimulation = step
+        return self
+
+    def __exit__(self, *exc):
+        self.p.stepSimulation = self.real
+        return False
 
 
 def main():
@@ -63,13 +122,20 @@ def main():
 
     tree = None
     records = {k: [] for k in ("seed", "episode", "action", "q", "qd", "q14", "qd14", "glider", "gripper", "button_pos", "contact_button",
-                               "contact_table", "reward", "done", "ee_target", "obs", "obs0")}
+                               "contact_table", "reward", "done", "ee_target", "obs", "obs0", "settle_q14", "settle_qd14", "n_contacts",
+                               "contact_normal", "contact_distance", "contact_normal_force", "contact_fric1", "contact_fric_dir1",
+                               "contact_fric2", "contact_fric_dir2")}
+    params_json = None
     arng = np.random.RandomState(1234)
     for seed in (0, 1, 2):
         env = ref.KukaButtonGymEnv(renders=False, is_discrete=True, srl_model="ground_truth", record_data=False)
         env.seed(seed)
         for episode in range(args.episodes):
-            obs = env.reset()
+            with SettleProbe(p, lambda: env._kuka.kuka_uid) as probe:           # (env._kuka is created inside reset(), before its first step)
+                obs = env.reset()
+            records["settle_q14"].append(probe.q); records["settle_qd14"].append(probe.qd)
+            if params_json is None:
+                params_json = engine_parameters(p)
             records["obs0"].append(np.asarray(obs, dtype=np.float64))
             if seed == 0 and episode == 0:
                 # scene heights as PyBullet settles them: top of the table, origin of the button's base link
@@ -96,12 +162,17 @@ def main():
                 records["gripper"].append(list(env.getArmPos())); records["button_pos"].append(list(env.button_pos))
                 records["contact_button"].append(int(len(p.getContactPoints(env.button_uid, env._kuka.kuka_uid, ref.BUTTON_LINK_IDX)) > 0))
                 records["contact_table"].append(int(len(p.getContactPoints(env.table_uid, env._kuka.kuka_uid)) > 0))
+                crec, ncon = contact_record(p, env.button_uid, env._kuka.kuka_uid)
+                records["n_contacts"].append(ncon)
+                for ck, cv in crec.items():
+                    records["contact_" + ck].append(cv)
                 records["reward"].append(float(reward)); records["done"].append(int(done))
                 records["ee_target"].append(list(env._kuka.end_effector_pos)); records["obs"].append(np.asarray(obs, dtype=np.float64))
         env.close()
     out = {k: np.asarray(v) for k, v in records.items()}
     out["model_table"] = kuka_model.to_table(model)
     out["tree_model_table"] = kuka_model.tree_to_table(tree)
+    out["physics_engine_parameters"] = np.array(params_json or "{}")
     out["pybullet_version"] = np.array(str(getattr(p, "getAPIVersion", lambda: "?")()))
     np.savez_compressed(args.out, **out)
     print("wrote {}: {} steps, model table from {}".format(args.out, len(out["action"]), sdf))

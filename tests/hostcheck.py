@@ -88,17 +88,17 @@ def tree_rollout(seeds, T, actions=None, **kw):
 
 def tree_default_model():
     import numpy as np
-    t = np.zeros(506)
+    t = np.zeros(510)
     lib().hostcheck_kuka_tree_default_model(t.ctypes.data_as(ctypes.c_void_p))
     return t
 
 
 def tree_set_model(table):
-    """Runtime full-model table (506 doubles) for tree_rollout(); None -> the baked model."""
+    """Runtime full-model table (510 doubles) for tree_rollout(); None -> the baked model."""
     import numpy as np
     if table is None:
         lib().hostcheck_kuka_tree_set_model(None)
         return
     t = np.ascontiguousarray(table, dtype=np.float64)
-    assert t.shape == (506,)
+    assert t.shape == (510,)
     lib().hostcheck_kuka_tree_set_model(t.ctypes.data_as(ctypes.c_void_p))

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import clib, kuka_clib
-from srlhip import _lib
+from srlhip import _lib, kuka_model
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -65,8 +65,15 @@ def test_fused_rollout_4096_envs():
     h = make(n)
     obs0 = h.reset()
     out = h.rollout(T, actions=actions)
+    kuka_clib.margins_reset()
     ora = kuka_clib.rollout(np.arange(n), T, actions=actions, trace=False)
     check_planes(ora, obs0, out)
+    # Flag parity is bit-exact because no threshold is approached to within the steppers' numerical difference (~1e-11: the same
+    # sums, associated differently; the predicates themselves are evaluated unfused on both sides): the smallest
+    # |value - threshold| behind a contact / distance flag over these 4.1e6 env-steps, recorded by the oracle
+    m = kuka_clib.margins()
+    print("flag margins over {} env-steps: {}".format(n * T, {k: float(v) for k, v in m.items()}))
+    assert min(m.values()) > 1e-10
     f = ora["final_state"]
     assert np.abs(h.get_state(_lib.F_KUKA_Q).T - f[:, 0:7]).max() <= TOL
     assert np.abs(h.get_state(_lib.F_KUKA_QD).T - f[:, 7:14]).max() <= 1e-3
@@ -507,7 +514,7 @@ def test_full_model_joint_limit_rows_and_row_budget():
     jj = np.array([3, 5])
     t[J[jj] + 16] = q_settled[jj] - 0.3
     t[J[jj] + 17] = q_settled[jj] + 0.3
-    t[-2] = 3.0
+    t[kuka_model.TREE_MAX_GENERIC_ROWS] = 3.0
     try:
         h = make(n, seed0=17, random_target=1)
         h.set_kuka_tree_model(t)

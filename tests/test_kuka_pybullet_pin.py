@@ -3,6 +3,10 @@ reward / done flags bit-exact).  The fixture tests/golden/kuka_pybullet_referenc
 tests/golden/make_kuka_pybullet_golden.py on a machine with pybullet==1.8.6 (this repo's build container has none): until
 it exists these tests SKIP — "PARITY UNPINNED" — and the dynamics parity claim stays GPU == oracle only.
 
+The fixture's table also carries the solver details the pin decides as DATA (solver_detail bits, contact_erp, limit_erp,
+linear_slop: tests/golden/fit_kuka_pin.py searches them on the oracle and writes the winner back with --write); fixtures written
+before that section existed are padded with the defaults.
+
 When the fixture exists: its FULL model table (srlhip_kuka_tree_model: the 12-DoF arm + gripper tree — link frames, inertial
 parameters, limits, friction read from the loaded PyBullet body, scene heights) is installed in the oracle and in the HIP
 stepper, the recorded seeds / actions are replayed, and every recorded step is compared (arm AND gripper joints)."""
@@ -22,6 +26,13 @@ def load_fixture():
         pytest.skip("PARITY UNPINNED: tests/golden/kuka_pybullet_reference.npz is absent — run "
                     "tests/golden/make_kuka_pybullet_golden.py where PyBullet is installed and commit its output")
     return np.load(FIXTURE)
+
+
+def fixture_table(fx):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fit_kuka_pin
+    return fit_kuka_pin.table_of(fx)
 
 
 def episodes_of(fx):
@@ -49,7 +60,7 @@ def compare(fx, idx, q, reward, done, gq=None):
 def test_oracle_matches_pybullet():
     fx = load_fixture()
     try:
-        kuka_clib.set_tree_model(fx["tree_model_table"])          # switches the oracle to the full model with PyBullet's own numbers
+        kuka_clib.set_tree_model(fixture_table(fx))               # switches the oracle to the full model with PyBullet's own numbers
         for seed, actions, idx in episodes_of(fx):
             out = kuka_clib.rollout([seed], len(actions), actions=actions[:, None], aux=True)
             compare(fx, idx, out["q"][:, 0], out["reward64"][:, 0], out["done"][:, 0], gq=out["q_all"][:, 0, 7:12])
@@ -66,7 +77,7 @@ def test_hip_stepper_matches_pybullet():
         cfg.num_envs, cfg.seed0, cfg.rng_mode, cfg.auto_reset = 1, seed, _lib.RNG_MT19937, 1
         assert cfg.kuka_model == _lib.KUKA_MODEL_FULL
         h = _lib.Handle(cfg)
-        h.set_kuka_tree_model(fx["tree_model_table"])
+        h.set_kuka_tree_model(fixture_table(fx))                   # model AND solver details from the fixture
         h.reset()
         q, gq, rew, done = [], [], [], []
         for a in actions:

@@ -7,6 +7,7 @@ import pytest
 
 import hostcheck
 from oracle import kuka_clib
+from srlhip import kuka_model
 
 TOL = 1e-9
 
@@ -71,7 +72,7 @@ def test_joint_limit_rows_and_row_budget_with_a_tightened_model():
     q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])              # roughly where the 500 settle steps leave the arm
     t[J[:7] + 16] = q_settled - 0.12                                          # lower limits
     t[J[:7] + 17] = q_settled + 0.12                                          # upper limits
-    t[-2] = 3.0                                                               # max_generic_rows
+    t[kuka_model.TREE_MAX_GENERIC_ROWS] = 3.0                                                               # max_generic_rows
     try:
         kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
         a = run(4, 600, 91, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
@@ -133,7 +134,7 @@ def test_two_button_variant_with_joint_limit_rows():
     jj = np.array([3, 5])
     t[J[jj] + 16] = q_settled[jj] - 0.3
     t[J[jj] + 17] = q_settled[jj] + 0.3
-    t[-2] = 3.0
+    t[kuka_model.TREE_MAX_GENERIC_ROWS] = 3.0
     n, T = 6, 700
     rs = np.random.RandomState(9)
     actions = rs.randint(6, size=(T, n)).astype(np.int32)
@@ -149,6 +150,85 @@ def test_two_button_variant_with_joint_limit_rows():
         hostcheck.tree_set_model(None); kuka_clib.set_full(True)
     lim, normals = a["rows"][:, :, 1] // 1000, a["rows"][:, :, 0]
     assert (lim > 0).mean() > 0.3 and ((lim > 0) & (normals > 0)).sum() > 50
+    assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
+    assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL
+    assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])
+
+
+# ---- solver details as data (round 4): every bit / scalar of srlhip_kuka_tree_model's solver section, kernel source vs oracle
+def detail_table(detail=0, contact_erp=None, limit_erp=None, linear_slop=None, tighten=False, budget=None):
+    t = kuka_clib.get_tree_model().copy()
+    t[kuka_model.TREE_SOLVER_DETAIL] = detail
+    if contact_erp is not None:
+        t[kuka_model.TREE_CONTACT_ERP] = contact_erp
+    if limit_erp is not None:
+        t[kuka_model.TREE_LIMIT_ERP] = limit_erp
+    if linear_slop is not None:
+        t[kuka_model.TREE_LINEAR_SLOP] = linear_slop
+    if tighten:                                                   # arm limits just beyond the settled pose: limit rows appear
+        J = kuka_model.TREE_JOINT0 + kuka_model.TREE_JOINT_STRIDE * np.arange(7)
+        q_settled = np.array([0.0, 0.6, 0.0, -0.86, 0.0, 1.68, 0.0])
+        t[J + kuka_model.TREE_LOWER] = q_settled - 0.12
+        t[J + kuka_model.TREE_UPPER] = q_settled + 0.12
+    if budget is not None:
+        t[kuka_model.TREE_MAX_GENERIC_ROWS] = budget
+    return t
+
+
+@pytest.mark.parametrize("detail", [1, 2, 3, 4, 7])
+def test_solver_detail_bits_free_and_contact_steps(detail):
+    """Alternating sweep (1), body-creation order (2), second friction direction (4) and combinations: the kernel source integrates
+    the same trajectory as the oracle with the same bits, and a DIFFERENT one from the default order (the bits are not no-ops)."""
+    base = run(6, 900, 5, rng_mode=kuka_clib.RNG_MT19937, random_target=True)
+    t = detail_table(detail)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        a = run(6, 900, 5, rng_mode=kuka_clib.RNG_MT19937, random_target=True)
+    finally:
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    normals, fric = a["rows"][:, :, 0].sum(), (a["rows"][:, :, 1] % 1000).sum()
+    assert normals > 10 and fric == (2 if detail & 4 else 1) * normals      # contact steps were part of it; friction rows per contact
+    assert np.abs(a["q"] - base["q"]).max() > 1e-6
+
+
+@pytest.mark.parametrize("detail", [0, 3, 7])
+def test_solver_detail_bits_with_joint_limit_rows(detail):
+    """The general path's LDS loop under the detail bits: limit rows (swept inside the non-contact segment, backwards on even
+    iterations with bit 0) together with contact and friction rows, row budget 3 overflowing (2 with two friction directions...)."""
+    t = detail_table(detail, tighten=True, budget=3)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        a = run(4, 500, 91, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
+    finally:
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    assert ((a["rows"][:, :, 1] // 1000) > 0).sum() > 50
+
+
+def test_erp_and_slop_are_data():
+    t = detail_table(0, contact_erp=0.08, limit_erp=0.1, linear_slop=1e-5, tighten=True)
+    base = run(4, 400, 17, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        a = run(4, 400, 17, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
+    finally:
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    assert np.abs(a["q"] - base["q"]).max() > 1e-6
+
+
+def test_two_button_variant_under_detail_bits():
+    n, T = 4, 900
+    actions = two_button_actions_full(n, T)
+    t = detail_table(7)
+    kw = dict(force_down=False, max_distance=2.0)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        kuka_clib.set_variant(2); hostcheck.set_variant(2)
+        a = kuka_clib.rollout(60 + np.arange(n), T, actions=actions, aux=True, **kw)
+        b = hostcheck.tree_rollout(60 + np.arange(n), T, actions=actions, **kw)
+    finally:
+        kuka_clib.set_variant(0); hostcheck.set_variant(0)
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    assert a["rows"][:, :, 0].sum() > 20
     assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
     assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL
     assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])

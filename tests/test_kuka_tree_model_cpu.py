@@ -16,7 +16,7 @@ def test_product_and_oracle_tables_agree_and_round_trip():
         o = kuka_clib.get_tree_model()
     finally:
         kuka_clib.set_full(False)
-    assert t.shape == (506,) and np.abs(t - o).max() < 1e-15
+    assert t.shape == (510,) and np.abs(t - o).max() < 1e-15
     m = kuka_model.tree_to_dict(t)
     assert m["nd"] == 12 and m["nsphere"] == 16 and m["ee_link"] == 6 and m["grip_link"] == 8
     assert [int(j["joint_index"]) for j in m["joints"]] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 13]
