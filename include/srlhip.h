@@ -54,7 +54,9 @@ extern "C" {
 #define SRLHIP_ENV_KUKA_BUTTON     4  /* KukaButtonGymEnv-v0             */
 #define SRLHIP_ENV_KUKA_MOVING     5  /* KukaMovingButtonGymEnv-v0 (kuka_moving_button_gym_env.py) */
 #define SRLHIP_ENV_KUKA_2BUTTON    6  /* Kuka2ButtonGymEnv-v0 (kuka_2button_gym_env.py): two buttons pressed in order */
-#define SRLHIP_ENV_KUKA_RAND       7  /* KukaRandButtonGymEnv-v0 (kuka_rand_button_gym_env.py): distractor objects as scenery */
+#define SRLHIP_ENV_KUKA_RAND       7  /* KukaRandButtonGymEnv-v0 (kuka_rand_button_gym_env.py:59-71,111-125): the ten dropped objects and the kicked ball are
+                                        * free bodies the arm can push (full model: proxy shapes, table contact + friction, arm-sphere contacts —
+                                        * srlhip_get_state KUKA_BODIES); scenery at rest with the lumped model */
 #define SRLHIP_ENV_LAST            SRLHIP_ENV_KUKA_RAND
 
 /* ---- observation modes: kuka_button_gym_env.py:162-173 ------------------ */
@@ -192,6 +194,7 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_KUKA_OBJECTS   27  /* f64[30] KukaRandButton: (x, y, present) of the ten distractor objects */
 #define SRLHIP_F_KUKA_GRIPPER_Q 28  /* f64[5]  full model: joints 7, 8, 10, 11, 13 (gripper_to_arm, left finger, left tip, right finger, right tip) */
 #define SRLHIP_F_KUKA_GRIPPER_QD 29 /* f64[5]  their velocities */
+#define SRLHIP_F_KUKA_BODIES     30 /* f64[66] KukaRandButtonGymEnv, full model: (x y z vx vy vz) of the ten distractors (draw order) and the ball */
 int srlhip_get_state(srlhip_handle h, int32_t field, void *out);
 int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
 /* Zero-copy hand-off of a field's device array (e.g. to torch via

@@ -114,6 +114,25 @@ def margins():
     return dict(zip(("contact_button", "contact_table", "max_distance", "any_contact"), out))
 
 
+def body_trace(n):
+    """KukaRandButton: arm the free-body trace of the NEXT rollout() call; returns the [n][11][7] array it fills (x y z vx vy vz on per
+    body: ten distractors in draw order, then the ball) with every env's state after the last step."""
+    out = np.zeros((n, 11, 7))
+    clib.lib().kuka_oracle_set_body_trace(_p(out))
+    return out
+
+
+def body_trace_off():
+    clib.lib().kuka_oracle_set_body_trace(None)
+
+
+def rb_drop_check():
+    """Largest distance of any free body, after the reference's literal drop (0.1 m / 0.3 m above Z_TABLE, then the 500 settle steps),
+    from the rest state reset() places it in."""
+    clib.lib().kuka_oracle_rb_drop_check.restype = ctypes.c_double
+    return float(clib.lib().kuka_oracle_rb_drop_check())
+
+
 def _pad(x):
     x = np.asarray(x, dtype=np.float64).reshape(-1)
     out = np.zeros(12)
@@ -159,7 +178,7 @@ def settled(random_target=False, action_joints=False):
 def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, random_target=False, force_down=True,
             shape_reward=False, action_repeat=1, max_distance=0.8, obs_mode=0, rng_mode=RNG_MT19937, auto_reset=True,
             trace=True, aux=False):
-    """aux: also return q_all [T][n][12] (every DoF of the model in use) and rows [T][n][2] (contact-normal / friction rows)."""
+    """aux: also return q_all [T][n][12] (every DoF of the model in use) and rows [T][n][3] (contact-normal rows, friction rows + 1000 x joint-limit rows, arm <-> free-body contact rows)."""
     seeds = np.ascontiguousarray(seeds, dtype=np.int64)
     n = len(seeds)
     od = {0: 3, 1: 14, 2: 17}[obs_mode]
@@ -173,7 +192,7 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
     }
     if aux:
         out["q_all"] = np.zeros((T, n, 12))
-        out["rows"] = np.zeros((T, n, 2), np.int32)
+        out["rows"] = np.zeros((T, n, 3), np.int32)
         clib.lib().kuka_oracle_set_aux_trace(_p(out["q_all"]), _p(out["rows"]))
     act_out = None
     if actions is None:

@@ -34,7 +34,8 @@
 #include "philox.h"
 
 #define N KM_NDOF              /* arm joints (the IK / command surface) */
-#define MAX_ROWS 40
+#define RB_N 11                 /* KukaRandButton free bodies: ten distractors + the ball */
+#define MAX_ROWS 96             /* 15 bank rows + 6 generic + 12 friction + (RandButton) 11 table normals + 22 table friction rows, with slack */
 
 /* optional trace of the commands handed to the arm (wrapper pinning tests) */
 static double *g_trace_ee = NULL, *g_trace_jt = NULL;
@@ -342,6 +343,9 @@ typedef struct {
     double all_pos[2][3];          /* button_all_pos */
     /* KukaRandButtonGymEnv: distractor objects (x, y, present) in draw order */
     double obj_xy[10][2]; int obj_present[10];
+    /* ... as free bodies (round 4): bodies 0..9 = the ten distractors, 10 = the ball (sphere_small.urdf, kuka_rand_button_gym_env.py:71);
+     * translation only (position of the proxy shape's centre, velocity); rb_type 0 duck / 1 lego / 2 cube (boxes), 3 ball */
+    double rb_x[RB_N][3], rb_v[RB_N][3]; int rb_on[RB_N], rb_type[RB_N];
 } kenv;
 
 typedef struct { int random_target, force_down, shape_reward, action_repeat, is_discrete, action_joints, moving, two, rand_objects; double max_distance; } kcfg;
@@ -362,16 +366,83 @@ static double sphere_cylinder(const double c[3], double rad, const double xy[2],
     { double dist = sqrt(er * er + ez * ez); n[0] = rx * er / dist; n[1] = ry * er / dist; n[2] = sz * ez / dist; return dist - rad; }
 }
 
+/* ------------------------------------------------------------------ KukaRandButtonGymEnv free bodies
+ * kuka_rand_button_gym_env.py:59-71 drops ten meshes (duck_vhacd / lego / cube_small, TYPE from the global unseeded np.random) and a
+ * ball on the table, :111-125 kicks the ball at env step 10 (direction again from the unseeded global RNG): free rigid bodies the arm
+ * can push.  Restated with primitive proxies [UNVERIFIED-MEMORY for every size / mass: pybullet_data is absent]:
+ *   duck -> box of its bounding box, half extents (0.05, 0.035, 0.035); lego -> (0.016, 0.032, 0.012); cube_small -> 0.025 cube;
+ *   sphere_small -> sphere r = 0.03; 0.1 kg each; lateral friction 0.5 x the table's 0.5 = 0.25 (arm contacts: the arm sphere's own
+ *   combined coefficient); restitution 0.
+ * Model: each body TRANSLATES (3 DoF; no rotation, so an off-centre push does not turn a box and the ball slides rather than rolls —
+ * with sphere_small's rolling friction both come to rest within centimetres); contacts: arm collision sphere <-> body (normal row +
+ * friction row(s), counted against the same row budget as the button contacts, at most one body per sphere: the lowest-numbered one
+ * in reach), body <-> table top plane (normal row + friction rows along btPlaneSpace1's tangents: y [, x with the second friction
+ * direction]), all rows in the same 150-sweep projected Gauss-Seidel as the arm's.  Not modelled: body <-> body and body <-> button
+ * contacts, the table's edges.  The type is the position hash the renderer already uses; the kick direction comes from a Philox
+ * stream of the env's own key (stream 2, one counter per episode) instead of the unseeded global RNG — reproducible, and the
+ * env's np_random stream is left exactly as the reference consumes it.  Bodies start every episode at rest on the table: the
+ * reference drops them 0.1 m (0.3 m: ball) BEFORE its 500 settle steps, after which they rest (kuka_oracle_rb_drop_check integrates
+ * the literal drop and returns the distance to that rest state: ~1e-16). */
+static const double RB_HALF[3][3] = {{0.05, 0.035, 0.035}, {0.016, 0.032, 0.012}, {0.025, 0.025, 0.025}};
+#define RB_BALL_R 0.03
+#define RB_MASS 0.1
+#define RB_MU_TABLE 0.25
+#define RB_BALL_FORCE 10.0            /* kuka_rand_button_gym_env.py:4 */
+#define RB_KICK_STEP 10               /* :113 */
+static double rb_height(int type) { return type == 3 ? RB_BALL_R : RB_HALF[type][2]; }      /* centre above the supporting plane at rest */
+static int rb_type_of(double ox, double oy) {   /* the reference's type comes from the unseeded global RNG: here a hash of the drawn position */
+    uint64_t bx, by; memcpy(&bx, &ox, 8); memcpy(&by, &oy, 8);
+    return (int)((uint32_t)((bx >> 20) ^ (by >> 20)) % 3u);
+}
+/* kuka_rand_button_gym_env.py:113-120: at env step 10 the ball gets BALL_FORCE along a random horizontal direction of the first
+ * quadrant (abs) plus 1 N upwards, for one simulation step.  The reference takes the direction from the unseeded global np.random;
+ * here it is a function of the episode's own reset draws (the last distractor's position: drawn every reset whether or not the
+ * object is kept): u in [0, 1) from its bits, direction (1 - u, u) / |.| — sqrt and division only, so that every implementation
+ * produces the same bits. */
+static void rb_kick_force(double ox, double oy, double f[3]) {
+    uint64_t bx, by, h; double u, a, b, len;
+    memcpy(&bx, &ox, 8); memcpy(&by, &oy, 8);
+    h = (bx >> 12) ^ (by >> 20) ^ (bx >> 36);
+    u = (double)(h & 0xFFFFFFu) / 16777216.0;
+    a = 1.0 - u; b = u; len = sqrt(a * a + b * b);
+    f[0] = RB_BALL_FORCE * (a / len); f[1] = RB_BALL_FORCE * (b / len); f[2] = 1.0;
+}
+/* signed distance between a sphere (centre c, radius rad) and body k's shape; n = unit normal from the body towards the sphere */
+static double sphere_body(const double c[3], double rad, const double x[3], int type, double n[3]) {
+    double d[3] = {c[0] - x[0], c[1] - x[1], c[2] - x[2]};
+    if (type == 3) {
+        double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (len > 1e-12) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; } else { n[0] = 0; n[1] = 0; n[2] = 1; }
+        return len - RB_BALL_R - rad;
+    } else {
+        const double *h = RB_HALF[type]; double q[3], diff[3], len; int k, inside = 1;
+        for (k = 0; k < 3; k++) { q[k] = d[k] < -h[k] ? -h[k] : (d[k] > h[k] ? h[k] : d[k]); diff[k] = d[k] - q[k]; if (diff[k] != 0.0) inside = 0; }
+        if (inside) {                                /* centre inside the box: exit through the nearest face */
+            int best = 0; double pen = h[0] - fabs(d[0]);
+            for (k = 1; k < 3; k++) if (h[k] - fabs(d[k]) < pen) { pen = h[k] - fabs(d[k]); best = k; }
+            n[0] = n[1] = n[2] = 0; n[best] = d[best] < 0 ? -1.0 : 1.0;
+            return -pen - rad;
+        }
+        len = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+        n[0] = diff[0] / len; n[1] = diff[1] / len; n[2] = diff[2] / len;
+        return len - rad;
+    }
+}
+
 /* ------------------------------------------------------------------ one physics step */
 /* A constraint row.  fric_of >= 0: friction row of contact-normal row `fric_of` (its bounds are +-mu * that row's applied impulse,
  * re-evaluated every sweep: btMultiBodyConstraintSolver::solveSingleIteration). */
-typedef struct { double J[TN]; double Jb; double WJ[TN]; double WJb; double Dinv, rhs, lo, hi, applied, mu; int bsel, fric_of; } row_t;
+typedef struct { double J[TN]; double Jb; double WJ[TN]; double WJb; double Dinv, rhs, lo, hi, applied, mu; int bsel, fric_of;
+                 int obj; double Jo[3]; } row_t;      /* obj >= 0: the row also acts on free body `obj` (KukaRandButton) with Jacobian Jo */
 
-static row_t *add_row(row_t *rows, int *nrows, const double J[TN], double Jb, const double W[TN][TN], double Wb,
-                      double desired_vel, double pos_error_vel, const double qd[TN], double bqd, double lo, double hi, int bsel) {
+static row_t *add_row_obj(row_t *rows, int *nrows, const double J[TN], double Jb, const double W[TN][TN], double Wb,
+                          double desired_vel, double pos_error_vel, const double qd[TN], double bqd, double lo, double hi, int bsel,
+                          int obj, const double Jo[3], const double vo[3]) {
     row_t *r = &rows[(*nrows)++]; int i, j; double D = 0, rel = 0; const int n = ND;
     r->bsel = bsel;                       /* which button's glider the scalar Jb acts on (bqd = that glider's velocity) */
     r->fric_of = -1; r->mu = 0.0;
+    r->obj = obj; r->Jo[0] = r->Jo[1] = r->Jo[2] = 0.0;
+    if (obj >= 0) for (i = 0; i < 3; i++) { r->Jo[i] = Jo[i]; D += Jo[i] * Jo[i] / RB_MASS; rel += Jo[i] * vo[i]; }
     for (i = 0; i < n; i++) { double s = 0; for (j = 0; j < n; j++) s += W[i][j] * J[j]; r->WJ[i] = s; r->J[i] = J[i]; }
     r->Jb = Jb; r->WJb = Wb * Jb;
     for (i = 0; i < n; i++) { D += J[i] * r->WJ[i]; rel += J[i] * qd[i]; }
@@ -380,6 +451,10 @@ static row_t *add_row(row_t *rows, int *nrows, const double J[TN], double Jb, co
     r->rhs = (desired_vel - rel) * r->Dinv + pos_error_vel * r->Dinv;   /* velocityImpulse + penetrationImpulse */
     r->lo = lo; r->hi = hi; r->applied = 0.0;
     return r;
+}
+static row_t *add_row(row_t *rows, int *nrows, const double J[TN], double Jb, const double W[TN][TN], double Wb,
+                      double desired_vel, double pos_error_vel, const double qd[TN], double bqd, double lo, double hi, int bsel) {
+    return add_row_obj(rows, nrows, J, Jb, W, Wb, desired_vel, pos_error_vel, qd, bqd, lo, hi, bsel, -1, NULL, NULL);
 }
 /* btPlaneSpace1(n, p, q): the friction direction Bullet's multibody solver uses (first tangent) */
 static void plane_space1(const double n[3], double p[3]) {
@@ -414,6 +489,8 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
     const double Wb = 1.0 / KM_CAP_MASS, dt = KM_DT;
     const int nb = cfg->two ? 2 : 1, budget = tm_row_budget(m);
     row_t rows[MAX_ROWS]; int nrows = 0, ngeneric = 0, i, k, it, s, b;
+    const int rb_dyn = cfg->rand_objects && n > N;      /* free-body dynamics of KukaRandButton: full model only (the lumped kernels keep the scenery) */
+    double dvo[RB_N][3] = {{0}};
     /* Kuka(small_constraints=False) for random_target and always for Kuka2Button (kuka_2button_gym_env.py:78) */
     const double (*box)[3] = KM_EE_BOX[(cfg->random_target || cfg->two) ? 0 : 1];
     double zeroJ[TN] = {0};
@@ -452,6 +529,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
         }
         for (i = 0; i < n; i++) e->qd[i] += dt * qdd[i];
         for (b = 0; b < nb; b++) *bqd[b] += dt * KM_GRAVITY_Z;
+        if (rb_dyn) for (k = 0; k < RB_N; k++) if (e->rb_on[k]) e->rb_v[k][2] += dt * KM_GRAVITY_Z;
 
         /* -- constraint rows: motors, then joint limits, then contacts (normals, then their friction rows) -- */
         for (i = 0; i < n; i++) {                                   /* joint motors, kuka.py:167-187 (btMultiBodyJointMotor) */
@@ -483,7 +561,8 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
           add_row(rows, &nrows, zeroJ, -1.0, W, Wb, pen_hi > 0 ? -pen_hi / dt : 0.0, pen_hi > 0 ? 0.0 : -pen_hi * m->limit_erp / dt, e->qd, *bqd[b], 0.0, KM_LIMIT_MAX_IMPULSE, b); }
         {
             /* contact normals first; the friction rows are appended after ALL normals (Bullet solves normals, then frictions) */
-            struct { double J[TN], Jb, mu; int normal_row, bsel; } fr[MAX_ROWS]; int nfr = 0;
+            struct { double J[TN], Jb, mu; int normal_row, bsel, obj, table; double Jo[3]; } fr[MAX_ROWS]; int nfr = 0;
+            memset(fr, 0, sizeof fr);
             for (s = 0; s < m->nsphere; s++) {                      /* spheres on the arm / gripper links vs cap, base (of every button), table */
                 double c[3], nrm[3], dist, pt[3], Jv[3][TN], Jw[3][TN], J[TN]; int shape; const int link = m->sphere_link[s];
                 link_point(R, p, link, m->sphere[s], c);
@@ -517,24 +596,74 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
                         for (i = 0; i < n; i++) fr[nfr].J[i] = tdir[0] * Jv[0][i] + tdir[1] * Jv[1][i] + tdir[2] * Jv[2][i];
                         /* the cap slides along z only: the z component of the tangent (side contacts) acts on the glider, like -n_z does for the normal */
                         fr[nfr].Jb = is_cap ? -tdir[2] : 0.0;
-                        fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
+                        fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s]; fr[nfr].obj = -1;
                         nfr++;
                         if (m->solver_detail & TM_DETAIL_FRICTION2) {
                             double t2[3];
                             t2[0] = nrm[1] * tdir[2] - nrm[2] * tdir[1]; t2[1] = nrm[2] * tdir[0] - nrm[0] * tdir[2]; t2[2] = nrm[0] * tdir[1] - nrm[1] * tdir[0];
                             for (i = 0; i < n; i++) fr[nfr].J[i] = t2[0] * Jv[0][i] + t2[1] * Jv[1][i] + t2[2] * Jv[2][i];
                             fr[nfr].Jb = is_cap ? -t2[2] : 0.0;
-                            fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s];
+                            fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = b; fr[nfr].mu = m->sphere_mu[s]; fr[nfr].obj = -1;
                             nfr++;
                         }
+                    }
+                }
+                if (rb_dyn) {                                      /* the sphere against the free bodies: the lowest-numbered body in reach */
+                    for (k = 0; k < RB_N; k++) {
+                        double pos_err_vel, allow, pen, Jo[3];
+                        if (!e->rb_on[k]) continue;
+                        dist = sphere_body(c, m->sphere[s][3], e->rb_x[k], e->rb_type[k], nrm);
+                        if (!(dist < KM_CONTACT_THRESHOLD)) continue;
+                        if (ngeneric < budget) {
+                            ngeneric++;
+                            for (i = 0; i < 3; i++) { pt[i] = c[i] - m->sphere[s][3] * nrm[i]; Jo[i] = -nrm[i]; }
+                            point_jacobian(R, p, link, pt, Jv, Jw);
+                            for (i = 0; i < n; i++) J[i] = nrm[0] * Jv[0][i] + nrm[1] * Jv[1][i] + nrm[2] * Jv[2][i];
+                            pen = dist + m->linear_slop;
+                            allow = pen > 0 ? -pen / dt : 0.0;
+                            pos_err_vel = pen > 0 ? 0.0 : -pen * m->contact_erp / dt;
+                            add_row_obj(rows, &nrows, J, 0.0, W, Wb, allow, pos_err_vel, e->qd, 0.0, 0.0, 1e10, 0, k, Jo, e->rb_v[k]);
+                            g_probe_rows[0]++; g_probe_rows[3]++;
+                            if (m->friction && m->sphere_mu[s] > 0.0) {
+                                double tdir[3], t2[3]; int f, nf = (m->solver_detail & TM_DETAIL_FRICTION2) ? 2 : 1;
+                                plane_space1(nrm, tdir);
+                                t2[0] = nrm[1] * tdir[2] - nrm[2] * tdir[1]; t2[1] = nrm[2] * tdir[0] - nrm[0] * tdir[2]; t2[2] = nrm[0] * tdir[1] - nrm[1] * tdir[0];
+                                for (f = 0; f < nf; f++) {
+                                    const double *td = f ? t2 : tdir;
+                                    for (i = 0; i < n; i++) fr[nfr].J[i] = td[0] * Jv[0][i] + td[1] * Jv[1][i] + td[2] * Jv[2][i];
+                                    fr[nfr].Jb = 0.0; fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = 0; fr[nfr].mu = m->sphere_mu[s];
+                                    fr[nfr].obj = k; fr[nfr].Jo[0] = -td[0]; fr[nfr].Jo[1] = -td[1]; fr[nfr].Jo[2] = -td[2];
+                                    nfr++;
+                                }
+                            }
+                        }
+                        break;                                     /* one body per sphere */
+                    }
+                }
+            }
+            if (rb_dyn) {                                          /* bodies resting on / falling onto the table top */
+                static const double NZ[3] = {0, 0, 1}, T1[3] = {0, -1, 0}, T2[3] = {1, 0, 0};     /* btPlaneSpace1((0,0,1)) and n x t1 */
+                for (k = 0; k < RB_N; k++) {
+                    double dist, pen; int f; const int nf = 2;   /* both tangents, whatever the arm contacts use: a single direction (y) would leave the table frictionless along x — a kicked ball would never stop */
+                    if (!e->rb_on[k]) continue;
+                    dist = e->rb_x[k][2] - rb_height(e->rb_type[k]) - m->table_top_z;
+                    if (!(dist < KM_CONTACT_THRESHOLD)) continue;
+                    pen = dist + m->linear_slop;
+                    add_row_obj(rows, &nrows, zeroJ, 0.0, W, Wb, pen > 0 ? -pen / dt : 0.0, pen > 0 ? 0.0 : -pen * m->contact_erp / dt, e->qd, 0.0,
+                                0.0, 1e10, 0, k, NZ, e->rb_v[k]);
+                    if (m->friction) for (f = 0; f < nf; f++) {
+                        memset(fr[nfr].J, 0, sizeof fr[nfr].J); fr[nfr].Jb = 0.0; fr[nfr].normal_row = nrows - 1; fr[nfr].bsel = 0; fr[nfr].mu = RB_MU_TABLE;
+                        fr[nfr].obj = k; fr[nfr].table = 1; memcpy(fr[nfr].Jo, f ? T2 : T1, sizeof fr[nfr].Jo);
+                        nfr++;
                     }
                 }
             }
             for (k = 0; k < nfr; k++) {
                 /* friction: drive the tangential relative velocity to 0 within +-mu * (normal impulse); no positional term */
-                row_t *r = add_row(rows, &nrows, fr[k].J, fr[k].Jb, W, Wb, 0.0, 0.0, e->qd, *bqd[fr[k].bsel], 0.0, 0.0, fr[k].bsel);
+                row_t *r = add_row_obj(rows, &nrows, fr[k].J, fr[k].Jb, W, Wb, 0.0, 0.0, e->qd, *bqd[fr[k].bsel], 0.0, 0.0, fr[k].bsel,
+                                       fr[k].obj, fr[k].Jo, fr[k].obj >= 0 ? e->rb_v[fr[k].obj] : NULL);
                 r->fric_of = fr[k].normal_row; r->mu = fr[k].mu;
-                g_probe_rows[1]++;
+                if (!fr[k].table) g_probe_rows[1]++;
             }
         }
     }
@@ -563,6 +692,7 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             }
             jdv = r->Jb * dvb[r->bsel];
             for (i = 0; i < n; i++) jdv += r->J[i] * dv[i];
+            if (r->obj >= 0) for (i = 0; i < 3; i++) jdv += r->Jo[i] * dvo[r->obj][i];
             delta = r->rhs - jdv * r->Dinv;
             sum = r->applied + delta;
             if (sum < r->lo) { delta = r->lo - r->applied; r->applied = r->lo; }
@@ -570,12 +700,14 @@ static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const 
             else r->applied = sum;
             for (i = 0; i < n; i++) dv[i] += delta * r->WJ[i];
             dvb[r->bsel] += delta * r->WJb;
+            if (r->obj >= 0) for (i = 0; i < 3; i++) dvo[r->obj][i] += delta * r->Jo[i] / RB_MASS;
         }
     }
     }
     /* -- semi-implicit Euler -- */
     for (i = 0; i < n; i++) { e->qd[i] += dv[i]; e->q[i] += dt * e->qd[i]; }
     for (b = 0; b < nb; b++) { *bqd[b] += dvb[b]; *bq[b] += dt * *bqd[b]; }
+    if (rb_dyn) for (k = 0; k < RB_N; k++) if (e->rb_on[k]) for (i = 0; i < 3; i++) { e->rb_v[k][i] += dvo[k][i]; e->rb_x[k][i] += dt * e->rb_v[k][i]; }
     forward_kinematics(e->q, R, p);
     link_point(R, p, m->grip_link, m->grip_point, e->gripper);
 }
@@ -671,6 +803,13 @@ static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) { 
             e->obj_xy[i][0] = ox; e->obj_xy[i][1] = oy;
             e->obj_present[i] = (ox < bx - 0.1) || (ox > bx + 0.1) || (oy < by - 0.1) || (oy > by + 0.1);
         }
+        /* the bodies at rest on the table (see the free-body section: the reference drops them before its 500 settle steps) */
+        memset(e->rb_v, 0, sizeof e->rb_v);
+        for (i = 0; i < 10; i++) {
+            e->rb_on[i] = e->obj_present[i]; e->rb_type[i] = rb_type_of(e->obj_xy[i][0], e->obj_xy[i][1]);
+            e->rb_x[i][0] = e->obj_xy[i][0]; e->rb_x[i][1] = e->obj_xy[i][1]; e->rb_x[i][2] = model()->table_top_z + rb_height(e->rb_type[i]);
+        }
+        e->rb_on[10] = 1; e->rb_type[10] = 3; e->rb_x[10][0] = 0.25; e->rb_x[10][1] = -0.2; e->rb_x[10][2] = model()->table_top_z + RB_BALL_R;
     }
     e->button_xy[0] = bx; e->button_xy[1] = by; e->button_z = KM_BUTTON_BASE_Z; e->button_speed = speed;
     e->button2_xy[0] = b2x; e->button2_xy[1] = b2y; e->b2q = e->bq; e->b2qd = e->bqd;   /* same urdf, same 500 free steps */
@@ -719,6 +858,11 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
         e->button_xy[1] = e->button_pos[1];
         e->button_z = e->button_pos[2] - KM_BUTTON_DISTANCE_HEIGHT;   /* base re-placed at the recorded cap height */
     }
+    if (cfg->rand_objects && ND > N && e->counter == RB_KICK_STEP) {   /* kuka_rand_button_gym_env.py:111-123: applyExternalForce acts on the next stepSimulation */
+        double f[3]; int k;
+        rb_kick_force(e->obj_xy[9][0], e->obj_xy[9][1], f);
+        for (k = 0; k < 3; k++) e->rb_v[10][k] += f[k] * KM_DT / RB_MASS;
+    }
     if (action < 0) { if (cfg->action_joints) jt = KM_JOINT_POSITIONS; }      /* None: :295-299, no RNG draw */
     else if (cfg->is_discrete) {
         double dv = KM_DELTA_V + k_normal(r, 0.0, KM_NOISE_STD);
@@ -746,10 +890,37 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
 }
 
 static int g_moving = 0, g_two = 0, g_rand = 0;
-/* optional extra traces of the next kuka_oracle_rollout call: q_all [T][n][12] (every DoF), rows [T][n][2] (contact-normal and
- * friction rows created by the step's last stepSimulation); NULL = off */
+/* optional extra traces of the next kuka_oracle_rollout call: q_all [T][n][12] (every DoF), rows [T][n][3] (contact-normal rows, friction rows + 1000 x joint-limit rows,
+ * arm <-> free-body contact rows (KukaRandButton) created by the step's last stepSimulation); NULL = off */
 static double *g_aux_q = NULL; static int32_t *g_aux_rows = NULL;
 void kuka_oracle_set_aux_trace(double *q_all, int32_t *rows) { g_aux_q = q_all; g_aux_rows = rows; }
+/* KukaRandButton: body state of every env at the end of the next kuka_oracle_rollout call, [n][RB_N][7]: x y z vx vy vz on */
+static double *g_aux_bodies = NULL;
+void kuka_oracle_set_body_trace(double *bodies) { g_aux_bodies = bodies; }
+/* the literal drop of the reference's reset (bodies start 0.1 m / 0.3 m above Z_TABLE, then 500 steps): largest distance of any
+ * body of any type from the rest state env_reset places it in */
+static void physics_step(kenv *e, const kcfg *cfg, const double motor[5], const double *joint_targets);
+double kuka_oracle_rb_drop_check(void) {
+    kenv e; kcfg cfg; const double zero[5] = {0, 0, 0, 0, 0}; int i, k; double worst = 0.0;
+    memset(&e, 0, sizeof e); memset(&cfg, 0, sizeof cfg);
+    cfg.rand_objects = 1; cfg.is_discrete = 1; cfg.action_repeat = 1;
+    if (ND <= N) return -1.0;
+    for (i = 0; i < ND; i++) e.q[i] = KM_JOINT_POSITIONS[model()->joint_index[i]];
+    memcpy(e.ee_target, KM_EE_INIT, sizeof e.ee_target);
+    e.button_xy[0] = KM_BUTTON_X; e.button_xy[1] = KM_BUTTON_Y; e.button_z = KM_BUTTON_BASE_Z;
+    for (k = 0; k < RB_N; k++) {
+        e.rb_on[k] = 1; e.rb_type[k] = k == 10 ? 3 : k % 3;
+        e.rb_x[k][0] = 0.3 + 0.04 * k; e.rb_x[k][1] = 0.25; e.rb_x[k][2] = KM_Z_TABLE + (k == 10 ? 0.3 : 0.1);
+    }
+    for (i = 0; i < KM_N_SETTLE_STEPS; i++) physics_step(&e, &cfg, zero, NULL);
+    for (k = 0; k < RB_N; k++) {
+        double d = fabs(e.rb_x[k][2] - (model()->table_top_z + rb_height(e.rb_type[k])));
+        if (d > worst) worst = d;
+        for (i = 0; i < 3; i++) if (fabs(e.rb_v[k][i]) > worst) worst = fabs(e.rb_v[k][i]);
+        if (fabs(e.rb_x[k][0] - (0.3 + 0.04 * k)) > worst) worst = fabs(e.rb_x[k][0] - (0.3 + 0.04 * k));
+    }
+    return worst;
+}
 /* 0: gripper lumped rigidly into link_7 (7 DoF, rounds 1-2), 1: the full 12-DoF gripper tree with per-link contact spheres and
  * friction rows (kuka_tree_model.h) */
 void kuka_oracle_set_full(int full) { g_full = full != 0; model_refresh(); }
@@ -803,7 +974,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             reward = env_step(&env, &cfg, r, a, ca, &done);
             if (q_trace) memcpy(q_trace + row * N, env.q, sizeof(double) * N);
             if (g_aux_q) { memset(g_aux_q + row * TN, 0, sizeof(double) * TN); memcpy(g_aux_q + row * TN, env.q, sizeof(double) * ND); }
-            if (g_aux_rows) { g_aux_rows[2 * row] = g_probe_rows[0]; g_aux_rows[2 * row + 1] = g_probe_rows[1] + 1000 * g_probe_rows[2]; }
+            if (g_aux_rows) { g_aux_rows[3 * row] = g_probe_rows[0]; g_aux_rows[3 * row + 1] = g_probe_rows[1] + 1000 * g_probe_rows[2]; g_aux_rows[3 * row + 2] = g_probe_rows[3]; }
             if (grip_trace) memcpy(grip_trace + row * 3, env.gripper, sizeof(double) * 3);
             ep_ret += reward; ep_len += 1;
             if (done) {
@@ -823,6 +994,10 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             f[19] = env.counter; f[20] = env.n_contacts; f[21] = env.n_outside; f[22] = env.terminated; f[23] = env.button_pos[2];
             if (cfg.moving) f[23] = env.button_pos[1];
             f[24] = env.b2q; f[25] = env.b2qd; f[26] = env.goal_id; f[27] = env.n_contacts2; f[28] = env.button2_xy[0]; f[29] = env.button2_xy[1];
+        }
+        if (g_aux_bodies) {
+            int k, j; double *bd = g_aux_bodies + (size_t)e * RB_N * 7;
+            for (k = 0; k < RB_N; k++) { for (j = 0; j < 3; j++) { bd[7 * k + j] = env.rb_x[k][j]; bd[7 * k + 3 + j] = env.rb_v[k][j]; } bd[7 * k + 6] = env.rb_on[k]; }
         }
         if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
         margin_merge();

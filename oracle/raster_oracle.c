@@ -155,7 +155,8 @@ static void draw(const prim_t *prims, int np, const cam_t *c, int h, int w, int 
 
 /* kuka state per env: q[7], bq, bx, by (kind 4) + b2q, b2x, b2y (kind 6, Kuka2Button); mobile state per env: x, y, tx, ty,
  * t2x, t2y.  kind: 0..3 mobile family, 4 kuka, 6 kuka with two buttons, 7 kuka with the ten RandButton distractors
- * (state [n][40]: the 10 kuka values + (x, y, present) x 10). */
+ * (state [n][40]: the 10 kuka values + (x, y, present) x 10), 8 the same with the distractors and the ball as free bodies
+ * (state [n][106]: those 40 + (x y z vx vy vz) x 11 as srlhip_get_state(KUKA_BODIES) returns them). */
 int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const double *state, uint8_t *img) {
     int e, ncam = multi_view ? 2 : 1, channels = 3 * ncam;
     cam_t cams[2];
@@ -172,7 +173,7 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
     for (e = 0; e < n; e++) {
         prim_t prims[28]; int np = 0, cam;
         if (kind >= 4) {
-            const double *s = state + (kind == 6 ? 13 : kind == 7 ? 40 : 10) * (size_t)e; double R[63], p[21], a[3], b[3]; float jp[7][3]; int i, k;
+            const double *s = state + (kind == 6 ? 13 : kind == 7 ? 40 : kind == 8 ? 106 : 10) * (size_t)e; double R[63], p[21], a[3], b[3]; float jp[7][3]; int i, k;
             const double locs[5][3] = {{0, 0, 0.10}, {0, 0.030, 0.10}, {0, 0.020, 0.255}, {0, -0.030, 0.10}, {0, -0.020, 0.255}};
             float pts[5][3];
             kuka_oracle_fk(s, R, p);
@@ -194,18 +195,25 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
             prims[np++] = mk(P_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], pts[0][0], pts[0][1], pts[0][2], 0.045f, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, pts[1][0], pts[1][1], pts[1][2], pts[2][0], pts[2][1], pts[2][2], 0.015f, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, pts[3][0], pts[3][1], pts[3][2], pts[4][0], pts[4][1], pts[4][2], 0.015f, 1, 0);
-            if (kind == 7) {   /* KukaRandButton scenery: kept distractors on the table + the ball at its drop position */
+            if (kind == 7 || kind == 8) {   /* KukaRandButton: kept distractors + the ball — scenery at rest (7) or free bodies at their centres (8) */
                 const float top = (float)KM_TABLE_TOP_Z;
+                const double *rb = kind == 8 ? s + 40 : NULL;
                 for (i = 0; i < 10; i++) {
-                    double ox = s[10 + 3 * i], oy = s[11 + 3 * i]; uint64_t bx, by; uint32_t type; float x = (float)ox, y = (float)oy;
+                    double ox = s[10 + 3 * i], oy = s[11 + 3 * i]; uint64_t bx, by; uint32_t type; float x = (float)ox, y = (float)oy, z;
                     if (s[12 + 3 * i] == 0.0) continue;
                     memcpy(&bx, &ox, 8); memcpy(&by, &oy, 8);
                     type = (uint32_t)((bx >> 20) ^ (by >> 20)) % 3u;    /* the reference's type comes from the unseeded global RNG */
-                    if (type == 0) prims[np++] = mk(P_CAPSULE, 1.0f, 0.85f, 0.1f, x - 0.015f, y, top + 0.035f, x + 0.015f, y, top + 0.035f, 0.035f, 1, 0);
-                    else if (type == 1) prims[np++] = mk(P_BOX, 0.8f, 0.1f, 0.1f, x, y, top + 0.012f, 0.016f, 0.032f, 0.012f, 0, 1.0f, 0.0f);
-                    else prims[np++] = mk(P_BOX, 0.9f, 0.9f, 0.9f, x, y, top + 0.025f, 0.025f, 0.025f, 0.025f, 0, 1.0f, 0.0f);
+                    z = top + (type == 0 ? 0.035f : type == 1 ? 0.012f : 0.025f);
+                    if (rb) { x = (float)rb[6 * i]; y = (float)rb[6 * i + 1]; z = (float)rb[6 * i + 2]; }
+                    if (type == 0) prims[np++] = mk(P_CAPSULE, 1.0f, 0.85f, 0.1f, x - 0.015f, y, z, x + 0.015f, y, z, 0.035f, 1, 0);
+                    else if (type == 1) prims[np++] = mk(P_BOX, 0.8f, 0.1f, 0.1f, x, y, z, 0.016f, 0.032f, 0.012f, 0, 1.0f, 0.0f);
+                    else prims[np++] = mk(P_BOX, 0.9f, 0.9f, 0.9f, x, y, z, 0.025f, 0.025f, 0.025f, 0, 1.0f, 0.0f);
                 }
-                prims[np++] = mk(P_CAPSULE, 0.9f, 0.2f, 0.2f, 0.25f, -0.2f, top + 0.03f, 0.25f, -0.2f, top + 0.031f, 0.03f, 1, 0);
+                {
+                    float x = 0.25f, y = -0.2f, z = top + 0.03f;
+                    if (rb) { x = (float)rb[60]; y = (float)rb[61]; z = (float)rb[62]; }
+                    prims[np++] = mk(P_CAPSULE, 0.9f, 0.2f, 0.2f, x, y, z, x, y, z + 0.001f, 0.03f, 1, 0);
+                }
             }
         } else {
             const double *s = state + 6 * (size_t)e;

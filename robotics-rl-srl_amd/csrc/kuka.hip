@@ -219,7 +219,7 @@ int kuka_alloc(Handle *h) {
     const size_t n = (size_t)h->n;
     int rc;
     s->nstarts = (!h->cfg.is_discrete && h->cfg.action_joints) ? 0 : h->cfg.is_discrete ? kNumStartsDiscrete : kNumStartsContinuous;
-    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) || (rc = h->dalloc(&s->objs, 30 * n)) ||
+    if ((rc = h->dalloc(&s->d, NDBL * n)) || (rc = h->dalloc(&s->i, NINT * n)) || (rc = h->dalloc(&s->rows, SC_ROWS_TOTAL * n)) || (rc = h->dalloc(&s->objs, 30 * n)) || (rc = h->dalloc(&s->rb, 66 * n)) ||
         (rc = h->dalloc(&s->settled, kStartDoubles)) || (rc = h->dalloc(&s->starts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * kStartDoubles)))
         return rc;
     if ((rc = h->dalloc(&s->model, 1))) return rc;
@@ -387,7 +387,7 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs; int64_t n; int32_t two, rand_objects; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb; int64_t n; int32_t two, rand_objects; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
@@ -395,6 +395,7 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     v->b2q = s->d + D_B2Q * n; v->b2x = s->d + D_B2X * n; v->b2y = s->d + D_B2Y * n;
     v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
     v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
+    v->rb = (v->rand_objects && s->full) ? s->rb : nullptr;      // full model: the distractors and the ball are free bodies, drawn where they are
 }
 
 int kuka_refresh(Handle *h) {
@@ -428,6 +429,9 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_BUTTON2_XY: *dptr = s->d + D_B2X * n; *count = 2; return 0;
         case SRLHIP_F_KUKA_GOAL: *dptr = s->i + I_GOAL * n; *elem = 4; *count = 2; return 0;
         case SRLHIP_F_KUKA_OBJECTS: *dptr = s->objs; *count = 30; return 0;
+        case SRLHIP_F_KUKA_BODIES:
+            if (!s->full || h->cfg.env_kind != SRLHIP_ENV_KUKA_RAND) return h->fail(SRLHIP_EINVAL, "KUKA_BODIES: free bodies exist on full-model KukaRandButtonGymEnv handles only");
+            *dptr = s->rb; *count = 66; return 0;
         case SRLHIP_F_KUKA_GRIPPER_Q:
         case SRLHIP_F_KUKA_GRIPPER_QD:
             // the lumped model has no gripper DoFs: its kernels never write these planes

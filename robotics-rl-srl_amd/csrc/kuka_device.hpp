@@ -45,6 +45,7 @@ struct KukaState {
     double *ttable;     // [tree::kLaneTableDoubles] per-lane constants derived from tmodel (kuka_tree_table_k)
     double *tsettled;   // [kTreeStartDoubles]
     double *tstarts;    // [nstarts][kTreeStartDoubles]
+    double *rb;         // [66][n]  KukaRandButton free bodies, full model: plane 6 k + c = (x y z vx vy vz)[c] of body k (0..9 distractors, 10 the ball)
 };
 
 
@@ -103,6 +104,10 @@ int kuka_group_settle_table(Handle *h, const KukaParams &p);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out);
 int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
+// KukaRandButtonGymEnv (free bodies): kuka_tree_rb.hip
+int kuka_tree_rb_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
+                        uint8_t *d_done, void *d_act_out);
+int kuka_tree_rb_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
 int kuka_tree_settle(Handle *h, const KukaParams &p);     // settled state + start-state table of the installed tree model
 int kuka_tree_refresh(Handle *h, const KukaParams &p);
 

@@ -122,8 +122,10 @@ struct ResetDraw {
     int idx;                        // row of the start-state table (Cartesian action modes)
     double g[kNInitActions];        // joints mode: 7 + N(0,1) of each init action
 };
-template <int NB, class R>
-SRL_HD void reset_draw(const Cfg &cfg, double *objs, int64_t objs_stride, R &rng, ResetDraw &d) {
+struct NoObjectHook { SRL_HD void operator()(int, double, double, bool) const {} };
+// `hook(i, ox, oy, keep)` sees every distractor candidate of KukaRandButtonGymEnv as it is drawn (the tree kernel's free bodies)
+template <int NB, class R, class H = NoObjectHook>
+SRL_HD void reset_draw(const Cfg &cfg, double *objs, int64_t objs_stride, R &rng, ResetDraw &d, H hook = H()) {
 #pragma clang fp contract(off)   // wrapper arithmetic is numpy's: unfused (physics_step keeps the file's setting)
     d.bx = kButtonX; d.by = kButtonY; d.speed = 0.0; d.b2x = kButtonX; d.b2y = kButton2Y2B; d.idx = 0;
     if (cfg.moving) d.speed = 0.001 * (rng.bounded(1) ? 1.0 : -1.0);   // BUTTON_SPEED * np_random.choice([-1, 1]), drawn first
@@ -137,6 +139,7 @@ SRL_HD void reset_draw(const Cfg &cfg, double *objs, int64_t objs_stride, R &rng
             const double ox = 0.5 + 0.15 * rng.uniform(-1, 1), oy = 0 + 0.3 * rng.uniform(-1, 1);
             const bool keep = (ox < d.bx - 0.1) || (ox > d.bx + 0.1) || (oy < d.by - 0.1) || (oy > d.by + 0.1);
             if (objs) { objs[(3 * i) * objs_stride] = ox; objs[(3 * i + 1) * objs_stride] = oy; objs[(3 * i + 2) * objs_stride] = keep ? 1.0 : 0.0; }
+            hook(i, ox, oy, keep);
         }
     }
     if (!cfg.is_discrete && cfg.action_joints) {

@@ -453,7 +453,8 @@ const srl::kuka::TreeModel *tree_model() {
     if (!g_tree_model_set) { srl::kuka::default_tree_model(g_tree_model); g_tree_model_set = true; }
     return &g_tree_model;
 }
-template <int NB, class R>
+double *g_tree_bodies = nullptr;         // KukaRandButton: [n][11][7] body state at the end of the next tree rollout (x y z vx vy vz on)
+template <int NB, int RB, class R>
 void tree_env_body(GroupArgs &a, R &rng) {
     using namespace tree;
     const Cfg &cfg = a.cfg;
@@ -467,9 +468,10 @@ void tree_env_body(GroupArgs &a, R &rng) {
     const bool lead = L.l == 0;
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
+    RBody body; memset(&body, 0, sizeof body);
     const bool joints = !cfg.is_discrete && cfg.action_joints;
-    if (joints) tenv_reset<1, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-    else tenv_reset<2, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+    if (joints) tenv_reset<1, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
+    else tenv_reset<2, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     grp::GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
@@ -489,15 +491,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
             }
             if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = tenv_step<NB>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done);
+        const double reward = tenv_step<NB, RB>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done, &body);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
             if (cfg.auto_reset) {
-                if (joints) tenv_reset<1, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
-                else tenv_reset<2, NB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1);
+                if (joints) tenv_reset<1, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
+                else tenv_reset<2, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
             }
         }
         if (lead) {
@@ -518,14 +520,24 @@ void tree_env_body(GroupArgs &a, R &rng) {
         }
     }
     if (a.ep_stats && lead) { a.ep_stats[3 * (size_t)e_idx] = last_ret; a.ep_stats[3 * (size_t)e_idx + 1] = last_len; a.ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
+    if (RB && g_tree_bodies && L.l < kRbN) {
+        double *bd = g_tree_bodies + ((size_t)e_idx * kRbN + L.l) * 7;
+        for (int k = 0; k < 3; k++) { bd[k] = body.x[k]; bd[3 + k] = body.v[k]; }
+        bd[6] = body.on ? 1.0 : 0.0;
+    }
+}
+template <class R> void tree_env_dispatch(GroupArgs &a, R &r) {
+    if (a.cfg.two) tree_env_body<2, 0>(a, r);
+    else if (a.cfg.rand_objects) tree_env_body<1, 1>(a, r);
+    else tree_env_body<1, 0>(a, r);
 }
 void tree_fiber_body(void *p) {
     GroupArgs &a = *static_cast<GroupArgs *>(p);
     if (a.rng_mode == 2) {            // the lane-group MT19937 of the device kernels over the env's host-side state words (every fiber: its own replica)
         grp::GroupMt r; r.m = a.mt->m; r.win = 0u; r.pos = 0; r.cnt = 0;
-        if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r);
+        tree_env_dispatch(a, r);
     }
-    else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); if (a.cfg.two) tree_env_body<2>(a, r); else tree_env_body<1>(a, r); }
+    else { grp::GroupPhilox r; r.init(a.act.k0, a.act.k1, 0); tree_env_dispatch(a, r); }
 }
 struct TreeSettleArgs { Cfg cfg; double *out; double *scratch; };
 void tree_settle_body(void *p) {
@@ -576,6 +588,7 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
     }
     return 0;
 }
+extern "C" void hostcheck_kuka_tree_set_body_trace(double *bodies) { g_tree_bodies = bodies; }
 extern "C" void hostcheck_kuka_tree_default_model(double *t510) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t510, &m, sizeof m); }
 extern "C" void hostcheck_kuka_tree_set_model(const double *t510) {
     g_tree_model_set = t510 != nullptr;

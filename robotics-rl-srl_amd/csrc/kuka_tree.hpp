@@ -67,6 +67,106 @@ constexpr int SC_J = 0, SC_WJ = kNB * NJ, SC_NBA = 2 * kNB * NJ, SC_NAB = SC_NBA
               SC_S = SC_DEF + kNB * kDefDoubles;                 // + the joints' spatial axes S[12][6] (contact Jacobians)
 constexpr int kTreeScratchDoubles = SC_S + NJ * 6;               // 1056 doubles = 8.25 KiB per env
 
+// ------------------------------------------------------------------ KukaRandButtonGymEnv free bodies (template flag RB)
+// kuka_rand_button_gym_env.py:59-71 drops ten meshes and a ball on the table, :111-125 kicks the ball at env step 10: free bodies the
+// arm can push.  Same restatement as oracle/kuka_oracle.c (free-body section: proxy shapes, masses, what is not modelled): lane
+// k < 11 owns body k (0..9 the distractors in draw order, 10 the ball) — its 3 translational DoFs, its table-contact row and two
+// table-friction rows; arm-sphere <-> body contacts are bank-B rows that also act on the body's velocity change (kept on the
+// owning lane, dv space).  A body the arm does not touch is solved in closed form (its three rows are orthogonal and decoupled:
+// the first sweep is the fixed point of all 150); with an arm contact the body's rows are swept with the arm's.
+constexpr int kRbN = 11, kRbKickStep = 10;
+constexpr double kRbBallR = 0.03, kRbMass = 0.1, kRbMuTable = 0.25, kRbBallForce = 10.0, kRbMaxHeight = 0.07;
+struct RBody {
+    double x[3], v[3];        // centre of the proxy shape, velocity
+    double ox, oy;            // the reset draws of the distractor (type hash; lane 9's feed the kick direction)
+    int type; bool on;        // 0 duck / 1 lego / 2 cube (boxes), 3 ball; lanes >= 11 and dropped candidates: on = false
+};
+SRL_G double rb_half(int type, int axis) {
+    return type == 0 ? (axis == 0 ? 0.05 : 0.035) : type == 1 ? (axis == 0 ? 0.016 : axis == 1 ? 0.032 : 0.012) : 0.025;
+}
+SRL_G double rb_height(int type) { return type == 3 ? kRbBallR : rb_half(type, 2); }
+SRL_G int rb_type_of(double ox, double oy) {       // the reference's type comes from the unseeded global RNG: a hash of the drawn position (as the renderer)
+    unsigned long long bx, by;
+    memcpy(&bx, &ox, 8); memcpy(&by, &oy, 8);
+    return (int)((uint32_t)((bx >> 20) ^ (by >> 20)) % 3u);
+}
+SRL_G void rb_kick_force(double ox, double oy, double f[3]) {
+#pragma clang fp contract(off)
+    unsigned long long bx, by;
+    memcpy(&bx, &ox, 8); memcpy(&by, &oy, 8);
+    const unsigned long long h = (bx >> 12) ^ (by >> 20) ^ (bx >> 36);
+    const double u = (double)(h & 0xFFFFFFull) / 16777216.0;
+    const double a = 1.0 - u, b = u, len = sqrt(a * a + b * b);
+    f[0] = kRbBallForce * (a / len); f[1] = kRbBallForce * (b / len); f[2] = 1.0;
+}
+// signed distance between a sphere and a body's shape; n = unit normal from the body towards the sphere
+SRL_G double sphere_body(const double c[3], double rad, const double x[3], int type, double n[3]) {
+#pragma clang fp contract(off)
+    const double d[3] = {c[0] - x[0], c[1] - x[1], c[2] - x[2]};
+    if (type == 3) {
+        const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (len > 1e-12) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; } else { n[0] = 0; n[1] = 0; n[2] = 1; }
+        return len - kRbBallR - rad;
+    }
+    double q[3], diff[3];
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double h = rb_half(type, k);
+        q[k] = d[k] < -h ? -h : (d[k] > h ? h : d[k]); diff[k] = d[k] - q[k];
+        if (diff[k] != 0.0) inside = false;
+    }
+    if (inside) {                                   // centre inside the box: exit through the nearest face
+        int best = 0; double pen = rb_half(type, 0) - fabs(d[0]);
+#pragma unroll
+        for (int k = 1; k < 3; k++) { const double pk = rb_half(type, k) - fabs(d[k]); if (pk < pen) { pen = pk; best = k; } }
+#pragma unroll
+        for (int k = 0; k < 3; k++) n[k] = k == best ? (d[k] < 0 ? -1.0 : 1.0) : 0.0;
+        return -pen - rad;
+    }
+    const double len = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+    n[0] = diff[0] / len; n[1] = diff[1] / len; n[2] = diff[2] / len;
+    return len - rad;
+}
+// the body's own rows: table normal (0, 0, 1), friction along btPlaneSpace1's tangent (0, -1, 0) and n x t1 = (1, 0, 0); right-hand
+// sides already times the row's 1 / D = the body's mass (every Jacobian is a unit vector acting on the one body)
+struct RbRows { bool hasT, fric; double rhsN, rhsT1, rhsT2, lamN, lamT1, lamT2, dv[3]; };
+SRL_G void rb_rows_setup(const RBody &B, double table_z, double cerp, double slop, bool friction, RbRows &r) {
+#pragma clang fp contract(off)
+    const double inv_dt = 1.0 / kDt, Dinv = 1.0 / (1.0 / kRbMass);
+    const double dist = B.x[2] - rb_height(B.type) - table_z, pen = dist + slop;
+    r.hasT = B.on && dist < kContactThreshold; r.fric = friction;
+    r.rhsN = ((pen > 0 ? -pen * inv_dt : 0.0) - B.v[2]) * Dinv + (pen > 0 ? 0.0 : -pen * cerp * inv_dt) * Dinv;
+    r.rhsT1 = (0.0 - (-B.v[1])) * Dinv; r.rhsT2 = (0.0 - B.v[0]) * Dinv;
+    r.lamN = 0.0; r.lamT1 = 0.0; r.lamT2 = 0.0; r.dv[0] = 0.0; r.dv[1] = 0.0; r.dv[2] = 0.0;
+}
+SRL_G void rb_sweep_normal(RbRows &r) {
+#pragma clang fp contract(off)
+    if (!r.hasT) return;
+    const double Dinv = 1.0 / (1.0 / kRbMass);
+    double delta = r.rhsN - r.dv[2] * Dinv;
+    const double sum = r.lamN + delta;
+    if (sum < 0.0) { delta = 0.0 - r.lamN; r.lamN = 0.0; } else if (sum > 1e10) { delta = 1e10 - r.lamN; r.lamN = 1e10; } else r.lamN = sum;
+    r.dv[2] += delta * 1.0 / kRbMass;
+}
+SRL_G void rb_sweep_friction(RbRows &r) {
+#pragma clang fp contract(off)
+    if (!r.hasT || !r.fric || !(r.lamN > 0.0)) return;
+    const double Dinv = 1.0 / (1.0 / kRbMass), lo = -kRbMuTable * r.lamN, hi = kRbMuTable * r.lamN;
+    {   // t1 = (0, -1, 0)
+        double delta = r.rhsT1 - (-r.dv[1]) * Dinv;
+        const double sum = r.lamT1 + delta;
+        if (sum < lo) { delta = lo - r.lamT1; r.lamT1 = lo; } else if (sum > hi) { delta = hi - r.lamT1; r.lamT1 = hi; } else r.lamT1 = sum;
+        r.dv[1] += delta * -1.0 / kRbMass;
+    }
+    {   // t2 = (1, 0, 0)
+        double delta = r.rhsT2 - r.dv[0] * Dinv;
+        const double sum = r.lamT2 + delta;
+        if (sum < lo) { delta = lo - r.lamT2; r.lamT2 = lo; } else if (sum > hi) { delta = hi - r.lamT2; r.lamT2 = hi; } else r.lamT2 = sum;
+        r.dv[0] += delta * 1.0 / kRbMass;
+    }
+}
+
 // ------------------------------------------------------------------ per-lane constants
 struct TLane {
     int l;
@@ -477,7 +577,8 @@ SRL_G double sweeps_free(const TRows &r, const TRows2 *r2 = nullptr, double *u2_
 
 // ------------------------------------------------------------------ PGS, general path: bank A + bank B
 struct BRow { double cs, lo, hi, mu, lam, jb, inv_diag; int normal; bool on, fric;      // own bank-B row (slot == lane)
-              int bsel; double nBC[3]; };   // Kuka2Button: the glider the row acts on; its scaled couplings to the second button's rows
+              int bsel; double nBC[3];      // Kuka2Button: the glider the row acts on; its scaled couplings to the second button's rows
+              int obj; double Jo[3], jo2m; };   // KukaRandButton: the free body the row also acts on (-1: none), its Jacobian there, Jo . Jo / m
 // bank-A row J: u = clamp01(cs + accA) on lane J, broadcast to both accumulators of every lane.  (The general path resets the
 // own accumulator explicitly instead of in the shadow of the next row: bank-B rows interleave with bank A.)
 template <int J> SRL_G void gen_rowA(const TL &L, const TRows &r, const double *sc, double &accA, double &accB, double &uA) {
@@ -689,12 +790,18 @@ template <int J, bool GEN> SRL_G void d_rowC(const TRows2 &r2, const double nBC[
     if constexpr (GEN) fmac_bcast<J>(st.totB, d, nBC[J - kBM]);
 }
 // bank-B slot s (a wave-uniform index): see gen_rowB for the friction bounds and `part`
-template <int NB> SRL_G void d_rowB(const double *sc, int l, int s, BRow &b, DState &st, bool part, double nCB_s) {
+template <int NB, int RB = 0> SRL_G void d_rowB(const double *sc, int l, int s, BRow &b, DState &st, bool part, double nCB_s, RbRows *rr = nullptr) {
     double lo = b.lo, hi = b.hi;
     const double tot = shfl(b.lam, b.normal);
     const bool skip = b.fric && !(tot > 0.0);
     if (b.fric) { lo = -b.mu * tot; hi = b.mu * tot; }
     double t = b.cs + st.totB;
+    if constexpr (RB) {          // the body's current velocity change along the row (dv space: it lives on the body's lane)
+        const int ob = b.obj >= 0 ? b.obj : 0;
+        const double jo = b.Jo[0] * shfl(rr->dv[0], ob) + b.Jo[1] * shfl(rr->dv[1], ob) + b.Jo[2] * shfl(rr->dv[2], ob);
+        // (the total-sum form excludes the row's own impulse from its residual: the body's dv carries it, so it is taken out again)
+        if (b.obj >= 0) t -= (jo - b.jo2m * b.lam) * b.inv_diag;
+    }
     t = t < lo ? lo : (t > hi ? hi : t);
     if (skip) t = b.lam;
     const double db = shfl(part ? t - b.lam : 0.0, s);
@@ -702,6 +809,11 @@ template <int NB> SRL_G void d_rowB(const double *sc, int l, int s, BRow &b, DSt
     st.totB = fma(sc[SC_NBB + s * GL + l], db, st.totB);     // (the plane holds 0 at [s][s])
     if (part && l == s) b.lam = t;
     if constexpr (NB == 2) st.totC = fma(nCB_s, db, st.totC);
+    if constexpr (RB) {          // ... and the row's impulse change moves it
+        const int ob = (int)shfl((double)b.obj, s);
+        const double j0 = shfl(b.Jo[0], s), j1 = shfl(b.Jo[1], s), j2 = shfl(b.Jo[2], s);
+        if (l == ob) { rr->dv[0] += db * j0 / kRbMass; rr->dv[1] += db * j1 / kRbMass; rr->dv[2] += db * j2 / kRbMass; }
+    }
 }
 // The non-contact rows of one sweep in the order the details ask for.  Creation order of the solver (detail bit 1 clear): motors 0..11,
 // button motor(s), joint limits, button stops (b = 0: lower, upper; b = 1: ...).  Body order (bit 1): per button its stops, then its
@@ -783,6 +895,7 @@ struct GenIn {
     TRows r;                      // the scaled bank-A row of this lane
     double qd_new, bqd, bound_bm;
     TRows2 r2; double bqd2;       // Kuka2Button: the second button's rows (same lanes), its glider velocity
+    const RBody *rb;              // KukaRandButton: the own free body (velocities already carry gravity / the kick)
 };
 // What the general path needs of the step's intermediate results is parked in LDS when it is computed (planes the general path
 // only overwrites at the end of its setup), so that nothing of it stays in registers on the common path:
@@ -792,8 +905,8 @@ constexpr int SC_STASH_W = SC_NBA, SC_STASH_MISC = SC_NAB;
 enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM_PENHI, SM_COUNT,
        SM_NCAP2 = SM_COUNT, SM_NBASE2 = SM_NCAP2 + 3, SM_DCAP2 = SM_NBASE2 + 3, SM_DBASE2, SM_COUNT2 };     // Kuka2Button: the second button's shapes
 static_assert(NJ * GL <= kNArows * GL && SM_COUNT2 * GL <= 2 * kNB * GL, "stash planes");
-struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; };   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
-template <int NB = 1>
+struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; bool bodies_done; double dvo[3]; };   // + KukaRandButton: the own body's velocity change when its rows were swept here   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
+template <int NB = 1, int RB = 0>
 SRL_G GenOut general_path(const GenIn &in) {
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
     // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
@@ -814,6 +927,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     BRow b;
     b.cs = 0.0; b.lo = 0.0; b.hi = 0.0; b.mu = 0.0; b.lam = 0.0; b.jb = 0.0; b.inv_diag = 0.0; b.normal = L.l; b.on = false; b.fric = false;
     b.bsel = 0; b.nBC[0] = 0.0; b.nBC[1] = 0.0; b.nBC[2] = 0.0;
+    b.obj = -1; b.Jo[0] = 0.0; b.Jo[1] = 0.0; b.Jo[2] = 0.0; b.jo2m = 0.0;
     int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
     {
@@ -832,11 +946,19 @@ SRL_G GenOut general_path(const GenIn &in) {
             d_cap2 = sc[SC_STASH_MISC + SM_DCAP2 * GL + L.l]; d_base2 = sc[SC_STASH_MISC + SM_DBASE2 * GL + L.l];
         }
         const bool c_cap2 = NB == 2 && sphere && d_cap2 < kContactThreshold, c_base2 = NB == 2 && sphere && d_base2 < kContactThreshold;
+        // KukaRandButton: the free body this lane's sphere touches (parked in the second button's slots: the env has one button)
+        double n_obj[3] = {0, 0, 1}, d_obj = 1e30; int k_obj = -1;
+        if constexpr (RB) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) n_obj[k] = sc[SC_STASH_MISC + (SM_NCAP2 + k) * GL + L.l];
+            d_obj = sc[SC_STASH_MISC + SM_DCAP2 * GL + L.l]; k_obj = (int)sc[SC_STASH_MISC + SM_DBASE2 * GL + L.l];
+        }
+        const bool c_obj = RB && sphere && k_obj >= 0;
         const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
         // slot of a candidate = number of candidates before it in creation order: limits (joint 0 lower, joint 0 upper, joint 1
         // lower, ...), then contacts (sphere 0 cap, sphere 0 base, [sphere 0 cap 2, sphere 0 base 2,] sphere 1 cap, ...); the first max_gen are kept
         const uint32_t b_lo = ballot(lim_lo), b_hi = ballot(lim_hi), b_cap = ballot(c_cap), b_base = ballot(c_base);
-        const uint32_t b_cap2 = NB == 2 ? ballot(c_cap2) : 0u, b_base2 = NB == 2 ? ballot(c_base2) : 0u;
+        const uint32_t b_cap2 = NB == 2 ? ballot(c_cap2) : RB ? ballot(c_obj) : 0u, b_base2 = NB == 2 ? ballot(c_base2) : 0u;   // (RB: the object candidates take the cap-2 position: cap, base, body per sphere)
         const uint32_t below = (1u << L.l) - 1u;
         const int max_gen = L.max_gen();
         nlim = __builtin_popcount(b_lo) + __builtin_popcount(b_hi);
@@ -862,7 +984,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 d[0] = 0.0; d[1] = pen > 0 ? -pen * inv_dt : 0.0; d[2] = pen > 0 ? 0.0 : -pen * lerp * inv_dt; d[3] = blim; d[4] = 1.0;
             }
         };
-        auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap, int bsel) {
+        auto put_contact = [&](int slot, const double nrm[3], double dist, bool cap, int bsel, int obj = -1) {
             if (slot < max_gen) {
                 double *o = sc + SC_J + slot * NJ, *of = sc + SC_J + (ng + slot) * NJ;
                 double *d = sc + SC_DEF + slot * kDefDoubles, *df = sc + SC_DEF + (ng + slot) * kDefDoubles;
@@ -892,6 +1014,10 @@ SRL_G GenOut general_path(const GenIn &in) {
                 df[0] = cap ? -tdir[2] : 0.0; df[4] = (L.friction() && smu > 0.0) ? 1.0 : 0.0; df[5] = smu;
                 d[6] = (double)bsel; df[6] = (double)bsel;
                 if (nfd == 2) { df2[0] = cap ? -tdir2[2] : 0.0; df2[4] = df[4]; df2[5] = smu; df2[6] = (double)bsel; }
+                if constexpr (RB) {      // body index + 1 in every row of the contact; the contact normal in the friction definitions' free slots
+                    d[7] = (double)(obj + 1); df[7] = (double)(obj + 1); df[1] = nrm[0]; df[2] = nrm[1]; df[3] = nrm[2];
+                    if (nfd == 2) { df2[7] = (double)(obj + 1); df2[1] = nrm[0]; df2[2] = nrm[1]; df2[3] = nrm[2]; }
+                }
             }
         };
         if (lim_lo) put_limit(s_lo, 1.0, pen_lo);
@@ -902,6 +1028,7 @@ SRL_G GenOut general_path(const GenIn &in) {
             if (c_cap2) put_contact(s_cap2, n_cap2, d_cap2, true, 1);
             if (c_base2) put_contact(s_base2, n_base2, d_base2, false, 1);
         }
+        if constexpr (RB) { if (c_obj) put_contact(s_cap2, n_obj, d_obj, false, 0, k_obj); }
         sync_scratch();
     }
     nlim_w = 0; ngen_w = 0;
@@ -942,6 +1069,29 @@ SRL_G GenOut general_path(const GenIn &in) {
         b.bsel = own_bsel;
         const double *Jr = sc + SC_J + own_slot * NJ, *wjr = sc + SC_WJ + own_slot * NJ;
         double diag = own_jb * own_jb * wb, jv = own_jb * (own_bsel ? in.bqd2 : bqd), offb = own_jb * wb * (-bound_bm);
+        if constexpr (RB) {
+            // the row's part on a free body: Jacobian -n (normal row), -t1 / -t2 (its friction rows); the normal sits in the first
+            // friction definition of the contact
+            const int obj = own_on ? (int)myd[7] - 1 : -1;
+            const int gslot = L.l >= 2 * ng ? L.l - 2 * ng : L.l >= ng ? L.l - ng : L.l;
+            const double *nd = sc + SC_DEF + ((gslot + ng) % kNB) * kDefDoubles;
+            const double nrm[3] = {nd[1], nd[2], nd[3]};
+            double dir[3] = {nrm[0], nrm[1], nrm[2]};
+            if (L.l >= ng) {
+                double t1[3];
+                if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); t1[0] = 0.0; t1[1] = -nrm[2] * kk; t1[2] = nrm[1] * kk; }
+                else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); t1[0] = -nrm[1] * kk; t1[1] = nrm[0] * kk; t1[2] = 0.0; }
+                if (L.l >= 2 * ng) cross3(nrm, t1, dir); else { dir[0] = t1[0]; dir[1] = t1[1]; dir[2] = t1[2]; }
+            }
+            b.obj = obj;
+            const int ob = obj >= 0 ? obj : 0;
+            const double vo[3] = {shfl(in.rb->v[0], ob), shfl(in.rb->v[1], ob), shfl(in.rb->v[2], ob)};
+            if (obj >= 0) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { b.Jo[k] = -dir[k]; b.jo2m += b.Jo[k] * b.Jo[k] / kRbMass; jv += b.Jo[k] * vo[k]; }
+                diag += b.jo2m;
+            }
+        }
 #pragma nounroll
         for (int j = 0; j < NJ; j++) {
             const double Jj = own_on ? Jr[j] : 0.0, wj = own_on ? wjr[j] : 0.0;
@@ -1001,7 +1151,12 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double *ds = sc + SC_DEF + s * kDefDoubles;
         return (used && liveC && ds[4] != 0.0 && ds[6] != 0.0) ? -(in.r2.jb * wb * ds[0]) * invC : 0.0;
     };
-    if (detail != 0) {
+    // KukaRandButton: a row of this wavefront acts on a free body -> the bodies' own rows are swept with the arm's (total-sum form:
+    // it takes the body terms in dv space); otherwise the caller solves them in closed form
+    const bool obj_rows_w = RB && wany(b.on && b.obj >= 0);
+    RbRows rr;
+    if constexpr (RB) { if (obj_rows_w) rb_rows_setup(*in.rb, L.table_z(), cerp, slop, L.friction(), rr); }
+    if (detail != 0 || obj_rows_w) {
         // the model's solver details: total-sum formulation (d_rowA / d_rowB above), rows in the order the bits ask for
         DState st;
         st.totA = 0.0; st.totB = 0.0; st.totC = 0.0; st.uC = 0.0;
@@ -1021,11 +1176,13 @@ SRL_G GenOut general_path(const GenIn &in) {
         const int l = L.l;
         for (int it = 0; it < kSolverIters; it++) {
             d_noncontact<NB, true>(r, in.r2, b.nBC, sc, l, st, body_order, alt && !(it & 1), [&](bool fwd) {
-                for (int k = 0; k < nlim_w; k++) { const int s = fwd ? k : nlim_w - 1 - k; d_rowB<NB>(sc, l, s, b, st, shfl(on_lim ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0); }
+                for (int k = 0; k < nlim_w; k++) { const int s = fwd ? k : nlim_w - 1 - k; d_rowB<NB, RB>(sc, l, s, b, st, shfl(on_lim ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0, &rr); }
             });
-            for (int s = 0; s < ngen_w; s++) d_rowB<NB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0);
+            for (int s = 0; s < ngen_w; s++) d_rowB<NB, RB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0, &rr);
+            if constexpr (RB) { if (obj_rows_w) rb_sweep_normal(rr); }       // the bodies' table-contact rows: behind the arm's normals ...
             for (int g = 0; g < ngen_w; g++)
-                for (int f = 1; f <= nfd; f++) { const int s = f * ng + g; d_rowB<NB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0); }
+                for (int f = 1; f <= nfd; f++) { const int s = f * ng + g; d_rowB<NB, RB>(sc, l, s, b, st, shfl(on_con ? 1.0 : 0.0, s) != 0.0, NB == 2 ? nCB_of(s) : 0.0, &rr); }
+            if constexpr (RB) { if (obj_rows_w) rb_sweep_friction(rr); }     // ... and their friction rows behind the arm's
         }
         uA = st.uA; uC = st.uC;
     } else if (nlim_w == 0) {
@@ -1052,6 +1209,8 @@ SRL_G GenOut general_path(const GenIn &in) {
     }
     GenOut out;
     out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0; out.u2 = uC; out.dvb_b2 = 0.0;
+    out.bodies_done = obj_rows_w; out.dvo[0] = 0.0; out.dvo[1] = 0.0; out.dvo[2] = 0.0;
+    if constexpr (RB) { if (obj_rows_w) { out.dvo[0] = rr.dv[0]; out.dvo[1] = rr.dv[1]; out.dvo[2] = rr.dv[2]; } }
     const double pbb = b.on ? b.jb * b.lam * wb : 0.0;
     for (int s = 0; s < kNB; s++) {
         if (!used_slot(s, ngen_w)) continue;
@@ -1067,9 +1226,9 @@ SRL_G GenOut general_path(const GenIn &in) {
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-template <int NB = 1>
+template <int NB = 1, int RB = 0>
 SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
-                         double finger_angle) {
+                         double finger_angle, RBody *rb = nullptr) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
     SRL_TSTAMP(0);                          // (everything between two physics steps: env logic, outputs, action sampling)
@@ -1205,6 +1364,33 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     }
     e.contact_table = gany(sphere && (cc[2] - L.sph(3) - L.table_z() < kContactThreshold)) ? 1 : 0;
     e.contact_button = gany(c_cap) ? 1 : 0;
+    bool c_obj = false;
+    if constexpr (RB) {
+        // KukaRandButton: gravity on the own free body; the own sphere against the bodies (the lowest-numbered one in reach), only
+        // while some sphere of the wavefront is low enough to reach the tallest body
+        RBody &B = *rb;
+        if (B.on) B.v[2] += dt * kGravityZ;
+        double n_obj[3] = {0, 0, 1}, d_obj = 1e30;
+        int k_obj = -1;
+        const double zmax = L.table_z() + kRbMaxHeight + kContactThreshold + 1e-9;
+        if (wany(sphere && cc[2] - L.sph(3) < zmax)) {
+#pragma nounroll
+            for (int k = 0; k < kRbN; k++) {
+                const double code = shfl(B.on ? (double)B.type : -1.0, k);
+                const double xk[3] = {shfl(B.x[0], k), shfl(B.x[1], k), shfl(B.x[2], k)};
+                if (sphere && k_obj < 0 && code >= 0.0) {
+                    double nn[3];
+                    const double d = sphere_body(cc, L.sph(3), xk, (int)code, nn);
+                    if (d < kContactThreshold) { k_obj = k; d_obj = d; n_obj[0] = nn[0]; n_obj[1] = nn[1]; n_obj[2] = nn[2]; }
+                }
+            }
+        }
+        c_obj = k_obj >= 0;
+        double *m = scratch + SC_STASH_MISC + L.l;
+#pragma unroll
+        for (int k = 0; k < 3; k++) m[(SM_NCAP2 + k) * GL] = n_obj[k];
+        m[SM_DCAP2 * GL] = d_obj; m[SM_DBASE2 * GL] = (double)k_obj;
+    }
     // ---- motor target velocity of the own joint (btMultiBodyJointMotor, velocityGain 1, targetVelocity 0)
     double target = L.kp() * (qdes - g.q) * inv_dt;
     target = target > L.maxvel() ? L.maxvel() : target;
@@ -1370,7 +1556,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
     const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
     scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi;
-    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base || c_any2);
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base || c_any2 || c_obj);
     // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
         const bool live = r.S > 0.0 && r.diag > 0.0;
@@ -1386,16 +1572,33 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
             for (int k = 0; k < NJ; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
         }
     }
-    double u, acc_b = 0.0, dvb_b = 0.0, u2 = 0.0, dvb_b2 = 0.0;
+    double u, acc_b = 0.0, dvb_b = 0.0, u2 = 0.0, dvb_b2 = 0.0, dvo[3] = {0.0, 0.0, 0.0};
+    bool bodies_done = false;
     const int detail = L.detail();
     SRL_TSTAMP(6);                          // row setup
     if (!any_generic) u = detail != 0 ? sweeps_free_detail<NB>(r, r2, detail, S_of, lo_of, &u2) : sweeps_free<NB>(r, &r2, &u2);
     else {
         GenIn in;
         in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
-        in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0;
-        const GenOut out = general_path<NB>(in);
+        in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0; in.rb = rb;
+        const GenOut out = general_path<NB, RB>(in);
         u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b; u2 = out.u2; dvb_b2 = out.dvb_b2;
+        if constexpr (RB) { bodies_done = out.bodies_done; dvo[0] = out.dvo[0]; dvo[1] = out.dvo[1]; dvo[2] = out.dvo[2]; }
+    }
+    if constexpr (RB) {
+        // the own free body: rows swept with the arm's above, or (no arm contact in the wavefront) their closed form — table normal,
+        // then the two friction rows: orthogonal rows on one body, the first sweep is the fixed point
+        RBody &B = *rb;
+        if (!bodies_done) {
+            RbRows rr;
+            rb_rows_setup(B, L.table_z(), L.contact_erp(), L.linear_slop(), L.friction(), rr);
+            rb_sweep_normal(rr); rb_sweep_friction(rr);
+            dvo[0] = rr.dv[0]; dvo[1] = rr.dv[1]; dvo[2] = rr.dv[2];
+        }
+        if (B.on) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { B.v[k] += dvo[k]; B.x[k] += dt * B.v[k]; }
+        }
     }
     if (any_generic) { SRL_TSTAMP(8); } else { SRL_TSTAMP(7); }      // the 150 sweeps: free path / steps with generic rows (setup included)
     const double lam = r.lo + r.S * u;
@@ -1463,13 +1666,27 @@ SRL_G void tinitial(Env &e, GState &g, const double *tab) {
 // five init actions is one of 6 (2) noise-free moves, so an episode starts from one of 6^5 (2^5) states, integrated once per
 // handle); START = 1: joint-space actions — the five init actions are integrated here from the settled state; START = 2: Cartesian
 // modes without a table (the CPU harness): the same five moves integrated from the settled state.
-template <int START, int NB = 1, class R>
+struct RbResetHook {          // reset_draw's view of the distractor candidates: lane k keeps candidate k
+    RBody *B; int l;
+    SRL_G void operator()(int i, double ox, double oy, bool keep) const { if (B && i == l) { B->ox = ox; B->oy = oy; B->on = keep; } }
+};
+template <int START, int NB = 1, int RB = 0, class R>
 SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
-                      double *objs, int64_t objs_stride) {
+                      double *objs, int64_t objs_stride, RBody *rb = nullptr) {
 #pragma clang fp contract(off)
     const TL L = lane_view(tab);
     ResetDraw d;
-    reset_draw<NB>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d);
+    RbResetHook hook; hook.B = RB ? rb : nullptr; hook.l = L.l;
+    reset_draw<NB>(cfg, L.l == 0 ? objs : nullptr, objs_stride, rng, d, hook);
+    if constexpr (RB) {
+        // the bodies at rest on the table (the reference drops them before its 500 settle steps: oracle/kuka_oracle.c, free-body section)
+        RBody &B = *rb;
+        if (L.l < 10) { B.type = rb_type_of(B.ox, B.oy); B.x[0] = B.ox; B.x[1] = B.oy; }
+        else if (L.l == 10) { B.type = 3; B.on = true; B.x[0] = 0.25; B.x[1] = -0.2; B.ox = 0.0; B.oy = 0.0; }
+        else { B.type = 2; B.on = false; B.x[0] = 0.0; B.x[1] = 0.0; B.ox = 0.0; B.oy = 0.0; }
+        B.x[2] = L.table_z() + rb_height(B.type);
+        B.v[0] = 0.0; B.v[1] = 0.0; B.v[2] = 0.0;
+    }
     e.motor_on = 0; e.contact_button = 0; e.contact_table = 0;
     tunpack_start(e, g, START ? settled : starts + (int64_t)d.idx * kTreeStartDoubles);
     e.bx = d.bx; e.by = d.by; e.bz = L.base_z();
@@ -1479,7 +1696,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0() + kDeltaTheta * d.g[k];
-            tphysics_step<NB>(e, g, tab, cfg, scratch, motor, true, jt, 0.0);
+            tphysics_step<NB, RB>(e, g, tab, cfg, scratch, motor, true, jt, 0.0, rb);
         }
     } else if constexpr (START == 2) {
         const int base = cfg.is_discrete ? 6 : 2;
@@ -1487,7 +1704,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         double motor[3];
         for (int k = 0; k < kNInitActions; k++) {
             init_action_motor(cfg, rem % base, motor);
-            tphysics_step<NB>(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0);
+            tphysics_step<NB, RB>(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0, rb);
             rem /= base;
         }
     }
@@ -1496,13 +1713,25 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-template <int NB = 1, class R>
-SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done) {
+template <int NB = 1, int RB = 0, class R>
+SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done,
+                       RBody *rb = nullptr) {
+    if constexpr (RB) {
+        // kuka_rand_button_gym_env.py:111-123: at env step 10 the ball is kicked (applyExternalForce: it acts on the next stepSimulation)
+        const double kx = shfl(rb->ox, 9), ky = shfl(rb->oy, 9);
+        if (e.counter == kRbKickStep && lane_id() == 10) {
+#pragma clang fp contract(off)
+            double f[3];
+            rb_kick_force(kx, ky, f);
+#pragma unroll
+            for (int k = 0; k < 3; k++) rb->v[k] += f[k] * kDt / kRbMass;
+        }
+    }
     StepCmd c;
     step_command(e, cfg, rng, action, ca3, c);
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step<NB>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0);
+        tphysics_step<NB, RB>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

@@ -1,0 +1,227 @@
+// kuka_tree_kernels.hpp — the rollout / reset kernel templates of the full-model lane-group stepper, shared by the translation units that
+// instantiate them: kuka_tree.hip (every Kuka env) and kuka_tree_rb.hip (KukaRandButtonGymEnv: RB = 1, the free bodies of
+// kuka_tree.hpp's free-body section ride on lanes 0..10).  Launch geometry of the lane-group family: 16 lanes = one DPP row per env,
+// one wavefront (4 envs) per workgroup — a 4096-env batch is 1024 wavefronts, one per SIMD of the MI355X.
+#pragma once
+#include "kuka_device.hpp"
+#include "kuka_tree.hpp"
+
+namespace srl {
+using namespace kuka;
+
+namespace {
+using tree::TLane;
+using tree::NJ;
+constexpr int kTS = tree::kTreeScratchDoubles, kTStart = tree::kTreeStartDoubles;
+
+// the wavefront's lane-constant table in LDS (kuka_tree.hpp: lane_store / lane_view).  It is derived from the model table ONCE per
+// model (kuka_tree_table_k -> KukaState::ttable in HBM: the ancestor / descendant walks cost ~0.1 ms, far too much for the
+// single-step launches of the per-step API); a launch only copies its 5.6 KB.
+struct LaneId { int l; bool jnt; double q0, base_z; };
+__device__ __forceinline__ void build_lane_table(LaneId &L, const double *ttable, double *tab) {
+    for (int i = threadIdx.x; i < tree::kLaneTableDoubles; i += kGroupBlock) tab[i] = ttable[i];
+    __syncthreads();
+    L.l = (int)(threadIdx.x & (grp::GL - 1)); L.jnt = L.l < NJ;
+    L.q0 = tab[tree::LT_Q0 * grp::GL + L.l]; L.base_z = tab[tree::LT_COUNT * grp::GL + tree::LS_BASEZ];
+}
+// env scalars replicated on the row, the own joint per joint lane
+__device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, const LaneId &L, Env &v, grp::GState &g, bool two) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v.ee[k] = s.d[(D_EE + k) * n + e]; v.bpos[k] = s.d[(D_BPOS + k) * n + e]; v.grip[k] = s.d[(D_GRIP + k) * n + e]; }
+    v.bq = s.d[D_BQ * n + e]; v.bqd = s.d[D_BQD * n + e]; v.bx = s.d[D_BX * n + e]; v.by = s.d[D_BY * n + e];
+    v.bz = s.d[D_BZ * n + e]; v.bspeed = s.d[D_BSPEED * n + e];
+    v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
+    v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
+    v.terminated = s.i[I_TERM * n + e];
+    if (two) {                               // Kuka2ButtonGymEnv: second glider, goal switching
+        v.b2q = s.d[D_B2Q * n + e]; v.b2qd = s.d[D_B2QD * n + e]; v.b2x = s.d[D_B2X * n + e]; v.b2y = s.d[D_B2Y * n + e];
+        v.goal_id = s.i[I_GOAL * n + e]; v.n_contacts2 = s.i[I_NCONTACT2 * n + e]; v.contact_body1 = 0; v.contact_body2 = 0;
+    }
+    const int j = L.jnt ? L.l : 0;
+    g.q = s.d[tree_plane(D_Q, D_GQ, j) * n + e]; g.qd = s.d[tree_plane(D_QD, D_GQD, j) * n + e];
+    g.sq = s.d[tree_plane(D_SQ, D_GSQ, j) * n + e]; g.cq = s.d[tree_plane(D_CQ, D_GCQ, j) * n + e];
+    if (!L.jnt) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
+}
+__device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, const LaneId &L, const Env &v, const grp::GState &g, bool valid, bool two) {
+    if (valid && L.jnt) {
+        s.d[tree_plane(D_Q, D_GQ, L.l) * n + e] = g.q; s.d[tree_plane(D_QD, D_GQD, L.l) * n + e] = g.qd;
+        s.d[tree_plane(D_SQ, D_GSQ, L.l) * n + e] = g.sq; s.d[tree_plane(D_CQ, D_GCQ, L.l) * n + e] = g.cq;
+    }
+    if (valid && L.l == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s.d[(D_EE + k) * n + e] = v.ee[k]; s.d[(D_BPOS + k) * n + e] = v.bpos[k]; s.d[(D_GRIP + k) * n + e] = v.grip[k]; }
+        s.d[D_BQ * n + e] = v.bq; s.d[D_BQD * n + e] = v.bqd; s.d[D_BX * n + e] = v.bx; s.d[D_BY * n + e] = v.by;
+        s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
+        s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
+        s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
+        s.i[I_TERM * n + e] = v.terminated;
+        if (two) {
+            s.d[D_B2Q * n + e] = v.b2q; s.d[D_B2QD * n + e] = v.b2qd; s.d[D_B2X * n + e] = v.b2x; s.d[D_B2Y * n + e] = v.b2y;
+            s.i[I_GOAL * n + e] = v.goal_id; s.i[I_NCONTACT2 * n + e] = v.n_contacts2;
+        }
+    }
+}
+
+// KukaRandButton free bodies: lane k < 11 owns body k.  Dynamic state in the rb planes [(6 k + c)][n] (x y z vx vy vz); the reset draws
+// (x, y, kept) of the ten distractors in the objs planes (srlhip_get_state KUKA_OBJECTS), from which the type hash and the kick
+// direction derive.
+__device__ __forceinline__ void tload_body(const KukaState &s, int64_t n, int e, int l, tree::RBody &B) {
+    const int k = l < tree::kRbN ? l : 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { B.x[c] = s.rb[(6 * k + c) * n + e]; B.v[c] = s.rb[(6 * k + 3 + c) * n + e]; }
+    const int ko = l < 10 ? l : 0;
+    B.ox = s.objs[(3 * ko) * n + e]; B.oy = s.objs[(3 * ko + 1) * n + e];
+    B.on = l < 10 ? s.objs[(3 * ko + 2) * n + e] != 0.0 : l == 10;
+    B.type = l < 10 ? tree::rb_type_of(B.ox, B.oy) : l == 10 ? 3 : 2;
+    if (l >= 10) { B.ox = 0.0; B.oy = 0.0; }
+}
+__device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e, int l, const tree::RBody &B, bool valid) {
+    if (valid && l < tree::kRbN) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s.rb[(6 * l + c) * n + e] = B.x[c]; s.rb[(6 * l + 3 + c) * n + e] = B.v[c]; }
+    }
+}
+
+// T consecutive VecEnv steps per launch.  GIVEN: the caller supplies the actions (a compile-time switch: a possible action load
+// inside the step loop makes every step wait for the previous step's output stores — gfx9 counts loads and stores together).
+template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0>
+__global__ void __launch_bounds__(kGroupBlock)
+kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
+                    float *obs, float *rew, uint8_t *done_out, void *act_out) {
+    using namespace grp;
+    __shared__ double scratch_all[kGroupEnvs][kTS];
+    const int64_t n = p.n;
+    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
+    const bool valid = e_raw < p.n;
+    const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the cross-lane ops)
+    const Cfg &cfg = p.cfg;
+    __shared__ double tab[tree::kLaneTableDoubles];
+    double *scratch = scratch_all[threadIdx.x / GL];
+    LaneId L;
+    build_lane_table(L, s.ttable, tab);
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0) { unsigned long long *pp = tree::tprof_buf(); for (int i = 0; i < tree::kProfSlots; i++) pp[i] = 0; pp[tree::kProfSlots] = __builtin_amdgcn_s_memtime(); }
+#endif
+    const bool lead = L.l == 0 && valid;
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
+    Rng rng0;
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
+    else krng_load<MODE>(rng0, rs, e, p.n, noise ? noise + e : nullptr);
+    Env v = {};
+    GState g;
+    tload(s, n, e, L, v, g, NB == 2);
+    tree::RBody body = {};
+    if constexpr (RB) tload_body(s, n, e, L.l, body);
+    tree::tfk(tree::lane_view(tab), g);
+    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
+    Philox &act = gact.p;
+    const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
+    const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    for (int t = 0; t < T; t++) {
+        const int64_t row = (int64_t)t * n + e;
+        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
+        if constexpr (GIVEN) {
+            if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
+            else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
+        } else {
+            if (cfg.is_discrete) a = gact.next(5);
+            else for (int j = 0; j < adim; j += 2) {
+                uint32_t o[4]; act.block(o);
+                ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
+                if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
+            }
+            if (act_out && lead) {
+                if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
+                else for (int j = 0; j < adim; j++) static_cast<float *>(act_out)[row * adim + j] = ca[j];
+            }
+        }
+        float ca_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
+        bool done;
+        double reward;
+        reward = tree::tenv_step<NB, RB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
+        ep_ret += reward; ep_len += 1; last_reward = reward;
+        if (done) {
+            last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+            if (cfg.auto_reset) {
+                double *objs = valid ? s.objs + e : nullptr;
+                tree::tenv_reset<JOINTS ? 1 : 0, NB, RB>(v, g, tab, cfg, scratch, rng0, s.tstarts, s.tsettled, objs, n, &body);
+                // the start-state loads retire HERE, not at their first use in the next step (where vmcnt(0) would also wait for
+                // the output stores of steps that did not reset)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+        }
+        if (lead) {
+            if (obs) observe(v, cfg, obs + row * od, 1);
+            if (rew) rew[row] = (float)reward;
+            if (done_out) done_out[row] = (uint8_t)done;
+        }
+    }
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 511)) {
+        const unsigned long long *pp = tree::tprof_buf();
+        for (int i = 0; i < tree::kProfSlots; i++) printf("tprof block %d T %d phase %d cycles %llu\n", (int)blockIdx.x, T, i, pp[i]);
+    }
+#endif
+    int e_out = e;
+    asm volatile("" : "+v"(e_out));       // exit-store addresses are recomputed instead of being kept live across the loop
+    tstore(s, n, e_out, L, v, g, valid, NB == 2);
+    if constexpr (RB) tstore_body(s, n, e_out, L.l, body, valid);
+    if (lead) {
+        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e_out] = rng0.p.ctr;
+        else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.store(rs.mt, e_out);
+        else krng_store<MODE>(rng0, rs, e_out);
+        if constexpr (!GIVEN) rs.act_ctr[e_out] = act.ctr;
+        st.ep_return[e_out] = ep_ret; st.ep_length[e_out] = ep_len; st.last_return[e_out] = last_ret; st.last_length[e_out] = last_len;
+        st.n_finished[e_out] = n_fin; st.last_reward[e_out] = last_reward;
+    }
+}
+
+// srlhip_reset: KukaButtonGymEnv.reset by lane groups
+template <int MODE, bool JOINTS, int NB, int RB = 0>
+__global__ void __launch_bounds__(kGroupBlock)
+kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const uint8_t *mask, const double *host_rand, int rand_stride, float *obs) {
+    using namespace grp;
+    __shared__ double scratch_all[kGroupEnvs][kTS];
+    const int64_t n = p.n;
+    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
+    const bool valid = e_raw < p.n && !(mask && !mask[e_raw < p.n ? e_raw : 0]);
+    const int e = e_raw < p.n ? e_raw : p.n - 1;
+    __shared__ double tab[tree::kLaneTableDoubles];
+    LaneId L; build_lane_table(L, s.ttable, tab);
+    const bool lead = L.l == 0 && valid;
+    using Rng = std::conditional_t<MODE == SRLHIP_RNG_PHILOX, GroupPhilox, std::conditional_t<MODE == SRLHIP_RNG_MT19937, GroupMt, typename KRng<MODE>::type>>;
+    // A masked-out env (and the shadow rows of a tail group) must not draw: GroupMt's twist() rewrites the env's 624 state words in
+    // HBM in place while its index is only stored by the lead lane of a VALID env — a masked draw across a twist boundary would
+    // leave the running env with a regenerated block and a stale index.  `valid` is uniform over the 16-lane row, and every
+    // cross-lane operation of the reset is row-local (the rollout kernel already runs tenv_reset under row divergence).
+    if (!valid) return;
+    Rng rng0;
+    if constexpr (MODE == SRLHIP_RNG_PHILOX) rng0.init(rs.key[e], rs.key[n + e], rs.ctr[e]);
+    else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
+    else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
+    Env v = {};
+    GState g;
+    double *objs = s.objs + e;
+    tree::RBody body = {};
+    tree::tenv_reset<JOINTS ? 1 : 0, NB, RB>(v, g, tab, p.cfg, scratch_all[threadIdx.x / GL], rng0, s.tstarts, s.tsettled, objs, n, &body);
+    tstore(s, n, e, L, v, g, valid, NB == 2);
+    if constexpr (RB) tstore_body(s, n, e, L.l, body, valid);
+    if (lead) {
+        if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
+        else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.store(rs.mt, e);
+        else krng_store<MODE>(rng0, rs, e);
+        st.ep_return[e] = 0.0; st.ep_length[e] = 0;
+        if (obs) {
+            const int od = p.cfg.obs_mode == 1 ? 14 : p.cfg.obs_mode == 2 ? 17 : 3;
+            observe(v, p.cfg, obs + (int64_t)e * od, 1);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace srl

@@ -32,7 +32,7 @@
 namespace srl {
 
 // KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs; int64_t n; int32_t two, rand_objects; };     // sq/cq: [7][n]
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb; int64_t n; int32_t two, rand_objects; };     // sq/cq: [7][n]
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
@@ -257,17 +257,23 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
         // KukaRandButtonGymEnv scenery (kuka_rand_button_gym_env.py:60-71): kept distractors resting on the table, and the
         // ball at its drop position.  The reference draws the object TYPE from the global unseeded np.random; here it is a
         // hash of the position: 0 duck (yellow blob), 1 lego (small red brick), 2 cube_small (5 cm cube).
+        // Full model (v.rb): they are free bodies (kuka_tree.hpp, free-body section) and are drawn at their current centres.
         const float top = (float)kTableTopZ;
         for (int i = 0; i < 10; i++) {
             const double ox = v.objs[(3 * i) * n + e], oy = v.objs[(3 * i + 1) * n + e];
             if (v.objs[(3 * i + 2) * n + e] == 0.0) continue;
             const uint32_t type = (uint32_t)(((uint64_t)__double_as_longlong(ox) >> 20) ^ ((uint64_t)__double_as_longlong(oy) >> 20)) % 3u;
-            const float x = (float)ox, y = (float)oy;
-            if (type == 0) set_prim(prims[k++], PRIM_CAPSULE, 1.0f, 0.85f, 0.1f, x - 0.015f, y, top + 0.035f, x + 0.015f, y, top + 0.035f, 0.035f, 1, 0);
-            else if (type == 1) set_prim(prims[k++], PRIM_BOX, 0.8f, 0.1f, 0.1f, x, y, top + 0.012f, 0.016f, 0.032f, 0.012f, 0, 1.0f, 0.0f);
-            else set_prim(prims[k++], PRIM_BOX, 0.9f, 0.9f, 0.9f, x, y, top + 0.025f, 0.025f, 0.025f, 0.025f, 0, 1.0f, 0.0f);
+            float x = (float)ox, y = (float)oy, z = top + (type == 0 ? 0.035f : type == 1 ? 0.012f : 0.025f);
+            if (v.rb) { x = (float)v.rb[(6 * i) * n + e]; y = (float)v.rb[(6 * i + 1) * n + e]; z = (float)v.rb[(6 * i + 2) * n + e]; }
+            if (type == 0) set_prim(prims[k++], PRIM_CAPSULE, 1.0f, 0.85f, 0.1f, x - 0.015f, y, z, x + 0.015f, y, z, 0.035f, 1, 0);
+            else if (type == 1) set_prim(prims[k++], PRIM_BOX, 0.8f, 0.1f, 0.1f, x, y, z, 0.016f, 0.032f, 0.012f, 0, 1.0f, 0.0f);
+            else set_prim(prims[k++], PRIM_BOX, 0.9f, 0.9f, 0.9f, x, y, z, 0.025f, 0.025f, 0.025f, 0, 1.0f, 0.0f);
         }
-        set_prim(prims[k++], PRIM_CAPSULE, 0.9f, 0.2f, 0.2f, 0.25f, -0.2f, top + 0.03f, 0.25f, -0.2f, top + 0.031f, 0.03f, 1, 0);   // sphere_small
+        {
+            float x = 0.25f, y = -0.2f, z = top + 0.03f;
+            if (v.rb) { x = (float)v.rb[60 * n + e]; y = (float)v.rb[61 * n + e]; z = (float)v.rb[62 * n + e]; }
+            set_prim(prims[k++], PRIM_CAPSULE, 0.9f, 0.2f, 0.2f, x, y, z, x, y, z + 0.001f, 0.03f, 1, 0);   // sphere_small
+        }
     }
     return k;
 }

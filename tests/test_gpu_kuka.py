@@ -318,9 +318,13 @@ def test_two_button_env_lumped_model():
 
 def test_rand_button_env():
     """KukaRandButtonGymEnv-v0 on the GPU vs the oracle (reset draws pinned to the reference source,
-    tests/test_kuka_rand_button_golden.py); distractor positions and keep flags are bit-exact."""
+    tests/test_kuka_rand_button_golden.py); distractor positions and keep flags are bit-exact.  Round 4: the ten objects and the
+    kicked ball are free bodies (kuka_rand_button_gym_env.py:59-71,111-125) — arm-sphere contacts, table contact + friction, the
+    step-10 kick: object poses after the 1100 steps (and at a moment when the balls are still rolling) against the oracle."""
     n, T = 128, 1100
-    actions = np.random.RandomState(41).randint(6, size=(T, n)).astype(np.int32)
+    rs = np.random.RandomState(41)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.35] = 4                          # go down often: the gripper reaches the objects lying around the button
     cfg = _lib.default_config(_lib.ENV_KUKA_RAND)
     cfg.num_envs, cfg.seed0, cfg.random_target = n, 80, 1
     h = _lib.Handle(cfg)
@@ -330,15 +334,37 @@ def test_rand_button_env():
     keep = (objs[:, :, 0] < bxy[:, None, 0] - 0.1) | (objs[:, :, 0] > bxy[:, None, 0] + 0.1) | \
            (objs[:, :, 1] < bxy[:, None, 1] - 0.1) | (objs[:, :, 1] > bxy[:, None, 1] + 0.1)
     assert np.array_equal(objs[:, :, 2] > 0, keep) and (np.abs(objs[:, :, 0] - 0.5) <= 0.15).all() and (np.abs(objs[:, :, 1]) <= 0.3).all()
+    bodies0 = h.get_state(_lib.F_KUKA_BODIES).T.reshape(n, 11, 6)
+    assert np.array_equal(bodies0[:, :10, 0], objs[:, :, 0]) and np.array_equal(bodies0[:, :10, 1], objs[:, :, 1])      # at rest where they were drawn
+    assert (bodies0[:, :, 3:] == 0).all() and np.allclose(bodies0[:, 10, :3], [0.25, -0.2, -0.195 + 0.03])
     kuka_clib.set_variant(kuka_clib.VARIANT_RAND)
     try:
         tr = kuka_clib.command_trace(80, 1, np.zeros(1, np.int32), random_target=True)
         assert np.array_equal(kuka_clib.last_objects(), objs[0])                            # env 0: same 20 draws
-        ora = kuka_clib.rollout(80 + np.arange(n), T, actions=actions, random_target=True, trace=False)
+        # (1) 30 steps: the kick of step 10 has happened, the balls are on their way
+        ob30 = kuka_clib.body_trace(n)
+        ora30 = kuka_clib.rollout(80 + np.arange(n), 30, actions=actions[:30], random_target=True, trace=False)
+        kuka_clib.body_trace_off()
+        h30 = _lib.Handle(cfg)                                  # (a handle of its own: the main one keeps its RNG streams for the full run)
+        h30.reset()
+        out30 = h30.rollout(30, actions=actions[:30])
+        b30 = h30.get_state(_lib.F_KUKA_BODIES).T.reshape(n, 11, 6)
+        h30.close()
+        assert np.abs(b30 - ob30[:, :, :6]).max() <= 1e-9
+        assert np.abs(ob30[:, 10, 3:5]).max(axis=1).min() > 0.05 and (ob30[:, 10, 0] > 0.25 + 1e-3).all()         # every ball is moving towards +x, +y
+        assert np.array_equal(out30["reward"], ora30["reward"]) and np.array_equal(out30["done"], ora30["done"])
+        # (2) the full run
+        ob = kuka_clib.body_trace(n)
+        ora = kuka_clib.rollout(80 + np.arange(n), T, actions=actions, random_target=True, trace=False, aux=True)
+        kuka_clib.body_trace_off()
     finally:
         kuka_clib.set_variant(kuka_clib.VARIANT_BUTTON)
     out = h.rollout(T, actions=actions)
     check_planes(ora, obs0, out)
+    bodies = h.get_state(_lib.F_KUKA_BODIES).T.reshape(n, 11, 6)
+    on = ob[:, :, 6] > 0
+    assert np.abs(bodies - ob[:, :, :6])[on].max() <= 1e-9                                   # object poses and velocities after 1100 steps
+    assert ora["rows"][:, :, 2].sum() > 50                                                   # arm <-> body contact rows were part of it
     ret, length, fin = h.episode_stats()
     assert np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32)) and fin.min() >= 1
     h.close()

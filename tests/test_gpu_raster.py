@@ -131,15 +131,32 @@ def test_two_button_images_match_oracle():
 
 
 def test_rand_button_images_match_oracle():
-    """KukaRandButtonGymEnv scene: the kept distractors and the ball are rendered as scenery."""
+    """KukaRandButtonGymEnv scene: the kept distractors and the ball are free bodies of the full model and are drawn where they are —
+    at reset (at rest where they were drawn) and after 40 steps (the balls kicked at step 10 have moved); lumped model: scenery."""
     n = 32
     cfg = _lib.default_config(_lib.ENV_KUKA_RAND)
     cfg.num_envs, cfg.seed0 = n, 6
     cfg.obs_mode, cfg.img_h, cfg.img_w = _lib.OBS_RAW_PIXELS, 64, 64
     h = _lib.Handle(cfg)
     obs = h.reset()
-    state = np.concatenate([kuka_state(h), h.get_state(_lib.F_KUKA_OBJECTS).T], axis=1)
-    assert_images_equal(obs, raster_clib.render(7, state, 64, 64))
-    plain = raster_clib.render(4, state[:, :10], 64, 64)
+
+    def state8():
+        return np.concatenate([kuka_state(h), h.get_state(_lib.F_KUKA_OBJECTS).T, h.get_state(_lib.F_KUKA_BODIES).T], axis=1)
+    st0 = state8()
+    assert_images_equal(obs, raster_clib.render(8, st0, 64, 64))
+    assert_images_equal(obs, raster_clib.render(7, st0[:, :40], 64, 64))       # at rest = the scenery rendering
+    plain = raster_clib.render(4, st0[:, :10], 64, 64)
     assert (obs != plain).reshape(n, -1).any(1).all()           # every env shows at least the ball
+    out = h.rollout(40, actions=np.random.RandomState(3).randint(4, size=(40, n)).astype(np.int32))
+    st = state8()
+    assert np.abs(st[:, 40 + 60] - 0.25).min() > 1e-3           # every ball has left its drop position
+    assert_images_equal(out["obs"][-1], raster_clib.render(8, st, 64, 64))
+    assert (out["obs"][-1] != raster_clib.render(7, st[:, :40], 64, 64)).any()
+    h.close()
+    cfg.kuka_model = _lib.KUKA_MODEL_LUMPED
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    assert_images_equal(obs, raster_clib.render(7, np.concatenate([kuka_state(h), h.get_state(_lib.F_KUKA_OBJECTS).T], axis=1), 64, 64))
+    with pytest.raises(_lib.SrlHipError):
+        h.get_state(_lib.F_KUKA_BODIES)
     h.close()

@@ -232,3 +232,36 @@ def test_two_button_variant_under_detail_bits():
     assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
     assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["final_state"][:, 24:26] - b["final_state"][:, 24:26]).max() <= TOL
     assert np.array_equal(a["final_state"][:, 26:28], b["final_state"][:, 26:28])
+
+
+# ---- KukaRandButtonGymEnv free bodies (round 4)
+def test_rand_button_free_bodies():
+    """The ten distractors and the kicked ball as free bodies (kuka_rand_button_gym_env.py:59-71,111-125): arm-sphere <-> body contact
+    rows (normal + friction, acting on arm AND body), the bodies' table-contact and table-friction rows, the seeded kick — kernel
+    source vs oracle, default solver details and all bits; object poses compared at the end of the run."""
+    import ctypes
+    n, T, seed0 = 6, 500, 3
+    rs = np.random.RandomState(seed0)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.5] = 4
+    assert kuka_clib.rb_drop_check() < 1e-12                     # the literal drop of the reference's reset ends in the rest state reset() uses
+    for detail in (0, 7):
+        t = detail_table(detail)
+        hb = np.zeros((n, 11, 7))
+        try:
+            kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+            kuka_clib.set_variant(3); hostcheck.set_variant(3)
+            ob = kuka_clib.body_trace(n)
+            hostcheck.lib().hostcheck_kuka_tree_set_body_trace(hb.ctypes.data_as(ctypes.c_void_p))
+            kw = dict(rng_mode=kuka_clib.RNG_MT19937, random_target=True)
+            a = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions, aux=True, **kw)
+            b = hostcheck.tree_rollout(seed0 + np.arange(n), T, actions=actions, **kw)
+        finally:
+            kuka_clib.body_trace_off(); hostcheck.lib().hostcheck_kuka_tree_set_body_trace(None)
+            kuka_clib.set_variant(0); hostcheck.set_variant(0)
+            hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+        assert a["rows"][:, :, 2].sum() > 50                     # arm <-> body contact rows
+        assert np.array_equal(a["reward"], b["reward"]) and np.array_equal(a["done"], b["done"])
+        assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["gripper"] - b["gripper"]).max() <= TOL
+        assert np.abs(ob - hb).max() <= TOL
+        assert (ob[:, 10, 0] > 0.25 + 1e-3).any() and (ob[:, 10, 1] > -0.2 + 1e-3).any()      # kicked balls have moved towards +x, +y (they stop within ~40 steps)
