@@ -198,10 +198,12 @@ def pixel_cpu_baseline(enc, env, budget_s=3.0, phys=None):
     h = env.h
     state = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_BUTTON_Q)[0][:, None],
                             h.get_state(_lib.F_KUKA_BUTTON_XY).T], axis=1)[:n]
-    frames = raster_clib.render(4, state, 64, 64)
+    gq = h.get_state(_lib.F_KUKA_GRIPPER_Q).T[:n] if h.cfg.kuka_model == _lib.KUKA_MODEL_FULL else None       # full model: fingers drawn from their joints
+    kuka_clib.set_full(gq is not None)
+    frames = raster_clib.render(4, state, 64, 64, gripper_q=gq)
     t0 = time.perf_counter(); reps = 0
     while time.perf_counter() - t0 < budget_s:
-        frames = raster_clib.render(4, state, 64, 64); reps += 1
+        frames = raster_clib.render(4, state, 64, 64, gripper_q=gq); reps += 1
     raster_rate = reps * n / (time.perf_counter() - t0)
     cpu_enc = SRLNeuralNetwork(enc.state_dim, cuda=False, img_shape=(64, 64), state_dict=enc.model.state_dict(), backend="torch")
     cpu_enc.getStates(frames[:64])
@@ -315,6 +317,17 @@ def bench_pixels(args, rank, local_rank, world, dev, K=None, W=None, cpu=True, p
                                      "stepper_and_launch_gaps": step_ms - raster_ms - (enc_ms or 0.0)},
                        "x_vs_published_250fps_cpu": value / PUBLISHED_REFERENCE_FPS},
             "roofline": roofline}
+    if world == 1 and rank == 0 and S == 64:
+        # HBM bytes per launch of the two pixel-path kernels, re-measured now: this command as child processes under rocprofv3 --pmc
+        # (separate FETCH_SIZE / WRITE_SIZE passes, MI355X_MICROARCH.md's HBM section), FETCH_SIZE x2 + WRITE_SIZE in KiB
+        t_r = live_traffic(args, "kuka_pixels", "raster_k")
+        t_e = live_traffic(args, "kuka_pixels", "encoder_fwd_k") if hip_encoder else None
+        src = "measured in this run: the same command re-run as child processes under rocprofv3 --pmc (FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
+        if t_r is not None:
+            raster_roof["traffic"] = t_r; raster_roof["traffic_source"] = src
+            raster_roof["traffic_over_algorithmic"] = t_r / float(n * S * S * 3)
+        if t_e is not None and hip_encoder:
+            roofline["traffic"] = t_e; roofline["traffic_source"] = src
     if world > 1:      # stragglers: every rank's own time for the K steps (value uses the maximum)
         line["config"]["ms_per_step_ranks"] = {"min": min(dt_ranks) * 1e3 / K, "max": max(dt_ranks) * 1e3 / K, "all": [x * 1e3 / K for x in dt_ranks]}
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline and S == 64:

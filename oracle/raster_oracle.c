@@ -19,7 +19,8 @@
 
 #include "kuka_model.h"
 
-void kuka_oracle_fk(const double *q, double *R63, double *p21);
+void kuka_oracle_fk(const double *q, double *R63, double *p21);     /* (writes 9 / 3 doubles per link of the model in use: 7 or 12 links) */
+int kuka_oracle_get_full(void);
 
 enum { P_PLANE = 0, P_BOX = 1, P_CYL = 2, P_CAPSULE = 3 };
 typedef struct { int type; float col[3]; float a[3]; float b[3]; float rad, cs, sn; } prim_t;
@@ -159,7 +160,13 @@ static void draw(const prim_t *prims, int np, const cam_t *c, int h, int w, int 
  * (state [n][106]: those 40 + (x y z vx vy vz) x 11 as srlhip_get_state(KUKA_BODIES) returns them). */
 int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const double *state, uint8_t *img) {
     int e, ncam = multi_view ? 2 : 1, channels = 3 * ncam;
+    /* kind | 16 (Kuka kinds): every state row carries 5 more doubles at its end — q of the gripper joints 7, 8, 10, 11, 13 — and the
+     * gripper is drawn from them with the full model's link frames (needs the oracle in full-model mode); without the flag the
+     * gripper is drawn welded to link 7 (the lumped model of rounds 1-2). */
+    const int fingers = kind >= 4 && (kind & 16) != 0;
     cam_t cams[2];
+    kind &= ~16;
+    if (fingers && !kuka_oracle_get_full()) return -1;
     if (kind >= 4) {
         const double t1[3] = {0.316, -0.2, -0.1}, t2[3] = {0.316, 0.316, -0.105};
         cams[0] = camera(t1, 1.1, 145, -36, 0, 60); cams[1] = camera(t2, 1.05, 32, -13, 0, 60);
@@ -173,10 +180,12 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
     for (e = 0; e < n; e++) {
         prim_t prims[28]; int np = 0, cam;
         if (kind >= 4) {
-            const double *s = state + (kind == 6 ? 13 : kind == 7 ? 40 : kind == 8 ? 106 : 10) * (size_t)e; double R[63], p[21], a[3], b[3]; float jp[7][3]; int i, k;
+            const int row = (kind == 6 ? 13 : kind == 7 ? 40 : kind == 8 ? 106 : 10) + (fingers ? 5 : 0);
+            const double *s = state + row * (size_t)e; double R[108], p[36], a[3], b[3], q12[12]; float jp[7][3]; int i, k;
             const double locs[5][3] = {{0, 0, 0.10}, {0, 0.030, 0.10}, {0, 0.020, 0.255}, {0, -0.030, 0.10}, {0, -0.020, 0.255}};
             float pts[5][3];
-            kuka_oracle_fk(s, R, p);
+            for (i = 0; i < 12; i++) q12[i] = i < 7 ? s[i] : fingers ? s[row - 5 + (i - 7)] : 0.0;
+            kuka_oracle_fk(q12, R, p);
             for (i = 0; i < 7; i++) for (k = 0; k < 3; k++) jp[i][k] = (float)p[3 * i + k];
             for (i = 0; i < 5; i++) {
                 for (k = 0; k < 3; k++) { a[k] = p[18 + k] + R[54 + 3 * k] * locs[i][0] + R[54 + 3 * k + 1] * locs[i][1] + R[54 + 3 * k + 2] * locs[i][2]; pts[i][k] = (float)a[k]; }
@@ -192,9 +201,21 @@ int raster_oracle_render(int kind, int n, int h, int w, int multi_view, const do
             }
             prims[np++] = mk(P_CAPSULE, 0.35f, 0.35f, 0.38f, (float)KM_BASE_POS[0], (float)KM_BASE_POS[1], (float)KM_BASE_POS[2], jp[0][0], jp[0][1], jp[0][2], 0.07f, 1, 0);
             for (i = 0; i < 6; i++) prims[np++] = mk(P_CAPSULE, 1.0f, 0.45f, 0.05f, jp[i][0], jp[i][1], jp[i][2], jp[i + 1][0], jp[i + 1][1], jp[i + 1][2], 0.06f, 1, 0);
+            if (fingers) {   /* full model: body capsule up to 0.05 above the gripper body's origin, finger link -> tip joint, tip link 0.045 long */
+                int side;
+                for (k = 0; k < 3; k++) a[k] = p[21 + k] + R[63 + 3 * k + 2] * 0.05;
+                prims[np++] = mk(P_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], (float)a[0], (float)a[1], (float)a[2], 0.045f, 1, 0);
+                for (side = 0; side < 2; side++) {
+                    const int f = 8 + 2 * side, t = f + 1;
+                    prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, (float)p[3 * f], (float)p[3 * f + 1], (float)p[3 * f + 2], (float)p[3 * t], (float)p[3 * t + 1], (float)p[3 * t + 2], 0.012f, 1, 0);
+                    for (k = 0; k < 3; k++) b[k] = p[3 * t + k] + R[9 * t + 3 * k + 2] * 0.045;
+                    prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, (float)p[3 * t], (float)p[3 * t + 1], (float)p[3 * t + 2], (float)b[0], (float)b[1], (float)b[2], 0.010f, 1, 0);
+                }
+            } else {
             prims[np++] = mk(P_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], pts[0][0], pts[0][1], pts[0][2], 0.045f, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, pts[1][0], pts[1][1], pts[1][2], pts[2][0], pts[2][1], pts[2][2], 0.015f, 1, 0);
             prims[np++] = mk(P_CAPSULE, 0.10f, 0.10f, 0.10f, pts[3][0], pts[3][1], pts[3][2], pts[4][0], pts[4][1], pts[4][2], 0.015f, 1, 0);
+            }
             if (kind == 7 || kind == 8) {   /* KukaRandButton: kept distractors + the ball — scenery at rest (7) or free bodies at their centres (8) */
                 const float top = (float)KM_TABLE_TOP_Z;
                 const double *rb = kind == 8 ? s + 40 : NULL;

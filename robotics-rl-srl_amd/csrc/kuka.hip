@@ -387,7 +387,7 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb; int64_t n; int32_t two, rand_objects; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; const kuka::TreeModel *tm; int64_t n; int32_t two, rand_objects; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
@@ -396,6 +396,8 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     v->n = (int64_t)n; v->two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
     v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
     v->rb = (v->rand_objects && s->full) ? s->rb : nullptr;      // full model: the distractors and the ball are free bodies, drawn where they are
+    // full model: the gripper is drawn from its own joints (gripper_to_arm, fingers, tips) through the installed table
+    v->tm = s->full ? s->tmodel : nullptr; v->gsq = s->d + D_GSQ * n; v->gcq = s->d + D_GCQ * n;
 }
 
 int kuka_refresh(Handle *h) {

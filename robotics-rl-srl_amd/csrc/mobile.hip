@@ -28,6 +28,7 @@
 namespace srl {
 
 namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;
 
@@ -311,8 +312,7 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
             if (obs) {
                 if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
                 else {
-                    __builtin_nontemporal_store(o0, obs + 2 * row);
-                    __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+                    __builtin_nontemporal_store(f32x2{o0, o1}, reinterpret_cast<f32x2 *>(obs + 2 * row));       // one 8-byte store per lane: a wavefront row is 512 contiguous bytes
                 }
             }
             if (rew) __builtin_nontemporal_store((float)reward, rew + row);
@@ -428,8 +428,7 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
                 if (obs) {
                     if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
                     else {
-                        __builtin_nontemporal_store(o0, obs + 2 * row);
-                        __builtin_nontemporal_store(o1, obs + 2 * row + 1);
+                        __builtin_nontemporal_store(f32x2{o0, o1}, reinterpret_cast<f32x2 *>(obs + 2 * row));       // one 8-byte store per lane: a wavefront row is 512 contiguous bytes
                     }
                 }
                 if (rew) __builtin_nontemporal_store((float)reward, rew + row);

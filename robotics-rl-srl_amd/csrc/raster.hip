@@ -28,17 +28,18 @@
 // reproduces the bytes.
 #include "internal.hpp"
 #include "kuka_core.hpp"
+#include "kuka_tree_model.hpp"
 
 namespace srl {
 
 // KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb; int64_t n; int32_t two, rand_objects; };     // sq/cq: [7][n]
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; const kuka::TreeModel *tm; int64_t n; int32_t two, rand_objects; };     // sq/cq: [7][n]
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
 
 constexpr int kRasterBlock = 256;
-constexpr int kMaxPrims = 28;   // Kuka scene 14 + second button 2 or ten distractors + ball 11
+constexpr int kMaxPrims = 28;   // Kuka scene 16 (full model: body + two finger + two tip capsules; lumped 14) + second button 2 or ten distractors + ball 11
 constexpr int kTilePixels = 8192;       // LDS band buffer (24 KiB): whole 8-row tile strips, image width <= 1024
 
 enum { PRIM_PLANE = 0, PRIM_BOX = 1, PRIM_CYL = 2, PRIM_CAPSULE = 3 };
@@ -220,6 +221,30 @@ __device__ int build_mobile_scene(const RasterParams &rp, const RasterMobileView
     return n;
 }
 
+// frame of a tree link from its parent's: child = parent * (xyz, Rj * Rot(axis, q)), R as columns x y z.  The same operations in the
+// same order as oracle/kuka_oracle.c (axis_rotation / rpy_to_mat for z axes, mat3_mul, mat3_vec): identical float64 results.
+__device__ void tree_child_frame(const double Rp[9], const double pp[3], const kuka::TreeJoint &J, double s, double c, double Rc[9], double pc[3]) {
+    double Rq[3][3], L[3][3];                                  // row-major like the oracle's mat3
+    const double a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2], vv = 1.0 - c;
+    if (a2 == 1.0) {                                           // rpy_to_mat(0, 0, q)
+        Rq[0][0] = c; Rq[0][1] = -s; Rq[0][2] = 0.0; Rq[1][0] = s; Rq[1][1] = c; Rq[1][2] = 0.0; Rq[2][0] = 0.0; Rq[2][1] = 0.0; Rq[2][2] = 1.0;
+    } else {
+        Rq[0][0] = c + a0 * a0 * vv;      Rq[0][1] = a0 * a1 * vv - a2 * s; Rq[0][2] = a0 * a2 * vv + a1 * s;
+        Rq[1][0] = a1 * a0 * vv + a2 * s; Rq[1][1] = c + a1 * a1 * vv;      Rq[1][2] = a1 * a2 * vv - a0 * s;
+        Rq[2][0] = a2 * a0 * vv - a1 * s; Rq[2][1] = a2 * a1 * vv + a0 * s; Rq[2][2] = c + a2 * a2 * vv;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) L[i][j] = J.Rj[3 * i] * Rq[0][j] + J.Rj[3 * i + 1] * Rq[1][j] + J.Rj[3 * i + 2] * Rq[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        pc[i] = pp[i] + (Rp[i] * J.xyz[0] + Rp[3 + i] * J.xyz[1] + Rp[6 + i] * J.xyz[2]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rc[3 * j + i] = Rp[i] * L[0][j] + Rp[3 + i] * L[1][j] + Rp[6 + i] * L[2][j];
+    }
+}
+
 __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     using namespace kuka;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {kBasePos[0], kBasePos[1], kBasePos[2]};
@@ -244,15 +269,40 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     for (int i = 0; i < ND - 1; i++)
         set_prim(prims[k++], PRIM_CAPSULE, 1.0f, 0.45f, 0.05f, jp[i][0], jp[i][1], jp[i][2], jp[i + 1][0], jp[i + 1][1],
                  jp[i + 1][2], 0.06f, 1, 0);
-    const double body[3] = {0, 0, 0.10}, fa0[3] = {0, 0.030, 0.10}, fa1[3] = {0, 0.020, 0.255}, fb0[3] = {0, -0.030, 0.10},
-                 fb1[3] = {0, -0.020, 0.255};
     double a[3], b[3];
-    tip_point(R, p, body, a);
-    set_prim(prims[k++], PRIM_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], (float)a[0], (float)a[1], (float)a[2], 0.045f, 1, 0);
-    tip_point(R, p, fa0, a); tip_point(R, p, fa1, b);
-    set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
-    tip_point(R, p, fb0, a); tip_point(R, p, fb1, b);
-    set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+    if (v.tm) {
+        // Full model: the gripper from its own joint state (kuka_button_gym_env.py:370-420 renders the bodies where they are): frames
+        // of the tree's links 7..11 — gripper_to_arm, left finger -> left tip, right finger -> right tip — composed from the
+        // installed table exactly as oracle/kuka_oracle.c::forward_kinematics does; body, two finger and two tip capsules.
+        double Rg[5][9], pg[5][3];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const TreeJoint &J = v.tm->j[7 + i];
+            const int par = (int)J.parent;                    // 6 (link_7) or an earlier gripper link
+            const double *Rp = par >= 7 ? Rg[par - 7] : R, *pp = par >= 7 ? pg[par - 7] : p;
+            tree_child_frame(Rp, pp, J, v.gsq[i * n + e], v.gcq[i * n + e], Rg[i], pg[i]);
+        }
+        const double up5[3] = {0, 0, 0.05}, up45[3] = {0, 0, 0.045};
+        tip_point(Rg[0], pg[0], up5, a);
+        set_prim(prims[k++], PRIM_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], (float)a[0], (float)a[1], (float)a[2], 0.045f, 1, 0);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const int f = 1 + 2 * side, t = f + 1;
+            set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)pg[f][0], (float)pg[f][1], (float)pg[f][2], (float)pg[t][0], (float)pg[t][1], (float)pg[t][2], 0.012f, 1, 0);
+            tip_point(Rg[t], pg[t], up45, b);
+            set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)pg[t][0], (float)pg[t][1], (float)pg[t][2], (float)b[0], (float)b[1], (float)b[2], 0.010f, 1, 0);
+        }
+    } else {
+        // lumped model (rounds 1-2): the gripper welded to link 7
+        const double body[3] = {0, 0, 0.10}, fa0[3] = {0, 0.030, 0.10}, fa1[3] = {0, 0.020, 0.255}, fb0[3] = {0, -0.030, 0.10},
+                     fb1[3] = {0, -0.020, 0.255};
+        tip_point(R, p, body, a);
+        set_prim(prims[k++], PRIM_CAPSULE, 0.20f, 0.20f, 0.22f, jp[6][0], jp[6][1], jp[6][2], (float)a[0], (float)a[1], (float)a[2], 0.045f, 1, 0);
+        tip_point(R, p, fa0, a); tip_point(R, p, fa1, b);
+        set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+        tip_point(R, p, fb0, a); tip_point(R, p, fb1, b);
+        set_prim(prims[k++], PRIM_CAPSULE, 0.10f, 0.10f, 0.10f, (float)a[0], (float)a[1], (float)a[2], (float)b[0], (float)b[1], (float)b[2], 0.015f, 1, 0);
+    }
     if (v.rand_objects) {
         // KukaRandButtonGymEnv scenery (kuka_rand_button_gym_env.py:60-71): kept distractors resting on the table, and the
         // ball at its drop position.  The reference draws the object TYPE from the global unseeded np.random; here it is a

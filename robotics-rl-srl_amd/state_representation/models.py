@@ -165,12 +165,103 @@ def getSRLDim(path=None, env_object=None):
     return env_object.getGroundTruthDim()
 
 
+class SRLPCA(object):
+    """state_representation/models.py:196-217 — a pickled sklearn PCA as the state representation.  The reference transforms one
+    flattened uint8 observation at a time on the host (`self.model.transform(observation.reshape(-1, n_features))`); here the whole
+    device-resident batch goes through ONE GEMM on the device: (X - mean_) @ components_.T [/ sqrt(explained_variance_) when the
+    PCA whitens], in float64 like sklearn (uint8 input is promoted to float64 there)."""
+
+    def __init__(self, state_dim, cuda=False, device=None):
+        self.state_dim = state_dim
+        self.device = th.device(device if device is not None else ("cuda" if cuda else "cpu"))
+        self.model, self._w, self._b = None, None, None
+        self.hip, self.backend = None, "gemm"
+
+    def load(self, path):
+        import pickle as pkl
+        try:
+            with open(path, "rb") as f:
+                self.model = pkl.load(f)
+        except UnicodeDecodeError:                 # pickle files saved with python 2 (models.py:204-207)
+            with open(path, "rb") as f:
+                self.model = pkl.load(f, encoding="latin1")
+        self.set_model(self.model)
+
+    def set_model(self, pca):
+        self.model = pca
+        comp = np.asarray(pca.components_, dtype=np.float64)                     # [state_dim][n_features]
+        mean = np.zeros(comp.shape[1]) if getattr(pca, "mean_", None) is None else np.asarray(pca.mean_, dtype=np.float64)
+        w = comp.T.copy()
+        if getattr(pca, "whiten", False):
+            w = w / np.sqrt(np.asarray(pca.explained_variance_, dtype=np.float64))[None, :]
+        self._w = th.from_numpy(w).to(self.device)                               # [n_features][state_dim]
+        self._b = th.from_numpy(-(mean @ w)).to(self.device)                     # folded: X @ w - mean @ w
+        assert self._w.shape[1] == self.state_dim, "exp_config.json state-dim does not match the pickled PCA"
+
+    @th.no_grad()
+    def getStates(self, images_u8, stream=None, out=None):
+        """uint8 [N][H][W][C] (numpy or device tensor) -> float64 [N][state_dim], one GEMM (rocBLAS dgemm on the GPU)."""
+        if isinstance(images_u8, np.ndarray):
+            images_u8 = th.from_numpy(images_u8)
+        x = images_u8.to(self.device).reshape(images_u8.shape[0], -1).to(th.float64)
+        return th.addmm(self._b, x, self._w)
+
+    def getState(self, observation, env_id=0):
+        return self.getStates(np.asarray(observation)[None])[0].to("cpu").numpy()
+
+
 def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_shape=(224, 224), n_channels=3):
-    """Factory with the reference's signature (models.py:38-107).  With a checkpoint path the state_dict is
-    loaded into the restated CustomCNN; without one the encoder is random-initialised."""
-    state_dict = None
+    """state_representation/models.py:38-107, same signature and the same checks.  With a path the log folder's exp_config.json is read
+    (as an OrderedDict: the order of the losses matters to srl_zoo) — `state-dim` (required), `losses`, `n_actions`, `model-type`,
+    `multi-view` (-> 6 input channels: srl_zoo sets preprocessing.N_CHANNELS = 6), `inverse-model-type`, `split-dimensions` (a dict whose
+    values sum to 0 means "combine the losses": None) — and the checkpoint is loaded: a `baselines/.../pca` path is a pickled PCA
+    (SRLPCA), anything else a torch state_dict for the encoder.  Only the `custom_cnn` encoder is restated (srl_zoo is an empty
+    submodule in the reference checkout): other model types raise NotImplementedError instead of silently building a different
+    network.  img_shape / n_channels: the frame shape the batched encoder is built for (the reference fixes it through srl_zoo
+    globals)."""
+    import json
+    from collections import OrderedDict
+    model_type, losses, n_actions, model = None, None, None, None
+    use_multi_view, split_dimensions, inverse_model_type = False, None, "linear"
     if path is not None:
-        state_dim = getSRLDim(path) if state_dim is None else state_dim
-        state_dict = th.load(path, map_location="cpu")
-    assert state_dim is not None and state_dim > 0
-    return SRLNeuralNetwork(state_dim, cuda, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict)
+        log_folder = "/".join(path.split("/")[:-1]) + "/"
+        with open(log_folder + "exp_config.json", "r") as f:
+            exp_config = json.load(f, object_pairs_hook=OrderedDict)
+        state_dim = exp_config.get("state-dim", None)
+        losses = exp_config.get("losses", None)              # None for the baseline models (pca, supervised)
+        n_actions = exp_config.get("n_actions", None)
+        model_type = exp_config.get("model-type", None)
+        use_multi_view = exp_config.get("multi-view", False)
+        inverse_model_type = exp_config.get("inverse-model-type", "linear")
+        assert state_dim is not None, "Please make sure you are loading an up to date model with a conform exp_config file."
+        split_dimensions = exp_config.get("split-dimensions")
+        if isinstance(split_dimensions, OrderedDict) and sum(split_dimensions.values()) == 0:
+            split_dimensions = None                          # combine the losses instead of splitting
+    else:
+        assert env_object is not None or (state_dim is not None and state_dim > 0), \
+            "When learning states, state_dim must be > 0. Otherwise, set SRL_MODEL_PATH to a srl_model.pth file with learned states."
+        model_type = "custom_cnn"                            # (the reference builds the model that is being learned: srl_zoo's default)
+        losses, n_actions = [], 0
+    if path is not None and "baselines" in path and "pca" in path:
+        model_type = "pca"
+        model = SRLPCA(state_dim, cuda)
+    assert model_type is not None or model is not None, \
+        "Model type not supported. In order to use loadSRLModel, a path to an SRL model must be given."
+    assert not (losses is None and not model_type == "pca"), \
+        "Please make sure you are loading an up to date model with a conform exp_config file."
+    assert not (n_actions is None and not (model_type == "pca" or "supervised" in losses)), \
+        "Please make sure you are loading an up to date model with a conform exp_config file."
+    if model is None:
+        if use_multi_view:
+            n_channels = 6                                   # preprocessing.preprocess.N_CHANNELS = 6
+        if model_type != "custom_cnn":
+            raise NotImplementedError("srl model type {!r}: only srl_zoo's custom_cnn encoder (and the pca baseline) are restated here "
+                                      "(srl_zoo is an empty submodule of the reference checkout)".format(model_type))
+        state_dict = th.load(path, map_location="cpu") if path is not None else None
+        if isinstance(state_dict, dict) and "state_dict" in state_dict:
+            state_dict = state_dict["state_dict"]
+        model = SRLNeuralNetwork(state_dim, cuda, model_type, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict)
+        model.losses, model.n_actions, model.split_dimensions, model.inverse_model_type = losses, n_actions, split_dimensions, inverse_model_type
+    elif path is not None:
+        model.load(path)
+    return model

@@ -70,7 +70,7 @@ def test_kuka_pixels_bench_configuration():
         st = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_BUTTON_Q)[0][:, None],
                              h.get_state(_lib.F_KUKA_BUTTON_XY).T], axis=1)
         frames = env.images.cpu().numpy()
-        assert np.array_equal(frames, raster_clib.render(4, st, 64, 64))          # bit-exact frames, all 4096 envs
+        assert np.array_equal(frames, raster_clib.render(4, st, 64, 64, gripper_q=h.get_state(_lib.F_KUKA_GRIPPER_Q).T))          # bit-exact frames, all 4096 envs
         ref = cpu.getStates(frames).numpy()
         err = np.abs(states.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
         assert err <= 2e-5, err

@@ -351,7 +351,8 @@ def test_rand_button_env():
         b30 = h30.get_state(_lib.F_KUKA_BODIES).T.reshape(n, 11, 6)
         h30.close()
         assert np.abs(b30 - ob30[:, :, :6]).max() <= 1e-9
-        assert np.abs(ob30[:, 10, 3:5]).max(axis=1).min() > 0.05 and (ob30[:, 10, 0] > 0.25 + 1e-3).all()         # every ball is moving towards +x, +y
+        assert np.abs(ob30[:, 10, 3:5]).max(axis=1).min() > 0.05 and (np.hypot(ob30[:, 10, 0] - 0.25, ob30[:, 10, 1] + 0.2) > 1e-3).all()   # every ball is on its way (first quadrant)
+        assert (ob30[:, 10, 3:5] >= 0).all()
         assert np.array_equal(out30["reward"], ora30["reward"]) and np.array_equal(out30["done"], ora30["done"])
         # (2) the full run
         ob = kuka_clib.body_trace(n)

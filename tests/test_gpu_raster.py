@@ -16,6 +16,11 @@ def kuka_state(h):
     return np.concatenate([q, b[:, None], bp[:, :2]], axis=1)
 
 
+def gq(h):
+    """q of the gripper joints (full-model handles: the rasteriser draws the fingers from them)"""
+    return h.get_state(_lib.F_KUKA_GRIPPER_Q).T
+
+
 def mobile_state(h):
     f = lambda k: h.get_state(k)
     return np.stack([f(_lib.F_POS_X), f(_lib.F_POS_Y), f(_lib.F_TARGET_X), f(_lib.F_TARGET_Y), f(_lib.F_TARGET2_X), f(_lib.F_TARGET2_Y)], 1)
@@ -38,11 +43,11 @@ def test_kuka_images_match_oracle(hw, multi_view):
     h = _lib.Handle(cfg)
     obs = h.reset()
     assert obs.shape == (n, hw[0], hw[1], 6 if multi_view else 3) and obs.dtype == np.uint8
-    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view))
+    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view, gripper_q=gq(h)))
     actions = np.random.RandomState(0).randint(6, size=(40, n)).astype(np.int32)
     for t in range(40):
         obs, r, d = h.step(actions[t])
-    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view))
+    assert_images_equal(obs, raster_clib.render(4, kuka_state(h), hw[0], hw[1], multi_view, gripper_q=gq(h)))
     assert_images_equal(h.render(), obs)
     assert len(np.unique(obs.reshape(-1, obs.shape[-1])[:, :3], axis=0)) > 50      # a real shaded scene, not a flat fill
     h.close()
@@ -121,12 +126,12 @@ def test_two_button_images_match_oracle():
     def state():
         s = kuka_state(h)
         return np.concatenate([s, h.get_state(_lib.F_KUKA_BUTTON2_Q)[0][:, None], h.get_state(_lib.F_KUKA_BUTTON2_XY).T], axis=1)
-    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64))
+    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64, gripper_q=gq(h)))
     dark_green = (obs[..., 0] < 80) & (obs[..., 1] > 100) & (obs[..., 2] > 50) & (obs[..., 2] < 130)
     assert dark_green.reshape(n, -1).sum(1).min() > 20          # the darker second cap is visible in every env
     for t in range(30):
         obs, r, d = h.step(np.full(n, 4, np.int32))
-    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64))
+    assert_images_equal(obs, raster_clib.render(6, state(), 64, 64, gripper_q=gq(h)))
     h.close()
 
 
@@ -142,16 +147,16 @@ def test_rand_button_images_match_oracle():
 
     def state8():
         return np.concatenate([kuka_state(h), h.get_state(_lib.F_KUKA_OBJECTS).T, h.get_state(_lib.F_KUKA_BODIES).T], axis=1)
-    st0 = state8()
-    assert_images_equal(obs, raster_clib.render(8, st0, 64, 64))
-    assert_images_equal(obs, raster_clib.render(7, st0[:, :40], 64, 64))       # at rest = the scenery rendering
-    plain = raster_clib.render(4, st0[:, :10], 64, 64)
+    st0, g0 = state8(), gq(h)
+    assert_images_equal(obs, raster_clib.render(8, st0, 64, 64, gripper_q=g0))
+    assert_images_equal(obs, raster_clib.render(7, st0[:, :40], 64, 64, gripper_q=g0))       # at rest = the scenery rendering
+    plain = raster_clib.render(4, st0[:, :10], 64, 64, gripper_q=g0)
     assert (obs != plain).reshape(n, -1).any(1).all()           # every env shows at least the ball
     out = h.rollout(40, actions=np.random.RandomState(3).randint(4, size=(40, n)).astype(np.int32))
     st = state8()
-    assert np.abs(st[:, 40 + 60] - 0.25).min() > 1e-3           # every ball has left its drop position
-    assert_images_equal(out["obs"][-1], raster_clib.render(8, st, 64, 64))
-    assert (out["obs"][-1] != raster_clib.render(7, st[:, :40], 64, 64)).any()
+    assert np.hypot(st[:, 40 + 60] - 0.25, st[:, 40 + 61] + 0.2).min() > 1e-3           # every ball has left its drop position
+    assert_images_equal(out["obs"][-1], raster_clib.render(8, st, 64, 64, gripper_q=gq(h)))
+    assert (out["obs"][-1] != raster_clib.render(7, st[:, :40], 64, 64, gripper_q=gq(h))).any()
     h.close()
     cfg.kuka_model = _lib.KUKA_MODEL_LUMPED
     h = _lib.Handle(cfg)
