@@ -576,6 +576,17 @@ def main():
                     sec[name]["kernel_ms"] = sub["config"]["kernel_ms"]
             except Exception as exc:          # a secondary leg must never sink the headline measurement
                 sec[name] = {"value": None, "error": repr(exc)}
+        # the rounds 1-2 lumped-gripper model on the same workload (round-3 advisor: the default moved to the full model without an
+        # external pin — both are reported): a different, cheaper simulation, NOT the headline
+        try:
+            args.inner_steps = None
+            saved_model, args.kuka_model = args.kuka_model, "lumped"
+            sub = bench_stepper(args, "kuka", rank, local_rank, world, dev, K=6, W=2, cpu=False)
+            sec["kuka_lumped_model"] = {"value": sub["value"], "unit": sub["unit"], "steps": sub["steps"], "warmup": sub["warmup"], "ms_per_step": sub["ms_per_step"],
+                                        "kernel": sub["roofline"]["kernel"], "workload": sub["config"]["workload"] + " (gripper welded to link 7: 7 DoF, 6 contact spheres, no friction rows)"}
+            args.kuka_model = saved_model
+        except Exception as exc:
+            sec["kuka_lumped_model"] = {"value": None, "error": repr(exc)}
         args.inner_steps = saved
         line["secondary"] = sec
     if rank == 0:

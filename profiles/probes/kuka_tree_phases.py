@@ -10,6 +10,7 @@ from srlhip import _lib
 
 assert "prof" in os.environ.get("SRLHIP_LIB", ""), "set SRLHIP_LIB to the profiling build"
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+NO_OUT = len(sys.argv) > 2 and sys.argv[2] == "noout"       # no observation / reward / done planes: what the output stores cost
 n = 4096
 dev = torch.device("cuda", 0)
 cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
@@ -22,7 +23,7 @@ h.reset(obs_out=0)
 h.sync()
 for rep in range(2):
     h.timing_begin()
-    h.rollout(T, out=(obs.data_ptr(), rew.data_ptr(), done.data_ptr(), 0))
+    h.rollout(T, out=(0, 0, 0, 0) if NO_OUT else (obs.data_ptr(), rew.data_ptr(), done.data_ptr(), 0))
     ms = h.timing_end()
     print("launch {}: T {} {:.3f} ms, {:.2f} us per step".format(rep, T, ms, ms * 1e3 / T), flush=True)
 h.close()

@@ -103,6 +103,7 @@ struct Handle {
     bool prefetch_valid = false;
     int prefetch_T = 0, prefetch_buf = 0;
     KukaState *kuka;
+    double kuka_tmodel_host[510] = {0};   // host copy of the installed full-model table (srlhip_kuka_tree_model): the rasteriser's gripper joint frames
     std::vector<void *> allocs;      // everything hipMalloc'ed for this handle
     // staging buffers for io_device == 0
     void *st_actions, *st_noise, *st_obs, *st_rew, *st_done, *st_mask, *st_rand;
@@ -111,6 +112,7 @@ struct Handle {
     // (built lazily on the first render; lives in `allocs`)
     float4 *raster_rays[2];
     uint32_t *raster_bg[2];
+    float *raster_grip = nullptr;         // [21][n] full Kuka model: the gripper capsules' end points (raster_grip_k, refreshed by every render)
     void *pin_in, *pin_out;          // pinned host bounce buffers of srlhip_step (host-pointer mode)
     size_t pin_in_sz, pin_out_sz;
 

@@ -237,6 +237,8 @@ int kuka_alloc(Handle *h) {
             (rc = h->dalloc(&s->tstarts, (size_t)(s->nstarts > 0 ? s->nstarts : 1) * tree::kTreeStartDoubles)))
             return rc;
         TreeModel tm; default_tree_model(tm);
+        static_assert(sizeof(TreeModel) == sizeof(h->kuka_tmodel_host), "host copy of the tree model table");
+        memcpy(h->kuka_tmodel_host, &tm, sizeof tm);
         SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, &tm, sizeof tm, hipMemcpyHostToDevice, h->stream));
         SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
         return kuka_tree_settle(h, params_of(h));
@@ -323,6 +325,7 @@ int kuka_uses_group_kernel(const Handle *h) { return h->kuka->full ? 2 : use_gro
 // srlhip_set_kuka_tree_model: install a full-model table; settled state and start table are re-integrated.  Envs must be reset afterwards.
 int kuka_set_tree_model(Handle *h, const double *table510) {
     KukaState *s = h->kuka;
+    memcpy(h->kuka_tmodel_host, table510, sizeof(TreeModel));
     SRL_HIP_CHECK(h, hipMemcpyAsync(s->tmodel, table510, sizeof(TreeModel), hipMemcpyHostToDevice, h->stream));
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return kuka_tree_settle(h, params_of(h));
@@ -387,7 +390,10 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; const kuka::TreeModel *tm; int64_t n; int32_t two, rand_objects; };
+// (raster.hip; gj: the five gripper joints of the installed full-model table — parent, frame in the parent link, axis — BY VALUE: kernel arguments
+//  are scalar loads; has_tm = 0 on lumped handles)
+struct RasterGripJoint { double parent, xyz[3], Rj[9], axis[3]; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; RasterGripJoint gj[5]; const float *grip; int64_t n; int32_t two, rand_objects, has_tm; };
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;
@@ -397,7 +403,14 @@ void kuka_raster_view(Handle *h, RasterKukaView *v) {
     v->objs = s->objs; v->rand_objects = h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
     v->rb = (v->rand_objects && s->full) ? s->rb : nullptr;      // full model: the distractors and the ball are free bodies, drawn where they are
     // full model: the gripper is drawn from its own joints (gripper_to_arm, fingers, tips) through the installed table
-    v->tm = s->full ? s->tmodel : nullptr; v->gsq = s->d + D_GSQ * n; v->gcq = s->d + D_GCQ * n;
+    v->grip = nullptr; v->has_tm = s->full ? 1 : 0; v->gsq = s->d + D_GSQ * n; v->gcq = s->d + D_GCQ * n;
+    for (int i = 0; i < 5; i++) {
+        const TreeJoint &J = reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->j[7 + i];
+        RasterGripJoint &g = v->gj[i];
+        g.parent = J.parent;
+        for (int k = 0; k < 3; k++) { g.xyz[k] = J.xyz[k]; g.axis[k] = J.axis[k]; }
+        for (int k = 0; k < 9; k++) g.Rj[k] = J.Rj[k];
+    }
 }
 
 int kuka_refresh(Handle *h) {

@@ -699,6 +699,51 @@ SRL_G double cn_own_lambda(const double *tN, const double *tF, int l) {
     for (int g = 0; g < kNGen; g++) { lam = l == g ? tN[g] : lam; lam = l == kNGen + g ? tF[g] : lam; }
     return lam;
 }
+// Round 4, one-button contact sweeps: (1) the button's three rows ride on motor rows 0..2 as on the free path — a motor row and a
+// button row never couple directly (only through bank-B rows, which come after both), so updating the pair at once changes no
+// value and takes three rows out of the sequential chain; (2) contact-normal rows live in u = lambda / 2^33 so that their projection
+// [0, 1e10] becomes the hardware clamp of the add (upper bound 2^33 = 8.6e9 instead of 1e10: impulses are ~1e-2): two dependent
+// operations per normal row instead of four.  The scaling is a power of two: exact.
+constexpr double kNormalScale = 8589934592.0;          // 2^33
+template <int J, int J2, bool LAST> SRL_G void cn_rowA2(const TRows &r, double nBA_J, double nBA_J2, double eJJ2, double &accA, double &accB, double &uA) {
+#if SRL_G_DEVICE
+    double t;
+    asm volatile("v_add_f64 %2, %3, %0 clamp\n\tv_fma_f64 %0, -%8, %0, %0\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+                 : "+v"(accA), "+v"(accB), "=&v"(t)
+                 : "v"(r.cs), "v"(r.n[J]), "v"(r.n[J2]), "v"(nBA_J), "v"(nBA_J2), "v"(eJJ2), "n"(J), "n"(J2));
+#else
+    const double t = clamp01(r.cs + accA);
+    accA = fma(-eJJ2, accA, accA);
+    const double ta = grp::host_exchange(t, J), tb = grp::host_exchange(t, J2);
+    accA = fma(ta, r.n[J], accA); accA = fma(tb, r.n[J2], accA);
+    accB = fma(ta, nBA_J, accB); accB = fma(tb, nBA_J2, accB);
+#endif
+    if (LAST) uA = fma(eJJ2, t - uA, uA);
+}
+// scaled contact-normal slot G on lane G: u = clamp01(cs_u + accB)
+template <int G> SRL_G void cn_rowNs(double csU, double &tN, double nAB, double nBB, double eS, double &accA, double &accB) {
+#if SRL_G_DEVICE
+    double t;
+    asm volatile("v_add_f64 %2, %3, %1 clamp\n\tv_fma_f64 %1, -%6, %1, %1\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                 : "+v"(accA), "+v"(accB), "=&v"(t) : "v"(csU), "v"(nAB), "v"(nBB), "v"(eS), "n"(G));
+#else
+    const double t = clamp01(csU + accB);
+    accB = fma(-eS, accB, accB);
+    const double tb = grp::host_exchange(t, G);
+    accA = fma(tb, nAB, accA); accB = fma(tb, nBB, accB);
+#endif
+    tN = t;
+}
+template <int G> SRL_G void cn_normals_s(double csU, double *tN, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
+    if (G < ngen_w) cn_rowNs<G>(csU, tN[G], nAB[G], nBB[G], eB[G], accA, accB);
+    if constexpr (G + 1 < kNGen) cn_normals_s<G + 1>(csU, tN, nAB, nBB, eB, accA, accB, ngen_w);
+}
 // Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
 // stops, normals, frictions).  nCB: the second button's rows' couplings to the bank-B slots (per lane, zero off the button lanes).
 SRL_G double sweeps_contacts2(const TRows &r, const TRows2 &r2, BRow &b, const double *sc, double accA, int ngen_w, const double *nCB, double *u2_out) {
@@ -744,25 +789,39 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     for (int j = 0; j < kNArows; j++) { nBA[j] = sc[SC_NBA + j * GL + l]; eA[j] = l == j ? 1.0 : 0.0; }
 #pragma unroll
     for (int s = 0; s < kNB; s++) { nAB[s] = sc[SC_NAB + s * GL + l]; nBB[s] = sc[SC_NBB + s * GL + l]; eB[s] = l == s ? 1.0 : 0.0; }
-    // a lane that owns no active normal row must hand round 0: hi = 0 does that (cs and the couplings of such a row are 0 anyway)
+    // a lane that owns no active row hands round 0: cs and every coupling INTO such a row are 0 (inv_diag = 0)
     BRow bb = b;
-    if (!(bb.on && !bb.fric)) bb.hi = 0.0;
     if (!bb.on) bb.cs = 0.0;
+    // contact-normal rows in u = lambda / 2^33 (cn_rowNs): what a normal slot hands round is scaled up at the receivers, what a
+    // normal lane receives is scaled down; a friction row's bound mu * lambda_normal becomes (mu 2^33) * u_normal
+    const double Sn = kNormalScale, iSn = 1.0 / kNormalScale;
+#pragma unroll
+    for (int s = 0; s < kNGen; s++) { nAB[s] *= Sn; nBB[s] *= Sn; }
+    if (l < kNGen) {
+#pragma unroll
+        for (int j = 0; j < kNArows; j++) nBA[j] *= iSn;
+#pragma unroll
+        for (int s = 0; s < kNB; s++) nBB[s] *= iSn;
+        bb.cs *= iSn;
+    }
+    bb.mu *= Sn;
+    // the button's rows ride on motor rows 0..2 (cn_rowA2): one restart mask per pair
+    const double e0 = eA[0] + eA[kBM], e1 = eA[1] + eA[kBLo], e2 = eA[2] + eA[kBHi];
     double accB = 0.0, uA = 0.0, tN[kNGen], tF[kNGen];
 #pragma unroll
     for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
 #define SRL_CN_SWEEP(LAST)                                                                                                                     \
-    cn_rowA<0, LAST>(r, nBA[0], eA[0], accA, accB, uA);   cn_rowA<1, LAST>(r, nBA[1], eA[1], accA, accB, uA);   cn_rowA<2, LAST>(r, nBA[2], eA[2], accA, accB, uA);   \
+    cn_rowA2<0, kBM, LAST>(r, nBA[0], nBA[kBM], e0, accA, accB, uA);   cn_rowA2<1, kBLo, LAST>(r, nBA[1], nBA[kBLo], e1, accA, accB, uA);      \
+    cn_rowA2<2, kBHi, LAST>(r, nBA[2], nBA[kBHi], e2, accA, accB, uA);                                                                         \
     cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
     cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
     cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
-    cn_rowA<kBM, LAST>(r, nBA[kBM], eA[kBM], accA, accB, uA); cn_rowA<kBLo, LAST>(r, nBA[kBLo], eA[kBLo], accA, accB, uA); cn_rowA<kBHi, LAST>(r, nBA[kBHi], eA[kBHi], accA, accB, uA); \
-    cn_normals<0>(bb, tN, nAB, nBB, eB, accA, accB, ngen_w);                                                                                   \
+    cn_normals_s<0>(bb.cs, tN, nAB, nBB, eB, accA, accB, ngen_w);                                                                              \
     cn_frictions<0>(bb, tN, tF, nAB, nBB, eB, accA, accB, ngen_w);
     for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
     { SRL_CN_SWEEP(true) }
 #undef SRL_CN_SWEEP
-    b.lam = cn_own_lambda(tN, tF, l);
+    b.lam = cn_own_lambda(tN, tF, l) * (l < kNGen ? Sn : 1.0);
     return uA;
 }
 
