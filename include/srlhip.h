@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SRLHIP_ABI_VERSION 1
+#define SRLHIP_ABI_VERSION 2   /* 2 (round 4): srlhip_kuka_tree_model grew its solver section (506 -> 510 doubles), SRLHIP_F_KUKA_BODIES */
 
 /* ---- error codes ------------------------------------------------------- */
 #define SRLHIP_OK            0

@@ -47,6 +47,7 @@ EXPORTS = [
 ]
 
 
+ABI_VERSION = 2
 KUKA_MODEL_DOUBLES = 138
 KUKA_TREE_MODEL_DOUBLES = 510
 KUKA_DETAIL_ALT_SWEEP, KUKA_DETAIL_BODY_ORDER, KUKA_DETAIL_FRICTION2 = 1, 2, 4
@@ -106,6 +107,9 @@ def load():
         pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    if lib.srlhip_abi_version() != ABI_VERSION:       # a stale build next to a newer host package (table sizes, field ids) must not be driven
+        raise SrlHipError("libsrlhip.so reports ABI version {}, this host package needs {}: rebuild it "
+                          "(make -C robotics-rl-srl_amd/csrc)".format(lib.srlhip_abi_version(), ABI_VERSION))
     lib.srlhip_last_error.restype = ctypes.c_char_p
     lib.srlhip_last_error.argtypes = [vp]
     lib.srlhip_default_config.argtypes = [i32, ctypes.POINTER(Config)]
