@@ -27,6 +27,7 @@ for rep in range(2):
     ms = h.timing_end()
     print("launch {}: T {} {:.3f} ms, {:.2f} us per step".format(rep, T, ms, ms * 1e3 / T), flush=True)
 h.close()
-names = ["between steps (env logic, outputs, actions)", "IK", "collision + motor targets", "RNEA sums", "CRBA", "Gauss-Jordan 12x12", "row setup",
-         "150 sweeps, free steps", "sweeps + setup, steps with generic rows", "integrate + refresh (sincos, FK)"]
+names = ["action / noise sampling + action mapping (loop top .. physics step)", "IK", "collision + motor targets", "RNEA sums", "CRBA", "Gauss-Jordan 12x12", "row setup",
+         "150 sweeps, free steps", "sweeps + setup, steps with generic rows", "integrate + refresh (sincos, FK)",
+         "counters, reward, termination", "episode statistics, auto-reset, observation + output stores"]
 print("phase names:", {i: s for i, s in enumerate(names)})

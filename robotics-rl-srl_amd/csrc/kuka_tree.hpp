@@ -1796,6 +1796,7 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     }
     const double reward = NB == 2 ? reward_two(e, cfg) : reward_fn(e, cfg);
     *done = termination(e, cfg);
+    SRL_TSTAMP(10);                         // counters, reward (one float64 sqrt), termination
     return reward;
 }
 

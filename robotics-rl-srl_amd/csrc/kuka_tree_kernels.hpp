@@ -160,6 +160,9 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             if (rew) rew[row] = (float)reward;
             if (done_out) done_out[row] = (uint8_t)done;
         }
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        { using namespace tree; SRL_TSTAMP(11); }     // episode statistics, auto-reset, observation + output stores
+#endif
     }
 #if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 511)) {
