@@ -573,3 +573,73 @@ def test_ragged_env_counts_with_mt19937_streams(n):
     check_planes(ora, obs0, out)
     assert ora["done"].sum() >= 2
     h.close()
+
+
+@pytest.mark.parametrize("mode", ["continuous_philox_agent", "joints_mt19937", "host_rng_masked_resets"])
+def test_rand_button_env_other_action_modes_and_ragged_batches(mode):
+    """KukaRandButtonGymEnv's free bodies under the other kernel instantiations: continuous Cartesian actions sampled on the device
+    (Philox agent), joint-space actions with the reference-exact MT19937 streams, and the host-RNG harness with masked resets — all on
+    batches that do not fill the last wavefront (its spare lane groups shadow the last env, bodies included)."""
+    cfg = _lib.default_config(_lib.ENV_KUKA_RAND)
+    T = 700
+    kuka_clib.set_variant(kuka_clib.VARIANT_RAND)
+    try:
+        if mode == "continuous_philox_agent":
+            n = 7
+            cfg.num_envs, cfg.seed0, cfg.random_target, cfg.is_discrete, cfg.rng_mode = n, 11, 1, 0, _lib.RNG_PHILOX
+            h = _lib.Handle(cfg)
+            obs0 = h.reset()
+            out = h.rollout(T)
+            ob = kuka_clib.body_trace(n)
+            ora = kuka_clib.rollout(11 + np.arange(n), T, actions=None, is_discrete=False, random_target=True, rng_mode=kuka_clib.RNG_PHILOX, trace=False)
+            kuka_clib.body_trace_off()
+            assert np.array_equal(ora["actions"], out["actions"])
+        elif mode == "joints_mt19937":
+            n = 5
+            cfg.num_envs, cfg.seed0, cfg.is_discrete, cfg.action_joints = n, 31, 0, 1
+            actions = np.random.RandomState(5).uniform(-1, 1, size=(T, n, 7)).astype(np.float32)
+            h = _lib.Handle(cfg)
+            assert h.cfg.rng_mode == _lib.RNG_MT19937
+            obs0 = h.reset()
+            out = h.rollout(T, actions=actions)
+            ob = kuka_clib.body_trace(n)
+            ora = kuka_clib.rollout(31 + np.arange(n), T, actions=actions, is_discrete=False, action_joints=True, trace=False)
+            kuka_clib.body_trace_off()
+        else:
+            from oracle import gym_seeding
+            n = 6
+            rs = np.random.RandomState(8)
+            actions = rs.randint(6, size=(T, n)).astype(np.int32)
+            actions[rs.rand(T, n) < 0.4] = 4
+            cfg.num_envs, cfg.rng_mode, cfg.auto_reset = n, _lib.RNG_HOST, 0
+            rngs = [gym_seeding.np_random(900 + i)[0] for i in range(n)]
+
+            def reset_draws(r):                               # 20 uniforms of the ten distractor candidates, then the 5 init actions
+                out = [r.uniform(-1, 1) for _ in range(20)]
+                for _ in range(5):
+                    out += [r.rand(), float(r.randint(3))]
+                return out
+            h = _lib.Handle(cfg)
+            obs0 = h.reset(host_rand=np.array([reset_draws(r) for r in rngs]))
+            ob = kuka_clib.body_trace(n)
+            ora = kuka_clib.rollout(900 + np.arange(n), T, actions=actions, trace=False)
+            kuka_clib.body_trace_off()
+            out = {"obs": [], "reward": [], "done": []}
+            for t in range(T):
+                noise = np.array([r.normal(0.0, scale=0.01) for r in rngs])
+                o, r_, d = h.step(actions[t], host_noise=noise)
+                if d.any():
+                    rand = np.zeros((n, 30))
+                    for i in np.nonzero(d)[0]:
+                        rand[i] = reset_draws(rngs[i])
+                    o = h.reset(mask=d, host_rand=rand, obs_out=o.copy())
+                out["obs"].append(o); out["reward"].append(r_); out["done"].append(d)
+            out = {k: np.array(v) for k, v in out.items()}
+    finally:
+        kuka_clib.set_variant(kuka_clib.VARIANT_BUTTON)
+        kuka_clib.body_trace_off()
+    check_planes(ora, obs0, out)
+    bodies = h.get_state(_lib.F_KUKA_BODIES).T.reshape(n, 11, 6)
+    on = ob[:, :, 6] > 0
+    assert np.abs(bodies - ob[:, :, :6])[on].max() <= 1e-9
+    h.close()
