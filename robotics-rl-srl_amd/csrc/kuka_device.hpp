@@ -104,6 +104,9 @@ int kuka_group_settle_table(Handle *h, const KukaParams &p);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out);
 int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
+// two wavefronts per SIMD, batches of >= 8192 envs: kuka_tree_occ.hip
+int kuka_tree_occ_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
+                         uint8_t *d_done, void *d_act_out);
 // KukaRandButtonGymEnv (free bodies): kuka_tree_rb.hip
 int kuka_tree_rb_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                         uint8_t *d_done, void *d_act_out);

@@ -57,6 +57,14 @@ uint32_t host_ballot(bool p);
 #define SRL_G_DEVICE 0
 #endif
 
+constexpr int kRowsPerWave = 4;       // 16-lane rows (envs) per wavefront
+SRL_G int row_id() {                  // the own row inside the wavefront (the fiber harness runs one env per group: row 0)
+#if SRL_G_DEVICE
+    return (int)((threadIdx.x & 63) >> 4);
+#else
+    return 0;
+#endif
+}
 SRL_G int lane_id() {
 #if SRL_G_DEVICE
     return (int)(threadIdx.x & (GL - 1));

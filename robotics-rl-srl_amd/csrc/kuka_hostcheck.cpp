@@ -454,7 +454,8 @@ const srl::kuka::TreeModel *tree_model() {
     return &g_tree_model;
 }
 double *g_tree_bodies = nullptr;         // KukaRandButton: [n][11][7] body state at the end of the next tree rollout (x y z vx vy vz on)
-template <int NB, int RB, class R>
+int g_tree_occ = 0;                      // 1: the two-wavefronts-per-SIMD variant's code path (OCC = 1: shared work area, per-env park, recomputed candidates)
+template <int NB, int RB, int OCC, class R>
 void tree_env_body(GroupArgs &a, R &rng) {
     using namespace tree;
     const Cfg &cfg = a.cfg;
@@ -469,9 +470,12 @@ void tree_env_body(GroupArgs &a, R &rng) {
     Env env; memset(&env, 0, sizeof env);
     GState g; memset(&g, 0, sizeof g);
     RBody body; memset(&body, 0, sizeof body);
+    static double park[kTreeParkDoubles];          // OCC: the env's park area (shared by the 16 fibers)
+    if (L.l == 0) for (int i = 0; i < kTreeParkDoubles; i++) park[i] = std::numeric_limits<double>::quiet_NaN();
+    grp::sync_scratch();
     const bool joints = !cfg.is_discrete && cfg.action_joints;
-    if (joints) tenv_reset<1, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
-    else tenv_reset<2, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
+    if (joints) tenv_reset<1, NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body, park);
+    else tenv_reset<2, NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body, park);
     if (a.obs0 && lead) observe(env, cfg, a.obs0 + (size_t)e_idx * od, 1);
     Philox act = a.act;
     grp::GroupActions gact; gact.init(a.act.k0, a.act.k1, 0);
@@ -491,15 +495,15 @@ void tree_env_body(GroupArgs &a, R &rng) {
             }
             if (a.act_out && lead) { if (cfg.is_discrete) static_cast<int32_t *>(a.act_out)[row] = ac; else memcpy(static_cast<float *>(a.act_out) + row * adim, ca, sizeof(float) * adim); }
         }
-        const double reward = tenv_step<NB, RB>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done, &body);
+        const double reward = tenv_step<NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done, &body, park);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
             if (cfg.auto_reset) {
-                if (joints) tenv_reset<1, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
-                else tenv_reset<2, NB, RB>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body);
+                if (joints) tenv_reset<1, NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body, park);
+                else tenv_reset<2, NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, a.starts, a.settled, nullptr, 1, &body, park);
             }
         }
         if (lead) {
@@ -527,9 +531,10 @@ void tree_env_body(GroupArgs &a, R &rng) {
     }
 }
 template <class R> void tree_env_dispatch(GroupArgs &a, R &r) {
-    if (a.cfg.two) tree_env_body<2, 0>(a, r);
-    else if (a.cfg.rand_objects) tree_env_body<1, 1>(a, r);
-    else tree_env_body<1, 0>(a, r);
+    if (a.cfg.two) tree_env_body<2, 0, 0>(a, r);
+    else if (a.cfg.rand_objects) tree_env_body<1, 1, 0>(a, r);
+    else if (g_tree_occ) tree_env_body<1, 0, 1>(a, r);
+    else tree_env_body<1, 0, 0>(a, r);
 }
 void tree_fiber_body(void *p) {
     GroupArgs &a = *static_cast<GroupArgs *>(p);
@@ -589,6 +594,7 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
     return 0;
 }
 extern "C" void hostcheck_kuka_tree_set_body_trace(double *bodies) { g_tree_bodies = bodies; }
+extern "C" void hostcheck_kuka_tree_set_occ(int occ) { g_tree_occ = occ; }
 extern "C" void hostcheck_kuka_tree_default_model(double *t510) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t510, &m, sizeof m); }
 extern "C" void hostcheck_kuka_tree_set_model(const double *t510) {
     g_tree_model_set = t510 != nullptr;

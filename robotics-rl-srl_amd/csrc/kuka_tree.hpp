@@ -65,7 +65,13 @@ constexpr int kTreeStartDoubles = 4 * NJ + 8;   // q12 qd12 sq12 cq12 ee3 bq bqd
 constexpr int kDefDoubles = 8;
 constexpr int SC_J = 0, SC_WJ = kNB * NJ, SC_NBA = 2 * kNB * NJ, SC_NAB = SC_NBA + kNArows * GL, SC_NBB = SC_NAB + kNB * GL, SC_DEF = SC_NBB + kNB * GL,
               SC_S = SC_DEF + kNB * kDefDoubles;                 // + the joints' spatial axes S[12][6] (contact Jacobians)
-constexpr int kTreeScratchDoubles = SC_S + NJ * 6;               // 1056 doubles = 8.25 KiB per env
+constexpr int kTreeScratchDoubles = SC_S + NJ * 6;               // 1080 doubles = 8.4 KiB per env
+// OCC = 1 (two wavefronts per SIMD, kuka_tree_occ.hip): ONE work area per wavefront (everything up to SC_S: the row definitions and
+// coupling planes of the general path, taken by the wavefront's four envs in turns) + a small per-env park (the own row of M^-1 and
+// the spatial axes: what a later turn still needs of the step's dynamics); sphere / limit candidates are recomputed in the turn
+// instead of being parked.
+constexpr int kTreeWorkDoubles = SC_S;                           // 1008 doubles = 7.9 KiB per wavefront
+constexpr int PK_W = 0, PK_S = NJ * GL, kTreeParkDoubles = PK_S + NJ * 6;     // 264 doubles = 2.1 KiB per env
 
 // ------------------------------------------------------------------ KukaRandButtonGymEnv free bodies (template flag RB)
 // kuka_rand_button_gym_env.py:59-71 drops ten meshes and a ball on the table, :111-125 kicks the ball at env step 10: free bodies the
@@ -945,6 +951,29 @@ SRL_G double sweeps_free_detail(const TRows &r, const TRows2 &r2, int detail, SO
     return st.uA;
 }
 
+// the own collision sphere against the button's cap and base (the detection block of tphysics_step as a function: the OCC variant's
+// general path recomputes it in its turn; culling is conservative, so the contact decisions are the same with any set of active rows)
+SRL_G void tdetect(const TL &L, const GState &g, const Env &e, double cc[3], double n_cap[3], double n_base[3], double &d_cap, double &d_base) {
+    const bool sphere = L.slink() >= 0;
+    {
+        double Rs[9], ps[3];
+        link_frame(g, sphere ? L.slink() : 0, Rs, ps);
+        const double sph3[3] = {L.sph(0), L.sph(1), L.sph(2)};
+        frame_point(Rs, ps, sph3, cc);
+    }
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
+    const double reach = L.sph(3) + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
+    const double rmax = kBaseRadius + reach;
+    const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
+    const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+    if (wany(sphere && !far)) {
+        if (sphere) {
+            d_cap = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+            d_base = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the general path
 // Steps that carry joint-limit / contact / friction rows are rare (a few percent of the wavefront-steps): row definitions,
 // couplings through LDS, the two-bank sweeps.  (Tried as a real call with its own frame, -mllvm -amdgpu-function-calls: the call
@@ -955,6 +984,7 @@ struct GenIn {
     double qd_new, bqd, bound_bm;
     TRows2 r2; double bqd2;       // Kuka2Button: the second button's rows (same lanes), its glider velocity
     const RBody *rb;              // KukaRandButton: the own free body (velocities already carry gravity / the kick)
+    double *park; const GState *g; const Env *e;      // OCC: the env's park area; the state the candidates are recomputed from
 };
 // What the general path needs of the step's intermediate results is parked in LDS when it is computed (planes the general path
 // only overwrites at the end of its setup), so that nothing of it stays in registers on the common path:
@@ -965,8 +995,9 @@ enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM
        SM_NCAP2 = SM_COUNT, SM_NBASE2 = SM_NCAP2 + 3, SM_DCAP2 = SM_NBASE2 + 3, SM_DBASE2, SM_COUNT2 };     // Kuka2Button: the second button's shapes
 static_assert(NJ * GL <= kNArows * GL && SM_COUNT2 * GL <= 2 * kNB * GL, "stash planes");
 struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; bool bodies_done; double dvo[3]; };   // + KukaRandButton: the own body's velocity change when its rows were swept here   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
-template <int NB = 1, int RB = 0>
+template <int NB = 1, int RB = 0, int OCC = 0>
 SRL_G GenOut general_path(const GenIn &in) {
+    static_assert(!OCC || (NB == 1 && RB == 0), "the two-wavefronts-per-SIMD variant covers the one-button envs");
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
     // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
     const double dt = kDt, inv_dt = 1.0 / kDt;
@@ -981,6 +1012,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     const int detail = L.detail(), ng = L.ng(), nfd = (detail & kDetailFriction2) ? 2 : 1, nslots = (1 + nfd) * ng;
     const double lerp = L.limit_erp(), cerp = L.contact_erp(), slop = L.linear_slop();
     auto used_slot = [&](int s_, int ngw) -> bool { return s_ < nslots && (s_ >= 2 * ng ? s_ - 2 * ng : s_ >= ng ? s_ - ng : s_) < ngw; };
+    const double *wpark = OCC ? in.park + PK_W : sc + SC_STASH_W, *spark = OCC ? in.park + PK_S : sc + SC_S;
     auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
     auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
     BRow b;
@@ -991,11 +1023,17 @@ SRL_G GenOut general_path(const GenIn &in) {
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
     {
         // ---- the parked inputs of this lane (the MISC plane is reused for the NAB couplings below)
-        double cc[3], n_cap[3], n_base[3];
+        double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30, pen_lo, pen_hi;
+        if constexpr (OCC) {               // recomputed from the (unchanged) start-of-step state: same operations as tphysics_step's detection
+            const GState &g = *in.g; const Env &e = *in.e;
+            tdetect(L, g, e, cc, n_cap, n_base, d_cap, d_base);
+            pen_lo = g.q - L.jlo(); pen_hi = L.jhi() - g.q;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { cc[k] = sc[SC_STASH_MISC + (SM_CC + k) * GL + L.l]; n_cap[k] = sc[SC_STASH_MISC + (SM_NCAP + k) * GL + L.l]; n_base[k] = sc[SC_STASH_MISC + (SM_NBASE + k) * GL + L.l]; }
-        const double d_cap = sc[SC_STASH_MISC + SM_DCAP * GL + L.l], d_base = sc[SC_STASH_MISC + SM_DBASE * GL + L.l];
-        const double pen_lo = sc[SC_STASH_MISC + SM_PENLO * GL + L.l], pen_hi = sc[SC_STASH_MISC + SM_PENHI * GL + L.l];
+            for (int k = 0; k < 3; k++) { cc[k] = sc[SC_STASH_MISC + (SM_CC + k) * GL + L.l]; n_cap[k] = sc[SC_STASH_MISC + (SM_NCAP + k) * GL + L.l]; n_base[k] = sc[SC_STASH_MISC + (SM_NBASE + k) * GL + L.l]; }
+            d_cap = sc[SC_STASH_MISC + SM_DCAP * GL + L.l]; d_base = sc[SC_STASH_MISC + SM_DBASE * GL + L.l];
+            pen_lo = sc[SC_STASH_MISC + SM_PENLO * GL + L.l]; pen_hi = sc[SC_STASH_MISC + SM_PENHI * GL + L.l];
+        }
         const bool sphere = L.slink() >= 0, has_lim = L.jnt && L.jlo() <= L.jhi();
         const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
         double n_cap2[3] = {0, 0, 1}, n_base2[3] = {0, 0, 1}, d_cap2 = 1e30, d_base2 = 1e30;
@@ -1060,7 +1098,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 cross3(nrm, tdir, tdir2);                                 // the second friction direction (SOLVER_USE_2_FRICTION_DIRECTIONS)
 #pragma nounroll
                 for (int j = 0; j < NJ; j++) {
-                    const double *Sj = sc + SC_S + j * 6;
+                    const double *Sj = spark + j * 6;
                     const double Swj[3] = {Sj[0], Sj[1], Sj[2]}, Svj[3] = {Sj[3], Sj[4], Sj[5]};
                     double c3[3];
                     cross3(Swj, pt3, c3);                                 // w_j x pt + v_j = velocity of the contact point per unit qd_j
@@ -1106,7 +1144,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 const double *Js = sc + SC_J + s * NJ, *ds = sc + SC_DEF + s * kDefDoubles;
                 const double act = ds[4], jbs = ds[0];
 #pragma unroll
-                for (int j = 0; j < NJ; j++) wjk = fma(sc[SC_STASH_W + j * GL + L.l], act != 0.0 ? Js[j] : 0.0, wjk);   // (a slot this env does not use holds stale LDS: select, never multiply by 0)
+                for (int j = 0; j < NJ; j++) wjk = fma(wpark[j * GL + L.l], act != 0.0 ? Js[j] : 0.0, wjk);   // (a slot this env does not use holds stale LDS: select, never multiply by 0)
                 if (L.jnt) sc[SC_WJ + s * NJ + L.l] = wjk;
                 else wjk = (is_button && act != 0.0 && (NB == 1 || ds[6] == 0.0)) ? r.jb * wb * jbs : 0.0;
             }
@@ -1285,9 +1323,9 @@ SRL_G GenOut general_path(const GenIn &in) {
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-template <int NB = 1, int RB = 0>
+template <int NB = 1, int RB = 0, int OCC = 0>
 SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
-                         double finger_angle, RBody *rb = nullptr) {
+                         double finger_angle, RBody *rb = nullptr, double *park = nullptr) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
     SRL_TSTAMP(0);                          // (everything between two physics steps: env logic, outputs, action sampling)
@@ -1298,7 +1336,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     cross3(g.p, S, S + 3);
     if (L.jnt) {                            // parked for the (rare) general path, see GenIn
 #pragma unroll
-        for (int k = 0; k < 6; k++) scratch[SC_S + L.l * 6 + k] = S[k];
+        for (int k = 0; k < 6; k++) (OCC ? park + PK_S : scratch + SC_S)[L.l * 6 + k] = S[k];
     }
     // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
     double qdes = L.arm ? jt_own : L.tsel() * finger_angle;
@@ -1393,7 +1431,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         }
     }
     const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
-    {
+    if constexpr (!OCC) {
         double *m = scratch + SC_STASH_MISC + L.l;
 #pragma unroll
         for (int k = 0; k < 3; k++) { m[(SM_CC + k) * GL] = cc[k]; m[(SM_NCAP + k) * GL] = n_cap[k]; m[(SM_NBASE + k) * GL] = n_base[k]; }
@@ -1543,7 +1581,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         gj_step<0, NJ, true>(L, W, unused);
         SRL_TSTAMP(5);                      // its inverse (Gauss-Jordan)
 #pragma unroll
-        for (int k = 0; k < NJ; k++) scratch[SC_STASH_W + k * GL + L.l] = W[k];
+        for (int k = 0; k < NJ; k++) (OCC ? park + PK_W : scratch + SC_STASH_W)[k * GL + L.l] = W[k];
     }
     double qdd = 0.0;
     rdot_step<0, NJ>(qdd, W, tau);
@@ -1614,7 +1652,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     const bool has_lim = L.jnt && L.jlo() <= L.jhi();
     const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
     const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
-    scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi;
+    if constexpr (!OCC) { scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi; }
     const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base || c_any2 || c_obj);
     // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k
     {
@@ -1636,10 +1674,28 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     const int detail = L.detail();
     SRL_TSTAMP(6);                          // row setup
     if (!any_generic) u = detail != 0 ? sweeps_free_detail<NB>(r, r2, detail, S_of, lo_of, &u2) : sweeps_free<NB>(r, &r2, &u2);
-    else {
+    else if constexpr (OCC) {
+        // one work area per wavefront: the envs that carry generic rows take it in turns (one 16-lane row active at a time: every
+        // cross-lane operation of the general path is row-local, its wave votes then see that row only); the others sweep their
+        // bank-A rows meanwhile as on a free step
+        const bool need = gany(lim_lo || lim_hi || c_cap || c_base);
+        u = 0.0;
+        if (!need) u = detail != 0 ? sweeps_free_detail<NB>(r, r2, detail, S_of, lo_of, &u2) : sweeps_free<NB>(r, &r2, &u2);
+        const int myrow = grp::row_id();
+#pragma nounroll
+        for (int turn = 0; turn < grp::kRowsPerWave; turn++) {
+            if (need && myrow == turn) {
+                GenIn in;
+                in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
+                in.r2 = r2; in.bqd2 = 0.0; in.rb = nullptr; in.park = park; in.g = &g; in.e = &e;
+                const GenOut out = general_path<NB, RB, OCC>(in);
+                u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
+            }
+        }
+    } else {
         GenIn in;
         in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
-        in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0; in.rb = rb;
+        in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0; in.rb = rb; in.park = nullptr; in.g = &g; in.e = &e;
         const GenOut out = general_path<NB, RB>(in);
         u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b; u2 = out.u2; dvb_b2 = out.dvb_b2;
         if constexpr (RB) { bodies_done = out.bodies_done; dvo[0] = out.dvo[0]; dvo[1] = out.dvo[1]; dvo[2] = out.dvo[2]; }
@@ -1729,9 +1785,9 @@ struct RbResetHook {          // reset_draw's view of the distractor candidates:
     RBody *B; int l;
     SRL_G void operator()(int i, double ox, double oy, bool keep) const { if (B && i == l) { B->ox = ox; B->oy = oy; B->on = keep; } }
 };
-template <int START, int NB = 1, int RB = 0, class R>
+template <int START, int NB = 1, int RB = 0, int OCC = 0, class R>
 SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, const double *starts, const double *settled,
-                      double *objs, int64_t objs_stride, RBody *rb = nullptr) {
+                      double *objs, int64_t objs_stride, RBody *rb = nullptr, double *park = nullptr) {
 #pragma clang fp contract(off)
     const TL L = lane_view(tab);
     ResetDraw d;
@@ -1755,7 +1811,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         const double motor[3] = {0, 0, 0};
         for (int k = 0; k < kNInitActions; k++) {
             const double jt = L.q0() + kDeltaTheta * d.g[k];
-            tphysics_step<NB, RB>(e, g, tab, cfg, scratch, motor, true, jt, 0.0, rb);
+            tphysics_step<NB, RB, OCC>(e, g, tab, cfg, scratch, motor, true, jt, 0.0, rb, park);
         }
     } else if constexpr (START == 2) {
         const int base = cfg.is_discrete ? 6 : 2;
@@ -1763,7 +1819,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
         double motor[3];
         for (int k = 0; k < kNInitActions; k++) {
             init_action_motor(cfg, rem % base, motor);
-            tphysics_step<NB, RB>(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0, rb);
+            tphysics_step<NB, RB, OCC>(e, g, tab, cfg, scratch, motor, false, L.q0(), 0.0, rb, park);
             rem /= base;
         }
     }
@@ -1772,9 +1828,9 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-template <int NB = 1, int RB = 0, class R>
+template <int NB = 1, int RB = 0, int OCC = 0, class R>
 SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done,
-                       RBody *rb = nullptr) {
+                       RBody *rb = nullptr, double *park = nullptr) {
     if constexpr (RB) {
         // kuka_rand_button_gym_env.py:111-123: at env step 10 the ball is kicked (applyExternalForce: it acts on the next stepSimulation)
         const double kx = shfl(rb->ox, 9), ky = shfl(rb->oy, 9);
@@ -1790,7 +1846,7 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     step_command(e, cfg, rng, action, ca3, c);
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step<NB, RB>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb);
+        tphysics_step<NB, RB, OCC>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

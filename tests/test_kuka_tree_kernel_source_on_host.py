@@ -270,3 +270,23 @@ def test_rand_button_free_bodies():
         assert np.abs(a["q"] - b["q"]).max() <= TOL and np.abs(a["gripper"] - b["gripper"]).max() <= TOL
         assert np.abs(ob - hb).max() <= TOL
         assert (ob[:, 10, 0] > 0.25 + 1e-3).any() and (ob[:, 10, 1] > -0.2 + 1e-3).any()      # kicked balls have moved towards +x, +y (they stop within ~40 steps)
+
+
+# ---- the two-wavefronts-per-SIMD variant's code path (OCC = 1, round 4)
+@pytest.mark.parametrize("detail,tighten", [(0, False), (0, True), (3, True)])
+def test_occ_variant_shared_work_area_and_recomputed_candidates(detail, tighten):
+    """kuka_tree_occ.hip's kernels run tphysics_step / general_path with OCC = 1: one general-path work area per wavefront taken in
+    turns, the own row of M^-1 and the spatial axes parked per env, sphere / limit candidates recomputed inside the turn.  Same
+    trajectories as the oracle (and therefore as the default variant): contact + friction steps, joint-limit rows, detail bits."""
+    t = detail_table(detail, tighten=tighten, budget=3 if tighten else None)
+    try:
+        kuka_clib.set_tree_model(t); hostcheck.tree_set_model(t)
+        hostcheck.lib().hostcheck_kuka_tree_set_occ(1)
+        a = run(6, 900, 5, rng_mode=kuka_clib.RNG_MT19937, random_target=True) if not tighten else run(4, 600, 91, rng_mode=kuka_clib.RNG_PHILOX, random_target=True)
+    finally:
+        hostcheck.lib().hostcheck_kuka_tree_set_occ(0)
+        hostcheck.tree_set_model(None); kuka_clib.set_full(True)
+    if tighten:
+        assert ((a["rows"][:, :, 1] // 1000) > 0).sum() > 50
+    else:
+        assert a["rows"][:, :, 0].sum() > 10
