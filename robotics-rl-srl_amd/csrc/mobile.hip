@@ -134,12 +134,14 @@ __device__ __forceinline__ void observe(const MobileParams &p, const MobileEnv &
 }
 
 // step: mobile_robot_env.py:235-280 --------------------------------------------
-// KIND / DISC >= 0: env kind / action type known at compile time (rollout kernels); -1: read from the params.
-template <int KIND = -1, int DISC = -1>
+// KIND / DISC / SHAPE >= 0: env kind / action type / shaped reward known at compile time (rollout kernels); -1: read from the params.
+// (SHAPE matters: with a run-time flag the compiler evaluates the shaped reward's float64 square root — a reciprocal-square-root
+//  estimate and ten dependent FMAs — in every step and selects afterwards.)
+template <int KIND = -1, int DISC = -1, int SHAPE = -1>
 __device__ __forceinline__ void step_env(const MobileParams &pp, MobileEnv &m, int a, float a0, float a1, double dv,
                                          double &reward, bool &done) {
     struct { int32_t kind, is_discrete, shape_reward; } p = {KIND >= 0 ? KIND : pp.kind, DISC >= 0 ? DISC : pp.is_discrete,
-                                                             pp.shape_reward};
+                                                             SHAPE >= 0 ? SHAPE : pp.shape_reward};
     double dx = 0.0, dy = 0.0;
     if (p.is_discrete) {
         if (p.kind == SRLHIP_ENV_MOBILE_1D) {
@@ -357,12 +359,12 @@ mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileStat
     ctr[e] = rs.ctr[e]; ep_return[e] = st.ep_return[e]; ep_length[e] = st.ep_length[e];
 }
 
-template <int KIND, int DISC>
+template <int KIND, int DISC, int SHAPE, bool ALL>
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
                     const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
                     uint8_t *__restrict__ done_out, int advance_actr, NextPlane next, void *__restrict__ act_out) {
-    p.kind = KIND; p.is_discrete = DISC;                                   // compile-time constants from here on
+    p.kind = KIND; p.is_discrete = DISC; p.shape_reward = SHAPE;            // compile-time constants from here on
     if ((int)blockIdx.x >= next.ep_blocks) {                               // spare workgroups: the next rollout's action plane
         const int64_t i = ((int64_t)blockIdx.x - next.ep_blocks) * kBlock + threadIdx.x;
         if (i < (int64_t)T * p.n) sample_plane_entry(p, rs.key, next.base, (uint64_t)T, i, next.act);
@@ -396,7 +398,44 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
     const int32_t *act_i = static_cast<const int32_t *>(actions);
     const float2 *act_f = static_cast<const float2 *>(actions);
     constexpr int kChunk = 16;                                             // see mobile_rollout_k: one vmcnt drain per chunk
-    for (int t0 = t_lo; t0 < t_hi; t0 += kChunk) {
+    int t_start = t_lo;
+    // Fast loop: whole chunks of INTERIOR steps.  Inside a segment `done` can only fire at the step that ends its episode
+    // (t_end - 1), so every earlier step needs no reset; with all four output planes present (ALL) and every lane of the wavefront
+    // holding a full chunk, a chunk is one straight-line block: no per-step predicate, no reset body to branch around, no plane
+    // checks — the scheduler overlaps one step's conversions and stores with the next step's dependent chain.  Ragged clocks, the
+    // last partial chunk and the episode-ending step go through the general loop below.
+    if constexpr (ALL) {
+        const int t_int_end = t_end - 1 < t_hi ? t_end - 1 : t_hi;       // interior steps: [t_lo, t_int_end)
+        while (__all(t_start + kChunk <= t_int_end)) {
+            int ai[kChunk]; float2 af[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; k++) {
+                const int64_t r = (int64_t)(t_start + k) * p.n + e;
+                if (p.is_discrete) ai[k] = act_i[r]; else af[k] = act_f[r];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+            for (int k = 0; k < kChunk; k++) {
+                const int64_t row = (int64_t)(t_start + k) * p.n + e;
+                const int a = p.is_discrete ? ai[k] : 0;
+                const float a0 = p.is_discrete ? 0.f : af[k].x, a1 = p.is_discrete ? 0.f : af[k].y;
+                if (p.is_discrete) __builtin_nontemporal_store(a, static_cast<int32_t *>(act_out) + row);
+                else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+                const double dv = 0.1 + rng.normal(0.0, 0.0);
+                double reward; bool done;
+                step_env<KIND, DISC, SHAPE>(p, m, a, a0, a1, dv, reward, done);     // done is false here (interior step)
+                ep_ret += reward; ep_len += 1; last_reward = reward;
+                float o0, o1;
+                observe(p, m, o0, o1);
+                if (p.kind == SRLHIP_ENV_MOBILE_1D) __builtin_nontemporal_store(o0, obs + row);
+                else __builtin_nontemporal_store(f32x2{o0, o1}, reinterpret_cast<f32x2 *>(obs + 2 * row));
+                __builtin_nontemporal_store((float)reward, rew + row);
+                __builtin_nontemporal_store((uint8_t)0, done_out + row);
+            }
+            t_start += kChunk;
+        }
+    }
+    for (int t0 = t_start; t0 < t_hi; t0 += kChunk) {
         int ai[kChunk]; float2 af[kChunk];
 #pragma unroll
         for (int k = 0; k < kChunk; k++) {
@@ -417,7 +456,7 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
                 }
                 const double dv = 0.1 + rng.normal(0.0, 0.0);              // DELTA_POS + N(0, NOISE_STD = 0): draws nothing
                 double reward; bool done;
-                step_env<KIND, DISC>(p, m, a, a0, a1, dv, reward, done);
+                step_env<KIND, DISC, SHAPE>(p, m, a, a0, a1, dv, reward, done);
                 ep_ret += reward; ep_len += 1; last_reward = reward;
                 if (done) {
                     seg_ret = ep_ret; seg_len = ep_len; ep_ret = 0.0; ep_len = 0;
@@ -546,10 +585,14 @@ int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_act
     const NextPlane next{next_plane, h->snap_actr, ep_blocks};
     dim3 grid((unsigned)(ep_blocks + extra)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
-#define SRL_GO(KIND, DISC)                                                                                              \
-    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
+    const bool all_planes = d_obs && d_rew && d_done && act_out;           // the fast loop stores without checking
+#define SRL_EP(KIND, DISC, SHAPE, ALL)                                                                                  \
+    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC, SHAPE, ALL>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
                        draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr, next, act_out)
-#define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
+#define SRL_GO(KIND, DISC)                                                                                              \
+    { if (p.shape_reward) { if (all_planes) SRL_EP(KIND, DISC, 1, true); else SRL_EP(KIND, DISC, 1, false); }           \
+      else { if (all_planes) SRL_EP(KIND, DISC, 0, true); else SRL_EP(KIND, DISC, 0, false); } }
+#define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1) else SRL_GO(KIND, 0) }
     switch (p.kind) {
         case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
         case SRLHIP_ENV_MOBILE_1D: SRL_KIND(SRLHIP_ENV_MOBILE_1D) break;
@@ -558,6 +601,7 @@ int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_act
     }
 #undef SRL_KIND
 #undef SRL_GO
+#undef SRL_EP
     return 0;
 }
 
