@@ -23,6 +23,13 @@
 // wavefront): taking the 10-round Philox block out of that chain is what matters — and so is cutting the chain
 // itself: with counter-based streams the episodes of an env are independent of each other, so a T-step rollout runs
 // as ceil(T / 251) + 1 segments per env on separate lanes (mobile_rollout_ep_k below).
+// Round 4: what is left is the issue stream of ONE wavefront over 251 steps, so the step was cut from ~200 to 57 instructions —
+// the shaped reward's float64 square root is a template parameter (with a run-time flag it was evaluated every step and
+// selected away), interior steps run in straight-line chunks of 8 (no per-step predicate, no reset body to branch around, no
+// plane checks; the next chunk's actions are requested ahead of the chunk's stores), and the sampler workgroups index the plane
+// without 64-bit divisions: 0.095 -> 0.053 ms per 4096-env x 2048-step rollout with the synthetic agent (of which ~15 us are the
+// sampler workgroups' 8.4 M Philox blocks sharing the SIMDs), 0.0375 ms with caller-supplied actions
+// (profiles/probes/mobile_chain_probe.py, profiles/r04_mobile_*).
 #include "internal.hpp"
 
 namespace srl {
@@ -244,21 +251,28 @@ __device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0
 }
 
 // All T x N synthetic actions of a rollout at once: thread (t, e) draws block act_ctr[e] + t of env e's action stream.
-// entry i = t * N + e of a [T][N] action plane whose first row is block base[e] + offset of env e's action stream
-__device__ __forceinline__ void sample_plane_entry(const MobileParams &p, const uint32_t *key, const uint64_t *base, uint64_t offset, int64_t i,
-                                                   void *__restrict__ act) {
-    const int e = (int)(i % p.n);
-    const int64_t t = i / p.n;
+// entry t * N + e of a [T][N] action plane whose first row is block base[e] + offset of env e's action stream.
+// The plane is covered by T rows of `bpr` workgroups; workgroup `sb` finds its row without an integer division (a 64-bit i / n and
+// i % n per entry cost three times the Philox block they index): t = trunc(sb * (1 / bpr)) in float64, off by at most one, corrected.
+struct PlaneMap { uint32_t bpr; double inv_bpr; };
+inline PlaneMap plane_map(int64_t n) { PlaneMap m; m.bpr = (uint32_t)((n + kBlock - 1) / kBlock); m.inv_bpr = 1.0 / (double)m.bpr; return m; }
+__device__ __forceinline__ void sample_plane_entry(const MobileParams &p, const uint32_t *key, const uint64_t *base, uint64_t offset, uint32_t sb,
+                                                   const PlaneMap &pm, int T, void *__restrict__ act) {
+    int32_t t = (int32_t)((double)sb * pm.inv_bpr);
+    int32_t r = (int32_t)sb - t * (int32_t)pm.bpr;
+    if (r < 0) { t -= 1; r += (int32_t)pm.bpr; } else if (r >= (int32_t)pm.bpr) { t += 1; r -= (int32_t)pm.bpr; }
+    const int64_t e64 = (int64_t)r * kBlock + threadIdx.x;
+    if (t >= T || e64 >= p.n) return;
+    const int e = (int)e64;
+    const int64_t i = (int64_t)t * p.n + e;
     int a = 0; float a0 = 0.f, a1 = 0.f;
     sample_action(p, key[e], key[p.n + e], base[e] + offset + (uint64_t)t, a, a0, a1);
     if (p.is_discrete) static_cast<int32_t *>(act)[i] = a;
     else static_cast<float2 *>(act)[i] = make_float2(a0, a1);
 }
 __global__ void __launch_bounds__(kBlock)
-mobile_sample_actions_k(MobileParams p, RngState rs, int T, void *__restrict__ act) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= (int64_t)T * p.n) return;
-    sample_plane_entry(p, rs.key, rs.act_ctr, 0, i, act);
+mobile_sample_actions_k(MobileParams p, RngState rs, int T, PlaneMap pm, void *__restrict__ act) {
+    sample_plane_entry(p, rs.key, rs.act_ctr, 0, blockIdx.x, pm, T, act);
 }
 
 // One launch == T consecutive VecEnv steps; T == 1 with plain stores is the per-step entry point, T > 1 the fused
@@ -347,7 +361,7 @@ struct MobileSnap { MobileState s; const uint64_t *ctr; const double *ep_return;
 // The synthetic agent's NEXT action plane, drawn by the workgroups of a rollout launch beyond its segment lanes (the rollout itself
 // is a latency-bound recurrence on 10 x N lanes: the chip has room) so that the following rollout starts without a sampler launch:
 // block base[e] + T + t of env e's action stream (base = the counters in the snapshot: the live ones move when the rollout ends).
-struct NextPlane { void *act; const uint64_t *base; int ep_blocks; };
+struct NextPlane { void *act; const uint64_t *base; int ep_blocks; PlaneMap pm; };
 
 __global__ void __launch_bounds__(kBlock)
 mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileState d, uint64_t *ctr, double *ep_return, int32_t *ep_length, uint64_t *actr) {
@@ -359,15 +373,14 @@ mobile_snapshot_k(int n, MobileState s, RngState rs, EpisodeStats st, MobileStat
     ctr[e] = rs.ctr[e]; ep_return[e] = st.ep_return[e]; ep_length[e] = st.ep_length[e];
 }
 
-template <int KIND, int DISC, int SHAPE, bool ALL>
+template <int KIND, int DISC, int SHAPE, int PLANES>      // PLANES: 0 check every output plane, 1 obs / reward / done present, 2 those and act_out
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
                     const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
                     uint8_t *__restrict__ done_out, int advance_actr, NextPlane next, void *__restrict__ act_out) {
     p.kind = KIND; p.is_discrete = DISC; p.shape_reward = SHAPE;            // compile-time constants from here on
     if ((int)blockIdx.x >= next.ep_blocks) {                               // spare workgroups: the next rollout's action plane
-        const int64_t i = ((int64_t)blockIdx.x - next.ep_blocks) * kBlock + threadIdx.x;
-        if (i < (int64_t)T * p.n) sample_plane_entry(p, rs.key, next.base, (uint64_t)T, i, next.act);
+        sample_plane_entry(p, rs.key, next.base, (uint64_t)T, blockIdx.x - (uint32_t)next.ep_blocks, next.pm, T, next.act);
         return;
     }
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -404,23 +417,31 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
     // holding a full chunk, a chunk is one straight-line block: no per-step predicate, no reset body to branch around, no plane
     // checks — the scheduler overlaps one step's conversions and stores with the next step's dependent chain.  Ragged clocks, the
     // last partial chunk and the episode-ending step go through the general loop below.
-    if constexpr (ALL) {
+    if constexpr (PLANES > 0) {
+        // The actions of the NEXT chunk are requested before this chunk's steps: loads and stores retire in order on one counter
+        // (vmcnt), so a load issued ahead of the chunk's 3-4 x kFast stores is awaited with those stores still in flight (the compiler
+        // counts them: the block is straight-line) instead of exposing a full memory round trip per chunk.  8 + 32 operations stay
+        // below the counter's 63.
+        constexpr int kFast = 8;
         const int t_int_end = t_end - 1 < t_hi ? t_end - 1 : t_hi;       // interior steps: [t_lo, t_int_end)
-        while (__all(t_start + kChunk <= t_int_end)) {
-            int ai[kChunk]; float2 af[kChunk];
+        int ai[kFast]; float2 af[kFast];
+        auto fetch = [&](int t0, int *di, float2 *df) {
 #pragma unroll
-            for (int k = 0; k < kChunk; k++) {
-                const int64_t r = (int64_t)(t_start + k) * p.n + e;
-                if (p.is_discrete) ai[k] = act_i[r]; else af[k] = act_f[r];
+            for (int k = 0; k < kFast; k++) {
+                const int64_t r = (int64_t)min(t0 + k, t_hi - 1) * p.n + e;   // clamped: a prefetch past the segment is harmless
+                if (p.is_discrete) di[k] = act_i[r]; else df[k] = act_f[r];
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+        };
+        auto chunk = [&](const int *ci, const float2 *cf) {
 #pragma unroll
-            for (int k = 0; k < kChunk; k++) {
+            for (int k = 0; k < kFast; k++) {
                 const int64_t row = (int64_t)(t_start + k) * p.n + e;
-                const int a = p.is_discrete ? ai[k] : 0;
-                const float a0 = p.is_discrete ? 0.f : af[k].x, a1 = p.is_discrete ? 0.f : af[k].y;
-                if (p.is_discrete) __builtin_nontemporal_store(a, static_cast<int32_t *>(act_out) + row);
-                else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+                const int a = p.is_discrete ? ci[k] : 0;
+                const float a0 = p.is_discrete ? 0.f : cf[k].x, a1 = p.is_discrete ? 0.f : cf[k].y;
+                if constexpr (PLANES == 2) {
+                    if (p.is_discrete) __builtin_nontemporal_store(a, static_cast<int32_t *>(act_out) + row);
+                    else static_cast<float2 *>(act_out)[row] = make_float2(a0, a1);
+                }
                 const double dv = 0.1 + rng.normal(0.0, 0.0);
                 double reward; bool done;
                 step_env<KIND, DISC, SHAPE>(p, m, a, a0, a1, dv, reward, done);     // done is false here (interior step)
@@ -432,7 +453,22 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
                 __builtin_nontemporal_store((float)reward, rew + row);
                 __builtin_nontemporal_store((uint8_t)0, done_out + row);
             }
-            t_start += kChunk;
+            t_start += kFast;
+        };
+        if (__all(t_start + kFast <= t_int_end)) {
+            fetch(t_start, ai, af);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) once, so that the loop header has nothing pending on either path
+            do {
+                int ni[kFast]; float2 nf[kFast];
+                fetch(t_start + kFast, ni, nf);
+                __builtin_amdgcn_sched_barrier(0);                         // keep the requests AHEAD of the chunk's stores
+                chunk(ai, af);
+                __builtin_amdgcn_sched_barrier(0);
+                // the copies are the first use of the prefetched registers: the wait lands HERE, where what is pending is known
+                // exactly (8 loads, then 32 stores) — at the loop header it would be merged with the entry path and drain everything
+#pragma unroll
+                for (int k = 0; k < kFast; k++) { ai[k] = ni[k]; af[k] = nf[k]; }
+            } while (__all(t_start + kFast <= t_int_end));
         }
     }
     for (int t0 = t_start; t0 < t_hi; t0 += kChunk) {
@@ -581,17 +617,17 @@ int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_act
     const int smax = 1 + (T - 1 + kEpisodeSteps - 1) / kEpisodeSteps;     // first segment of one step + whole episodes
     const int64_t lanes = (int64_t)smax * h->n;
     const int ep_blocks = (int)((lanes + kBlock - 1) / kBlock);
-    const int64_t extra = next_plane ? ((int64_t)T * h->n + kBlock - 1) / kBlock : 0;
-    const NextPlane next{next_plane, h->snap_actr, ep_blocks};
+    const PlaneMap pm = plane_map(h->n);
+    const int64_t extra = next_plane ? (int64_t)T * pm.bpr : 0;
+    const NextPlane next{next_plane, h->snap_actr, ep_blocks, pm};
     dim3 grid((unsigned)(ep_blocks + extra)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
-    const bool all_planes = d_obs && d_rew && d_done && act_out;           // the fast loop stores without checking
-#define SRL_EP(KIND, DISC, SHAPE, ALL)                                                                                  \
-    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC, SHAPE, ALL>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
+    const int planes = d_obs && d_rew && d_done ? (act_out ? 2 : 1) : 0;   // the fast loop stores without checking
+#define SRL_EP(KIND, DISC, SHAPE, PLANES)                                                                               \
+    hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC, SHAPE, PLANES>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
                        draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr, next, act_out)
-#define SRL_GO(KIND, DISC)                                                                                              \
-    { if (p.shape_reward) { if (all_planes) SRL_EP(KIND, DISC, 1, true); else SRL_EP(KIND, DISC, 1, false); }           \
-      else { if (all_planes) SRL_EP(KIND, DISC, 0, true); else SRL_EP(KIND, DISC, 0, false); } }
+#define SRL_PL(KIND, DISC, SHAPE) { if (planes == 2) SRL_EP(KIND, DISC, SHAPE, 2); else if (planes == 1) SRL_EP(KIND, DISC, SHAPE, 1); else SRL_EP(KIND, DISC, SHAPE, 0); }
+#define SRL_GO(KIND, DISC) { if (p.shape_reward) SRL_PL(KIND, DISC, 1) else SRL_PL(KIND, DISC, 0) }
 #define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1) else SRL_GO(KIND, 0) }
     switch (p.kind) {
         case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
@@ -601,6 +637,7 @@ int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_act
     }
 #undef SRL_KIND
 #undef SRL_GO
+#undef SRL_PL
 #undef SRL_EP
     return 0;
 }
@@ -632,9 +669,9 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
             int cur = 0;
             if (h->prefetch_valid && h->prefetch_T == T) cur = h->prefetch_buf;
             else {
-                const int64_t total = (int64_t)T * h->n;
-                hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                                   p, h->rng, T, h->act_plane[0]);
+                const PlaneMap pm = plane_map(h->n);
+                hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((int64_t)T * pm.bpr)), dim3(kBlock), 0, h->stream,
+                                   p, h->rng, T, pm, h->act_plane[0]);
                 SRL_HIP_CHECK(h, hipGetLastError());
             }
             int rc = launch_rollout_ep(h, p, T, h->act_plane[cur], d_obs, d_rew, d_done, 1, h->act_plane[cur ^ 1], d_act_out);
@@ -658,9 +695,9 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
             }
             plane = h->st_noise;
         }
-        const int64_t total = (int64_t)T * h->n;
-        hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                           p, h->rng, T, plane);
+        const PlaneMap pm = plane_map(h->n);
+        hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((int64_t)T * pm.bpr)), dim3(kBlock), 0, h->stream,
+                           p, h->rng, T, pm, plane);
         SRL_HIP_CHECK(h, hipGetLastError());
         d_actions = plane;
         advance = 1;
