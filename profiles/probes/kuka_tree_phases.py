@@ -29,5 +29,7 @@ for rep in range(2):
 h.close()
 names = ["action / noise sampling + action mapping (loop top .. physics step)", "IK", "collision + motor targets", "RNEA sums", "CRBA", "Gauss-Jordan 12x12", "row setup",
          "150 sweeps, free steps", "sweeps + setup, steps with generic rows", "integrate + refresh (sincos, FK)",
-         "counters, reward, termination", "episode statistics, auto-reset, observation + output stores"]
+         "counters, reward, termination", "episode statistics, auto-reset, observation + output stores",
+         "generic: candidates -> row definitions", "generic: W J of every slot", "generic: own bank-B row (diagonal, rhs, couplings)", "generic: the 150 sweeps",
+         "generic: outputs", "NUMBER of steps with generic rows (a count, not cycles)", "NUMBER of steps with a joint-limit row", "NUMBER of steps with a contact row"]
 print("phase names:", {i: s for i, s in enumerate(names)})

@@ -45,11 +45,13 @@ using grp::wany;
 // between consecutive stamps, accumulated per phase by lane 0 of the workgroup in LDS, printed by workgroup 0 when the kernel ends.
 // The product build compiles them away.
 #if defined(SRL_TREE_PROF) && SRL_G_DEVICE
-constexpr int kProfSlots = 12;
+constexpr int kProfSlots = 20;      // 0..11: phases of a step; 12..16: inside general_path; 17..19: number of steps with generic rows / a limit row / a contact row
 SRL_G unsigned long long *tprof_buf() { __shared__ unsigned long long p[kProfSlots + 1]; return p; }
+#define SRL_TCOUNT(i) do { if (threadIdx.x == 0) tprof_buf()[i] += 1; } while (0)
 #define SRL_TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long *p_ = tprof_buf(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p_[i] += t_ - p_[kProfSlots]; p_[kProfSlots] = t_; } } while (0)
 #else
 #define SRL_TSTAMP(i)
+#define SRL_TCOUNT(i)
 #endif
 
 constexpr int NJ = 12;                          // joint lanes
@@ -1000,6 +1002,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     static_assert(!OCC || (NB == 1 && RB == 0), "the two-wavefronts-per-SIMD variant covers the one-button envs");
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
     // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
+    SRL_TSTAMP(8); SRL_TCOUNT(17);
     const double dt = kDt, inv_dt = 1.0 / kDt;
     const double *tab = in.tab;
     double *sc = in.scratch;
@@ -1128,6 +1131,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         if constexpr (RB) { if (c_obj) put_contact(s_cap2, n_obj, d_obj, false, 0, k_obj); }
         sync_scratch();
     }
+    SRL_TSTAMP(12);                         // candidates -> row definitions in LDS
     nlim_w = 0; ngen_w = 0;
 #pragma nounroll
     for (int k = 0; k < kNGen; k++) { if (wany(k < nlim)) nlim_w = k + 1; if (wany(k < ngen)) ngen_w = k + 1; }
@@ -1152,6 +1156,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         }
     }
     sync_scratch();                        // W J complete; the parked W rows (NBA plane) are dead from here on
+    SRL_TSTAMP(13);                         // W J of every slot
     {
         // ---- the own bank-B row (slot == lane): scalars, diagonal, couplings to bank A and to bank B
         const int own_slot = L.l < kNB ? L.l : 0;                       // lanes >= kNB own no bank-B row
@@ -1230,6 +1235,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         on_lim = b.on && L.l < nlim; on_con = b.on && !on_lim;
     }
     sync_scratch();
+    SRL_TSTAMP(14);                         // the own bank-B row: diagonal, right-hand side, couplings
     // ---- Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
     // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept before
     // any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
@@ -1253,6 +1259,8 @@ SRL_G GenOut general_path(const GenIn &in) {
     const bool obj_rows_w = RB && wany(b.on && b.obj >= 0);
     RbRows rr;
     if constexpr (RB) { if (obj_rows_w) rb_rows_setup(*in.rb, L.table_z(), cerp, slop, L.friction(), rr); }
+    if (nlim_w > 0) SRL_TCOUNT(18);        // profiling build: steps of this wavefront with a joint-limit row
+    if (ngen_w > nlim_w) SRL_TCOUNT(19);   //                  ... with a contact row
     if (detail != 0 || obj_rows_w) {
         // the model's solver details: total-sum formulation (d_rowA / d_rowB above), rows in the order the bits ask for
         DState st;
@@ -1304,6 +1312,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         for (int s = 0; s < ngen_w; s++) gen_rowB<NB>(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0, &accC, NB == 2 ? nCB_of(s) : 0.0);
         for (int s = kNGen; s < kNGen + ngen_w; s++) gen_rowB<NB>(L, sc, s, b, accA, accB, shfl(on_con ? 1.0 : 0.0, s) != 0.0, &accC, NB == 2 ? nCB_of(s) : 0.0);
     }
+    SRL_TSTAMP(15);                         // the 150 sweeps
     GenOut out;
     out.u = uA; out.acc_b = 0.0; out.dvb_b = 0.0; out.u2 = uC; out.dvb_b2 = 0.0;
     out.bodies_done = obj_rows_w; out.dvo[0] = 0.0; out.dvo[1] = 0.0; out.dvo[2] = 0.0;
@@ -1316,6 +1325,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         if constexpr (NB == 2) out.dvb_b2 += shfl(b.bsel ? pbb : 0.0, s);
     }
     sync_scratch();                          // scratch is reused by the next step
+    SRL_TSTAMP(16);
     return out;
 }
 
