@@ -107,7 +107,7 @@ def test_episode_parallel_rollout_equals_step_by_step(kind, random_target, discr
         acts = rs.randint(N_ACT[kind], size=(T + 200, n)).astype(np.int32)
     else:
         acts = rs.uniform(-1.2, 1.2, size=(T + 200, n, 2)).astype(np.float32)
-    hs = [make(kind, n, _lib.RNG_PHILOX, seed0=21, random_target=random_target, is_discrete=discrete) for _ in range(2)]
+    hs = [make(kind, n, _lib.RNG_PHILOX, seed0=21, random_target=random_target, is_discrete=discrete, shape_reward=1 if kind == 2 else 0) for _ in range(2)]
     for h in hs:
         h.reset()
         h.rollout(70, actions=acts[:70])                               # T >= 32: already the episode-parallel kernel
@@ -326,3 +326,40 @@ def test_synthetic_agent_action_plane_drawn_ahead(kind, is_discrete):
             if k in x and x[k] is not None:
                 assert np.array_equal(x[k], y[k]), k
     assert not np.array_equal(a[0]["actions"], a[1]["actions"])         # consecutive planes continue the stream
+
+
+@pytest.mark.parametrize("kind,shape_reward", [(0, 1), (2, 1), (3, 1), (1, 1), (0, 0)])
+def test_episode_parallel_kernel_instantiations(kind, shape_reward):
+    """mobile_rollout_ep_k is compiled per (kind, action type, shaped reward, which output planes exist): the shaped reward's
+    float64 sqrt, the straight-line chunks of interior steps with all four planes (synthetic agent), with three (the caller's
+    actions) and the per-step checked loop (a plane missing) — every combination against the oracle's Philox restatement
+    (ragged episode clocks inside a wavefront: test_episode_parallel_rollout_equals_step_by_step)."""
+    n, T = 700, 2 * 251 + 61
+    rs = np.random.RandomState(40 + kind)
+    acts = rs.randint(N_ACT[kind], size=(T + 90, n)).astype(np.int32)
+    seeds = 9 + np.arange(n)
+    okw = dict(shape_reward=bool(shape_reward), random_target=True, rng_mode=clib.RNG_PHILOX)
+    # (a) caller's actions, all output planes: three stores per step
+    h = make(kind, n, _lib.RNG_PHILOX, seed0=9, shape_reward=shape_reward, random_target=1)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=acts[:T])
+    ora = clib.mobile_rollout(kind, seeds, T, actions=acts[:T], **okw)
+    assert_same(ora, obs0, out["obs"], out["reward"], out["done"], "given")
+    if shape_reward:
+        assert np.array_equal(h.get_state(_lib.F_LAST_REWARD), ora["reward64"][-1])
+    # (b) the same continued with a plane missing (reward not wanted): the checked loop; the state it leaves must be the same
+    more = h.rollout(90, actions=acts[T:], want=("obs", "done"))
+    ora2 = clib.mobile_rollout(kind, seeds, T + 90, actions=acts, **okw)
+    assert np.array_equal(more["obs"], ora2["obs"][T:]) and np.array_equal(more["done"], ora2["done"][T:])
+    h.close()
+    # (c) synthetic agent: four stores per step; the second rollout starts 77 steps into the episodes
+    h = make(kind, n, _lib.RNG_PHILOX, seed0=9, shape_reward=shape_reward, random_target=1)
+    h.reset()
+    a = h.rollout(77)
+    b = h.rollout(T)
+    ora = clib.mobile_rollout(kind, seeds, 77 + T, actions=None, **okw)
+    assert np.array_equal(np.concatenate([a["actions"], b["actions"]]), ora["actions"])
+    assert np.array_equal(np.concatenate([a["obs"], b["obs"]]), ora["obs"])
+    assert np.array_equal(np.concatenate([a["reward"], b["reward"]]), ora["reward"])
+    assert np.array_equal(np.concatenate([a["done"], b["done"]]), ora["done"])
+    h.close()
