@@ -683,7 +683,8 @@ template <int G, int NB = 1> SRL_G void cn_rowN(const BRow &b, double &tN, doubl
 // friction slot kNGen + G: bounds +-mu * (current impulse of normal slot G); the row keeps its value while that is not positive
 // (mu > 0 on a lane that owns an active friction row, 0 elsewhere: hi > 0 says both)
 template <int G, int NB = 1> SRL_G void cn_rowF(const BRow &b, double tN, double &tF, double nAB, double nBB, double eS, double &accA, double &accB, double *accC = nullptr, double nCB = 0.0) {
-    const double hi = b.mu * bcast<G>(tN);
+    double hi = 0.0;
+    fmac_bcast<G>(hi, tN, b.mu);                    // mu * (impulse of normal slot G), one DPP instruction (0 + a b rounds like a b)
     double t = fmin(fmax(b.cs + accB, -hi), hi);
     t = hi > 0.0 ? t : tF;
     accB = fma(-eS, accB, accB);
@@ -748,9 +749,35 @@ template <int G> SRL_G void cn_rowNs(double csU, double &tN, double nAB, double 
 #endif
     tN = t;
 }
-template <int G> SRL_G void cn_normals_s(double csU, double *tN, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB, int ngen_w) {
-    if (G < ngen_w) cn_rowNs<G>(csU, tN[G], nAB[G], nBB[G], eB[G], accA, accB);
-    if constexpr (G + 1 < kNGen) cn_normals_s<G + 1>(csU, tN, nAB, nBB, eB, accA, accB, ngen_w);
+// The one-button sweep loop with the number of bank-B slots in use as a COMPILE-TIME constant: with a run-time count every slot
+// costs a check (the compiler round-trips the condition through a VGPR: four instructions per slot, 48 of the loop's 261), and
+// contact steps — four to six per cent of all steps, 160 k cycles each, which is also what a single-step launch lasts — are
+// this loop 150 times.
+template <int G, int NG> SRL_G void cn_normals_sn(double csU, double *tN, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB) {
+    if constexpr (G < NG) {
+        cn_rowNs<G>(csU, tN[G], nAB[G], nBB[G], eB[G], accA, accB);
+        cn_normals_sn<G + 1, NG>(csU, tN, nAB, nBB, eB, accA, accB);
+    }
+}
+template <int G, int NG> SRL_G void cn_frictions_n(const BRow &b, const double *tN, double *tF, const double *nAB, const double *nBB, const double *eB, double &accA, double &accB) {
+    if constexpr (G < NG) {
+        cn_rowF<G>(b, tN[G], tF[G], nAB[kNGen + G], nBB[kNGen + G], eB[kNGen + G], accA, accB);
+        cn_frictions_n<G + 1, NG>(b, tN, tF, nAB, nBB, eB, accA, accB);
+    }
+}
+template <int NG> SRL_G void cn_sweeps(const TRows &r, const BRow &bb, const double *nBA, const double *eA, double e0, double e1, double e2, const double *nAB,
+                                       const double *nBB, const double *eB, double &accA, double &accB, double &uA, double *tN, double *tF) {
+#define SRL_CN_SWEEP(LAST)                                                                                                                     \
+    cn_rowA2<0, kBM, LAST>(r, nBA[0], nBA[kBM], e0, accA, accB, uA);   cn_rowA2<1, kBLo, LAST>(r, nBA[1], nBA[kBLo], e1, accA, accB, uA);      \
+    cn_rowA2<2, kBHi, LAST>(r, nBA[2], nBA[kBHi], e2, accA, accB, uA);                                                                         \
+    cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
+    cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
+    cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
+    cn_normals_sn<0, NG>(bb.cs, tN, nAB, nBB, eB, accA, accB);                                                                                 \
+    cn_frictions_n<0, NG>(bb, tN, tF, nAB, nBB, eB, accA, accB);
+    for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
+    { SRL_CN_SWEEP(true) }
+#undef SRL_CN_SWEEP
 }
 // Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
 // stops, normals, frictions).  nCB: the second button's rows' couplings to the bank-B slots (per lane, zero off the button lanes).
@@ -818,17 +845,15 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     double accB = 0.0, uA = 0.0, tN[kNGen], tF[kNGen];
 #pragma unroll
     for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
-#define SRL_CN_SWEEP(LAST)                                                                                                                     \
-    cn_rowA2<0, kBM, LAST>(r, nBA[0], nBA[kBM], e0, accA, accB, uA);   cn_rowA2<1, kBLo, LAST>(r, nBA[1], nBA[kBLo], e1, accA, accB, uA);      \
-    cn_rowA2<2, kBHi, LAST>(r, nBA[2], nBA[kBHi], e2, accA, accB, uA);                                                                         \
-    cn_rowA<3, LAST>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, LAST>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, LAST>(r, nBA[5], eA[5], accA, accB, uA);   \
-    cn_rowA<6, LAST>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, LAST>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, LAST>(r, nBA[8], eA[8], accA, accB, uA);   \
-    cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
-    cn_normals_s<0>(bb.cs, tN, nAB, nBB, eB, accA, accB, ngen_w);                                                                              \
-    cn_frictions<0>(bb, tN, tF, nAB, nBB, eB, accA, accB, ngen_w);
-    for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
-    { SRL_CN_SWEEP(true) }
-#undef SRL_CN_SWEEP
+    switch (ngen_w) {                                  // wave-uniform
+        case 0: cn_sweeps<0>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 1: cn_sweeps<1>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 2: cn_sweeps<2>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 3: cn_sweeps<3>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 4: cn_sweeps<4>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 5: cn_sweeps<5>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        default: cn_sweeps<kNGen>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+    }
     b.lam = cn_own_lambda(tN, tF, l) * (l < kNGen ? Sn : 1.0);
     return uA;
 }
