@@ -765,6 +765,55 @@ template <int G, int NG> SRL_G void cn_frictions_n(const BRow &b, const double *
         cn_frictions_n<G + 1, NG>(b, tN, tF, nAB, nBB, eB, accA, accB);
     }
 }
+// The bank-A rows of a one-button contact sweep (every sweep but the last) as three hand-scheduled statements.  A DPP operand
+// written by the previous VALU instruction needs two wait states; a row written on its own fills them with the restart FMA and
+// an s_nop and is followed by the compiler's statement padding: six issue slots.  Here the row's second fmac (its coupling into
+// the bank-B accumulator, which nothing reads before the bank-B phase) is DEFERRED into the next row's wait states — rows
+// alternate between two value registers — so a row is four slots: add, restart, previous row's accB fmac, own accA fmac
+// (profiles/probes/pgs_row_timing.hip: 11.4 -> 9.2 ns per row; the dependent chain add -> fmac alone is 7.9).  Same operations
+// on the same accumulators in the same order: bit-identical to cn_rowA / cn_rowA2.
+SRL_G void cn_phaseA(const TRows &r, const double *nBA, const double *eA, double e0, double e1, double e2, double &accA, double &accB) {
+#if SRL_G_DEVICE
+    double t0, t1;
+#define SRL_DPP(J) " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("v_add_f64 %[t0], %[cs], %[a] clamp\n\tv_fma_f64 %[a], -%[e0], %[a], %[a]\n\ts_nop 0\n\t"
+                 "v_fmac_f64_dpp %[a], %[t0], %[n0]" SRL_DPP(0) "v_fmac_f64_dpp %[a], %[t0], %[n12]" SRL_DPP(12)
+                 "v_add_f64 %[t1], %[cs], %[a] clamp\n\tv_fma_f64 %[a], -%[e1], %[a], %[a]\n\t"
+                 "v_fmac_f64_dpp %[b], %[t0], %[m0]" SRL_DPP(0) "v_fmac_f64_dpp %[b], %[t0], %[m12]" SRL_DPP(12)
+                 "v_fmac_f64_dpp %[a], %[t1], %[n1]" SRL_DPP(1) "v_fmac_f64_dpp %[a], %[t1], %[n13]" SRL_DPP(13)
+                 "v_add_f64 %[t0], %[cs], %[a] clamp\n\tv_fma_f64 %[a], -%[e2], %[a], %[a]\n\t"
+                 "v_fmac_f64_dpp %[b], %[t1], %[m1]" SRL_DPP(1) "v_fmac_f64_dpp %[b], %[t1], %[m13]" SRL_DPP(13)
+                 "v_fmac_f64_dpp %[a], %[t0], %[n2]" SRL_DPP(2) "v_fmac_f64_dpp %[a], %[t0], %[n14]" SRL_DPP(14)
+                 : [a] "+v"(accA), [b] "+v"(accB), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                 : [cs] "v"(r.cs), [e0] "v"(e0), [e1] "v"(e1), [e2] "v"(e2), [n0] "v"(r.n[0]), [n12] "v"(r.n[kBM]), [n1] "v"(r.n[1]), [n13] "v"(r.n[kBLo]),
+                   [n2] "v"(r.n[2]), [n14] "v"(r.n[kBHi]), [m0] "v"(nBA[0]), [m12] "v"(nBA[kBM]), [m1] "v"(nBA[1]), [m13] "v"(nBA[kBLo]));
+#define SRL_A1(T, TP, J, JP) "v_add_f64 %[" #T "], %[cs], %[a] clamp\n\tv_fma_f64 %[a], -%[e" #J "], %[a], %[a]\n\t"                 \
+                             "v_fmac_f64_dpp %[b], %[" #TP "], %[m" #JP "]" SRL_DPP(JP) "v_fmac_f64_dpp %[a], %[" #T "], %[n" #J "]" SRL_DPP(J)
+    asm volatile("v_add_f64 %[t1], %[cs], %[a] clamp\n\tv_fma_f64 %[a], -%[e3], %[a], %[a]\n\t"
+                 "v_fmac_f64_dpp %[b], %[t0], %[m2]" SRL_DPP(2) "v_fmac_f64_dpp %[b], %[t0], %[m14]" SRL_DPP(14)
+                 "v_fmac_f64_dpp %[a], %[t1], %[n3]" SRL_DPP(3)
+                 SRL_A1(t0, t1, 4, 3) SRL_A1(t1, t0, 5, 4) SRL_A1(t0, t1, 6, 5) SRL_A1(t1, t0, 7, 6)
+                 : [a] "+v"(accA), [b] "+v"(accB), [t0] "+v"(t0), [t1] "=&v"(t1)
+                 : [cs] "v"(r.cs), [e3] "v"(eA[3]), [e4] "v"(eA[4]), [e5] "v"(eA[5]), [e6] "v"(eA[6]), [e7] "v"(eA[7]),
+                   [n3] "v"(r.n[3]), [n4] "v"(r.n[4]), [n5] "v"(r.n[5]), [n6] "v"(r.n[6]), [n7] "v"(r.n[7]),
+                   [m2] "v"(nBA[2]), [m14] "v"(nBA[kBHi]), [m3] "v"(nBA[3]), [m4] "v"(nBA[4]), [m5] "v"(nBA[5]), [m6] "v"(nBA[6]));
+    asm volatile(SRL_A1(t0, t1, 8, 7) SRL_A1(t1, t0, 9, 8) SRL_A1(t0, t1, 10, 9) SRL_A1(t1, t0, 11, 10)
+                 "v_fmac_f64_dpp %[b], %[t1], %[m11]" SRL_DPP(11)
+                 : [a] "+v"(accA), [b] "+v"(accB), [t0] "=&v"(t0), [t1] "+v"(t1)
+                 : [cs] "v"(r.cs), [e8] "v"(eA[8]), [e9] "v"(eA[9]), [e10] "v"(eA[10]), [e11] "v"(eA[11]),
+                   [n8] "v"(r.n[8]), [n9] "v"(r.n[9]), [n10] "v"(r.n[10]), [n11] "v"(r.n[11]),
+                   [m7] "v"(nBA[7]), [m8] "v"(nBA[8]), [m9] "v"(nBA[9]), [m10] "v"(nBA[10]), [m11] "v"(nBA[11]));
+#undef SRL_A1
+#undef SRL_DPP
+#else
+    double uA = 0.0;
+    cn_rowA2<0, kBM, false>(r, nBA[0], nBA[kBM], e0, accA, accB, uA);   cn_rowA2<1, kBLo, false>(r, nBA[1], nBA[kBLo], e1, accA, accB, uA);
+    cn_rowA2<2, kBHi, false>(r, nBA[2], nBA[kBHi], e2, accA, accB, uA);
+    cn_rowA<3, false>(r, nBA[3], eA[3], accA, accB, uA);   cn_rowA<4, false>(r, nBA[4], eA[4], accA, accB, uA);   cn_rowA<5, false>(r, nBA[5], eA[5], accA, accB, uA);
+    cn_rowA<6, false>(r, nBA[6], eA[6], accA, accB, uA);   cn_rowA<7, false>(r, nBA[7], eA[7], accA, accB, uA);   cn_rowA<8, false>(r, nBA[8], eA[8], accA, accB, uA);
+    cn_rowA<9, false>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, false>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, false>(r, nBA[11], eA[11], accA, accB, uA);
+#endif
+}
 template <int NG> SRL_G void cn_sweeps(const TRows &r, const BRow &bb, const double *nBA, const double *eA, double e0, double e1, double e2, const double *nAB,
                                        const double *nBB, const double *eB, double &accA, double &accB, double &uA, double *tN, double *tF) {
 #define SRL_CN_SWEEP(LAST)                                                                                                                     \
@@ -775,8 +824,12 @@ template <int NG> SRL_G void cn_sweeps(const TRows &r, const BRow &bb, const dou
     cn_rowA<9, LAST>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, LAST>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, LAST>(r, nBA[11], eA[11], accA, accB, uA); \
     cn_normals_sn<0, NG>(bb.cs, tN, nAB, nBB, eB, accA, accB);                                                                                 \
     cn_frictions_n<0, NG>(bb, tN, tF, nAB, nBB, eB, accA, accB);
-    for (int it = 0; it < kSolverIters - 1; it++) { SRL_CN_SWEEP(false) }
-    { SRL_CN_SWEEP(true) }
+    for (int it = 0; it < kSolverIters - 1; it++) {
+        cn_phaseA(r, nBA, eA, e0, e1, e2, accA, accB);
+        cn_normals_sn<0, NG>(bb.cs, tN, nAB, nBB, eB, accA, accB);
+        cn_frictions_n<0, NG>(bb, tN, tF, nAB, nBB, eB, accA, accB);
+    }
+    { SRL_CN_SWEEP(true) }                              // the last sweep keeps every row's own value (uA): row by row
 #undef SRL_CN_SWEEP
 }
 // Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
