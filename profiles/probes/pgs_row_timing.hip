@@ -22,6 +22,16 @@
 #define ROW_V4(J) "v_add_f64 %[t], %[cs], %[acc] clamp\n\tv_fma_f64 %[acc], -%[e], %[acc], %[acc]\n\tv_mov_b32 %[f], %[f]\n\t" \
                   "v_fmac_f64_dpp %[acc], %[t], %[n] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
 #define ALL12(R) R(0) R(1) R(2) R(3) R(4) R(5) R(6) R(7) R(8) R(9) R(10) R(11)
+// the free sweep as it is: the button's rows 12..14 ride on rows 0..2 — a second fmac IN the accumulator's chain
+#define ROW_RIDE(J, JB) "v_add_f64 %[t], %[cs], %[acc] clamp\n\tv_fma_f64 %[acc], -%[e], %[acc], %[acc]\n\ts_nop 0\n\t" \
+                  "v_fmac_f64_dpp %[acc], %[t], %[n] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %[acc], %[t], %[m] row_newbcast:" #JB " row_mask:0xf bank_mask:0xf\n\t"
+// the button's three rows as their own chain (accumulator accb, value tb), one of its instructions in each arm row's wait states
+#define ROW_SEP(J, FILL) "v_add_f64 %[t], %[cs], %[acc] clamp\n\tv_fma_f64 %[acc], -%[e], %[acc], %[acc]\n\t" FILL \
+                  "v_fmac_f64_dpp %[acc], %[t], %[n] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define B_ADD "v_add_f64 %[tb], %[cs], %[accb] clamp\n\t"
+#define B_RST "v_fma_f64 %[accb], -%[e], %[accb], %[accb]\n\t"
+#define B_MAC(JB) "v_fmac_f64_dpp %[accb], %[tb], %[m] row_newbcast:" #JB " row_mask:0xf bank_mask:0xf\n\t"
 
 template <int V>
 __global__ void rows_k(double *out, long long *ticks, int sweeps, double cs, double e, double n, double m) {
@@ -37,6 +47,13 @@ __global__ void rows_k(double *out, long long *ticks, int sweeps, double cs, dou
                          ROW_V1(6, t, t2, 5) ROW_V1(7, t2, t, 6) ROW_V1(8, t, t2, 7) ROW_V1(9, t2, t, 8) ROW_V1(10, t, t2, 9) ROW_V1(11, t2, t, 10)
                          : [acc] "+v"(acc), [accb] "+v"(accb), [t] "+v"(t), [t2] "+v"(t2) : [cs] "v"(cs), [e] "v"(e), [n] "v"(n), [m] "v"(m));
         if constexpr (V == 3) asm volatile(ALL12(ROW_V3) : [acc] "+v"(acc), [t] "=&v"(t) : [cs] "v"(cs), [n] "v"(n));
+        if constexpr (V == 5)
+            asm volatile(ROW_RIDE(0, 12) ROW_RIDE(1, 13) ROW_RIDE(2, 14) ROW_V0(3) ROW_V0(4) ROW_V0(5) ROW_V0(6) ROW_V0(7) ROW_V0(8) ROW_V0(9) ROW_V0(10) ROW_V0(11)
+                         : [acc] "+v"(acc), [t] "=&v"(t) : [cs] "v"(cs), [e] "v"(e), [n] "v"(n), [m] "v"(m));
+        if constexpr (V == 6)
+            asm volatile(ROW_SEP(0, B_ADD) ROW_SEP(1, B_RST) ROW_SEP(2, "s_nop 0\n\t") ROW_SEP(3, B_MAC(12)) ROW_SEP(4, B_ADD) ROW_SEP(5, B_RST) ROW_SEP(6, "s_nop 0\n\t")
+                         ROW_SEP(7, B_MAC(13)) ROW_SEP(8, B_ADD) ROW_SEP(9, B_RST) ROW_SEP(10, "s_nop 0\n\t") ROW_SEP(11, B_MAC(14))
+                         : [acc] "+v"(acc), [accb] "+v"(accb), [t] "=&v"(t), [tb] "+v"(t2) : [cs] "v"(cs), [e] "v"(e), [n] "v"(n), [m] "v"(m));
         if constexpr (V == 4) asm volatile(ALL12(ROW_V4) : [acc] "+v"(acc), [t] "=&v"(t), [f] "+v"(f) : [cs] "v"(cs), [e] "v"(e), [n] "v"(n));
     }
     const long long t1 = wall_clock64();
@@ -63,6 +80,8 @@ int main() {
         run<0>("V0 free row now: add, restart fma, s_nop 0, fmac_dpp", threads);
         run<4>("V4 the same with a VALU filler (v_mov_b32) instead of the s_nop", threads);
         run<3>("V3 no restart: add, s_nop 1, fmac_dpp (lower bound of the chain)", threads);
+        run<5>("V5 free SWEEP now: rows 0..2 carry the button's fmac in the chain (per row of 12)", threads);
+        run<6>("V6 free sweep with the button's three rows as a separate interleaved chain (per row of 12)", threads);
         run<2>("V2 contact row now: add, restart fma, s_nop 0, fmac_dpp, fmac_dpp (accB), s_nop 0", threads);
         run<1>("V1 contact row pipelined: add, restart fma, fmac_dpp (accB of the previous row), fmac_dpp", threads);
     }
