@@ -814,8 +814,11 @@ SRL_G void cn_phaseA(const TRows &r, const double *nBA, const double *eA, double
     cn_rowA<9, false>(r, nBA[9], eA[9], accA, accB, uA);   cn_rowA<10, false>(r, nBA[10], eA[10], accA, accB, uA); cn_rowA<11, false>(r, nBA[11], eA[11], accA, accB, uA);
 #endif
 }
-template <int NG> SRL_G void cn_sweeps(const TRows &r, const BRow &bb, const double *nBA, const double *eA, double e0, double e1, double e2, const double *nAB,
-                                       const double *nBB, const double *eB, double &accA, double &accB, double &uA, double *tN, double *tF) {
+template <int NG> SRL_G double cn_sweeps(const TRows &r, const BRow &bb, const double *nBA, const double *eA, double e0, double e1, double e2, const double *nAB,
+                                         const double *nBB, const double *eB, double &accA, double &accB, double &uA, int l) {
+    double tN[kNGen], tF[kNGen];                        // (local to the instantiation: handed in by pointer they ended up in scratch in some kernels)
+#pragma unroll
+    for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
 #define SRL_CN_SWEEP(LAST)                                                                                                                     \
     cn_rowA2<0, kBM, LAST>(r, nBA[0], nBA[kBM], e0, accA, accB, uA);   cn_rowA2<1, kBLo, LAST>(r, nBA[1], nBA[kBLo], e1, accA, accB, uA);      \
     cn_rowA2<2, kBHi, LAST>(r, nBA[2], nBA[kBHi], e2, accA, accB, uA);                                                                         \
@@ -831,6 +834,7 @@ template <int NG> SRL_G void cn_sweeps(const TRows &r, const BRow &bb, const dou
     }
     { SRL_CN_SWEEP(true) }                              // the last sweep keeps every row's own value (uA): row by row
 #undef SRL_CN_SWEEP
+    return cn_own_lambda(tN, tF, l);
 }
 // Kuka2Button: the same sweeps with the second button's rows in Bullet's order (motors, both button motors, both pairs of button
 // stops, normals, frictions).  nCB: the second button's rows' couplings to the bank-B slots (per lane, zero off the button lanes).
@@ -895,19 +899,17 @@ SRL_G double sweeps_contacts(const TRows &r, BRow &b, const double *sc, double a
     bb.mu *= Sn;
     // the button's rows ride on motor rows 0..2 (cn_rowA2): one restart mask per pair
     const double e0 = eA[0] + eA[kBM], e1 = eA[1] + eA[kBLo], e2 = eA[2] + eA[kBHi];
-    double accB = 0.0, uA = 0.0, tN[kNGen], tF[kNGen];
-#pragma unroll
-    for (int g = 0; g < kNGen; g++) { tN[g] = 0.0; tF[g] = 0.0; }
+    double accB = 0.0, uA = 0.0, lam = 0.0;
     switch (ngen_w) {                                  // wave-uniform
-        case 0: cn_sweeps<0>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        case 1: cn_sweeps<1>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        case 2: cn_sweeps<2>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        case 3: cn_sweeps<3>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        case 4: cn_sweeps<4>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        case 5: cn_sweeps<5>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
-        default: cn_sweeps<kNGen>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, tN, tF); break;
+        case 0: lam = cn_sweeps<0>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        case 1: lam = cn_sweeps<1>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        case 2: lam = cn_sweeps<2>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        case 3: lam = cn_sweeps<3>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        case 4: lam = cn_sweeps<4>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        case 5: lam = cn_sweeps<5>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
+        default: lam = cn_sweeps<kNGen>(r, bb, nBA, eA, e0, e1, e2, nAB, nBB, eB, accA, accB, uA, l); break;
     }
-    b.lam = cn_own_lambda(tN, tF, l) * (l < kNGen ? Sn : 1.0);
+    b.lam = lam * (l < kNGen ? Sn : 1.0);
     return uA;
 }
 
@@ -1150,7 +1152,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         // slot kNGen + s: J[12] + (Jb, -, -, -, on, mu).  Every lane first clears the definition of its own slot.
         if (L.l < kNB) {
             double *d = sc + SC_DEF + L.l * kDefDoubles;
-#pragma nounroll
+#pragma unroll
             for (int k = 0; k < kDefDoubles; k++) d[k] = 0.0;
         }
         sync_scratch();                    // (also: every lane has read its parked MISC values)
@@ -1177,7 +1179,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 if (fabs(nrm[2]) > 0.7071067811865475244) { const double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a); tdir[0] = 0.0; tdir[1] = -nrm[2] * kk; tdir[2] = nrm[1] * kk; }
                 else { const double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a); tdir[0] = -nrm[1] * kk; tdir[1] = nrm[0] * kk; tdir[2] = 0.0; }
                 cross3(nrm, tdir, tdir2);                                 // the second friction direction (SOLVER_USE_2_FRICTION_DIRECTIONS)
-#pragma nounroll
+#pragma unroll 4
                 for (int j = 0; j < NJ; j++) {
                     const double *Sj = spark + j * 6;
                     const double Swj[3] = {Sj[0], Sj[1], Sj[2]}, Svj[3] = {Sj[3], Sj[4], Sj[5]};
@@ -1218,7 +1220,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     {
         const bool liveA = r.S > 0.0 && r.diag > 0.0;
         const double invA = liveA ? 1.0 / (r.diag * r.S) : 0.0;
-#pragma nounroll
+#pragma unroll 2
         for (int s = 0; s < kNB; s++) {
             const bool used = used_slot(s, ngen_w);
             double wjk = 0.0;
@@ -1272,7 +1274,7 @@ SRL_G GenOut general_path(const GenIn &in) {
                 diag += b.jo2m;
             }
         }
-#pragma nounroll
+#pragma unroll 4
         for (int j = 0; j < NJ; j++) {
             const double Jj = own_on ? Jr[j] : 0.0, wj = own_on ? wjr[j] : 0.0;
             const double qj = shfl(qd_new, j);                           // the unconstrained velocity of joint j
@@ -1285,7 +1287,7 @@ SRL_G GenOut general_path(const GenIn &in) {
         const double des = (own_on && !mine_f) ? myd[1] : 0.0, perr = (own_on && !mine_f) ? myd[2] : 0.0;
         b.cs = ((des - jv) + perr - offb) * b.inv_diag;
         // couplings of the own bank-B row to the bank-A rows j (in u units: a_rj S_j) and to the bank-B rows s
-#pragma nounroll
+#pragma unroll 5
         for (int j = 0; j < kNArows; j++) {
             double a = 0.0;
             if (j < NJ) a = own_on ? wjr[j] : 0.0;
@@ -1298,7 +1300,7 @@ SRL_G GenOut general_path(const GenIn &in) {
             const double ab = own_bsel ? own_jb * wb * b.inv_diag : 0.0;
             b.nBC[0] = -ab * S_of(kBM); b.nBC[1] = -ab * S_of(kBLo); b.nBC[2] = ab * S_of(kBHi);
         }
-#pragma nounroll
+#pragma unroll 2
         for (int s = 0; s < kNB; s++) {
             const bool used = used_slot(s, ngen_w);
             double a = 0.0;
