@@ -297,7 +297,7 @@ int srlhip_set_kuka_tree_model(srlhip_handle h, const srlhip_kuka_tree_model *m)
  * envs), 0 = lane-per-env (kuka_rollout_k: larger batches and the lumped Kuka2ButtonGymEnv); the environment variable
  * SRLHIP_KUKA_KERNEL=group|lane overrides the choice.  Both read and write the same state and produce the same outputs
  * (to ~1e-11 on joint positions; discrete flags identical).  The tree kernel has a two-wavefronts-per-SIMD variant
- * (kuka_tree_rollout_occ_k: one-button envs, Cartesian actions) that the library uses from 32768 envs up;
+ * (kuka_tree_rollout_occ_k: one-button envs, Cartesian actions) that the library uses from 65536 envs up;
  * SRLHIP_KUKA_OCC=0|1 forces either.  Same state, same outputs to the same bar. */
 int srlhip_kuka_kernel(srlhip_handle h);
 

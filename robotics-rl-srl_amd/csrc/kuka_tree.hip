@@ -83,15 +83,16 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND) return kuka_tree_rb_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);   // free bodies: kuka_tree_rb.hip
     {
         // Very large batches run the two-wavefronts-per-SIMD variant (kuka_tree_occ.hip: one-button envs, Cartesian actions).
-        // Measured (profiles/r04_occ_nsweep.jsonl): 4096 envs -34 % (128-thread workgroups place unevenly when the chip is not
-        // full), 8192 / 16384 +-1 %, 32768 +2 %, 65536 +5.7 %, 131072 +9.4 %: the sweep is a dependent f64 chain that one
-        // wavefront already issues at 6.2 of the SIMD's 4.1 cycles per op (profiles/r04_f64_issue_rate.txt), so a second
-        // wavefront can hide little, and its register diet (256 instead of 512) costs ~1 KB/lane of scratch.  Hence the threshold.
+        // Measured after the contact-sweep work (profiles/r04_occ_nsweep_final.jsonl, one -> two wavefronts, env-steps/s x 1e8):
+        // 16384 envs 1.62 -> 1.37, 32768 1.63 -> 1.56, 65536 1.65 -> 1.67, 131072 1.66 -> 1.73 (before that work the variant won from
+        // 32768: profiles/r04_occ_nsweep.jsonl).  The sweep is a dependent f64 chain that one wavefront already issues at 6.2 of
+        // the SIMD's 4.1 cycles per op (profiles/r04_f64_issue_rate.txt), so a second wavefront can hide little, its register diet
+        // (256 instead of 512) costs ~1 KB/lane of scratch, and its four envs take turns in the contact path.  Hence the threshold.
         // SRLHIP_KUKA_OCC=0|1 forces either variant (tests run both on small batches).
         const char *force = getenv("SRLHIP_KUKA_OCC");
         const bool one_button = h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON || h->cfg.env_kind == SRLHIP_ENV_KUKA_MOVING;
         const bool cartesian = h->cfg.is_discrete || !h->cfg.action_joints;
-        const bool occ = force ? force[0] == '1' : h->n >= 32768;
+        const bool occ = force ? force[0] == '1' : h->n >= 65536;
         if (occ && one_button && cartesian) return kuka_tree_occ_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
     }
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);

@@ -1,12 +1,12 @@
 // kuka_tree_occ.hip — the full-model lane-group rollout at TWO wavefronts per SIMD, for very large batches (one-button envs, Cartesian
-// action modes; the library picks it from 32768 envs up, SRLHIP_KUKA_OCC=0|1 forces either variant).  What it takes (kuka_tree.hpp,
+// action modes; the library picks it from 65536 envs up, SRLHIP_KUKA_OCC=0|1 forces either variant).  What it takes (kuka_tree.hpp,
 // OCC = 1): <= 256 registers (what the one-wavefront kernel keeps in its other 256 becomes 0.8-1.0 KB per lane of scratch) and <= 20 KiB
 // of LDS per wavefront — ONE general-path work area per wavefront, taken by its four envs in turns, a 2.1 KiB park per env, sphere /
 // limit candidates recomputed inside the turn; two wavefronts share a workgroup and its lane table.
 // What it buys is bounded: the projected Gauss-Seidel sweep is one dependent chain of float64 ops, and one wavefront alone already issues
 // such a chain every 6.2 cycles where the SIMD's limit is 4.1 (profiles/probes/f64_issue_rate.hip, profiles/r04_f64_issue_rate.txt): two
-// chains on one SIMD reach 1.31x at best.  Measured whole-rollout gain (profiles/r04_occ_nsweep.jsonl): +-1 % at 8192 / 16384 envs, +2 %
-// at 32768, +5.7 % at 65536, +9.4 % at 131072; -34 % at 4096 (the chip is not full: 128-thread workgroups place unevenly).
+// chains on one SIMD reach 1.31x at best.  Measured whole-rollout gain (profiles/r04_occ_nsweep_final.jsonl, after the contact-sweep work):
+// -15 % at 16384 envs, -5 % at 32768, +1 % at 65536, +4 % at 131072 (before that work: +2 % / +6 % / +9 % from 32768, r04_occ_nsweep.jsonl).
 #include "kuka_tree_kernels.hpp"
 
 namespace srl {

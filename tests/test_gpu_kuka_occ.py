@@ -1,7 +1,7 @@
 """GPU parity of the two-wavefronts-per-SIMD variant of the full-model Kuka kernel (csrc/kuka_tree_occ.hip): the same step
 functions (csrc/kuka_tree.hpp, OCC = 1) with the contact-candidate list recomputed instead of kept in registers, the generic
 path's work area shared by the four envs of a wavefront (they take turns) and the per-env state parked in LDS meanwhile.  The
-library picks it for one-button envs with Cartesian actions from 32768 envs up; SRLHIP_KUKA_OCC=1 forces it on the small batches
+library picks it for one-button envs with Cartesian actions from 65536 envs up; SRLHIP_KUKA_OCC=1 forces it on the small batches
 the oracle finishes in seconds, =0 forces the one-wavefront kernel.  Bar: the north star's (1e-4 on joints, flags bit for bit)."""
 import numpy as np
 import pytest
@@ -66,9 +66,9 @@ def test_both_variants_agree_on_state_handover(monkeypatch):
         h.close()
 
 
-def test_default_dispatch_at_32768_envs():
-    """No override: 32768 envs go to the two-wavefront kernel (ragged: 32768 + 37 envs, the last workgroup partly idle)."""
-    n, T = 32768 + 37, 130
+def test_default_dispatch_at_65536_envs():
+    """No override: 65536 envs go to the two-wavefront kernel (ragged: 65536 + 37 envs, the last workgroup partly idle)."""
+    n, T = 65536 + 37, 100
     actions = pressing_actions(T, n, 6)
     h = make(n)
     obs0 = h.reset()
