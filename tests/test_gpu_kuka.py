@@ -643,3 +643,33 @@ def test_rand_button_env_other_action_modes_and_ragged_batches(mode):
     on = ob[:, :, 6] > 0
     assert np.abs(bodies - ob[:, :, :6])[on].max() <= 1e-9
     h.close()
+
+
+@pytest.mark.parametrize("budget", [1, 2, 6])
+def test_contact_sweep_instantiations_by_row_budget(budget):
+    """The register-resident contact sweeps are compiled per number of bank-B slots in use (cn_sweeps<NG>, hand-scheduled bank-A
+    rows).  With the reference's geometry a press brings ONE gripper sphere to the button, rarely two, almost never three (oracle:
+    283 / 15 / 0 of 38 400 env-steps), so NG = 1 and 2 are the instantiations that run; the model table's row budget caps the number:
+    budget 1 drops the second contact, 2 and 6 keep it — each against the oracle with the same budget."""
+    n, T = 192, 500
+    rs = np.random.RandomState(70 + budget)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.35] = 4
+    t = _lib.kuka_tree_default_model().copy()
+    t[kuka_model.TREE_MAX_GENERIC_ROWS] = float(budget)
+    try:
+        h = make(n, seed0=29)
+        h.set_kuka_tree_model(t)
+        obs0 = h.reset()
+        out = h.rollout(T, actions=actions)
+        kuka_clib.set_tree_model(t)
+        ora = kuka_clib.rollout(29 + np.arange(n), T, actions=actions, aux=True, trace=False)
+        normals = ora["rows"][:, :, 0]
+        assert min(budget, 2) <= normals.max() <= budget and (normals >= min(budget, 2)).sum() > 5
+        check_planes(ora, obs0, out)
+        q = np.concatenate([h.get_state(_lib.F_KUKA_Q).T, h.get_state(_lib.F_KUKA_GRIPPER_Q).T], axis=1)
+        f = ora["final_state"]
+        assert np.abs(q - np.concatenate([f[:, :7], f[:, 30:35]], axis=1)).max() <= TOL
+        h.close()
+    finally:
+        kuka_clib.set_full(True)
