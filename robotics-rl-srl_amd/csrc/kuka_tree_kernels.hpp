@@ -19,7 +19,14 @@ constexpr int kTS = tree::kTreeScratchDoubles, kTStart = tree::kTreeStartDoubles
 // single-step launches of the per-step API); a launch only copies its 5.6 KB.
 struct LaneId { int l; bool jnt; double q0, base_z; };
 __device__ __forceinline__ void build_lane_table(LaneId &L, const double *ttable, double *tab) {
-    for (int i = threadIdx.x; i < tree::kLaneTableDoubles; i += kGroupBlock) tab[i] = ttable[i];
+    // every load of the copy in flight before the first wait (a rolled copy loop waits out one global-memory round trip per 512
+    // bytes: eleven of them, ~7 us of a 38-us single-step launch)
+    constexpr int kCopyIters = (tree::kLaneTableDoubles + kGroupBlock - 1) / kGroupBlock;
+    double row[kCopyIters];
+#pragma unroll
+    for (int k = 0; k < kCopyIters; k++) { const int i = (int)threadIdx.x + k * kGroupBlock; row[k] = i < tree::kLaneTableDoubles ? ttable[i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < kCopyIters; k++) { const int i = (int)threadIdx.x + k * kGroupBlock; if (i < tree::kLaneTableDoubles) tab[i] = row[k]; }
     __syncthreads();
     L.l = (int)(threadIdx.x & (grp::GL - 1)); L.jnt = L.l < NJ;
     L.q0 = tab[tree::LT_Q0 * grp::GL + L.l]; L.base_z = tab[tree::LT_COUNT * grp::GL + tree::LS_BASEZ];
@@ -113,10 +120,11 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     tload(s, n, e, L, v, g, NB == 2);
     tree::RBody body = {};
     if constexpr (RB) tload_body(s, n, e, L.l, body);
-    tree::tfk(tree::lane_view(tab), g);
+    // (requested before the forward kinematics so that their round trip overlaps it: single-step launches are latency)
     double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
     int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
     GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
+    tree::tfk(tree::lane_view(tab), g);
     Philox &act = gact.p;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
