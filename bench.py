@@ -488,6 +488,10 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
             util = pmc_issue_util(kernel, avg_launch_s)
         if util:
             roofline.update(util)
+            # what the number is measured against: ONE wavefront per SIMD running ONE dependent float64 chain (which is what a
+            # Gauss-Seidel sweep is) completes an operation every 2.60 ns where the SIMD's issue limit is 1.72 ns
+            # (profiles/probes/f64_issue_rate.hip, profiles/r04_f64_issue_rate.txt)
+            roofline["issue_util_of_one_dependent_f64_chain"] = 0.66
     if traffic is not None:
         roofline["traffic_source"] = ("measured in this run: the same command re-run as child processes under rocprofv3 --pmc "
                                       "(separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 + WRITE_SIZE, KiB), bytes per launch"
