@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define SRLHIP_ABI_VERSION 2   /* 2 (round 4): srlhip_kuka_tree_model grew its solver section (506 -> 510 doubles), SRLHIP_F_KUKA_BODIES */
+#define SRLHIP_ABI_VERSION 3   /* 2 (round 4): srlhip_kuka_tree_model grew its solver section (506 -> 510 doubles), SRLHIP_F_KUKA_BODIES;
+                                 * 3 (round 5): SRLHIP_F_KUKA_IK_CROSSED */
 
 /* ---- error codes ------------------------------------------------------- */
 #define SRLHIP_OK            0
@@ -195,6 +196,17 @@ int srlhip_rollout(srlhip_handle h, int32_t T, const void *actions_TN,
 #define SRLHIP_F_KUKA_GRIPPER_Q 28  /* f64[5]  full model: joints 7, 8, 10, 11, 13 (gripper_to_arm, left finger, left tip, right finger, right tip) */
 #define SRLHIP_F_KUKA_GRIPPER_QD 29 /* f64[5]  their velocities */
 #define SRLHIP_F_KUKA_BODIES     30 /* f64[66] KukaRandButtonGymEnv, full model: (x y z vx vy vz) of the ten distractors (draw order) and the ball */
+/* IK conditioning flag of the full model (no counterpart in the reference; it qualifies the parity claim of this library).
+ * Kuka.applyAction's damped-least-squares IK (kuka.py:41-42 jd = 1e-5, kuka.py:144-156) has a gain of up to 1 / (2 sqrt(jd)) = 158
+ * along a vanishing singular direction of the arm's Jacobian: while the arm is driven through the neighbourhood of a kinematic
+ * singularity (e.g. the elbow joint through 0 with a saturating policy at the far edge of the workspace box), the closed loop
+ * IK -> position motors -> IK amplifies float64 rounding differences by ~2.4x per step, so NO two float64 implementations (PyBullet
+ * included) agree to 1e-4 on joint positions, or bit for bit on reward / done, after such a crossing.  Bit 0 of the value: sticky
+ * per episode, set when an IK solve of the episode had det(J^T J + jd I) < SRLHIP_KUKA_IK_CROSS_DET (random-agent rollouts stay
+ * above 1e-7, amplification starts near 1e-9), cleared by the episode's reset.  value >> 1: env-steps taken with the bit set since the
+ * handle was created.  Parity with the oracle (tests/) is asserted on every env-step BEFORE the bit. */
+#define SRLHIP_F_KUKA_IK_CROSSED 31 /* i32     full model: (flagged env-steps << 1) | sticky bit */
+#define SRLHIP_KUKA_IK_CROSS_DET 3e-9
 int srlhip_get_state(srlhip_handle h, int32_t field, void *out);
 int srlhip_set_state(srlhip_handle h, int32_t field, const void *in);
 /* Zero-copy hand-off of a field's device array (e.g. to torch via

@@ -177,8 +177,10 @@ def settled(random_target=False, action_joints=False):
 
 def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, random_target=False, force_down=True,
             shape_reward=False, action_repeat=1, max_distance=0.8, obs_mode=0, rng_mode=RNG_MT19937, auto_reset=True,
-            trace=True, aux=False):
-    """aux: also return q_all [T][n][12] (every DoF of the model in use) and rows [T][n][3] (contact-normal rows, friction rows + 1000 x joint-limit rows, arm <-> free-body contact rows)."""
+            trace=True, aux=False, ik_trace=False):
+    """aux: also return q_all [T][n][12] (every DoF of the model in use) and rows [T][n][3] (contact-normal rows, friction rows + 1000 x joint-limit rows, arm <-> free-body contact rows).
+    ik_trace: also ik_det [T][n] (det(J^T J + damping I) of the step's IK solve), ik_crossed [T][n] (the episode's sticky conditioning bit after
+    the step: some IK solve of the episode had det < KM_IK_CROSS_DET), ik_final [n][2] (the bit at the end, env-steps taken with it set)."""
     seeds = np.ascontiguousarray(seeds, dtype=np.int64)
     n = len(seeds)
     od = {0: 3, 1: 14, 2: 17}[obs_mode]
@@ -190,6 +192,9 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
         "q": np.zeros((T, n, 7)) if trace else None, "gripper": np.zeros((T, n, 3)) if trace else None,
         "final_state": np.zeros((n, 40)), "ep_stats": np.zeros((n, 3)),
     }
+    if ik_trace:
+        out["ik_det"], out["ik_crossed"], out["ik_final"] = np.zeros((T, n)), np.zeros((T, n), np.uint8), np.zeros((n, 2), np.int32)
+        clib.lib().kuka_oracle_set_ik_trace(_p(out["ik_det"]), _p(out["ik_crossed"]), _p(out["ik_final"]))
     if aux:
         out["q_all"] = np.zeros((T, n, 12))
         out["rows"] = np.zeros((T, n, 3), np.int32)
@@ -206,6 +211,8 @@ def rollout(seeds, T, actions=None, is_discrete=True, action_joints=False, rando
         _p(seeds), _p(keys), _p(lens), _p(actions), _p(out["obs0"]), _p(out["obs"]), _p(out["reward"]),
         _p(out["reward64"]), _p(out["done"]), _p(act_out), _p(out["q"]), _p(out["gripper"]),
         _p(out["final_state"]), _p(out["ep_stats"]))
+    if ik_trace:
+        clib.lib().kuka_oracle_set_ik_trace(None, None, None)
     if aux:
         clib.lib().kuka_oracle_set_aux_trace(None, None)
     assert rc == 0

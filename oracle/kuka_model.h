@@ -61,6 +61,7 @@ static double KM_SPHERE[KM_NSPHERE][4] = {              /* centre xyz, radius   
     {0, 0, 0.100, 0.060}, {0, 0, 0.0, 0.070}};                /* gripper body, wrist                        */
 #define KM_IK_DAMPING 1e-5                                    /* kuka.py:41-42 jd                           */
 #define KM_IK_DAMPING_DEFAULT 0.5                             /* pybullet server default when no jointDamping is passed (Kuka2Button) [UNVERIFIED-MEMORY] */
+#define KM_IK_CROSS_DET 3e-9                                  /* det(J^T J + damping I) below this: the controller's closed loop amplifies float64 noise (kuka_oracle.c ik_conditioning_note; srlhip.h SRLHIP_KUKA_IK_CROSS_DET) */
 #define KM_BUTTON1_Y_2B 0.125                                 /* kuka_2button_gym_env.py:56-62 */
 #define KM_BUTTON2_Y_2B (-0.125)                              /* :66-70 */
 #define KM_Z_TABLE (-0.2)                                     /* kuka_button_gym_env.py Z_TABLE */

@@ -287,6 +287,26 @@ static int solve_linear(double A[N][N], double b[N], double x[N]) {   /* Gaussia
     for (i = N - 1; i >= 0; i--) { double s = b[i]; for (j = i + 1; j < N; j++) s -= A[i][j] * x[j]; x[i] = s / A[i][i]; }
     return 0;
 }
+/* IK conditioning probe (round 5).  det(J^T J + damping I) of the last damped-least-squares solve, as the product of the pivots of an
+ * unpivoted elimination (the matrix is symmetric positive definite).  Near a kinematic singularity of the arm the controller's
+ * closed loop (IK step -> position motors -> next IK step) amplifies any difference between two float64 implementations by a
+ * constant factor per step (measured: x 2.4 per step while the sixth singular value of J is below ~1e-2, i.e. while the DLS gain
+ * sigma / (sigma^2 + damping) with the reference's damping 1e-5 (kuka.py:41-42) exceeds ~100), so the 1e-4 / bit-exact parity bar
+ * cannot hold THROUGH such a crossing for any pair of implementations.  det < KM_IK_CROSS_DET marks the regime: random-agent
+ * rollouts stay above 1e-7, the elbow crossing (joint 3 through 0) starts to amplify at 1e-9.  t_ik_det = smallest det of the IK
+ * solves since ik_conditioning_reset(). */
+static double t_ik_det = 1e300;
+#pragma omp threadprivate(t_ik_det)
+static void ik_conditioning_reset(void) { t_ik_det = 1e300; }
+static void ik_conditioning_note(double A[N][N]) {
+    double M[N][N], det = 1.0; int i, j, k;
+    memcpy(M, A, sizeof M);
+    for (k = 0; k < N; k++) {
+        det *= M[k][k];
+        for (i = k + 1; i < N; i++) { const double f = M[i][k] / M[k][k]; for (j = k; j < N; j++) M[i][j] -= f * M[k][j]; }
+    }
+    if (det < t_ik_det) t_ik_det = det;
+}
 /* The end effector (link 6) does not move with the gripper joints: their Jacobian columns are zero, so the 12-DoF damped
  * least-squares step of the full model leaves them at exactly 0 and the 7x7 arm block is the whole solve. */
 static void inverse_kinematics(const double q[TN], const mat3 R[TN], const double p[TN][3], const double target[3], double damping, double q_des[N]) {
@@ -317,6 +337,7 @@ static void inverse_kinematics(const double q[TN], const mat3 R[TN], const doubl
         A[i][i] += damping;
         { double s = 0; for (k = 0; k < 6; k++) s += J[k][i] * dS[k]; b[i] = s; }
     }
+    ik_conditioning_note(A);
     if (solve_linear(A, b, dth) != 0) memset(dth, 0, sizeof dth);
     for (i = 0; i < N; i++) if (fabs(dth[i]) > maxabs) maxabs = fabs(dth[i]);
     if (maxabs > KM_IK_MAX_ANGLE) for (i = 0; i < N; i++) dth[i] *= KM_IK_MAX_ANGLE / maxabs;
@@ -336,6 +357,7 @@ typedef struct {
     double gripper[3];             /* getArmPos() after the last physics step      */
     int contact_button, contact_table;   /* manifolds of the last stepSimulation  */
     int counter, n_contacts, n_outside, terminated;
+    int ik_crossed;                /* sticky per episode: an IK solve of this episode had det(J^T J + damping I) < KM_IK_CROSS_DET (ik_conditioning_note) */
     /* Kuka2ButtonGymEnv: second button (same urdf), per-body contact flags, goal bookkeeping */
     double b2q, b2qd, button2_xy[2];
     int contact_body[2];           /* any link (cap or base) of button k touches the arm: getContactPoints(button_uid[k], kuka) */
@@ -840,7 +862,7 @@ static void env_reset(kenv *e, const kcfg *cfg, krng *r, const kenv *settled) { 
         memcpy(e->button_pos, e->all_pos[0], sizeof e->button_pos);
     }
     e->goal_id = 0; e->n_contacts2 = 0;
-    e->counter = 0; e->n_contacts = 0; e->n_outside = 0; e->terminated = 0;
+    e->counter = 0; e->n_contacts = 0; e->n_outside = 0; e->terminated = 0; e->ik_crossed = 0;
 }
 
 static void observe(const kenv *e, int obs_mode, float *o) {     /* getSRLState :175-189 */
@@ -881,11 +903,13 @@ static double env_step(kenv *e, const kcfg *cfg, krng *r, int action, const floa
         motor[2] = cfg->force_down ? -fabs((double)caction[2] * dv) : (double)caction[2] * dv;
     }
     e->button_motor_on = 1;                                        /* step2 :347 */
+    ik_conditioning_reset();
     for (rep = 0; rep < cfg->action_repeat; rep++) {
         physics_step(e, cfg, motor, jt);
         if (termination_cfg(e, cfg)) break;
         e->counter += 1;
     }
+    if (t_ik_det < KM_IK_CROSS_DET) e->ik_crossed = 1;
     { double reward = reward_fn(e, cfg); *done = termination_cfg(e, cfg); return reward; }
 }
 
@@ -894,6 +918,11 @@ static int g_moving = 0, g_two = 0, g_rand = 0;
  * arm <-> free-body contact rows (KukaRandButton) created by the step's last stepSimulation); NULL = off */
 static double *g_aux_q = NULL; static int32_t *g_aux_rows = NULL;
 void kuka_oracle_set_aux_trace(double *q_all, int32_t *rows) { g_aux_q = q_all; g_aux_rows = rows; }
+/* IK conditioning of the next kuka_oracle_rollout call: det [T][n] (smallest det(J^T J + damping I) of the step's IK solves; 1e300 in joint
+ * mode), flag [T][n] (the episode's sticky ik_crossed bit after the step, before a possible auto-reset), fin [n][2] (the bit at the end
+ * of the rollout, number of env-steps taken with the bit set); NULL = off */
+static double *g_aux_ikdet = NULL; static uint8_t *g_aux_ikflag = NULL; static int32_t *g_aux_ikfin = NULL;
+void kuka_oracle_set_ik_trace(double *det, uint8_t *flag, int32_t *fin) { g_aux_ikdet = det; g_aux_ikflag = flag; g_aux_ikfin = fin; }
 /* KukaRandButton: body state of every env at the end of the next kuka_oracle_rollout call, [n][RB_N][7]: x y z vx vy vz on */
 static double *g_aux_bodies = NULL;
 void kuka_oracle_set_body_trace(double *bodies) { g_aux_bodies = bodies; }
@@ -954,7 +983,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
 #pragma omp parallel for schedule(dynamic, 4)
     for (e = 0; e < n; e++) {
         kenv env; krng *r = (krng *)malloc(sizeof(krng)); philox_t act; int t;
-        double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0;
+        double ep_ret = 0, last_ret = 0; int ep_len = 0, last_len = 0, n_fin = 0, n_ikx = 0;
         r->mode = rng_mode;
         if (rng_mode == 2) np_rng_seed_array(&r->mt, mt_keys + 2 * (size_t)e, mt_key_len[e]);
         r->ph.k0 = (uint32_t)(uint64_t)seeds[e]; r->ph.k1 = (uint32_t)((uint64_t)seeds[e] >> 32); r->ph.ctr = 0; r->ph.stream = 0;
@@ -976,6 +1005,9 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             if (g_aux_q) { memset(g_aux_q + row * TN, 0, sizeof(double) * TN); memcpy(g_aux_q + row * TN, env.q, sizeof(double) * ND); }
             if (g_aux_rows) { g_aux_rows[3 * row] = g_probe_rows[0]; g_aux_rows[3 * row + 1] = g_probe_rows[1] + 1000 * g_probe_rows[2]; g_aux_rows[3 * row + 2] = g_probe_rows[3]; }
             if (grip_trace) memcpy(grip_trace + row * 3, env.gripper, sizeof(double) * 3);
+            if (g_aux_ikdet) g_aux_ikdet[row] = t_ik_det;
+            if (g_aux_ikflag) g_aux_ikflag[row] = (uint8_t)env.ik_crossed;
+            n_ikx += env.ik_crossed;
             ep_ret += reward; ep_len += 1;
             if (done) {
                 last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
@@ -999,6 +1031,7 @@ int kuka_oracle_rollout(int is_discrete, int action_joints, int random_target, i
             int k, j; double *bd = g_aux_bodies + (size_t)e * RB_N * 7;
             for (k = 0; k < RB_N; k++) { for (j = 0; j < 3; j++) { bd[7 * k + j] = env.rb_x[k][j]; bd[7 * k + 3 + j] = env.rb_v[k][j]; } bd[7 * k + 6] = env.rb_on[k]; }
         }
+        if (g_aux_ikfin) { g_aux_ikfin[2 * (size_t)e] = env.ik_crossed; g_aux_ikfin[2 * (size_t)e + 1] = n_ikx; }
         if (ep_stats) { ep_stats[3 * (size_t)e] = last_ret; ep_stats[3 * (size_t)e + 1] = last_len; ep_stats[3 * (size_t)e + 2] = n_fin; }
         margin_merge();
         free(r);

@@ -447,6 +447,9 @@ int kuka_field(Handle *h, int field, void **dptr, size_t *elem, int *count) {
         case SRLHIP_F_KUKA_BODIES:
             if (!s->full || h->cfg.env_kind != SRLHIP_ENV_KUKA_RAND) return h->fail(SRLHIP_EINVAL, "KUKA_BODIES: free bodies exist on full-model KukaRandButtonGymEnv handles only");
             *dptr = s->rb; *count = 66; return 0;
+        case SRLHIP_F_KUKA_IK_CROSSED:
+            if (!s->full) return h->fail(SRLHIP_EINVAL, "KUKA_IK_CROSSED: the IK conditioning flag exists on full-model handles only (cfg.kuka_model = SRLHIP_KUKA_MODEL_FULL)");
+            *dptr = s->i + I_IKX * n; *elem = 4; return 0;
         case SRLHIP_F_KUKA_GRIPPER_Q:
         case SRLHIP_F_KUKA_GRIPPER_QD:
             // the lumped model has no gripper DoFs: its kernels never write these planes

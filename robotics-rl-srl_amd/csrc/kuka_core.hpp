@@ -77,6 +77,10 @@ constexpr double kIkDamping = 1e-5;
 // (kuka.py:147-148): pybullet ignores null-space lists whose length is not the DoF count and then falls back to its
 // default damping [UNVERIFIED-MEMORY, DESIGN.md §Kuka2Button]
 constexpr double kIkDampingDefault = 0.5;
+// IK conditioning flag (srlhip.h SRLHIP_KUKA_IK_CROSS_DET, oracle KM_IK_CROSS_DET): det(J^T J + damping I) of an IK solve below
+// this marks the episode as having crossed the neighbourhood of a kinematic singularity, where the controller's closed loop
+// amplifies float64 rounding noise by a constant factor per step (no two implementations agree to 1e-4 beyond it)
+constexpr double kIkCrossDet = 3e-9;
 constexpr double kButton1Y2B = 0.125, kButton2Y2B = -0.125, kZTable = -0.2;   // kuka_2button_gym_env.py:56-70
 constexpr int kMaxSteps2Button = 1500;
 constexpr double kIkMaxAngle = 45.0 * kPi / 180.0;
@@ -169,6 +173,9 @@ struct Env {
     // (getContactPoints(button_uid[k], kuka) has no link filter there), goal bookkeeping
     double b2q, b2qd, b2x, b2y;
     int32_t contact_body1, contact_body2, goal_id, n_contacts2;
+    // bit 0: sticky per episode — an IK solve of this episode had det(J^T J + damping I) < kIkCrossDet; bits 1..: env-steps taken with
+    // the bit set since the handle was created (full model only; the lumped kernels leave it 0)
+    int32_t ikx;
 };
 
 struct Cfg {

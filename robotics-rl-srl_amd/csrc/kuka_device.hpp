@@ -17,7 +17,7 @@ namespace srl {
 using namespace kuka;
 
 constexpr int kWave = 64;
-constexpr int NDBL = 67, NINT = 9;
+constexpr int NDBL = 67, NINT = 10;
 constexpr int kGroupKernelMaxEnvs = 12288;     // batches up to this size are stepped by the lane-group kernel (measured crossover, profiles/r02_nsweep_kuka.jsonl)
 
 // SoA planes (doubles): q7 qd7 sq7 cq7 ee3 bq bqd bx by bpos3 grip3
@@ -27,7 +27,8 @@ enum { D_Q = 0, D_QD = 7, D_SQ = 14, D_CQ = 21, D_EE = 28, D_BQ = 31, D_BQD = 32
 // plane of joint lane l of the full model: arm joints in the q7 planes, gripper joints behind them
 __host__ __device__ inline int tree_plane(int base_arm, int base_gripper, int l) { return l < ND ? base_arm + l : base_gripper + (l - ND); }
 // SoA planes (int32): motor_on contact_button contact_table counter n_contacts n_outside terminated
-enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6, I_GOAL = 7, I_NCONTACT2 = 8 };
+enum { I_MOTOR = 0, I_CB = 1, I_CT = 2, I_COUNTER = 3, I_NCONTACT = 4, I_NOUT = 5, I_TERM = 6, I_GOAL = 7, I_NCONTACT2 = 8,
+       I_IKX = 9 };          // full model: IK conditioning flag (bit 0, sticky per episode) + flagged env-steps << 1 (Env::ikx)
 
 struct KukaState {
     double *d;          // [NDBL][n]
@@ -104,7 +105,7 @@ int kuka_group_settle_table(Handle *h, const KukaParams &p);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out);
 int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
-// two wavefronts per SIMD, batches of >= 8192 envs: kuka_tree_occ.hip
+// two wavefronts per SIMD (default from 65536 envs, SRLHIP_KUKA_OCC forces either): kuka_tree_occ.hip
 int kuka_tree_occ_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                          uint8_t *d_done, void *d_act_out);
 // KukaRandButtonGymEnv (free bodies): kuka_tree_rb.hip

@@ -175,7 +175,7 @@ SRL_HD void reset_finish(Env &e, const ResetDraw &d, double base_z = kButtonBase
     e.bpos[0] = d.bx; e.bpos[1] = d.by;
     e.bpos[2] = base_z + kGliderOriginZ + e.bq + kButtonDistanceHeight;
     if constexpr (NB == 2) { e.bpos[2] = kZTable + kButtonDistanceHeight; e.goal_id = 0; e.n_contacts2 = 0; e.contact_body1 = 0; e.contact_body2 = 0; }
-    e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0; e.ikx &= ~1;
 }
 
 // KukaButtonGymEnv.reset.  `starts` = table of episode start states, `settled` = state after the settle steps.

@@ -454,6 +454,7 @@ const srl::kuka::TreeModel *tree_model() {
     return &g_tree_model;
 }
 double *g_tree_bodies = nullptr;         // KukaRandButton: [n][11][7] body state at the end of the next tree rollout (x y z vx vy vz on)
+uint8_t *g_tree_ik_flag = nullptr; int32_t *g_tree_ik_fin = nullptr;     // IK conditioning flag: [T][n] sticky bit after each step, [n] final Env::ikx
 int g_tree_occ = 0;                      // 1: the two-wavefronts-per-SIMD variant's code path (OCC = 1: shared work area, per-env park, recomputed candidates)
 template <int NB, int RB, int OCC, class R>
 void tree_env_body(GroupArgs &a, R &rng) {
@@ -498,6 +499,7 @@ void tree_env_body(GroupArgs &a, R &rng) {
         const double reward = tenv_step<NB, RB, OCC>(env, g, tab, cfg, a.scratch, rng, ac, ca, L.arm ? ca[L.l] : 0.f, &done, &body, park);
         if (a.q_trace && L.arm) a.q_trace[row * ND + L.l] = g.q;
         if (a.grip_trace && lead) memcpy(a.grip_trace + row * 3, env.grip, sizeof(double) * 3);
+        if (g_tree_ik_flag && lead) g_tree_ik_flag[row] = (uint8_t)(env.ikx & 1);
         ep_ret += reward; ep_len += 1;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0; ep_len = 0;
@@ -524,6 +526,7 @@ void tree_env_body(GroupArgs &a, R &rng) {
         }
     }
     if (a.ep_stats && lead) { a.ep_stats[3 * (size_t)e_idx] = last_ret; a.ep_stats[3 * (size_t)e_idx + 1] = last_len; a.ep_stats[3 * (size_t)e_idx + 2] = n_fin; }
+    if (g_tree_ik_fin && lead) g_tree_ik_fin[e_idx] = env.ikx;
     if (RB && g_tree_bodies && L.l < kRbN) {
         double *bd = g_tree_bodies + ((size_t)e_idx * kRbN + L.l) * 7;
         for (int k = 0; k < 3; k++) { bd[k] = body.x[k]; bd[3 + k] = body.v[k]; }
@@ -594,6 +597,7 @@ extern "C" int hostcheck_kuka_tree_rollout(int is_discrete, int action_joints, i
     return 0;
 }
 extern "C" void hostcheck_kuka_tree_set_body_trace(double *bodies) { g_tree_bodies = bodies; }
+extern "C" void hostcheck_kuka_tree_set_ik_trace(uint8_t *flag, int32_t *fin) { g_tree_ik_flag = flag; g_tree_ik_fin = fin; }
 extern "C" void hostcheck_kuka_tree_set_occ(int occ) { g_tree_occ = occ; }
 extern "C" void hostcheck_kuka_tree_default_model(double *t510) { srl::kuka::TreeModel m; srl::kuka::default_tree_model(m); memcpy(t510, &m, sizeof m); }
 extern "C" void hostcheck_kuka_tree_set_model(const double *t510) {

@@ -470,8 +470,10 @@ template <int K, int N> SRL_G void rdot_step(double &acc, const double *row, dou
     if constexpr (K + 1 < N) rdot_step<K + 1, N>(acc, row, x);
 }
 // In-place Gauss-Jordan on an N x N SPD matrix, row i on lane i (lanes >= N carry zero rows).  INV: A <- A^-1, else A x = b -> b.
-template <int K, int N, bool INV> SRL_G void gj_step(const TL &L, double *A, double &b) {
-    const double r = rcp(bcast<K>(A[K]));
+template <int K, int N, bool INV> SRL_G void gj_step(const TL &L, double *A, double &b, double *det = nullptr) {
+    const double piv = bcast<K>(A[K]);
+    if (det) *det *= piv;                    // product of the pivots = determinant (the IK's conditioning flag)
+    const double r = rcp(piv);
     const double g = -((A[K] - L.e(K)) * r);
     if constexpr (INV) {
         A[K] = L.e(K);
@@ -495,7 +497,7 @@ template <int K, int N, bool INV> SRL_G void gj_step(const TL &L, double *A, dou
         for (int c = K + 1; c < N; c++) fmac_bcast<K>(A[c], A[c], g);
         fmac_bcast<K>(b, b, g);
     }
-    if constexpr (K + 1 < N) gj_step<K + 1, N, INV>(L, A, b);
+    if constexpr (K + 1 < N) gj_step<K + 1, N, INV>(L, A, b, det);
 }
 
 // ------------------------------------------------------------------ PGS, bank A only (no limit / contact row in the wavefront)
@@ -1485,7 +1487,9 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         for (int k = 0; k < NA; k++) A[k] = fma(damping, L.e(k), A[k]);
 #pragma unroll
         for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
-        gj_step<0, NA, false>(L, A, bb);
+        double det = 1.0;
+        gj_step<0, NA, false>(L, A, bb, &det);
+        if (det < kIkCrossDet) e.ikx |= 1;      // sticky until the episode's reset (kuka_core.hpp kIkCrossDet)
         bb *= L.am;
         double all[NA], maxabs = 0.0;
         ball_step<0, NA>(bb, all);
@@ -1861,7 +1865,7 @@ SRL_G void tinitial(Env &e, GState &g, const double *tab) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { e.ee[k] = kEeInit[k]; e.bpos[k] = 0.0; }
     e.bq = 0.0; e.bqd = 0.0; e.bx = kButtonX; e.by = kButtonY; e.bz = L.base_z(); e.bspeed = 0.0;
-    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0; e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0;
+    e.motor_on = 0; e.contact_button = 0; e.contact_table = 0; e.counter = 0; e.n_contacts = 0; e.n_outside = 0; e.terminated = 0; e.ikx = 0;
     e.b2q = 0.0; e.b2qd = 0.0; e.b2x = kButtonX; e.b2y = kButton2Y2B; e.contact_body1 = 0; e.contact_body2 = 0; e.goal_id = 0; e.n_contacts2 = 0;
     trefresh(L, g, e);
 }
@@ -1940,6 +1944,7 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
         if (termination(e, cfg)) break;
         e.counter += 1;
     }
+    e.ikx += (e.ikx & 1) << 1;               // env-steps taken under the conditioning flag
     const double reward = NB == 2 ? reward_two(e, cfg) : reward_fn(e, cfg);
     *done = termination(e, cfg);
     SRL_TSTAMP(10);                         // counters, reward (one float64 sqrt), termination

@@ -39,7 +39,7 @@ __device__ __forceinline__ void tload(const KukaState &s, int64_t n, int e, cons
     v.bz = s.d[D_BZ * n + e]; v.bspeed = s.d[D_BSPEED * n + e];
     v.motor_on = s.i[I_MOTOR * n + e]; v.contact_button = s.i[I_CB * n + e]; v.contact_table = s.i[I_CT * n + e];
     v.counter = s.i[I_COUNTER * n + e]; v.n_contacts = s.i[I_NCONTACT * n + e]; v.n_outside = s.i[I_NOUT * n + e];
-    v.terminated = s.i[I_TERM * n + e];
+    v.terminated = s.i[I_TERM * n + e]; v.ikx = s.i[I_IKX * n + e];
     if (two) {                               // Kuka2ButtonGymEnv: second glider, goal switching
         v.b2q = s.d[D_B2Q * n + e]; v.b2qd = s.d[D_B2QD * n + e]; v.b2x = s.d[D_B2X * n + e]; v.b2y = s.d[D_B2Y * n + e];
         v.goal_id = s.i[I_GOAL * n + e]; v.n_contacts2 = s.i[I_NCONTACT2 * n + e]; v.contact_body1 = 0; v.contact_body2 = 0;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void tstore(const KukaState &s, int64_t n, int e, con
         s.d[D_BZ * n + e] = v.bz; s.d[D_BSPEED * n + e] = v.bspeed;
         s.i[I_MOTOR * n + e] = v.motor_on; s.i[I_CB * n + e] = v.contact_button; s.i[I_CT * n + e] = v.contact_table;
         s.i[I_COUNTER * n + e] = v.counter; s.i[I_NCONTACT * n + e] = v.n_contacts; s.i[I_NOUT * n + e] = v.n_outside;
-        s.i[I_TERM * n + e] = v.terminated;
+        s.i[I_TERM * n + e] = v.terminated; s.i[I_IKX * n + e] = v.ikx;
         if (two) {
             s.d[D_B2Q * n + e] = v.b2q; s.d[D_B2QD * n + e] = v.b2qd; s.d[D_B2X * n + e] = v.b2x; s.d[D_B2Y * n + e] = v.b2y;
             s.i[I_GOAL * n + e] = v.goal_id; s.i[I_NCONTACT2 * n + e] = v.n_contacts2;
@@ -216,6 +216,7 @@ kuka_tree_reset_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, const
     else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.load(rs.mt, e);
     else krng_load<MODE>(rng0, rs, e, p.n, host_rand ? host_rand + (int64_t)e * rand_stride : nullptr);
     Env v = {};
+    v.ikx = s.i[I_IKX * n + e];              // the flagged-step count outlives the episode (tenv_reset clears the sticky bit only)
     GState g;
     double *objs = s.objs + e;
     tree::RBody body = {};

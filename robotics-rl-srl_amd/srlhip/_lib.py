@@ -19,7 +19,7 @@ F_POS_X, F_POS_Y, F_TARGET_X, F_TARGET_Y, F_STEP_COUNT, F_CUR_TARGET, F_LAST_REW
 F_TARGET2_X, F_TARGET2_Y = 9, 10
 F_LAST_RETURN, F_LAST_LENGTH, F_N_FINISHED = 11, 12, 13
 F_KUKA_Q, F_KUKA_QD, F_KUKA_EE_TARGET, F_KUKA_BUTTON_Q, F_KUKA_BUTTON_POS, F_KUKA_GRIPPER, F_KUKA_COUNTERS = range(16, 23)
-F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS, F_KUKA_GRIPPER_Q, F_KUKA_GRIPPER_QD, F_KUKA_BODIES = range(23, 31)
+F_KUKA_BUTTON_XY, F_KUKA_BUTTON2_Q, F_KUKA_BUTTON2_XY, F_KUKA_GOAL, F_KUKA_OBJECTS, F_KUKA_GRIPPER_Q, F_KUKA_GRIPPER_QD, F_KUKA_BODIES, F_KUKA_IK_CROSSED = range(23, 32)
 KUKA_MODEL_LUMPED, KUKA_MODEL_FULL = 0, 1          # srlhip_config.kuka_model
 
 _FIELD_SHAPES = {
@@ -31,7 +31,7 @@ _FIELD_SHAPES = {
     F_KUKA_BUTTON_Q: (np.float64, 2), F_KUKA_BUTTON_POS: (np.float64, 3), F_KUKA_GRIPPER: (np.float64, 3),
     F_KUKA_COUNTERS: (np.int32, 3), F_KUKA_BUTTON_XY: (np.float64, 2), F_KUKA_BUTTON2_Q: (np.float64, 2),
     F_KUKA_BUTTON2_XY: (np.float64, 2), F_KUKA_GOAL: (np.int32, 2), F_KUKA_OBJECTS: (np.float64, 30),
-    F_KUKA_GRIPPER_Q: (np.float64, 5), F_KUKA_GRIPPER_QD: (np.float64, 5), F_KUKA_BODIES: (np.float64, 66),
+    F_KUKA_GRIPPER_Q: (np.float64, 5), F_KUKA_GRIPPER_QD: (np.float64, 5), F_KUKA_BODIES: (np.float64, 66), F_KUKA_IK_CROSSED: (np.int32, 1),
 }
 
 EXPORTS = [
@@ -47,7 +47,7 @@ EXPORTS = [
 ]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 KUKA_MODEL_DOUBLES = 138
 KUKA_TREE_MODEL_DOUBLES = 510
 KUKA_DETAIL_ALT_SWEEP, KUKA_DETAIL_BODY_ORDER, KUKA_DETAIL_FRICTION2 = 1, 2, 4

@@ -210,12 +210,38 @@ class SRLPCA(object):
         return self.getStates(np.asarray(observation)[None])[0].to("cpu").numpy()
 
 
+_SRL_HEADS = ("forward_net.", "inverse_net.", "reward_net.")
+
+
+def _encoder_state_dict(state_dict, losses, split_dimensions):
+    """The encoder's tensors out of a checkpoint the reference would load with `self.model.load_state_dict(th.load(path))`
+    (state_representation/models.py:150-169).  There `self.model` is a bare CustomCNN only for the supervised baseline; every other
+    loss combination is wrapped in srl_zoo's SRLModules (keys `model.<encoder key>` next to the forward / inverse / reward heads
+    `forward_net.* / inverse_net.* / reward_net.*`), or SRLModulesSplit when `split-dimensions` is a non-zero dict.  [srl_zoo is an
+    empty submodule of the reference checkout: this layout is recalled, UNVERIFIED.]  With `autoencoder` / `dae` / `vae` among the
+    losses SRLModules builds CNNAutoEncoder / CNNVAE instead of CustomCNN even when model-type is `custom_cnn` — different networks
+    that are not restated here: refuse instead of mis-loading."""
+    other = [name for name in ("autoencoder", "dae", "vae") if name in (losses or [])]
+    if other:
+        raise NotImplementedError("srl model with the {} loss: srl_zoo builds CNNAutoEncoder / CNNVAE for it, only the CustomCNN encoder "
+                                  "is restated here".format(" / ".join(other)))
+    if split_dimensions is not None:
+        raise NotImplementedError("split-dimensions models (srl_zoo SRLModulesSplit) are not restated here")
+    if any(k.startswith("model.") for k in state_dict):
+        stray = [k for k in state_dict if not k.startswith("model.") and not k.startswith(_SRL_HEADS)]
+        if stray:
+            raise KeyError("unexpected keys next to the encoder in the srl checkpoint: {}".format(stray[:4]))
+        return {k[len("model."):]: v for k, v in state_dict.items() if k.startswith("model.")}
+    return dict(state_dict)
+
+
 def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_shape=(224, 224), n_channels=3):
     """state_representation/models.py:38-107, same signature and the same checks.  With a path the log folder's exp_config.json is read
     (as an OrderedDict: the order of the losses matters to srl_zoo) — `state-dim` (required), `losses`, `n_actions`, `model-type`,
     `multi-view` (-> 6 input channels: srl_zoo sets preprocessing.N_CHANNELS = 6), `inverse-model-type`, `split-dimensions` (a dict whose
     values sum to 0 means "combine the losses": None) — and the checkpoint is loaded: a `baselines/.../pca` path is a pickled PCA
-    (SRLPCA), anything else a torch state_dict for the encoder.  Only the `custom_cnn` encoder is restated (srl_zoo is an empty
+    (SRLPCA), anything else a torch state_dict — a bare CustomCNN's, or srl_zoo's SRLModules layout (`model.*` + loss heads, which are
+    dropped: _encoder_state_dict).  Only the `custom_cnn` encoder is restated (srl_zoo is an empty
     submodule in the reference checkout): other model types raise NotImplementedError instead of silently building a different
     network.  img_shape / n_channels: the frame shape the batched encoder is built for (the reference fixes it through srl_zoo
     globals)."""
@@ -260,6 +286,8 @@ def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_sha
         state_dict = th.load(path, map_location="cpu") if path is not None else None
         if isinstance(state_dict, dict) and "state_dict" in state_dict:
             state_dict = state_dict["state_dict"]
+        if state_dict is not None:
+            state_dict = _encoder_state_dict(state_dict, losses, split_dimensions)
         model = SRLNeuralNetwork(state_dim, cuda, model_type, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict)
         model.losses, model.n_actions, model.split_dimensions, model.inverse_model_type = losses, n_actions, split_dimensions, inverse_model_type
     elif path is not None:

@@ -26,11 +26,10 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # The rounds 1-2 lumped-gripper kernels (cfg.kuka_model = LUMPED) are kept selectable but are no longer the default model: their GPU
-    # tests run with SRLHIP_TEST_LUMPED=1 only (one lumped handle stays inside the default run: tests/test_gpu_kuka.py::
-    # test_full_model_is_the_default_and_gripper_state_matches_the_oracle, and the lumped frames in tests/test_gpu_raster.py).
-    if not os.environ.get("SRLHIP_TEST_LUMPED"):
-        skip_lumped = pytest.mark.skip(reason="lumped-gripper kernels: set SRLHIP_TEST_LUMPED=1")
+    # The rounds 1-2 lumped-gripper kernels (cfg.kuka_model = LUMPED) are no longer the default model, but the ABI exposes them and
+    # bench.py times them (secondary.kuka_lumped_model): their GPU tests run in the default suite (SRLHIP_SKIP_LUMPED=1 leaves them out).
+    if os.environ.get("SRLHIP_SKIP_LUMPED"):
+        skip_lumped = pytest.mark.skip(reason="lumped-gripper kernels: SRLHIP_SKIP_LUMPED is set")
         for item in items:
             if "lumped_kuka" in item.keywords:
                 item.add_marker(skip_lumped)

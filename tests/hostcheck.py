@@ -72,10 +72,23 @@ def default_model():
     return kuka_clib.model_to_dict(t)
 
 
-def tree_rollout(seeds, T, actions=None, **kw):
+def tree_rollout(seeds, T, actions=None, ik_trace=False, **kw):
     """Same, computed by the FULL-model lane-group stepper (csrc/kuka_tree.hpp: 12-DoF gripper tree, contact spheres per link,
-    friction rows) under the fiber harness; compare with oracle.kuka_clib.rollout after kuka_clib.set_full(True)."""
+    friction rows) under the fiber harness; compare with oracle.kuka_clib.rollout after kuka_clib.set_full(True).
+    ik_trace: also "ik_crossed" [T][n] (the kernel source's sticky IK conditioning bit after each step) and "ik_final" [n][2]
+    (bit, flagged env-steps) unpacked from Env::ikx — same layout as the oracle's."""
+    import numpy as np
     l = lib()
+    if ik_trace:
+        n = len(seeds)
+        flag, fin = np.zeros((T, n), np.uint8), np.zeros(n, np.int32)
+        l.hostcheck_kuka_tree_set_ik_trace(flag.ctypes.data_as(ctypes.c_void_p), fin.ctypes.data_as(ctypes.c_void_p))
+        try:
+            out = tree_rollout(seeds, T, actions=actions, **kw)
+        finally:
+            l.hostcheck_kuka_tree_set_ik_trace(None, None)
+        out["ik_crossed"], out["ik_final"] = flag, np.stack([fin & 1, fin >> 1], axis=1)
+        return out
     l.hostcheck_kuka_tree_rollout.argtypes = l.hostcheck_kuka_rollout.argtypes
     fake = types.SimpleNamespace(kuka_oracle_rollout=l.hostcheck_kuka_tree_rollout)
     real = kuka_clib._lib
