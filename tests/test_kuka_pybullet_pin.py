@@ -45,7 +45,13 @@ def episodes_of(fx):
 GRIPPER_JOINTS = [7, 8, 10, 11, 13]             # the movable gripper joints of kuka_with_gripper2.sdf (9 and 12 are fixed)
 
 
-def compare(fx, idx, q, reward, done, gq=None):
+def compare(fx, idx, q, reward, done, gq=None, crossed=None):
+    """crossed: the per-step IK conditioning flag of the replay (oracle ik_crossed / SRLHIP_F_KUKA_IK_CROSSED & 1).  From the first
+    flagged step on, this env's record is not compared: no two float64 implementations agree behind such a crossing
+    (tests/kuka_scripts.py; the random-action fixture is not expected to contain one)."""
+    n_use = len(idx) if crossed is None or not np.any(crossed) else int(np.argmax(np.asarray(crossed) != 0))
+    idx, q, reward, done = idx[:n_use], q[:n_use], reward[:n_use], done[:n_use]
+    gq = None if gq is None else gq[:n_use]
     assert np.array_equal(done.astype(int), fx["done"][idx]), "done flags differ from PyBullet"
     assert np.array_equal(reward, fx["reward"][idx].astype(reward.dtype)), "rewards differ from PyBullet"
     live = fx["done"][idx] == 0                     # the state after a terminal step already belongs to the next episode
@@ -62,8 +68,8 @@ def test_oracle_matches_pybullet():
     try:
         kuka_clib.set_tree_model(fixture_table(fx))               # switches the oracle to the full model with PyBullet's own numbers
         for seed, actions, idx in episodes_of(fx):
-            out = kuka_clib.rollout([seed], len(actions), actions=actions[:, None], aux=True)
-            compare(fx, idx, out["q"][:, 0], out["reward64"][:, 0], out["done"][:, 0], gq=out["q_all"][:, 0, 7:12])
+            out = kuka_clib.rollout([seed], len(actions), actions=actions[:, None], aux=True, ik_trace=True)
+            compare(fx, idx, out["q"][:, 0], out["reward64"][:, 0], out["done"][:, 0], gq=out["q_all"][:, 0, 7:12], crossed=out["ik_crossed"][:, 0])
     finally:
         kuka_clib.set_full(False)
 
@@ -79,10 +85,11 @@ def test_hip_stepper_matches_pybullet():
         h = _lib.Handle(cfg)
         h.set_kuka_tree_model(fixture_table(fx))                   # model AND solver details from the fixture
         h.reset()
-        q, gq, rew, done = [], [], [], []
+        q, gq, rew, done, crossed = [], [], [], [], []
         for a in actions:
+            crossed.append(int(h.get_state(_lib.F_KUKA_IK_CROSSED)[0]) & 1)   # read BEFORE the step: an auto-reset clears the bit
             o, r, d = h.step(np.array([a], np.int32))
             q.append(h.get_state(_lib.F_KUKA_Q)[:, 0].copy()); gq.append(h.get_state(_lib.F_KUKA_GRIPPER_Q)[:, 0].copy())
             rew.append(float(r[0])); done.append(int(d[0]))
-        compare(fx, idx, np.array(q), np.array(rew), np.array(done), gq=np.array(gq))
+        compare(fx, idx, np.array(q), np.array(rew), np.array(done), gq=np.array(gq), crossed=np.array(crossed[1:] + [0]))
         h.close()
