@@ -5,6 +5,7 @@ Runs on the GPU box:  python profiles/probes/ik_crossing_extent.py > gpurun_out/
   * the scripted saturating policies of tests/kuka_scripts.py (seeds 7..10, default config, MT19937, one episode each): episodes that
     cross, env-steps before / behind the flag, max |dq| vs the oracle before / behind it, reward / done mismatches behind it.
 TEST INFRASTRUCTURE (drives the oracle next to the product)."""
+import contextlib
 import json
 import os
 import sys
@@ -35,7 +36,8 @@ res["random_agent"] = {"envs": n, "env_steps": 4 * n * T, "flagged_env_steps": i
 h.close()
 for name, scripts, kw in (("discrete", kuka_scripts.discrete_scripts(), {}), ("continuous", kuka_scripts.continuous_scripts(), {"is_discrete": False}),
                           ("joints", kuka_scripts.joint_scripts(), {"is_discrete": False, "action_joints": True})):
-    st, ora = tg.run(scripts, kuka_scripts.T_SCRIPT, **kw)
+    with contextlib.redirect_stdout(sys.stderr):
+        st, ora = tg.run(scripts, kuka_scripts.T_SCRIPT, **kw)
     names, ss, _ = kuka_scripts.batch(scripts, tg.SEEDS)
     st["episodes"] = len(names)
     st["crossing_scripts"] = sorted({nm.split("/")[0] for nm, c in zip(names, ora["ik_final"][:, 0]) if c})

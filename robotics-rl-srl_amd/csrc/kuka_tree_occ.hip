@@ -51,6 +51,10 @@ kuka_tree_rollout_occ_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st,
     Philox &act = gact.p;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
+    // Every load of the prologue retires HERE.  Otherwise the compiler's wait for them sits at their first use INSIDE the loop, as
+    // `s_waitcnt vmcnt(0)` — and gfx9 counts stores on the same counter, so from the second step on that wait drains the previous
+    // step's output stores: a full store round trip (~1.5 k cycles) in every step of the rollout.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int t = 0; t < T; t++) {
         const int64_t row = (int64_t)t * n + e;
         int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
