@@ -224,6 +224,12 @@ int srlhip_render(srlhip_handle h, void *img_out);
  * (environments/utils.py:54).  HOST pointers, any may be NULL. */
 int srlhip_episode_stats(srlhip_handle h, double *last_return, int32_t *last_length,
                          int32_t *n_finished);
+/* The same two record planes WITHOUT a copy, for the per-step loop of rl_baselines.train (SubprocVecEnv's workers hand back
+ * info['episode'] with the step's result, rl_baselines/utils.py:213-229; environments/utils.py:54): host-pointer handles
+ * (cfg.io_device = 0) keep last_return [n] f64 / last_length [n] i32 in mapped pinned host memory that the step kernels write
+ * directly.  The pointers stay valid until srlhip_destroy; entry i is final for the episode env i finished in a step once that
+ * srlhip_step / srlhip_rollout call has returned.  EINVAL on device-pointer handles (use srlhip_episode_stats_device there). */
+int srlhip_episode_records(srlhip_handle h, const double **last_return, const int32_t **last_length);
 
 /* Same statistics for DEVICE-resident consumers (cfg.io_device-independent): enqueue-only on the handle's stream, no
  * host synchronisation.  last_return is narrowed to float32 — the element the multi-GPU path all-gathers over RCCL

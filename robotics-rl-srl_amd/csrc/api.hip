@@ -230,9 +230,19 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
             return bail(rc);
     }
     EpisodeStats &st = h->stats;
-    if ((rc = h->dalloc(&st.ep_return, n)) || (rc = h->dalloc(&st.ep_length, n)) || (rc = h->dalloc(&st.last_return, n)) ||
-        (rc = h->dalloc(&st.last_length, n)) || (rc = h->dalloc(&st.n_finished, n)) || (rc = h->dalloc(&st.last_reward, n)))
+    if ((rc = h->dalloc(&st.ep_return, n)) || (rc = h->dalloc(&st.ep_length, n)) || (rc = h->dalloc(&st.n_finished, n)) || (rc = h->dalloc(&st.last_reward, n)))
         return bail(rc);
+    if (!cfg->io_device) {
+        // Monitor's (r, l) of the last finished episode where the host can read them without a copy: the kernels' exit stores go
+        // over PCIe (12 bytes per env and launch), srlhip_episode_records() hands out the host view
+        void *dp = nullptr;
+        if (hipHostMalloc(&h->ep_host, 12 * n, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, h->ep_host, 0) != hipSuccess) {
+            h->err = "create: hipHostMalloc (episode records) failed"; return bail(SRLHIP_ENOMEM);
+        }
+        memset(h->ep_host, 0, 12 * n);
+        st.last_return = static_cast<double *>(dp);
+        st.last_length = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dp) + 8 * n);
+    } else if ((rc = h->dalloc(&st.last_return, n)) || (rc = h->dalloc(&st.last_length, n))) return bail(rc);
     rc = is_mobile(cfg->env_kind) ? mobile_alloc(h) : kuka_alloc(h);
     if (rc) return bail(rc);
     std::vector<int64_t> seeds(n);
@@ -255,6 +265,7 @@ int srlhip_destroy(srlhip_handle hh) {
     for (void *p : h->act_plane) if (p) (void)hipFree(p);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->ep_host) (void)hipHostFree(h->ep_host);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -442,6 +453,10 @@ int srlhip_get_state(srlhip_handle hh, int32_t field, void *out) {
     void *d; size_t elem; int count;
     if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->ep_host && (field == SRLHIP_F_LAST_RETURN || field == SRLHIP_F_LAST_LENGTH)) {        // mapped host block (create)
+        memcpy(out, static_cast<const uint8_t *>(h->ep_host) + (field == SRLHIP_F_LAST_LENGTH ? 8 * (size_t)h->n : 0), elem * (size_t)h->n);
+        return 0;
+    }
     SRL_HIP_CHECK(h, hipMemcpy(out, d, elem * count * (size_t)h->n, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -454,6 +469,10 @@ int srlhip_set_state(srlhip_handle hh, int32_t field, const void *in) {
     void *d; size_t elem; int count;
     if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->ep_host && (field == SRLHIP_F_LAST_RETURN || field == SRLHIP_F_LAST_LENGTH)) {
+        memcpy(static_cast<uint8_t *>(h->ep_host) + (field == SRLHIP_F_LAST_LENGTH ? 8 * (size_t)h->n : 0), in, elem * (size_t)h->n);
+        return 0;
+    }
     SRL_HIP_CHECK(h, hipMemcpy(d, in, elem * count * (size_t)h->n, hipMemcpyHostToDevice));
     if (field == SRLHIP_F_KUKA_Q || field == SRLHIP_F_KUKA_GRIPPER_Q) return kuka_refresh(h);        // derived planes: sin/cos of q, gripper position
     return 0;
@@ -489,9 +508,23 @@ int srlhip_episode_stats(srlhip_handle hh, double *last_return, int32_t *last_le
     if (rc) return rc;
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->n;
-    if (last_return) SRL_HIP_CHECK(h, hipMemcpy(last_return, h->stats.last_return, 8 * n, hipMemcpyDeviceToHost));
-    if (last_length) SRL_HIP_CHECK(h, hipMemcpy(last_length, h->stats.last_length, 4 * n, hipMemcpyDeviceToHost));
+    if (h->ep_host) {          // host-pointer handle: the records already are in host memory
+        if (last_return) memcpy(last_return, h->ep_host, 8 * n);
+        if (last_length) memcpy(last_length, static_cast<const uint8_t *>(h->ep_host) + 8 * n, 4 * n);
+    } else {
+        if (last_return) SRL_HIP_CHECK(h, hipMemcpy(last_return, h->stats.last_return, 8 * n, hipMemcpyDeviceToHost));
+        if (last_length) SRL_HIP_CHECK(h, hipMemcpy(last_length, h->stats.last_length, 4 * n, hipMemcpyDeviceToHost));
+    }
     if (n_finished) SRL_HIP_CHECK(h, hipMemcpy(n_finished, h->stats.n_finished, 4 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int srlhip_episode_records(srlhip_handle hh, const double **last_return, const int32_t **last_length) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (!h->ep_host) return h->fail(SRLHIP_EINVAL, "episode_records: host-pointer handles only (cfg.io_device = 0); device-pointer handles use srlhip_episode_stats_device");
+    if (last_return) *last_return = static_cast<const double *>(h->ep_host);
+    if (last_length) *last_length = reinterpret_cast<const int32_t *>(static_cast<const uint8_t *>(h->ep_host) + 8 * (size_t)h->n);
     return 0;
 }
 

@@ -112,8 +112,11 @@ struct Handle {
     // (built lazily on the first render; lives in `allocs`)
     float4 *raster_rays[2];
     uint32_t *raster_bg[2];
-    float *raster_grip = nullptr;         // [21][n] full Kuka model: the gripper capsules' end points (raster_grip_k, refreshed by every render)
+    float *raster_grip = nullptr;         // [42][n] full Kuka model: the gripper capsules' end points, then the arm's joint origins (raster_grip_k, refreshed by every render)
     void *pin_in, *pin_out;          // pinned host bounce buffers of srlhip_step (host-pointer mode)
+    // host-pointer handles (io_device = 0): stats.last_return / last_length live in ONE mapped pinned host block ([n] f64, then [n] i32)
+    // that the kernels address directly, so the per-step API reads an ended episode's (r, l) without a device copy (srlhip_episode_records)
+    void *ep_host = nullptr;
     size_t pin_in_sz, pin_out_sz;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }

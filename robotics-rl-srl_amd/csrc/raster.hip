@@ -258,7 +258,10 @@ __global__ void __launch_bounds__(64) raster_grip_k(RasterKukaView v, float *__r
     const int64_t n = v.n;
     if (e >= n) return;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {kBasePos[0], kBasePos[1], kBasePos[2]};
-#define SRL_FK(I) fk_forward<I>(R, p, v.sq[(I) * n + e], v.cq[(I) * n + e]);
+    // planes 21..41: the arm's joint origins jp[0..6] — the float64 forward kinematics build_kuka_scene used to run on ONE lane of every
+    // 256-lane rasteriser workgroup (with the other 255 waiting at the barrier) is done here once per env, one env per lane
+#define SRL_FK(I) { fk_forward<I>(R, p, v.sq[(I) * n + e], v.cq[(I) * n + e]); \
+                    out[(int64_t)(21 + 3 * (I)) * n + e] = (float)p[0]; out[(int64_t)(22 + 3 * (I)) * n + e] = (float)p[1]; out[(int64_t)(23 + 3 * (I)) * n + e] = (float)p[2]; }
     SRL_FK(0) SRL_FK(1) SRL_FK(2) SRL_FK(3) SRL_FK(4) SRL_FK(5) SRL_FK(6)
 #undef SRL_FK
     double Rg[5][9], pg[5][3];
@@ -304,9 +307,16 @@ __device__ int build_kuka_scene(const RasterKukaView &v, int e, Prim *prims) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {kBasePos[0], kBasePos[1], kBasePos[2]};
     float jp[ND][3];
     const int64_t n = v.n;
+    if (v.has_tm) {                // full model: the pre-pass (raster_grip_k) has run the arm's forward kinematics for this env
+#pragma unroll
+        for (int i = 0; i < ND; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) jp[i][k] = v.grip[(int64_t)(21 + 3 * i + k) * n + e];
+    } else {
 #define SRL_FK(I) { fk_forward<I>(R, p, v.sq[(I) * n + e], v.cq[(I) * n + e]); jp[I][0] = (float)p[0]; jp[I][1] = (float)p[1]; jp[I][2] = (float)p[2]; }
-    SRL_FK(0) SRL_FK(1) SRL_FK(2) SRL_FK(3) SRL_FK(4) SRL_FK(5) SRL_FK(6)
+        SRL_FK(0) SRL_FK(1) SRL_FK(2) SRL_FK(3) SRL_FK(4) SRL_FK(5) SRL_FK(6)
 #undef SRL_FK
+    }
     const float bx = (float)v.bx[e], by = (float)v.by[e], cap_z = (float)(v.bz[e] + kGliderOriginZ + v.bq[e]);
     int k = 0;
     set_prim(prims[k++], PRIM_PLANE, 0.68f, 0.78f, 0.94f, 0, 0, -1.0f, 0, 0, 0, 0, 1, 0);
@@ -892,7 +902,7 @@ int raster_render(Handle *h, void *d_img) {
         // full Kuka model: the gripper's capsule end points of every env, before anything builds a scene (raster_grip_k)
         if (!h->raster_grip) {
             int rc;
-            if ((rc = h->dalloc(&h->raster_grip, (size_t)21 * h->n))) return rc;
+            if ((rc = h->dalloc(&h->raster_grip, (size_t)42 * h->n))) return rc;
         }
         kv.grip = h->raster_grip;
         hipLaunchKernelGGL(raster_grip_k, dim3((h->n + 63) / 64), dim3(64), 0, h->stream, kv, h->raster_grip);

@@ -38,7 +38,7 @@ EXPORTS = [
     "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
     "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
-    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
+    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_records", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model", "srlhip_kuka_tree_default_model", "srlhip_set_kuka_tree_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_feature_count", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
@@ -126,6 +126,7 @@ def load():
     lib.srlhip_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
     lib.srlhip_episode_stats.argtypes = [vp, vp, vp, vp]
     lib.srlhip_episode_stats_device.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_episode_records.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     lib.srlhip_selftest_group_primitives.argtypes = [i32, vp, vp, i32]
     lib.srlhip_kuka_kernel.argtypes = [vp]
     lib.srlhip_kuka_default_model.argtypes = [vp]
@@ -341,6 +342,29 @@ class Handle(object):
         (raw pointers, 0 = skip) on the handle's stream."""
         self._check(self._lib.srlhip_episode_stats_device(self._h, last_return or None, last_length or None, n_finished or None),
                     "srlhip_episode_stats_device")
+
+    def episode_records(self):
+        """Zero-copy numpy views (last_return float64 [n], last_length int32 [n]) of the mapped host block a host-pointer handle's
+        kernels write Monitor's (r, l) into: read entry i after a step / rollout call in which env i reported done."""
+        r, l = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.srlhip_episode_records(self._h, ctypes.byref(r), ctypes.byref(l)), "srlhip_episode_records")
+        n = self.num_envs
+        ret = np.ctypeslib.as_array(ctypes.cast(r, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+        length = np.ctypeslib.as_array(ctypes.cast(l, ctypes.POINTER(ctypes.c_int32)), shape=(n,))
+        ret.flags.writeable = length.flags.writeable = False
+        return ret, length
+
+    def step_fn(self, actions, host_noise=None):
+        """A closure for per-step loops on a host-pointer handle: the output arrays, their ctypes pointers and the C entry point are
+        bound once, so a step costs one foreign call.  `actions` is the caller's int32 / float32 array that it refills in place
+        before every call; returns (call, obs, reward, done) — call() steps and returns the library's status code."""
+        assert not self.cfg.io_device
+        a = self.action_array(actions)
+        assert a is actions, "step_fn needs the final contiguous int32 / float32 action array"
+        obs, rew, done = self.new_obs(), np.zeros(self.num_envs, np.float32), np.zeros(self.num_envs, np.uint8)
+        fn, hh = self._lib.srlhip_step, self._h
+        pa, pn, po, pr, pd = _ptr(a), _ptr(host_noise), _ptr(obs), _ptr(rew), _ptr(done)
+        return (lambda: fn(hh, pa, pn, po, pr, pd)), obs, rew, done
 
     def episode_stats(self):
         n = self.num_envs

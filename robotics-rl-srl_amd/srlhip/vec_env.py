@@ -105,9 +105,20 @@ class HipVecEnv(object):
         else:
             self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self._h.obs_dim,), dtype=np.float32)
         self._actions = None
-        self._infos = [{} for _ in range(self.num_envs)]     # reused between steps: one distinct dict per env
-        self._dirty_infos = []
+        # infos of a step in which no episode ended: ONE immutable tuple of per-env empty dicts, handed out as is (SubprocVecEnv
+        # returns a tuple too); a step with episode records gets its own list
+        self._quiet_infos = tuple({} for _ in range(self.num_envs))
         self._n_finished = np.zeros(self.num_envs, np.int32)
+        # per-step fast path of the ground-truth observation modes (host-pointer handle): actions are copied into ONE bound array, the
+        # foreign call is bound once (Handle.step_fn), Monitor's (r, l) are read from the handle's mapped record planes
+        # (srlhip_episode_records) — no device copy, no second call, when an episode ends
+        self._fast = None
+        if self._enc is None:
+            act = np.zeros((self.num_envs,) if cfg.is_discrete else (self.num_envs, self._h.action_dim), np.int32 if cfg.is_discrete else np.float32)
+            call, obs, rew, done = self._h.step_fn(act)
+            ret, length = self._h.episode_records()
+            self._fast = {"act": act, "call": call, "obs": obs, "rew": rew, "done": done, "ret": ret, "len": length}
+        self._mon_rows, self._mon_count, self._mon_flushed = {}, 0, time.time()
         self._t_start = time.time()
         # bench.Monitor files, one per env like the reference (environments/utils.py:54).  They are NOT kept open: at the
         # batch sizes this env is meant for (4096+) that would exceed RLIMIT_NOFILE; rows are appended when episodes end.
@@ -141,17 +152,27 @@ class HipVecEnv(object):
             raise RuntimeError("Tried to reset an environment before done. If you want to allow early resets, "
                                "wrap your env with Monitor(env, path, allow_early_resets=True)")
         self._was_reset = True
+        if self._monitors is not None and self._mon_rows:
+            self._flush_monitors()
         if self._enc is None:
             return self._h.reset()
         self._h.reset(obs_out=self._t["images"].data_ptr())
         return self._encode()
 
     def step_async(self, actions):
+        f = self._fast
         if self.cfg.is_discrete:
             if isinstance(actions, np.ndarray) and actions.dtype != object:      # fast path: no `None` entries possible
-                self._actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
+                if f is not None:
+                    self._actions = f["act"]
+                    np.copyto(self._actions, actions.reshape(self.num_envs), casting="unsafe")
+                else:
+                    self._actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
             else:
                 self._actions = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
+                if f is not None:
+                    f["act"][:] = self._actions
+                    self._actions = f["act"]
             if self._actions.size and (self._actions.min() < -1 or self._actions.max() >= self._h.num_actions):
                 # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
                 raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(self._h.num_actions))
@@ -159,9 +180,32 @@ class HipVecEnv(object):
             if any(a is None for a in actions):
                 raise NotImplementedError("None actions need a discrete action space")
             self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._h.action_dim)
+            if f is not None:
+                f["act"][...] = self._actions
+                self._actions = f["act"]
+
+    def _flush_monitors(self):
+        """Monitor rows are buffered per env and appended in one write per file: at 4096 envs some episode ends in every step, and an
+        open / write / close per episode (15 us each) would cost more than the step.  Batches of up to 64 envs write through; larger ones
+        flush every 512 rows, every second, on reset()
+        and on close() — the reference's Monitor flushes per episode; a reader of the CSV files sees rows at most a second late."""
+        for i, rows in self._mon_rows.items():
+            fd = os.open(self._monitors[i], os.O_WRONLY | os.O_APPEND)
+            try:
+                os.write(fd, "".join(rows).encode())
+            finally:
+                os.close(fd)
+        self._mon_rows, self._mon_count, self._mon_flushed = {}, 0, time.time()
 
     def step_wait(self):
-        if self._enc is None:
+        f = self._fast
+        if f is not None:
+            rc = f["call"]()
+            if rc:
+                self._h._check(rc, "srlhip_step")
+            # fresh arrays per step, like SubprocVecEnv's np.stack (callers keep references across steps)
+            obs, rew, done = f["obs"].copy(), f["rew"].copy(), f["done"]
+        elif self._enc is None:
             obs, rew, done = self._h.step(self._actions)
         else:
             import torch
@@ -172,29 +216,28 @@ class HipVecEnv(object):
             obs = self._encode()                                         # syncs the stepper's stream
             rew, done = t["rew"].to("cpu").numpy(), t["done"].to("cpu").numpy()
         dones = done.astype(bool)
-        for i in self._dirty_infos:                      # entries that carried an 'episode' record last step
-            self._infos[i] = {}
-        self._dirty_infos = []
-        infos = self._infos
+        infos = self._quiet_infos
         if dones.any():
-            ret, length, fin = self._h.episode_stats()
-            t = round(time.time() - self._t_start, 6)
-            for i in np.nonzero(dones)[0]:
-                ep = {"r": round(float(ret[i]), 6), "l": int(length[i]), "t": t}
+            idx = np.flatnonzero(dones)
+            if f is not None:
+                ret, length = f["ret"][idx], f["len"][idx]          # mapped record planes: final once the step call has returned
+                self._n_finished[idx] += 1
+            else:
+                ret, length, fin = self._h.episode_stats()
+                ret, length, self._n_finished = ret[idx], length[idx], fin
+            now = time.time()
+            t = round(now - self._t_start, 6)
+            infos = list(infos)
+            for k, i in enumerate(idx.tolist()):
+                ep = {"r": round(float(ret[k]), 6), "l": int(length[k]), "t": t}
                 infos[i] = {"episode": ep}
-                self._dirty_infos.append(int(i))
                 if self._monitors is not None:
-                    # one unbuffered O_APPEND write per finished episode (no text-IO object per row: at 4096 envs in
-                    # lock-step MobileRobot episodes every env finishes on the same step)
-                    fd = os.open(self._monitors[i], os.O_WRONLY | os.O_APPEND)
-                    try:
-                        os.write(fd, "{},{},{}\n".format(ep["r"], ep["l"], ep["t"]).encode())
-                    finally:
-                        os.close(fd)
-            self._n_finished = fin
-        # a fresh list per step like SubprocVecEnv's tuple (callers may keep the previous step's infos); the per-env dicts of
-        # steps without an episode end are shared empties, replaced (never mutated) when an episode record appears
-        return obs, rew, dones, list(infos)
+                    self._mon_rows.setdefault(i, []).append("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
+            if self._monitors is not None:
+                self._mon_count += len(idx)
+                if self.num_envs <= 64 or self._mon_count >= 512 or now - self._mon_flushed >= 1.0:
+                    self._flush_monitors()
+        return obs, rew, dones, infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -224,7 +267,10 @@ class HipVecEnv(object):
         return self._h.episode_stats()
 
     def close(self):
+        if self._monitors is not None and self._mon_rows:
+            self._flush_monitors()
         self._monitors = None
+        self._fast = None                                # numpy views into the handle's mapped memory die with it
         if self._h is not None:
             self._h.close()
             self._h = None
