@@ -47,6 +47,10 @@
 #include "../../include/srlhip.h"
 #include "encoder_general.hpp"
 
+#ifndef ENC_X
+#define ENC_X 0          // experiment builds (profiles/probes/encoder_experiments.sh); 0 = the product
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -100,6 +104,26 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ half8 lds16(int off) { return *reinterpret_cast<const half8 *>(enc_lds + off); }
+// An MFMA the compiler may not move: `asm volatile` statements keep their order among themselves AND against every memory operation
+// (ds_read / ds_write / global_load are chained behind unmodelled side effects), so a hand-written interleave of MFMAs and loads
+// survives the scheduler exactly as written in the source — which it does not with the builtin: left to itself the scheduler issues
+// the loads of a k-step in one burst between two MFMA groups (only ~5 single-issue instructions hide behind one 32-cycle MFMA with
+// one wave per SIMD, MI355X_MICROARCH.md) and re-groups MFMAs into dependent runs on one accumulator.  The accumulator of a chain
+// must be READ by compiler-visible code only after mfma_fence(): the hazard recogniser does not see the MFMA inside the statement.
+__device__ __forceinline__ void mfma16_pinned(f32x16 &c, half8 a, half8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// wait states between the last pinned MFMA of a phase and the first VALU / v_accvgpr_read of its result (8-pass XDL write -> VALU
+// read needs 11 on gfx950; 20 issued)
+__device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3"); }
+// first MFMA of a chain: C = 0 as the inline constant (no 16 v_accvgpr_write per accumulator)
+__device__ __forceinline__ void mfma16_pinned_first(f32x16 &c, half8 a, half8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+// "the results of these chains may be read from here on": an empty pinned statement that redefines the accumulators, placed (in source
+// order = issue order) at least four pinned MFMAs (128 cycles) behind the last MFMA that wrote them — the compiler schedules every
+// reader behind this statement, which keeps the XDL-write -> VALU-read distance the hazard recogniser cannot see
+__device__ __forceinline__ void mfma_results_ready(f32x16 &a, f32x16 &b) { asm volatile("" : "+a"(a), "+a"(b)); }
 
 // f32 -> (hi, lo) f16 planes at byte offset `off` inside the plane pair starting at hbase / lbase
 __device__ __forceinline__ void store_split(int hbase, int lbase, int off, float v, bool &ovf) {
@@ -110,33 +134,39 @@ __device__ __forceinline__ void store_split(int hbase, int lbase, int off, float
     *reinterpret_cast<_Float16 *>(enc_lds + lbase + off) = lo;
 }
 
-// two conv-1 output rows (32 pixels x this wave's 32 channels each): raw accumulators (pre-scaled weights)
+// two conv-1 output rows (32 pixels x this wave's 32 channels each): raw accumulators (pre-scaled weights).  Pinned MFMAs in issue
+// order, the two accumulators alternating, the next k-step's fragments between them (see mfma16_pinned).
 __device__ __forceinline__ void conv1_pair(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int rb, int lane_base,
                                            f32x16 &v0, f32x16 &v1) {
-    f32x16 a0 = {0}, a1 = {0};
     const int base0 = 2 * ra * IN_PITCH + lane_base, base1 = 2 * rb * IN_PITCH + lane_base;
+    half8 x0 = lds16(base0), x1 = lds16(base1);
 #pragma unroll
     for (int s = 0; s < kS1; s++) {
-        const int off = (s >> 1) * IN_PITCH + (s & 1) * 32;       // kernel row s/2, pixel slots 4(s&1)+2h, +1
-        const half8 x0 = lds16(base0 + off), x1 = lds16(base1 + off);
-        a0 = mfma16(x0, Bh[s], a0);
-        a1 = mfma16(x1, Bh[s], a1);
-        a0 = mfma16(x0, Bl[s], a0);
-        a1 = mfma16(x1, Bl[s], a1);
+        const int offn = ((s + 1) >> 1) * IN_PITCH + ((s + 1) & 1) * 32;       // kernel row (s+1)/2, pixel slots 4((s+1)&1)+2h, +1
+        half8 y0 = x0, y1 = x1;
+        if (s == 0) mfma16_pinned_first(v0, x0, Bh[0]); else mfma16_pinned(v0, x0, Bh[s]);
+        if (s + 1 < kS1) y0 = lds16(base0 + offn);
+        if (s == 0) mfma16_pinned_first(v1, x1, Bh[0]); else mfma16_pinned(v1, x1, Bh[s]);
+        if (s + 1 < kS1) y1 = lds16(base1 + offn);
+        mfma16_pinned(v0, x0, Bl[s]);
+        mfma16_pinned(v1, x1, Bl[s]);
+        x0 = y0; x1 = y1;
     }
-    v0 = a0;
-    v1 = a1;
 }
-// one conv-1 output row
+// one conv-1 output row: two chains (hi / lo weights), summed by the caller's reader
 __device__ __forceinline__ void conv1_single(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int lane_base, f32x16 &v0) {
-    f32x16 a0 = {0}, a1 = {0};                                    // two chains, summed at the end
+    f32x16 a0, a1;
     const int base0 = 2 * ra * IN_PITCH + lane_base;
+    half8 x0 = lds16(base0);
 #pragma unroll
     for (int s = 0; s < kS1; s++) {
-        const half8 x0 = lds16(base0 + (s >> 1) * IN_PITCH + (s & 1) * 32);
-        a0 = mfma16(x0, Bh[s], a0);
-        a1 = mfma16(x0, Bl[s], a1);
+        half8 y0 = x0;
+        if (s == 0) mfma16_pinned_first(a0, x0, Bh[0]); else mfma16_pinned(a0, x0, Bh[s]);
+        if (s + 1 < kS1) y0 = lds16(base0 + ((s + 1) >> 1) * IN_PITCH + ((s + 1) & 1) * 32);
+        if (s == 0) mfma16_pinned_first(a1, x0, Bl[0]); else mfma16_pinned(a1, x0, Bl[s]);
+        x0 = y0;
     }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a0), "+a"(a1));              // XDL write -> VALU read distance (see mfma_fence)
 #pragma unroll
     for (int r = 0; r < 16; r++) v0[r] = a0[r] + a1[r];
 }
@@ -248,21 +278,71 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
             };
             if constexpr (MG == 2) {
                 conv1_pair(B1h, B1l, 2 * kRows1 * mh, 2 * kRows1 * mh + 1, lane_base, v0, v1);
-#pragma unroll 1
-                for (int p = 0; p < kRows1 - 1; p++) {
-                    const int prow = kRows1 * mh + p;                      // pooled row <- conv rows 2p-1, 2p, 2p+1
-                    f32x16 n0, n1;
-                    conv1_pair(B1h, B1l, 2 * prow + 2, 2 * prow + 3, lane_base, n0, n1);
-                    epilogue(prow, carry, v0, v1);
-                    // pin the interleave: per MFMA (32 cycles of matrix pipe) four VALU and one LDS instruction
+                // Software pipeline, written out by hand (round 5): the 56 MFMAs of the NEXT two conv rows are pinned statements in
+                // issue order — the two accumulators alternate, so no MFMA waits for its predecessor — and between them, in source
+                // order, sit the next k-step's two A fragments and the sixteen LDS stores of the PREVIOUS pair's pooled row (its max /
+                // scale / split arithmetic is plain VALU that the scheduler places in front of the store that needs it).  Fully unrolled:
+                // carry / v0 / v1 rotate by renaming (the rolled loop spent ~250 cycles per pooled row on 56 register moves), and the
+                // sched_group_barrier pipeline it replaces let the scheduler re-group the MFMAs into runs of 6-8 on ONE accumulator.
+                // One pipeline step: (n0, n1) <- conv rows 2 prow + 2, 2 prow + 3; pooled row prow <- (carry, v0, v1); carry <- v1.
+                auto pipe_step = [&](int prow, f32x16 &v0_, f32x16 &v1_, f32x16 &n0, f32x16 &n1) {
+                    const int base0 = 2 * (2 * prow + 2) * IN_PITCH + lane_base, base1 = 2 * (2 * prow + 3) * IN_PITCH + lane_base;
+                    half8 x0 = lds16(base0), x1 = lds16(base1), y0 = x0, y1 = x1;
+                    f32x16 m;
+                    float left[4] = {0.f, 0.f, 0.f, 0.f};
+                    // MFMA i of the step (k-step i / 4: n0 * hi, n1 * hi, n0 * lo, n1 * lo) and, behind it in issue order, slot i of
+                    // the previous pooled row's epilogue.  Only ~5 single-issue instructions hide behind one MFMA, so the epilogue is
+                    // dealt out a few instructions per slot; its accumulator reads are pinned statements too (plain VALU is not ordered
+                    // against the pinned MFMAs: the scheduler would issue all ~90 instructions of the max stage in one block).
 #pragma unroll
-                    for (int u = 0; u < 56; u++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+                    for (int i = 0; i < 4 * kS1; i++) {
+                        const int ks = i >> 2, q = i & 3;
+                        if (i == 0) mfma16_pinned_first(n0, x0, B1h[0]);
+                        else if (i == 1) mfma16_pinned_first(n1, x1, B1h[0]);
+                        else if (q == 0) mfma16_pinned(n0, x0, B1h[ks]);
+                        else if (q == 1) mfma16_pinned(n1, x1, B1h[ks]);
+                        else if (q == 2) mfma16_pinned(n0, x0, B1l[ks]);
+                        else mfma16_pinned(n1, x1, B1l[ks]);
+                        if (ks + 1 < kS1) {                                 // the next k-step's fragments
+                            const int offn = ((ks + 1) >> 1) * IN_PITCH + ((ks + 1) & 1) * 32;
+                            if (q == 0) y0 = lds16(base0 + offn);
+                            if (q == 1) y1 = lds16(base1 + offn);
+                        }
+                        if (q == 3) { x0 = y0; x1 = y1; }
+                        if (i == 4) mfma_results_ready(v0_, v1_);           // last written >= 5 pinned MFMAs (160 cycles) ago
+                        if (i >= 5 && i < 21) {                             // max over the three conv rows, one register per slot
+                            const int r = i - 5;
+                            float e0, e1;
+                            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=&v"(e0), "=v"(e1) : "a"(v0_[r]), "a"(v1_[r]));
+                            m[r] = fmaxf(carry[r], fmaxf(e0, e1));
+                            carry[r] = e1;
+                        }
+                        if (i == 21) {
+                            const float t3 = __shfl_xor(m[3], 32), t7 = __shfl_xor(m[7], 32), t11 = __shfl_xor(m[11], 32),
+                                        t15 = __shfl_xor(m[15], 32);
+                            left[0] = h ? t3 : kNegInf; left[1] = h ? t7 : t3; left[2] = h ? t11 : t7; left[3] = h ? t15 : t11;
+                        }
+                        if (i >= 24 && i < 48 && (i - 24) % 3 == 0) {       // eight pooled pixels, one split store pair per third slot
+                            const int u = (i - 24) / 3, g = u >> 1;
+                            const float kv = (u & 1) ? fmaxf(fmaxf(m[4 * g + 1], m[4 * g + 2]), m[4 * g + 3])
+                                                     : fmaxf(fmaxf(m[4 * g], m[4 * g + 1]), left[g]);
+                            store_split(A2H, A2L, (prow * 16 + 4 * g + 2 * h + (u & 1)) * PX + ch * 2, fmaxf(0.f, kv * inv1), ovf);
+                        }
                     }
-                    carry = v1; v0 = n0; v1 = n1;
+                };
+                // two steps per rolled iteration: the accumulator pairs (v0, v1) and (w0, w1) swap roles without a register move
+                static_assert((kRows1 - 1) % 2 == 1, "the pipeline below is written for an odd number of hidden pooled rows");
+                f32x16 w0, w1;
+                int prow = kRows1 * mh;
+#pragma unroll 1
+                for (int pp = 0; pp < (kRows1 - 1) / 2; pp++, prow += 2) {
+                    pipe_step(prow, v0, v1, w0, w1);
+                    pipe_step(prow + 1, w0, w1, v0, v1);
                 }
+                pipe_step(prow, v0, v1, w0, w1);
+                v0 = w0; v1 = w1;
+                // the last pooled row of this group: nothing left to hide it behind
+                asm volatile("s_nop 15\n\ts_nop 3" : "+a"(v0), "+a"(v1));
                 epilogue(kRows1 * mh + kRows1 - 1, carry, v0, v1);
             } else {
                 // two waves per SIMD: the partner wave's MFMAs cover this wave's epilogue, no in-wave pipelining (registers)
@@ -270,6 +350,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                 for (int p = 0; p < kRows1; p++) {
                     const int prow = kRows1 * mh + p;
                     conv1_pair(B1h, B1l, 2 * prow, 2 * prow + 1, lane_base, v0, v1);
+                    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(v0), "+a"(v1));      // pinned MFMAs: XDL write -> VALU read distance
                     epilogue(prow, carry, v0, v1);
                     carry = v1;
                 }
@@ -328,34 +409,45 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
             tap_addr(0, 0);
 #pragma unroll
             for (int t = 0; t < kTiles2; t++) { ah[t] = lds16(A2H + addr[t]); al[t] = lds16(A2L + addr[t]); }
-            // One rolled iteration = one kernel row = 12 k-steps, so ring slots are compile-time indices.
+            // One rolled iteration = one kernel row = 12 k-steps, so ring slots are compile-time indices.  A k-step is 3 * kTiles2
+            // pinned MFMAs (hi*hi, lo*hi, hi*lo per tile: consecutive MFMAs never share an accumulator) with the step's other work —
+            // the next step's 2 * kTiles2 A fragments, the refill of the ring slot — written BETWEEN them, one load per MFMA gap.
 #pragma unroll 1
             for (int ky = 0; ky < 3; ky++) {
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
                     const int slot = i % kB2Ahead;
-                    // -- A fragments of the next k-step (the step after the last one re-reads the zero pixel)
                     const int in = (i + 1) % 12, qn = in & 3;
                     if (qn == 0) tap_addr(in == 0 ? ky + 1 : ky, in >> 2);   // ky + 1 == 3: every row is out of range -> zero pixel
-#pragma unroll
-                    for (int t = 0; t < kTiles2; t++) { nh_[t] = lds16(A2H + addr[t] + qn * 32); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(ah[t], Rh[slot], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(ah[t], Rl[slot], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < kTiles2; t++) acc[t] = mfma16(al[t], Rh[slot], acc[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // refill the slot
                     const int sn = 12 * ky + i + kB2Ahead;
                     const half8 *pn = reinterpret_cast<const half8 *>(bp + (size_t)(sn < kS2 ? sn : kS2 - 1) * 64 * 32);
+                    const half8 bh = Rh[slot], bl = Rl[slot];
+#if ENC_X == 1            // experiment: no LDS reads in the loop
+#pragma unroll
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], ah[t], bh); nh_[t] = ah[t]; }
+#pragma unroll
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], al[t], bh); nl_[t] = al[t]; }
+#else
+#pragma unroll
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], ah[t], bh); nh_[t] = lds16(A2H + addr[t] + qn * 32); }
+#pragma unroll
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], al[t], bh); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
+#endif
+#if ENC_X != 2            // experiment 2: no B streaming
                     Rh[slot] = pn[0];                                      // (the last requests of a frame re-read fragment 35: harmless)
+#endif
+#pragma unroll
+                    for (int t = 0; t < kTiles2; t++) mfma16_pinned(acc[t], ah[t], bl);
+#if ENC_X != 2
                     Rl[slot] = pn[1];
+#endif
 #pragma unroll
                     for (int t = 0; t < kTiles2; t++) { ah[t] = nh_[t]; al[t] = nl_[t]; }
                 }
             }
+            // (tied to the accumulators: their readers are scheduled behind it)
+            if constexpr (kTiles2 == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+            else { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1])); }
             ENC_STAMP(4);
             // layer 3's B fragments for this wave's K part: one burst, in flight during the epilogue below
 #pragma unroll
