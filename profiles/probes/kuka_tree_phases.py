@@ -27,9 +27,10 @@ for rep in range(2):
     ms = h.timing_end()
     print("launch {}: T {} {:.3f} ms, {:.2f} us per step".format(rep, T, ms, ms * 1e3 / T), flush=True)
 h.close()
-names = ["action / noise sampling + action mapping (loop top .. physics step)", "IK", "collision + motor targets", "RNEA sums", "CRBA", "Gauss-Jordan 12x12", "row setup",
+names = ["start of the physics step (what is left of the old phase 0 once 20 and 21 are stamped)", "IK", "collision + motor targets", "RNEA sums", "CRBA", "Gauss-Jordan 12x12", "row setup",
          "150 sweeps, free steps", "sweeps + setup, steps with generic rows", "integrate + refresh (sincos, FK)",
          "counters, reward, termination", "episode statistics, auto-reset, observation + output stores",
          "generic: candidates -> row definitions", "generic: W J of every slot", "generic: own bank-B row (diagonal, rhs, couplings)", "generic: the 150 sweeps",
-         "generic: outputs", "NUMBER of steps with generic rows (a count, not cycles)", "NUMBER of steps with a joint-limit row", "NUMBER of steps with a contact row"]
+         "generic: outputs", "NUMBER of steps with generic rows (a count, not cycles)", "NUMBER of steps with a joint-limit row", "NUMBER of steps with a contact row",
+         "loop back-edge + action sampling", "noise draw + action mapping (step_command)"]
 print("phase names:", {i: s for i, s in enumerate(names)})

@@ -45,7 +45,7 @@ using grp::wany;
 // between consecutive stamps, accumulated per phase by lane 0 of the workgroup in LDS, printed by workgroup 0 when the kernel ends.
 // The product build compiles them away.
 #if defined(SRL_TREE_PROF) && SRL_G_DEVICE
-constexpr int kProfSlots = 20;      // 0..11: phases of a step; 12..16: inside general_path; 17..19: number of steps with generic rows / a limit row / a contact row
+constexpr int kProfSlots = 22;      // 0..11: phases of a step; 12..16: inside general_path; 17..19: number of steps with generic rows / a limit row / a contact row; 20, 21: loop top -> action sampled -> command mapped
 SRL_G unsigned long long *tprof_buf() { __shared__ unsigned long long p[kProfSlots + 1]; return p; }
 #define SRL_TCOUNT(i) do { if (threadIdx.x == 0) tprof_buf()[i] += 1; } while (0)
 #define SRL_TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long *p_ = tprof_buf(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p_[i] += t_ - p_[kProfSlots]; p_[kProfSlots] = t_; } } while (0)
@@ -1939,6 +1939,7 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     StepCmd c;
     step_command(e, cfg, rng, action, ca3, c);
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
+    SRL_TSTAMP(21);                         // noise draw + action mapping (step_command)
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
         tphysics_step<NB, RB, OCC>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
         if (termination(e, cfg)) break;

@@ -153,6 +153,9 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         float ca_own = 0.f;
 #pragma unroll
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
+#if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        { using namespace tree; SRL_TSTAMP(20); }     // loop back-edge + the agent's action (sampled or loaded)
+#endif
         bool done;
         double reward;
         reward = tree::tenv_step<NB, RB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);

@@ -138,3 +138,48 @@ def test_dataset_generator_cli(tmp_path):
              "--img-size", "64"])
     pp = np.load(root + "kuka/preprocessed_data.npz")
     assert pp["episode_starts"].sum() == 3 and set(np.unique(pp["rewards"])) <= {-1, 0, 1}
+
+
+def test_episode_records_are_the_episode_stats_without_a_copy(tmp_path):
+    """srlhip_episode_records: host-pointer handles keep Monitor's (r, l) in mapped host memory the kernels write — the views equal
+    srlhip_episode_stats' copies after per-step calls, fused rollouts and masked resets, on both env families; HipVecEnv's
+    info['episode'] (read from the views) matches, with buffered Monitor rows flushed on close; device-pointer handles refuse."""
+    from srlhip import _lib
+    from srlhip.vec_env import HipVecEnv
+    for kind, T in ((_lib.ENV_KUKA_BUTTON, 1300), (_lib.ENV_MOBILE, 600)):
+        cfg = _lib.default_config(kind)
+        cfg.num_envs, cfg.rng_mode, cfg.auto_reset = 96, _lib.RNG_PHILOX, 1
+        h = _lib.Handle(cfg)
+        h.reset()
+        ret_v, len_v = h.episode_records()
+        acts = np.random.RandomState(1).randint(4 if kind == _lib.ENV_MOBILE else 6, size=(T, 96)).astype(np.int32)
+        seen = 0
+        for t in range(T // 2):
+            o, r, d = h.step(acts[t])
+            seen += int(d.sum())
+        h.rollout(T - T // 2, actions=acts[T // 2:])
+        ret, length, fin = h.episode_stats()
+        assert fin.sum() >= seen and fin.min() >= 1 and np.array_equal(ret, ret_v) and np.array_equal(length, len_v)
+        assert np.array_equal(h.get_state(_lib.F_LAST_RETURN), ret_v) and np.array_equal(h.get_state(_lib.F_LAST_LENGTH), len_v)
+        h.close()
+    cfg = _lib.default_config(_lib.ENV_MOBILE)
+    cfg.num_envs, cfg.io_device, cfg.rng_mode = 8, 1, _lib.RNG_PHILOX
+    h = _lib.Handle(cfg)
+    with pytest.raises(_lib.SrlHipError):
+        h.episode_records()
+    h.close()
+    env = HipVecEnv("KukaButtonGymEnv-v0", 128, seed=0, env_kwargs={"srl_model": "ground_truth"}, log_dir=str(tmp_path))
+    env.reset()
+    rs, n_ep, ret_sum = np.random.RandomState(2), np.zeros(128, int), np.zeros(128)
+    running = np.zeros(128)
+    for t in range(1200):
+        obs, rew, done, infos = env.step(rs.randint(6, size=128))
+        running += rew
+        for i in np.flatnonzero(done):
+            assert infos[i]["episode"]["r"] == round(float(running[i]), 6)
+            n_ep[i] += 1; running[i] = 0.0
+        assert all(info == {} for i, info in enumerate(infos) if not done[i])
+    env.close()
+    for i in (0, 77, 127):
+        rows = open(os.path.join(str(tmp_path), "%d.monitor.csv" % i)).read().splitlines()[2:]
+        assert len(rows) == n_ep[i] >= 1
