@@ -282,6 +282,9 @@ int srlhip_set_kuka_model(srlhip_handle h, const srlhip_kuka_model *m);
  * the getArmPos() link / point (kuka_gripper_index 8: its COM), up to 16 collision spheres (link, centre, radius, combined lateral
  * friction), table / button-base heights, the per-step budget of limit + contact-normal rows (<= 6: the lane group's second row bank; values above are rejected) and the
  * friction switch, then the SOLVER DETAILS below.
+ * Impulse bounds: a contact-normal row is boxed to [0, 1e10] (Bullet's default upper bound) in the oracle and in the kernel's general
+ * path; the one-button contact fast path solves normal rows in u = lambda / 2^33 so that the projection is the hardware clamp of one add,
+ * i.e. its upper bound is 2^33 = 8.59e9 — impulses are ~1e-2, neither bound is ever reached, the results are identical.
  * The arm part is in-tree or pinned elsewhere (srlhip_kuka_model); the gripper part is RECALLED from kuka_with_gripper2.sdf
  * [UNVERIFIED-MEMORY] — tests/golden/make_kuka_pybullet_golden.py overwrites it from pybullet_data when PyBullet is importable. */
 typedef struct srlhip_kuka_tree_joint {

@@ -77,6 +77,12 @@ int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
 
 // raster.hip
 int raster_render(Handle *h, void *d_img);
+// What the rasteriser sees of a Kuka handle (filled by kuka.hip::kuka_raster_view, passed BY VALUE to raster.hip's kernels — one
+// definition, so that the two translation units cannot drift apart): raw plane pointers (sq / cq: [7][n] ...), gj = the five gripper
+// joints of the installed full-model table (parent, frame in the parent link, axis), grip = raster_grip_k's output planes
+// ([42][n]: gripper capsule end points, then the arm's joint origins); has_tm = 0 on lumped handles.
+struct RasterGripJoint { double parent, xyz[3], Rj[9], axis[3]; };
+struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; RasterGripJoint gj[5]; const float *grip; int64_t n; int32_t two, rand_objects, has_tm; };
 
 struct KukaState;   // defined in kuka.hip
 

@@ -390,10 +390,7 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-// (raster.hip; gj: the five gripper joints of the installed full-model table — parent, frame in the parent link, axis — BY VALUE: kernel arguments
-//  are scalar loads; has_tm = 0 on lumped handles)
-struct RasterGripJoint { double parent, xyz[3], Rj[9], axis[3]; };
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; RasterGripJoint gj[5]; const float *grip; int64_t n; int32_t two, rand_objects, has_tm; };
+// (RasterKukaView: internal.hpp — one definition for this file and raster.hip)
 void kuka_raster_view(Handle *h, RasterKukaView *v) {
     const KukaState *s = h->kuka;
     const size_t n = (size_t)h->n;

@@ -32,11 +32,7 @@
 
 namespace srl {
 
-// KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers.
-// (gj: the five gripper joints of the installed full-model table — parent, frame in the parent link, axis — BY VALUE: kernel arguments
-//  are scalar loads; has_tm = 0 on lumped handles)
-struct RasterGripJoint { double parent, xyz[3], Rj[9], axis[3]; };
-struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; RasterGripJoint gj[5]; const float *grip; int64_t n; int32_t two, rand_objects, has_tm; };     // sq/cq: [7][n]
+// KukaState / planes are private to kuka.hip; the rasteriser gets raw plane pointers (RasterKukaView: internal.hpp).
 struct RasterMobileView { const double *x, *y, *tx, *ty, *t2x, *t2y; const int32_t *cur; };
 
 namespace {
