@@ -224,11 +224,18 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
             B1l[s] = p[1];
         }
         // ---- phase 0: uint8 frame (already staged in LDS) -> f16 (R, G, B, 1) pixels inside the zero ring ------
+        // (every raw word is read before the first pixel is written: the compiler cannot prove that the IN stores do not alias the RAW
+        //  reads, so a read-convert-write loop waits out one LDS round trip per piece)
+        uint32_t rawq[1024 / kThreads][3];
+#pragma unroll
+        for (int i = 0; i < 1024 / kThreads; i++) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(enc_lds + RAW + 12 * (tid + kThreads * i));
+            rawq[i][0] = w[0]; rawq[i][1] = w[1]; rawq[i][2] = w[2];
+        }
 #pragma unroll
         for (int i = 0; i < 1024 / kThreads; i++) {
             const int q = tid + kThreads * i;                              // four consecutive pixels = 12 bytes
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(enc_lds + RAW + 12 * q);
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t w0 = rawq[i][0], w1 = rawq[i][1], w2 = rawq[i][2];
             const uint32_t px[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
             const int y = (4 * q) >> 6, x = (4 * q) & 63;
 #pragma unroll
