@@ -289,6 +289,7 @@ int srlhip_seed(srlhip_handle hh, const uint8_t *mask, const int64_t *seeds) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     h->prefetch_valid = false;                  // the action-stream counters restart
+    h->snap_valid = false;
     return rc ? rc : seed_impl(h, mask, seeds);
 }
 
@@ -468,6 +469,7 @@ int srlhip_set_state(srlhip_handle hh, int32_t field, const void *in) {
     if (rc) return rc;
     void *d; size_t elem; int count;
     if ((rc = field_lookup(h, field, &d, &elem, &count))) return rc;
+    h->snap_valid = false;                 // (MobileRobot: the rollout's chained snapshot no longer equals the live state)
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     if (h->ep_host && (field == SRLHIP_F_LAST_RETURN || field == SRLHIP_F_LAST_LENGTH)) {
         memcpy(static_cast<uint8_t *>(h->ep_host) + (field == SRLHIP_F_LAST_LENGTH ? 8 * (size_t)h->n : 0), in, elem * (size_t)h->n);
@@ -624,6 +626,7 @@ int srlhip_graph_begin(srlhip_handle hh) {
     int rc = set_device(h);
     if (rc) return rc;
     h->prefetch_valid = false;             // a captured synthetic-agent rollout moves the action-stream counters on the device at every replay
+    h->snap_valid = false;
     SRL_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     return 0;
 }
@@ -651,6 +654,7 @@ int srlhip_graph_launch(srlhip_handle hh, srlhip_graph_handle g) {
     if (!hh || !g) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     h->prefetch_valid = false;             // (see srlhip_graph_begin: the action plane drawn ahead belongs to counters the replay has consumed)
+    h->snap_valid = false;                 // ... and the replay moved the live state
     SRL_HIP_CHECK(h, hipGraphLaunch(g->exec, h->stream));
     return 0;
 }

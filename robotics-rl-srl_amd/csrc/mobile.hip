@@ -358,6 +358,8 @@ constexpr int kEpisodeSteps = 251;
 // overwrites its state: the segments therefore read this snapshot, taken by mobile_snapshot_k in stream order right
 // before the launch, and only write the live state.
 struct MobileSnap { MobileState s; const uint64_t *ctr; const double *ep_return; const int32_t *ep_length; };
+// where the lane that leaves an env's final state ALSO writes it: the snapshot set the next launch will read (null planes: nowhere)
+struct MobileSnapOut { MobileState s; uint64_t *ctr, *actr; double *ep_return; int32_t *ep_length; };
 // The synthetic agent's NEXT action plane, drawn by the workgroups of a rollout launch beyond its segment lanes (the rollout itself
 // is a latency-bound recurrence on 10 x N lanes: the chip has room) so that the following rollout starts without a sampler launch:
 // block base[e] + T + t of env e's action stream (base = the counters in the snapshot: the live ones move when the rollout ends).
@@ -377,7 +379,7 @@ template <int KIND, int DISC, int SHAPE, int PLANES>      // PLANES: 0 check eve
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs, EpisodeStats st, int T, int draws_per_reset, int smax,
                     const void *__restrict__ actions, float *__restrict__ obs, float *__restrict__ rew,
-                    uint8_t *__restrict__ done_out, int advance_actr, NextPlane next, void *__restrict__ act_out) {
+                    uint8_t *__restrict__ done_out, int advance_actr, NextPlane next, void *__restrict__ act_out, MobileSnapOut snap_out) {
     p.kind = KIND; p.is_discrete = DISC; p.shape_reward = SHAPE;            // compile-time constants from here on
     if ((int)blockIdx.x >= next.ep_blocks) {                               // spare workgroups: the next rollout's action plane
         sample_plane_entry(p, rs.key, next.base, (uint64_t)T, blockIdx.x - (uint32_t)next.ep_blocks, next.pm, T, next.act);
@@ -517,9 +519,14 @@ mobile_rollout_ep_k(MobileParams p, MobileState s, MobileSnap snap, RngState rs,
     if (last) {
         store_env(s, e, m);
         rs.ctr[e] = rng.p.ctr;
-        if (advance_actr) rs.act_ctr[e] += (uint64_t)T;
+        const uint64_t actr = rs.act_ctr[e] + (advance_actr ? (uint64_t)T : 0);
+        if (advance_actr) rs.act_ctr[e] = actr;
         st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_reward[e] = last_reward;
         st.n_finished[e] += n_completed;
+        if (snap_out.ctr) {                  // the next launch's snapshot (this launch reads the other set)
+            store_env(snap_out.s, e, m);
+            snap_out.ctr[e] = rng.p.ctr; snap_out.actr[e] = actr; snap_out.ep_return[e] = ep_ret; snap_out.ep_length[e] = ep_len;
+        }
     }
 }
 
@@ -559,6 +566,12 @@ int mobile_alloc(Handle *h) {
             (rc = h->dalloc(&h->snap_ep_return, n)) || (rc = h->dalloc(&h->snap_ep_length, n)) || (rc = h->dalloc(&h->snap_ctr, n)) ||
             (rc = h->dalloc(&h->snap_actr, n)))
             return rc;
+        MobileState &d2 = h->mobile_snap2;
+        if ((rc = h->dalloc(&d2.pos_x, n)) || (rc = h->dalloc(&d2.pos_y, n)) || (rc = h->dalloc(&d2.tgt_x, n)) || (rc = h->dalloc(&d2.tgt_y, n)) ||
+            (rc = h->dalloc(&d2.tgt2_x, n)) || (rc = h->dalloc(&d2.tgt2_y, n)) || (rc = h->dalloc(&d2.counter, n)) || (rc = h->dalloc(&d2.cur_target, n)) ||
+            (rc = h->dalloc(&h->snap2_ep_return, n)) || (rc = h->dalloc(&h->snap2_ep_length, n)) || (rc = h->dalloc(&h->snap2_ctr, n)) ||
+            (rc = h->dalloc(&h->snap2_actr, n)))
+            return rc;
     }
     return 0;
 }
@@ -566,6 +579,7 @@ int mobile_alloc(Handle *h) {
 void mobile_free(Handle *) {}
 
 int mobile_reset(Handle *h, const uint8_t *d_mask, const double *d_host_rand, float *d_obs) {
+    h->snap_valid = false;
     MobileParams p = params_of(h);
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
     int stride = mobile_reset_rand_count(h->cfg);
@@ -611,21 +625,40 @@ void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actio
 // when `d_actions` is an internal one
 int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_actions, float *d_obs, float *d_rew,
                       uint8_t *d_done, int advance_actr, void *next_plane, void *act_out) {
-    hipLaunchKernelGGL(mobile_snapshot_k, dim3((h->n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->n, h->mobile, h->rng, h->stats,
-                       h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length, h->snap_actr);
-    const MobileSnap snap{h->mobile_snap, h->snap_ctr, h->snap_ep_return, h->snap_ep_length};
+    // two snapshot sets in turn: this launch reads set `cur` — written by the previous rollout launch's final-state lanes, or by
+    // mobile_snapshot_k now when anything else has touched the state since — and writes the env's final state into the other one.
+    // Inside a stream capture the copy kernel always runs and nothing is written ahead: a replayed graph must not depend on which set
+    // the previous replay left behind.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &capture);
+    const bool chained = capture == hipStreamCaptureStatusNone;
+    const int cur = h->snap_cur;
+    MobileState &sin = cur ? h->mobile_snap2 : h->mobile_snap, &sout = cur ? h->mobile_snap : h->mobile_snap2;
+    uint64_t *in_ctr = cur ? h->snap2_ctr : h->snap_ctr, *in_actr = cur ? h->snap2_actr : h->snap_actr;
+    double *in_ret = cur ? h->snap2_ep_return : h->snap_ep_return;
+    int32_t *in_len = cur ? h->snap2_ep_length : h->snap_ep_length;
+    if (!h->snap_valid || !chained)
+        hipLaunchKernelGGL(mobile_snapshot_k, dim3((h->n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->n, h->mobile, h->rng, h->stats,
+                           sin, in_ctr, in_ret, in_len, in_actr);
+    const MobileSnap snap{sin, in_ctr, in_ret, in_len};
+    MobileSnapOut snap_out = {};
+    if (chained)
+        snap_out = MobileSnapOut{sout, cur ? h->snap_ctr : h->snap2_ctr, cur ? h->snap_actr : h->snap2_actr,
+                                 cur ? h->snap_ep_return : h->snap2_ep_return, cur ? h->snap_ep_length : h->snap2_ep_length};
+    h->snap_cur = chained ? cur ^ 1 : cur;
+    h->snap_valid = chained;
     const int smax = 1 + (T - 1 + kEpisodeSteps - 1) / kEpisodeSteps;     // first segment of one step + whole episodes
     const int64_t lanes = (int64_t)smax * h->n;
     const int ep_blocks = (int)((lanes + kBlock - 1) / kBlock);
     const PlaneMap pm = plane_map(h->n);
     const int64_t extra = next_plane ? (int64_t)T * pm.bpr : 0;
-    const NextPlane next{next_plane, h->snap_actr, ep_blocks, pm};
+    const NextPlane next{next_plane, in_actr, ep_blocks, pm};
     dim3 grid((unsigned)(ep_blocks + extra)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
     const int planes = d_obs && d_rew && d_done ? (act_out ? 2 : 1) : 0;   // the fast loop stores without checking
 #define SRL_EP(KIND, DISC, SHAPE, PLANES)                                                                               \
     hipLaunchKernelGGL((mobile_rollout_ep_k<KIND, DISC, SHAPE, PLANES>), grid, block, 0, h->stream, p, h->mobile, snap, h->rng, h->stats, T, \
-                       draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr, next, act_out)
+                       draws, smax, d_actions, d_obs, d_rew, d_done, advance_actr, next, act_out, snap_out)
 #define SRL_PL(KIND, DISC, SHAPE) { if (planes == 2) SRL_EP(KIND, DISC, SHAPE, 2); else if (planes == 1) SRL_EP(KIND, DISC, SHAPE, 1); else SRL_EP(KIND, DISC, SHAPE, 0); }
 #define SRL_GO(KIND, DISC) { if (p.shape_reward) SRL_PL(KIND, DISC, 1) else SRL_PL(KIND, DISC, 0) }
 #define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1) else SRL_GO(KIND, 0) }
@@ -704,6 +737,8 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
     }
     // counter-based streams + fixed-length episodes: segments of the rollout run in parallel (mobile_rollout_ep_k)
     if (ep_path) { int rc = launch_rollout_ep(h, p, T, d_actions, d_obs, d_rew, d_done, advance, nullptr, nullptr); if (rc) return rc; }
+    else h->snap_valid = false;          // the sequential kernels below move the live state only
+    if (ep_path) {}
     else if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) launch_rollout<SRLHIP_RNG_PHILOX>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     else launch_rollout<SRLHIP_RNG_MT19937>(h, p, T, d_actions, nullptr, d_obs, d_rew, d_done, advance);
     SRL_HIP_CHECK(h, hipGetLastError());
@@ -713,6 +748,7 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
 int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *d_obs, float *d_rew,
                 uint8_t *d_done) {
     if (h->cfg.rng_mode != SRLHIP_RNG_HOST) return mobile_rollout(h, 1, d_actions, d_obs, d_rew, d_done, nullptr);
+    h->snap_valid = false;
     MobileParams p = params_of(h);
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, -1, -1>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,

@@ -363,3 +363,39 @@ def test_episode_parallel_kernel_instantiations(kind, shape_reward):
     assert np.array_equal(np.concatenate([a["reward"], b["reward"]]), ora["reward"])
     assert np.array_equal(np.concatenate([a["done"], b["done"]]), ora["done"])
     h.close()
+
+
+def test_chained_rollouts_with_steps_and_state_writes_in_between():
+    """Round 5: back-to-back episode-parallel rollouts read the snapshot the previous launch's final-state lanes wrote (no copy kernel);
+    per-step calls, a masked reset and a set_state in between fall back to the copy.  The whole sequence equals the same handle
+    configuration stepped one launch per step."""
+    n, seed0 = 300, 21
+    rs = np.random.RandomState(3)
+    plan = [("rollout", 300), ("rollout", 40), ("steps", 5), ("rollout", 700), ("rollout", 33), ("reset_mask", 0), ("rollout", 260),
+            ("set_state", 0), ("rollout", 100), ("rollout", 100)]
+    ha = make(0, n, _lib.RNG_PHILOX, seed0=seed0, random_target=1)
+    hb = make(0, n, _lib.RNG_PHILOX, seed0=seed0, random_target=1)
+    assert np.array_equal(ha.reset(), hb.reset())
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    for what, T in plan:
+        if what in ("rollout", "steps"):
+            actions = rs.randint(4, size=(T, n)).astype(np.int32)
+            ob, rw, dn = np.zeros((T, n, 2), np.float32), np.zeros((T, n), np.float32), np.zeros((T, n), np.uint8)
+            for t in range(T):
+                ob[t], rw[t], dn[t] = hb.step(actions[t])
+            if what == "rollout":
+                out = ha.rollout(T, actions=actions)
+                got = (out["obs"], out["reward"], out["done"])
+            else:
+                got = (np.zeros_like(ob), np.zeros_like(rw), np.zeros_like(dn))
+                for t in range(T):
+                    got[0][t], got[1][t], got[2][t] = ha.step(actions[t])
+            assert np.array_equal(got[0], ob) and np.array_equal(got[1], rw) and np.array_equal(got[2], dn), (what, T)
+        elif what == "reset_mask":
+            assert np.array_equal(ha.reset(mask=mask), hb.reset(mask=mask))
+        else:
+            x = ha.get_state(_lib.F_POS_X) * 0.5
+            ha.set_state(_lib.F_POS_X, x); hb.set_state(_lib.F_POS_X, x)
+        for f in (_lib.F_POS_X, _lib.F_POS_Y, _lib.F_STEP_COUNT, _lib.F_EP_RETURN, _lib.F_EP_LENGTH, _lib.F_LAST_RETURN, _lib.F_N_FINISHED):
+            assert np.array_equal(ha.get_state(f), hb.get_state(f)), (what, T, f)
+    ha.close(); hb.close()
