@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <new>
 
 #include "internal.hpp"
@@ -118,6 +119,12 @@ __global__ void episode_stats_k(EpisodeStats st, int n, float *ret, int32_t *len
     if (len) len[e] = st.last_length[e];
     if (fin) fin[e] = st.n_finished[e];
 }
+
+// Host-pointer calls validate what the kernels cannot afford to: the full-model Kuka kernels are compiled with -fno-honor-nans, so a NaN
+// or an infinity in a continuous action or in host-drawn noise would propagate through the step unchecked (the reference's
+// np.clip / pybullet would raise or saturate).  Device-pointer callers own their buffers' contents.
+bool all_finite_f32(const float *p, size_t count) { for (size_t i = 0; i < count; i++) if (!std::isfinite(p[i])) return false; return true; }
+bool all_finite_f64(const double *p, size_t count) { for (size_t i = 0; i < count; i++) if (!std::isfinite(p[i])) return false; return true; }
 
 int field_lookup(Handle *h, int field, void **dptr, size_t *elem, int *count) {
     *count = 1;
@@ -355,6 +362,9 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
     static const bool zc_enabled = [] { const char *v = getenv("SRLHIP_ZERO_COPY"); return !v || atoi(v) != 0; }();   // =0: bounce buffers
     const bool zero_copy = zc_enabled && !h->cfg.io_device && !pixels && out_total <= ((size_t)1 << 20);
     if (!h->cfg.io_device) {
+        if (!h->cfg.is_discrete && !all_finite_f32(static_cast<const float *>(actions), ab / sizeof(float)))
+            return h->fail(SRLHIP_EINVAL, "step: non-finite continuous action");
+        if (host_noise && !all_finite_f64(host_noise, (size_t)n)) return h->fail(SRLHIP_EINVAL, "step: non-finite host_noise");
         if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, out_total)))
             return rc;
         memcpy(h->pin_in, actions, ab);
@@ -411,6 +421,8 @@ int srlhip_rollout(srlhip_handle hh, int32_t T, const void *actions_TN, void *ob
     void *d_act_out = act_out_TN;
     const size_t ob = obs_bytes_per_env(h) * tn, ab = action_bytes(h) * (size_t)T;
     if (!h->cfg.io_device) {
+        if (actions_TN && !h->cfg.is_discrete && !all_finite_f32(static_cast<const float *>(actions_TN), ab / sizeof(float)))
+            return h->fail(SRLHIP_EINVAL, "rollout: non-finite continuous action");
         if (actions_TN) { if ((rc = stage_in(h, &h->st_actions, &h->st_actions_sz, actions_TN, ab))) return rc; d_act = h->st_actions; }
         else if (act_out_TN) { if ((rc = ensure(h, &h->st_actions, &h->st_actions_sz, ab))) return rc; d_act_out = h->st_actions; }
         if (obs_TN) { if ((rc = ensure(h, &h->st_obs, &h->st_obs_sz, ob))) return rc; d_obs = h->st_obs; }

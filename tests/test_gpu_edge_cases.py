@@ -84,6 +84,24 @@ def test_degenerate_calls_are_rejected_not_executed():
         env.step([0, 1, 6, 2])                                  # the reference indexes a 6-entry list
     env.step([0, None, 5, 2])
     env.close(); h.close()
+    # non-finite continuous actions / host noise are refused at the boundary (the full-model kernels are built with -fno-honor-nans)
+    c = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    c.num_envs, c.is_discrete = 4, 0
+    h = _lib.Handle(c)
+    h.reset()
+    a = np.zeros((4, 3), np.float32)
+    h.step(a)
+    for bad in (np.nan, np.inf, -np.inf):
+        a[2, 1] = bad
+        with pytest.raises(_lib.SrlHipError):
+            h.step(a)
+        with pytest.raises(_lib.SrlHipError):
+            h.rollout(3, actions=np.stack([a, a, a]))
+    a[2, 1] = 0.5
+    q = h.get_state(_lib.F_KUKA_Q)
+    h.step(a)
+    assert np.isfinite(h.get_state(_lib.F_KUKA_Q)).all() and not np.array_equal(q, h.get_state(_lib.F_KUKA_Q))
+    h.close()
 
 
 def test_large_handle_mobile_one_million_envs():
