@@ -506,23 +506,52 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 
         // ---- layer 3: conv3x3/2 p1 (7x7 -> 4x4) + ReLU + maxpool3/2 (-> 1x1); K split over the wave groups ----
         {
-            f32x16 c0 = {0}, c1 = {0};                                     // two chains: 3 dependent MFMAs per k-step otherwise
+            f32x16 c0;
             const bool pix = j < 16;
             const int oy = (j >> 2) & 3, ox = j & 3;
-#pragma unroll
-            for (int ii = 0; ii < kSteps3; ii++) {
+            auto a3_addr = [&](int ii) {
                 const int s = kSteps3 * mh + ii, tap = s >> 2, q = s & 3;
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
                 const bool ok = pix && (unsigned)sy < 7u && (unsigned)sx < 7u;
-                const int addr = (ok ? sy * 7 + sx : 49) * PX + h * 16 + q * 32;
-                const half8 ah = lds16(A3H + addr), al = lds16(A3L + addr);
-                c0 = mfma16(ah, B3h[ii], c0);
-                c1 = mfma16(ah, B3l[ii], c1);
-                c1 = mfma16(al, B3h[ii], c1);
-            }
+                return (ok ? sy * 7 + sx : 49) * PX + h * 16 + q * 32;
+            };
+            if constexpr (MG == 2) {
+                // three chains (hi*hi, hi*lo, lo*hi), pinned in issue order so that no MFMA waits for its predecessor; the next k-step's
+                // two A fragments are requested between them (the compiler's schedule read them right before their use and chained the
+                // two MFMAs of one accumulator back to back): 4.1 k -> 2.9 k cycles for the phase
+                f32x16 c1, c2;
+                half8 ah = lds16(A3H + a3_addr(0)), al = lds16(A3L + a3_addr(0));
 #pragma unroll
-            for (int r = 0; r < 16; r++) c0[r] += c1[r];
+                for (int ii = 0; ii < kSteps3; ii++) {
+                    half8 nh2 = ah, nl2 = al;
+                    if (ii == 0) mfma16_pinned_first(c0, ah, B3h[0]); else mfma16_pinned(c0, ah, B3h[ii]);
+                    if (ii + 1 < kSteps3) nh2 = lds16(A3H + a3_addr(ii + 1));
+                    if (ii == 0) mfma16_pinned_first(c1, ah, B3l[0]); else mfma16_pinned(c1, ah, B3l[ii]);
+                    if (ii + 1 < kSteps3) nl2 = lds16(A3L + a3_addr(ii + 1));
+                    if (ii == 0) mfma16_pinned_first(c2, al, B3h[0]); else mfma16_pinned(c2, al, B3h[ii]);
+                    ah = nh2; al = nl2;
+                }
+                asm volatile("s_nop 15\n\ts_nop 3" : "+a"(c0), "+a"(c1), "+a"(c2));       // XDL write -> VALU read distance
+#pragma unroll
+                for (int r = 0; r < 16; r++) c0[r] += c1[r] + c2[r];
+            } else {
+                // (the two-waves-per-SIMD experiment keeps the compiler-scheduled loop: with its 256-register budget the pinned form
+                //  above produced wrong features on the GPU — not understood, see profiles/NOTES.md section O)
+                f32x16 c1 = {0};
+#pragma unroll
+                for (int r = 0; r < 16; r++) c0[r] = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < kSteps3; ii++) {
+                    const int addr = a3_addr(ii);
+                    const half8 ah = lds16(A3H + addr), al = lds16(A3L + addr);
+                    c0 = mfma16(ah, B3h[ii], c0);
+                    c1 = mfma16(ah, B3l[ii], c1);
+                    c1 = mfma16(al, B3h[ii], c1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) c0[r] += c1[r];
+            }
             if (mh > 0) {                                                  // A2 is dead: its first KiBs carry the partial sums
                 float *pw = reinterpret_cast<float *>(enc_lds + PART) + ((mh - 1) * 2 + nh) * 8 * 64 + lane;
 #pragma unroll

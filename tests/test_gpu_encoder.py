@@ -3,6 +3,8 @@ network on the CPU — the reference the op restates (state_representation/model
 computes on the float16 matrix pipe with every operand split into hi + lo/2048 (22 significant bits per product,
 float32 accumulation), so it is held to 2e-5 relative to the largest state component; MIOpen's own float32
 forward differs from the CPU by about as much."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -145,3 +147,22 @@ def test_hip_encoder_rejects_what_it_does_not_cover():
     with pytest.raises(_lib.SrlHipError):
         gpu.hip.forward(0, 4, 0)                                           # null buffers
     assert gpu.getStates(np.zeros((0, 64, 64, 3), np.uint8)).shape == (0, 2)
+
+
+def test_two_waves_per_simd_variant_in_a_subprocess():
+    """SRLHIP_ENCODER_WAVES=8 selects the MG = 4 instantiation of encoder_fwd_k (an experiment knob read once per process): the same
+    parity bar, in a child process — a variant the library can be switched to must not go untested."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path[:0] = {!r}; import torch; "
+            "from state_representation.models import SRLNeuralNetwork; torch.manual_seed(0); "
+            "g = SRLNeuralNetwork(5, cuda=True, img_shape=(64, 64), backend='hip'); "
+            "c = SRLNeuralNetwork(5, cuda=False, img_shape=(64, 64), state_dict=g.model.state_dict(), backend='torch'); "
+            "x = np.random.RandomState(1).randint(0, 256, size=(300, 64, 64, 3)).astype(np.uint8); "
+            "a, b = g.getStates(x).cpu().numpy(), c.getStates(x).numpy(); "
+            "print('ERR', float(np.abs(a - b).max() / max(1.0, np.abs(b).max())), g.hip.overflow())").format(sys.path[:4])
+    env = dict(os.environ, SRLHIP_ENCODER_WAVES="8")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float(out.stdout.split("ERR")[1].split()[0])
+    assert err < TOL and "False" in out.stdout.split("ERR")[1]
