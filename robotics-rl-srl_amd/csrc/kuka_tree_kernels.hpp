@@ -91,7 +91,11 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 
 // T consecutive VecEnv steps per launch.  GIVEN: the caller supplies the actions (a compile-time switch: a possible action load
 // inside the step loop makes every step wait for the previous step's output stores — gfx9 counts loads and stores together).
-template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0>
+// SPEC = 1: the reference's DEFAULT KukaButtonGymEnv configuration (discrete actions, static button, ground-truth observation, force_down,
+// action_repeat 1, sparse reward, auto-reset: kuka_button_gym_env.py:93-98 ctor defaults) as compile-time constants — the run-time
+// configuration tests of the env logic and of the step's branches fold away (the host selects it only for a handle with exactly
+// this configuration, kuka_tree.hip: spec_config_of).
+template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0, int SPEC = 0>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
                     float *obs, float *rew, uint8_t *done_out, void *act_out) {
@@ -101,7 +105,13 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
     const bool valid = e_raw < p.n;
     const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the cross-lane ops)
-    const Cfg &cfg = p.cfg;
+    Cfg cfg_c = p.cfg;
+    if constexpr (SPEC == 1) {
+        cfg_c.is_discrete = 1; cfg_c.action_joints = 0; cfg_c.random_target = 0; cfg_c.force_down = 1; cfg_c.shape_reward = 0;
+        cfg_c.action_repeat = 1; cfg_c.obs_mode = 0; cfg_c.auto_reset = 1; cfg_c.moving = 0; cfg_c.two = 0; cfg_c.rand_objects = 0;
+        cfg_c.max_steps = kMaxSteps;
+    }
+    const Cfg &cfg = cfg_c;
     __shared__ double tab[tree::kLaneTableDoubles];
     double *scratch = scratch_all[threadIdx.x / GL];
     LaneId L;

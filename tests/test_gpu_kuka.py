@@ -673,3 +673,31 @@ def test_contact_sweep_instantiations_by_row_budget(budget):
         h.close()
     finally:
         kuka_clib.set_full(True)
+
+
+def test_configuration_specialised_instantiation_equals_the_generic_one(tmp_path):
+    """Round 5: a handle with the reference's default KukaButtonGymEnv configuration on Philox streams runs kuka_tree_rollout_k's SPEC = 1
+    instantiation (that configuration folded in as compile-time constants).  SRLHIP_KUKA_SPEC=0 (read once per process) keeps the
+    generic one: a child process produces the same rollout with it — reward / done / sampled actions bit for bit, observations and
+    final joints to 1e-9 (the two instantiations are scheduled differently, the arithmetic is the same)."""
+    import os
+    import subprocess
+    import sys
+    n, T = 512, 1100
+    path = str(tmp_path / "generic.npz")
+    code = ("import sys, numpy as np; sys.path[:0] = {!r}; import torch; from srlhip import _lib; "
+            "cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON); cfg.num_envs, cfg.rng_mode, cfg.auto_reset = {}, _lib.RNG_PHILOX, 1; "
+            "h = _lib.Handle(cfg); o0 = h.reset(); out = h.rollout({}); "
+            "np.savez({!r}, obs0=o0, q=h.get_state(_lib.F_KUKA_Q), **out)").format(sys.path[:4], n, T, path)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRLHIP_KUKA_SPEC="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    gen = np.load(path)
+    h = make(n, rng_mode=_lib.RNG_PHILOX)
+    obs0 = h.reset()
+    out = h.rollout(T)
+    assert np.array_equal(obs0, gen["obs0"])
+    for k in ("reward", "done", "actions"):
+        assert np.array_equal(out[k], gen[k]), k
+    assert np.abs(out["obs"] - gen["obs"]).max() <= 1e-6 and np.abs(h.get_state(_lib.F_KUKA_Q) - gen["q"]).max() <= 1e-9
+    assert out["done"].sum() >= n
+    h.close()
