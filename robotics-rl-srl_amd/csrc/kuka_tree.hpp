@@ -1079,7 +1079,9 @@ enum { SM_CC = 0, SM_NCAP = 3, SM_NBASE = 6, SM_DCAP = 9, SM_DBASE, SM_PENLO, SM
        SM_NCAP2 = SM_COUNT, SM_NBASE2 = SM_NCAP2 + 3, SM_DCAP2 = SM_NBASE2 + 3, SM_DBASE2, SM_COUNT2 };     // Kuka2Button: the second button's shapes
 static_assert(NJ * GL <= kNArows * GL && SM_COUNT2 * GL <= 2 * kNB * GL, "stash planes");
 struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; bool bodies_done; double dvo[3]; };   // + KukaRandButton: the own body's velocity change when its rows were swept here   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
-template <int NB = 1, int RB = 0, int OCC = 0>
+// DET >= 0: the table's solver_detail as a compile-time constant (the configuration-specialised rollout instantiation: the host checks
+// the installed table), -1: read from the lane table
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1>
 SRL_G GenOut general_path(const GenIn &in) {
     static_assert(!OCC || (NB == 1 && RB == 0), "the two-wavefronts-per-SIMD variant covers the one-button envs");
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
@@ -1094,7 +1096,7 @@ SRL_G GenOut general_path(const GenIn &in) {
     const double qd_new = in.qd_new, bound_bm = in.bound_bm, bqd = in.bqd;
     const bool is_button = L.l == kBM || L.l == kBLo || L.l == kBHi;
     // bank-B slot layout: normals / limits 0..ng-1, friction rows ng + g [, second friction direction 2 ng + g] — 6 + 6, or 4 + 4 + 4
-    const int detail = L.detail(), ng = L.ng(), nfd = (detail & kDetailFriction2) ? 2 : 1, nslots = (1 + nfd) * ng;
+    const int detail = DET >= 0 ? DET : L.detail(), ng = L.ng(), nfd = (detail & kDetailFriction2) ? 2 : 1, nslots = (1 + nfd) * ng;
     const double lerp = L.limit_erp(), cerp = L.contact_erp(), slop = L.linear_slop();
     auto used_slot = [&](int s_, int ngw) -> bool { return s_ < nslots && (s_ >= 2 * ng ? s_ - 2 * ng : s_ >= ng ? s_ - ng : s_) < ngw; };
     const double *wpark = OCC ? in.park + PK_W : sc + SC_STASH_W, *spark = OCC ? in.park + PK_S : sc + SC_S;
@@ -1415,7 +1417,7 @@ SRL_G GenOut general_path(const GenIn &in) {
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-template <int NB = 1, int RB = 0, int OCC = 0>
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1>
 SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
                          double finger_angle, RBody *rb = nullptr, double *park = nullptr) {
     const double dt = kDt, inv_dt = 1.0 / kDt;
@@ -1765,7 +1767,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     }
     double u, acc_b = 0.0, dvb_b = 0.0, u2 = 0.0, dvb_b2 = 0.0, dvo[3] = {0.0, 0.0, 0.0};
     bool bodies_done = false;
-    const int detail = L.detail();
+    const int detail = DET >= 0 ? DET : L.detail();
     SRL_TSTAMP(6);                          // row setup
     if (!any_generic) u = detail != 0 ? sweeps_free_detail<NB>(r, r2, detail, S_of, lo_of, &u2) : sweeps_free<NB>(r, &r2, &u2);
     else if constexpr (OCC) {
@@ -1782,7 +1784,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
                 GenIn in;
                 in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
                 in.r2 = r2; in.bqd2 = 0.0; in.rb = nullptr; in.park = park; in.g = &g; in.e = &e;
-                const GenOut out = general_path<NB, RB, OCC>(in);
+                const GenOut out = general_path<NB, RB, OCC, DET>(in);
                 u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
             }
         }
@@ -1790,7 +1792,7 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
         GenIn in;
         in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = bound_bm;
         in.r2 = r2; in.bqd2 = NB == 2 ? e.b2qd : 0.0; in.rb = rb; in.park = nullptr; in.g = &g; in.e = &e;
-        const GenOut out = general_path<NB, RB>(in);
+        const GenOut out = general_path<NB, RB, 0, DET>(in);
         u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b; u2 = out.u2; dvb_b2 = out.dvb_b2;
         if constexpr (RB) { bodies_done = out.bodies_done; dvo[0] = out.dvo[0]; dvo[1] = out.dvo[1]; dvo[2] = out.dvo[2]; }
     }
@@ -1922,7 +1924,7 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-template <int NB = 1, int RB = 0, int OCC = 0, class R>
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, class R>
 SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done,
                        RBody *rb = nullptr, double *park = nullptr) {
     if constexpr (RB) {
@@ -1941,7 +1943,7 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     SRL_TSTAMP(21);                         // noise draw + action mapping (step_command)
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step<NB, RB, OCC>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
+        tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

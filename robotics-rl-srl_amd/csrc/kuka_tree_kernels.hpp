@@ -92,7 +92,8 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 // T consecutive VecEnv steps per launch.  GIVEN: the caller supplies the actions (a compile-time switch: a possible action load
 // inside the step loop makes every step wait for the previous step's output stores — gfx9 counts loads and stores together).
 // SPEC = 1: the reference's DEFAULT KukaButtonGymEnv configuration (discrete actions, static button, ground-truth observation, force_down,
-// action_repeat 1, sparse reward, auto-reset: kuka_button_gym_env.py:93-98 ctor defaults) as compile-time constants — the run-time
+// action_repeat 1, sparse reward, auto-reset: kuka_button_gym_env.py:93-98 ctor defaults) AND the model table's default solver details
+// (solver_detail = 0) as compile-time constants — the run-time
 // configuration tests of the env logic and of the step's branches fold away (the host selects it only for a handle with exactly
 // this configuration, kuka_tree.hip: spec_config_of).
 template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0, int SPEC = 0>
@@ -168,7 +169,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #endif
         bool done;
         double reward;
-        reward = tree::tenv_step<NB, RB>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
+        reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
