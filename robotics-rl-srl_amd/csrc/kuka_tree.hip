@@ -97,16 +97,18 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     }
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
-    // the reference's default KukaButtonGymEnv configuration on Philox streams: the instantiation with that configuration folded in
+    // the reference's default KukaButtonGymEnv configuration on a device RNG mode: the instantiation with that configuration folded in
     // (kuka_tree_kernels.hpp, SPEC = 1); SRLHIP_KUKA_SPEC=0 keeps the generic instantiation (tests compare the two)
     const srlhip_config &c = h->cfg;
     static const bool spec_enabled = [] { const char *v = getenv("SRLHIP_KUKA_SPEC"); return !v || atoi(v) != 0; }();
-    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && c.rng_mode == SRLHIP_RNG_PHILOX && c.is_discrete && !c.random_target &&
+    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.random_target &&
                       c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset &&
                       (c.obs_mode == SRLHIP_OBS_GROUND_TRUTH || (c.obs_mode == SRLHIP_OBS_RAW_PIXELS && !obs));      // raw_pixels: the rasteriser draws, the stepper writes no observation
     if (spec) {
-        if (d_actions) hipLaunchKernelGGL((kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
-        else hipLaunchKernelGGL((kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, false, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
+#define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+        if (c.rng_mode == SRLHIP_RNG_PHILOX) { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, true); else SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, false); }
+        else { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_MT19937, true); else SRL_TREE_SPEC(SRLHIP_RNG_MT19937, false); }     // (the reference's own streams: HipVecEnv's default)
+#undef SRL_TREE_SPEC
         SRL_HIP_CHECK(h, hipGetLastError());
         return 0;
     }
