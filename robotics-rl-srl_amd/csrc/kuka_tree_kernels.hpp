@@ -143,12 +143,23 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     // `s_waitcnt vmcnt(0)` — and gfx9 counts stores on the same counter, so from the second step on that wait drains the previous
     // step's output stores: a full store round trip (~1.5 k cycles) in every step of the rollout.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    // Per-lane RUNNING plane pointers in VGPRs, advanced by one [n]-row per step: with the base pointers left in the kernel arguments
+    // the compiler, short of SGPRs, re-read them from the kernarg segment at every store site (s_load + s_waitcnt lgkmcnt(0): four
+    // scalar-cache round trips per step) and rebuilt each address with 64-bit multiplies.
+    float *obs_p = obs ? obs + (int64_t)e * od : nullptr, *rew_p = rew ? rew + e : nullptr;
+    uint8_t *done_p = done_out ? done_out + e : nullptr;
+    char *act_p = act_out ? static_cast<char *>(act_out) + (int64_t)e * adim * 4 : nullptr;
+    const char *given_p = GIVEN ? static_cast<const char *>(actions) + (int64_t)e * adim * 4 : nullptr;
+    const int64_t act_stride = n * adim * 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(obs_p), "+v"(rew_p), "+v"(done_p), "+v"(act_p), "+v"(given_p));
+#endif
     for (int t = 0; t < T; t++) {
-        const int64_t row = (int64_t)t * n + e;
         int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
         if constexpr (GIVEN) {
-            if (cfg.is_discrete) a = static_cast<const int32_t *>(actions)[row];
-            else for (int j = 0; j < adim; j++) ca[j] = static_cast<const float *>(actions)[row * adim + j];
+            if (cfg.is_discrete) a = *reinterpret_cast<const int32_t *>(given_p);
+            else for (int j = 0; j < adim; j++) ca[j] = reinterpret_cast<const float *>(given_p)[j];
+            given_p += act_stride;
         } else {
             if (cfg.is_discrete) a = gact.next(5);
             else for (int j = 0; j < adim; j += 2) {
@@ -156,10 +167,11 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
                 ca[j] = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
                 if (j + 1 < adim) ca[j + 1] = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
             }
-            if (act_out && lead) {
-                if (cfg.is_discrete) static_cast<int32_t *>(act_out)[row] = a;
-                else for (int j = 0; j < adim; j++) static_cast<float *>(act_out)[row * adim + j] = ca[j];
+            if (act_p && lead) {
+                if (cfg.is_discrete) *reinterpret_cast<int32_t *>(act_p) = a;
+                else for (int j = 0; j < adim; j++) reinterpret_cast<float *>(act_p)[j] = ca[j];
             }
+            if (act_p) act_p += act_stride;
         }
         float ca_own = 0.f;
 #pragma unroll
@@ -182,10 +194,13 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             }
         }
         if (lead) {
-            if (obs) observe(v, cfg, obs + row * od, 1);
-            if (rew) rew[row] = (float)reward;
-            if (done_out) done_out[row] = (uint8_t)done;
+            if (obs_p) observe(v, cfg, obs_p, 1);
+            if (rew_p) *rew_p = (float)reward;
+            if (done_p) *done_p = (uint8_t)done;
         }
+        if (obs_p) obs_p += n * od;
+        if (rew_p) rew_p += n;
+        if (done_p) done_p += n;
 #if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
         { using namespace tree; SRL_TSTAMP(11); }     // episode statistics, auto-reset, observation + output stores
 #endif
