@@ -81,6 +81,13 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out) {
     if (h->cfg.env_kind == SRLHIP_ENV_KUKA_RAND) return kuka_tree_rb_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);   // free bodies: kuka_tree_rb.hip
+    // the reference's default KukaButtonGymEnv configuration on a device RNG mode: the instantiation with that configuration folded in
+    // (kuka_tree_kernels.hpp, SPEC = 1); SRLHIP_KUKA_SPEC=0 keeps the generic instantiation (tests compare the two)
+    const srlhip_config &c = h->cfg;
+    static const bool spec_enabled = [] { const char *v = getenv("SRLHIP_KUKA_SPEC"); return !v || atoi(v) != 0; }();
+    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.random_target &&
+                      c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset &&
+                      (c.obs_mode == SRLHIP_OBS_GROUND_TRUTH || (c.obs_mode == SRLHIP_OBS_RAW_PIXELS && !obs));      // raw_pixels: the rasteriser draws, the stepper writes no observation
     {
         // Very large batches run the two-wavefronts-per-SIMD variant (kuka_tree_occ.hip: one-button envs, Cartesian actions).
         // Measured after the contact-sweep work (profiles/r04_occ_nsweep_final.jsonl, one -> two wavefronts, env-steps/s x 1e8):
@@ -92,18 +99,14 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
         const char *force = getenv("SRLHIP_KUKA_OCC");
         const bool one_button = h->cfg.env_kind == SRLHIP_ENV_KUKA_BUTTON || h->cfg.env_kind == SRLHIP_ENV_KUKA_MOVING;
         const bool cartesian = h->cfg.is_discrete || !h->cfg.action_joints;
-        const bool occ = force ? force[0] == '1' : h->n >= 65536;
+        // (round 5: where the configuration-specialised one-wavefront instantiation applies it is the faster one at every size measured
+        //  — 65536 envs 1.73e8 against 1.66e8, 131072 1.74e8 against 1.72e8, profiles/r05_nsweep_kuka.jsonl — so the default dispatch takes
+        //  the two-wavefront variant only for configurations that instantiation does not cover)
+        const bool occ = force ? force[0] == '1' : (h->n >= 65536 && !spec);
         if (occ && one_button && cartesian) return kuka_tree_occ_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
     }
     dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
-    // the reference's default KukaButtonGymEnv configuration on a device RNG mode: the instantiation with that configuration folded in
-    // (kuka_tree_kernels.hpp, SPEC = 1); SRLHIP_KUKA_SPEC=0 keeps the generic instantiation (tests compare the two)
-    const srlhip_config &c = h->cfg;
-    static const bool spec_enabled = [] { const char *v = getenv("SRLHIP_KUKA_SPEC"); return !v || atoi(v) != 0; }();
-    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.random_target &&
-                      c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset &&
-                      (c.obs_mode == SRLHIP_OBS_GROUND_TRUTH || (c.obs_mode == SRLHIP_OBS_RAW_PIXELS && !obs));      // raw_pixels: the rasteriser draws, the stepper writes no observation
     if (spec) {
 #define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
         if (c.rng_mode == SRLHIP_RNG_PHILOX) { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, true); else SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, false); }
