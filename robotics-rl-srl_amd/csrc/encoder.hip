@@ -429,7 +429,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                     const int sn = 12 * ky + i + kB2Ahead;
                     const half8 *pn = reinterpret_cast<const half8 *>(bp + (size_t)(sn < kS2 ? sn : kS2 - 1) * 64 * 32);
                     const half8 bh = Rh[slot], bl = Rl[slot];
-#if ENC_X == 1            // experiment: no LDS reads in the loop
+#if ENC_X == 1 || ENC_X == 3            // experiment: no LDS reads in the loop
 #pragma unroll
                     for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], ah[t], bh); nh_[t] = ah[t]; }
 #pragma unroll
@@ -440,12 +440,12 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll
                     for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], al[t], bh); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
 #endif
-#if ENC_X != 2            // experiment 2: no B streaming
+#if ENC_X != 2 && ENC_X != 3            // experiment 2: no B streaming (3: neither LDS reads nor B streaming)
                     Rh[slot] = pn[0];                                      // (the last requests of a frame re-read fragment 35: harmless)
 #endif
 #pragma unroll
                     for (int t = 0; t < kTiles2; t++) mfma16_pinned(acc[t], ah[t], bl);
-#if ENC_X != 2
+#if ENC_X != 2 && ENC_X != 3
                     Rl[slot] = pn[1];
 #endif
 #pragma unroll
