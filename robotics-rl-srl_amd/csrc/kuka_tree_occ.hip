@@ -45,8 +45,12 @@ kuka_tree_rollout_occ_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st,
     tree::RBody body = {};
     if constexpr (RB) tload_body(s, n, e, L.l, body);
     tree::tfk(tree::lane_view(tab), g);
-    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
-    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    // (Monitor's record of the last finished episode is written only when an episode finishes in this launch and is not read: on
+    //  host-pointer handles those two planes are mapped host memory — srlhip_episode_records — and a read / an unconditional
+    //  write-back would cross PCIe in every launch)
+    double ep_ret = st.ep_return[e], last_ret = 0.0, last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = 0, n_fin = st.n_finished[e];
+    const int32_t n_fin0 = n_fin;
     GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
     Philox &act = gact.p;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
@@ -105,7 +109,8 @@ kuka_tree_rollout_occ_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st,
         else if constexpr (MODE == SRLHIP_RNG_MT19937) rng0.store(rs.mt, e_out);
         else krng_store<MODE>(rng0, rs, e_out);
         if constexpr (!GIVEN) rs.act_ctr[e_out] = act.ctr;
-        st.ep_return[e_out] = ep_ret; st.ep_length[e_out] = ep_len; st.last_return[e_out] = last_ret; st.last_length[e_out] = last_len;
+        st.ep_return[e_out] = ep_ret; st.ep_length[e_out] = ep_len;
+        if (n_fin != n_fin0) { st.last_return[e_out] = last_ret; st.last_length[e_out] = last_len; }
         st.n_finished[e_out] = n_fin; st.last_reward[e_out] = last_reward;
     }
 }
