@@ -177,7 +177,8 @@ class HipVecEnv(object):
                 # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
                 raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(self._h.num_actions))
         else:
-            if any(a is None for a in actions):
+            # (a numeric ndarray cannot hold None: the per-element scan below would cost a 4096-iteration Python loop per step)
+            if not (isinstance(actions, np.ndarray) and actions.dtype != object) and any(a is None for a in actions):
                 raise NotImplementedError("None actions need a discrete action space")
             self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._h.action_dim)
             if f is not None:
