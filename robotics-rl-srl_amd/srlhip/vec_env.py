@@ -130,6 +130,11 @@ class HipVecEnv(object):
             for path in self._monitors:
                 with open(path, "wt") as f:
                     f.write(header)
+            # buffered rows must not die with a process that never calls close() (rl_baselines.train leaves that to interpreter exit)
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref()._monitors is not None and ref()._mon_rows and ref()._flush_monitors())
 
     # -- VecEnv API ----------------------------------------------------------------
     def _encode(self):
