@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Parity soak of the headline configuration: HIP stepper (through the C-ABI) vs the oracle over several seed bases at the BASELINE
+size, every plane of every step compared — a larger sample behind "reward / done bit for bit, joints 1e-11" than the test suite's
+4.1e6 env-steps (tests/test_gpu_kuka.py::test_fused_rollout_4096_envs, whose construction this follows).
+Runs on the GPU box (the oracle leg uses the host's cores: ~2 minutes per base):
+    python profiles/probes/parity_soak.py [bases=3] [n=4096] [T=1001] > gpurun_out/r05_parity_soak.json
+Per base b: seeds 100000 b + (0..n-1) (numpy MT19937 streams, the reference's seeding), actions uniform over the 6 discrete actions
+with 25 % extra 'down' (episodes end by contact well before 1001 steps: every env crosses >= 1 auto-reset), one fused launch.
+Reported: mismatching reward / done entries, max |obs - obs_oracle| (float32 planes), max |q - q_oracle| of the final state, the
+smallest |value - threshold| behind any contact / distance flag (oracle margin probe), episodes finished.
+TEST INFRASTRUCTURE (drives the oracle next to the product)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (os.path.join(REPO, "robotics-rl-srl_amd"), REPO):
+    sys.path.insert(0, p)
+import torch  # noqa: F401,E402  (before libsrlhip.so: __graft_entry__.build())
+from oracle import kuka_clib  # noqa: E402
+from srlhip import _lib  # noqa: E402
+
+bases = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 1001
+kuka_clib.set_full(True)
+res = {"n": n, "T": T, "bases": [], "env_steps": 0, "reward_mismatches": 0, "done_mismatches": 0}
+for b in range(1, bases + 1):
+    seed0 = 100000 * b
+    rs = np.random.RandomState(1000 + b)
+    actions = rs.randint(6, size=(T, n)).astype(np.int32)
+    actions[rs.rand(T, n) < 0.25] = 4
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0 = n, _lib.RNG_MT19937, 1, seed0
+    h = _lib.Handle(cfg)
+    obs0 = h.reset()
+    out = h.rollout(T, actions=actions)
+    kuka_clib.margins_reset()
+    t0 = time.time()
+    ora = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions, trace=False)
+    t_ora = time.time() - t0
+    m = kuka_clib.margins()
+    f = ora["final_state"]
+    ret, length, fin = h.episode_stats()
+    st = {"seed0": seed0,
+          "reward_mismatches": int((ora["reward"] != out["reward"]).sum()), "done_mismatches": int((ora["done"] != out["done"]).sum()),
+          "max_obs_diff": float(max(np.abs(ora["obs"] - out["obs"]).max(), np.abs(ora["obs0"] - obs0).max())),
+          "max_final_q_diff": float(np.abs(h.get_state(_lib.F_KUKA_Q).T - f[:, 0:7]).max()),
+          "episode_counts_equal": bool(np.array_equal(fin, ora["ep_stats"][:, 2].astype(np.int32)) and np.array_equal(length, ora["ep_stats"][:, 1].astype(np.int32))),
+          "episodes_finished": int(fin.sum()), "min_episodes_per_env": int(fin.min()),
+          "ik_flagged_env_steps": int((h.get_state(_lib.F_KUKA_IK_CROSSED) >> 1).sum()),
+          "flag_margins": {k: float(v) for k, v in m.items()}, "oracle_seconds": round(t_ora, 1)}
+    h.close()
+    res["bases"].append(st)
+    res["env_steps"] += n * T
+    res["reward_mismatches"] += st["reward_mismatches"]
+    res["done_mismatches"] += st["done_mismatches"]
+    print(json.dumps(st), file=sys.stderr, flush=True)
+res["max_obs_diff"] = max(s["max_obs_diff"] for s in res["bases"])
+res["max_final_q_diff"] = max(s["max_final_q_diff"] for s in res["bases"])
+res["min_flag_margin"] = min(min(s["flag_margins"].values()) for s in res["bases"])
+json.dump(res, sys.stdout, indent=1)
+print()
