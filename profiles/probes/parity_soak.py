@@ -3,7 +3,9 @@
 size, every plane of every step compared — a larger sample behind "reward / done bit for bit, joints 1e-11" than the test suite's
 4.1e6 env-steps (tests/test_gpu_kuka.py::test_fused_rollout_4096_envs, whose construction this follows).
 Runs on the GPU box (the oracle leg uses the host's cores: ~2 minutes per base):
-    python profiles/probes/parity_soak.py [bases=3] [n=4096] [T=1001] > gpurun_out/r05_parity_soak.json
+    python profiles/probes/parity_soak.py [bases=3] [n=4096] [T=1001] [mode=given] > gpurun_out/r05_parity_soak.json
+    python profiles/probes/parity_soak.py 4 4096 2048 philox > gpurun_out/r05_parity_soak_philox.json
+mode philox = the launch bench.py times: Philox env streams, actions sampled on the device by the synthetic agent (compared too).
 Per base b: seeds 100000 b + (0..n-1) (numpy MT19937 streams, the reference's seeding), actions uniform over the 6 discrete actions
 with 25 % extra 'down' (episodes end by contact well before 1001 steps: every env crosses >= 1 auto-reset), one fused launch.
 Reported: mismatching reward / done entries, max |obs - obs_oracle| (float32 planes), max |q - q_oracle| of the final state, the
@@ -26,26 +28,30 @@ from srlhip import _lib  # noqa: E402
 bases = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 1001
+philox = len(sys.argv) > 4 and sys.argv[4] == "philox"
 kuka_clib.set_full(True)
-res = {"n": n, "T": T, "bases": [], "env_steps": 0, "reward_mismatches": 0, "done_mismatches": 0}
+res = {"n": n, "T": T, "mode": "philox streams, device-sampled actions" if philox else "MT19937 streams, given actions", "bases": [], "env_steps": 0, "reward_mismatches": 0, "done_mismatches": 0}
 for b in range(1, bases + 1):
     seed0 = 100000 * b
     rs = np.random.RandomState(1000 + b)
     actions = rs.randint(6, size=(T, n)).astype(np.int32)
     actions[rs.rand(T, n) < 0.25] = 4
     cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
-    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0 = n, _lib.RNG_MT19937, 1, seed0
+    cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0 = n, _lib.RNG_PHILOX if philox else _lib.RNG_MT19937, 1, seed0
     h = _lib.Handle(cfg)
     obs0 = h.reset()
-    out = h.rollout(T, actions=actions)
+    out = h.rollout(T) if philox else h.rollout(T, actions=actions)
     kuka_clib.margins_reset()
     t0 = time.time()
-    ora = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions, trace=False)
+    if philox:
+        ora = kuka_clib.rollout(seed0 + np.arange(n), T, actions=None, rng_mode=kuka_clib.RNG_PHILOX, trace=False)
+    else:
+        ora = kuka_clib.rollout(seed0 + np.arange(n), T, actions=actions, trace=False)
     t_ora = time.time() - t0
     m = kuka_clib.margins()
     f = ora["final_state"]
     ret, length, fin = h.episode_stats()
-    st = {"seed0": seed0,
+    st = {"seed0": seed0, "action_mismatches": int((ora["actions"] != out["actions"]).sum()) if philox else 0,
           "reward_mismatches": int((ora["reward"] != out["reward"]).sum()), "done_mismatches": int((ora["done"] != out["done"]).sum()),
           "max_obs_diff": float(max(np.abs(ora["obs"] - out["obs"]).max(), np.abs(ora["obs0"] - obs0).max())),
           "max_final_q_diff": float(np.abs(h.get_state(_lib.F_KUKA_Q).T - f[:, 0:7]).max()),
