@@ -1,0 +1,42 @@
+"""The hand-pinned MFMAs of csrc/encoder.hip are invisible to the compiler's hazard recogniser (they are `asm volatile` statements):
+the distance between such an MFMA and the first non-MFMA access to its accumulator is kept by the SOURCE (mfma_fence,
+mfma_results_ready).  This test checks the BUILT code object instead of trusting that: profiles/probes/mfma_asm_hazard_lint.py walks
+the gfx950 ISA of every encoder kernel (straight line + every loop back-edge) and reports any access closer than the compiler's own
+minimum.  No GPU needed; the object is the one __graft_entry__.build() / make leaves in csrc/build."""
+import importlib.util
+import os
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(REPO, "robotics-rl-srl_amd", "csrc", "build", "encoder.hip.o")
+
+
+def _lint():
+    spec = importlib.util.spec_from_file_location("mfma_asm_hazard_lint", os.path.join(REPO, "profiles", "probes", "mfma_asm_hazard_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_lint_sees_a_planted_hazard_and_accepts_the_fenced_form():
+    L = _lint()
+    mf = "\tv_mfma_f32_32x32x16_f16 a[0:15], v[4:7], v[8:11], a[0:15] // 000000001000: D3D58000 04020108"
+    rd = "\tv_accvgpr_read_b32 v0, a3 // 000000001010: D3D84000 18000103"
+    other = "\tv_mfma_f32_32x32x16_f16 a[16:31], v[4:7], v[8:11], a[16:31] // 000000001008: D3D58010 04420108"
+    nop = "\ts_nop 15 // 00000000100C: BF80000F"
+    for seq, bad in (([mf, rd], True), ([mf, other, other, rd], True), ([mf, nop, rd], False), ([mf] + [other] * 12 + [rd], False),
+                     ([mf, "\tv_accvgpr_read_b32 v0, a16 // 000000001010: D3D84000 18000110"], False)):
+        found = set()
+        L.scan([L.Ins(x) for x in seq], "planted", found)
+        assert bool(found) == bad, (seq, found)
+
+
+def test_no_unfenced_access_to_a_pinned_mfma_result_in_the_built_encoder():
+    if not os.path.exists(OBJ):
+        pytest.skip("csrc/build/encoder.hip.o not built")
+    L = _lint()
+    found, stats = L.lint(OBJ)
+    product = [k for k in stats if "encoder_fwd_k<false, 2>" in k]
+    assert product and stats[product[0]]["mfma"] >= 400 and stats[product[0]]["back_edges"] >= 4, stats      # the lint looked at the real thing
+    assert not found, "\n".join(found)
