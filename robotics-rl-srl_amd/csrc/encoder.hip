@@ -536,8 +536,10 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) c0[r] += c1[r] + c2[r];
             } else {
-                // (the two-waves-per-SIMD experiment keeps the compiler-scheduled loop: with its 256-register budget the pinned form
-                //  above produced wrong features on the GPU — not understood, see profiles/NOTES.md section O)
+                // (the two-waves-per-SIMD experiment keeps TWO accumulator chains: in this 256-register instantiation a third chain in
+                //  layer 3 produces wrong features on the GPU — with builtin MFMAs as well as pinned ones, even when the third
+                //  accumulator's result is discarded, while two PINNED chains are right: not a hazard of the pinning, cause not
+                //  found; profiles/NOTES.md section O, profiles/probes/encoder_mg4_probe.py)
                 f32x16 c1 = {0};
 #pragma unroll
                 for (int r = 0; r < 16; r++) c0[r] = 0.f;
