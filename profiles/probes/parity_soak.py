@@ -6,6 +6,7 @@ Runs on the GPU box (the oracle leg uses the host's cores: ~2 minutes per base):
     python profiles/probes/parity_soak.py [bases=3] [n=4096] [T=1001] [mode=given] > gpurun_out/r05_parity_soak.json
     python profiles/probes/parity_soak.py 4 4096 2048 philox > gpurun_out/r05_parity_soak_philox.json
 mode philox = the launch bench.py times: Philox env streams, actions sampled on the device by the synthetic agent (compared too).
+mode continuous | joints = KukaButton with 3-D Cartesian / 7-D joint-space Box actions (uniform in [-1, 1]).
 mode moving | two | rand = the env variants at the BASELINE size (KukaMovingButton with shape_reward, Kuka2Button, KukaRandButton with
 random_target; MT19937 streams, given actions): the test suite compares them at 128 envs.
 Per base b: seeds 100000 b + (0..n-1) (numpy MT19937 streams, the reference's seeding), actions uniform over the 6 discrete actions
@@ -33,7 +34,7 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 1001
 mode = sys.argv[4] if len(sys.argv) > 4 else "given"
 philox = mode == "philox"
 KIND = {"moving": _lib.ENV_KUKA_MOVING, "two": _lib.ENV_KUKA_2BUTTON, "rand": _lib.ENV_KUKA_RAND}.get(mode, _lib.ENV_KUKA_BUTTON)
-ORA_KW = {"moving": dict(shape_reward=True), "two": dict(force_down=False, max_distance=2.0), "rand": dict(random_target=True)}.get(mode, {})
+ORA_KW = {"continuous": dict(is_discrete=False), "joints": dict(is_discrete=False, action_joints=True), "moving": dict(shape_reward=True), "two": dict(force_down=False, max_distance=2.0), "rand": dict(random_target=True)}.get(mode, {})
 kuka_clib.set_full(True)
 res = {"n": n, "T": T, "mode": "philox streams, device-sampled actions" if philox else "MT19937 streams, given actions" + ("" if mode == "given" else ", env variant " + mode), "bases": [], "env_steps": 0, "reward_mismatches": 0, "done_mismatches": 0}
 for b in range(1, bases + 1):
@@ -45,6 +46,9 @@ for b in range(1, bases + 1):
     cfg.num_envs, cfg.rng_mode, cfg.auto_reset, cfg.seed0 = n, _lib.RNG_PHILOX if philox else _lib.RNG_MT19937, 1, seed0
     if mode == "moving":
         cfg.shape_reward = 1
+    if mode in ("continuous", "joints"):
+        cfg.is_discrete, cfg.action_joints = 0, int(mode == "joints")
+        actions = rs.uniform(-1, 1, size=(T, n, 7 if mode == "joints" else 3)).astype(np.float32)
     if mode == "rand":
         cfg.random_target = 1
     h = _lib.Handle(cfg)
