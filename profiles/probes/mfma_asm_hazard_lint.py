@@ -14,6 +14,13 @@ accumulator between two pinned MFMAs would silently break it.  This lint checks 
 along the straight-line order of every kernel and, for every backward branch, along the path loop end -> loop head.
 MFMA -> MFMA on the same accumulator is interlocked by the hardware and is not checked.
 
+Rule B (the other direction): no VALU instruction may write a register that an MFMA reads (SrcA / SrcB / SrcC) within the
+REQUIRED_RAW wait states before that MFMA.  Found on the GPU: in the 256-register two-waves-per-SIMD instantiation the compiler
+reloads spilled B fragments with v_accvgpr_read right in front of the pinned MFMA that consumes them; with the reload as the
+instruction directly before the MFMA the features were wrong (deterministically), one instruction earlier they were right, and
+`-mllvm -amdgpu-snop-padding=1` cured every failing variant (profiles/NOTES.md section O).  For a builtin MFMA the compiler keeps
+>= 4 (encoder_general.hip.o); the pinned MFMAs of that instantiation therefore carry `s_nop 1` inside their statement.
+
     python profiles/probes/mfma_asm_hazard_lint.py [object=robotics-rl-srl_amd/csrc/build/encoder.hip.o] [kernel-regex=.]
 exit status 1 and one line per violation if any; used by tests/test_encoder_isa_lint.py."""
 import os
@@ -28,6 +35,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # instructions / nop cycles between itself and the MFMA — the lint reports nothing at 12 and the compiler's own code at 13.  The
 # hand-pinned streams keep >= 17.
 REQUIRED = 12
+REQUIRED_RAW = 2       # rule B: VALU write of an operand register -> MFMA (0 fails on the GPU, 1 was observed to work)
 WINDOW = 64            # instructions followed past a back-edge
 
 _reg = re.compile(r"\b([av])(?:\[(\d+):(\d+)\]|(\d+)\b)")
@@ -55,7 +63,7 @@ def regs_of(text):
 
 
 class Ins:
-    __slots__ = ("addr", "mnem", "ops", "is_mfma", "dst", "regs", "ws", "target")
+    __slots__ = ("addr", "mnem", "ops", "is_mfma", "dst", "regs", "ws", "target", "wdst")
 
     def __init__(self, line):
         body, _, tail = line.partition("//")
@@ -67,6 +75,7 @@ class Ins:
         self.is_mfma = self.mnem.startswith("v_mfma") or self.mnem.startswith("v_smfmac")
         self.regs = regs_of(self.ops)
         self.dst = regs_of(self.ops.split(",")[0]) if self.is_mfma else set()
+        self.wdst = regs_of(self.ops.split(",")[0]) if (self.mnem.startswith("v_") and not self.is_mfma) else set()
         self.ws = int(self.ops.strip()) + 1 if self.mnem == "s_nop" else 1
         self.target = None
         if self.mnem.startswith("s_cbranch") or self.mnem == "s_branch":
@@ -95,7 +104,19 @@ def kernels(asm):
 
 def scan(seq, where, found):
     pending = {}                              # register -> (wait states since the MFMA that wrote it, that MFMA)
+    recent = []                               # rule B: (VALU instruction, wait states issued since it) of the last few wait states
     for ins in seq:
+        if ins.is_mfma:
+            ops = [o.strip() for o in ins.ops.split(",")]
+            srcs = set().union(*[regs_of(o) for o in ops[1:4]])
+            for pv, ws in recent:
+                if ws < REQUIRED_RAW and pv.wdst & srcs:
+                    r = sorted(pv.wdst & srcs)[0]
+                    found.add("%s: %s %s at 0x%x writes %s%d only %d wait states before %s at 0x%x reads it" % (
+                        where, pv.mnem, pv.ops.strip(), pv.addr, r[0], r[1], ws, ins.mnem, ins.addr))
+        recent = [(pv, ws + ins.ws) for pv, ws in recent if ws + ins.ws < REQUIRED_RAW]
+        if not ins.is_mfma and ins.mnem.startswith("v_"):
+            recent.append((ins, 0))
         if not ins.is_mfma:
             for r in ins.regs:
                 if r in pending and pending[r][0] < REQUIRED:

@@ -27,7 +27,7 @@
 //   * B fragments come from L2 (352 KiB, shared by every CU): layer 1's (112 VGPRs per wave) are requested before
 //     the frame is unpacked and stay in registers for the layer, layer 2's are streamed through a 6-deep register
 //     ring, layer 3's arrive in one burst behind layer 2's k-loop; the next frame's bytes are fetched during layer 2.
-//     Two waves per SIMD (MG = 4, SRLHIP_ENCODER_WAVES=8) is kept as a measured alternative: 0.55 ms against 0.43 ms
+//     Two waves per SIMD (MG = 4, SRLHIP_ENCODER_WAVES=8) is kept as a measured alternative: 0.55 ms (0.64 with its MFMAs padded, see mfma16_pinned) against 0.43 ms
 //     per 4096 frames — each wave then streams its own B copies, 256 registers per lane spill the hoisted
 //     addresses, and the groups wait for each other at the barriers.  Weights resident across frames starve the
 //     layer-2 loop of registers (its ring becomes loop-carried copies behind `s_waitcnt vmcnt(0)`).
@@ -110,15 +110,21 @@ __device__ __forceinline__ half8 lds16(int off) { return *reinterpret_cast<const
 // the loads of a k-step in one burst between two MFMA groups (only ~5 single-issue instructions hide behind one 32-cycle MFMA with
 // one wave per SIMD, MI355X_MICROARCH.md) and re-groups MFMAs into dependent runs on one accumulator.  The accumulator of a chain
 // must be READ by compiler-visible code only after mfma_fence(): the hazard recogniser does not see the MFMA inside the statement.
-__device__ __forceinline__ void mfma16_pinned(f32x16 &c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+// PAD = true puts two wait states in front of the MFMA, INSIDE the statement: the other hazard the compiler cannot see is a VALU write
+// of an operand register directly before the statement (it reloads spilled fragments with v_accvgpr_read in the 256-register
+// two-waves-per-SIMD instantiation; a reload issued right before its MFMA produced wrong features on the GPU, one instruction
+// earlier it does not — profiles/NOTES.md section O).  The 512-register product has no such reloads (ISA lint, rule B) and runs unpadded.
+template <bool PAD = false> __device__ __forceinline__ void mfma16_pinned(f32x16 &c, half8 a, half8 b) {
+    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // wait states between the last pinned MFMA of a phase and the first VALU / v_accvgpr_read of its result (8-pass XDL write -> VALU
 // read needs 11 on gfx950; 20 issued)
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3"); }
 // first MFMA of a chain: C = 0 as the inline constant (no 16 v_accvgpr_write per accumulator)
-__device__ __forceinline__ void mfma16_pinned_first(f32x16 &c, half8 a, half8 b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+template <bool PAD = false> __device__ __forceinline__ void mfma16_pinned_first(f32x16 &c, half8 a, half8 b) {
+    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 // "the results of these chains may be read from here on": an empty pinned statement that redefines the accumulators, placed (in source
 // order = issue order) at least four pinned MFMAs (128 cycles) behind the last MFMA that wrote them — the compiler schedules every
@@ -136,7 +142,7 @@ __device__ __forceinline__ void store_split(int hbase, int lbase, int off, float
 
 // two conv-1 output rows (32 pixels x this wave's 32 channels each): raw accumulators (pre-scaled weights).  Pinned MFMAs in issue
 // order, the two accumulators alternating, the next k-step's fragments between them (see mfma16_pinned).
-__device__ __forceinline__ void conv1_pair(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int rb, int lane_base,
+template <bool PAD> __device__ __forceinline__ void conv1_pair(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int rb, int lane_base,
                                            f32x16 &v0, f32x16 &v1) {
     const int base0 = 2 * ra * IN_PITCH + lane_base, base1 = 2 * rb * IN_PITCH + lane_base;
     half8 x0 = lds16(base0), x1 = lds16(base1);
@@ -144,26 +150,26 @@ __device__ __forceinline__ void conv1_pair(const half8 (&Bh)[kS1], const half8 (
     for (int s = 0; s < kS1; s++) {
         const int offn = ((s + 1) >> 1) * IN_PITCH + ((s + 1) & 1) * 32;       // kernel row (s+1)/2, pixel slots 4((s+1)&1)+2h, +1
         half8 y0 = x0, y1 = x1;
-        if (s == 0) mfma16_pinned_first(v0, x0, Bh[0]); else mfma16_pinned(v0, x0, Bh[s]);
+        if (s == 0) mfma16_pinned_first<PAD>(v0, x0, Bh[0]); else mfma16_pinned<PAD>(v0, x0, Bh[s]);
         if (s + 1 < kS1) y0 = lds16(base0 + offn);
-        if (s == 0) mfma16_pinned_first(v1, x1, Bh[0]); else mfma16_pinned(v1, x1, Bh[s]);
+        if (s == 0) mfma16_pinned_first<PAD>(v1, x1, Bh[0]); else mfma16_pinned<PAD>(v1, x1, Bh[s]);
         if (s + 1 < kS1) y1 = lds16(base1 + offn);
-        mfma16_pinned(v0, x0, Bl[s]);
-        mfma16_pinned(v1, x1, Bl[s]);
+        mfma16_pinned<PAD>(v0, x0, Bl[s]);
+        mfma16_pinned<PAD>(v1, x1, Bl[s]);
         x0 = y0; x1 = y1;
     }
 }
 // one conv-1 output row: two chains (hi / lo weights), summed by the caller's reader
-__device__ __forceinline__ void conv1_single(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int lane_base, f32x16 &v0) {
+template <bool PAD> __device__ __forceinline__ void conv1_single(const half8 (&Bh)[kS1], const half8 (&Bl)[kS1], int ra, int lane_base, f32x16 &v0) {
     f32x16 a0, a1;
     const int base0 = 2 * ra * IN_PITCH + lane_base;
     half8 x0 = lds16(base0);
 #pragma unroll
     for (int s = 0; s < kS1; s++) {
         half8 y0 = x0;
-        if (s == 0) mfma16_pinned_first(a0, x0, Bh[0]); else mfma16_pinned(a0, x0, Bh[s]);
+        if (s == 0) mfma16_pinned_first<PAD>(a0, x0, Bh[0]); else mfma16_pinned<PAD>(a0, x0, Bh[s]);
         if (s + 1 < kS1) y0 = lds16(base0 + ((s + 1) >> 1) * IN_PITCH + ((s + 1) & 1) * 32);
-        if (s == 0) mfma16_pinned_first(a1, x0, Bl[0]); else mfma16_pinned(a1, x0, Bl[s]);
+        if (s == 0) mfma16_pinned_first<PAD>(a1, x0, Bl[0]); else mfma16_pinned<PAD>(a1, x0, Bl[s]);
         x0 = y0;
     }
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a0), "+a"(a1));              // XDL write -> VALU read distance (see mfma_fence)
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) carry[r] = kNegInf;           // conv row -1 is pool padding
             } else {
-                conv1_single(B1h, B1l, 2 * kRows1 * mh - 1, lane_base, carry);
+                conv1_single<MG != 2>(B1h, B1l, 2 * kRows1 * mh - 1, lane_base, carry);
             }
             // Software pipeline: the 56 MFMAs of pooled row p+1 and the pooling / split / store epilogue of row p are
             // independent instruction streams in one basic block, so the epilogue's VALU and LDS work issues in the
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                 }
             };
             if constexpr (MG == 2) {
-                conv1_pair(B1h, B1l, 2 * kRows1 * mh, 2 * kRows1 * mh + 1, lane_base, v0, v1);
+                conv1_pair<MG != 2>(B1h, B1l, 2 * kRows1 * mh, 2 * kRows1 * mh + 1, lane_base, v0, v1);
                 // Software pipeline, written out by hand (round 5): the 56 MFMAs of the NEXT two conv rows are pinned statements in
                 // issue order — the two accumulators alternate, so no MFMA waits for its predecessor — and between them, in source
                 // order, sit the next k-step's two A fragments and the sixteen LDS stores of the PREVIOUS pair's pooled row (its max /
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll 1
                 for (int p = 0; p < kRows1; p++) {
                     const int prow = kRows1 * mh + p;
-                    conv1_pair(B1h, B1l, 2 * prow, 2 * prow + 1, lane_base, v0, v1);
+                    conv1_pair<MG != 2>(B1h, B1l, 2 * prow, 2 * prow + 1, lane_base, v0, v1);
                     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(v0), "+a"(v1));      // pinned MFMAs: XDL write -> VALU read distance
                     epilogue(prow, carry, v0, v1);
                     carry = v1;
@@ -431,20 +437,20 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                     const half8 bh = Rh[slot], bl = Rl[slot];
 #if ENC_X == 1 || ENC_X == 3            // experiment: no LDS reads in the loop
 #pragma unroll
-                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], ah[t], bh); nh_[t] = ah[t]; }
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned<MG != 2>(acc[t], ah[t], bh); nh_[t] = ah[t]; }
 #pragma unroll
-                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], al[t], bh); nl_[t] = al[t]; }
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned<MG != 2>(acc[t], al[t], bh); nl_[t] = al[t]; }
 #else
 #pragma unroll
-                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], ah[t], bh); nh_[t] = lds16(A2H + addr[t] + qn * 32); }
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned<MG != 2>(acc[t], ah[t], bh); nh_[t] = lds16(A2H + addr[t] + qn * 32); }
 #pragma unroll
-                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned(acc[t], al[t], bh); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
+                    for (int t = 0; t < kTiles2; t++) { mfma16_pinned<MG != 2>(acc[t], al[t], bh); nl_[t] = lds16(A2L + addr[t] + qn * 32); }
 #endif
 #if ENC_X != 2 && ENC_X != 3            // experiment 2: no B streaming (3: neither LDS reads nor B streaming)
                     Rh[slot] = pn[0];                                      // (the last requests of a frame re-read fragment 35: harmless)
 #endif
 #pragma unroll
-                    for (int t = 0; t < kTiles2; t++) mfma16_pinned(acc[t], ah[t], bl);
+                    for (int t = 0; t < kTiles2; t++) mfma16_pinned<MG != 2>(acc[t], ah[t], bl);
 #if ENC_X != 2 && ENC_X != 3
                     Rl[slot] = pn[1];
 #endif
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                 const bool ok = pix && (unsigned)sy < 7u && (unsigned)sx < 7u;
                 return (ok ? sy * 7 + sx : 49) * PX + h * 16 + q * 32;
             };
-            if constexpr (MG == 2) {
+            {
                 // three chains (hi*hi, hi*lo, lo*hi), pinned in issue order so that no MFMA waits for its predecessor; the next k-step's
                 // two A fragments are requested between them (the compiler's schedule read them right before their use and chained the
                 // two MFMAs of one accumulator back to back): 4.1 k -> 2.9 k cycles for the phase
@@ -525,34 +531,16 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
 #pragma unroll
                 for (int ii = 0; ii < kSteps3; ii++) {
                     half8 nh2 = ah, nl2 = al;
-                    if (ii == 0) mfma16_pinned_first(c0, ah, B3h[0]); else mfma16_pinned(c0, ah, B3h[ii]);
+                    if (ii == 0) mfma16_pinned_first<MG != 2>(c0, ah, B3h[0]); else mfma16_pinned<MG != 2>(c0, ah, B3h[ii]);
                     if (ii + 1 < kSteps3) nh2 = lds16(A3H + a3_addr(ii + 1));
-                    if (ii == 0) mfma16_pinned_first(c1, ah, B3l[0]); else mfma16_pinned(c1, ah, B3l[ii]);
+                    if (ii == 0) mfma16_pinned_first<MG != 2>(c1, ah, B3l[0]); else mfma16_pinned<MG != 2>(c1, ah, B3l[ii]);
                     if (ii + 1 < kSteps3) nl2 = lds16(A3L + a3_addr(ii + 1));
-                    if (ii == 0) mfma16_pinned_first(c2, al, B3h[0]); else mfma16_pinned(c2, al, B3h[ii]);
+                    if (ii == 0) mfma16_pinned_first<MG != 2>(c2, al, B3h[0]); else mfma16_pinned<MG != 2>(c2, al, B3h[ii]);
                     ah = nh2; al = nl2;
                 }
                 asm volatile("s_nop 15\n\ts_nop 3" : "+a"(c0), "+a"(c1), "+a"(c2));       // XDL write -> VALU read distance
 #pragma unroll
                 for (int r = 0; r < 16; r++) c0[r] += c1[r] + c2[r];
-            } else {
-                // (the two-waves-per-SIMD experiment keeps TWO accumulator chains: in this 256-register instantiation a third chain in
-                //  layer 3 produces wrong features on the GPU — with builtin MFMAs as well as pinned ones, even when the third
-                //  accumulator's result is discarded, while two PINNED chains are right: not a hazard of the pinning, cause not
-                //  found; profiles/NOTES.md section O, profiles/probes/encoder_mg4_probe.py)
-                f32x16 c1 = {0};
-#pragma unroll
-                for (int r = 0; r < 16; r++) c0[r] = 0.f;
-#pragma unroll
-                for (int ii = 0; ii < kSteps3; ii++) {
-                    const int addr = a3_addr(ii);
-                    const half8 ah = lds16(A3H + addr), al = lds16(A3L + addr);
-                    c0 = mfma16(ah, B3h[ii], c0);
-                    c1 = mfma16(ah, B3l[ii], c1);
-                    c1 = mfma16(al, B3h[ii], c1);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) c0[r] += c1[r];
             }
             if (mh > 0) {                                                  // A2 is dead: its first KiBs carry the partial sums
                 float *pw = reinterpret_cast<float *>(enc_lds + PART) + ((mh - 1) * 2 + nh) * 8 * 64 + lane;

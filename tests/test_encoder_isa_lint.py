@@ -2,7 +2,8 @@
 the distance between such an MFMA and the first non-MFMA access to its accumulator is kept by the SOURCE (mfma_fence,
 mfma_results_ready).  This test checks the BUILT code object instead of trusting that: profiles/probes/mfma_asm_hazard_lint.py walks
 the gfx950 ISA of every encoder kernel (straight line + every loop back-edge) and reports any access closer than the compiler's own
-minimum.  No GPU needed; the object is the one __graft_entry__.build() / make leaves in csrc/build."""
+minimum (rule A), and any VALU write of an MFMA's operand registers within two wait states before it (rule B: compiler-inserted
+reloads in front of a pinned MFMA, profiles/NOTES.md section O).  No GPU needed; the object is the one __graft_entry__.build() / make leaves in csrc/build."""
 import importlib.util
 import os
 
@@ -30,9 +31,18 @@ def test_the_lint_sees_a_planted_hazard_and_accepts_the_fenced_form():
         found = set()
         L.scan([L.Ins(x) for x in seq], "planted", found)
         assert bool(found) == bad, (seq, found)
+    # rule B: a VALU write of an MFMA operand directly (or one wait state) before the MFMA — what the register allocator's reloads did
+    # in the two-waves-per-SIMD instantiation (wrong features on the GPU until the pinned MFMAs were padded)
+    reload = "\tv_accvgpr_read_b32 v8, a40 // 000000000FF8: D3D84008 18000128"
+    unrelated = "\tv_add_u32_e32 v90, 1, v91 // 000000000FFC: 68B4B681"
+    for seq, bad in (([reload, mf], True), ([reload, unrelated, mf], True), ([reload, unrelated, unrelated, mf], False),
+                     ([reload, "\ts_nop 1 // 000000000FFC: BF800001", mf], False), ([unrelated, mf], False)):
+        found = set()
+        L.scan([L.Ins(x) for x in seq], "planted", found)
+        assert bool(found) == bad, (seq, found)
 
 
-def test_no_unfenced_access_to_a_pinned_mfma_result_in_the_built_encoder():
+def test_no_hazard_around_the_pinned_mfmas_of_the_built_encoder():
     if not os.path.exists(OBJ):
         pytest.skip("csrc/build/encoder.hip.o not built")
     L = _lint()
