@@ -21,7 +21,13 @@ instruction directly before the MFMA the features were wrong (deterministically)
 `-mllvm -amdgpu-snop-padding=1` cured every failing variant (profiles/NOTES.md section O).  For a builtin MFMA the compiler keeps
 >= 4 (encoder_general.hip.o); the pinned MFMAs of that instantiation therefore carry `s_nop 1` inside their statement.
 
+Rule C (`--dpp`, for the Kuka kernels): the lane-group primitives are DPP instructions inside asm statements (csrc/kuka_group.hpp
+fmac_bcast, the projected Gauss-Seidel rows of kuka_tree.hpp); a DPP read of a VGPR needs 2 wait states after a VALU write of it, which
+the statements provide themselves (`s_nop 1` / an independent instruction in between).  Checked on the built object: for every
+*_dpp instruction, the closest preceding VALU write of its DPP source operand.
+
     python profiles/probes/mfma_asm_hazard_lint.py [object=robotics-rl-srl_amd/csrc/build/encoder.hip.o] [kernel-regex=.]
+    python profiles/probes/mfma_asm_hazard_lint.py --dpp [object=robotics-rl-srl_amd/csrc/build/kuka_tree.hip.o]
 exit status 1 and one line per violation if any; used by tests/test_encoder_isa_lint.py."""
 import os
 import re
@@ -150,7 +156,42 @@ def lint(obj, pattern="."):
     return sorted(found), stats
 
 
+REQUIRED_DPP = 2
+
+
+def lint_dpp(obj):
+    """(violations, {distance: count}, number of DPP instructions): distance = wait states between a VALU write of a DPP instruction's
+    permuted source (src0) and that instruction, over every kernel of the object (straight-line order; distances >= 6 not recorded)."""
+    found, hist, n_dpp = [], {}, 0
+    for name, seq in kernels(disassemble(obj)).items():
+        recent = []
+        for ins in seq:
+            if "_dpp" in ins.mnem:
+                n_dpp += 1
+                ops = [o.strip() for o in ins.ops.split(",")]
+                src0 = regs_of(ops[1].split()[0]) if len(ops) > 1 else set()
+                for pv, ws in recent:
+                    if pv.wdst & src0:
+                        hist[ws] = hist.get(ws, 0) + 1
+                        if ws < REQUIRED_DPP:
+                            found.append("%s: %s %s at 0x%x writes the DPP source of %s %s at 0x%x only %d wait states before it" % (
+                                name[:80], pv.mnem, pv.ops.strip(), pv.addr, ins.mnem, ins.ops.strip(), ins.addr, ws))
+            recent = [(pv, ws + ins.ws) for pv, ws in recent if ws + ins.ws < 6]
+            if ins.mnem.startswith("v_"):
+                recent.append((ins, 0))
+    return found, hist, n_dpp
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dpp":
+        repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        obj = sys.argv[2] if len(sys.argv) > 2 else os.path.join(repo, "robotics-rl-srl_amd", "csrc", "build", "kuka_tree.hip.o")
+        found, hist, n = lint_dpp(obj)
+        print("%d DPP instructions; VALU write of the DPP source -> DPP instruction, wait states: %s" % (n, sorted(hist.items())))
+        for f in found:
+            print("HAZARD " + f)
+        print("%d violation(s)" % len(found))
+        sys.exit(1 if found else 0)
     repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(repo, "robotics-rl-srl_amd", "csrc", "build", "encoder.hip.o")
     found, stats = lint(obj, sys.argv[2] if len(sys.argv) > 2 else ".")
