@@ -28,7 +28,7 @@ the statements provide themselves (`s_nop 1` / an independent instruction in bet
 
     python profiles/probes/mfma_asm_hazard_lint.py [object=robotics-rl-srl_amd/csrc/build/encoder.hip.o] [kernel-regex=.]
     python profiles/probes/mfma_asm_hazard_lint.py --dpp [object=robotics-rl-srl_amd/csrc/build/kuka_tree.hip.o]
-exit status 1 and one line per violation if any; used by tests/test_encoder_isa_lint.py."""
+exit status 1 and one line per violation if any; used by tests/test_isa_lint.py."""
 import os
 import re
 import subprocess
