@@ -51,6 +51,10 @@ def parse():
                     help="full = the 12-DoF arm + gripper tree of kuka_with_gripper2.sdf (library default); lumped = the rounds 1-2 approximation")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short BASELINE config 2 (mobile) and config 4 (kuka_pixels) runs nested under \"secondary\"")
+    ap.add_argument("--per-step", action="store_true",
+                    help="time the per-step VecEnv API (HipVecEnv.step_async / step_wait: the path rl_baselines.train drives) instead of fused "
+                         "rollouts; with --device-ids the ONE process shards the envs over those GPUs")
+    ap.add_argument("--device-ids", default=None, help="--per-step: GPUs of the sharded HipVecEnv ('all' or e.g. 0,1,2,3; default: device 0)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="roofline.traffic / issue_util from the committed profiles/ summaries only (no rocprofv3 --pmc child passes)")
     return ap.parse_args()
@@ -472,6 +476,11 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
             roofline["achieved"] = traffic / avg_launch_s / 1e9
             roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
             roofline["physical_hbm_gbs"], roofline["physical_hbm_frac"] = roofline["achieved"], roofline["frac"]
+            roofline["frac_basis"] = "physical"
+        else:
+            # no PMC figure for this geometry (no rocprofv3, or not 4096 x 2048): achieved / frac stay NUMERIC — the SURVEY 8(d)
+            # contract figure, flagged (it can exceed 1 for a fused rollout, see `note`)
+            roofline["achieved"], roofline["frac"], roofline["frac_basis"] = achieved_gbs, achieved_gbs / HBM_PEAK_GBS, "survey_8d_contract (no PMC traffic for this geometry)"
     else:
         from srlhip import kuka_model
         kk = h.kuka_kernel()
@@ -550,8 +559,56 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     return line
 
 
+def bench_per_step(args):
+    """The per-step API of the drop-in (rl_baselines/utils.py:213-229 -> HipVecEnv): K x (step_async + step_wait) with host-side random
+    actions, every shard launched before any is collected.  ONE process; n = envs_per_gpu x number of shards.  Also reports the split
+    (time inside step_async = launches only; inside step_wait = the GPU's step + collection) and the single-shard figure beside it."""
+    from srlhip.vec_env import HipVecEnv, parse_device_ids
+    device_ids = parse_device_ids(args.device_ids) or [0]
+    workload = "kuka" if args.workload == "auto" else args.workload
+    env_id = {"kuka": "KukaButtonGymEnv-v0", "mobile": "MobileRobotGymEnv-v0"}[workload]
+    K = args.steps if args.steps is not None else 2000
+    W = args.warmup if args.warmup is not None else 300
+
+    def run(ids):
+        n = args.envs_per_gpu * len(ids)
+        env = HipVecEnv(env_id, n, seed=0, env_kwargs={"srl_model": "ground_truth"}, device_ids=ids, rng_mode=args.rng)
+        env.reset()
+        acts = np.random.RandomState(0).randint(env.action_space.n, size=(64, n)).astype(np.int32)
+        for t in range(W):
+            env.step(acts[t % 64])
+        ta = tw = 0.0
+        lat = np.zeros(K)
+        t_begin = time.perf_counter()
+        for t in range(K):
+            t0 = time.perf_counter()
+            env.step_async(acts[t % 64])
+            t1 = time.perf_counter()
+            env.step_wait()
+            t2 = time.perf_counter()
+            ta += t1 - t0; tw += t2 - t1; lat[t] = t2 - t0
+        dt = time.perf_counter() - t_begin
+        env.close()
+        return {"n": n, "value": n * K / dt, "us_per_step_mean": dt / K * 1e6, "us_per_step_median": float(np.median(lat)) * 1e6,
+                "us_in_step_async": ta / K * 1e6, "us_in_step_wait": tw / K * 1e6}
+
+    r = run(device_ids)
+    line = {"metric": "env steps/sec, per-step VecEnv API (HipVecEnv.step), {} {} envs per shard x {} shard(s)".format(
+                env_id.split("-")[0], args.envs_per_gpu, len(device_ids)),
+            "value": r["value"], "unit": "env-steps/s", "n_gpus": len(set(device_ids)), "steps": K, "warmup": W, "ms_per_step": r["us_per_step_mean"] / 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "{} ground_truth obs through HipVecEnv.step_async / step_wait, one process, device_ids {}".format(env_id, device_ids),
+                       "envs_per_shard": args.envs_per_gpu, "device_ids": device_ids, "rng_mode": args.rng, "per_step": r}}
+    if len(device_ids) > 1:
+        line["config"]["single_shard"] = run(device_ids[:1])
+        line["config"]["step_time_vs_single_shard"] = r["us_per_step_median"] / line["config"]["single_shard"]["us_per_step_median"]
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
+    if args.per_step:
+        return bench_per_step(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     from srlhip import sharding

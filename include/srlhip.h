@@ -37,8 +37,10 @@
 extern "C" {
 #endif
 
-#define SRLHIP_ABI_VERSION 3   /* 2 (round 4): srlhip_kuka_tree_model grew its solver section (506 -> 510 doubles), SRLHIP_F_KUKA_BODIES;
-                                 * 3 (round 5): SRLHIP_F_KUKA_IK_CROSSED */
+#define SRLHIP_ABI_VERSION 4   /* 2 (round 4): srlhip_kuka_tree_model grew its solver section (506 -> 510 doubles), SRLHIP_F_KUKA_BODIES;
+                                 * 3 (round 5): SRLHIP_F_KUKA_IK_CROSSED;
+                                 * 4 (round 6): srlhip_step_async / srlhip_step_wait / srlhip_step_pending, srlhip_config.info_bits
+                                 *              (was reserved0) */
 
 /* ---- error codes ------------------------------------------------------- */
 #define SRLHIP_OK            0
@@ -109,7 +111,9 @@ typedef struct srlhip_config {
                                  rl_baselines/utils.py:216-220); needs rng_mode != HOST     */
     int32_t io_device;        /* 0 host pointers, 1 device pointers (see Conventions)      */
     int32_t kuka_model;       /* SRLHIP_KUKA_MODEL_* (Kuka envs; srlhip_default_config picks FULL where it exists) */
-    int32_t reserved0;        /* 0                                                         */
+    int32_t info_bits;        /* 0: done_out bytes are 0 / 1.  1 (full-model Kuka handles; ignored elsewhere): bit 1 of every
+                                 done_out byte = the env-step ran under the IK conditioning flag (SRLHIP_F_KUKA_IK_CROSSED bit 0,
+                                 sampled BEFORE an auto-reset clears it) — the per-step `infos` of the VecEnv surface    */
     int64_t seed0;            /* base seed: env i is seeded seed0 + first_env_id + i       */
     double  max_distance;     /* ctor kwarg max_distance                                   */
 } srlhip_config;
@@ -154,6 +158,19 @@ int srlhip_reset_rand_count(srlhip_handle h);
  * next episode. */
 int srlhip_step(srlhip_handle h, const void *actions, const double *host_noise,
                 void *obs_out, float *reward_out, uint8_t *done_out);
+
+/* srlhip_step in two halves, for HOST-pointer handles (cfg.io_device = 0): what SubprocVecEnv.step_async / step_wait are to the
+ * reference (rl_baselines/utils.py:213-220 builds the SubprocVecEnv whose step_async only SENDS the actions to the workers and whose
+ * step_wait collects them).  srlhip_step_async validates the inputs, copies them into the handle's pinned block and ENQUEUES the
+ * step on the handle's stream: it returns before the GPU has run it, so a caller holding G handles (one per GPU — the sharded
+ * HipVecEnv) has all G devices stepping at once, and a single-handle caller overlaps its own work with the step.
+ * srlhip_step_wait waits for that step and copies its planes out (any pointer may be NULL); with cfg.auto_reset the observation of
+ * a finished env is the first one of its next episode.  One step may be pending per handle: a second srlhip_step_async, or a
+ * srlhip_step, before the wait returns SRLHIP_EINVAL; srlhip_step_wait without a pending step too.  srlhip_step ==
+ * srlhip_step_async + srlhip_step_wait.  srlhip_step_pending: 1 between the two, else 0. */
+int srlhip_step_async(srlhip_handle h, const void *actions, const double *host_noise);
+int srlhip_step_wait(srlhip_handle h, void *obs_out, float *reward_out, uint8_t *done_out);
+int srlhip_step_pending(srlhip_handle h);
 
 /* Fused rollout: T consecutive steps with auto-reset, outputs streamed as
  * [T][num_envs] planes.  Replaces the random-agent hot loop
@@ -238,6 +255,12 @@ int srlhip_episode_stats_device(srlhip_handle h, float *d_last_return, int32_t *
 
 /* Stream ordering and live kernel timing (HIP events on the handle's stream). */
 int srlhip_sync(srlhip_handle h);
+/* Enqueue a copy of `bytes` bytes on the handle's stream, ordered with the steps / renders / encoder forwards enqueued there
+ * (device <-> device, or device <-> PINNED host memory; the direction is taken from the pointers).  What a device-pointer caller
+ * uses to feed actions and fetch reward / done / state planes without a second stream: the sharded HipVecEnv with a learned SRL
+ * model moves only [n][state_dim] floats per step this way (the reference pickles a 150 KB frame per env and step through
+ * MultiprocessSRLModel's queues, rl_baselines/utils.py:162-191).  Returns without waiting. */
+int srlhip_copy_async(srlhip_handle h, void *dst, const void *src, size_t bytes);
 int srlhip_stream(srlhip_handle h, void **hip_stream);
 int srlhip_timing_begin(srlhip_handle h);
 int srlhip_timing_end(srlhip_handle h, float *elapsed_ms);   /* synchronises */

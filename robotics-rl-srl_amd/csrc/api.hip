@@ -204,6 +204,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->kuka_model != SRLHIP_KUKA_MODEL_LUMPED && cfg->kuka_model != SRLHIP_KUKA_MODEL_FULL) {
         g_create_error = "create: unknown kuka_model"; return SRLHIP_EINVAL;
     }
+    if (cfg->info_bits != 0 && cfg->info_bits != 1) { g_create_error = "create: info_bits must be 0 or 1"; return SRLHIP_EINVAL; }
     if (cfg->env_kind >= SRLHIP_ENV_KUKA_BUTTON && cfg->action_repeat < 1) {
         g_create_error = "create: action_repeat must be >= 1"; return SRLHIP_EINVAL;
     }
@@ -340,73 +341,128 @@ int srlhip_reset(srlhip_handle hh, const uint8_t *mask, const double *host_rand,
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+// The host-pointer step in two halves (srlhip_step = both, srlhip_step_async / srlhip_step_wait = one each).
+// Small steps (ground-truth observations of a few thousand envs: < 1 MiB each way) are ZERO-COPY: the kernel reads the actions from
+// and writes obs / reward / done to mapped pinned host memory over PCIe, so a step is one launch + one stream sync (measured ~10 us
+// faster per 4096-env step than enqueueing an H2D and a D2H copy).  Larger steps (images, very large batches): one pinned bounce
+// buffer each way -> one H2D and one D2H DMA transfer.
+struct StepLayout { size_t ob, ab, in_noise, in_total, out_rew, out_done, out_total; bool pixels, zero_copy; };
+StepLayout step_layout(const Handle *h) {
+    StepLayout L;
+    const size_t n = (size_t)h->n;
+    L.ob = obs_bytes_per_env(h) * n; L.ab = action_bytes(h);
+    L.in_noise = (L.ab + 15) & ~(size_t)15; L.in_total = L.in_noise + sizeof(double) * n;
+    L.out_rew = (L.ob + 15) & ~(size_t)15; L.out_done = L.out_rew + 4 * n; L.out_total = L.out_done + n;
+    L.pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
+    static const bool zc_enabled = [] { const char *v = getenv("SRLHIP_ZERO_COPY"); return !v || atoi(v) != 0; }();   // =0: bounce buffers
+    L.zero_copy = zc_enabled && !h->cfg.io_device && !L.pixels && L.out_total <= ((size_t)1 << 20);
+    return L;
+}
+
+// validate + stage the inputs, enqueue the step (and, in bounce mode, the D2H copy of its outputs) on the handle's stream; no wait
+int host_step_begin(Handle *h, const void *actions, const double *host_noise, bool want_obs) {
+    const int n = h->n;
+    const StepLayout L = step_layout(h);
+    int rc;
+    if (!h->cfg.is_discrete && !all_finite_f32(static_cast<const float *>(actions), L.ab / sizeof(float)))
+        return h->fail(SRLHIP_EINVAL, "step: non-finite continuous action");
+    if (host_noise && !all_finite_f64(host_noise, (size_t)n)) return h->fail(SRLHIP_EINVAL, "step: non-finite host_noise");
+    if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total)))
+        return rc;
+    memcpy(h->pin_in, actions, L.ab);
+    if (host_noise) memcpy(static_cast<uint8_t *>(h->pin_in) + L.in_noise, host_noise, sizeof(double) * n);
+    uint8_t *din = nullptr, *o = nullptr;
+    if (L.zero_copy) {
+        void *dp = nullptr;
+        SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dp, h->pin_in, 0));
+        din = static_cast<uint8_t *>(dp);
+        SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dp, h->pin_out, 0));
+        o = static_cast<uint8_t *>(dp);
+    } else {
+        if ((rc = ensure(h, &h->st_actions, &h->st_actions_sz, L.in_total)) || (rc = ensure(h, &h->st_obs, &h->st_obs_sz, L.out_total)))
+            return rc;
+        SRL_HIP_CHECK(h, hipMemcpyAsync(h->st_actions, h->pin_in, host_noise ? L.in_total : L.ab, hipMemcpyHostToDevice, h->stream));
+        din = static_cast<uint8_t *>(h->st_actions);
+        o = static_cast<uint8_t *>(h->st_obs);
+    }
+    const double *d_noise = host_noise ? reinterpret_cast<const double *>(din + L.in_noise) : nullptr;
+    void *d_obs = want_obs ? o : nullptr;
+    float *d_rew = reinterpret_cast<float *>(o + L.out_rew);
+    uint8_t *d_done = o + L.out_done;
+    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, din, d_noise, L.pixels ? nullptr : static_cast<float *>(d_obs), d_rew, d_done)
+                                    : kuka_step(h, din, d_noise, L.pixels ? nullptr : d_obs, d_rew, d_done);
+    if (rc) return rc;
+    if (L.pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;
+    if (!L.zero_copy) {
+        const size_t from = want_obs ? 0 : L.out_rew;
+        SRL_HIP_CHECK(h, hipMemcpyAsync(static_cast<uint8_t *>(h->pin_out) + from, static_cast<uint8_t *>(h->st_obs) + from,
+                                        L.out_total - from, hipMemcpyDeviceToHost, h->stream));
+    }
+    return 0;
+}
+
+// wait for the step enqueued by host_step_begin and hand its planes to the caller
+int host_step_finish(Handle *h, void *obs_out, float *reward_out, uint8_t *done_out) {
+    const StepLayout L = step_layout(h);
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    const uint8_t *po = static_cast<const uint8_t *>(h->pin_out);
+    if (obs_out) memcpy(obs_out, po, L.ob);
+    if (reward_out) memcpy(reward_out, po + L.out_rew, 4 * (size_t)h->n);
+    if (done_out) memcpy(done_out, po + L.out_done, h->n);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
 int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise, void *obs_out, float *reward_out,
                 uint8_t *done_out) {
     if (!hh || !actions) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     if (rc) return rc;
-    const int n = h->n;
     if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !host_noise)
         return h->fail(SRLHIP_EINVAL, "step: RNG_HOST needs host_noise");
-    const void *d_act = actions; const double *d_noise = host_noise;
-    void *d_obs = obs_out; float *d_rew = reward_out; uint8_t *d_done = done_out;
-    const size_t ob = obs_bytes_per_env(h) * n, ab = action_bytes(h);
-    // host-pointer mode.  Small steps (ground-truth observations of a few thousand envs: < 1 MiB each way) are ZERO-COPY:
-    // the kernel reads the actions from and writes obs / reward / done to mapped pinned host memory over PCIe, so a step
-    // is one launch + one stream sync (measured ~10 us faster per 4096-env step than enqueueing an H2D and a D2H copy).
-    // Larger steps (images, very large batches): one pinned bounce buffer each way -> one H2D and one D2H DMA transfer.
-    const size_t in_noise = (ab + 15) & ~(size_t)15, in_total = in_noise + sizeof(double) * n;
-    const size_t out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * (size_t)n, out_total = out_done + n;
+    if (h->step_pending) return h->fail(SRLHIP_EINVAL, "step: a srlhip_step_async is pending (call srlhip_step_wait first)");
+    if (!h->cfg.io_device) {
+        if ((rc = host_step_begin(h, actions, host_noise, obs_out != nullptr))) return rc;
+        return host_step_finish(h, obs_out, reward_out, done_out);
+    }
     const bool pixels = h->cfg.obs_mode == SRLHIP_OBS_RAW_PIXELS;
-    static const bool zc_enabled = [] { const char *v = getenv("SRLHIP_ZERO_COPY"); return !v || atoi(v) != 0; }();   // =0: bounce buffers
-    const bool zero_copy = zc_enabled && !h->cfg.io_device && !pixels && out_total <= ((size_t)1 << 20);
-    if (!h->cfg.io_device) {
-        if (!h->cfg.is_discrete && !all_finite_f32(static_cast<const float *>(actions), ab / sizeof(float)))
-            return h->fail(SRLHIP_EINVAL, "step: non-finite continuous action");
-        if (host_noise && !all_finite_f64(host_noise, (size_t)n)) return h->fail(SRLHIP_EINVAL, "step: non-finite host_noise");
-        if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, out_total)))
-            return rc;
-        memcpy(h->pin_in, actions, ab);
-        if (host_noise) memcpy(static_cast<uint8_t *>(h->pin_in) + in_noise, host_noise, sizeof(double) * n);
-        uint8_t *din = nullptr, *o = nullptr;
-        if (zero_copy) {
-            void *dp = nullptr;
-            SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dp, h->pin_in, 0));
-            din = static_cast<uint8_t *>(dp);
-            SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dp, h->pin_out, 0));
-            o = static_cast<uint8_t *>(dp);
-        } else {
-            if ((rc = ensure(h, &h->st_actions, &h->st_actions_sz, in_total)) || (rc = ensure(h, &h->st_obs, &h->st_obs_sz, out_total)))
-                return rc;
-            SRL_HIP_CHECK(h, hipMemcpyAsync(h->st_actions, h->pin_in, host_noise ? in_total : ab, hipMemcpyHostToDevice, h->stream));
-            din = static_cast<uint8_t *>(h->st_actions);
-            o = static_cast<uint8_t *>(h->st_obs);
-        }
-        d_act = din;
-        if (host_noise) d_noise = reinterpret_cast<const double *>(din + in_noise);
-        d_obs = obs_out ? o : nullptr;
-        d_rew = reinterpret_cast<float *>(o + out_rew);
-        d_done = o + out_done;
-    }
-    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, d_act, d_noise, pixels ? nullptr : static_cast<float *>(d_obs), d_rew, d_done)
-                                    : kuka_step(h, d_act, d_noise, pixels ? nullptr : d_obs, d_rew, d_done);
+    rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, actions, host_noise, pixels ? nullptr : static_cast<float *>(obs_out), reward_out, done_out)
+                                    : kuka_step(h, actions, host_noise, pixels ? nullptr : obs_out, reward_out, done_out);
     if (rc) return rc;
-    if (pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;
-    if (!h->cfg.io_device) {
-        if (!zero_copy) {
-            const size_t from = obs_out ? 0 : out_rew;
-            SRL_HIP_CHECK(h, hipMemcpyAsync(static_cast<uint8_t *>(h->pin_out) + from, static_cast<uint8_t *>(h->st_obs) + from,
-                                            out_total - from, hipMemcpyDeviceToHost, h->stream));
-        }
-        SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-        const uint8_t *po = static_cast<const uint8_t *>(h->pin_out);
-        if (obs_out) memcpy(obs_out, po, ob);
-        if (reward_out) memcpy(reward_out, po + out_rew, 4 * (size_t)n);
-        if (done_out) memcpy(done_out, po + out_done, n);
-    }
+    if (pixels && obs_out && (rc = raster_render(h, obs_out))) return rc;
     return 0;
 }
+
+int srlhip_step_async(srlhip_handle hh, const void *actions, const double *host_noise) {
+    if (!hh || !actions) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (h->cfg.io_device) return h->fail(SRLHIP_EINVAL, "step_async: host-pointer handles only (on a device-pointer handle srlhip_step already only enqueues)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !host_noise) return h->fail(SRLHIP_EINVAL, "step_async: RNG_HOST needs host_noise");
+    if (h->step_pending) return h->fail(SRLHIP_EINVAL, "step_async: the previous srlhip_step_async was not collected (srlhip_step_wait)");
+    if ((rc = host_step_begin(h, actions, host_noise, true))) return rc;
+    h->step_pending = true;
+    return 0;
+}
+
+int srlhip_step_wait(srlhip_handle hh, void *obs_out, float *reward_out, uint8_t *done_out) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (!h->step_pending) return h->fail(SRLHIP_EINVAL, "step_wait: no srlhip_step_async is pending");
+    int rc = set_device(h);
+    if (rc) return rc;
+    h->step_pending = false;
+    return host_step_finish(h, obs_out, reward_out, done_out);
+}
+
+int srlhip_step_pending(srlhip_handle hh) { return hh ? (reinterpret_cast<Handle *>(hh)->step_pending ? 1 : 0) : SRLHIP_EINVAL; }
 
 int srlhip_rollout(srlhip_handle hh, int32_t T, const void *actions_TN, void *obs_TN, float *reward_TN,
                    uint8_t *done_TN, void *act_out_TN) {
@@ -618,6 +674,15 @@ int srlhip_sync(srlhip_handle hh) {
     if (!hh) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int srlhip_copy_async(srlhip_handle hh, void *dst, const void *src, size_t bytes) {
+    if (!hh || (bytes && (!dst || !src))) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (bytes) SRL_HIP_CHECK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
     return 0;
 }
 

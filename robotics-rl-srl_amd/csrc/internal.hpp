@@ -133,6 +133,7 @@ struct Handle {
     // that the kernels address directly, so the per-step API reads an ended episode's (r, l) without a device copy (srlhip_episode_records)
     void *ep_host = nullptr;
     size_t pin_in_sz, pin_out_sz;
+    bool step_pending = false;       // srlhip_step_async enqueued a step that srlhip_step_wait has not collected yet
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     template <class T>

@@ -143,8 +143,9 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
     krng_load<MODE>(rng, rs, e, p.n, noise ? noise + e : nullptr);
     Env v = {};
     load_env<NB>(s, n, e, v);
-    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
-    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    double ep_ret = st.ep_return[e], last_ret = 0.0, last_reward = 0.0;      // (last_* : written only when an episode finished, never read — mobile.hip)
+    int32_t ep_len = st.ep_length[e], last_len = 0, n_fin = st.n_finished[e];
+    const int32_t n_fin0 = n_fin;
     Philox act; act.k0 = rs.key[e]; act.k1 = rs.key[n + e]; act.ctr = rs.act_ctr[e]; act.stream = 1;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
     const int adim = cfg.is_discrete ? 1 : cfg.action_joints ? 7 : 3;
@@ -180,7 +181,8 @@ kuka_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, c
     store_env<NB>(s, n, e, v);
     krng_store<MODE>(rng, rs, e);
     if (!actions) rs.act_ctr[e] = act.ctr;
-    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
+    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len;
+    if (n_fin != n_fin0) { st.last_return[e] = last_ret; st.last_length[e] = last_len; }
     st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 

@@ -183,6 +183,7 @@ struct Cfg {
     int32_t moving, max_steps;  // KukaMovingButtonGymEnv: moving = 1, max_steps = 1500
     int32_t two;                // Kuka2ButtonGymEnv: large workspace, default IK damping, max_steps = 1500
     int32_t rand_objects;       // KukaRandButtonGymEnv: reset() draws ten distractor positions (scenery only)
+    int32_t info_bits;          // srlhip_config.info_bits: 1 = bit 1 of every done_out byte carries the step's IK conditioning flag (full model)
     double max_distance;
 };
 

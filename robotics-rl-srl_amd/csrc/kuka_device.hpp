@@ -86,6 +86,7 @@ inline KukaParams params_of(const Handle *h) {
     p.cfg.moving = c.env_kind == SRLHIP_ENV_KUKA_MOVING ? 1 : 0;
     p.cfg.two = c.env_kind == SRLHIP_ENV_KUKA_2BUTTON ? 1 : 0;
     p.cfg.rand_objects = c.env_kind == SRLHIP_ENV_KUKA_RAND ? 1 : 0;
+    p.cfg.info_bits = c.info_bits;
     p.cfg.max_steps = p.cfg.moving ? 1500 : p.cfg.two ? kMaxSteps2Button : kMaxSteps;
     p.n = h->n;
     return p;

@@ -54,8 +54,9 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         if (!L.arm) { g.q = 0.0; g.qd = 0.0; g.sq = 0.0; g.cq = 1.0; }
         gfk<CM>(L, g);
     }
-    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
-    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    double ep_ret = st.ep_return[e], last_ret = 0.0, last_reward = 0.0;      // (last_* : written only when an episode finished, never read — mobile.hip)
+    int32_t ep_len = st.ep_length[e], last_len = 0, n_fin = st.n_finished[e];
+    const int32_t n_fin0 = n_fin;
     GroupActions gact; gact.init(rs.key[e], rs.key[n + e], rs.act_ctr[e]);
     Philox &act = gact.p;
     const int od = cfg.obs_mode == 1 ? 14 : cfg.obs_mode == 2 ? 17 : 3;
@@ -124,7 +125,8 @@ kuka_group_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, in
         if constexpr (MODE == SRLHIP_RNG_PHILOX) rs.ctr[e] = rng0.p.ctr;
         else krng_store<MODE>(rng0, rs, e);
         if constexpr (!GIVEN) rs.act_ctr[e] = act.ctr;
-        st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret; st.last_length[e] = last_len;
+        st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len;
+        if (n_fin != n_fin0) { st.last_return[e] = last_ret; st.last_length[e] = last_len; }
         st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
     }
 #undef e

@@ -141,7 +141,7 @@ extern "C" int hostcheck_kuka_rollout(int is_discrete, int action_joints, int ra
                                       float *obs0, float *obs, float *rew, double *rew64, uint8_t *done_out,
                                       void *act_out, double *q_trace, double *grip_trace, double *final_state,
                                       double *ep_stats) {
-    Cfg cfg;
+    Cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.random_target = random_target; cfg.force_down = force_down; cfg.shape_reward = shape_reward;
     cfg.action_repeat = action_repeat; cfg.is_discrete = is_discrete; cfg.action_joints = action_joints;
     cfg.obs_mode = obs_mode; cfg.auto_reset = auto_reset; cfg.max_distance = max_distance;

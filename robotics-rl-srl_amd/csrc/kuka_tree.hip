@@ -85,7 +85,7 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     // (kuka_tree_kernels.hpp, SPEC = 1); SRLHIP_KUKA_SPEC=0 keeps the generic instantiation (tests compare the two)
     const srlhip_config &c = h->cfg;
     static const bool spec_enabled = [] { const char *v = getenv("SRLHIP_KUKA_SPEC"); return !v || atoi(v) != 0; }();
-    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.random_target &&
+    const bool spec = spec_enabled && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.action_joints && !c.random_target &&
                       c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset &&
                       (c.obs_mode == SRLHIP_OBS_GROUND_TRUTH || (c.obs_mode == SRLHIP_OBS_RAW_PIXELS && !obs));      // raw_pixels: the rasteriser draws, the stepper writes no observation
     {

@@ -187,6 +187,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         double reward;
         reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
         ep_ret += reward; ep_len += 1; last_reward = reward;
+        const int info = cfg.info_bits ? (v.ikx & 1) << 1 : 0;      // srlhip_config.info_bits: the IK conditioning flag this step ran under (before the auto-reset clears it)
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
@@ -200,7 +201,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         if (lead) {
             if (obs_p) observe(v, cfg, obs_p, 1);
             if (rew_p) *rew_p = (float)reward;
-            if (done_p) *done_p = (uint8_t)done;
+            if (done_p) *done_p = (uint8_t)((int)done | info);
         }
         if (obs_p) obs_p += n * od;
         if (rew_p) rew_p += n;

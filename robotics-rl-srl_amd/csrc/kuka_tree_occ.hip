@@ -84,6 +84,7 @@ kuka_tree_rollout_occ_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st,
         double reward;
         reward = tree::tenv_step<NB, RB, 1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, park);
         ep_ret += reward; ep_len += 1; last_reward = reward;
+        const int info = cfg.info_bits ? (v.ikx & 1) << 1 : 0;      // (kuka_tree_kernels.hpp)
         if (done) {
             last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
             if (cfg.auto_reset) {
@@ -97,7 +98,7 @@ kuka_tree_rollout_occ_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st,
         if (lead) {
             if (obs) observe(v, cfg, obs + row * od, 1);
             if (rew) rew[row] = (float)reward;
-            if (done_out) done_out[row] = (uint8_t)done;
+            if (done_out) done_out[row] = (uint8_t)((int)done | info);
         }
     }
     int e_out = e;

@@ -291,8 +291,12 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     rng_load<MODE>(rng, rs, e, p.n, nullptr, 0, noise);
     MobileEnv m;
     load_env(s, e, m);
-    double ep_ret = st.ep_return[e], last_ret = st.last_return[e], last_reward = 0.0;
-    int32_t ep_len = st.ep_length[e], last_len = st.last_length[e], n_fin = st.n_finished[e];
+    // (Monitor's record of the last finished episode is written only when an episode finishes in this launch and is never read: on
+    //  host-pointer handles those two planes are mapped host memory — srlhip_episode_records — and a read / an unconditional write-back
+    //  would cross PCIe in every launch)
+    double ep_ret = st.ep_return[e], last_ret = 0.0, last_reward = 0.0;
+    int32_t ep_len = st.ep_length[e], last_len = 0, n_fin = st.n_finished[e];
+    const int32_t n_fin0 = n_fin;
     const int32_t *act_i = static_cast<const int32_t *>(actions);
     const float2 *act_f = static_cast<const float2 *>(actions);
     // Actions are fetched kChunk steps at a time: on gfx9 loads and stores share one in-order counter (vmcnt), so waiting
@@ -338,8 +342,9 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     store_env(s, e, m);
     rng_store<MODE>(rng, rs, e);
     if (advance_actr) rs.act_ctr[e] += (uint64_t)T;
-    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len; st.last_return[e] = last_ret;
-    st.last_length[e] = last_len; st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
+    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len;
+    if (n_fin != n_fin0) { st.last_return[e] = last_ret; st.last_length[e] = last_len; }
+    st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 
 // Episode-parallel rollout (Philox mode with auto-reset).  In the MobileRobot family an episode always lasts exactly

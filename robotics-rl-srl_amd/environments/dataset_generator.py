@@ -1,6 +1,7 @@
 """python -m environments.dataset_generator — same CLI, seeding and on-disk output as
 /root/reference/environments/dataset_generator.py:120-274, but the `--num-cpu` "threads"
-are lanes of ONE batched GPU handle instead of OS processes: thread t still runs its own
+are lanes of batched GPU handles instead of OS processes (the reference forks num_cpu workers, :166-190; here `--device-ids`
+spreads the lanes over the node's GPUs in contiguous blocks, one handle per GPU, all stepping at once): thread t still runs its own
 episode list with the reference's per-episode seeds (:80-86), every env is re-seeded and
 reset individually when its episode ends (srlhip_seed / srlhip_reset with a mask), and a
 random agent samples actions from a per-thread action-space RandomState exactly like
@@ -35,40 +36,78 @@ def episode_seeds(args, thread_num):
             for i in range(n_ep)]
 
 
-class _BatchState(object):
-    """Host view of the per-env quantities the recorder needs."""
+class _Fleet(object):
+    """The generator's lanes ("threads" 0..n-1) spread over one handle per GPU, contiguous blocks in thread order.  Every method takes /
+    returns arrays over ALL lanes; a thread's episode seeds depend on its number only (episode_seeds), so the dataset does not depend
+    on how many GPUs generate it."""
 
-    def __init__(self, handle, env_cls):
-        self.h, self.kuka = handle, handle.cfg.env_kind >= _lib.ENV_KUKA_BUTTON
-        self.kind = handle.cfg.env_kind
+    def __init__(self, make_cfg, n, device_ids):
+        from srlhip.vec_env import shard_bounds
+        device_ids = list(device_ids)[:max(1, min(len(device_ids), n))]
+        self.n, self.parts = n, []
+        for (lo, hi), dev in zip(shard_bounds(n, len(device_ids)), device_ids):
+            self.parts.append((_lib.Handle(make_cfg(hi - lo, dev, lo)), lo, hi))
+        h0 = self.parts[0][0]
+        self.cfg, self.kind, self.kuka = h0.cfg, h0.cfg.env_kind, h0.cfg.env_kind >= _lib.ENV_KUKA_BUTTON
+        self.obs_dim, self.action_dim, self.num_actions = h0.obs_dim, h0.action_dim, h0.num_actions
+
+    def _cat(self, field):
+        return np.concatenate([h.get_state(field) for h, _, _ in self.parts], axis=-1)
+
+    def seed_and_reset(self, seeds, mask):
+        m = mask.astype(np.uint8)
+        for h, lo, hi in self.parts:
+            if m[lo:hi].any():
+                h.seed(seeds[lo:hi], mask=m[lo:hi])
+                h.reset(mask=m[lo:hi], obs_out=np.zeros((hi - lo, self.obs_dim), np.float32))
+
+    def step(self, actions):
+        """one step of every lane: launched on every GPU first (srlhip_step_async), then collected -> done uint8 [n]"""
+        for h, lo, hi in self.parts:
+            h.step_async(actions[lo:hi])
+        return np.concatenate([h.step_wait()[2] for h, _, _ in self.parts])
+
+    def last_reward(self):
+        return self._cat(_lib.F_LAST_REWARD)
+
+    def render(self):
+        return np.concatenate([h.render() for h, _, _ in self.parts])
 
     def ground_truth_and_target(self):
-        h = self.h
         if self.kuka:
-            return h.get_state(_lib.F_KUKA_GRIPPER).T.copy(), h.get_state(_lib.F_KUKA_BUTTON_POS).T.copy()
-        x, y = h.get_state(_lib.F_POS_X), h.get_state(_lib.F_POS_Y)
-        cur = h.get_state(_lib.F_CUR_TARGET)
-        tx = np.where(cur > 0, h.get_state(_lib.F_TARGET2_X), h.get_state(_lib.F_TARGET_X))
-        ty = np.where(cur > 0, h.get_state(_lib.F_TARGET2_Y), h.get_state(_lib.F_TARGET_Y))
+            return self._cat(_lib.F_KUKA_GRIPPER).T.copy(), self._cat(_lib.F_KUKA_BUTTON_POS).T.copy()
+        x, y = self._cat(_lib.F_POS_X), self._cat(_lib.F_POS_Y)
+        cur = self._cat(_lib.F_CUR_TARGET)
+        tx = np.where(cur > 0, self._cat(_lib.F_TARGET2_X), self._cat(_lib.F_TARGET_X))
+        ty = np.where(cur > 0, self._cat(_lib.F_TARGET2_Y), self._cat(_lib.F_TARGET_Y))
         if self.kind == _lib.ENV_MOBILE_1D:
             return x[:, None], tx[:, None]
         if self.kind == _lib.ENV_MOBILE_LINE:
             return np.stack([x, y], 1), (tx - 0.2)[:, None]
         return np.stack([x, y], 1), np.stack([tx, ty], 1)
 
+    def close(self):
+        for h, _, _ in self.parts:
+            h.close()
+
 
 def run_batched(args):
+    from srlhip.vec_env import parse_device_ids
     env_cls = registered_env[args.env][0]
     n = args.num_cpu
-    cfg = _lib.default_config(env_cls.ENV_KIND)
-    cfg.num_envs, cfg.device_id = n, args.device_id
-    cfg.is_discrete, cfg.random_target = int(not args.continuous_actions), int(args.random_target)
-    cfg.shape_reward, cfg.multi_view = int(args.shape_reward), int(args.multi_view)     # force_down: the env class's own ctor default (srlhip_default_config), the reference never passes it
-    cfg.max_distance = args.max_distance
-    cfg.obs_mode, cfg.rng_mode, cfg.auto_reset = _lib.OBS_GROUND_TRUTH, _lib.RNG_MT19937, 0
-    cfg.img_h = cfg.img_w = args.img_size                       # frames come from srlhip_render (tile rasteriser)
-    h = _lib.Handle(cfg)
-    view = _BatchState(h, env_cls)
+
+    def make_cfg(count, device, first):
+        cfg = _lib.default_config(env_cls.ENV_KIND)
+        cfg.num_envs, cfg.device_id, cfg.first_env_id = count, device, first
+        cfg.is_discrete, cfg.random_target = int(not args.continuous_actions), int(args.random_target)
+        cfg.shape_reward, cfg.multi_view = int(args.shape_reward), int(args.multi_view)     # force_down: the env class's own ctor default (srlhip_default_config), the reference never passes it
+        cfg.max_distance = args.max_distance
+        cfg.obs_mode, cfg.rng_mode, cfg.auto_reset = _lib.OBS_GROUND_TRUTH, _lib.RNG_MT19937, 0
+        cfg.img_h = cfg.img_w = args.img_size                       # frames come from srlhip_render (tile rasteriser)
+        return cfg
+
+    fleet = _Fleet(make_cfg, n, parse_device_ids(getattr(args, "device_ids", None)) or [args.device_id])
+    cfg = fleet.cfg
     partition = n > 1
     savers = None
     if not args.no_record_data:
@@ -80,7 +119,7 @@ def run_batched(args):
     ep_idx = np.zeros(n, dtype=np.int64)
     active = np.array([len(s) > 0 for s in seeds])
     arng = [np.random.RandomState() for _ in range(n)]
-    adim = h.action_dim
+    adim = fleet.action_dim
     t_ep = np.zeros(n, dtype=np.int64)
 
     def start_episodes(mask):
@@ -88,11 +127,10 @@ def run_batched(args):
         for i in np.nonzero(mask)[0]:
             sd[i] = seeds[i][ep_idx[i]]
             arng[i].seed(int(sd[i]) % 2 ** 32)                 # env.action_space.seed(seed)
-        h.seed(sd, mask=mask.astype(np.uint8))
-        h.reset(mask=mask.astype(np.uint8), obs_out=np.zeros((n, h.obs_dim), np.float32))
+        fleet.seed_and_reset(sd, mask)
         if savers is not None:
-            gt, tgt = view.ground_truth_and_target()
-            frames_rgb = h.render()
+            gt, tgt = fleet.ground_truth_and_target()
+            frames_rgb = fleet.render()
             for i in np.nonzero(mask)[0]:
                 savers[i].reset(frames_rgb[i], tgt[i], gt[i])
         t_ep[mask] = 0
@@ -103,19 +141,18 @@ def run_batched(args):
         if cfg.is_discrete:
             actions = np.full(n, -1, dtype=np.int32)
             for i in np.nonzero(active)[0]:
-                actions[i] = arng[i].randint(h.num_actions)
+                actions[i] = arng[i].randint(fleet.num_actions)
         else:
             actions = np.zeros((n, adim), dtype=np.float32)
             for i in np.nonzero(active)[0]:
                 actions[i] = arng[i].uniform(-1, 1, adim).astype(np.float32)
-        _, _, done = h.step(actions)
-        done = done.astype(bool) & active
+        done = fleet.step(actions).astype(bool) & active
         frames += int(active.sum())
         t_ep[active] += 1
         if savers is not None:
-            gt, _ = view.ground_truth_and_target()
-            rew = h.get_state(_lib.F_LAST_REWARD)
-            frames_rgb = h.render()
+            gt, _ = fleet.ground_truth_and_target()
+            rew = fleet.last_reward()
+            frames_rgb = fleet.render()
             for i in np.nonzero(active)[0]:
                 r = float(rew[i]) if args.shape_reward else int(rew[i])
                 a = int(actions[i]) if cfg.is_discrete else actions[i]
@@ -131,7 +168,7 @@ def run_batched(args):
                 start_episodes(restart)
     fps = frames / max(time.time() - start_time, 1e-9)
     print("{:.2f} FPS".format(fps))
-    h.close()
+    fleet.close()
     return fps
 
 
@@ -156,12 +193,13 @@ _FLAGS = [
     (("--ppo2-timesteps",), dict(type=int, default=1000)),
     (("--toward-target-timesteps-proportion",), dict(type=float, default=0.0)),
     (("--device-id",), dict(type=int, default=0, help="HIP device ordinal")),
+    (("--device-ids",), dict(type=str, default=None, help="GPUs the --num-cpu lanes are spread over: 'all' or e.g. 0,1,2,3 (default: --device-id only)")),
     (("--img-size",), dict(type=int, default=224, help="recorded frame size (reference: 224)")),
 ]
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Deterministic dataset generator for SRL training (batched on one MI355X)")
+    parser = argparse.ArgumentParser(description="Deterministic dataset generator for SRL training (batched on the MI355Xs of one node)")
     for flags, kw in _FLAGS:
         parser.add_argument(*flags, **kw)
     return parser

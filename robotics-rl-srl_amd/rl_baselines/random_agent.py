@@ -4,7 +4,8 @@ import time
 
 class RandomAgentModel(object):
     def customArguments(self, parser):
-        parser.add_argument('--num-cpu', help='Number of envs (one GPU handle)', type=int, default=1)
+        parser.add_argument('--num-cpu', help='Number of envs (lanes of the GPU handles)', type=int, default=1)
+        parser.add_argument('--device-ids', help="GPUs the envs are sharded over: 'all' or e.g. 0,1,2,3 (default: device 0)", type=str, default=None)
         return parser
 
     def makeEnv(self, args, env_kwargs=None, load_path_normalise=None):

@@ -1,14 +1,19 @@
 """rl_baselines/utils.py:194-229 — createEnvs with the batched GPU vec env spliced in
 where the reference builds `[makeEnv(...)] -> DummyVecEnv | SubprocVecEnv` (:213-220).
 Everything after that line is unchanged: VecFrameStack, then VecNormalize for non-pixel
-observations."""
+observations.
+
+Multi-GPU: rl_baselines/train.py is ONE process, so the node is used from inside this VecEnv — `args.device_ids` ("all", "0,1,2,3" or
+a list; `--device-ids` on the command lines of this package) shards the `num_cpu` envs over those GPUs (contiguous blocks of global
+env ids, env i seeded seed + i as at environments/utils.py:52 whatever the number of GPUs); without it the env runs on
+`args.device_id` (default 0)."""
 from environments import ThreadingType
 
 try:                                        # pragma: no cover - stable_baselines is absent here
     from stable_baselines.common.vec_env import VecNormalize, VecFrameStack
 except Exception:                           # noqa: BLE001
     from srlhip.vec_wrappers import VecNormalize, VecFrameStack
-from srlhip.vec_env import HipVecEnv
+from srlhip.vec_env import HipVecEnv, parse_device_ids
 
 
 def createEnvs(args, allow_early_resets=False, env_kwargs=None, load_path_normalise=None):
@@ -20,8 +25,11 @@ def createEnvs(args, allow_early_resets=False, env_kwargs=None, load_path_normal
     # learned SRL models (registered_srl[...][0] is SRLType.SRL): the reference starts a MultiprocessSRLModel server and hands
     # every env a queue pair (:213-216); HipVecEnv loads the encoder once on the GPU (env_kwargs["srl_model_path"],
     # ["state_dim"]) and returns its states as the observation
+    device_ids = parse_device_ids(getattr(args, "device_ids", None))
+    if device_ids is not None:
+        device_ids = device_ids[:max(1, min(len(device_ids), args.num_cpu))]          # never more shards than envs
     envs = HipVecEnv(args.env, args.num_cpu, seed=args.seed, env_kwargs=kwargs, log_dir=getattr(args, "log_dir", None),
-                     device_id=getattr(args, "device_id", 0), allow_early_resets=allow_early_resets)
+                     device_id=getattr(args, "device_id", 0), device_ids=device_ids, allow_early_resets=allow_early_resets)
     envs = VecFrameStack(envs, getattr(args, "num_stack", 1))
     if kwargs["srl_model"] != "raw_pixels":
         envs = VecNormalize(envs, norm_obs=True, norm_reward=False)

@@ -37,8 +37,8 @@ _FIELD_SHAPES = {
 EXPORTS = [
     "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
-    "srlhip_reset_rand_count", "srlhip_step", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
-    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_records", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_stream", "srlhip_timing_begin",
+    "srlhip_reset_rand_count", "srlhip_step", "srlhip_step_async", "srlhip_step_wait", "srlhip_step_pending", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
+    "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_records", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_copy_async", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model", "srlhip_kuka_tree_default_model", "srlhip_set_kuka_tree_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
     "srlhip_encoder_supported", "srlhip_encoder_feature_count", "srlhip_encoder_create", "srlhip_encoder_forward", "srlhip_encoder_overflow",
@@ -47,7 +47,7 @@ EXPORTS = [
 ]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 KUKA_MODEL_DOUBLES = 138
 KUKA_TREE_MODEL_DOUBLES = 510
 KUKA_DETAIL_ALT_SWEEP, KUKA_DETAIL_BODY_ORDER, KUKA_DETAIL_FRICTION2 = 1, 2, 4
@@ -78,7 +78,7 @@ class Config(ctypes.Structure):
         ("action_repeat", ctypes.c_int32), ("action_joints", ctypes.c_int32), ("obs_mode", ctypes.c_int32),
         ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32), ("multi_view", ctypes.c_int32),
         ("rng_mode", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("io_device", ctypes.c_int32),
-        ("kuka_model", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("kuka_model", ctypes.c_int32), ("info_bits", ctypes.c_int32),
         ("seed0", ctypes.c_int64), ("max_distance", ctypes.c_double),
     ]
 
@@ -115,11 +115,13 @@ def load():
     lib.srlhip_default_config.argtypes = [i32, ctypes.POINTER(Config)]
     lib.srlhip_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     for name in ("srlhip_destroy", "srlhip_obs_dim", "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions",
-                 "srlhip_reset_rand_count", "srlhip_sync", "srlhip_timing_begin"):
+                 "srlhip_reset_rand_count", "srlhip_sync", "srlhip_timing_begin", "srlhip_step_pending"):
         getattr(lib, name).argtypes = [vp]
     lib.srlhip_seed.argtypes = [vp, vp, vp]
     lib.srlhip_reset.argtypes = [vp, vp, vp, vp]
     lib.srlhip_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.srlhip_step_async.argtypes = [vp, vp, vp]
+    lib.srlhip_step_wait.argtypes = [vp, vp, vp, vp]
     lib.srlhip_rollout.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.srlhip_get_state.argtypes = [vp, i32, vp]
     lib.srlhip_set_state.argtypes = [vp, i32, vp]
@@ -135,6 +137,7 @@ def load():
     lib.srlhip_set_kuka_tree_model.argtypes = [vp, vp]
     lib.srlhip_render.argtypes = [vp, vp]
     lib.srlhip_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.srlhip_copy_async.argtypes = [vp, vp, vp, ctypes.c_size_t]
     lib.srlhip_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.srlhip_graph_begin.argtypes = [vp]
     lib.srlhip_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
@@ -366,6 +369,38 @@ class Handle(object):
         pa, pn, po, pr, pd = _ptr(a), _ptr(host_noise), _ptr(obs), _ptr(rew), _ptr(done)
         return (lambda: fn(hh, pa, pn, po, pr, pd)), obs, rew, done
 
+    def step_split_fn(self, actions, obs, rew, done):
+        """The two halves of a per-step loop on a host-pointer handle, bound once to the CALLER's arrays (contiguous, e.g. this
+        shard's slices of global planes): go() = srlhip_step_async on `actions` (refilled in place before every call), collect() =
+        srlhip_step_wait into obs / rew / done.  Both return the library's status code."""
+        assert not self.cfg.io_device
+        assert self.action_array(actions) is actions, "step_split_fn needs the final contiguous int32 / float32 action array"
+        assert obs.flags.c_contiguous and obs.nbytes == self.obs_bytes * self.num_envs, (obs.shape, obs.dtype)
+        assert rew.flags.c_contiguous and rew.dtype == np.float32 and rew.shape == (self.num_envs,)
+        assert done.flags.c_contiguous and done.dtype == np.uint8 and done.shape == (self.num_envs,)
+        go, wait, hh = self._lib.srlhip_step_async, self._lib.srlhip_step_wait, self._h
+        pa, po, pr, pd = _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done)
+        keep = (actions, obs, rew, done)                     # the pointers above borrow these arrays
+        return (lambda: go(hh, pa, None)), (lambda _keep=keep: wait(hh, po, pr, pd))
+
+    def step_async(self, actions, host_noise=None):
+        """srlhip_step_async: enqueue one step of a host-pointer handle (returns before the GPU has run it)"""
+        a = self.action_array(actions)
+        if host_noise is not None:
+            host_noise = np.ascontiguousarray(host_noise, dtype=np.float64)
+        self._check(self._lib.srlhip_step_async(self._h, _ptr(a), _ptr(host_noise)), "srlhip_step_async")
+
+    def step_wait(self, out=None):
+        """srlhip_step_wait: (obs, reward, done) of the step srlhip_step_async enqueued"""
+        if out is None:
+            out = (self.new_obs(), np.zeros(self.num_envs, np.float32), np.zeros(self.num_envs, np.uint8))
+        obs, rew, done = out
+        self._check(self._lib.srlhip_step_wait(self._h, _ptr(obs), _ptr(rew), _ptr(done)), "srlhip_step_wait")
+        return out
+
+    def step_pending(self):
+        return self._lib.srlhip_step_pending(self._h) == 1
+
     def episode_stats(self):
         n = self.num_envs
         ret, length, fin = np.zeros(n, np.float64), np.zeros(n, np.int32), np.zeros(n, np.int32)
@@ -375,6 +410,10 @@ class Handle(object):
 
     def sync(self):
         self._check(self._lib.srlhip_sync(self._h), "srlhip_sync")
+
+    def copy_async(self, dst, src, nbytes):
+        """srlhip_copy_async: raw pointers (device, or pinned host), enqueued on the handle's stream"""
+        self._check(self._lib.srlhip_copy_async(self._h, ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(nbytes)), "srlhip_copy_async")
 
     def stream(self):
         p = ctypes.c_void_p()

@@ -1,5 +1,12 @@
 """HipVecEnv — the batched replacement for `[makeEnv(...)] -> DummyVecEnv | SubprocVecEnv`
-(rl_baselines/utils.py:213-220): one handle on one GPU steps every env per call.
+(rl_baselines/utils.py:213-220): one libsrlhip handle per GPU steps that GPU's shard of the envs, all GPUs at once.
+
+ONE process drives the whole node (rl_baselines/train.py:172-333 is a single process): `device_ids=[0, 1, ..., 7]` splits the N
+envs into contiguous blocks of global env ids, shard g on GPU device_ids[g] with cfg.first_env_id = its first global id, so every
+env's seed is `seed + global id` (environments/utils.py:52) and its trajectory does not depend on how many GPUs the batch is
+spread over.  step_async() ENQUEUES the step on every shard's stream (srlhip_step_async) and returns; step_wait() collects the
+shards in global env-id order (srlhip_step_wait): the G devices step concurrently, and a caller that does its own work between
+the two calls (SubprocVecEnv's contract: step_async only sends the actions to the workers) overlaps it with the step.
 
 Duck-types stable_baselines.common.vec_env.VecEnv (2.5.0): num_envs,
 observation_space, action_space, reset(), step_async(), step_wait(), step(),
@@ -9,9 +16,10 @@ info['episode'] like stable_baselines.bench.Monitor (environments/utils.py:54).
 
 Learned SRL models (state_representation/registry.py: SRLType.SRL — autoencoder, robotic_priors, ...): the reference
 runs ONE encoder process that every env queries through queues (MultiprocessSRLModel, rl_baselines/utils.py:162-191).
-Here the stepper renders all frames into HBM, the encoder (state_representation.models: fused HIP kernel for 64x64x3
-frames, PyTorch-ROCm otherwise) maps the batch to states on the same device, and only [N][state_dim] floats cross
-PCIe: the observation the policy sees is `srl_model.getState(render())`, as in the reference."""
+Here every shard renders its frames into its GPU's HBM, a replica of the encoder on that GPU (state_representation.models: HIP
+kernels through the C-ABI, PyTorch-ROCm otherwise) maps them to states on the shard's own stream, and only [N][state_dim] floats
+cross PCIe: the observation the policy sees is `srl_model.getState(render())`, as in the reference."""
+import ctypes
 import json
 import os
 import time
@@ -45,87 +53,144 @@ def _env_kind(env_id):
     return ENV_CLASSES[env_id].ENV_KIND
 
 
+def shard_bounds(num_envs, n_shards):
+    """Contiguous blocks of global env ids, as even as possible: [(lo, hi)] * n_shards (the first num_envs % n_shards blocks hold one
+    env more).  An 8-GPU node at 4096 envs per GPU: (0, 4096), (4096, 8192), ..."""
+    if not 1 <= n_shards <= num_envs:
+        raise ValueError("need 1 <= number of shards ({}) <= num_envs ({})".format(n_shards, num_envs))
+    base, extra = divmod(num_envs, n_shards)
+    out, lo = [], 0
+    for g in range(n_shards):
+        hi = lo + base + (1 if g < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def visible_device_ids():
+    """Every HIP device this process sees (HIP_VISIBLE_DEVICES applies): what `--device-ids all` expands to."""
+    import torch
+    return list(range(torch.cuda.device_count()))
+
+
+def parse_device_ids(spec):
+    """CLI form of a device list: "all" | "0,1,2,3" | "0" -> [int] (rl_baselines.train / dataset_generator --device-ids)."""
+    if spec is None:
+        return None
+    if isinstance(spec, (list, tuple)):
+        return [int(d) for d in spec]
+    spec = str(spec).strip()
+    if spec == "all":
+        ids = visible_device_ids()
+        if not ids:
+            raise _lib.SrlHipError("--device-ids all: no HIP device is visible to this process")
+        return ids
+    return [int(d) for d in spec.split(",") if d.strip() != ""]
+
+
+class _Shard(object):
+    """One GPU's block of the batch: handle, global id range [lo, hi), and what the per-step calls are bound to."""
+    __slots__ = ("h", "lo", "hi", "n", "device_id", "enc", "t", "go", "collect", "ret", "len", "quiet")
+
+
 class HipVecEnv(object):
     def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode=None,
-                 log_dir=None, allow_early_resets=False, encoder=None):
+                 log_dir=None, allow_early_resets=False, encoder=None, device_ids=None):
         kw = dict(env_kwargs or {})
         rng_mode = rng_mode or default_rng_mode()
         self.allow_early_resets, self._was_reset = bool(allow_early_resets), False
         self.env_id, self.num_envs, self.log_dir = env_id, int(num_envs), log_dir
+        self.device_ids = [int(device_id)] if device_ids is None else parse_device_ids(device_ids)
+        if not self.device_ids:
+            raise ValueError("device_ids is empty")
         kind = _env_kind(env_id)
-        cfg = _lib.default_config(kind)
-        cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = self.num_envs, device_id, first_env_id, int(seed)
-        cfg.is_discrete = int(kw.get("is_discrete", True))
-        cfg.random_target = int(kw.get("random_target", False))
-        cfg.shape_reward = int(kw.get("shape_reward", False))
-        cfg.force_down = int(kw.get("force_down", bool(cfg.force_down)))      # ctor default differs per env (Kuka2Button: False)
-        cfg.action_repeat = int(kw.get("action_repeat", 1))
-        cfg.action_joints = int(kw.get("action_joints", False))
-        cfg.multi_view = int(bool(kw.get("multi_view", False)) or bool(kw.get("fpv", False)))   # Kuka: multi_view, Mobile: fpv
-        if "max_distance" in kw:
-            cfg.max_distance = float(kw["max_distance"])
         self.srl_model = kw.get("srl_model", "raw_pixels")
-        if "img_shape" in kw:                       # (H, W); the reference renders 224 x 224
-            cfg.img_h, cfg.img_w = kw["img_shape"]
-        self._enc = None
-        if self.srl_model not in OBS_MODES:
+        learned = self.srl_model not in OBS_MODES
+        if learned:
             # a learned SRL model: pixels stay on the device, the encoder turns them into the observation
             from state_representation.registry import registered_srl, SRLType
             if registered_srl.get(self.srl_model, (None,))[0] is not SRLType.SRL:
                 raise KeyError("unknown srl_model {!r}".format(self.srl_model))
-            if encoder is None:
-                from state_representation.models import loadSRLModel
-                encoder = loadSRLModel(kw.get("srl_model_path"), cuda=True, state_dim=kw.get("state_dim"),
-                                       img_shape=(cfg.img_h, cfg.img_w), n_channels=6 if cfg.multi_view else 3)
-            self._enc = encoder
-            cfg.obs_mode, cfg.io_device = _lib.OBS_RAW_PIXELS, 1
-        else:
-            cfg.obs_mode, cfg.io_device = OBS_MODES[self.srl_model], 0
-        cfg.rng_mode, cfg.auto_reset = RNG_MODES[rng_mode], 1
-        self.cfg = cfg
-        self._h = _lib.Handle(cfg)
-        if self._enc is not None:
-            import torch
-            dev = torch.device("cuda", device_id)
-            ch = 6 if cfg.multi_view else 3
-            self._t = {"images": torch.zeros((self.num_envs, cfg.img_h, cfg.img_w, ch), dtype=torch.uint8, device=dev),
-                       "rew": torch.zeros((self.num_envs,), dtype=torch.float32, device=dev),
-                       "done": torch.zeros((self.num_envs,), dtype=torch.uint8, device=dev),
-                       "act": torch.zeros((self.num_envs,) if cfg.is_discrete else (self.num_envs, self._h.action_dim),
-                                          dtype=torch.int32 if cfg.is_discrete else torch.float32, device=dev)}
+
+        def make_cfg(n, dev, first):
+            cfg = _lib.default_config(kind)
+            cfg.num_envs, cfg.device_id, cfg.first_env_id, cfg.seed0 = n, dev, first, int(seed)
+            cfg.is_discrete = int(kw.get("is_discrete", True))
+            cfg.random_target = int(kw.get("random_target", False))
+            cfg.shape_reward = int(kw.get("shape_reward", False))
+            cfg.force_down = int(kw.get("force_down", bool(cfg.force_down)))      # ctor default differs per env (Kuka2Button: False)
+            cfg.action_repeat = int(kw.get("action_repeat", 1))
+            cfg.action_joints = int(kw.get("action_joints", False))
+            cfg.multi_view = int(bool(kw.get("multi_view", False)) or bool(kw.get("fpv", False)))   # Kuka: multi_view, Mobile: fpv
+            if "max_distance" in kw:
+                cfg.max_distance = float(kw["max_distance"])
+            if "img_shape" in kw:                       # (H, W); the reference renders 224 x 224
+                cfg.img_h, cfg.img_w = kw["img_shape"]
+            if learned:
+                cfg.obs_mode, cfg.io_device = _lib.OBS_RAW_PIXELS, 1
+            else:
+                cfg.obs_mode, cfg.io_device = OBS_MODES[self.srl_model], 0
+            cfg.rng_mode, cfg.auto_reset = RNG_MODES[rng_mode], 1
+            # full-model Kuka handles report the IK conditioning flag with every step (bit 1 of the done bytes -> infos[i]["ik_crossed"])
+            cfg.info_bits = int(kind >= _lib.ENV_KUKA_BUTTON and cfg.kuka_model == _lib.KUKA_MODEL_FULL)
+            return cfg
+
+        self._shards = []
+        for (lo, hi), dev in zip(shard_bounds(self.num_envs, len(self.device_ids)), self.device_ids):
+            sh = _Shard()
+            sh.lo, sh.hi, sh.n, sh.device_id = lo, hi, hi - lo, dev
+            sh.h = _lib.Handle(make_cfg(sh.n, dev, int(first_env_id) + lo))
+            sh.enc = sh.t = sh.go = sh.collect = sh.ret = sh.len = None
+            sh.quiet = tuple({} for _ in range(sh.n))
+            self._shards.append(sh)
+        h0 = self._shards[0].h
+        self.cfg = cfg = h0.cfg                                   # shard 0's: everything but num_envs / device_id / first_env_id is common
+        self.first_env_id = int(first_env_id)
+        self._info_bits = bool(cfg.info_bits)
+        self._enc = None
+        if learned:
+            self._enc = self._place_encoders(encoder, kw)
             self.state_dim = int(self._enc.state_dim)
+            self._alloc_device_io()
         if cfg.is_discrete:
-            self.action_space = Discrete(self._h.num_actions)
+            self.action_space = Discrete(h0.num_actions)
         else:
-            self.action_space = Box(low=-1, high=1, shape=(self._h.action_dim,), dtype=np.float32)
+            self.action_space = Box(low=-1, high=1, shape=(h0.action_dim,), dtype=np.float32)
         if self._enc is not None:
             self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.state_dim,), dtype=np.float32)
         elif cfg.obs_mode == _lib.OBS_RAW_PIXELS:
             self.observation_space = Box(low=0, high=255, shape=(cfg.img_h, cfg.img_w, 6 if cfg.multi_view else 3), dtype=np.uint8)
         else:
-            self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self._h.obs_dim,), dtype=np.float32)
-        self._actions = None
+            self.observation_space = Box(low=-np.inf, high=np.inf, shape=(h0.obs_dim,), dtype=np.float32)
+        self._actions, self._pending = None, False
+        if self._enc is None:
+            self._host = self._host_np = None
         # infos of a step in which no episode ended: ONE immutable tuple of per-env empty dicts, handed out as is (SubprocVecEnv
         # returns a tuple too); a step with episode records gets its own list
         self._quiet_infos = tuple({} for _ in range(self.num_envs))
         self._n_finished = np.zeros(self.num_envs, np.int32)
-        # per-step fast path of the ground-truth observation modes (host-pointer handle): actions are copied into ONE bound array, the
-        # foreign call is bound once (Handle.step_fn), Monitor's (r, l) are read from the handle's mapped record planes
-        # (srlhip_episode_records) — no device copy, no second call, when an episode ends
+        # per-step fast path of the host-pointer handles (ground-truth observation modes, raw pixels): GLOBAL action / obs / reward /
+        # done arrays; every shard's two foreign calls are bound ONCE to its slice of them (a step costs one srlhip_step_async and
+        # one srlhip_step_wait per shard, no per-step ctypes marshalling, no concatenation); Monitor's (r, l) are read from the
+        # shards' mapped record planes (srlhip_episode_records) — no device copy, no extra call, when an episode ends
         self._fast = None
         if self._enc is None:
-            act = np.zeros((self.num_envs,) if cfg.is_discrete else (self.num_envs, self._h.action_dim), np.int32 if cfg.is_discrete else np.float32)
-            call, obs, rew, done = self._h.step_fn(act)
-            ret, length = self._h.episode_records()
-            self._fast = {"act": act, "call": call, "obs": obs, "rew": rew, "done": done, "ret": ret, "len": length}
+            n = self.num_envs
+            act = np.zeros((n,) if cfg.is_discrete else (n, h0.action_dim), np.int32 if cfg.is_discrete else np.float32)
+            obs = np.zeros((n,) + tuple(self.observation_space.shape), self.observation_space.dtype)
+            rew, done = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+            for sh in self._shards:
+                sh.go, sh.collect = sh.h.step_split_fn(act[sh.lo:sh.hi], obs[sh.lo:sh.hi], rew[sh.lo:sh.hi], done[sh.lo:sh.hi])
+                sh.ret, sh.len = sh.h.episode_records()
+            self._fast = {"act": act, "obs": obs, "rew": rew, "done": done}
         self._mon_rows, self._mon_count, self._mon_flushed = {}, 0, time.time()
         self._t_start = time.time()
-        # bench.Monitor files, one per env like the reference (environments/utils.py:54).  They are NOT kept open: at the
-        # batch sizes this env is meant for (4096+) that would exceed RLIMIT_NOFILE; rows are appended when episodes end.
+        # bench.Monitor files, one per env like the reference (environments/utils.py:54), named by GLOBAL env id.  They are NOT kept
+        # open: at the batch sizes this env is meant for (4096+) that would exceed RLIMIT_NOFILE; rows are appended when episodes end.
         self._monitors = None
         if log_dir is not None:
             os.makedirs(log_dir, exist_ok=True)
-            self._monitors = [os.path.join(log_dir, "{}.monitor.csv".format(first_env_id + i)) for i in range(self.num_envs)]
+            self._monitors = [os.path.join(log_dir, "{}.monitor.csv".format(self.first_env_id + i)) for i in range(self.num_envs)]
             header = "#%s\nr,l,t\n" % json.dumps({"t_start": self._t_start, "env_id": env_id})
             for path in self._monitors:
                 with open(path, "wt") as f:
@@ -136,65 +201,156 @@ class HipVecEnv(object):
             ref = weakref.ref(self)
             atexit.register(lambda: ref() is not None and ref()._monitors is not None and ref()._mon_rows and ref()._flush_monitors())
 
-    # -- VecEnv API ----------------------------------------------------------------
-    def _encode(self):
-        """states of the frames the stepper just rendered (its stream) -> float32 numpy [N][state_dim]"""
-        import torch
-        if getattr(self._enc, "hip", None) is not None:
-            st = self._enc.getStates(self._t["images"], stream=self._h.stream())     # same stream: ordered behind the rasteriser
-            self._h.sync()
-        else:
-            self._h.sync()
-            st = self._enc.getStates(self._t["images"])
-            torch.cuda.synchronize()
-        return st.to("cpu").numpy()
+    # -- learned-SRL plumbing --------------------------------------------------------
+    @property
+    def _h(self):
+        """shard 0's handle (the only one of a single-GPU env)"""
+        return self._shards[0].h if self._shards else None
 
+    def _place_encoders(self, encoder, kw):
+        """One encoder replica per shard, on the shard's GPU (the reference's ONE MultiprocessSRLModel server becomes one per device).
+        `encoder`: None (load kw["srl_model_path"] / random-init per device), one model (used as is by the shards on its device,
+        replicated onto the others), or a list with one model per shard."""
+        import torch
+        cfg = self.cfg
+        from state_representation.models import loadSRLModel
+        if isinstance(encoder, (list, tuple)):
+            if len(encoder) != len(self._shards):
+                raise ValueError("encoder list: one model per shard ({}) expected".format(len(self._shards)))
+            for sh, enc in zip(self._shards, encoder):
+                sh.enc = enc
+            return encoder[0]
+        by_device = {}
+        for sh in self._shards:
+            dev = torch.device("cuda", sh.device_id)
+            if sh.device_id not in by_device:
+                if encoder is None and not by_device:
+                    by_device[sh.device_id] = loadSRLModel(kw.get("srl_model_path"), cuda=True, state_dim=kw.get("state_dim"),
+                                                           img_shape=(cfg.img_h, cfg.img_w), n_channels=6 if cfg.multi_view else 3, device=dev)
+                else:
+                    src = encoder if encoder is not None else next(iter(by_device.values()))
+                    src_dev = torch.device(getattr(src, "device", dev))
+                    same = src_dev.type == "cuda" and (src_dev.index or 0) == sh.device_id
+                    by_device[sh.device_id] = src if same else src.replicate(dev)
+            sh.enc = by_device[sh.device_id]
+        return self._shards[0].enc
+
+    def _alloc_device_io(self):
+        """Device-side step buffers per shard + ONE pinned host block per plane that every shard's results land in (global env-id order)."""
+        import torch
+        cfg, n = self.cfg, self.num_envs
+        ch = 6 if cfg.multi_view else 3
+        adim = self._shards[0].h.action_dim
+        sdt = getattr(self._enc, "state_dtype", torch.float32)
+        self._host = {"act": torch.zeros((n,) if cfg.is_discrete else (n, adim), dtype=torch.int32 if cfg.is_discrete else torch.float32).pin_memory(),
+                      "states": torch.zeros((n, self.state_dim), dtype=sdt).pin_memory(),
+                      "rew": torch.zeros((n,), dtype=torch.float32).pin_memory(), "done": torch.zeros((n,), dtype=torch.uint8).pin_memory()}
+        for sh in self._shards:
+            dev = torch.device("cuda", sh.device_id)
+            sh.t = {"images": torch.zeros((sh.n, cfg.img_h, cfg.img_w, ch), dtype=torch.uint8, device=dev),
+                    "states": torch.zeros((sh.n, self.state_dim), dtype=sdt, device=dev),
+                    "rew": torch.zeros((sh.n,), dtype=torch.float32, device=dev),
+                    "done": torch.zeros((sh.n,), dtype=torch.uint8, device=dev),
+                    "act": torch.zeros((sh.n,) if cfg.is_discrete else (sh.n, adim),
+                                       dtype=torch.int32 if cfg.is_discrete else torch.float32, device=dev)}
+        # (the pinned blocks are only ever touched by srlhip_copy_async on the handles' own streams — torch's stream bookkeeping
+        #  never sees those streams, which die with the handles)
+        self._host_np = {k: v.numpy() for k, v in self._host.items()}
+
+    def _to_host(self, sh, key):
+        """D2H of one of the shard's planes into its slice of the pinned block, on the shard's stream"""
+        dst, src = self._host[key][sh.lo:sh.hi], sh.t[key]
+        sh.h.copy_async(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size())
+
+    def _enqueue_encode(self, sh):
+        """frames the shard's stepper just rendered (its stream) -> states -> the pinned block.  HIP encoders (the C-ABI kernels) are
+        enqueued on the shard's stream: no host synchronisation, all shards overlap.  A PyTorch-backend encoder (a frame shape the
+        kernels do not cover) runs on torch's stream after a sync of this shard."""
+        if getattr(sh.enc, "hip", None) is not None:
+            sh.enc.getStates(sh.t["images"], stream=sh.h.stream(), out=sh.t["states"])
+        else:
+            import torch
+            sh.h.sync()
+            with torch.cuda.device(sh.device_id):
+                sh.t["states"].copy_(sh.enc.getStates(sh.t["images"]))
+                torch.cuda.current_stream().synchronize()
+        self._to_host(sh, "states")
+
+    # -- VecEnv API ----------------------------------------------------------------
     def reset(self):
         # stable_baselines.bench.Monitor(allow_early_resets=False) refuses a reset() in the middle of an episode
         # (environments/utils.py:54, rl_baselines/utils.py:194): here that is a reset while some env's running episode has steps
         # (checked first so that allow_early_resets costs no device read)
-        if not self.allow_early_resets and self._was_reset and (self._h.get_state(_lib.F_EP_LENGTH) > 0).any():
+        if self._pending:
+            self.step_wait()
+        if not self.allow_early_resets and self._was_reset and any((sh.h.get_state(_lib.F_EP_LENGTH) > 0).any() for sh in self._shards):
             raise RuntimeError("Tried to reset an environment before done. If you want to allow early resets, "
                                "wrap your env with Monitor(env, path, allow_early_resets=True)")
         self._was_reset = True
         if self._monitors is not None and self._mon_rows:
             self._flush_monitors()
         if self._enc is None:
-            return self._h.reset()
-        self._h.reset(obs_out=self._t["images"].data_ptr())
-        return self._encode()
+            obs = self._fast["obs"]
+            for sh in self._shards:
+                sh.h.reset(obs_out=obs[sh.lo:sh.hi])
+            return obs.copy()
+        for sh in self._shards:
+            sh.h.reset(obs_out=sh.t["images"].data_ptr())
+            self._enqueue_encode(sh)
+        for sh in self._shards:
+            sh.h.sync()
+        return self._host_np["states"].copy()
 
     def step_async(self, actions):
-        f = self._fast
+        if self._pending:
+            raise RuntimeError("step_async called twice without step_wait")
+        n = self.num_envs
+        nact = self._shards[0].h.num_actions
+        dst = self._fast["act"] if self._fast is not None else self._host_np["act"]
         if self.cfg.is_discrete:
             if isinstance(actions, np.ndarray) and actions.dtype != object:      # fast path: no `None` entries possible
-                if f is not None:
-                    self._actions = f["act"]
-                    np.copyto(self._actions, actions.reshape(self.num_envs), casting="unsafe")
-                else:
-                    self._actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.num_envs)
+                np.copyto(dst, actions.reshape(n), casting="unsafe")
             else:
-                self._actions = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
-                if f is not None:
-                    f["act"][:] = self._actions
-                    self._actions = f["act"]
-            if self._actions.size and (self._actions.min() < -1 or self._actions.max() >= self._h.num_actions):
+                dst[:] = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
+            if dst.size and (dst.min() < -1 or dst.max() >= nact):
                 # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
-                raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(self._h.num_actions))
+                raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(nact))
         else:
             # (a numeric ndarray cannot hold None: the per-element scan below would cost a 4096-iteration Python loop per step)
             if not (isinstance(actions, np.ndarray) and actions.dtype != object) and any(a is None for a in actions):
                 raise NotImplementedError("None actions need a discrete action space")
-            self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._h.action_dim)
-            if f is not None:
-                f["act"][...] = self._actions
-                self._actions = f["act"]
+            dst[...] = np.asarray(actions, dtype=np.float32).reshape(n, self._shards[0].h.action_dim)
+        self._actions = dst
+        # launch: every shard's step is in flight on its own GPU / stream when this returns
+        if self._fast is not None:
+            for sh in self._shards:
+                rc = sh.go()
+                if rc:
+                    self._drain()
+                    sh.h._check(rc, "srlhip_step_async")
+        else:
+            host = self._host
+            for sh in self._shards:
+                t = sh.t
+                a = host["act"][sh.lo:sh.hi]
+                sh.h.copy_async(t["act"].data_ptr(), a.data_ptr(), a.numel() * a.element_size())
+                sh.h.step(t["act"].data_ptr(), out=(t["images"].data_ptr(), t["rew"].data_ptr(), t["done"].data_ptr()))
+                self._enqueue_encode(sh)
+                self._to_host(sh, "rew")
+                self._to_host(sh, "done")
+        self._pending = True
+
+    def _drain(self):
+        """collect whatever is in flight after a failed launch so that the handles stay usable"""
+        for sh in self._shards:
+            if sh.h.step_pending():
+                sh.collect()
 
     def _flush_monitors(self):
         """Monitor rows are buffered per env and appended in one write per file: at 4096 envs some episode ends in every step, and an
         open / write / close per episode (15 us each) would cost more than the step.  Batches of up to 64 envs write through; larger ones
-        flush every 512 rows, every second, on reset()
-        and on close() — the reference's Monitor flushes per episode; a reader of the CSV files sees rows at most a second late."""
+        flush every 512 rows, every second (checked in every step_wait), on reset() and on close() — the reference's Monitor flushes per
+        episode; a reader of the CSV files sees rows at most a second late."""
         for i, rows in self._mon_rows.items():
             fd = os.open(self._monitors[i], os.O_WRONLY | os.O_APPEND)
             try:
@@ -204,45 +360,75 @@ class HipVecEnv(object):
         self._mon_rows, self._mon_count, self._mon_flushed = {}, 0, time.time()
 
     def step_wait(self):
+        if not self._pending:
+            raise RuntimeError("step_wait called without step_async")
+        self._pending = False
         f = self._fast
         if f is not None:
-            rc = f["call"]()
-            if rc:
-                self._h._check(rc, "srlhip_step")
+            bad = None
+            for sh in self._shards:
+                rc = sh.collect()
+                if rc and bad is None:
+                    bad = (sh, rc)
+            if bad is not None:
+                bad[0].h._check(bad[1], "srlhip_step_wait")
             # fresh arrays per step, like SubprocVecEnv's np.stack (callers keep references across steps)
             obs, rew, done = f["obs"].copy(), f["rew"].copy(), f["done"]
-        elif self._enc is None:
-            obs, rew, done = self._h.step(self._actions)
         else:
-            import torch
-            t = self._t
-            t["act"].copy_(torch.from_numpy(self._actions))
-            torch.cuda.current_stream().synchronize()                    # the actions must be in HBM before the stepper's stream reads them
-            self._h.step(t["act"].data_ptr(), out=(t["images"].data_ptr(), t["rew"].data_ptr(), t["done"].data_ptr()))
-            obs = self._encode()                                         # syncs the stepper's stream
-            rew, done = t["rew"].to("cpu").numpy(), t["done"].to("cpu").numpy()
-        dones = done.astype(bool)
+            for sh in self._shards:
+                sh.h.sync()
+            host = self._host_np
+            obs, rew, done = host["states"].copy(), host["rew"].copy(), host["done"]
+        ik = None
+        if self._info_bits:
+            ik = done >> 1                                   # srlhip_config.info_bits: the step ran under the IK conditioning flag
+            dones = (done & 1).astype(bool)
+            if not ik.any():
+                ik = None
+        else:
+            dones = done.astype(bool)
         infos = self._quiet_infos
+        if ik is not None:
+            # (include/srlhip.h SRLHIP_F_KUKA_IK_CROSSED: behind this flag the reference's own DLS controller amplifies rounding, parity
+            #  with PyBullet is not claimed; rare — random agents never raise it, saturating policies do)
+            infos = list(infos)
+            for i in np.flatnonzero(ik).tolist():
+                infos[i] = {"ik_crossed": True}
         if dones.any():
             idx = np.flatnonzero(dones)
             if f is not None:
-                ret, length = f["ret"][idx], f["len"][idx]          # mapped record planes: final once the step call has returned
+                # mapped record planes: final once the step call has returned
+                if len(self._shards) == 1:
+                    sh = self._shards[0]
+                    ret, length = sh.ret[idx], sh.len[idx]
+                else:
+                    ret, length = np.empty(len(idx), np.float64), np.empty(len(idx), np.int32)
+                    cut = np.searchsorted(idx, [sh.lo for sh in self._shards] + [self.num_envs])
+                    for g, sh in enumerate(self._shards):
+                        a, b = cut[g], cut[g + 1]
+                        if b > a:
+                            loc = idx[a:b] - sh.lo
+                            ret[a:b], length[a:b] = sh.ret[loc], sh.len[loc]
                 self._n_finished[idx] += 1
             else:
-                ret, length, fin = self._h.episode_stats()
-                ret, length, self._n_finished = ret[idx], length[idx], fin
+                stats = [sh.h.episode_stats() for sh in self._shards]
+                ret, length = np.concatenate([s[0] for s in stats])[idx], np.concatenate([s[1] for s in stats])[idx]
+                self._n_finished = np.concatenate([s[2] for s in stats])
             now = time.time()
             t = round(now - self._t_start, 6)
-            infos = list(infos)
+            if infos is self._quiet_infos:
+                infos = list(infos)
             for k, i in enumerate(idx.tolist()):
                 ep = {"r": round(float(ret[k]), 6), "l": int(length[k]), "t": t}
-                infos[i] = {"episode": ep}
+                infos[i] = dict(infos[i], episode=ep) if infos[i] else {"episode": ep}
                 if self._monitors is not None:
                     self._mon_rows.setdefault(i, []).append("{},{},{}\n".format(ep["r"], ep["l"], ep["t"]))
             if self._monitors is not None:
                 self._mon_count += len(idx)
                 if self.num_envs <= 64 or self._mon_count >= 512 or now - self._mon_flushed >= 1.0:
                     self._flush_monitors()
+        elif self._mon_rows and time.time() - self._mon_flushed >= 1.0:
+            self._flush_monitors()                        # rows of earlier steps never wait for the next episode end
         return obs, rew, dones, infos
 
     def step(self, actions):
@@ -250,37 +436,77 @@ class HipVecEnv(object):
         return self.step_wait()
 
     def rollout(self, n_steps, actions=None):
-        """Fused device-side rollout (no per-step host round trip): dict of [T][N] planes."""
+        """Fused device-side rollout (no per-step host round trip): dict of [T][N] planes, global env-id order.  With several shards
+        every GPU runs its rollout at the same time (one host thread per shard: the foreign calls release the GIL)."""
         if self._enc is not None:
             raise NotImplementedError("fused rollouts with a learned SRL encoder: use srlhip.pixel_env.PixelStateVecEnv")
-        return self._h.rollout(n_steps, actions=actions)
+        if self._pending:
+            self.step_wait()
+        if len(self._shards) == 1:
+            return self._h.rollout(n_steps, actions=actions)
+        acts = None if actions is None else np.asarray(actions)
+
+        def run(sh):
+            return sh.h.rollout(n_steps, actions=None if acts is None else np.ascontiguousarray(acts[:, sh.lo:sh.hi]))
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(self._shards)) as pool:
+            parts = list(pool.map(run, self._shards))
+        return {k: (None if parts[0][k] is None else np.concatenate([p[k] for p in parts], axis=1)) for k in parts[0]}
 
     def get_images(self):
+        if self._pending:
+            self.step_wait()
         if self._enc is not None:
-            self._h.render(out=self._t["images"].data_ptr())
-            self._h.sync()
-            return list(self._t["images"].to("cpu").numpy())
-        return list(self._h.render())
+            for sh in self._shards:
+                sh.h.render(out=sh.t["images"].data_ptr())
+            out = []
+            for sh in self._shards:
+                sh.h.sync()
+                out.extend(sh.t["images"].to("cpu").numpy())
+            return out
+        out = []
+        for sh in self._shards:
+            out.extend(sh.h.render())
+        return out
 
     def render(self, mode="human"):
         return np.array([])
 
     def seed(self, seed):
-        self._h.seed(int(seed) + self.cfg.first_env_id + np.arange(self.num_envs, dtype=np.int64))
+        for sh in self._shards:
+            sh.h.seed(int(seed) + self.first_env_id + sh.lo + np.arange(sh.n, dtype=np.int64))
 
     def episode_returns(self):
         """Per-env return/length of the last finished episode and the number of finished episodes."""
-        return self._h.episode_stats()
+        stats = [sh.h.episode_stats() for sh in self._shards]
+        return tuple(np.concatenate([s[k] for s in stats]) for k in range(3))
+
+    def ik_crossed(self):
+        """Full-model Kuka envs: int32 [N], (env-steps taken under the IK conditioning flag << 1) | the running episode's sticky bit
+        (include/srlhip.h SRLHIP_F_KUKA_IK_CROSSED)."""
+        return np.concatenate([sh.h.get_state(_lib.F_KUKA_IK_CROSSED) for sh in self._shards])
 
     def close(self):
         if self._monitors is not None and self._mon_rows:
             self._flush_monitors()
         self._monitors = None
-        self._fast = None                                # numpy views into the handle's mapped memory die with it
-        if self._h is not None:
-            self._h.close()
-            self._h = None
+        self._fast = None                                # numpy views into the handles' mapped memory die with them
+        for sh in self._shards:
+            if sh.h is not None and sh.t is not None:
+                sh.h.sync()                              # nothing of this shard's stream still writes to the buffers freed below
+        for sh in self._shards:
+            sh.go = sh.collect = sh.ret = sh.len = sh.t = None
+            if sh.h is not None:
+                sh.h.close()
+                sh.h = None
+        self._shards = []
+        self._host = self._host_np = None
 
     @property
     def unwrapped(self):
         return self
+
+
+# SURVEY §8(e) / VERDICT r5 name for the same thing: a HipVecEnv over several GPUs
+def ShardedHipVecEnv(env_id, num_envs, device_ids, **kw):
+    return HipVecEnv(env_id, num_envs, device_ids=device_ids, **kw)

@@ -114,6 +114,19 @@ class SRLNeuralNetwork(object):
             raise RuntimeError("the HIP encoder needs a GPU and 3- or 6-channel frames of 8..1024 pixels a side "
                                "(got device {}, shape {}x{})".format(self.device, img_shape, n_channels))
         self.img_shape, self.n_channels = tuple(img_shape), n_channels
+        self._backend_arg = backend
+
+    state_dtype = th.float32
+
+    def replicate(self, device):
+        """The same encoder on another GPU (one replica per shard of a multi-GPU HipVecEnv: the reference's single
+        MultiprocessSRLModel server, rl_baselines/utils.py:162-191, becomes one per device)."""
+        twin = SRLNeuralNetwork(self.state_dim, cuda=True, n_channels=self.n_channels, img_shape=self.img_shape,
+                                state_dict=self.model.state_dict(), device=device, backend=self._backend_arg)
+        for name in ("losses", "n_actions", "split_dimensions", "inverse_model_type"):
+            if hasattr(self, name):
+                setattr(twin, name, getattr(self, name))
+        return twin
 
     def folded_weights(self):
         """((conv1_w, conv1_b), (conv2_w, conv2_b), (conv3_w, conv3_b), (fc_w, fc_b)) as float32 numpy arrays in torch
@@ -177,6 +190,13 @@ class SRLPCA(object):
         self.model, self._w, self._b = None, None, None
         self.hip, self.backend = None, "gemm"
 
+    state_dtype = th.float64
+
+    def replicate(self, device):
+        twin = SRLPCA(self.state_dim, device=device)
+        twin.set_model(self.model)
+        return twin
+
     def load(self, path):
         import pickle as pkl
         try:
@@ -225,7 +245,9 @@ def _encoder_state_dict(state_dict, losses, split_dimensions):
     if other:
         raise NotImplementedError("srl model with the {} loss: srl_zoo builds CNNAutoEncoder / CNNVAE for it, only the CustomCNN encoder "
                                   "is restated here".format(" / ".join(other)))
-    if split_dimensions is not None:
+    # (the reference takes the SRLModulesSplit path only for an OrderedDict, state_representation/models.py:159; any other value — srl_zoo
+    #  is recalled to write -1 when not splitting — loads plain SRLModules)
+    if isinstance(split_dimensions, dict) and sum(split_dimensions.values()) > 0:
         raise NotImplementedError("split-dimensions models (srl_zoo SRLModulesSplit) are not restated here")
     if any(k.startswith("model.") for k in state_dict):
         stray = [k for k in state_dict if not k.startswith("model.") and not k.startswith(_SRL_HEADS)]
@@ -235,7 +257,7 @@ def _encoder_state_dict(state_dict, losses, split_dimensions):
     return dict(state_dict)
 
 
-def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_shape=(224, 224), n_channels=3):
+def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_shape=(224, 224), n_channels=3, device=None):
     """state_representation/models.py:38-107, same signature and the same checks.  With a path the log folder's exp_config.json is read
     (as an OrderedDict: the order of the losses matters to srl_zoo) — `state-dim` (required), `losses`, `n_actions`, `model-type`,
     `multi-view` (-> 6 input channels: srl_zoo sets preprocessing.N_CHANNELS = 6), `inverse-model-type`, `split-dimensions` (a dict whose
@@ -244,7 +266,7 @@ def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_sha
     dropped: _encoder_state_dict).  Only the `custom_cnn` encoder is restated (srl_zoo is an empty
     submodule in the reference checkout): other model types raise NotImplementedError instead of silently building a different
     network.  img_shape / n_channels: the frame shape the batched encoder is built for (the reference fixes it through srl_zoo
-    globals)."""
+    globals); device: the GPU a multi-GPU caller wants this replica on (default cuda:0 when cuda)."""
     import json
     from collections import OrderedDict
     model_type, losses, n_actions, model = None, None, None, None
@@ -261,8 +283,8 @@ def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_sha
         inverse_model_type = exp_config.get("inverse-model-type", "linear")
         assert state_dim is not None, "Please make sure you are loading an up to date model with a conform exp_config file."
         split_dimensions = exp_config.get("split-dimensions")
-        if isinstance(split_dimensions, OrderedDict) and sum(split_dimensions.values()) == 0:
-            split_dimensions = None                          # combine the losses instead of splitting
+        if not isinstance(split_dimensions, dict) or sum(split_dimensions.values()) == 0:
+            split_dimensions = None                          # combine the losses instead of splitting (a dict summing to 0, or no dict: -1 / None)
     else:
         assert env_object is not None or (state_dim is not None and state_dim > 0), \
             "When learning states, state_dim must be > 0. Otherwise, set SRL_MODEL_PATH to a srl_model.pth file with learned states."
@@ -270,7 +292,7 @@ def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_sha
         losses, n_actions = [], 0
     if path is not None and "baselines" in path and "pca" in path:
         model_type = "pca"
-        model = SRLPCA(state_dim, cuda)
+        model = SRLPCA(state_dim, cuda, device=device)
     assert model_type is not None or model is not None, \
         "Model type not supported. In order to use loadSRLModel, a path to an SRL model must be given."
     assert not (losses is None and not model_type == "pca"), \
@@ -288,7 +310,7 @@ def loadSRLModel(path=None, cuda=False, state_dim=None, env_object=None, img_sha
             state_dict = state_dict["state_dict"]
         if state_dict is not None:
             state_dict = _encoder_state_dict(state_dict, losses, split_dimensions)
-        model = SRLNeuralNetwork(state_dim, cuda, model_type, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict)
+        model = SRLNeuralNetwork(state_dim, cuda, model_type, n_channels=n_channels, img_shape=img_shape, state_dict=state_dict, device=device)
         model.losses, model.n_actions, model.split_dimensions, model.inverse_model_type = losses, n_actions, split_dimensions, inverse_model_type
     elif path is not None:
         model.load(path)

@@ -137,3 +137,25 @@ def test_srl_registry_and_vec_env_argument_checks():
         HipVecEnv("KukaButtonGymEnv-v0", 4, env_kwargs={"srl_model": "no_such_model"})
     with pytest.raises(KeyError):
         HipVecEnv("NoSuchEnv-v0", 4)
+
+
+def test_shard_bounds_and_device_id_parsing():
+    """HipVecEnv(device_ids=...): contiguous blocks of global env ids, as even as possible, covering [0, N) exactly once (the first
+    N % G shards hold one env more); CLI spellings of a device list."""
+    import pytest
+    from srlhip.vec_env import shard_bounds, parse_device_ids
+    assert shard_bounds(32768, 8) == [(4096 * g, 4096 * (g + 1)) for g in range(8)]
+    assert shard_bounds(1000, 3) == [(0, 334), (334, 667), (667, 1000)]
+    assert shard_bounds(37, 8) == [(0, 5), (5, 10), (10, 15), (15, 20), (20, 25), (25, 29), (29, 33), (33, 37)]
+    assert shard_bounds(1, 1) == [(0, 1)]
+    for n, g in ((4096, 7), (13, 13), (100, 9)):
+        b = shard_bounds(n, g)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:])) and max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+    for bad in ((4, 5), (4, 0)):
+        with pytest.raises(ValueError):
+            shard_bounds(*bad)
+    assert parse_device_ids(None) is None and parse_device_ids("0") == [0] and parse_device_ids("0,1, 2,3") == [0, 1, 2, 3]
+    assert parse_device_ids([3, "1"]) == [3, 1] and parse_device_ids("2,2") == [2, 2]
+    from environments import dataset_generator as dg
+    a = dg.build_parser().parse_args(["--device-ids", "0,1", "--num-cpu", "8"])
+    assert a.device_ids == "0,1" and dg.build_parser().parse_args([]).device_ids is None

@@ -66,6 +66,19 @@ def test_srl_zoo_style_checkpoint_keys(tmp_path):
             loadSRLModel(path, cuda=False, img_shape=(64, 64))
 
 
+def test_non_dict_split_dimensions_means_no_split(tmp_path):
+    """state_representation/models.py:159 takes the SRLModulesSplit path only for an OrderedDict: any other value of `split-dimensions`
+    (srl_zoo is recalled to write -1 when not splitting; also null) loads the plain SRLModules layout."""
+    folder = str(tmp_path / "logs" / "kuka" / "inverse")
+    net = CustomCNN(3, n_channels=3, img_shape=(64, 64))
+    path = os.path.join(folder, "srl_model.pth")
+    for value in (-1, None, {"inverse": 0}):
+        write_cfg(folder, {"state-dim": 3, "losses": ["inverse"], "n_actions": 6, "model-type": "custom_cnn", "split-dimensions": value})
+        torch.save({"model." + k: v for k, v in net.state_dict().items()}, path)
+        m = loadSRLModel(path, cuda=False, img_shape=(64, 64))
+        assert isinstance(m, SRLNeuralNetwork) and m.split_dimensions is None
+
+
 def test_non_conform_configs_fail_like_the_reference(tmp_path):
     folder = str(tmp_path / "a")
     write_cfg(folder, {"losses": ["autoencoder"], "n_actions": 6, "model-type": "custom_cnn"})
