@@ -17,6 +17,12 @@
 //     (lo*lo ~ 2^-22 is dropped).  Each layer's weights are pre-scaled by a power of two chosen by the packer so
 //     that the lo parts stay in f16's normal range; the scale is undone in the epilogue.  uint8 pixels are exact
 //     in f16, so layer 1 needs only the weight split (2 MFMAs per fragment), layers 2-3 need 3;
+//   * layer 1 (round 6) runs on the INT8 matrix pipe, exactly: the frame's bytes are the A operand as they are (p - 128 as i8: one XOR,
+//     no f16 unpack; a pixel is 4 bytes R G B mask), every folded layer-1 weight is a per-output-channel 24-bit fixed-point number
+//     split into three balanced base-256 digits, v_mfma_i32_32x32x32_i8 x 3 accumulate in int32 without rounding (K = 224 x 128 x 128
+//     < 2^22), and the three sums are recombined in integer arithmetic in the epilogue — 21 MFMAs of K = 32 per conv row where the
+//     f16 form takes 28 of K = 16, half the LDS fragment bytes, and the max-pool runs on int32.  The f16 layer 1 (rounds 2-5) is kept
+//     as the measured alternative (SRLHIP_ENCODER_L1=f16) and for the two-waves-per-SIMD variant;
 //   * the ImageNet normalisation of preprocessImage is folded into the layer-1 weights; the fourth input channel
 //     is a validity mask (1 inside the image, 0 in the padding ring) whose weights carry -sum_c w*mean_c/std_c
 //     per tap, which keeps zero padding in NORMALISED space exact; the folded BN bias rides on the centre tap;
@@ -56,9 +62,16 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kImg = 64, kCh = 64;
 constexpr int kS1 = 14;                 // layer-1 k-steps: K = 7 rows x (8 pixel slots x 4 channels) = 224
+constexpr int kS1i = 7;                 // int8 layer 1: one k-step per kernel row, K = 8 pixel slots x (R, G, B, mask) bytes = 32
+constexpr int kDigits = 3;              // balanced base-256 digits of a 24-bit fixed-point weight, most significant first
+constexpr int kMaskI8 = 127;            // value of the validity-mask byte of an inside pixel (its tap carries weight / 127: same scale as the colour taps)
+constexpr int kIntNegInf = -2147483647 - 1;   // max-pool padding on combined int32 sums (|sum| <= 9.4e8)
+constexpr int kWeightTopI8 = 127 * 65536 + 127 * 256 + 127;   // largest |fixed-point weight| three balanced digits hold
 constexpr int kS2 = 36;                 // layers 2/3:      K = 9 taps x 64 channels = 576
 constexpr int kB2Ahead = 6;             // layer-2 B fragments are requested this many k-steps before their MFMAs
 constexpr float kWeightTop = 16384.f;   // packer: largest |weight| of a layer after its power-of-two pre-scale
@@ -70,6 +83,7 @@ constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 
 constexpr int kMaxGroups = 4;                    // wave groups along M: 2 (4 waves, one per SIMD) or 4 (8 waves, two per SIMD)
 constexpr int IN_PITCH = 72 * 8;                 // padded input row: 72 pixels x (R, G, B, mask) f16
 constexpr int IN_BYTES = 70 * IN_PITCH;          // 3-pixel zero ring around 64x64
+constexpr int IN8_PITCH = 72 * 4;                // int8 layer 1: 72 pixels x (R, G, B, mask) i8; pixel x sits at slot x + 4 (16-byte aligned quads), rows as above
 constexpr int PX = 144;                          // pixel pitch of the f16 activation planes (128 B + 16 B skew)
 constexpr int A2_PLANE = 257 * PX;               // 16x16 pixels + one all-zero pixel (index 256)
 constexpr int A2H = IN_BYTES, A2L = A2H + A2_PLANE;
@@ -84,12 +98,15 @@ static_assert(IN_BYTES % 16 == 0 && A2_PLANE % 16 == 0 && A3_PLANE % 16 == 0, "L
 static_assert(LDS_TOTAL <= 160 * 1024, "encoder LDS map exceeds one CU");
 
 constexpr size_t kPack1Bytes = 2 * kS1 * 64 * 32, kPack2Bytes = 2 * kS2 * 64 * 32;
+constexpr size_t kPack1iBytes = 2 * kS1i * kDigits * 64 * 16;      // [n-half][k-step][digit][lane][16 i8]
 constexpr int kDefaultGroups = 2;
 
 struct EncParams {
     const uint8_t *images;      // [n][64][64][3]
     int n;
     const char *b1, *b2, *b3;   // packed B fragments: [n-half][k-step][lane][8 hi | 8 lo] f16
+    const char *b1i;            // int8 layer 1: [n-half][k-step][digit][lane][16 i8]
+    const float *inv1c;         // int8 layer 1: [64] per-output-channel 256 / fixed-point scale (powers of two)
     const float *inv_scale;     // [3] 1 / weight pre-scale of layers 1..3
     const float *bias2, *bias3, *fcw, *fcb;
     int state_dim;
@@ -130,6 +147,47 @@ template <bool PAD = false> __device__ __forceinline__ void mfma16_pinned_first(
 // order = issue order) at least four pinned MFMAs (128 cycles) behind the last MFMA that wrote them — the compiler schedules every
 // reader behind this statement, which keeps the XDL-write -> VALU-read distance the hazard recogniser cannot see
 __device__ __forceinline__ void mfma_results_ready(f32x16 &a, f32x16 &b) { asm volatile("" : "+a"(a), "+a"(b)); }
+
+// ---- int8 layer 1: pinned v_mfma_i32_32x32x32_i8.  A = 16 frame bytes per lane (VGPRs), B = 16 weight digits per lane (AGPRs: they
+// stay resident for the whole layer), accumulators in VGPRs — the epilogue reads the sums without a v_accvgpr_read per value (an MFMA's
+// vdst and srcC share one register bank: a chain cannot accumulate in AGPRs and deliver to VGPRs).
+#if ENC_X == 6          // experiment: the chains accumulate in AGPRs (with ENC_X >= 4 nothing reads them)
+#define ENC_ACC8 "a"
+#else
+#define ENC_ACC8 "v"
+#endif
+__device__ __forceinline__ void mfma8_first(i32x16 &c, i32x4 a, i32x4 b) {
+    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&" ENC_ACC8(c) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma8_next(i32x16 &c, i32x4 a, i32x4 b) {
+    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+" ENC_ACC8(c) : "v"(a), "a"(b));
+}
+// k-step `ks` of a chain (compile-time after unrolling)
+__device__ __forceinline__ void mfma8_step(int ks, i32x16 &c, i32x4 a, i32x4 b) {
+    if (ks == 0) mfma8_first(c, a, b);
+    else mfma8_next(c, a, b);
+}
+// 16 frame bytes at an 8-byte aligned LDS offset (output pixel j starts at input pixel 2 j)
+__device__ __forceinline__ i32x4 lds16u(int off) {
+    const uint2 a = *reinterpret_cast<const uint2 *>(enc_lds + off), b = *reinterpret_cast<const uint2 *>(enc_lds + off + 8);
+    i32x4 r; r[0] = (int)a.x; r[1] = (int)a.y; r[2] = (int)b.x; r[3] = (int)b.y;
+    return r;
+}
+// the three digit sums of one output -> one int32 in units of 256 fixed-point steps: 256 a2 + a1 + floor(a0 / 256).  Exact but for the
+// floor (< 1 unit in ~1e7); |result| <= 224 * 128 * kWeightTopI8 / 256 < 2^30.
+__device__ __forceinline__ int comb3(int a2, int a1, int a0) { return a2 * 256 + a1 + (a0 >> 8); }
+// the same as ONE pinned statement (ordered among the pinned MFMAs: plain VALU is not, the scheduler would issue the whole epilogue as
+// one block instead of a few instructions per MFMA gap)
+__device__ __forceinline__ int comb3_pinned(int a2, int a1, int a0) {
+    int s, u;
+    asm volatile("v_lshl_add_u32 %0, %2, 8, %3\n\tv_ashrrev_i32 %1, 8, %4\n\tv_add_u32 %0, %0, %1" : "=&v"(s), "=&v"(u) : "v"(a2), "v"(a1), "v"(a0));
+    return s;
+}
+__device__ __forceinline__ int max3_pinned(int a, int b, int c) {
+    int m;
+    asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
 
 // f32 -> (hi, lo) f16 planes at byte offset `off` inside the plane pair starting at hbase / lbase
 __device__ __forceinline__ void store_split(int hbase, int lbase, int off, float v, bool &ovf) {
@@ -177,6 +235,30 @@ template <bool PAD> __device__ __forceinline__ void conv1_single(const half8 (&B
     for (int r = 0; r < 16; r++) v0[r] = a0[r] + a1[r];
 }
 
+// int8 layer 1, not pipelined: one conv row -> its three digit sums (21 pinned MFMAs, the three chains rotating)
+__device__ __forceinline__ void conv1_row_i8(const i32x4 (&Bd)[kDigits][kS1i], int ra, int lane_base, i32x16 (&R)[kDigits]) {
+    const int base0 = 2 * ra * IN8_PITCH + lane_base;
+    i32x4 x0 = lds16u(base0);
+#pragma unroll
+    for (int ks = 0; ks < kS1i; ks++) {
+        i32x4 y0 = x0;
+#pragma unroll
+        for (int d = 0; d < kDigits; d++) {
+            mfma8_step(ks, R[d], x0, Bd[d][ks]);
+            if (d == 0 && ks + 1 < kS1i) y0 = lds16u(base0 + (ks + 1) * IN8_PITCH);
+        }
+        x0 = y0;
+    }
+}
+// one conv row -> combined int32 sums
+__device__ __forceinline__ void conv1_single_i8(const i32x4 (&Bd)[kDigits][kS1i], int ra, int lane_base, i32x16 &out) {
+    i32x16 R[kDigits];
+    conv1_row_i8(Bd, ra, lane_base, R);
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]));      // XDL write -> VALU read distance (see mfma_fence)
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[r] = comb3(R[0][r], R[1][r], R[2][r]);
+}
+
 // PROF: workgroup 0 stamps s_memtime at 9 points of its first kProfFrames frames (srlhip_encoder_phase_cycles)
 constexpr int kProfFrames = 8, kProfStamps = 9, kProfWaves = 2 * kMaxGroups;
 #define ENC_STAMP(k)                                                                                          \
@@ -187,14 +269,17 @@ constexpr int kProfFrames = 8, kProfStamps = 9, kProfWaves = 2 * kMaxGroups;
 
 // MG = wave groups along M (output pixels): group g owns 16/MG pooled layer-1 rows, 8/MG layer-2 tiles, 36/MG of
 // layer 3's k-steps; the two waves of a group own 32 output channels each.
-template <bool PROF, int MG>
+// I8 = layer 1 on the int8 matrix pipe (the product; MG = 2 only), else the split-f16 layer 1 of rounds 2-5.
+template <bool PROF, int MG, bool I8>
 __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
+    static_assert(!I8 || MG == 2, "the int8 layer 1 is written for one wave per SIMD");
     constexpr int kThreads = 128 * MG, kRows1 = 16 / MG, kTiles2 = 8 / MG, kSteps3 = kS2 / MG;
     constexpr int kRawIters = (768 + kThreads - 1) / kThreads;          // 16-byte pieces of a frame per thread
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int mh = wave >> 1, nh = wave & 1;      // which wave group (part of the pixels) / half of the output channels this wave owns
-    const int j = lane & 31, h = lane >> 5;       // MFMA lane coordinates: column (channel) j, k / row half h
-    const int ch = 32 * nh + j;                   // the output channel this lane owns in every layer
+    const int tid0 = threadIdx.x;
+    int tid = tid0, wave = tid >> 6, lane = tid & 63;
+    int mh = wave >> 1, nh = wave & 1;            // which wave group (part of the pixels) / half of the output channels this wave owns
+    int j = lane & 31, h = lane >> 5;             // MFMA lane coordinates: column (channel) j, k / row half h
+    int ch = 32 * nh + j;                         // the output channel this lane owns in every layer
     bool ovf = false;
 
     // -- once per workgroup: zero the padded input (ring stays zero), the all-zero pixels; stage the first frame
@@ -206,7 +291,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
         *reinterpret_cast<uint4 *>(enc_lds + A3L + 49 * PX + tid * 16) = make_uint4(0, 0, 0, 0);
     }
     const float bias2 = P.bias2[ch], bias3 = P.bias3[ch];
-    const float inv1 = P.inv_scale[0], inv2 = P.inv_scale[1], inv3 = P.inv_scale[2];
+    const float inv1 = I8 ? P.inv1c[ch] : P.inv_scale[0], inv2 = P.inv_scale[1], inv3 = P.inv_scale[2];
     if (blockIdx.x < P.n) {                       // first frame of this workgroup (later ones are prefetched in layer 2)
         const uint4 *src = reinterpret_cast<const uint4 *>(P.images + (size_t)blockIdx.x * (kImg * kImg * 3));
         uint4 *raw = reinterpret_cast<uint4 *>(enc_lds + RAW);
@@ -216,9 +301,213 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
     }
     __syncthreads();
 
+    // int8 layer 1: this wave's weight digits, 84 AGPRs, loaded ONCE per workgroup and resident across frames (the AGPR half of the
+    // register file is otherwise idle outside the accumulators; the f16 form reloads its 112 VGPRs of fragments every frame).  The
+    // pinned statement puts them in their AGPRs here: a v_accvgpr_write the compiler would otherwise sink in front of its first pinned
+    // MFMA is the VALU-write -> MFMA-operand hazard the recogniser cannot see inside the statement (ISA lint rule B).
+    i32x4 Bd[kDigits][kS1i];
+    if constexpr (I8) {
+#pragma unroll
+        for (int s = 0; s < kS1i; s++)
+#pragma unroll
+            for (int d = 0; d < kDigits; d++)
+                Bd[d][s] = *reinterpret_cast<const i32x4 *>(P.b1i + ((size_t)((nh * kS1i + s) * kDigits + d) * 64 + lane) * 16);
+#pragma unroll
+        for (int d = 0; d < kDigits; d++)
+            asm volatile("s_nop 4" : "+a"(Bd[d][0]), "+a"(Bd[d][1]), "+a"(Bd[d][2]), "+a"(Bd[d][3]), "+a"(Bd[d][4]), "+a"(Bd[d][5]), "+a"(Bd[d][6]));
+    }
+
+    // layer 3's A-fragment offsets (lane constants with a division each): computed once per workgroup, explicitly — the int8 variant
+    // re-derives the lane coordinates per frame (below) and would otherwise recompute them between layer 3's pinned MFMAs
+    int a3o[kSteps3];
+    {
+        const int oy = (j >> 2) & 3, ox = j & 3;
+#pragma unroll
+        for (int ii = 0; ii < kSteps3; ii++) {
+            const int s = kSteps3 * mh + ii, tap = s >> 2, q = s & 3;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
+            const bool ok = j < 16 && (unsigned)sy < 7u && (unsigned)sx < 7u;
+            a3o[ii] = (ok ? sy * 7 + sx : 49) * PX + h * 16 + q * 32;
+        }
+    }
+
     int frame = 0;
     for (int img = blockIdx.x; img < P.n; img += gridDim.x, frame++) {
+        if constexpr (I8) {
+            // The lane coordinates are re-derived per frame from an opaque copy of the thread id: everything computed from them (dozens of
+            // LDS / global addresses of layers 2, 3 and the FC) is then recomputed where it is used instead of being hoisted out of the
+            // frame loop and kept live across it — with the digits resident in AGPRs those hoisted values were spilled to scratch and
+            // reloaded inside the layer-2 / layer-3 epilogues (+5 k cycles per frame).
+            tid = tid0;
+            asm volatile("" : "+v"(tid));
+            wave = tid >> 6; lane = tid & 63; mh = wave >> 1; nh = wave & 1; j = lane & 31; h = lane >> 5; ch = 32 * nh + j;
+        }
         ENC_STAMP(0);
+        if constexpr (I8) {
+        // ---- int8 layer 1 -------------------------------------------------------------------------------------------------------------
+        // ---- phase 0: uint8 frame (staged in LDS) -> (R - 128, G - 128, B - 128, 127) int8 pixels inside the zero ring: p ^ 0x80 per byte;
+        // the validity mask is 127, not 1, so that its tap (weight / 127) is quantised on the same scale as the colour taps (|p - 128| <= 128)
+        uint32_t rawq[1024 / kThreads][3];
+#pragma unroll
+        for (int i = 0; i < 1024 / kThreads; i++) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(enc_lds + RAW + 12 * (tid + kThreads * i));
+            rawq[i][0] = w[0]; rawq[i][1] = w[1]; rawq[i][2] = w[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 1024 / kThreads; i++) {
+            const int q = tid + kThreads * i;                              // four consecutive pixels = 12 bytes
+            const uint32_t w0 = rawq[i][0], w1 = rawq[i][1], w2 = rawq[i][2];
+            const uint32_t px[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
+            const int y = (4 * q) >> 6, x = (4 * q) & 63;
+            *reinterpret_cast<uint4 *>(enc_lds + ((y + 3) * 72 + (x + 4)) * 4) =
+                make_uint4((px[0] ^ 0x808080u) | 0x7f000000u, (px[1] ^ 0x808080u) | 0x7f000000u, (px[2] ^ 0x808080u) | 0x7f000000u, (px[3] ^ 0x808080u) | 0x7f000000u);
+        }
+        __syncthreads();
+        ENC_STAMP(1);
+        // wave group g owns pooled rows R g .. R g + R-1 <- conv rows 2R g - 1 .. 2R (g+1) - 1 (its first row is recomputed, not exchanged).
+        // Output pixel j of a conv row reads input pixels 2 j - 3 .. 2 j + 3 = slots 2 j + 1 .. 2 j + 7: the fragment starts at slot 2 j
+        // (8-byte aligned), its first slot carries zero weights.
+        {
+            const int lane_base = j * 8 + h * 16;
+            i32x16 carry;
+            i32x16 R0[kDigits], R1[kDigits];
+            if (mh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) carry[r] = kIntNegInf;        // conv row -1 is pool padding
+            } else {
+                conv1_single_i8(Bd, 2 * kRows1 * mh - 1, lane_base, carry);
+            }
+            conv1_row_i8(Bd, 2 * kRows1 * mh, lane_base, R0);
+            conv1_row_i8(Bd, 2 * kRows1 * mh + 1, lane_base, R1);
+            // One pipeline step = csrc/encoder_l1_step.inc (GENERATED by gen/gen_encoder_l1_step.py: every MFMA gap holds at most seven
+            // other instructions).  N0 <- conv row 2 prow + 2 (slots 0..20), N1 <- conv row 2 prow + 3 (slots 21..41): 21 pinned MFMAs
+            // each, k-step major, the three digit chains rotating.  In their shadow: the A fragments two k-steps ahead (three rotating
+            // registers F0..F2; the last two loads of a step are the next step's first fragments), pooled row prow <- (carry, S0, Q1)
+            // — S0 = row 0 of the previous pair, already recombined; Q1 = row 1's three digit sums — and this pair's row-0 recombination
+            // into S0.  carry <- Q1 recombined.  Every VALU piece is a pinned statement (plain VALU is not ordered against the MFMAs).
+            i32x16 S0;
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(R0[0]), "+v"(R0[1]), "+v"(R0[2]));
+#pragma unroll
+            for (int r = 0; r < 16; r++) S0[r] = comb3(R0[0][r], R0[1][r], R0[2][r]);
+            const unsigned long long hmask = 0xffffffff00000000ull;          // lanes 32..63: h = 1
+            int mx = 0;                                                      // largest pooled value of the layer (overflow watch)
+            auto step = [&](int prow, i32x16 (&Q1)[kDigits], i32x16 (&N1)[kDigits], i32x4 &F0, i32x4 &F1, i32x4 &F2) {
+                const int base0 = 2 * (2 * prow + 2) * IN8_PITCH + lane_base;
+                i32x16 N0[kDigits];
+                i32x16 m;
+                int neg = kIntNegInf, left[4], ka[4], kb[4];
+                float pf[4][2];
+                unsigned phi[4][2];
+                int baseH = 0, baseL = 0;
+#define L1_MF(row, ks, d, fv) mfma8_step(ks, (row) ? N1[d] : N0[d], F##fv, Bd[d][ks])
+#define L1_LD(n, fv) F##fv = lds16u(base0 + (((n) / kS1i) * 2 + (n) % kS1i) * IN8_PITCH)
+#define L1_BASE() do { baseH = A2H + (prow * 16 + 2 * h) * PX + ch * 2; baseL = baseH + A2_PLANE; } while (0)
+#define L1_READY() asm volatile("" : "+v"(Q1[0]), "+v"(Q1[1]), "+v"(Q1[2]))
+                // row 1 of the previous pair, register r: digits -> one int32; 3-row max; the row becomes the next pair's carry
+#define L1_C1(r) do { int s1_, m_;                                                                                          \
+        asm volatile("v_lshl_add_u32 %0, %2, 8, %3\n\tv_ashrrev_i32 %1, 8, %4\n\tv_add_u32 %0, %0, %1\n\tv_max3_i32 %1, %5, %6, %0" \
+                     : "=&v"(s1_), "=&v"(m_) : "v"(Q1[0][r]), "v"(Q1[1][r]), "v"(Q1[2][r]), "v"(carry[r]), "v"(S0[r]));              \
+        carry[r] = s1_; m[r] = m_; } while (0)
+                // row 0 of THIS pair, register r (its chains finished at slot 20)
+#define L1_C0(r) do { int s0_, u_;                                                                                          \
+        asm volatile("v_lshl_add_u32 %0, %2, 8, %3\n\tv_ashrrev_i32 %1, 8, %4\n\tv_add_u32 %0, %0, %1"                       \
+                     : "=&v"(s0_), "=&v"(u_) : "v"(N0[0][r]), "v"(N0[1][r]), "v"(N0[2][r]));                                  \
+        S0[r] = s0_; } while (0)
+                // pooled pixel 2 h + 1 of group g: window registers 4 g + 1 .. 4 g + 3, ReLU in integers
+#define L1_KB(g) asm volatile("v_max3_i32 %0, %1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=&v"(kb[g]) : "v"(m[4 * (g) + 1]), "v"(m[4 * (g) + 2]), "v"(m[4 * (g) + 3]))
+                // the pixel left of a lane's 4-group is lane^32's: h = 1 lanes need the partner's register 4 g + 3, h = 0 lanes its register
+                // 4 g - 1 (nothing for g = 0).  v_permlane32_swap A, B exchanges A's upper with B's lower half-wave: A = m[4 g - 1], B = m[4 g + 3],
+                // in place (KB(g), KB(g - 1) have read them; the half of B the next group needs is the one the swap leaves alone)
+#define L1_XC(g) do { int a_ = (g) ? m[(g) ? 4 * (g) - 1 : 0] : neg, b_ = m[4 * (g) + 3];                                 \
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_cndmask_b32_e64 %2, %1, %0, %3"                             \
+                     : "+v"(a_), "+v"(b_), "=&v"(left[g]) : "s"(hmask));                                                       \
+        m[4 * (g) + 3] = b_; } while (0)
+#define L1_KA(g) asm volatile("v_max3_i32 %0, %1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=&v"(ka[g]) : "v"(m[4 * (g)]), "v"(m[4 * (g) + 1]), "v"(left[g]))
+#define L1_MX(g) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(mx) : "v"(ka[g]), "v"(kb[g]))
+                // pooled pixel (g, u): int -> f32 scale -> f16 hi -> A2H; then lo = f16(f - hi) -> A2L
+#define L1_PB(g, u) do { asm volatile("v_cvt_f32_i32 %0, %2\n\tv_mul_f32 %0, %3, %0\n\tv_cvt_f16_f32 %1, %0"               \
+                                      : "=&v"(pf[g][u]), "=&v"(phi[g][u]) : "v"((u) ? kb[g] : ka[g]), "v"(inv1));              \
+        *reinterpret_cast<unsigned short *>(enc_lds + baseH + (4 * (g) + (u)) * PX) = (unsigned short)phi[g][u]; } while (0)
+#define L1_PC(g, u) do { unsigned lo_;                                                                                      \
+        asm volatile("v_cvt_f32_f16 %0, %1\n\tv_sub_f32 %0, %2, %0\n\tv_cvt_f16_f32 %0, %0" : "=&v"(lo_) : "v"(phi[g][u]), "v"(pf[g][u])); \
+        *reinterpret_cast<unsigned short *>(enc_lds + baseL + (4 * (g) + (u)) * PX) = (unsigned short)lo_; } while (0)
+#if ENC_X >= 4          // experiments 4-6: the bare MFMA + fragment-load stream of the step (results are wrong by construction)
+#undef L1_READY
+#undef L1_C1
+#undef L1_C0
+#undef L1_KB
+#undef L1_XC
+#undef L1_KA
+#undef L1_MX
+#undef L1_PB
+#undef L1_PC
+#define L1_READY() (void)0
+#define L1_C1(r) (void)0
+#define L1_C0(r) (void)0
+#define L1_KB(g) (void)0
+#define L1_XC(g) (void)0
+#define L1_KA(g) (void)0
+#define L1_MX(g) (void)0
+#define L1_PB(g, u) (void)0
+#define L1_PC(g, u) (void)0
+#endif
+#if ENC_X == 5          // ... without the fragment loads
+#undef L1_LD
+#define L1_LD(n, fv) (void)0
+#endif
+#include "encoder_l1_step.inc"
+#if ENC_X >= 4
+                asm volatile("" :: ENC_ACC8(N0[0]), ENC_ACC8(N0[1]), ENC_ACC8(N0[2]), ENC_ACC8(N1[0]), ENC_ACC8(N1[1]), ENC_ACC8(N1[2]));
+#endif
+#undef L1_MF
+#undef L1_LD
+#undef L1_BASE
+#undef L1_READY
+#undef L1_C1
+#undef L1_C0
+#undef L1_KB
+#undef L1_XC
+#undef L1_KA
+#undef L1_MX
+#undef L1_PB
+#undef L1_PC
+            };
+            static_assert((kRows1 - 1) % 2 == 1, "the pipeline below is written for an odd number of hidden pooled rows");
+            i32x16 W1[kDigits];
+            int prow = kRows1 * mh;
+            // the first step's first two fragments (conv row 2 prow + 2, k-steps 0 and 1)
+            i32x4 F0 = lds16u(2 * (2 * prow + 2) * IN8_PITCH + lane_base), F1 = lds16u(2 * (2 * prow + 2) * IN8_PITCH + lane_base + IN8_PITCH), F2 = F0;
+#pragma unroll 1
+            for (int pp = 0; pp < (kRows1 - 1) / 2; pp++, prow += 2) {
+                step(prow, R1, W1, F0, F1, F2);
+                step(prow + 1, W1, R1, F2, F0, F1);        // a step leaves the next one's fragments in its third and first register
+                F0 = F1; F1 = F2;
+            }
+            step(prow, R1, W1, F0, F1, F2);
+            // the last pooled row of this group: nothing left to hide it behind
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(W1[0]), "+v"(W1[1]), "+v"(W1[2]));
+            {
+                const int last = kRows1 * mh + kRows1 - 1;
+                i32x16 m;
+#pragma unroll
+                for (int r = 0; r < 16; r++) m[r] = max(carry[r], max(S0[r], comb3(W1[0][r], W1[1][r], W1[2][r])));
+                const int t3 = __shfl_xor(m[3], 32), t7 = __shfl_xor(m[7], 32), t11 = __shfl_xor(m[11], 32), t15 = __shfl_xor(m[15], 32);
+                const int left[4] = {h ? t3 : kIntNegInf, h ? t7 : t3, h ? t11 : t7, h ? t15 : t11};
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int ka = max(max(max(m[4 * g], m[4 * g + 1]), left[g]), 0);
+                    const int kb = max(max(max(m[4 * g + 1], m[4 * g + 2]), m[4 * g + 3]), 0);
+                    mx = max(mx, max(ka, kb));
+                    const int k = 4 * g + 2 * h;
+                    bool dummy = false;
+                    store_split(A2H, A2L, (last * 16 + k) * PX + ch * 2, (float)ka * inv1, dummy);
+                    store_split(A2H, A2L, (last * 16 + k + 1) * PX + ch * 2, (float)kb * inv1, dummy);
+                }
+            }
+            ovf |= !((float)mx * inv1 < kF16Max);
+        }
+        } else {
         // this wave's layer-1 B fragments (112 VGPRs, in registers for the whole layer): requested before the unpack.
         // (Keeping them — or layer 3's — resident across frames starves the layer-2 loop of registers: its prefetch
         // ring then becomes loop-carried copies behind `s_waitcnt vmcnt(0)` and spills; measured slower.)
@@ -369,6 +658,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
                 }
             }
         }
+        }
         ENC_STAMP(2);
         __syncthreads();
         ENC_STAMP(3);
@@ -513,15 +803,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
         // ---- layer 3: conv3x3/2 p1 (7x7 -> 4x4) + ReLU + maxpool3/2 (-> 1x1); K split over the wave groups ----
         {
             f32x16 c0;
-            const bool pix = j < 16;
-            const int oy = (j >> 2) & 3, ox = j & 3;
-            auto a3_addr = [&](int ii) {
-                const int s = kSteps3 * mh + ii, tap = s >> 2, q = s & 3;
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
-                const bool ok = pix && (unsigned)sy < 7u && (unsigned)sx < 7u;
-                return (ok ? sy * 7 + sx : 49) * PX + h * 16 + q * 32;
-            };
+            auto a3_addr = [&](int ii) { return a3o[ii]; };
             {
                 // three chains (hi*hi, hi*lo, lo*hi), pinned in issue order so that no MFMA waits for its predecessor; the next k-step's
                 // two A fragments are requested between them (the compiler's schedule read them right before their use and chained the
@@ -633,6 +915,54 @@ float pack_layer1(const float *w, const float *b, _Float16 *out) {
                 }
     return scale;
 }
+// int8 layer 1: the same folded taps around p - 128.  k = ky * 32 + slot * 4 + c4; slot 0 carries zero weights (the fragment of output
+// pixel j starts at input pixel 2 j - 4), slot s >= 1 is kernel column kx = s - 1; c4 < 3: w / (255 std_c) (multiplies p - 128); c4 = 3, the
+// validity mask (byte value 127 inside the frame, 0 in the ring): [sum_c w_c (128 / 255 - mean_c) / std_c — zero padding stays exact
+// in NORMALISED space — plus the folded BN bias on the centre tap] / 127.
+double layer1_weight_i8(const float *w, const float *b, int o, int k) {
+    const int ky = k / 32, slot = (k % 32) / 4, c4 = k % 4, kx = slot - 1;
+    double v = 0.0;
+    if (slot >= 1) {
+        if (c4 < 3) {
+            v = (double)w[((o * 3 + c4) * 7 + kx) * 7 + ky] / (255.0 * (double)kStd[c4]);
+        } else {
+            for (int c = 0; c < 3; c++) v += (double)w[((o * 3 + c) * 7 + kx) * 7 + ky] * (128.0 / 255.0 - (double)kMean[c]) / (double)kStd[c];
+            if (ky == 3 && kx == 3) v += (double)b[o];
+            v /= (double)kMaskI8;
+        }
+    }
+    return v;
+}
+// out: [n-half][k-step][digit][lane][16 i8], digit 0 = most significant; inv256[o] = 256 / scale_o, scale_o = the largest power of two
+// with max_k |w| scale_o <= kWeightTopI8: weight = (65536 d0 + 256 d1 + d2) / scale_o with balanced digits in [-128, 127].
+void pack_layer1_i8(const float *w, const float *b, int8_t *out, float *inv256) {
+    for (int o = 0; o < 64; o++) {
+        double wmax = 0.0;
+        for (int k = 0; k < 32 * kS1i; k++) wmax = fmax(wmax, fabs(layer1_weight_i8(w, b, o, k)));
+        int e = 0;
+        if (wmax > 0.0 && std::isfinite(wmax)) {
+            frexp((double)kWeightTopI8 / wmax, &e);      // kWeightTopI8 / wmax = f * 2^e, f in [0.5, 1)
+            e = e - 1 > 60 ? 60 : (e - 1 < -60 ? -60 : e - 1);
+        }
+        const double scale = ldexp(1.0, e);
+        inv256[o] = (float)(256.0 / scale);
+        const int nh = o >> 5;
+        for (int k = 0; k < 32 * kS1i; k++) {
+            long long z = llround(layer1_weight_i8(w, b, o, k) * scale);
+            if (z > kWeightTopI8) z = kWeightTopI8;
+            if (z < -kWeightTopI8) z = -kWeightTopI8;
+            int dg[kDigits];
+            for (int d = kDigits - 1; d >= 0; d--) {          // least significant first
+                long long r = ((z + 128) % 256 + 256) % 256 - 128;
+                dg[d] = (int)r;
+                z = (z - r) / 256;
+            }
+            const int s = k / 32, hh = (k % 32) / 16, el = k % 16, lane = hh * 32 + (o & 31);
+            for (int d = 0; d < kDigits; d++)
+                out[((size_t)((nh * kS1i + s) * kDigits + d) * 64 + lane) * 16 + el] = (int8_t)dg[d];
+        }
+    }
+}
 }  // namespace
 
 namespace srlenc {
@@ -674,6 +1004,9 @@ struct srlhip_encoder {
     int *d_status;
     int num_cus;
     int groups;            // wave groups along M: 2 = 4 waves per workgroup, 4 = 8 waves
+    int l1_i8;             // layer 1 on the int8 matrix pipe (default with groups == 2); SRLHIP_ENCODER_L1=f16 keeps the split-f16 form
+    char *d_pack_i8;       // int8 layer-1 digits
+    float *d_inv1c;        // [64] per-channel 256 / scale
     srlenc::General *general;   // non-null: the layered path of encoder_general.hip serves this handle (any shape but 64x64x3)
     int img_h, img_w, n_channels;
     std::string err;
@@ -693,6 +1026,14 @@ bool supported_shape(int img_h, int img_w, int n_channels) { return srlenc::geom
 extern "C" {
 
 size_t srlhip_encoder_pack_bytes(void) { return kPack1Bytes + 2 * kPack2Bytes; }
+
+size_t srlhip_encoder_pack_i8_bytes(void) { return kPack1iBytes; }
+
+int srlhip_encoder_pack_i8(const float *conv1_w, const float *conv1_b, void *out, size_t out_bytes, float *inv_scale64) {
+    if (!conv1_w || !conv1_b || !out || !inv_scale64 || out_bytes < kPack1iBytes) return SRLHIP_EINVAL;
+    pack_layer1_i8(conv1_w, conv1_b, static_cast<int8_t *>(out), inv_scale64);
+    return SRLHIP_OK;
+}
 
 int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv3_w,
                         void *out, size_t out_bytes, float *scales3) {
@@ -732,7 +1073,7 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
         srlhip_encoder *e = new (std::nothrow) srlhip_encoder();
         if (!e) return SRLHIP_ENOMEM;
         e->device_id = device_id; e->state_dim = state_dim; e->d_pack = nullptr; e->d_f32 = nullptr; e->d_status = nullptr; e->general = nullptr;
-        e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels;
+        e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels; e->d_pack_i8 = nullptr; e->d_inv1c = nullptr; e->l1_i8 = 0;
         const int rc = srlenc::general_create(device_id, srlenc::geometry(img_h, img_w, n_channels), state_dim, conv1_w, conv1_b, conv2_w, conv2_b,
                                               conv3_w, conv3_b, fc_w, fc_b, &e->general, g_enc_create_error);
         if (rc != SRLHIP_OK) { delete e; return rc; }
@@ -748,7 +1089,10 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     srlhip_encoder *e = new (std::nothrow) srlhip_encoder();
     if (!e) return SRLHIP_ENOMEM;
     e->device_id = device_id; e->state_dim = state_dim; e->d_pack = nullptr; e->d_f32 = nullptr; e->d_status = nullptr; e->general = nullptr;
-    e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels;
+    e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels; e->d_pack_i8 = nullptr; e->d_inv1c = nullptr; e->l1_i8 = 0;
+    std::vector<int8_t> pack_i8(kPack1iBytes);
+    float inv1c[64];
+    pack_layer1_i8(conv1_w, conv1_b, pack_i8.data(), inv1c);
 #define ENC_CHECK(expr)                                                                              \
     do {                                                                                             \
         hipError_t e__ = (expr);                                                                     \
@@ -776,13 +1120,21 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     ENC_CHECK(hipMemcpy(e->d_pack, pack.data(), pack.size(), hipMemcpyHostToDevice));
     ENC_CHECK(hipMemcpy(e->d_f32, f.data(), nf * sizeof(float), hipMemcpyHostToDevice));
     ENC_CHECK(hipMemset(e->d_status, 0, sizeof(int)));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipMalloc(reinterpret_cast<void **>(&e->d_pack_i8), kPack1iBytes));
+    ENC_CHECK(hipMalloc(reinterpret_cast<void **>(&e->d_inv1c), sizeof inv1c));
+    ENC_CHECK(hipMemcpy(e->d_pack_i8, pack_i8.data(), kPack1iBytes, hipMemcpyHostToDevice));
+    ENC_CHECK(hipMemcpy(e->d_inv1c, inv1c, sizeof inv1c, hipMemcpyHostToDevice));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<false, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    ENC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_k<true, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     {
         const char *w = getenv("SRLHIP_ENCODER_WAVES");       // experiment knob: 4 (one wave per SIMD) or 8 (two)
         e->groups = (w && atoi(w) == 4) ? 2 : (w && atoi(w) == 8) ? 4 : kDefaultGroups;
+        const char *l1 = getenv("SRLHIP_ENCODER_L1");         // experiment knob: f16 = the split-f16 layer 1 of rounds 2-5
+        e->l1_i8 = e->groups == 2 && !(l1 && strcmp(l1, "f16") == 0);
     }
 #undef ENC_CHECK
     *out = e;
@@ -803,9 +1155,11 @@ int srlhip_encoder_forward(srlhip_encoder_handle e, const uint8_t *images_dev, i
     p.inv_scale = e->d_f32; p.bias2 = e->d_f32 + 4; p.bias3 = e->d_f32 + 68; p.fcw = e->d_f32 + 132;
     p.fcb = e->d_f32 + 132 + (size_t)e->state_dim * kCh;
     p.state_dim = e->state_dim; p.out = states_dev; p.status = e->d_status; p.prof = nullptr;
+    p.b1i = e->d_pack_i8; p.inv1c = e->d_inv1c;
     const int grid = n < e->num_cus ? n : e->num_cus;
-    if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<false, 2>), dim3(grid), dim3(256), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
-    else hipLaunchKernelGGL((encoder_fwd_k<false, 4>), dim3(grid), dim3(512), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
+    if (e->groups == 2 && e->l1_i8) hipLaunchKernelGGL((encoder_fwd_k<false, 2, true>), dim3(grid), dim3(256), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
+    else if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<false, 2, false>), dim3(grid), dim3(256), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
+    else hipLaunchKernelGGL((encoder_fwd_k<false, 4, false>), dim3(grid), dim3(512), LDS_TOTAL, static_cast<hipStream_t>(hip_stream), p);
     rc = hipGetLastError();
     if (rc != hipSuccess) return e->fail(SRLHIP_EHIP, std::string("encoder_fwd_k launch: ") + hipGetErrorString(rc));
     return SRLHIP_OK;
@@ -832,9 +1186,11 @@ int srlhip_encoder_phase_cycles(srlhip_encoder_handle e, const uint8_t *images_d
     p.inv_scale = e->d_f32; p.bias2 = e->d_f32 + 4; p.bias3 = e->d_f32 + 68; p.fcw = e->d_f32 + 132;
     p.fcb = e->d_f32 + 132 + (size_t)e->state_dim * kCh;
     p.state_dim = e->state_dim; p.out = states_dev; p.status = e->d_status; p.prof = d_prof;
+    p.b1i = e->d_pack_i8; p.inv1c = e->d_inv1c;
     const int grid = n < e->num_cus ? n : e->num_cus;
-    if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<true, 2>), dim3(grid), dim3(256), LDS_TOTAL, nullptr, p);
-    else hipLaunchKernelGGL((encoder_fwd_k<true, 4>), dim3(grid), dim3(512), LDS_TOTAL, nullptr, p);
+    if (e->groups == 2 && e->l1_i8) hipLaunchKernelGGL((encoder_fwd_k<true, 2, true>), dim3(grid), dim3(256), LDS_TOTAL, nullptr, p);
+    else if (e->groups == 2) hipLaunchKernelGGL((encoder_fwd_k<true, 2, false>), dim3(grid), dim3(256), LDS_TOTAL, nullptr, p);
+    else hipLaunchKernelGGL((encoder_fwd_k<true, 4, false>), dim3(grid), dim3(512), LDS_TOTAL, nullptr, p);
     ENC_RC(hipGetLastError());
     std::vector<long long> host(words);
     ENC_RC(hipMemcpy(host.data(), d_prof, words * sizeof(long long), hipMemcpyDeviceToHost));
@@ -880,6 +1236,8 @@ int srlhip_encoder_destroy(srlhip_encoder_handle e) {
     (void)hipSetDevice(e->device_id);
     if (e->general) srlenc::general_destroy(e->general);
     if (e->d_pack) (void)hipFree(e->d_pack);
+    if (e->d_pack_i8) (void)hipFree(e->d_pack_i8);
+    if (e->d_inv1c) (void)hipFree(e->d_inv1c);
     if (e->d_f32) (void)hipFree(e->d_f32);
     if (e->d_status) (void)hipFree(e->d_status);
     delete e;

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(REPO, "include", "srlhip.h")).read()
-    return sorted(set(re.findall(r"\b(srlhip_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(srlhip_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -50,6 +50,11 @@ def emulate(img, w1, w2, w3, b2, b3, fcw, fcb):
         for ox in range(32):
             patch = inp[2 * oy:2 * oy + 7, 2 * ox:2 * ox + 8, :].reshape(-1)      # k = ky*32 + slot*4 + c4
             c1[oy, ox] = w1 @ patch
+    return emulate_from_c1(c1, w2, w3, b2, b3, fcw, fcb)
+
+
+def emulate_from_c1(c1, w2, w3, b2, b3, fcw, fcb):
+    """the walk from the raw conv-1 map [32][32][64] on"""
     c1 = np.maximum(c1, 0)
     pad = np.zeros((34, 34, 64)); pad[1:33, 1:33] = c1
     a2 = np.zeros((16, 16, 64))
@@ -99,6 +104,63 @@ def test_pack_decodes_to_the_network():
     for i in range(3):
         out = emulate(imgs[i].astype(np.float64), e1, e2, e3, b2.astype(np.float64), b3.astype(np.float64),
                       fw.astype(np.float64), fb.astype(np.float64))
+        assert np.abs(out - ref[i]).max() < 2e-4 * max(1.0, np.abs(ref[i]).max()), (i, out, ref[i])
+
+
+def test_int8_layer1_pack_decodes_to_the_network():
+    """Round 6: layer 1 of the fused kernel runs on the int8 matrix pipe (csrc/encoder.hip, pack_layer1_i8).  The digit image is
+    decoded with numpy — balanced base-256 digits, per-channel power-of-two scales, slot 0 of every kernel row empty, mask tap around
+    p - 128 — and the kernel's INTEGER data flow is emulated exactly (int64 sums of (p - 128) x digit, recombined as
+    256 a2 + a1 + floor(a0 / 256)): followed by the float64 walk through layers 2 / 3 / FC it has to match PyTorch."""
+    net = random_bn_net(5, 3)
+    (w1, b1), (w2, b2), (w3, b3), (fw, fb) = net.folded_weights()
+    dig, inv = _lib.encoder_pack_i8(w1, b1)
+    assert dig.shape == (2, 7, 3, 64, 16) and dig.dtype == np.int8
+    assert all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in inv)                  # powers of two: undone exactly
+    # [o][k = row * 32 + slot * 4 + c] per digit
+    z = np.zeros((3, 64, 224), np.int64)
+    for nh in range(2):
+        for lane in range(64):
+            o, h = 32 * nh + (lane & 31), lane >> 5
+            for s in range(7):
+                for d in range(3):
+                    z[d, o, 32 * s + 16 * h:32 * s + 16 * h + 16] = dig[nh, s, d, lane]
+    fixed = 65536 * z[0] + 256 * z[1] + z[2]
+    assert np.abs(fixed).max(axis=1).min() > 2 ** 21 and np.abs(fixed).max() <= 127 * 65536 + 127 * 256 + 127     # every channel uses its 24 bits
+    assert np.all(fixed.reshape(64, 7, 8, 4)[:, :, 0, :] == 0)                             # the fragment's first pixel slot carries no tap
+    # effective real weights: colour taps multiply p - 128, the mask tap carries the rest
+    eff = fixed.reshape(64, 7, 8, 4) * (inv.astype(np.float64) / 256.0)[:, None, None, None]
+    std, mean = np.array([0.229, 0.224, 0.225], np.float32).astype(np.float64), np.array([0.485, 0.456, 0.406], np.float32).astype(np.float64)   # (the packer's float constants)
+    wt = np.transpose(w1.astype(np.float64), (0, 3, 2, 1))                                  # [o][ky][kx][c] = w[o][c][kx][ky] (the frame is seen transposed)
+    step = (inv.astype(np.float64) / 256.0)[:, None, None, None]                           # one fixed-point unit of channel o
+    assert np.all(np.abs(eff[:, :, 1:, :3] - wt / (255.0 * std)) <= 0.501 * step)
+    assert np.all(step[:, 0, 0, 0] <= 2.0 ** -21 * np.abs(eff).reshape(64, -1).max(axis=1))  # >= 22 bits below the channel's largest tap
+    mask_ref = (wt * ((128.0 / 255.0 - mean) / std)).sum(axis=3)
+    mask_ref[:, 3, 3] += b1
+    mask_ref /= 127.0                                                                       # the mask byte of an inside pixel is 127
+    assert np.all(np.abs(eff[:, :, 1:, 3] - mask_ref) <= 0.501 * step[:, :, :, 0])
+    pack, scales = _lib.encoder_pack(w1, b1, w2, w3)
+    _, e2, e3 = decode_pack(pack, scales.astype(np.float64))
+    rs = np.random.RandomState(0)
+    imgs = rs.randint(0, 256, size=(3, 64, 64, 3)).astype(np.uint8)
+    imgs[1, :, :32] = 0
+    imgs[2] = 255
+    with torch.no_grad():
+        ref = net.model.getStates(preprocess(torch.from_numpy(imgs))).numpy()
+    for i in range(3):
+        inp = np.zeros((70, 72, 4), np.int64)                                              # pixel x at slot x + 4, 3 rows of top margin
+        inp[3:67, 4:68, :3] = imgs[i].astype(np.int64) - 128
+        inp[3:67, 4:68, 3] = 127
+        c1 = np.zeros((32, 32, 64))
+        for oy in range(32):
+            for ox in range(32):
+                patch = inp[2 * oy:2 * oy + 7, 2 * ox:2 * ox + 8, :].reshape(-1)
+                a = z @ patch                                                              # [3][64] exact digit sums
+                assert np.abs(a).max() < 2 ** 22
+                comb = 256 * a[0] + a[1] + (a[2] >> 8)
+                assert np.abs(comb).max() < 2 ** 30
+                c1[oy, ox] = comb.astype(np.float64) * inv
+        out = emulate_from_c1(c1, e2, e3, b2.astype(np.float64), b3.astype(np.float64), fw.astype(np.float64), fb.astype(np.float64))
         assert np.abs(out - ref[i]).max() < 2e-4 * max(1.0, np.abs(ref[i]).max()), (i, out, ref[i])
 
 

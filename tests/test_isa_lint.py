@@ -47,8 +47,8 @@ def test_no_hazard_around_the_pinned_mfmas_of_the_built_encoder():
         pytest.skip("csrc/build/encoder.hip.o not built")
     L = _lint()
     found, stats = L.lint(OBJ)
-    product = [k for k in stats if "encoder_fwd_k<false, 2>" in k]
-    assert product and stats[product[0]]["mfma"] >= 400 and stats[product[0]]["back_edges"] >= 4, stats      # the lint looked at the real thing
+    product = [k for k in stats if "encoder_fwd_k<false, 2, true>" in k]
+    assert product and stats[product[0]]["mfma"] >= 380 and stats[product[0]]["back_edges"] >= 4, stats      # the lint looked at the real thing
     assert not found, "\n".join(found)
 
 
