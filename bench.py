@@ -636,10 +636,17 @@ def main():
         # BASELINE configs 2 and 4, briefly, in the same driver-run line (their own value / roofline / cpu_baseline)
         sec = {}
         saved = args.inner_steps
-        for name in ("mobile", "kuka_pixels"):
+        saved_img = args.img_size
+        for name in ("mobile", "kuka_pixels", "kuka_pixels_224"):
             try:
                 args.inner_steps = None
-                if name == "mobile":
+                args.img_size = saved_img
+                if name == "kuka_pixels_224":
+                    # the reference's own frame size (kuka_button_gym_env.py:21-22 RENDER 224 x 224): rasteriser + the layered encoder
+                    # (csrc/encoder_general.hip); 16 VecEnv steps per bench step, 2 bench steps
+                    args.img_size, args.inner_steps = 224, 16
+                    sub = bench_pixels(args, rank, local_rank, world, dev, K=2, W=1, cpu=False)
+                elif name == "mobile":
                     # (a rollout of this family lasts 0.1 ms: 300 of them, so that the GPU clocks are up and the timed region is not
                     #  2 ms; the headline's CPU baseline has just torn down 256 worker processes and a 256-thread OpenMP team: give
                     #  the host two seconds, this leg issues a launch every 50 us)
@@ -654,6 +661,7 @@ def main():
                     sec[name]["kernel_ms"] = sub["config"]["kernel_ms"]
             except Exception as exc:          # a secondary leg must never sink the headline measurement
                 sec[name] = {"value": None, "error": repr(exc)}
+        args.img_size = saved_img
         # the rounds 1-2 lumped-gripper model on the same workload (round-3 advisor: the default moved to the full model without an
         # external pin — both are reported): a different, cheaper simulation, NOT the headline
         saved_model = args.kuka_model

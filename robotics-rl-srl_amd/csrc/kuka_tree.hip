@@ -105,7 +105,7 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
         const bool occ = force ? force[0] == '1' : (h->n >= 65536 && !spec);
         if (occ && one_button && cartesian) return kuka_tree_occ_launch(h, p, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out);
     }
-    dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
+    dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
     if (spec) {
 #define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)

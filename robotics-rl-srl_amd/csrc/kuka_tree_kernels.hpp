@@ -103,7 +103,14 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     using namespace grp;
     __shared__ double scratch_all[kGroupEnvs][kTS];
     const int64_t n = p.n;
-    const int e_raw = blockIdx.x * kGroupEnvs + (int)(threadIdx.x / GL);
+    // XCD-aware block -> env map (the grid is a multiple of 8 blocks, kuka_tree.hip): workgroup b runs on XCD b % 8 and every XCD has its
+    // own L2, so with env = 4 b + ... the 8 wavefronts whose 16-byte pieces make up one 128-byte line of an output plane sat on 8
+    // different L2s and every line went to HBM in pieces (WRITE_SIZE 1.95x the planes, rounds 3-5).  XCD x now owns the contiguous env
+    // range [x, x + 1) * nb / 8 * 4: a line is assembled in ONE L2.  Placement is a speed matter only; results do not depend on it.
+    const int bid = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (bid * kGroupEnvs >= p.n) return;             // a padding block of the rounded-up grid (whole wavefront): it must not shadow env n - 1
+                                                     // from another wavefront (GroupMt regenerates the env's generator state in HBM in place)
+    const int e_raw = bid * kGroupEnvs + (int)(threadIdx.x / GL);
     const bool valid = e_raw < p.n;
     const int e = valid ? e_raw : p.n - 1;           // tail groups shadow the last env (every lane stays active for the cross-lane ops)
     Cfg cfg_c = p.cfg;

@@ -15,7 +15,7 @@ using namespace kuka;
     else SRL_TREE_RB_GO(MODE, false, false);
 int kuka_tree_rb_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                         uint8_t *d_done, void *d_act_out) {
-    dim3 grid((h->n + kGroupEnvs - 1) / kGroupEnvs), block(kGroupBlock);
+    dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_TREE_RB_MODE(SRLHIP_RNG_PHILOX) break;
