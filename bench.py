@@ -33,6 +33,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # f32-in / f32-accumulate MFMA = the f32 vector r
 # algorithmic bytes per env-step
 ALG_BYTES = {"mobile": 73, "kuka": 213, "kuka_pixels": 24900}
 PUBLISHED_REFERENCE_FPS = 250.0   # /root/reference/README.md:9 (8 cores, with 224x224 rendering)
+PROFILE_ROUND = 6                 # committed PMC summaries older than this round are NOT read back (profiles/rNN_*: the kernels they measured are gone)
 
 
 def parse():
@@ -155,7 +156,8 @@ def measured_traffic(kernel, env_steps_per_launch):
     kernels = [kernel] + (["mobile_sample_actions_k"] if wl == "mobile" else [])   # the timed region covers both mobile kernels
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_{}_pmc_{}.csv".format(wl, counter))))
+        # only this round's summaries: a silent fall-back to an older round's file would report another kernel's traffic
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r{:02d}_{}_pmc_{}.csv".format(PROFILE_ROUND, wl, counter))))
         if not files:
             return None
         rows = [row for row in csv.DictReader(open(files[-1])) if row["kernel"] in kernels and row["counter"] == counter]
@@ -362,7 +364,7 @@ def pmc_issue_util(kernel, avg_launch_s, clock_hz=2.35e9):      # (the PMC pass'
     x 4 cycles per wave64 float64 instruction / cycles of one launch (live duration x 2.4 GHz).  None without a summary."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kuka_pmc_SQ_WAVES.csv")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r{:02d}_kuka_pmc_SQ_WAVES.csv".format(PROFILE_ROUND))))
     files = [f for f in files if any(row["kernel"] == kernel for row in csv.DictReader(open(f)))]      # a summary that saw THIS kernel
     if not files:
         return None

@@ -401,13 +401,14 @@ int srlhip_encoder_pack_first_layer(int32_t n_channels, const float *conv1_w, co
 size_t srlhip_encoder_pack_bytes(void);
 /* Host-only: layer 1 of the fused 64x64x3 kernel as it runs since round 6 — on the INT8 matrix pipe, exactly.  out = [channel half]
  * [kernel row 0..6][digit 0..2][lane][16 i8] (srlhip_encoder_pack_i8_bytes() bytes): the folded weight of output channel o at k =
- * row * 32 + slot * 4 + c (slot 0 zero, slot s = kernel column s - 1; c < 3 the colour taps w / (255 std_c) that multiply p - 128,
+ * row * 32 + slot * 4 + c (zero_slot = 0, the fused kernel: slot 0 empty, slot s = kernel column s - 1; zero_slot = 7, the layered
+ * kernels of 3-channel frames of any other size: slot s = kernel column s, slot 7 empty; c < 3 the colour taps w / (255 std_c) that multiply p - 128,
  * c = 3 the validity-mask tap [sum_c w_c (128 / 255 - mean_c) / std_c plus the folded bias on the centre tap] / 127: the mask
  * byte of an inside pixel is 127) is the 24-bit
  * fixed-point number (65536 d0 + 256 d1 + d2) / scale_o with balanced digits d in [-128, 127]; inv_scale64[o] = 256 / scale_o, a
  * power of two.  Lane (h, n) of a fragment holds k = 16 h .. 16 h + 15 of output channel 32 * half + n. */
 size_t srlhip_encoder_pack_i8_bytes(void);
-int srlhip_encoder_pack_i8(const float *conv1_w, const float *conv1_b, void *out, size_t out_bytes, float *inv_scale64);
+int srlhip_encoder_pack_i8(const float *conv1_w, const float *conv1_b, int32_t zero_slot, void *out, size_t out_bytes, float *inv_scale64);
 int srlhip_encoder_pack(const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv3_w,
                         void *out, size_t out_bytes, float *scales3 /* power-of-two pre-scale of layers 1..3 */);
 

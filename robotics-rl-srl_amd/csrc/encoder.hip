@@ -67,11 +67,10 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kImg = 64, kCh = 64;
 constexpr int kS1 = 14;                 // layer-1 k-steps: K = 7 rows x (8 pixel slots x 4 channels) = 224
-constexpr int kS1i = 7;                 // int8 layer 1: one k-step per kernel row, K = 8 pixel slots x (R, G, B, mask) bytes = 32
-constexpr int kDigits = 3;              // balanced base-256 digits of a 24-bit fixed-point weight, most significant first
-constexpr int kMaskI8 = 127;            // value of the validity-mask byte of an inside pixel (its tap carries weight / 127: same scale as the colour taps)
+constexpr int kS1i = srlenc::kI8Steps;  // int8 layer 1: one k-step per kernel row, K = 8 pixel slots x (R, G, B, mask) bytes = 32
+constexpr int kDigits = srlenc::kI8Digits;   // balanced base-256 digits of a 24-bit fixed-point weight, most significant first
+constexpr unsigned kMaskByte = (unsigned)srlenc::kMaskI8 << 24;   // the validity-mask byte of an inside pixel is 127 (its tap carries weight / 127: same scale as the colour taps)
 constexpr int kIntNegInf = -2147483647 - 1;   // max-pool padding on combined int32 sums (|sum| <= 9.4e8)
-constexpr int kWeightTopI8 = 127 * 65536 + 127 * 256 + 127;   // largest |fixed-point weight| three balanced digits hold
 constexpr int kS2 = 36;                 // layers 2/3:      K = 9 taps x 64 channels = 576
 constexpr int kB2Ahead = 6;             // layer-2 B fragments are requested this many k-steps before their MFMAs
 constexpr float kWeightTop = 16384.f;   // packer: largest |weight| of a layer after its power-of-two pre-scale
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(128 * MG, 1) void encoder_fwd_k(EncParams P) {
             const uint32_t px[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
             const int y = (4 * q) >> 6, x = (4 * q) & 63;
             *reinterpret_cast<uint4 *>(enc_lds + ((y + 3) * 72 + (x + 4)) * 4) =
-                make_uint4((px[0] ^ 0x808080u) | 0x7f000000u, (px[1] ^ 0x808080u) | 0x7f000000u, (px[2] ^ 0x808080u) | 0x7f000000u, (px[3] ^ 0x808080u) | 0x7f000000u);
+                make_uint4((px[0] ^ 0x808080u) | kMaskByte, (px[1] ^ 0x808080u) | kMaskByte, (px[2] ^ 0x808080u) | kMaskByte, (px[3] ^ 0x808080u) | kMaskByte);
         }
         __syncthreads();
         ENC_STAMP(1);
@@ -915,14 +914,19 @@ float pack_layer1(const float *w, const float *b, _Float16 *out) {
                 }
     return scale;
 }
-// int8 layer 1: the same folded taps around p - 128.  k = ky * 32 + slot * 4 + c4; slot 0 carries zero weights (the fragment of output
-// pixel j starts at input pixel 2 j - 4), slot s >= 1 is kernel column kx = s - 1; c4 < 3: w / (255 std_c) (multiplies p - 128); c4 = 3, the
-// validity mask (byte value 127 inside the frame, 0 in the ring): [sum_c w_c (128 / 255 - mean_c) / std_c — zero padding stays exact
-// in NORMALISED space — plus the folded BN bias on the centre tap] / 127.
-double layer1_weight_i8(const float *w, const float *b, int o, int k) {
-    const int ky = k / 32, slot = (k % 32) / 4, c4 = k % 4, kx = slot - 1;
+}  // namespace
+
+namespace srlenc {
+// int8 layer 1 (3-channel frames): the folded taps around p - 128.  k = ky * 32 + slot * 4 + c4; ONE of the eight pixel slots of a kernel
+// row carries zero weights — slot 0 in the fused kernel (the fragment of output pixel j starts at input pixel 2 j - 4, 16-byte aligned
+// quads), slot 7 in the layered kernels (the fragment starts at the window column of tap 0); c4 < 3: w / (255 std_c) (multiplies
+// p - 128); c4 = 3, the validity mask (byte value 127 inside the frame, 0 outside): [sum_c w_c (128 / 255 - mean_c) / std_c — zero
+// padding stays exact in NORMALISED space — plus the folded BN bias on the centre tap] / 127.
+static double layer1_weight_i8(const float *w, const float *b, int zero_slot, int o, int k) {
+    constexpr float kMean[3] = {0.485f, 0.456f, 0.406f}, kStd[3] = {0.229f, 0.224f, 0.225f};
+    const int ky = k / 32, slot = (k % 32) / 4, c4 = k % 4, kx = zero_slot == 0 ? slot - 1 : slot;
     double v = 0.0;
-    if (slot >= 1) {
+    if (slot != zero_slot) {
         if (c4 < 3) {
             v = (double)w[((o * 3 + c4) * 7 + kx) * 7 + ky] / (255.0 * (double)kStd[c4]);
         } else {
@@ -935,10 +939,10 @@ double layer1_weight_i8(const float *w, const float *b, int o, int k) {
 }
 // out: [n-half][k-step][digit][lane][16 i8], digit 0 = most significant; inv256[o] = 256 / scale_o, scale_o = the largest power of two
 // with max_k |w| scale_o <= kWeightTopI8: weight = (65536 d0 + 256 d1 + d2) / scale_o with balanced digits in [-128, 127].
-void pack_layer1_i8(const float *w, const float *b, int8_t *out, float *inv256) {
+void pack_layer1_i8(const float *w, const float *b, int zero_slot, int8_t *out, float *inv256) {
     for (int o = 0; o < 64; o++) {
         double wmax = 0.0;
-        for (int k = 0; k < 32 * kS1i; k++) wmax = fmax(wmax, fabs(layer1_weight_i8(w, b, o, k)));
+        for (int k = 0; k < 32 * kI8Steps; k++) wmax = fmax(wmax, fabs(layer1_weight_i8(w, b, zero_slot, o, k)));
         int e = 0;
         if (wmax > 0.0 && std::isfinite(wmax)) {
             frexp((double)kWeightTopI8 / wmax, &e);      // kWeightTopI8 / wmax = f * 2^e, f in [0.5, 1)
@@ -947,25 +951,23 @@ void pack_layer1_i8(const float *w, const float *b, int8_t *out, float *inv256) 
         const double scale = ldexp(1.0, e);
         inv256[o] = (float)(256.0 / scale);
         const int nh = o >> 5;
-        for (int k = 0; k < 32 * kS1i; k++) {
-            long long z = llround(layer1_weight_i8(w, b, o, k) * scale);
+        for (int k = 0; k < 32 * kI8Steps; k++) {
+            long long z = llround(layer1_weight_i8(w, b, zero_slot, o, k) * scale);
             if (z > kWeightTopI8) z = kWeightTopI8;
             if (z < -kWeightTopI8) z = -kWeightTopI8;
-            int dg[kDigits];
-            for (int d = kDigits - 1; d >= 0; d--) {          // least significant first
+            int dg[kI8Digits];
+            for (int d = kI8Digits - 1; d >= 0; d--) {          // least significant first
                 long long r = ((z + 128) % 256 + 256) % 256 - 128;
                 dg[d] = (int)r;
                 z = (z - r) / 256;
             }
             const int s = k / 32, hh = (k % 32) / 16, el = k % 16, lane = hh * 32 + (o & 31);
-            for (int d = 0; d < kDigits; d++)
-                out[((size_t)((nh * kS1i + s) * kDigits + d) * 64 + lane) * 16 + el] = (int8_t)dg[d];
+            for (int d = 0; d < kI8Digits; d++)
+                out[((size_t)((nh * kI8Steps + s) * kI8Digits + d) * 64 + lane) * 16 + el] = (int8_t)dg[d];
         }
     }
 }
-}  // namespace
 
-namespace srlenc {
 void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
@@ -1029,9 +1031,9 @@ size_t srlhip_encoder_pack_bytes(void) { return kPack1Bytes + 2 * kPack2Bytes; }
 
 size_t srlhip_encoder_pack_i8_bytes(void) { return kPack1iBytes; }
 
-int srlhip_encoder_pack_i8(const float *conv1_w, const float *conv1_b, void *out, size_t out_bytes, float *inv_scale64) {
-    if (!conv1_w || !conv1_b || !out || !inv_scale64 || out_bytes < kPack1iBytes) return SRLHIP_EINVAL;
-    pack_layer1_i8(conv1_w, conv1_b, static_cast<int8_t *>(out), inv_scale64);
+int srlhip_encoder_pack_i8(const float *conv1_w, const float *conv1_b, int32_t zero_slot, void *out, size_t out_bytes, float *inv_scale64) {
+    if (!conv1_w || !conv1_b || !out || !inv_scale64 || out_bytes < kPack1iBytes || (zero_slot != 0 && zero_slot != 7)) return SRLHIP_EINVAL;
+    srlenc::pack_layer1_i8(conv1_w, conv1_b, zero_slot, static_cast<int8_t *>(out), inv_scale64);
     return SRLHIP_OK;
 }
 
@@ -1092,7 +1094,7 @@ int srlhip_encoder_create(int32_t device_id, int32_t img_h, int32_t img_w, int32
     e->img_h = img_h; e->img_w = img_w; e->n_channels = n_channels; e->d_pack_i8 = nullptr; e->d_inv1c = nullptr; e->l1_i8 = 0;
     std::vector<int8_t> pack_i8(kPack1iBytes);
     float inv1c[64];
-    pack_layer1_i8(conv1_w, conv1_b, pack_i8.data(), inv1c);
+    srlenc::pack_layer1_i8(conv1_w, conv1_b, 0, pack_i8.data(), inv1c);
 #define ENC_CHECK(expr)                                                                              \
     do {                                                                                             \
         hipError_t e__ = (expr);                                                                     \

@@ -53,6 +53,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PX = 144;                 // LDS pixel pitch of a 64-channel f16 plane (128 B + 16 B skew)
 constexpr float kF16Max = 65504.f, kNegInf = -3.0e38f;
@@ -70,6 +72,7 @@ struct LayerParams {
     const char *pack;                // B fragments [channel half][k-step][lane][8 hi | 8 lo] f16
     const float *bias;               // [64], null for layer 1 (its bias rides on the mask channel)
     float inv_scale;
+    const float *inv1c;              // int8 layer 1: [64] per-output-channel 256 / fixed-point scale
     int Hin, Win, Cimg, Hc, Wc, Hp, Wp, nbands, bands_per_wg;
     int *status;
 };
@@ -87,21 +90,29 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // LDSB (layer 1, 3 channels): four wavefronts per workgroup — two column segments x two channel halves — with the layer's
 // weights in LDS (56 KiB, shared) instead of 112 registers per lane: under 256 registers two workgroups = eight wavefronts
 // fit a CU, and one wavefront's MFMAs overlap another's staging / pooling.
-template <int LAYER, int CPIX, int R, int NC, bool LDSB = false>
+// I8 (layer 1, 3-channel frames, LDSB): the layer on the INT8 matrix pipe, exactly, as in the fused kernel (csrc/encoder.hip): the
+// window holds the frame's bytes as (p - 128, mask 127) i8 pixels — 4 bytes per pixel, no f16 unpack —, the weights are three balanced
+// base-256 digits of per-channel 24-bit fixed-point numbers (43 KiB of LDS instead of 56), one v_mfma_i32_32x32x32_i8 per kernel row
+// and digit (105 MFMAs per band and wavefront where the f16 form takes 140), two convolution rows at a time with their three digit
+// chains; the sums are recombined as 256 a0 + a1 + (a2 >> 8) in int32 (exact but for the last floor), then the float max-pool of the
+// other layers.
+template <int LAYER, int CPIX, int R, int NC, bool LDSB = false, bool I8 = false>
 __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(LayerParams P) {
+    static_assert(!I8 || (LAYER == 1 && CPIX == 4 && LDSB), "the int8 form exists for layer 1 of 3-channel frames");
     constexpr int T = 2 * R + 1;                              // convolution rows of a band
-    constexpr int KS = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
+    constexpr int KS = LAYER == 1 ? (I8 ? kI8Steps : CPIX == 4 ? 14 : 28) : 36;
     constexpr int S = LAYER == 2 ? 1 : 2, PAD = LAYER == 1 ? 3 : 1, KW = LAYER == 1 ? 7 : 3, PPAD = LAYER == 1 ? 1 : 0;
     constexpr int NR = S * (T - 1) + KW;                      // staged input rows
-    constexpr int PIXB = LAYER == 1 ? CPIX * 2 : PX;          // staged bytes per pixel (and plane)
+    constexpr int PIXB = LAYER == 1 ? (I8 ? 4 : CPIX * 2) : PX;   // staged bytes per pixel (and plane)
     constexpr int PLANE = NR * NC * PIXB;
     // tid: thread within its wavefront PAIR (the unit that owns a window); sp: the pair (column segment) inside an LDSB workgroup
     const int tid = threadIdx.x & 127, lane = tid & 63, nh = tid >> 6, m = lane & 31, h = lane >> 5, sp = threadIdx.x >> 7;
     const int seg = LDSB ? 2 * blockIdx.x + sp : blockIdx.x, img = blockIdx.z;
     constexpr int KSB = LAYER == 1 ? (CPIX == 4 ? 14 : 28) : 36;
-    constexpr int WGT_BYTES = LDSB ? 2 * KSB * 2048 : 0;      // LDSB: [channel half][k-step][lane][8 hi | 8 lo] at the start of LDS
+    // LDSB: the layer's weights at the start of LDS — [channel half][k-step][lane][8 hi | 8 lo] f16, or [channel half][kernel row][digit][lane][16 i8]
+    constexpr int WGT_BYTES = LDSB ? (I8 ? (int)kPackI8Bytes : 2 * KSB * 2048) : 0;
     constexpr int T_ = 2 * R + 1, NR_ = (LAYER == 2 ? 1 : 2) * (T_ - 1) + (LAYER == 1 ? 7 : 3);
-    constexpr int WIN_BYTES = LDSB ? (NR_ * NC * CPIX * 2 > R * 15 * 256 ? NR_ * NC * CPIX * 2 : R * 15 * 256) : 0;
+    constexpr int WIN_BYTES = LDSB ? (NR_ * NC * PIXB > R * 15 * 256 ? NR_ * NC * PIXB : R * 15 * 256) : 0;
     char *const win = lds + WGT_BYTES + sp * WIN_BYTES;        // this pair's window, later its pooled band
     const int woff = WGT_BYTES + sp * WIN_BYTES;
     const int c0 = 30 * seg - PPAD, ix0 = S * c0 - PAD;
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
     }
     const int ch = 32 * nh + m;
     float bias = P.bias ? P.bias[ch] : 0.f;
-    asm volatile("" : "+v"(bias));                         // waited for here, not at its first use behind the window prefetch
+    float inv_scale = I8 ? P.inv1c[ch] : P.inv_scale;
+    asm volatile("" : "+v"(bias), "+v"(inv_scale));        // waited for here, not at its first use behind the window prefetch
     bool ovf = false;
     const int band_end = min(P.nbands, ((int)blockIdx.y + 1) * P.bands_per_wg);
     // Staging is split in two: `issue` sends every load of a band's input window (all of a lane's loads before anything else,
@@ -179,6 +191,11 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                         const uint32_t lo = tail ? (w0 >> 16) | (w1 << 16) : w0, hi = tail ? w1 >> 16 : w1;      // channels 0..3 | 4, 5
                         a = lo; b = (lo >> 24) | ((hi & 0xffffu) << 8);
                     }
+                    if (I8) {
+                        // (R - 128, G - 128, B - 128, mask 127) as four i8: one XOR, no conversion; outside the frame all zero
+                        *reinterpret_cast<uint32_t *>(win + pix * 4) = in ? ((a & 0xffffffu) ^ 0x808080u) | ((uint32_t)kMaskI8 << 24) : 0u;
+                        continue;
+                    }
                     a = in ? (a & 0xffffffu) | 0x01000000u : 0u;                           // byte 3: the mask
                     b = in ? b : 0u;
                     if (CPIX == 4) {
@@ -214,9 +231,59 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
-        const int abase = woff + (LAYER == 1 ? (CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16);
+        const int abase = woff + (LAYER == 1 ? (I8 ? (2 * m + 4 * h) * 4 : CPIX == 4 ? (2 * m + 2 * h) * 8 : (2 * m + h) * 16) : S * m * PX + h * 16);
         constexpr int ROWSTRIDE = S * NC * PIXB;
-        if (LAYER == 1) {
+        if constexpr (I8) {
+            if (band + 1 < band_end) issue(band + 1);
+            // lane (m, h) of conv row t, kernel row ks: the 16 bytes of window pixels 2 m + 4 h .. + 3 (8-byte aligned: two 8-byte reads)
+            auto frag = [&](int off) {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(lds + off), hi = *reinterpret_cast<const uint2 *>(lds + off + 8);
+                i32x4 r; r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)hi.x; r[3] = (int)hi.y;
+                return r;
+            };
+            // Rows in pairs, the three digit chains of a pair together (six accumulators: consecutive MFMAs never share one), one pass over
+            // the kernel rows per pair: a fragment is read from LDS once and meets its three digits.  All T rows at once would need 15
+            // accumulators (240 registers); a digit at a time keeps every fragment of the pair live across the three passes (spills).
+            i32x16 S[T];
+#pragma unroll
+            for (int t0 = 0; t0 < T; t0 += 2) {
+                constexpr int G = 2;
+                i32x16 ai[kI8Digits][G];
+                // (opaque per pair: otherwise the digit loads of the three pairs are merged and all 21 fragments — 84 registers — stay live)
+                int lb = lane;
+                asm volatile("" : "+v"(lb));
+#pragma unroll
+                for (int d = 0; d < kI8Digits; d++)
+#pragma unroll
+                    for (int u = 0; u < G; u++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) ai[d][u][i] = 0;
+#pragma unroll
+                for (int ks = 0; ks < kI8Steps; ks++) {
+                    i32x4 a[G];
+#pragma unroll
+                    for (int u = 0; u < G; u++) if (t0 + u < T) a[u] = frag(abase + (t0 + u) * ROWSTRIDE + ks * NC * 4);
+#pragma unroll
+                    for (int d = 0; d < kI8Digits; d++) {
+                        const i32x4 B = *reinterpret_cast<const i32x4 *>(lds + ((size_t)((nh * kI8Steps + ks) * kI8Digits + d) * 64 + lb) * 16);
+#pragma unroll
+                        for (int u = 0; u < G; u++) if (t0 + u < T) ai[d][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[u], B, ai[d][u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++)
+                    if (t0 + u < T) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) S[t0 + u][i] = ai[0][u][i] * 256 + ai[1][u][i] + (ai[2][u][i] >> 8);
+                    }
+                __builtin_amdgcn_sched_barrier(0);            // the scheduler may not merge the pairs' passes (all their accumulators live at once)
+            }
+            // (int -> float is monotone: the float max-pool below picks the same winners; |S| < 2^30 rounds to 24 bits like any f32 sum)
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[t][i] = (float)S[t][i];
+        } else if (LAYER == 1) {
             if (band + 1 < band_end) issue(band + 1);
 #pragma unroll
             for (int s = 0; s < KS; s++) {
@@ -268,7 +335,7 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
         constexpr int OPIX = R * 15, OPLANE = OPIX * 128;
         // pooled value `val` of row j, column jj of the band -> scale / bias / ReLU -> the LDS band (hi | lo planes, or float32)
         auto emit = [&](int j, int jj, float val, bool on) {
-            const float x = fmaxf(val * P.inv_scale + bias, 0.f);
+            const float x = fmaxf(val * inv_scale + bias, 0.f);
             if (on) {
                 if (LAYER == 3) *reinterpret_cast<float *>(win + ((j * 15 + jj) * 64 + ch) * 4) = x;
                 else {
@@ -423,6 +490,8 @@ struct General {
     int device_id, state_dim, F;
     Geometry g;
     char *d_pack;          // layer 1 | layer 2 | layer 3 B fragments
+    char *d_pack_i8;       // 3-channel frames: layer 1 as int8 digits (pack_layer1_i8, zero slot 7), then [64] float 256 / scale
+    bool l1_i8;            // layer 1 runs on the int8 pipe (3 channels, SRLHIP_ENCODER_L1=i8: the measured alternative, slower here)
     size_t pack1_bytes;
     float *d_f32;          // bias2[64] bias3[64] fcb[state_dim] fcw[state_dim][F]
     float inv_scale[3];
@@ -437,6 +506,7 @@ void general_destroy(General *g) {
     if (!g) return;
     (void)hipSetDevice(g->device_id);
     if (g->d_pack) (void)hipFree(g->d_pack);
+    if (g->d_pack_i8) (void)hipFree(g->d_pack_i8);
     if (g->d_f32) (void)hipFree(g->d_f32);
     if (g->d_status) (void)hipFree(g->d_status);
     if (g->d_act) (void)hipFree(g->d_act);
@@ -449,7 +519,15 @@ int general_create(int device_id, const Geometry &geo, int state_dim, const floa
     General *g = new (std::nothrow) General();
     if (!g) return SRLHIP_ENOMEM;
     g->device_id = device_id; g->state_dim = state_dim; g->g = geo; g->d_pack = nullptr; g->d_f32 = nullptr; g->d_status = nullptr;
-    g->d_act = nullptr; g->cap = 0;
+    g->d_act = nullptr; g->cap = 0; g->d_pack_i8 = nullptr;
+    {
+        // The int8 form of layer 1 is NOT the default here (it is in the fused 64x64x3 kernel): left to the compiler's scheduler its six
+        // digit accumulators per row pair + the 80 recombined sums + hoisted fragment loads spill (88 registers at the 256 of two
+        // workgroups per CU, 50 at 512), and 4096 frames of 224x224 take 13.4 ms against 8.2 ms (profiles/NOTES.md section U).
+        // SRLHIP_ENCODER_L1=i8 selects it (tests run both).
+        const char *l1 = getenv("SRLHIP_ENCODER_L1");
+        g->l1_i8 = geo.C == 3 && l1 && strcmp(l1, "i8") == 0;
+    }
     const int F = 64 * geo.Hp[2] * geo.Wp[2];
     g->F = F;
     const int ks1 = geo.C == 3 ? 14 : 28;
@@ -486,6 +564,13 @@ int general_create(int device_id, const Geometry &geo, int state_dim, const floa
     GEN_CHECK(hipMemcpy(g->d_pack, pack.data(), pack.size(), hipMemcpyHostToDevice));
     GEN_CHECK(hipMemcpy(g->d_f32, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     GEN_CHECK(hipMemset(g->d_status, 0, sizeof(int)));
+    if (geo.C == 3) {
+        std::vector<char> p8(kPackI8Bytes + 64 * sizeof(float));
+        pack_layer1_i8(conv1_w, conv1_b, 7, reinterpret_cast<int8_t *>(p8.data()), reinterpret_cast<float *>(p8.data() + kPackI8Bytes));
+        GEN_CHECK(hipMalloc(reinterpret_cast<void **>(&g->d_pack_i8), p8.size()));
+        GEN_CHECK(hipMemcpy(g->d_pack_i8, p8.data(), p8.size(), hipMemcpyHostToDevice));
+        GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<1, 4, kR1, kNC1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
     constexpr int lds2 = 2 * (kR2 * 2 + 3) * kNC2 * PX, lds3 = 2 * (2 * (2 * kR3) + 3) * kNC3 * PX;
     GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<2, 4, kR2, kNC2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     GEN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(enc_layer_k<1, 4, kR1, kNC1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -537,7 +622,13 @@ int general_forward(General *g, const uint8_t *images_dev, int n, float *states_
         for (int b = 5; b <= 8; b++)
             if ((p.nbands + b - 1) / b * b - p.nbands <= (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg * p.bands_per_wg - p.nbands) p.bands_per_wg = b;
         dim3 grid1((p.Wp + 14) / 15, (p.nbands + p.bands_per_wg - 1) / p.bands_per_wg, nn);
-        if (geo.C == 3) {
+        if (geo.C == 3 && g->l1_i8) {
+            // 3 channels, int8 layer 1: digits in LDS, four wavefronts per workgroup (two column segments), bands of kR1 pooled rows
+            constexpr int win = (2 * (2 * kR1) + 7) * kNC1 * 4, band = kR1 * 15 * 256;
+            p.pack = g->d_pack_i8; p.inv1c = reinterpret_cast<const float *>(g->d_pack_i8 + kPackI8Bytes);
+            hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1, true, true>), dim3((grid1.x + 1) / 2, grid1.y, nn), dim3(256),
+                               (int)kPackI8Bytes + 2 * (win > band ? win : band), stream, p);
+        } else if (geo.C == 3) {
             // 3 channels: weights in LDS, four wavefronts per workgroup (two column segments), bands of kR1 pooled rows
             constexpr int win = (2 * (2 * kR1) + 7) * kNC1 * 8, band = kR1 * 15 * 256;
             hipLaunchKernelGGL((enc_layer_k<1, 4, kR1, kNC1, true>), dim3((grid1.x + 1) / 2, grid1.y, nn), dim3(256),

@@ -32,6 +32,13 @@ void general_destroy(General *g);
 // layer 1 of the layered path, host-only (srlhip_encoder_pack_first_layer); returns the pre-scale, 0 on bad arguments
 float pack_layer1_general(const float *w, const float *b, int n_channels, void *out, size_t out_bytes);
 
+// int8 layer 1 (3-channel frames; csrc/encoder.hip has the description): three balanced base-256 digits of per-channel 24-bit fixed-point
+// weights, [channel half][kernel row][digit][lane][16 i8]; zero_slot = the pixel slot of a kernel row that carries no tap (0: fused
+// kernel, 7: layered kernels); inv256[o] = 256 / scale_o
+constexpr int kI8Steps = 7, kI8Digits = 3, kMaskI8 = 127, kWeightTopI8 = 127 * 65536 + 127 * 256 + 127;
+constexpr size_t kPackI8Bytes = 2 * kI8Steps * kI8Digits * 64 * 16;
+void pack_layer1_i8(const float *w, const float *b, int zero_slot, int8_t *out, float *inv256);
+
 // shared with encoder.hip's packers
 void split_f16(float v, _Float16 &hi, _Float16 &lo);
 float pick_scale(double wmax);

@@ -158,7 +158,7 @@ def load():
     lib.srlhip_encoder_pack.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.srlhip_encoder_pack_i8_bytes.restype = ctypes.c_size_t
     lib.srlhip_encoder_pack_i8_bytes.argtypes = []
-    lib.srlhip_encoder_pack_i8.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.srlhip_encoder_pack_i8.argtypes = [vp, vp, i32, vp, ctypes.c_size_t, vp]
     lib.srlhip_encoder_pack_first_layer.argtypes = [i32, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float)]
     _lib = lib
     return lib
@@ -489,14 +489,15 @@ def encoder_pack(conv1_w, conv1_b, conv2_w, conv3_w):
     return out, scales
 
 
-def encoder_pack_i8(conv1_w, conv1_b):
-    """Host-only: (int8 digits [2][7][3][64][16], float32 [64] per-channel 256 / scale) of the fused kernel's int8 layer 1."""
+def encoder_pack_i8(conv1_w, conv1_b, zero_slot=0):
+    """Host-only: (int8 digits [2][7][3][64][16], float32 [64] per-channel 256 / scale) of the int8 layer 1 — zero_slot 0: the fused
+    64x64x3 kernel's layout, 7: the layered kernels' (3-channel frames of any other size)."""
     lib = load()
     w1, b1 = _f32(conv1_w), _f32(conv1_b)
     assert w1.shape == (64, 3, 7, 7) and b1.shape == (64,)
     out = np.zeros(lib.srlhip_encoder_pack_i8_bytes(), np.int8)
     inv = np.zeros(64, np.float32)
-    rc = lib.srlhip_encoder_pack_i8(_ptr(w1), _ptr(b1), _ptr(out), out.nbytes, _ptr(inv))
+    rc = lib.srlhip_encoder_pack_i8(_ptr(w1), _ptr(b1), int(zero_slot), _ptr(out), out.nbytes, _ptr(inv))
     if rc:
         raise SrlHipError("srlhip_encoder_pack_i8 failed ({})".format(rc))
     return out.reshape(2, 7, 3, 64, 16), inv

@@ -109,3 +109,18 @@ def test_pixel_pipeline_on_the_layered_encoder(shape, multi_view, use_graph):
         assert rel_err(states.cpu().numpy(), cpu.getStates(env.images.cpu().numpy()).numpy()) < TOL, t
     assert (len(env._graphs) == 1) == use_graph
     env.close()
+
+
+@pytest.mark.parametrize("shape,n", [((224, 224), 4), ((75, 61), 6), ((48, 56), 33)])
+def test_int8_first_layer_of_the_layered_path(shape, n, monkeypatch):
+    """SRLHIP_ENCODER_L1=i8 (read when the handle is created): layer 1 of the layered path on the int8 matrix pipe, the measured
+    alternative (slower than the split-f16 form in this kernel — DESIGN.md, NOTES section U — so not the default): same bar."""
+    monkeypatch.setenv("SRLHIP_ENCODER_L1", "i8")
+    gpu, cpu = make_nets(3, 5, shape, 3)
+    imgs = frames(n, shape, 3, n)
+    out, ref = gpu.getStates(imgs).cpu().numpy(), cpu.getStates(imgs).numpy()
+    assert rel_err(out, ref) < TOL, rel_err(out, ref)
+    assert not gpu.hip.overflow()
+    monkeypatch.delenv("SRLHIP_ENCODER_L1")
+    gpu2, _ = make_nets(3, 5, shape, 3)
+    assert rel_err(gpu2.getStates(imgs).cpu().numpy(), out) < TOL
