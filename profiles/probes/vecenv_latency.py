@@ -39,3 +39,20 @@ for n in (16, 256, 4096):
         t0 = time.perf_counter(); h.episode_stats(); ts.append(time.perf_counter() - t0)
     print("   srlhip_episode_stats n=%d: median %.1f us" % (n, np.median(np.array(ts) * 1e6)), flush=True)
     h.close()
+# round 6: the launch / collect split of a step (step_async enqueues every shard's kernel, step_wait collects) and the SAME 4096 envs
+# as 2 and 4 shards of one process (HipVecEnv(device_ids=[...]); here every shard lives on device 0: the host-side cost of sharding
+# and the concurrency of the shards' launches, not a multi-GPU number)
+for ids in ([0], [0, 0], [0, 0, 0, 0]):
+    n = 4096
+    env = HipVecEnv("KukaButtonGymEnv-v0", n, seed=0, env_kwargs={"srl_model": "ground_truth"}, device_ids=ids)
+    env.reset()
+    acts = np.random.RandomState(0).randint(6, size=(WARM + TIMED, n))
+    for t in range(WARM): env.step(acts[t])
+    ta, tw = [], []
+    for t in range(WARM, WARM + TIMED):
+        t0 = time.perf_counter(); env.step_async(acts[t]); t1 = time.perf_counter(); env.step_wait(); t2 = time.perf_counter()
+        ta.append(t1 - t0); tw.append(t2 - t1)
+    ta, tw = np.array(ta) * 1e6, np.array(tw) * 1e6
+    print("HipVecEnv n=%d as %d shard(s) on device 0: step median %.1f us = step_async %.1f (launches only) + step_wait %.1f" % (
+        n, len(ids), np.median(ta + tw), np.median(ta), np.median(tw)), flush=True)
+    env.close()
