@@ -29,6 +29,10 @@
 
 #include "../../include/srlhip.h"
 
+#ifndef EG_X
+#define EG_X 0          // experiment builds (profiles/probes/encoder_general_experiments.sh): 1 = layers 2-3 without their MFMAs, 2 = without
+#endif                  // the pooling / band stores, 3 = without the window loads.  Results are wrong by construction; 0 = the product.
+
 namespace srlenc {
 
 Geometry geometry(int img_h, int img_w, int n_channels) {
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
     const int band_end = min(P.nbands, ((int)blockIdx.y + 1) * P.bands_per_wg);
     // Staging is split in two: `issue` sends every load of a band's input window (all of a lane's loads before anything else,
     // so the window costs one memory round trip), `commit` converts / stores them to LDS.  Layer 1 issues the NEXT band's
-    // loads before this band's MFMAs and commits them after the pooled rows have been stored; layers 2-3 keep the registers
-    // for the weight ring instead (loads return in order: a window prefetch would also stall that ring).
+    // loads before this band's MFMAs and commits them after the pooled rows have been stored; layers 2-3 issue them behind
+    // the k-loop (loads return in order: in front of it a window prefetch would stall the weight ring).
     constexpr int ITER = LAYER == 1 ? (NR * NC + 127) / 128 : (NR * NC * 16 + 127) / 128;
     static_assert(LAYER == 1 ? 2 * ITER <= 32 : ITER <= 64, "one flag word per lane");
     uint32_t raw1[LAYER == 1 ? ITER : 1][2];
@@ -172,7 +176,11 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                 const int yy = pix / NC, y = iy0 + yy, x = ix0 + pix - yy * NC;
                 // branch-free: cells outside the map read the frame's first pixel and are zeroed in commit()
                 const bool in = pix < NR * NC && y >= 0 && y < P.Hin && x >= 0 && x < P.Win;
+#if EG_X == 3
+                raw[it] = u32x4{(uint32_t)idx, 0u, 0u, 0u};
+#else
                 raw[it] = *reinterpret_cast<const u32x4 *>((pl ? P.in_lo : P.in_hi) + (((size_t)img * P.Hin + (in ? y : 0)) * P.Win + (in ? x : 0)) * 64 + c8 * 8);
+#endif
                 inside |= (uint64_t)(in ? 1u : 0u) << it;
             }
         }
@@ -218,11 +226,13 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
         }
     };
     const int band0 = blockIdx.y * P.bands_per_wg;
-    if (LAYER == 1 && band0 < band_end) issue(band0);
+    // (the wide layer-3 window is 41 loads per lane: held across the pooling they spill; that variant keeps its loads at the loop top)
+    constexpr bool PREFETCH = LAYER == 1 || LAYER == 2 || NC == kNC3Narrow;
+    if (PREFETCH && band0 < band_end) issue(band0);
     for (int band = band0; band < band_end; band++) {
         const int p0 = band * R, rr0 = 2 * p0 - PPAD;
         __syncthreads();                                      // the previous band's fragments have been read
-        if (LAYER != 1) issue(band);
+        if (!PREFETCH) issue(band);
         commit();
         __syncthreads();
         // ---- 2R+1 convolution rows x 32 columns x this wavefront's 32 channels: raw accumulators ----------------------------
@@ -299,34 +309,67 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                 for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bl, acc[t]);
             }
         } else {
-            // one trip per kernel tap (4 k-steps of 16 channels); the B ring holds two trips, so its slots are static
+            // Round 6: the k-loop as a hand-scheduled stream, like the fused kernel's layer 2 (csrc/encoder.hip, NOTES section O).  Left to
+            // the compiler it read a fragment, waited out the LDS round trip and issued its MFMAs — two of them back to back on the
+            // same accumulator.  Every MFMA is a pinned statement now: per k-step 3 T of them — hi x hi, hi x lo, lo x hi for each of
+            // the T rows, consecutive ones on different accumulators, the same order per accumulator as before (bit-identical sums) —
+            // with the NEXT k-step's 2 T fragments requested one per gap and the weight ring's two refills behind their last use.
+            // 36 k-steps fully unrolled: ring slots, fragment rotation and tap offsets are compile-time.
             half8 rbh[8], rbl[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) { rbh[u] = glb16(bp + (size_t)u * 2048); rbl[u] = glb16(bp + (size_t)u * 2048 + 16); }
-#pragma unroll 1
-            for (int tap2 = 0; tap2 < 10; tap2 += 2) {
+            auto koff = [&](int ks) { const int tap = ks >> 2, ky = tap / 3, kx = tap - 3 * ky; return abase + (ky * NC + kx) * PX + (ks & 3) * 32; };
+            // ONE running pointer for the ring's refills, opaque per k-step: 28 distinct 64-bit addresses would otherwise be computed ahead
+            // and parked in AGPRs (56 registers the window prefetch needs)
+            const char *rp = bp + (size_t)8 * 2048;
+            half8 ah[T], al[T], nh_[T], nl_[T];
 #pragma unroll
-                for (int v = 0; v < 8; v++) {
-                    const int tap = tap2 + (v >> 2), u = v & 3;
-                    if (tap < 9) {
-                        const int ky = tap / 3, kx = tap - 3 * ky, toff = abase + (ky * NC + kx) * PX;
-                        const half8 Bh = rbh[v], Bl = rbl[v];
-                        half8 ah[T], al[T];                   // consecutive MFMAs go to different accumulators
+            for (int t = 0; t < T; t++) { ah[t] = lds16(koff(0) + t * ROWSTRIDE); al[t] = lds16(PLANE + koff(0) + t * ROWSTRIDE); nh_[t] = ah[t]; nl_[t] = al[t]; }
 #pragma unroll
-                        for (int t = 0; t < T; t++) { ah[t] = lds16(toff + t * ROWSTRIDE + u * 32); al[t] = lds16(PLANE + toff + t * ROWSTRIDE + u * 32); }
+            for (int ks = 0; ks < 36; ks++) {
+                const int slot = ks & 7;
+                const half8 Bh = rbh[slot], Bl = rbl[slot];
 #pragma unroll
-                        for (int t = 0; t < T; t++) acc[t] = mfma16(ah[t], Bh, acc[t]);
-#pragma unroll
-                        for (int t = 0; t < T; t++) acc[t] = mfma16(ah[t], Bl, acc[t]);
-#pragma unroll
-                        for (int t = 0; t < T; t++) acc[t] = mfma16(al[t], Bh, acc[t]);
-                        if (tap + 2 < 9) {
-                            rbh[v] = glb16(bp + (size_t)(4 * tap + 8 + u) * 2048); rbl[v] = glb16(bp + (size_t)(4 * tap + 8 + u) * 2048 + 16);
-                        }
-                    }
+                for (int t = 0; t < T; t++) {
+#if EG_X != 1
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(ah[t]), "v"(Bh));
+#else
+                    asm volatile("" :: "v"(ah[t]), "v"(Bh));
+#endif
+                    if (ks + 1 < 36) nh_[t] = lds16(koff(ks + 1) + t * ROWSTRIDE);
                 }
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+#if EG_X != 1
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(ah[t]), "v"(Bl));
+#else
+                    asm volatile("" :: "v"(ah[t]), "v"(Bl));
+#endif
+                    if (ks + 1 < 36) nl_[t] = lds16(PLANE + koff(ks + 1) + t * ROWSTRIDE);
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+#if EG_X != 1
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(al[t]), "v"(Bh));
+#else
+                    asm volatile("" :: "v"(al[t]), "v"(Bh));
+#endif
+                    if (t == 0 && ks + 8 < 36) rbh[slot] = glb16(rp);
+                    if (t == 1 && ks + 8 < 36) rbl[slot] = glb16(rp + 16);
+                }
+                if (ks + 8 < 36) { rp += 2048; asm volatile("" : "+v"(rp)); }
+#pragma unroll
+                for (int t = 0; t < T; t++) { ah[t] = nh_[t]; al[t] = nl_[t]; }
             }
+            // XDL write -> VALU read distance of the pinned MFMAs (the hazard recogniser does not see inside the statements)
+            if constexpr (T == 5) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]));
+            else if constexpr (T == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]));
+            else static_assert(T == 3 || T == 5, "fence the accumulators of this band height");
         }
+        // layers 2-3 (round 6): the NEXT band's window is requested HERE — behind the last weight-ring load of this band (loads return in
+        // order: requested earlier it would stall the ring) and in front of the pooling, the band's stores and the loop turn-around, which
+        // now cover its memory round trip instead of following it (one wavefront per SIMD: nothing else would)
+        if (LAYER != 1 && PREFETCH && band + 1 < band_end) issue(band + 1);
         // ---- 3x3/2 max-pool on the raw accumulators, then scale / bias / ReLU on the pooled values only --------------------------
         // acc[t][i] of lane l: convolution row rr0 + t, column c0 + 8 (i / 4) + 4 (l / 32) + i % 4, channel ch.
         // The pooled band is assembled in LDS (over the input window, which is dead by now) as [plane][row][column][64 channels]
@@ -346,6 +389,9 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                 }
             }
         };
+#if EG_X == 2
+        if (LAYER != 1) { float sink = 0.f; for (int t = 0; t < T; t++) sink += acc[t][0]; if (sink == 12345.f) ovf = true; __syncthreads(); continue; }
+#endif
         const bool edge = c0 < 0 || c0 + 32 > P.Wc;           // the map's left / right edge runs through this tile
         // Rows in pairs: lanes 0-31 finish pooled row 2jp, lanes 32-63 row 2jp + 1.  Columns arrive eight at a time
         // (accumulator quad g of both wavefront halves): v_permlane32_swap(va, vb) hands every lane its own row's value of the

@@ -61,6 +61,16 @@ def test_no_hazard_around_the_pinned_mfmas_of_the_built_encoder():
     assert not found, "\n".join(found)
 
 
+def test_no_hazard_around_the_pinned_mfmas_of_the_layered_encoder():
+    """Round 6: the k-loop of the layered encoder's layers 2 and 3 (csrc/encoder_general.hip) is a stream of pinned MFMAs too: same
+    rules A and B on its built object (540 MFMAs in the layer-2 kernel, fully unrolled)."""
+    L = _lint()
+    found, stats = L.lint(_built("encoder_general.hip.o"))
+    layer2 = [k for k in stats if "enc_layer_k<2, 4, 2, 34" in k]
+    assert layer2 and stats[layer2[0]]["mfma"] == 540, stats
+    assert not found, "\n".join(found)
+
+
 @pytest.mark.parametrize("obj", ["kuka_tree.hip.o", "kuka_tree_occ.hip.o", "kuka_tree_rb.hip.o", "kuka_group.hip.o"])
 def test_dpp_sources_of_the_kuka_kernels_are_never_read_closer_than_two_wait_states_after_a_valu_write(obj):
     """Rule C: the lane-group primitives of the Kuka kernels are DPP instructions inside asm statements; the two wait states a DPP read
