@@ -372,7 +372,18 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
     if (host_noise && !all_finite_f64(host_noise, (size_t)n)) return h->fail(SRLHIP_EINVAL, "step: non-finite host_noise");
     if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total)))
         return rc;
-    memcpy(h->pin_in, actions, L.ab);
+    if (h->cfg.is_discrete) {
+        // copy and range-check in one pass: the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`) — an IndexError in
+        // its worker; -1 is its `None` action.  (Checked here so that the per-step Python path needs no reductions over the batch.)
+        const int32_t *src = static_cast<const int32_t *>(actions);
+        int32_t *dst = static_cast<int32_t *>(h->pin_in);
+        const int32_t top = num_actions_of(h->cfg);
+        int32_t bad = 0;
+        for (int i = 0; i < n; i++) { const int32_t a = src[i]; dst[i] = a; bad |= (a < -1) | (a >= top); }
+        if (bad) return h->fail(SRLHIP_EINVAL, "step: discrete action out of range (valid: -1 = no-op, 0 .. num_actions - 1)");
+    } else {
+        memcpy(h->pin_in, actions, L.ab);
+    }
     if (host_noise) memcpy(static_cast<uint8_t *>(h->pin_in) + L.in_noise, host_noise, sizeof(double) * n);
     uint8_t *din = nullptr, *o = nullptr;
     if (L.zero_copy) {

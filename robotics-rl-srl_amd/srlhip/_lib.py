@@ -210,6 +210,9 @@ class Handle(object):
         if rc:
             raise SrlHipError("{} failed ({}): {}".format(what, rc, self._lib.srlhip_last_error(self._h).decode()))
 
+    def last_error(self):
+        return self._lib.srlhip_last_error(self._h).decode()
+
     def close(self):
         if self._h:
             self._lib.srlhip_destroy(self._h)

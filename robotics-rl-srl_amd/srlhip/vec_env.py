@@ -312,8 +312,9 @@ class HipVecEnv(object):
                 np.copyto(dst, actions.reshape(n), casting="unsafe")
             else:
                 dst[:] = np.array([-1 if a is None else int(a) for a in actions], dtype=np.int32)
-            if dst.size and (dst.min() < -1 or dst.max() >= nact):
-                # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
+            # (range check: host-pointer handles do it inside srlhip_step_async while copying — no reductions over the batch here; the
+            #  device-pointer path of a learned SRL model checks below)
+            if self._fast is None and dst.size and (dst.min() < -1 or dst.max() >= nact):
                 raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(nact))
         else:
             # (a numeric ndarray cannot hold None: the per-element scan below would cost a 4096-iteration Python loop per step)
@@ -327,6 +328,10 @@ class HipVecEnv(object):
                 rc = sh.go()
                 if rc:
                     self._drain()
+                    msg = sh.h.last_error()
+                    if "out of range" in msg:
+                        # the reference indexes a per-action list (`[-dv, dv, 0, 0, 0, 0][action]`): IndexError in the worker
+                        raise IndexError("discrete action out of range [0, {}) (None/-1 = no-op)".format(nact))
                     sh.h._check(rc, "srlhip_step_async")
         else:
             host = self._host
@@ -381,10 +386,9 @@ class HipVecEnv(object):
             obs, rew, done = host["states"].copy(), host["rew"].copy(), host["done"]
         ik = None
         if self._info_bits:
-            ik = done >> 1                                   # srlhip_config.info_bits: the step ran under the IK conditioning flag
-            dones = (done & 1).astype(bool)
-            if not ik.any():
-                ik = None
+            dones = (done & 1).view(np.bool_)                # (a fresh array: `done` is the reused global plane)
+            if done.max() > 1:                               # srlhip_config.info_bits: some step ran under the IK conditioning flag
+                ik = done >> 1
         else:
             dones = done.astype(bool)
         infos = self._quiet_infos
