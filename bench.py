@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--per-step", action="store_true",
                     help="time the per-step VecEnv API (HipVecEnv.step_async / step_wait: the path rl_baselines.train drives) instead of fused "
                          "rollouts; with --device-ids the ONE process shards the envs over those GPUs")
+    ap.add_argument("--persistent", action="store_true", help="--per-step: persistent stepping (srlhip_set_persistent: a resident kernel, no launch per step); "
+                    "the launching path's figure is reported beside it")
     ap.add_argument("--device-ids", default=None, help="--per-step: GPUs of the sharded HipVecEnv ('all' or e.g. 0,1,2,3; default: device 0)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="roofline.traffic / issue_util from the committed profiles/ summaries only (no rocprofv3 --pmc child passes)")
@@ -572,9 +574,9 @@ def bench_per_step(args):
     K = args.steps if args.steps is not None else 2000
     W = args.warmup if args.warmup is not None else 300
 
-    def run(ids):
+    def run(ids, persistent=None):
         n = args.envs_per_gpu * len(ids)
-        env = HipVecEnv(env_id, n, seed=0, env_kwargs={"srl_model": "ground_truth"}, device_ids=ids, rng_mode=args.rng)
+        env = HipVecEnv(env_id, n, seed=0, env_kwargs={"srl_model": "ground_truth"}, device_ids=ids, rng_mode=args.rng, persistent=persistent)
         env.reset()
         acts = np.random.RandomState(0).randint(env.action_space.n, size=(64, n)).astype(np.int32)
         for t in range(W):
@@ -594,15 +596,18 @@ def bench_per_step(args):
         return {"n": n, "value": n * K / dt, "us_per_step_mean": dt / K * 1e6, "us_per_step_median": float(np.median(lat)) * 1e6,
                 "us_in_step_async": ta / K * 1e6, "us_in_step_wait": tw / K * 1e6}
 
-    r = run(device_ids)
-    line = {"metric": "env steps/sec, per-step VecEnv API (HipVecEnv.step), {} {} envs per shard x {} shard(s)".format(
-                env_id.split("-")[0], args.envs_per_gpu, len(device_ids)),
+    r = run(device_ids, True if args.persistent else None)
+    line = {"metric": "env steps/sec, per-step VecEnv API (HipVecEnv.step{}), {} {} envs per shard x {} shard(s)".format(
+                ", persistent stepping" if args.persistent else "", env_id.split("-")[0], args.envs_per_gpu, len(device_ids)),
             "value": r["value"], "unit": "env-steps/s", "n_gpus": len(set(device_ids)), "steps": K, "warmup": W, "ms_per_step": r["us_per_step_mean"] / 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "{} ground_truth obs through HipVecEnv.step_async / step_wait, one process, device_ids {}".format(env_id, device_ids),
                        "envs_per_shard": args.envs_per_gpu, "device_ids": device_ids, "rng_mode": args.rng, "per_step": r}}
+    if args.persistent:
+        line["config"]["persistent"] = True
+        line["config"]["launch_per_step"] = run(device_ids)
     if len(device_ids) > 1:
-        line["config"]["single_shard"] = run(device_ids[:1])
+        line["config"]["single_shard"] = run(device_ids[:1], True if args.persistent else None)
         line["config"]["step_time_vs_single_shard"] = r["us_per_step_median"] / line["config"]["single_shard"]["us_per_step_median"]
     print(json.dumps(line))
 

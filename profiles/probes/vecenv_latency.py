@@ -56,3 +56,29 @@ for ids in ([0], [0, 0], [0, 0, 0, 0]):
     print("HipVecEnv n=%d as %d shard(s) on device 0: step median %.1f us = step_async %.1f (launches only) + step_wait %.1f" % (
         n, len(ids), np.median(ta + tw), np.median(ta), np.median(tw)), flush=True)
     env.close()
+# round 6: persistent stepping (srlhip_set_persistent / HipVecEnv(persistent=True)): the same loops without a launch per step
+for n in (16, 256, 4096):
+    env = HipVecEnv("KukaButtonGymEnv-v0", n, seed=0, env_kwargs={"srl_model": "ground_truth"}, persistent=True)
+    env.reset()
+    acts = np.random.RandomState(0).randint(6, size=(WARM + TIMED, n))
+    for t in range(WARM): env.step(acts[t])
+    ts = []
+    for t in range(WARM, WARM + TIMED):
+        t0 = time.perf_counter(); env.step(acts[t]); ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    print("PERSISTENT HipVecEnv n=%d: mean %.1f us per step, median %.1f, p90 %.1f, max %.1f (%.3g env-steps/s)" % (n, ts.mean(), np.median(ts), np.percentile(ts, 90), ts.max(), n / ts.mean() * 1e6), flush=True)
+    env.close()
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg.num_envs, cfg.seed0 = n, 0
+    h = _lib.Handle(cfg)
+    h.reset()
+    h.set_persistent(True)
+    a = acts.astype(np.int32)
+    out = (h.new_obs(), np.zeros(n, np.float32), np.zeros(n, np.uint8))
+    for t in range(WARM): h.step(a[t], out=out)
+    ts = []
+    for t in range(WARM, WARM + TIMED):
+        t0 = time.perf_counter(); h.step(a[t], out=out); ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    print("   PERSISTENT raw srlhip_step n=%d: mean %.1f us, median %.1f, p90 %.1f, max %.1f" % (n, ts.mean(), np.median(ts), np.percentile(ts, 90), ts.max()), flush=True)
+    h.close()

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
 #include <new>
 
@@ -48,7 +49,9 @@ int ensure_pinned(Handle *h, void **buf, size_t *cap, size_t bytes) {
     if (*cap >= bytes) return 0;
     if (*buf) (void)hipHostFree(*buf);
     *buf = nullptr; *cap = 0;
-    SRL_HIP_CHECK(h, hipHostMalloc(buf, bytes, hipHostMallocMapped));      // mapped: kernels may address it directly (zero-copy step)
+    // mapped: kernels may address it directly (zero-copy step); coherent (fine-grained): what a RESIDENT kernel writes and releases at
+    // system scope is visible to the host while the kernel is still running (persistent stepping; + 16: its copy works in dwords)
+    SRL_HIP_CHECK(h, hipHostMalloc(buf, bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
     *cap = bytes;
     return 0;
 }
@@ -68,8 +71,51 @@ size_t obs_bytes_per_env(const Handle *h) {
     return sizeof(float) * obs_dim_of(h->cfg);
 }
 
-int set_device(Handle *h) {
+// ---- persistent stepping: host side of the protocol (internal.hpp PersistArgs) ---------------------------------------------------------
+struct PersistHost { volatile uint32_t seq, stop, parked; uint32_t pad[13]; volatile uint32_t done[16]; };     // mapped, coherent; done[8]: one per eighth of the workgroups
+PersistHost *persist_ctl(Handle *h) { return static_cast<PersistHost *>(h->persist_host); }
+
+// the resident kernel writes the state back and exits; afterwards the handle is an ordinary one again
+int persist_park(Handle *h) {
+    if (!h->persist_running) return 0;
+    PersistHost *c = persist_ctl(h);
+    __atomic_store_n(&c->stop, 1u, __ATOMIC_RELEASE);
+    SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    c->stop = 0; c->parked = 0;
+    h->persist_running = false;
+    return 0;
+}
+
+// step_pair: the caller is srlhip_step / _async / _wait.  Every OTHER entry point sees the state in HBM: the resident kernel parks first.
+int set_device(Handle *h, bool step_pair = false) {
     SRL_HIP_CHECK(h, hipSetDevice(h->cfg.device_id));
+    if (h->persist_running && !step_pair) return persist_park(h);
+    return 0;
+}
+
+// (re)start the resident kernel; it will treat `start_seq` as the last step it has done
+int persist_launch(Handle *h, uint32_t start_seq) {
+    PersistHost *c = persist_ctl(h);
+    c->stop = 0; c->parked = 0;
+    for (uint32_t g = 0; g < 8; g++) c->done[g] = start_seq;
+    SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay), (int)start_seq, 8 * kPersistWordStride, h->stream));
+    SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay + 8 * kPersistWordStride), 0, 8 * kPersistWordStride, h->stream));
+    void *dctl = nullptr, *din = nullptr, *dout = nullptr;
+    SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dctl, h->persist_host, 0));
+    SRL_HIP_CHECK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
+    SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dout, h->pin_out, 0));
+    uint32_t *w = static_cast<uint32_t *>(dctl);
+    PersistArgs pa;
+    pa.seq = w; pa.stop = w + 1; pa.parked = w + 2; pa.done = w + 16; pa.relay = h->persist_relay; pa.count = h->persist_relay + 8 * kPersistWordStride;
+    pa.start_seq = start_seq;
+    pa.spin_limit = h->persist_park_us / 2 + 1;        // one poll of workgroup 0: two PCIe reads + s_sleep 16, ~2 us
+    const size_t n = (size_t)h->n, ob = obs_bytes_per_env(h) * n, out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * n;
+    pa.stage = static_cast<const uint32_t *>(h->persist_stage); pa.host_out = static_cast<uint32_t *>(dout);
+    pa.rew_dw = (uint32_t)(out_rew / 4); pa.done_dw = (uint32_t)(out_done / 4);
+    uint8_t *o = static_cast<uint8_t *>(h->persist_stage);
+    int rc = kuka_persist_start(h, din, reinterpret_cast<float *>(o), reinterpret_cast<float *>(o + out_rew), o + out_done, pa);
+    if (rc) return rc;
+    h->persist_running = true;
     return 0;
 }
 
@@ -244,7 +290,7 @@ int srlhip_create(const srlhip_config *cfg, srlhip_handle *out) {
         // Monitor's (r, l) of the last finished episode where the host can read them without a copy: the kernels' exit stores go
         // over PCIe (12 bytes per env and launch), srlhip_episode_records() hands out the host view
         void *dp = nullptr;
-        if (hipHostMalloc(&h->ep_host, 12 * n, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, h->ep_host, 0) != hipSuccess) {
+        if (hipHostMalloc(&h->ep_host, 12 * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dp, h->ep_host, 0) != hipSuccess) {
             h->err = "create: hipHostMalloc (episode records) failed"; return bail(SRLHIP_ENOMEM);
         }
         memset(h->ep_host, 0, 12 * n);
@@ -265,7 +311,12 @@ int srlhip_destroy(srlhip_handle hh) {
     if (!hh) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     (void)hipSetDevice(h->cfg.device_id);
+    h->persist_step = false;
+    (void)persist_park(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->persist_host) (void)hipHostFree(h->persist_host);
+    if (h->persist_relay) (void)hipFree(h->persist_relay);
+    if (h->persist_stage) (void)hipFree(h->persist_stage);
     if (h->kuka) kuka_free(h);
     for (void *p : h->allocs) (void)hipFree(p);
     void *st[] = {h->st_actions, h->st_noise, h->st_obs, h->st_rew, h->st_done, h->st_mask, h->st_rand};
@@ -399,6 +450,16 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
         din = static_cast<uint8_t *>(h->st_actions);
         o = static_cast<uint8_t *>(h->st_obs);
     }
+    if (h->persist_on && L.zero_copy && !host_noise && !is_mobile(h->cfg.env_kind)) {
+        // persistent stepping: no launch — (re)start the resident kernel if it is parked, then hand it the step's sequence number
+        PersistHost *c = persist_ctl(h);
+        if (h->persist_running && c->parked) { if ((rc = persist_park(h))) return rc; }
+        if (!h->persist_running && (rc = persist_launch(h, h->persist_seq))) return rc;
+        h->persist_seq = h->persist_seq + 1 == kPersistPark ? 1 : h->persist_seq + 1;
+        __atomic_store_n(&c->seq, h->persist_seq, __ATOMIC_RELEASE);       // the actions above are visible before the number
+        h->persist_step = true;                        // host_step_finish collects this step from the resident kernel
+        return 0;
+    }
     const double *d_noise = host_noise ? reinterpret_cast<const double *>(din + L.in_noise) : nullptr;
     void *d_obs = want_obs ? o : nullptr;
     float *d_rew = reinterpret_cast<float *>(o + L.out_rew);
@@ -418,6 +479,35 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
 // wait for the step enqueued by host_step_begin and hand its planes to the caller
 int host_step_finish(Handle *h, void *obs_out, float *reward_out, uint8_t *done_out) {
     const StepLayout L = step_layout(h);
+    if (h->persist_step) {
+        // wait for every workgroup's `done` word; a kernel that parked before it saw this step (its timeout ran out while the caller
+        // was busy) is restarted: workgroup 0 relays either the step to everybody or the park token to everybody, never a mix
+        PersistHost *c = persist_ctl(h);
+        const uint32_t want = h->persist_seq;
+        h->persist_step = false;
+        uint64_t spins = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        // (persist_blocks real workgroups in a grid rounded up to a multiple of 8: eighth g reports iff it holds a real workgroup)
+        const uint32_t per = (h->persist_blocks + 7) / 8;
+        for (uint32_t b = 0; b < 8 && b * per < h->persist_blocks; b++) {
+            while (__atomic_load_n(&c->done[b], __ATOMIC_ACQUIRE) != want) {
+                if ((++spins & 1023u) != 0) continue;
+                if (c->parked) {
+                    int rc = persist_park(h);
+                    if (rc) return rc;
+                    if ((rc = persist_launch(h, want == 1 ? kPersistPark - 1 : want - 1))) return rc;
+                    b = 0;
+                } else if ((spins & ((1u << 20) - 1)) == 0) {
+                    // every few ms: a kernel that is gone without having parked has failed; a step never takes 20 s
+                    if (hipStreamQuery(h->stream) != hipErrorNotReady) { h->persist_running = false; return h->fail(SRLHIP_EHIP, "persistent step: the resident kernel is gone"); }
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                        (void)persist_park(h);
+                        return h->fail(SRLHIP_EHIP, "persistent step: timed out (a workgroup of the resident kernel never started: is the device shared?)");
+                    }
+                }
+            }
+        }
+    } else
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     const uint8_t *po = static_cast<const uint8_t *>(h->pin_out);
     if (obs_out) memcpy(obs_out, po, L.ob);
@@ -433,7 +523,7 @@ int srlhip_step(srlhip_handle hh, const void *actions, const double *host_noise,
                 uint8_t *done_out) {
     if (!hh || !actions) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
-    int rc = set_device(h);
+    int rc = set_device(h, true);
     if (rc) return rc;
     if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !host_noise)
         return h->fail(SRLHIP_EINVAL, "step: RNG_HOST needs host_noise");
@@ -454,7 +544,7 @@ int srlhip_step_async(srlhip_handle hh, const void *actions, const double *host_
     if (!hh || !actions) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     if (h->cfg.io_device) return h->fail(SRLHIP_EINVAL, "step_async: host-pointer handles only (on a device-pointer handle srlhip_step already only enqueues)");
-    int rc = set_device(h);
+    int rc = set_device(h, true);
     if (rc) return rc;
     if (h->cfg.rng_mode == SRLHIP_RNG_HOST && !host_noise) return h->fail(SRLHIP_EINVAL, "step_async: RNG_HOST needs host_noise");
     if (h->step_pending) return h->fail(SRLHIP_EINVAL, "step_async: the previous srlhip_step_async was not collected (srlhip_step_wait)");
@@ -467,11 +557,49 @@ int srlhip_step_wait(srlhip_handle hh, void *obs_out, float *reward_out, uint8_t
     if (!hh) return SRLHIP_EINVAL;
     Handle *h = reinterpret_cast<Handle *>(hh);
     if (!h->step_pending) return h->fail(SRLHIP_EINVAL, "step_wait: no srlhip_step_async is pending");
-    int rc = set_device(h);
+    int rc = set_device(h, true);
     if (rc) return rc;
     h->step_pending = false;
     return host_step_finish(h, obs_out, reward_out, done_out);
 }
+
+int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
+    if (!hh) return SRLHIP_EINVAL;
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    if (h->step_pending) return h->fail(SRLHIP_EINVAL, "set_persistent: a srlhip_step_async is pending");
+    int rc = set_device(h);                            // (parks a resident kernel)
+    if (rc) return rc;
+    if (!on) { h->persist_on = false; return 0; }
+    if (h->cfg.io_device || is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_ENOTSUP, "set_persistent: host-pointer Kuka handles only");
+    const int blocks = kuka_persist_blocks(h);
+    if (blocks <= 0 || !step_layout(h).zero_copy)
+        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs the default KukaButtonGymEnv configuration on a device RNG mode (the configuration-specialised "
+                                       "kernel), zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
+    if (!h->persist_host) {
+        const size_t bytes = sizeof(PersistHost);
+        if (hipHostMalloc(&h->persist_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipHostMalloc failed");
+        memset(h->persist_host, 0, bytes);
+        if (hipMalloc(reinterpret_cast<void **>(&h->persist_relay), 16 * kPersistWordStride * sizeof(uint32_t) + 64 * (size_t)((blocks + 7) / 8 * 8)) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
+        const StepLayout L = step_layout(h);
+        if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total))) return rc;
+        if (hipMalloc(&h->persist_stage, L.out_total + 16) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
+    }
+    h->persist_blocks = (uint32_t)blocks;
+    h->persist_park_us = park_us > 0 ? (uint32_t)park_us : 2000u;
+    h->persist_on = true;
+    return 0;
+}
+
+#if defined(SRL_PERSIST_PROF)
+// timeline build only (profiles/probes/persist_timeline.py): parks the resident kernel and returns the 8 stamps of every workgroup's last step
+int srlhip_debug_persist_prof(srlhip_handle hh, uint64_t *out, int32_t blocks) {
+    Handle *h = reinterpret_cast<Handle *>(hh);
+    int rc = set_device(h);
+    if (rc) return rc;
+    SRL_HIP_CHECK(h, hipMemcpy(out, h->persist_relay + 16 * kPersistWordStride, 64 * (size_t)blocks, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 int srlhip_step_pending(srlhip_handle hh) { return hh ? (reinterpret_cast<Handle *>(hh)->step_pending ? 1 : 0) : SRLHIP_EINVAL; }
 

@@ -45,6 +45,7 @@ struct MobileParams {
 };
 
 struct Handle;
+struct PersistArgs;
 
 // mobile.hip
 int mobile_alloc(Handle *h);
@@ -74,6 +75,8 @@ void kuka_default_model(double *table138);
 int kuka_set_tree_model(Handle *h, const double *table510);
 void kuka_default_tree_model(double *table510);
 int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
+int kuka_persist_blocks(Handle *h);          // persistent stepping: workgroups that report `done` (0: this handle has no persistent form)
+int kuka_persist_start(Handle *h, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done, const struct PersistArgs &pa);
 
 // raster.hip
 int raster_render(Handle *h, void *d_img);
@@ -85,6 +88,25 @@ struct RasterGripJoint { double parent, xyz[3], Rj[9], axis[3]; };
 struct RasterKukaView { const double *sq, *cq, *bq, *bx, *by, *bz, *b2q, *b2x, *b2y, *objs, *rb, *gsq, *gcq; RasterGripJoint gj[5]; const float *grip; int64_t n; int32_t two, rand_objects, has_tm; };
 
 struct KukaState;   // defined in kuka.hip
+
+// Persistent stepping (srlhip_set_persistent): the per-step API without a launch per step.  ONE launch of the rollout kernel stays
+// resident — every wavefront keeps its envs' state in registers — and takes its steps from the host through mapped memory: the host
+// writes the actions, then a new sequence number; workgroup 0 polls that word over PCIe and relays it through a device-memory word
+// (one poller on the bus, not 1024); every wavefront steps, writes its outputs to the mapped planes and its own `done` word.  The kernel
+// PARKS (writes the state back and exits) when told to (any other API call on the handle) or when no step arrived for park_us.
+struct PersistArgs {
+    const uint32_t *seq, *stop;     // host-written (mapped, coherent): sequence number of the newest step; 1 = park now
+    uint32_t *parked;               // device-written: workgroup 0 decided to park (the host must synchronise and relaunch)
+    uint32_t *done;                 // device-written [8]: sequence number of the last step that eighth of the workgroups finished
+    uint32_t *relay;                // device memory [8 x stride]: workgroup 0's token for the others (a sequence number, or kPersistPark)
+    uint32_t *count;                // device memory [8 x stride]: arrivals per eighth of the workgroups, never reset while resident
+    const uint32_t *stage;          // device memory: the staging copy of the step's output planes (same layout as the host's), dword view
+    uint32_t *host_out;             // the host's mapped output planes, dword view; reward / done planes start rew_dw / done_dw dwords in
+    uint32_t rew_dw, done_dw;
+    uint32_t start_seq, spin_limit;
+};
+constexpr int kPersistWordStride = 64;         // (uint32 words: 256 bytes between two relay / counter words)
+constexpr uint32_t kPersistPark = 0xffffffffu;
 
 struct Handle {
     srlhip_config cfg;
@@ -134,6 +156,12 @@ struct Handle {
     void *ep_host = nullptr;
     size_t pin_in_sz, pin_out_sz;
     bool step_pending = false;       // srlhip_step_async enqueued a step that srlhip_step_wait has not collected yet
+    // persistent stepping (PersistArgs): the mapped control block [seq, stop, parked, pad..., done[blocks]], the device relay word
+    bool persist_on = false, persist_running = false, persist_step = false;
+    void *persist_host = nullptr;
+    uint32_t *persist_relay = nullptr;
+    void *persist_stage = nullptr;
+    uint32_t persist_seq = 0, persist_blocks = 0, persist_park_us = 2000;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     template <class T>

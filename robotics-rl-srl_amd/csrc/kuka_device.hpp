@@ -103,6 +103,9 @@ int kuka_group_launch_table(Handle *h, const KukaParams &p, int T, const void *d
 int kuka_group_reset_table(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);
 int kuka_group_settle_table(Handle *h, const KukaParams &p);
 // full-model lane-group kernels (kuka_tree.hip)
+// persistent stepping: 1 when this handle's configuration has a persistent instantiation and its grid is co-resident on the device
+int kuka_tree_persist_blocks(Handle *h);       // > 0: the number of workgroups that report `done`; 0: not supported
+int kuka_tree_persist_launch(Handle *h, const KukaParams &p, const void *d_actions, float *obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out);
 int kuka_tree_reset(Handle *h, const KukaParams &p, const uint8_t *d_mask, const double *d_host_rand, int stride, float *obs);

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
 
 }  // namespace
 
-#define SRL_TREE_GO(MODE, J, G, NB) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, NB>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+#define SRL_TREE_GO(MODE, J, G, NB) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, NB>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
 // (Kuka2ButtonGymEnv takes discrete actions only: no joints-mode instantiation of the two-button kernels)
 #define SRL_TREE_MODE(MODE)                                         \
     if (two && d_actions) SRL_TREE_GO(MODE, false, true, 2);        \
@@ -108,7 +108,7 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
     if (spec) {
-#define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+#define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
         if (c.rng_mode == SRLHIP_RNG_PHILOX) { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, true); else SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, false); }
         else { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_MT19937, true); else SRL_TREE_SPEC(SRLHIP_RNG_MT19937, false); }     // (the reference's own streams: HipVecEnv's default)
 #undef SRL_TREE_SPEC
@@ -120,6 +120,39 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
         case SRLHIP_RNG_MT19937: SRL_TREE_MODE(SRLHIP_RNG_MT19937) break;
         default: SRL_TREE_MODE(SRLHIP_RNG_HOST)
     }
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- persistent stepping (internal.hpp PersistArgs; srlhip_set_persistent) ---------------------------------------------------------
+// Only the configuration the drop-in runs by default has a persistent instantiation: the configuration-specialised kernel (reference
+// ctor defaults, default solver details) on a device RNG mode.  The grid must be CO-RESIDENT: a workgroup that waits for the host in a
+// loop never makes room for one that has not started.
+static bool persist_config(const Handle *h) {
+    const srlhip_config &c = h->cfg;
+    return h->kuka && h->cfg.kuka_model == SRLHIP_KUKA_MODEL_FULL && reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 &&
+           c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.action_joints &&
+           !c.random_target && c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset && c.obs_mode == SRLHIP_OBS_GROUND_TRUTH;
+}
+int kuka_tree_persist_blocks(Handle *h) {
+    if (!persist_config(h)) return 0;
+    const int real = (h->n + kGroupEnvs - 1) / kGroupEnvs, grid = (real + 7) / 8 * 8;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->cfg.device_id) != hipSuccess) return 0;
+    const void *fn = h->cfg.rng_mode == SRLHIP_RNG_PHILOX ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 1, 1>)
+                                                          : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 1, 0, 1, 1>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGroupBlock, 0) != hipSuccess) return 0;
+    return (long long)per_cu * prop.multiProcessorCount >= grid ? real : 0;
+}
+int kuka_tree_persist_launch(Handle *h, const KukaParams &p, const void *d_actions, float *obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa) {
+    dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);
+    const double *no_noise = nullptr;
+    void *no_act = nullptr;
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX)
+        hipLaunchKernelGGL((kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, 0, d_actions, no_noise, obs, d_rew, d_done, no_act, pa);
+    else
+        hipLaunchKernelGGL((kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 1, 0, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, 0, d_actions, no_noise, obs, d_rew, d_done, no_act, pa);
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }

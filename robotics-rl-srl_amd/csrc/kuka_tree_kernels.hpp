@@ -96,10 +96,66 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 // (solver_detail = 0) as compile-time constants — the run-time
 // configuration tests of the env logic and of the step's branches fold away (the host selects it only for a handle with exactly
 // this configuration, kuka_tree.hip: spec_config_of).
-template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0, int SPEC = 0>
+// PERSIST = 1 (srlhip_set_persistent; GIVEN actions): the loop does not count to T — before every step the wavefront waits for the host's
+// next sequence number (PersistArgs: workgroup 0 polls the mapped word, the others its relay in device memory), reads its actions from
+// the SAME mapped row every step, writes its outputs to a staging copy of the output planes (the last wavefront of its eighth of the
+// grid copies them to the host and reports), publishes Monitor's record of an episode that ended right away; it leaves the loop (and
+// writes the state back like any rollout) when workgroup 0 relays the park token.
+// (timeline build of persistent stepping, profiles/probes/persist_timeline.py: -DSRL_PERSIST_PROF; 100 MHz device-wide clock, the stamps of
+//  a workgroup's LAST step, 8 per workgroup, behind the relay / counter words)
+#if defined(SRL_PERSIST_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define SRL_PSTAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(pa.relay + 16 * kPersistWordStride)[bid * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define SRL_PSTAMP(k) do { } while (0)
+#endif
+
+// persistent stepping: one wavefront copies an env range of the three output planes staging -> mapped host planes.  The staging copy was
+// written through by wavefronts of every XCD: agent-scope loads (sc1), ALL of them in flight before the first store — 16 bytes per lane
+// where the range is 16-byte aligned (always for obs / reward: ranges start at a multiple of 4 envs), dwords for the rest.
+struct PersistSeg { const uint32_t *src; uint32_t *dst; int count; };      // (dwords)
+__device__ __forceinline__ void persist_copy(const PersistSeg (&seg)[3]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kQ = 9;                                                    // 16-byte pieces in flight per lane: 9 KB per pass
+    int n4[3];                                                               // 16-byte pieces of each segment (0: not aligned)
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        n4[k] = ((reinterpret_cast<uintptr_t>(seg[k].src) | reinterpret_cast<uintptr_t>(seg[k].dst)) & 15) == 0 ? seg[k].count / 4 : 0;
+    const int pieces = n4[0] + n4[1] + n4[2];
+    for (int base = 0; base < pieces; base += kQ * kGroupBlock) {
+        u32x4 w[kQ];
+        const uint32_t *sp[kQ];
+        int64_t off[kQ];
+#pragma unroll
+        for (int q = 0; q < kQ; q++) {
+            int g = base + q * kGroupBlock + (int)threadIdx.x;
+            const bool on = g < pieces;
+            g = on ? g : 0;
+            const int k = g < n4[0] ? 0 : g < n4[0] + n4[1] ? 1 : 2;
+            const int idx = g - (k == 0 ? 0 : k == 1 ? n4[0] : n4[0] + n4[1]);
+            sp[q] = seg[k].src + (int64_t)idx * 4;
+            off[q] = on ? (seg[k].dst + (int64_t)idx * 4) - seg[k].src - (int64_t)idx * 4 : 0;   // dst - src of the piece's segment; 0 = skip
+            // (unconditional — a lane past the end re-reads piece 0 — so that no select sits between the load and the wait below)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[q]) : "v"(sp[q]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < kQ; q++)
+            if (off[q]) *reinterpret_cast<u32x4 *>(const_cast<uint32_t *>(sp[q]) + off[q]) = w[q];
+    }
+    // what is left: unaligned segments whole, the last count % 4 dwords of aligned ones
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int i = n4[k] * 4 + (int)threadIdx.x; i < seg[k].count; i += kGroupBlock)
+            seg[k].dst[i] = __hip_atomic_load(seg[k].src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+template <int MODE, bool JOINTS, bool GIVEN, int NB, int RB = 0, int SPEC = 0, int PERSIST = 0>
 __global__ void __launch_bounds__(kGroupBlock)
 kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int T, const void *actions, const double *noise,
-                    float *obs, float *rew, uint8_t *done_out, void *act_out) {
+                    float *obs, float *rew, uint8_t *done_out, void *act_out, PersistArgs pa) {
+    static_assert(!PERSIST || GIVEN, "persistent stepping takes the caller's actions");
     using namespace grp;
     __shared__ double scratch_all[kGroupEnvs][kTS];
     const int64_t n = p.n;
@@ -165,12 +221,54 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(obs_p), "+v"(rew_p), "+v"(done_p), "+v"(act_p), "+v"(given_p));
 #endif
-    for (int t = 0; t < T; t++) {
+    uint32_t my_seq = pa.start_seq, persist_k = 0;      // persist_k: steps since this launch
+    (void)my_seq; (void)persist_k;
+    for (int t = 0; PERSIST || t < T; t++) {
+        if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            uint32_t token = 0;
+            if (threadIdx.x == 0) {
+                if (blockIdx.x == 0) {
+                    // the one poller on the bus: a new sequence number -> relay it; told to stop, or nothing for spin_limit polls -> park
+                    uint32_t sq = my_seq, stop = 0, spins = 0;
+                    for (;;) {
+                        // (seq, stop) are one aligned 8-byte word of the control block: ONE PCIe read per poll
+                        const uint64_t w = __hip_atomic_load(reinterpret_cast<const uint64_t *>(pa.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        sq = (uint32_t)w; stop = (uint32_t)(w >> 32);
+                        if (sq != my_seq || stop || ++spins >= pa.spin_limit) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    token = sq != my_seq ? sq : kPersistPark;
+                    if (token == kPersistPark) __hip_atomic_store(pa.parked, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // eight relay words, 256 bytes apart (eight memory channels): a poller reads the word of its blockIdx % 8
+                    for (int x = 0; x < 8; x++) __hip_atomic_store(pa.relay + x * kPersistWordStride, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const uint32_t *rw = pa.relay + (blockIdx.x & 7) * kPersistWordStride;
+                    for (;;) {
+                        token = __hip_atomic_load(rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (token != my_seq) break;
+                        __builtin_amdgcn_s_sleep(8);              // ~128 pollers per word, ~0.25 us between two polls of a wavefront
+                    }
+                }
+            }
+            token = __builtin_amdgcn_readfirstlane(token);
+            if (token == kPersistPark) break;
+            my_seq = token;
+            persist_k += 1;
+            SRL_PSTAMP(0);
+            asm volatile("" ::: "memory");                       // the action reads below stay behind the token (they are system-scope loads)
+#endif
+        }
         int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
         if constexpr (GIVEN) {
-            if (cfg.is_discrete) a = *reinterpret_cast<const int32_t *>(given_p);
-            else for (int j = 0; j < adim; j++) ca[j] = reinterpret_cast<const float *>(given_p)[j];
-            given_p += act_stride;
+            if constexpr (PERSIST) {           // the same mapped row every step: re-read, never cached in a register
+                if (cfg.is_discrete) a = __hip_atomic_load(reinterpret_cast<const int32_t *>(given_p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else for (int j = 0; j < adim; j++) ca[j] = __hip_atomic_load(reinterpret_cast<const float *>(given_p) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                if (cfg.is_discrete) a = *reinterpret_cast<const int32_t *>(given_p);
+                else for (int j = 0; j < adim; j++) ca[j] = reinterpret_cast<const float *>(given_p)[j];
+                given_p += act_stride;
+            }
         } else {
             if (cfg.is_discrete) a = gact.next(5);
             else for (int j = 0; j < adim; j += 2) {
@@ -187,6 +285,9 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
         float ca_own = 0.f;
 #pragma unroll
         for (int j = 0; j < ND; j++) ca_own = L.l == j ? ca[j] : ca_own;
+#if defined(SRL_PERSIST_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (PERSIST) { __builtin_amdgcn_s_waitcnt(0x0F70); SRL_PSTAMP(1); }
+#endif
 #if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
         { using namespace tree; SRL_TSTAMP(20); }     // loop back-edge + the agent's action (sampled or loaded)
 #endif
@@ -205,14 +306,61 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
         }
-        if (lead) {
-            if (obs_p) observe(v, cfg, obs_p, 1);
-            if (rew_p) *rew_p = (float)reward;
-            if (done_p) *done_p = (uint8_t)((int)done | info);
+        if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // The outputs go to a STAGING copy of the host's planes in device memory, by agent-scope (write-through) stores.  Neither
+            // way of writing them to the mapped planes directly works from 1024 wavefronts: a plain store stays in the XCD's L2 until a
+            // write-back (measured: the host saw the previous step's observations; a release fence per wavefront writes back the whole
+            // L2 — generator states, spills — 1024 times per step: 121 us), a system-scope store of 1-12 bytes crosses PCIe as its own
+            // serialised transaction (~40 ns each, 20 k per step: 835 us).  Monitor's record of an episode that ended in this step goes
+            // to its mapped plane directly (rare: system-scope stores).
+            SRL_PSTAMP(2);
+            if (lead) {
+                float ob[17];
+                observe(v, cfg, ob, 1);
+                for (int j = 0; j < od; j++) __hip_atomic_store(obs_p + j, ob[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rew_p, (float)reward, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done_p, (uint8_t)((int)done | info), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done) {
+                    __hip_atomic_store(st.last_return + e, last_ret, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(st.last_length + e, last_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // "written through" = the store counter reaching 0
+            asm volatile("" ::: "memory");
+            SRL_PSTAMP(3);
+            // Every eighth of the workgroups (a contiguous env range) has an arrival counter; the LAST wavefront to arrive copies that
+            // range of the three planes from the staging copy to the host's — dwords, coalesced, whole lines — makes them visible with
+            // ONE system-scope release (a write-back of its L2) and then writes the eighth's `done` word: the host polls 8 words.  The
+            // counter is never reset: after k steps it stands at k * (real workgroups of the eighth).
+            const int per = (int)gridDim.x >> 3, grp8 = bid / per;
+            int real = (p.n + kGroupEnvs - 1) / kGroupEnvs - grp8 * per;
+            real = real > per ? per : real;
+            uint32_t last = 0;
+            if (threadIdx.x == 0) last = __hip_atomic_fetch_add(pa.count + grp8 * kPersistWordStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (uint32_t)real * persist_k;
+            SRL_PSTAMP(4);
+            if (__builtin_amdgcn_readfirstlane(last)) {
+                const int lo = grp8 * per * kGroupEnvs, hi = min(lo + per * kGroupEnvs, p.n);
+                const PersistSeg seg[3] = {{pa.stage + (int64_t)lo * od, pa.host_out + (int64_t)lo * od, (hi - lo) * od},
+                                           {pa.stage + pa.rew_dw + lo, pa.host_out + pa.rew_dw + lo, hi - lo},
+                                           {pa.stage + pa.done_dw + lo / 4, pa.host_out + pa.done_dw + lo / 4, (hi - lo + 3) / 4}};
+                persist_copy(seg);
+                SRL_PSTAMP(5);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                SRL_PSTAMP(6);
+                if (threadIdx.x == 0) __hip_atomic_store(pa.done + grp8, my_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#endif
+        } else {
+            if (lead) {
+                if (obs_p) observe(v, cfg, obs_p, 1);
+                if (rew_p) *rew_p = (float)reward;
+                if (done_p) *done_p = (uint8_t)((int)done | info);
+            }
+            if (obs_p) obs_p += n * od;
+            if (rew_p) rew_p += n;
+            if (done_p) done_p += n;
         }
-        if (obs_p) obs_p += n * od;
-        if (rew_p) rew_p += n;
-        if (done_p) done_p += n;
 #if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
         { using namespace tree; SRL_TSTAMP(11); }     // episode statistics, auto-reset, observation + output stores
 #endif

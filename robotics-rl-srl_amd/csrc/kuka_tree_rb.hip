@@ -7,7 +7,7 @@
 namespace srl {
 using namespace kuka;
 
-#define SRL_TREE_RB_GO(MODE, J, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out)
+#define SRL_TREE_RB_GO(MODE, J, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
 #define SRL_TREE_RB_MODE(MODE)                                      \
     if (joints && d_actions) SRL_TREE_RB_GO(MODE, true, true);      \
     else if (joints) SRL_TREE_RB_GO(MODE, true, false);             \

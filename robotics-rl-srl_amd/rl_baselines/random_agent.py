@@ -6,6 +6,8 @@ class RandomAgentModel(object):
     def customArguments(self, parser):
         parser.add_argument('--num-cpu', help='Number of envs (lanes of the GPU handles)', type=int, default=1)
         parser.add_argument('--device-ids', help="GPUs the envs are sharded over: 'all' or e.g. 0,1,2,3 (default: device 0)", type=str, default=None)
+        parser.add_argument('--persistent', action='store_true', default=False,
+                            help='no kernel launch per step: a resident kernel per GPU takes the steps through mapped memory (KukaButtonGymEnv, ground truth)')
         return parser
 
     def makeEnv(self, args, env_kwargs=None, load_path_normalise=None):

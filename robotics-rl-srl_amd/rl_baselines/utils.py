@@ -29,7 +29,8 @@ def createEnvs(args, allow_early_resets=False, env_kwargs=None, load_path_normal
     if device_ids is not None:
         device_ids = device_ids[:max(1, min(len(device_ids), args.num_cpu))]          # never more shards than envs
     envs = HipVecEnv(args.env, args.num_cpu, seed=args.seed, env_kwargs=kwargs, log_dir=getattr(args, "log_dir", None),
-                     device_id=getattr(args, "device_id", 0), device_ids=device_ids, allow_early_resets=allow_early_resets)
+                     device_id=getattr(args, "device_id", 0), device_ids=device_ids, allow_early_resets=allow_early_resets,
+                     persistent=True if getattr(args, "persistent", False) else None)      # (--persistent: no kernel launch per step, srlhip_set_persistent)
     envs = VecFrameStack(envs, getattr(args, "num_stack", 1))
     if kwargs["srl_model"] != "raw_pixels":
         envs = VecNormalize(envs, norm_obs=True, norm_reward=False)

@@ -37,7 +37,7 @@ _FIELD_SHAPES = {
 EXPORTS = [
     "srlhip_abi_version", "srlhip_default_config", "srlhip_create", "srlhip_destroy", "srlhip_obs_dim",
     "srlhip_obs_bytes", "srlhip_action_dim", "srlhip_num_actions", "srlhip_seed", "srlhip_reset",
-    "srlhip_reset_rand_count", "srlhip_step", "srlhip_step_async", "srlhip_step_wait", "srlhip_step_pending", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
+    "srlhip_reset_rand_count", "srlhip_step", "srlhip_step_async", "srlhip_step_wait", "srlhip_step_pending", "srlhip_set_persistent", "srlhip_rollout", "srlhip_get_state", "srlhip_set_state",
     "srlhip_device_ptr", "srlhip_render", "srlhip_episode_stats", "srlhip_episode_records", "srlhip_episode_stats_device", "srlhip_sync", "srlhip_copy_async", "srlhip_stream", "srlhip_timing_begin",
     "srlhip_timing_end", "srlhip_last_error", "srlhip_selftest_group_primitives", "srlhip_kuka_kernel", "srlhip_kuka_default_model", "srlhip_set_kuka_model", "srlhip_kuka_tree_default_model", "srlhip_set_kuka_tree_model",
     "srlhip_graph_begin", "srlhip_graph_end", "srlhip_graph_launch", "srlhip_graph_destroy",
@@ -47,7 +47,7 @@ EXPORTS = [
 ]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 KUKA_MODEL_DOUBLES = 138
 KUKA_TREE_MODEL_DOUBLES = 510
 KUKA_DETAIL_ALT_SWEEP, KUKA_DETAIL_BODY_ORDER, KUKA_DETAIL_FRICTION2 = 1, 2, 4
@@ -122,6 +122,7 @@ def load():
     lib.srlhip_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.srlhip_step_async.argtypes = [vp, vp, vp]
     lib.srlhip_step_wait.argtypes = [vp, vp, vp, vp]
+    lib.srlhip_set_persistent.argtypes = [vp, i32, i32]
     lib.srlhip_rollout.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.srlhip_get_state.argtypes = [vp, i32, vp]
     lib.srlhip_set_state.argtypes = [vp, i32, vp]
@@ -406,6 +407,11 @@ class Handle(object):
 
     def step_pending(self):
         return self._lib.srlhip_step_pending(self._h) == 1
+
+    def set_persistent(self, on=True, park_us=0):
+        """srlhip_set_persistent: per-step calls without a launch per step (a resident kernel takes its steps through mapped memory).
+        Raises SrlHipError (ENOTSUP) for handles that have no persistent form."""
+        self._check(self._lib.srlhip_set_persistent(self._h, int(bool(on)), int(park_us)), "srlhip_set_persistent")
 
     def episode_stats(self):
         n = self.num_envs

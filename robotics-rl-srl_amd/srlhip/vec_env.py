@@ -95,7 +95,7 @@ class _Shard(object):
 
 class HipVecEnv(object):
     def __init__(self, env_id, num_envs, seed=0, env_kwargs=None, device_id=0, first_env_id=0, rng_mode=None,
-                 log_dir=None, allow_early_resets=False, encoder=None, device_ids=None):
+                 log_dir=None, allow_early_resets=False, encoder=None, device_ids=None, persistent=None, park_us=0):
         kw = dict(env_kwargs or {})
         rng_mode = rng_mode or default_rng_mode()
         self.allow_early_resets, self._was_reset = bool(allow_early_resets), False
@@ -183,6 +183,21 @@ class HipVecEnv(object):
                 sh.go, sh.collect = sh.h.step_split_fn(act[sh.lo:sh.hi], obs[sh.lo:sh.hi], rew[sh.lo:sh.hi], done[sh.lo:sh.hi])
                 sh.ret, sh.len = sh.h.episode_records()
             self._fast = {"act": act, "obs": obs, "rew": rew, "done": done}
+        # Persistent stepping (srlhip_set_persistent; opt-in: persistent=True or SRLHIP_PERSISTENT=1): no launch per step — a resident kernel
+        # per shard keeps the envs in registers and takes its steps through mapped memory; it parks for every other call and after
+        # park_us without a step.  It occupies its whole GPU while resident: for policies that run on the host or on another device.
+        want = persistent if persistent is not None else os.environ.get("SRLHIP_PERSISTENT", "0") not in ("", "0")
+        self.persistent = False
+        if want:
+            try:
+                for sh in self._shards:
+                    sh.h.set_persistent(True, park_us)
+                self.persistent = True
+            except _lib.SrlHipError:
+                for sh in self._shards:
+                    sh.h.set_persistent(False)
+                if persistent:                          # asked for explicitly: say why not
+                    raise
         self._mon_rows, self._mon_count, self._mon_flushed = {}, 0, time.time()
         self._t_start = time.time()
         # bench.Monitor files, one per env like the reference (environments/utils.py:54), named by GLOBAL env id.  They are NOT kept

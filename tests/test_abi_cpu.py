@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(declared) == sorted(_lib.EXPORTS)
-    assert lib.srlhip_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.srlhip_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_config_struct_matches_header():

@@ -1,0 +1,88 @@
+"""GPU: persistent stepping (srlhip_set_persistent, HipVecEnv(persistent=True)) — the per-step API of the drop-in
+(rl_baselines/utils.py:213-229: SubprocVecEnv.step_async / step_wait) without a kernel launch per step: one launch of the rollout kernel
+stays resident with every env's state in registers and takes its steps from the host through mapped memory.  Same kernel code, so the
+bar is bit-exact equality with the launching path — observations, rewards, dones, infos, Monitor files — across parks and restarts
+(other API calls in between, the idle timeout), and a measurable latency gain."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from srlhip import _lib
+from srlhip.vec_env import HipVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _strip_t(infos):
+    return [{k: ({kk: vv for kk, vv in v.items() if kk != "t"} if k == "episode" else v) for k, v in d.items()} for d in infos]
+
+
+@pytest.mark.parametrize("n, rng_mode", [(4096, "mt19937"), (1000, "philox"), (7, "mt19937")])
+def test_persistent_env_is_the_launching_env_bit_for_bit(n, rng_mode, tmp_path):
+    kw = {"srl_model": "ground_truth"}
+    a = HipVecEnv("KukaButtonGymEnv-v0", n, seed=3, env_kwargs=kw, rng_mode=rng_mode, log_dir=str(tmp_path / "a"))
+    b = HipVecEnv("KukaButtonGymEnv-v0", n, seed=3, env_kwargs=kw, rng_mode=rng_mode, log_dir=str(tmp_path / "b"), persistent=True, park_us=3000)
+    assert b.persistent and not a.persistent
+    assert np.array_equal(a.reset(), b.reset())
+    rs = np.random.RandomState(0)
+    ended = 0
+    for t in range(1250):
+        act = rs.randint(6, size=n)
+        x, y = a.step(act), b.step(act)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), t
+        assert _strip_t(x[3]) == _strip_t(y[3]), t
+        ended += int(x[2].sum())
+        if t % 200 == 50:                  # another entry point parks the resident kernel; the next step restarts it
+            assert np.array_equal(a._h.get_state(_lib.F_KUKA_Q), b._h.get_state(_lib.F_KUKA_Q))
+        if t == 333:
+            time.sleep(0.02)               # the idle timeout parks it too
+        if t == 700:
+            ia, ib = a.get_images(), b.get_images()
+            assert all(np.array_equal(p, q) for p, q in zip(ia[:8], ib[:8]))
+    assert ended >= n
+    for u, v in zip(a.episode_returns(), b.episode_returns()):
+        assert np.array_equal(u, v)
+    a.close(); b.close()
+    for i in range(n):
+        with open(str(tmp_path / "a" / "{}.monitor.csv".format(i))) as f, open(str(tmp_path / "b" / "{}.monitor.csv".format(i))) as g:
+            ra = [row.split(",")[:2] for row in f.read().splitlines()[2:]]
+            rb = [row.split(",")[:2] for row in g.read().splitlines()[2:]]
+        assert ra == rb, i
+
+
+def test_persistent_is_refused_where_it_cannot_work():
+    for kind, tweak in ((_lib.ENV_MOBILE, {}), (_lib.ENV_KUKA_BUTTON, {"random_target": 1}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}),
+                        (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}), (_lib.ENV_KUKA_2BUTTON, {})):
+        cfg = _lib.default_config(kind)
+        cfg.num_envs, cfg.rng_mode = 64, _lib.RNG_PHILOX
+        for k, v in tweak.items():
+            setattr(cfg, k, v)
+        h = _lib.Handle(cfg)
+        with pytest.raises(_lib.SrlHipError):
+            h.set_persistent(True)
+        h.close()
+    with pytest.raises(_lib.SrlHipError):
+        HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "ground_truth"}, persistent=True)
+    env = HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "ground_truth"})      # SRLHIP_PERSISTENT unset: plain launches
+    assert not env.persistent
+    env.close()
+
+
+def test_persistent_step_latency():
+    """steady state, 4096 envs, the reference's MT19937 streams: median step of the launching path against the resident kernel"""
+    res = {}
+    for name, persistent in (("launch per step", False), ("resident kernel", True)):
+        env = HipVecEnv("KukaButtonGymEnv-v0", 4096, seed=0, env_kwargs={"srl_model": "ground_truth"}, persistent=persistent)
+        env.reset()
+        acts = np.random.RandomState(0).randint(6, size=(1500, 4096))
+        for t in range(1100):
+            env.step(acts[t])
+        ts = []
+        for t in range(1100, 1500):
+            t0 = time.perf_counter(); env.step(acts[t]); ts.append(time.perf_counter() - t0)
+        res[name] = float(np.median(ts)) * 1e6
+        env.close()
+    print("HipVecEnv.step, 4096 envs, steady state: " + ", ".join("{} {:.1f} us".format(k, v) for k, v in res.items()))
+    assert res["resident kernel"] < 0.95 * res["launch per step"]
