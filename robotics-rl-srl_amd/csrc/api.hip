@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <mutex>
 #include <cmath>
 #include <new>
 
@@ -74,6 +75,17 @@ size_t obs_bytes_per_env(const Handle *h) {
 // ---- persistent stepping: host side of the protocol (internal.hpp PersistArgs) ---------------------------------------------------------
 struct PersistHost { volatile uint32_t seq, stop, parked; uint32_t pad[13]; volatile uint32_t done[16]; };     // mapped, coherent; done[8]: one per eighth of the workgroups
 PersistHost *persist_ctl(Handle *h) { return static_cast<PersistHost *>(h->persist_host); }
+
+// Resident kernels of several handles on ONE device (the shards of HipVecEnv(device_ids=[0, 0])) must all fit at once: a workgroup that
+// waits for the host never makes room for another kernel's.  Per-device tally of the grids of the handles in persistent mode, process-wide.
+std::mutex g_persist_mu;
+int g_persist_reserved[64] = {0};
+void persist_release(Handle *h) {
+    if (!h->persist_reserved) return;
+    std::lock_guard<std::mutex> lk(g_persist_mu);
+    g_persist_reserved[h->cfg.device_id & 63] -= h->persist_reserved;
+    h->persist_reserved = 0;
+}
 
 // the resident kernel writes the state back and exits; afterwards the handle is an ordinary one again
 int persist_park(Handle *h) {
@@ -313,6 +325,7 @@ int srlhip_destroy(srlhip_handle hh) {
     (void)hipSetDevice(h->cfg.device_id);
     h->persist_step = false;
     (void)persist_park(h);
+    persist_release(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->persist_host) (void)hipHostFree(h->persist_host);
     if (h->persist_relay) (void)hipFree(h->persist_relay);
@@ -569,9 +582,10 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
     if (h->step_pending) return h->fail(SRLHIP_EINVAL, "set_persistent: a srlhip_step_async is pending");
     int rc = set_device(h);                            // (parks a resident kernel)
     if (rc) return rc;
-    if (!on) { h->persist_on = false; return 0; }
+    if (!on) { h->persist_on = false; persist_release(h); return 0; }
     if (h->cfg.io_device || is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_ENOTSUP, "set_persistent: host-pointer Kuka handles only");
-    const int blocks = kuka_persist_blocks(h);
+    int capacity = 0;
+    const int blocks = kuka_persist_blocks(h, &capacity);
     if (blocks <= 0 || !step_layout(h).zero_copy)
         return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs the default KukaButtonGymEnv configuration on a device RNG mode (the configuration-specialised "
                                        "kernel), zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
@@ -583,6 +597,14 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
         const StepLayout L = step_layout(h);
         if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total))) return rc;
         if (hipMalloc(&h->persist_stage, L.out_total + 16) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
+    }
+    if (!h->persist_reserved) {
+        const int grid = (blocks + 7) / 8 * 8;
+        std::lock_guard<std::mutex> lk(g_persist_mu);
+        if (g_persist_reserved[h->cfg.device_id & 63] + grid > capacity)
+            return h->fail(SRLHIP_ENOTSUP, "set_persistent: the resident kernels of the handles already in persistent mode on this device leave no room for this one");
+        g_persist_reserved[h->cfg.device_id & 63] += grid;
+        h->persist_reserved = grid;
     }
     h->persist_blocks = (uint32_t)blocks;
     h->persist_park_us = park_us > 0 ? (uint32_t)park_us : 2000u;

@@ -75,7 +75,7 @@ void kuka_default_model(double *table138);
 int kuka_set_tree_model(Handle *h, const double *table510);
 void kuka_default_tree_model(double *table510);
 int kuka_group_probe(const double *q7_host, double *out_host, int out_doubles);
-int kuka_persist_blocks(Handle *h);          // persistent stepping: workgroups that report `done` (0: this handle has no persistent form)
+int kuka_persist_blocks(Handle *h, int *capacity);   // persistent stepping: real workgroups of the resident kernel (0: this handle has no persistent form); capacity: how many the device holds at once
 int kuka_persist_start(Handle *h, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done, const struct PersistArgs &pa);
 
 // raster.hip
@@ -162,6 +162,7 @@ struct Handle {
     uint32_t *persist_relay = nullptr;
     void *persist_stage = nullptr;
     uint32_t persist_seq = 0, persist_blocks = 0, persist_park_us = 2000;
+    int persist_reserved = 0;        // workgroups this handle holds in the per-device residency tally (api.hip)
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     template <class T>

@@ -392,7 +392,7 @@ int kuka_step(Handle *h, const void *d_actions, const double *d_noise, void *d_o
     return 0;
 }
 
-int kuka_persist_blocks(Handle *h) { return h->kuka && h->kuka->full ? kuka_tree_persist_blocks(h) : 0; }
+int kuka_persist_blocks(Handle *h, int *capacity) { if (capacity) *capacity = 0; return h->kuka && h->kuka->full ? kuka_tree_persist_blocks(h, capacity) : 0; }
 int kuka_persist_start(Handle *h, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa) {
     return kuka_tree_persist_launch(h, params_of(h), d_actions, d_obs, d_rew, d_done, pa);
 }

@@ -104,7 +104,7 @@ int kuka_group_reset_table(Handle *h, const KukaParams &p, const uint8_t *d_mask
 int kuka_group_settle_table(Handle *h, const KukaParams &p);
 // full-model lane-group kernels (kuka_tree.hip)
 // persistent stepping: 1 when this handle's configuration has a persistent instantiation and its grid is co-resident on the device
-int kuka_tree_persist_blocks(Handle *h);       // > 0: the number of workgroups that report `done`; 0: not supported
+int kuka_tree_persist_blocks(Handle *h, int *capacity);       // > 0: the number of real workgroups; 0: not supported.  capacity: workgroups of that kernel the device holds at once
 int kuka_tree_persist_launch(Handle *h, const KukaParams &p, const void *d_actions, float *obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa);
 int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_actions, const double *d_noise, float *obs, float *d_rew,
                      uint8_t *d_done, void *d_act_out);

@@ -134,7 +134,8 @@ static bool persist_config(const Handle *h) {
            c.env_kind == SRLHIP_ENV_KUKA_BUTTON && (c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) && c.is_discrete && !c.action_joints &&
            !c.random_target && c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset && c.obs_mode == SRLHIP_OBS_GROUND_TRUTH;
 }
-int kuka_tree_persist_blocks(Handle *h) {
+int kuka_tree_persist_blocks(Handle *h, int *capacity) {
+    if (capacity) *capacity = 0;
     if (!persist_config(h)) return 0;
     const int real = (h->n + kGroupEnvs - 1) / kGroupEnvs, grid = (real + 7) / 8 * 8;
     int per_cu = 0;
@@ -143,6 +144,7 @@ int kuka_tree_persist_blocks(Handle *h) {
     const void *fn = h->cfg.rng_mode == SRLHIP_RNG_PHILOX ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 1, 1>)
                                                           : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 1, 0, 1, 1>);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGroupBlock, 0) != hipSuccess) return 0;
+    if (capacity) *capacity = per_cu * prop.multiProcessorCount;       // workgroups of this kernel the device holds at once
     return (long long)per_cu * prop.multiProcessorCount >= grid ? real : 0;
 }
 int kuka_tree_persist_launch(Handle *h, const KukaParams &p, const void *d_actions, float *obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa) {
