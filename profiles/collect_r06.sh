@@ -38,12 +38,19 @@ timeout 300 python profiles/probes/vecenv_latency.py > $OUT/vecenv_latency.txt 2
 timeout 300 python bench.py --per-step > $OUT/bench_per_step.json 2>/dev/null
 timeout 300 python bench.py --per-step --envs-per-gpu 2048 --device-ids 0,0 > $OUT/bench_per_step_2x2048_one_device.json 2>/dev/null
 timeout 300 python bench.py --per-step --envs-per-gpu 1024 --device-ids 0,0,0,0 > $OUT/bench_per_step_4x1024_one_device.json 2>/dev/null
+timeout 300 python bench.py --per-step --persistent > $OUT/bench_per_step_persistent.json 2>/dev/null
+timeout 300 python bench.py --per-step --persistent --envs-per-gpu 256 > $OUT/bench_per_step_persistent_256.json 2>/dev/null
+[ -f robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so ] && SRLHIP_LIB=$R/robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so timeout 200 python profiles/probes/persist_timeline.py 4096 2>&1 | grep -v libdrm > $OUT/persist_timeline.txt
 timeout 300 python profiles/encoder_microbench.py > $OUT/encoder_microbench.txt 2>&1
 SRLHIP_ENCODER_L1=f16 timeout 300 python profiles/encoder_microbench.py > $OUT/encoder_microbench_f16_layer1.txt 2>&1
 for n in 4 5 6; do
   [ -f robotics-rl-srl_amd/csrc/build/libsrlhip_encx$n.so ] && SRLHIP_LIB=$R/robotics-rl-srl_amd/csrc/build/libsrlhip_encx$n.so timeout 200 python profiles/probes/encoder_phase_probe.py 2>&1 | grep -v libdrm >> $OUT/encoder_experiments.txt
 done
 timeout 200 python profiles/probes/encoder_phase_probe.py 2>&1 | grep -v libdrm >> $OUT/encoder_experiments.txt
+for n in 1 2 3 4 5 6; do
+  [ -f robotics-rl-srl_amd/csrc/build/libsrlhip_egx$n.so ] && SRLHIP_LIB=$R/robotics-rl-srl_amd/csrc/build/libsrlhip_egx$n.so timeout 200 python profiles/probes/encoder_general_layer_times.py 2>&1 | grep "ms per" >> $OUT/encoder_general_experiments.txt
+done
+timeout 200 python profiles/probes/encoder_general_layer_times.py 2>&1 | grep "ms per" >> $OUT/encoder_general_experiments.txt
 SRLHIP_SINGLE_DEVICE=1 SRLHIP_DIST_BACKEND=gloo timeout 600 python bench.py --workload kuka_pixels --gpus 8 2>/dev/null | grep "^{" > $OUT/bench_pixels_gpus8_single_device.json
 for n in 4096 16384 65536; do
   timeout 300 python bench.py --workload kuka --no-cpu-baseline --no-secondary --no-live-pmc --envs-per-gpu $n --steps 3 --inner-steps 1024 >> $OUT/nsweep_kuka.jsonl 2>/dev/null

@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/../../robotics-rl-srl_amd/csrc"
 for n in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -DENC_X=$n -c encoder.hip -o build/encoder_x$n.hip.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsrlhip_encx$n.so $(ls build/*.hip.o build/*.cpp.o | grep -v "encoder.hip.o\|encoder_x\|kuka_tree_prof") build/encoder_x$n.hip.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsrlhip_encx$n.so $(ls build/*.hip.o build/*.cpp.o | grep -v "encoder.hip.o\|encoder_x\|encoder_general_x\|kuka_tree_prof\|_pprof") build/encoder_x$n.hip.o
 done

@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/../../robotics-rl-srl_amd/csrc"
 for n in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -DEG_X=$n -c encoder_general.hip -o build/encoder_general_x$n.hip.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsrlhip_egx$n.so $(ls build/*.hip.o build/*.cpp.o | grep -v "encoder_general.hip.o\|encoder_general_x\|encoder_x\|kuka_tree_prof") build/encoder_general_x$n.hip.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsrlhip_egx$n.so $(ls build/*.hip.o build/*.cpp.o | grep -v "encoder_general.hip.o\|encoder_general_x\|encoder_x\|kuka_tree_prof\|_pprof") build/encoder_general_x$n.hip.o
 done

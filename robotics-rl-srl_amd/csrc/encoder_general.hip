@@ -31,7 +31,8 @@
 
 #ifndef EG_X
 #define EG_X 0          // experiment builds (profiles/probes/encoder_general_experiments.sh): 1 = layers 2-3 without their MFMAs, 2 = without
-#endif                  // the pooling / band stores, 3 = without the window loads.  Results are wrong by construction; 0 = the product.
+#endif                  // the pooling / band stores, 3 = without the window loads; 4 / 5 / 6 = layer 1 without its MFMAs / pooling and
+                        // stores / pixel unpack.  Results are wrong by construction; 0 = the product.
 
 namespace srlenc {
 
@@ -204,6 +205,9 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                         *reinterpret_cast<uint32_t *>(win + pix * 4) = in ? ((a & 0xffffffu) ^ 0x808080u) | ((uint32_t)kMaskI8 << 24) : 0u;
                         continue;
                     }
+#if EG_X == 6
+                    if (CPIX == 4) { *reinterpret_cast<uint32_t *>(win + pix * 8) = a; continue; }
+#endif
                     a = in ? (a & 0xffffffu) | 0x01000000u : 0u;                           // byte 3: the mask
                     b = in ? b : 0u;
                     if (CPIX == 4) {
@@ -303,10 +307,15 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                 for (int t = 0; t < T; t++) a[t] = lds16(abase + t * ROWSTRIDE + koff);
                 const half8 Bh = LDSB ? lds16(((nh * KS + s) * 64 + lane) * 32) : Bh1[LDSB ? 0 : s];
                 const half8 Bl = LDSB ? lds16(((nh * KS + s) * 64 + lane) * 32 + 16) : Bl1[LDSB ? 0 : s];
+#if EG_X == 4
+#pragma unroll
+                for (int t = 0; t < T; t++) { asm volatile("" :: "v"(a[t]), "v"(Bh)); asm volatile("" :: "v"(Bl)); }
+#else
 #pragma unroll
                 for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bh, acc[t]);
 #pragma unroll
                 for (int t = 0; t < T; t++) acc[t] = mfma16(a[t], Bl, acc[t]);
+#endif
             }
         } else {
             // Round 6: the k-loop as a hand-scheduled stream, like the fused kernel's layer 2 (csrc/encoder.hip, NOTES section O).  Left to
@@ -389,6 +398,9 @@ __global__ __launch_bounds__(LDSB ? 256 : 128, LDSB ? 2 : 1) void enc_layer_k(La
                 }
             }
         };
+#if EG_X == 5
+        if (LAYER == 1) { float sink = 0.f; for (int t = 0; t < T; t++) sink += acc[t][0]; if (sink == 12345.f) ovf = true; __syncthreads(); continue; }
+#endif
 #if EG_X == 2
         if (LAYER != 1) { float sink = 0.f; for (int t = 0; t < T; t++) sink += acc[t][0]; if (sink == 12345.f) ovf = true; __syncthreads(); continue; }
 #endif
