@@ -173,9 +173,9 @@ int srlhip_step_async(srlhip_handle h, const void *actions, const double *host_n
 int srlhip_step_wait(srlhip_handle h, void *obs_out, float *reward_out, uint8_t *done_out);
 int srlhip_step_pending(srlhip_handle h);
 
-/* Persistent stepping (opt-in; host-pointer KukaButtonGymEnv handles in the reference's default configuration — discrete
- * actions, ground-truth observations, a device RNG mode — whose wavefronts are all resident at once: up to 4096 envs on an
- * MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
+/* Persistent stepping (opt-in; host-pointer handles of the one-button Kuka envs — KukaButtonGymEnv, KukaMovingButtonGymEnv, any
+ * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
+ * 4096 envs on an MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
  * the device with every env's state in registers.  srlhip_step_async writes the actions and a sequence number into mapped
  * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront steps and writes its
  * outputs to a staging copy of the output planes in device memory; the last wavefront of each eighth of the grid to finish

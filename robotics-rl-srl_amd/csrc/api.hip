@@ -587,8 +587,8 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
     int capacity = 0;
     const int blocks = kuka_persist_blocks(h, &capacity);
     if (blocks <= 0 || !step_layout(h).zero_copy)
-        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs the default KukaButtonGymEnv configuration on a device RNG mode (the configuration-specialised "
-                                       "kernel), zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
+        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs a one-button Kuka env (KukaButtonGymEnv, KukaMovingButtonGymEnv) on a device RNG mode, non-pixel "
+                                       "observations, zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
     if (!h->persist_host) {
         const size_t bytes = sizeof(PersistHost);
         if (hipHostMalloc(&h->persist_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipHostMalloc failed");

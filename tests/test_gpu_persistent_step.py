@@ -53,8 +53,8 @@ def test_persistent_env_is_the_launching_env_bit_for_bit(n, rng_mode, tmp_path):
 
 
 def test_persistent_is_refused_where_it_cannot_work():
-    for kind, tweak in ((_lib.ENV_MOBILE, {}), (_lib.ENV_KUKA_BUTTON, {"random_target": 1}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}),
-                        (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}), (_lib.ENV_KUKA_2BUTTON, {})):
+    for kind, tweak in ((_lib.ENV_MOBILE, {}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}), (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}),
+                        (_lib.ENV_KUKA_2BUTTON, {}), (_lib.ENV_KUKA_RAND, {})):
         cfg = _lib.default_config(kind)
         cfg.num_envs, cfg.rng_mode = 64, _lib.RNG_PHILOX
         for k, v in tweak.items():
@@ -109,3 +109,31 @@ def test_persistent_shards_on_one_device_share_its_residency():
     c = HipVecEnv("KukaButtonGymEnv-v0", 64, seed=5, env_kwargs=kw, persistent=True)     # released with the handles
     assert c.persistent
     c.close(); a.close()
+
+
+@pytest.mark.parametrize("env_id, kw, rng_mode", [
+    ("KukaButtonGymEnv-v0", {"srl_model": "ground_truth", "random_target": True}, "mt19937"),
+    ("KukaButtonGymEnv-v0", {"srl_model": "ground_truth", "is_discrete": False, "shape_reward": True}, "philox"),
+    ("KukaButtonGymEnv-v0", {"srl_model": "joints_position", "is_discrete": False, "action_joints": True}, "mt19937"),
+    ("KukaButtonGymEnv-v0", {"srl_model": "joints", "action_repeat": 2}, "philox"),
+    ("KukaMovingButtonGymEnv-v0", {"srl_model": "ground_truth"}, "mt19937"),
+])
+def test_persistent_generic_instantiations(env_id, kw, rng_mode):
+    """the one-button configurations the configuration-specialised kernel does not cover run the generic persistent instantiations:
+    random targets, continuous Cartesian and joint-space actions, the joints observation modes, action repeat, the moving button"""
+    n = 520
+    a = HipVecEnv(env_id, n, seed=11, env_kwargs=kw, rng_mode=rng_mode)
+    b = HipVecEnv(env_id, n, seed=11, env_kwargs=kw, rng_mode=rng_mode, persistent=True)
+    assert b.persistent
+    assert np.array_equal(a.reset(), b.reset())
+    rs = np.random.RandomState(2)
+    ended = 0
+    for t in range(700):
+        act = rs.randint(a.action_space.n, size=n) if kw.get("is_discrete", True) else rs.uniform(-1, 1, size=(n,) + a.action_space.shape).astype(np.float32)
+        x, y = a.step(act), b.step(act)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), t
+        ended += int(x[2].sum())
+        if t == 400:
+            assert np.array_equal(a._h.get_state(_lib.F_KUKA_Q), b._h.get_state(_lib.F_KUKA_Q))
+    assert ended > 0 or kw.get("action_joints")
+    a.close(); b.close()
