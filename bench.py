@@ -563,7 +563,7 @@ def bench_stepper(args, workload, rank, local_rank, world, dev, K=None, W=None, 
     return line
 
 
-def bench_per_step(args):
+def bench_per_step(args, emit=True):
     """The per-step API of the drop-in (rl_baselines/utils.py:213-229 -> HipVecEnv): K x (step_async + step_wait) with host-side random
     actions, every shard launched before any is collected.  ONE process; n = envs_per_gpu x number of shards.  Also reports the split
     (time inside step_async = launches only; inside step_wait = the GPU's step + collection) and the single-shard figure beside it."""
@@ -609,7 +609,9 @@ def bench_per_step(args):
     if len(device_ids) > 1:
         line["config"]["single_shard"] = run(device_ids[:1], True if args.persistent else None)
         line["config"]["step_time_vs_single_shard"] = r["us_per_step_median"] / line["config"]["single_shard"]["us_per_step_median"]
-    print(json.dumps(line))
+    if emit:
+        print(json.dumps(line))
+    return line
 
 
 def main():
@@ -682,6 +684,18 @@ def main():
             sec["kuka_lumped_model"] = {"value": None, "error": repr(exc)}
         finally:
             args.kuka_model, args.inner_steps = saved_model, saved
+        # the per-step VecEnv API (what rl_baselines.train drives: rl_baselines/utils.py:213-229), steady state (every env past its first
+        # episode), the reference's MT19937 streams: persistent stepping with the launching path's figure beside it
+        try:
+            import copy
+            a = copy.copy(args)
+            a.workload, a.persistent, a.device_ids, a.steps, a.warmup, a.rng = "kuka", True, None, 1000, 1100, "mt19937"
+            sub = bench_per_step(a, emit=False)
+            sec["per_step_api"] = {"metric": sub["metric"], "value": sub["value"], "unit": sub["unit"], "steps": sub["steps"], "warmup": sub["warmup"],
+                                   "ms_per_step": sub["ms_per_step"], "us_per_step_median": sub["config"]["per_step"]["us_per_step_median"],
+                                   "launch_per_step": sub["config"]["launch_per_step"], "workload": sub["config"]["workload"]}
+        except Exception as exc:
+            sec["per_step_api"] = {"value": None, "error": repr(exc)}
         line["secondary"] = sec
     if rank == 0:
         print(json.dumps(line))
