@@ -1417,17 +1417,122 @@ SRL_G GenOut general_path(const GenIn &in) {
 // Kuka.applyAction (kuka.py:118-187) + p.stepSimulation() for the full model.  `e`: the env's scalar state replicated on the 16
 // lanes, `g`: the lane's own joint and frame (valid on entry: trefresh()), jt_own: the joint-mode target of the own arm joint,
 // finger_angle: motor_commands[4] (0.0 in every env of the reference: gripper closed).
-template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1>
-SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
-                         double finger_angle, RBody *rb = nullptr, double *park = nullptr) {
-    const double dt = kDt, inv_dt = 1.0 / kDt;
-    const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
-    SRL_TSTAMP(0);                          // (everything between two physics steps: env logic, outputs, action sampling)
+// The action-independent half of a physics step: the own joint's spatial axis, then velocities / bias forces / composite inertias (the
+// masked sums), the mass matrix (CRBA) and its inverse (Gauss-Jordan) -> the own row W of M^-1, the bias torque tau.  One definition for
+// tphysics_step and for the persistent kernels, which run it for the NEXT step while they wait for the host's action (tphysics_pre).
+SRL_G void tjoint_axis(const TL &L, const GState &g, double S[6]) {
     // ---- spatial joint axis about the world origin: S = [w ; p x w], w = R * axis
-    double S[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) S[k] = (g.R[k] * L.ax(0) + g.R[3 + k] * L.ax(1) + g.R[6 + k] * L.ax(2)) * L.jm;
     cross3(g.p, S, S + 3);
+}
+SRL_G void tdynamics(const TL &L, const GState &g, const double S[6], double qd, double W[NJ], double &tau) {
+    {
+        double w[3], vo[3], aw[3], av[3];
+        {
+            double le[NJ];                        // ancestors-or-self of the own link
+            make_mask(L.anc(), le);
+            {
+                double xw[3], xv[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { xw[k] = S[k] * qd; xv[k] = S[3 + k] * qd; }
+                msum3(xw, le, w); msum3(xv, le, vo);
+            }
+            double t0[3], t1[3], t2[3];
+            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
+            {
+                double xw[3], xv[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { xw[k] = t0[k] * qd; xv[k] = (t1[k] + t2[k]) * qd; }
+                msum3(xw, le, aw); msum3(xv, le, av, -kGravityZ);
+            }
+        }
+        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
+        double Io[6], h[3];
+        {
+            const double *R = g.R;
+            double cw[3], T[9];
+            const double com3[3] = {L.com(0), L.com(1), L.com(2)};
+            frame_point(R, g.p, com3, cw);
+            // T = R * Ilink (columns of T), Io = T * R^T + m (|c|^2 1 - c c^T)
+            const double I00 = L.in(0), I01 = L.in(1), I02 = L.in(2), I11 = L.in(3), I12 = L.in(4), I22 = L.in(5);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                T[k] = R[k] * I00 + R[3 + k] * I01 + R[6 + k] * I02;
+                T[3 + k] = R[k] * I01 + R[3 + k] * I11 + R[6 + k] * I12;
+                T[6 + k] = R[k] * I02 + R[3 + k] * I12 + R[6 + k] * I22;
+            }
+            const double m = L.mass(), ccs = dot3(cw, cw);
+            Io[0] = T[0] * R[0] + T[3] * R[3] + T[6] * R[6] + m * (ccs - cw[0] * cw[0]);
+            Io[1] = T[0] * R[1] + T[3] * R[4] + T[6] * R[7] - m * cw[0] * cw[1];
+            Io[2] = T[0] * R[2] + T[3] * R[5] + T[6] * R[8] - m * cw[0] * cw[2];
+            Io[3] = T[1] * R[1] + T[4] * R[4] + T[7] * R[7] + m * (ccs - cw[1] * cw[1]);
+            Io[4] = T[1] * R[2] + T[4] * R[5] + T[7] * R[8] - m * cw[1] * cw[2];
+            Io[5] = T[2] * R[2] + T[5] * R[5] + T[8] * R[8] + m * (ccs - cw[2] * cw[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
+        }
+        double Fn[3], Ff[3], Ioc[6], hc[3];
+        {
+            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
+            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass() * av[k] - t1[k]; }
+            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass() * vo[k] - t1[k]; }
+            cross3(w, n, t0); cross3(vo, f, t1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
+            cross3(w, f, t0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) ff[k] += t0[k];
+            double ge[NJ];                        // descendants-or-self
+            make_mask(L.desc(), ge);
+            msum3(fn, ge, Fn); msum3(ff, ge, Ff); msum3(h, ge, hc);
+            msum3(Io, ge, Ioc); msum3(Io + 3, ge, Ioc + 3);
+        }
+        tau = -L.damping() * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
+        SRL_TSTAMP(3);                      // velocities, bias forces, composite inertias (the masked sums)
+        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
+        double Fc[6], t0[3], t1[3], low[NJ];
+        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp() * S[3 + k] - t1[k]; }
+        dot6_all12(Fc, S, low);
+        {
+            double le[NJ];
+            make_mask(L.anc(), le);
+#pragma unroll
+            for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
+        }
+        transpose_step<0>(L, low, W);
+        SRL_TSTAMP(4);                      // mass matrix (CRBA)
+        double unused = 0.0;
+        gj_step<0, NJ, true>(L, W, unused);
+        SRL_TSTAMP(5);                      // its inverse (Gauss-Jordan)
+    }
+}
+struct PreDyn { double S[6], W[NJ], tau; };
+SRL_G void tphysics_pre(const GState &g, const double *tab, PreDyn &P) {
+    const TL L = lane_view(tab);
+    tjoint_axis(L, g, P.S);
+    tdynamics(L, g, P.S, g.qd * L.jm, P.W, P.tau);
+}
+
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, int EARLY = 0>
+SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
+                         double finger_angle, RBody *rb = nullptr, double *park = nullptr, const PreDyn *pre = nullptr) {
+    const double dt = kDt, inv_dt = 1.0 / kDt;
+    const TL L = lane_view(tab);           // lane constants are read from LDS where they are used
+    SRL_TSTAMP(0);                          // (everything between two physics steps: env logic, outputs, action sampling)
+    double S[6];
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) S[k] = pre->S[k];
+    } else {
+        tjoint_axis(L, g, S);
+    }
     if (L.jnt) {                            // parked for the (rare) general path, see GenIn
 #pragma unroll
         for (int k = 0; k < 6; k++) (OCC ? park + PK_S : scratch + SC_S)[L.l * 6 + k] = S[k];
@@ -1592,99 +1697,23 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     // ---- dynamics in world coordinates
     const double qd = g.qd * L.jm;
     double W[NJ], tau;
-    {
-        double w[3], vo[3], aw[3], av[3];
-        {
-            double le[NJ];                        // ancestors-or-self of the own link
-            make_mask(L.anc(), le);
-            {
-                double xw[3], xv[3];
+    if constexpr (EARLY) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { xw[k] = S[k] * qd; xv[k] = S[3 + k] * qd; }
-                msum3(xw, le, w); msum3(xv, le, vo);
-            }
-            double t0[3], t1[3], t2[3];
-            cross3(w, S, t0); cross3(w, S + 3, t1); cross3(vo, S, t2);
-            {
-                double xw[3], xv[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { xw[k] = t0[k] * qd; xv[k] = (t1[k] + t2[k]) * qd; }
-                msum3(xw, le, aw); msum3(xv, le, av, -kGravityZ);
-            }
-        }
-        // rigid-body inertia of the own link about the world origin: Io (xx xy xz yy yz zz), h = m c
-        double Io[6], h[3];
-        {
-            const double *R = g.R;
-            double cw[3], T[9];
-            const double com3[3] = {L.com(0), L.com(1), L.com(2)};
-            frame_point(R, g.p, com3, cw);
-            // T = R * Ilink (columns of T), Io = T * R^T + m (|c|^2 1 - c c^T)
-            const double I00 = L.in(0), I01 = L.in(1), I02 = L.in(2), I11 = L.in(3), I12 = L.in(4), I22 = L.in(5);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                T[k] = R[k] * I00 + R[3 + k] * I01 + R[6 + k] * I02;
-                T[3 + k] = R[k] * I01 + R[3 + k] * I11 + R[6 + k] * I12;
-                T[6 + k] = R[k] * I02 + R[3 + k] * I12 + R[6 + k] * I22;
-            }
-            const double m = L.mass(), ccs = dot3(cw, cw);
-            Io[0] = T[0] * R[0] + T[3] * R[3] + T[6] * R[6] + m * (ccs - cw[0] * cw[0]);
-            Io[1] = T[0] * R[1] + T[3] * R[4] + T[6] * R[7] - m * cw[0] * cw[1];
-            Io[2] = T[0] * R[2] + T[3] * R[5] + T[6] * R[8] - m * cw[0] * cw[2];
-            Io[3] = T[1] * R[1] + T[4] * R[4] + T[7] * R[7] + m * (ccs - cw[1] * cw[1]);
-            Io[4] = T[1] * R[2] + T[4] * R[5] + T[7] * R[8] - m * cw[1] * cw[2];
-            Io[5] = T[2] * R[2] + T[5] * R[5] + T[8] * R[8] + m * (ccs - cw[2] * cw[2]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) h[k] = m * cw[k];
-        }
-        double Fn[3], Ff[3], Ioc[6], hc[3];
-        {
-            double n[3], f[3], t0[3], t1[3], fn[3], ff[3];
-            sym_mul(Io, aw, n); cross3(h, av, t0); cross3(h, aw, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { fn[k] = n[k] + t0[k]; ff[k] = L.mass() * av[k] - t1[k]; }
-            sym_mul(Io, w, n); cross3(h, vo, t0); cross3(h, w, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { n[k] += t0[k]; f[k] = L.mass() * vo[k] - t1[k]; }
-            cross3(w, n, t0); cross3(vo, f, t1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) fn[k] += t0[k] + t1[k];
-            cross3(w, f, t0);
-#pragma unroll
-            for (int k = 0; k < 3; k++) ff[k] += t0[k];
-            double ge[NJ];                        // descendants-or-self
-            make_mask(L.desc(), ge);
-            msum3(fn, ge, Fn); msum3(ff, ge, Ff); msum3(h, ge, hc);
-            msum3(Io, ge, Ioc); msum3(Io + 3, ge, Ioc + 3);
-        }
-        tau = -L.damping() * qd - (dot3(S, Fn) + dot3(S + 3, Ff));
-        SRL_TSTAMP(3);                      // velocities, bias forces, composite inertias (the masked sums)
-        // ---- CRBA: M_kl = S_k . (Ic_l S_l) for k an ancestor-or-self of l (on lane l), mirrored; W = M^-1 in place
-        double Fc[6], t0[3], t1[3], low[NJ];
-        sym_mul(Ioc, S, Fc); cross3(hc, S + 3, t0); cross3(hc, S, t1);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { Fc[k] += t0[k]; Fc[3 + k] = L.mcomp() * S[3 + k] - t1[k]; }
-        dot6_all12(Fc, S, low);
-        {
-            double le[NJ];
-            make_mask(L.anc(), le);
-#pragma unroll
-            for (int k = 0; k < NJ; k++) { low[k] *= le[k] * L.jm; W[k] = low[k]; }
-        }
-        transpose_step<0>(L, low, W);
-        SRL_TSTAMP(4);                      // mass matrix (CRBA)
-        double unused = 0.0;
-        gj_step<0, NJ, true>(L, W, unused);
-        SRL_TSTAMP(5);                      // its inverse (Gauss-Jordan)
-#pragma unroll
-        for (int k = 0; k < NJ; k++) (OCC ? park + PK_W : scratch + SC_STASH_W)[k * GL + L.l] = W[k];
+        for (int k = 0; k < NJ; k++) W[k] = pre->W[k];
+        tau = pre->tau;
+    } else {
+        tdynamics(L, g, S, qd, W, tau);
     }
+#pragma unroll
+    for (int k = 0; k < NJ; k++) (OCC ? park + PK_W : scratch + SC_STASH_W)[k * GL + L.l] = W[k];
     double qdd = 0.0;
     rdot_step<0, NJ>(qdd, W, tau);
 #pragma unroll
     for (int k = 0; k < NJ; k++) SRL_GDBG(0, L.l * NJ + k, W[k]);
     SRL_GDBG(1, L.l, qdd); SRL_GDBG(2, L.l, tau); SRL_GDBG(3, L.l, qdes); SRL_GDBG(4, L.l, target);
-    const double qd_new = qd + dt * qdd;
+    // (explicit: left to the contraction pass, WHICH product joins the add depends on how many uses `qd` has — the persistent kernels take
+    //  W and tau from tphysics_pre and use `qd` only here, and got g.qd * jm + round(dt * qdd) where every other kernel has this)
+    const double qd_new = fma(dt, qdd, qd);
     e.bqd += dt * kGravityZ;
     if constexpr (NB == 2) e.b2qd += dt * kGravityZ;
     // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
@@ -1924,9 +1953,10 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, class R>
+// EARLY = 1 (persistent kernels): `pre` holds the action-independent half of the FIRST physics step (tphysics_pre on the state this call starts from)
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, int EARLY = 0, class R>
 SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done,
-                       RBody *rb = nullptr, double *park = nullptr) {
+                       RBody *rb = nullptr, double *park = nullptr, const PreDyn *pre = nullptr) {
     if constexpr (RB) {
         // kuka_rand_button_gym_env.py:111-123: at env step 10 the ball is kicked (applyExternalForce: it acts on the next stepSimulation)
         const double kx = shfl(rb->ox, 9), ky = shfl(rb->oy, 9);
@@ -1943,7 +1973,12 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     SRL_TSTAMP(21);                         // noise draw + action mapping (step_command)
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
+        if constexpr (EARLY) {
+            if (rep == 0) tphysics_step<NB, RB, OCC, DET, 1>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park, pre);
+            else tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
+        } else {
+            tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
+        }
         if (termination(e, cfg)) break;
         e.counter += 1;
     }

@@ -224,6 +224,12 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     uint32_t my_seq = pa.start_seq, persist_k = 0;      // persist_k: steps since this launch
     (void)my_seq; (void)persist_k;
     for (int t = 0; PERSIST || t < T; t++) {
+        tree::PreDyn pre;
+        if constexpr (PERSIST) {
+            // the action-independent half of the step's (first) physics step — joint axes, bias forces, the mass matrix and its inverse:
+            // 8 k of a free step's 53 k cycles — runs BEFORE the wait for the host's action: off the step's latency
+            tree::tphysics_pre(g, tab, pre);
+        }
         if constexpr (PERSIST) {
 #if defined(__HIP_DEVICE_COMPILE__)
             uint32_t token = 0;
@@ -293,7 +299,8 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #endif
         bool done;
         double reward;
-        reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
+        if constexpr (PERSIST) reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1, 1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, &pre);
+        else reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         const int info = cfg.info_bits ? (v.ikx & 1) << 1 : 0;      // srlhip_config.info_bits: the IK conditioning flag this step ran under (before the auto-reset clears it)
         if (done) {
