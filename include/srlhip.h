@@ -177,10 +177,12 @@ int srlhip_step_pending(srlhip_handle h);
  * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
  * 4096 envs on an MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
  * the device with every env's state in registers.  srlhip_step_async writes the actions and a sequence number into mapped
- * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront steps and writes its
- * outputs to a staging copy of the output planes in device memory; the last wavefront of each eighth of the grid to finish
- * copies that eighth's env range to the host's mapped planes in whole lines, releases them at system scope and writes the
- * eighth's `done` word; srlhip_step_wait polls those 8 words.  What a per-step launch pays every time — the launch itself, the
+ * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront has already run the
+ * action-independent half of the step (bias forces, mass matrix and its inverse) while it waited, finishes the step and writes its
+ * outputs to the host's mapped planes with plain stores — they stay in its XCD's L2; the last wavefront of each eighth of the
+ * grid (= one XCD, verified at launch through HW_REG_XCC_ID) to finish writes that L2 back with ONE system-scope release and
+ * writes the eighth's `done` word; srlhip_step_wait polls those 8 words.  (Where an eighth does not sit on one XCD, or with
+ * SRLHIP_PERSIST_STAGED=1, the outputs go through a staging copy in device memory that the eighth's last wavefront copies out.)  What a per-step launch pays every time — the launch itself, the
  * 5.6 KB model table, ~40 state planes, the generators, forward kinematics, the stream synchronisation — is paid once: measured
  * ~10 us less per step at every batch size (HipVecEnv.step 94.5 -> 84.1 us at 4096 envs, 44.9 -> 34.0 at 16).  Same kernel
  * code, same arithmetic: results are those of the launching path bit for bit (tests/test_gpu_persistent_step.py).

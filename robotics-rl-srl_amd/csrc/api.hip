@@ -111,15 +111,16 @@ int persist_launch(Handle *h, uint32_t start_seq) {
     c->stop = 0; c->parked = 0;
     for (uint32_t g = 0; g < 8; g++) c->done[g] = start_seq;
     SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay), (int)start_seq, 8 * kPersistWordStride, h->stream));
-    SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay + 8 * kPersistWordStride), 0, 8 * kPersistWordStride, h->stream));
+    SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay + 8 * kPersistWordStride), 0, 12 * kPersistWordStride, h->stream));
     void *dctl = nullptr, *din = nullptr, *dout = nullptr;
     SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dctl, h->persist_host, 0));
     SRL_HIP_CHECK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
     SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dout, h->pin_out, 0));
     uint32_t *w = static_cast<uint32_t *>(dctl);
     PersistArgs pa;
-    pa.seq = w; pa.stop = w + 1; pa.parked = w + 2; pa.done = w + 16; pa.relay = h->persist_relay; pa.count = h->persist_relay + 8 * kPersistWordStride;
+    pa.seq = w; pa.stop = w + 1; pa.parked = w + 2; pa.done = w + 16; pa.relay = h->persist_relay; pa.count = h->persist_relay + 8 * kPersistWordStride; pa.ctrl = h->persist_relay + 16 * kPersistWordStride;
     pa.start_seq = start_seq;
+    { const char *v = getenv("SRLHIP_PERSIST_STAGED"); pa.force_staged = v && atoi(v) != 0; }
     pa.spin_limit = h->persist_park_us / 2 + 1;        // one poll of workgroup 0: two PCIe reads + s_sleep 16, ~2 us
     const size_t n = (size_t)h->n, ob = obs_bytes_per_env(h) * n, out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * n;
     pa.stage = static_cast<const uint32_t *>(h->persist_stage); pa.host_out = static_cast<uint32_t *>(dout);
@@ -593,7 +594,7 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
         const size_t bytes = sizeof(PersistHost);
         if (hipHostMalloc(&h->persist_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipHostMalloc failed");
         memset(h->persist_host, 0, bytes);
-        if (hipMalloc(reinterpret_cast<void **>(&h->persist_relay), 16 * kPersistWordStride * sizeof(uint32_t) + 64 * (size_t)((blocks + 7) / 8 * 8)) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
+        if (hipMalloc(reinterpret_cast<void **>(&h->persist_relay), 20 * kPersistWordStride * sizeof(uint32_t) + 64 * (size_t)((blocks + 7) / 8 * 8)) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
         const StepLayout L = step_layout(h);
         if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total))) return rc;
         if (hipMalloc(&h->persist_stage, L.out_total + 16) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
@@ -618,7 +619,7 @@ int srlhip_debug_persist_prof(srlhip_handle hh, uint64_t *out, int32_t blocks) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     if (rc) return rc;
-    SRL_HIP_CHECK(h, hipMemcpy(out, h->persist_relay + 16 * kPersistWordStride, 64 * (size_t)blocks, hipMemcpyDeviceToHost));
+    SRL_HIP_CHECK(h, hipMemcpy(out, h->persist_relay + 20 * kPersistWordStride, 64 * (size_t)blocks, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -100,10 +100,12 @@ struct PersistArgs {
     uint32_t *done;                 // device-written [8]: sequence number of the last step that eighth of the workgroups finished
     uint32_t *relay;                // device memory [8 x stride]: workgroup 0's token for the others (a sequence number, or kPersistPark)
     uint32_t *count;                // device memory [8 x stride]: arrivals per eighth of the workgroups, never reset while resident
+    uint32_t *ctrl;                 // device memory: [0] workgroups registered | XCD mismatches << 16, [stride] the start barrier's verdict
     const uint32_t *stage;          // device memory: the staging copy of the step's output planes (same layout as the host's), dword view
     uint32_t *host_out;             // the host's mapped output planes, dword view; reward / done planes start rew_dw / done_dw dwords in
     uint32_t rew_dw, done_dw;
     uint32_t start_seq, spin_limit;
+    uint32_t force_staged;          // SRLHIP_PERSIST_STAGED=1: the staging copy + copier even where the direct form is valid (tests run both)
 };
 constexpr int kPersistWordStride = 64;         // (uint32 words: 256 bytes between two relay / counter words)
 constexpr uint32_t kPersistPark = 0xffffffffu;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 // (timeline build of persistent stepping, profiles/probes/persist_timeline.py: -DSRL_PERSIST_PROF; 100 MHz device-wide clock, the stamps of
 //  a workgroup's LAST step, 8 per workgroup, behind the relay / counter words)
 #if defined(SRL_PERSIST_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SRL_PSTAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(pa.relay + 16 * kPersistWordStride)[bid * 8 + (k)] = wall_clock64(); } while (0)
+#define SRL_PSTAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(pa.relay + 20 * kPersistWordStride)[bid * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define SRL_PSTAMP(k) do { } while (0)
 #endif
@@ -164,6 +164,15 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     // different L2s and every line went to HBM in pieces (WRITE_SIZE 1.95x the planes, rounds 3-5).  XCD x now owns the contiguous env
     // range [x, x + 1) * nb / 8 * 4: a line is assembled in ONE L2.  Placement is a speed matter only; results do not depend on it.
     const int bid = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Every workgroup (the padding ones too) registers with the XCD it runs on: the direct output path below is valid only if the
+        // eighth of the grid that shares an arrival counter (blockIdx % 8) shares an L2, i.e. IS one XCD.  One word: count | mismatches << 16.
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(pa.ctrl, 1u + (((xcc & 15u) != (blockIdx.x & 7u)) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     if (bid * kGroupEnvs >= p.n) return;             // a padding block of the rounded-up grid (whole wavefront): it must not shadow env n - 1
                                                      // from another wavefront (GroupMt regenerates the env's generator state in HBM in place)
     const int e_raw = bid * kGroupEnvs + (int)(threadIdx.x / GL);
@@ -223,7 +232,40 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #endif
     uint32_t my_seq = pa.start_seq, persist_k = 0;      // persist_k: steps since this launch
     (void)my_seq; (void)persist_k;
-    for (int t = 0; PERSIST || t < T; t++) {
+    bool direct = false, park_now = false;
+    (void)direct; (void)park_now;
+    if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Start barrier (the grid is co-resident): workgroup 0 waits until every workgroup has registered and publishes the verdict —
+        // 1: every eighth of the grid sits on one XCD -> the wavefronts write their outputs STRAIGHT to the host's mapped planes (plain
+        // stores: they stay in that XCD's L2) and the eighth's last arriver writes the L2 back once; 2: not so -> the staging copy and
+        // the copier below (valid on any placement); 3: told to stop while waiting (a workgroup never started) -> everybody parks.
+        uint32_t verdict = 0;
+        if (threadIdx.x == 0) {
+            uint32_t *vw = pa.ctrl + kPersistWordStride;
+            if (blockIdx.x == 0) {
+                for (;;) {
+                    const uint32_t reg = __hip_atomic_load(pa.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((reg & 0xffffu) == gridDim.x) { verdict = ((reg >> 16) || pa.force_staged) ? 2u : 1u; break; }
+                    if (__hip_atomic_load(pa.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { verdict = 3u; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __hip_atomic_store(vw, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (!(verdict = __hip_atomic_load(vw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        verdict = __builtin_amdgcn_readfirstlane(verdict);
+        direct = verdict == 1u;
+        park_now = verdict == 3u;
+        if (direct) {
+            obs_p = reinterpret_cast<float *>(pa.host_out) + (int64_t)e * od;
+            rew_p = reinterpret_cast<float *>(pa.host_out + pa.rew_dw) + e;
+            done_p = reinterpret_cast<uint8_t *>(pa.host_out + pa.done_dw) + e;
+        }
+#endif
+    }
+    for (int t = 0; (PERSIST && !park_now) || (!PERSIST && t < T); t++) {
         tree::PreDyn pre;
         if constexpr (PERSIST) {
             // the action-independent half of the step's (first) physics step — joint axes, bias forces, the mass matrix and its inverse:
@@ -325,9 +367,15 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             if (lead) {
                 float ob[17];
                 observe(v, cfg, ob, 1);
-                for (int j = 0; j < od; j++) __hip_atomic_store(obs_p + j, ob[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(rew_p, (float)reward, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(done_p, (uint8_t)((int)done | info), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (direct) {                                    // plain stores to the mapped planes: into this XCD's L2
+                    for (int j = 0; j < od; j++) obs_p[j] = ob[j];
+                    *rew_p = (float)reward;
+                    *done_p = (uint8_t)((int)done | info);
+                } else {
+                    for (int j = 0; j < od; j++) __hip_atomic_store(obs_p + j, ob[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(rew_p, (float)reward, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done_p, (uint8_t)((int)done | info), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (done) {
                     __hip_atomic_store(st.last_return + e, last_ret, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(st.last_length + e, last_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -336,10 +384,11 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             __builtin_amdgcn_s_waitcnt(0x0F70);         // "written through" = the store counter reaching 0
             asm volatile("" ::: "memory");
             SRL_PSTAMP(3);
-            // Every eighth of the workgroups (a contiguous env range) has an arrival counter; the LAST wavefront to arrive copies that
-            // range of the three planes from the staging copy to the host's — dwords, coalesced, whole lines — makes them visible with
-            // ONE system-scope release (a write-back of its L2) and then writes the eighth's `done` word: the host polls 8 words.  The
-            // counter is never reset: after k steps it stands at k * (real workgroups of the eighth).
+            // Every eighth of the workgroups (a contiguous env range) has an arrival counter; the LAST wavefront to arrive — staged
+            // form: copies that range of the three planes from the staging copy to the host's, dwords, coalesced, whole lines —
+            // makes them visible with ONE system-scope release (a write-back of its L2: in the direct form that IS the transfer) and
+            // then writes the eighth's `done` word: the host polls 8 words.  The counter is never reset: after k steps it stands at
+            // k * (real workgroups of the eighth).
             const int per = (int)gridDim.x >> 3, grp8 = bid / per;
             int real = (p.n + kGroupEnvs - 1) / kGroupEnvs - grp8 * per;
             real = real > per ? per : real;
@@ -351,7 +400,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
                 const PersistSeg seg[3] = {{pa.stage + (int64_t)lo * od, pa.host_out + (int64_t)lo * od, (hi - lo) * od},
                                            {pa.stage + pa.rew_dw + lo, pa.host_out + pa.rew_dw + lo, hi - lo},
                                            {pa.stage + pa.done_dw + lo / 4, pa.host_out + pa.done_dw + lo / 4, (hi - lo + 3) / 4}};
-                persist_copy(seg);
+                if (!direct) persist_copy(seg);
                 SRL_PSTAMP(5);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 SRL_PSTAMP(6);

@@ -137,3 +137,21 @@ def test_persistent_generic_instantiations(env_id, kw, rng_mode):
             assert np.array_equal(a._h.get_state(_lib.F_KUKA_Q), b._h.get_state(_lib.F_KUKA_Q))
     assert ended > 0 or kw.get("action_joints")
     a.close(); b.close()
+
+
+def test_persistent_staged_output_path(monkeypatch):
+    """the output path that is valid on ANY workgroup placement (staging copy in device memory + one copier per eighth of the grid): the
+    default takes it only when an eighth of the grid does not sit on one XCD, SRLHIP_PERSIST_STAGED=1 forces it"""
+    monkeypatch.setenv("SRLHIP_PERSIST_STAGED", "1")
+    n, kw = 1000, {"srl_model": "ground_truth"}
+    a = HipVecEnv("KukaButtonGymEnv-v0", n, seed=9, env_kwargs=kw)
+    b = HipVecEnv("KukaButtonGymEnv-v0", n, seed=9, env_kwargs=kw, persistent=True)
+    assert np.array_equal(a.reset(), b.reset())
+    rs = np.random.RandomState(4)
+    for t in range(600):
+        act = rs.randint(6, size=n)
+        x, y = a.step(act), b.step(act)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), t
+        if t % 150 == 70:
+            assert np.array_equal(a._h.get_state(_lib.F_KUKA_Q), b._h.get_state(_lib.F_KUKA_Q))      # park + restart
+    a.close(); b.close()
