@@ -73,7 +73,8 @@ size_t obs_bytes_per_env(const Handle *h) {
 }
 
 // ---- persistent stepping: host side of the protocol (internal.hpp PersistArgs) ---------------------------------------------------------
-struct PersistHost { volatile uint32_t seq, stop, parked; uint32_t pad[13]; volatile uint32_t done[16]; };     // mapped, coherent; done[8]: one per eighth of the workgroups
+struct PersistHost { volatile uint32_t seq, stop, parked; volatile uint32_t pad[13]; volatile uint32_t done[16]; };     // mapped, coherent; done[0..7]: persistent stepping, one per eighth of the workgroups;
+                                                                                                                          // done[8..15]: the early completion signal of single-step launches
 PersistHost *persist_ctl(Handle *h) { return static_cast<PersistHost *>(h->persist_host); }
 
 // Resident kernels of several handles on ONE device (the shards of HipVecEnv(device_ids=[0, 0])) must all fit at once: a workgroup that
@@ -85,6 +86,19 @@ void persist_release(Handle *h) {
     std::lock_guard<std::mutex> lk(g_persist_mu);
     g_persist_reserved[h->cfg.device_id & 63] -= h->persist_reserved;
     h->persist_reserved = 0;
+}
+
+// the mapped control block + the device words (relay, arrival counters, start barrier, the single-step signal's counters, timeline stamps)
+// shared by persistent stepping and by the early completion signal of single-step launches
+int ensure_signal_buffers(Handle *h) {
+    if (h->persist_host) return 0;
+    const size_t bytes = sizeof(PersistHost), blocks = ((size_t)h->n + 3) / 4;
+    if (hipHostMalloc(&h->persist_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "step: hipHostMalloc (control block) failed");
+    memset(h->persist_host, 0, bytes);
+    const size_t words = 28 * kPersistWordStride + 16 * ((blocks + 7) / 8 * 8);
+    if (hipMalloc(reinterpret_cast<void **>(&h->persist_relay), words * sizeof(uint32_t)) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "step: hipMalloc (control words) failed");
+    SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay), 0, words, h->stream));
+    return 0;
 }
 
 // the resident kernel writes the state back and exits; afterwards the handle is an ordinary one again
@@ -327,6 +341,7 @@ int srlhip_destroy(srlhip_handle hh) {
     h->persist_step = false;
     (void)persist_park(h);
     persist_release(h);
+    if (getenv("SRLHIP_DEBUG_SIGNAL")) fprintf(stderr, "srlhip: handle n=%d: %u signalled steps, %u fell back to the stream synchronisation (XCD mismatch), %u timed out\n", h->n, h->signal_steps, h->signal_fallbacks & 0xffffu, h->signal_fallbacks >> 16);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->persist_host) (void)hipHostFree(h->persist_host);
     if (h->persist_relay) (void)hipFree(h->persist_relay);
@@ -478,9 +493,29 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
     void *d_obs = want_obs ? o : nullptr;
     float *d_rew = reinterpret_cast<float *>(o + L.out_rew);
     uint8_t *d_done = o + L.out_done;
+    // Early completion signal (zero-copy steps of the full-model Kuka kernels; SRLHIP_STEP_SIGNAL=0: always wait for the kernel's end):
+    // the kernel reports the step's outputs per eighth of its grid (kuka_tree_kernels.hpp), host_step_finish polls those words instead
+    // of synchronising the stream — the kernel's exit stores and the completion wake-up leave the step's latency.
+    static const bool sig_enabled = [] { const char *v = getenv("SRLHIP_STEP_SIGNAL"); return !v || atoi(v) != 0; }();
+    PersistArgs sg{};
+    h->signal_wait = false;
+    if (sig_enabled && L.zero_copy && !host_noise && !is_mobile(h->cfg.env_kind) && !ensure_signal_buffers(h)) {
+        if (h->signal_seq >= 0xfffffff0u) {               // the arrival counters count in step with the sequence number: restart both
+            SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay + 20 * kPersistWordStride), 0, 8 * kPersistWordStride, h->stream));
+            h->signal_seq = 0;
+        }
+        void *dctl = nullptr;
+        SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dctl, h->persist_host, 0));
+        uint32_t *w = static_cast<uint32_t *>(dctl);
+        sg.done = w + 16 + 8; sg.count = h->persist_relay + 20 * kPersistWordStride; sg.relay = h->persist_relay;
+        sg.start_seq = h->signal_seq + 1;
+        h->step_signal = &sg; h->step_signal_armed = false;
+    }
     rc = is_mobile(h->cfg.env_kind) ? mobile_step(h, din, d_noise, L.pixels ? nullptr : static_cast<float *>(d_obs), d_rew, d_done)
                                     : kuka_step(h, din, d_noise, L.pixels ? nullptr : d_obs, d_rew, d_done);
+    h->step_signal = nullptr;
     if (rc) return rc;
+    if (h->step_signal_armed) { h->signal_seq += 1; h->signal_wait = true; h->step_signal_armed = false; }
     if (L.pixels && d_obs && (rc = raster_render(h, d_obs))) return rc;
     if (!L.zero_copy) {
         const size_t from = want_obs ? 0 : L.out_rew;
@@ -521,6 +556,29 @@ int host_step_finish(Handle *h, void *obs_out, float *reward_out, uint8_t *done_
                 }
             }
         }
+    } else if (h->signal_wait) {
+        // the early completion signal of a single-step launch: every eighth of the grid that holds a real workgroup reports the step's
+        // sequence number.  Nothing depends on the signal ARRIVING: after ~2 ms without it (or when a workgroup found itself on another
+        // XCD than its eighth's) the stream synchronisation below is the answer, as before.
+        h->signal_wait = false;
+        PersistHost *c = persist_ctl(h);
+        const uint32_t want = h->signal_seq, blocks = ((uint32_t)h->n + 3) / 4, per = (blocks + 7) / 8;
+        bool seen = true;
+        uint64_t spins = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool split = false;                              // an eighth of the grid reported from more than one XCD (~want)
+        for (uint32_t b = 0; seen && b < 8 && b * per < blocks; b++)
+            for (;;) {
+                const uint32_t v = __atomic_load_n(&c->done[8 + b], __ATOMIC_ACQUIRE);
+                if (v == want) break;
+                if (v == ~want) { split = true; break; }
+                if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { seen = false; break; }
+            }
+        if (!seen || split) {
+            h->signal_fallbacks += 1 + (seen ? 0 : 0x10000);
+            SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        }
+        h->signal_steps++;
     } else
     SRL_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     const uint8_t *po = static_cast<const uint8_t *>(h->pin_out);
@@ -590,11 +648,8 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
     if (blocks <= 0 || !step_layout(h).zero_copy)
         return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs a one-button Kuka env (KukaButtonGymEnv, KukaMovingButtonGymEnv) on a device RNG mode, non-pixel "
                                        "observations, zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
-    if (!h->persist_host) {
-        const size_t bytes = sizeof(PersistHost);
-        if (hipHostMalloc(&h->persist_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipHostMalloc failed");
-        memset(h->persist_host, 0, bytes);
-        if (hipMalloc(reinterpret_cast<void **>(&h->persist_relay), 20 * kPersistWordStride * sizeof(uint32_t) + 64 * (size_t)((blocks + 7) / 8 * 8)) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
+    if ((rc = ensure_signal_buffers(h))) return rc;
+    if (!h->persist_stage) {
         const StepLayout L = step_layout(h);
         if ((rc = ensure_pinned(h, &h->pin_in, &h->pin_in_sz, L.in_total)) || (rc = ensure_pinned(h, &h->pin_out, &h->pin_out_sz, L.out_total))) return rc;
         if (hipMalloc(&h->persist_stage, L.out_total + 16) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
@@ -619,7 +674,7 @@ int srlhip_debug_persist_prof(srlhip_handle hh, uint64_t *out, int32_t blocks) {
     Handle *h = reinterpret_cast<Handle *>(hh);
     int rc = set_device(h);
     if (rc) return rc;
-    SRL_HIP_CHECK(h, hipMemcpy(out, h->persist_relay + 20 * kPersistWordStride, 64 * (size_t)blocks, hipMemcpyDeviceToHost));
+    SRL_HIP_CHECK(h, hipMemcpy(out, h->persist_relay + 28 * kPersistWordStride, 64 * (size_t)blocks, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -164,6 +164,10 @@ struct Handle {
     uint32_t *persist_relay = nullptr;
     void *persist_stage = nullptr;
     uint32_t persist_seq = 0, persist_blocks = 0, persist_park_us = 2000;
+    // early completion signal of single-step launches (host_step_begin / host_step_finish; kuka_tree_launch arms it where the kernel supports it)
+    const PersistArgs *step_signal = nullptr;
+    bool step_signal_armed = false, signal_wait = false;
+    uint32_t signal_seq = 0, signal_steps = 0, signal_fallbacks = 0;
     int persist_reserved = 0;        // workgroups this handle holds in the per-device residency tally (api.hip)
 
     int fail(int code, const std::string &msg) { err = msg; return code; }

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(kGroupBlock) kuka_tree_refresh_k(KukaParams p,
 
 }  // namespace
 
-#define SRL_TREE_GO(MODE, J, G, NB) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, NB>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
+#define SRL_TREE_GO(MODE, J, G, NB) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, NB>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, G ? sig : PersistArgs{})
 // (Kuka2ButtonGymEnv takes discrete actions only: no joints-mode instantiation of the two-button kernels)
 #define SRL_TREE_MODE(MODE)                                         \
     if (two && d_actions) SRL_TREE_GO(MODE, false, true, 2);        \
@@ -107,8 +107,12 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     }
     dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints, two = h->cfg.env_kind == SRLHIP_ENV_KUKA_2BUTTON;
+    // a single-step launch with the caller's actions on a handle whose host side armed the early completion signal (api.hip): this
+    // kernel reports the step's outputs per eighth of the grid before it ends
+    PersistArgs sig{};
+    if (h->step_signal && T == 1 && d_actions) { sig = *h->step_signal; h->step_signal_armed = true; }
     if (spec) {
-#define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
+#define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, G ? sig : PersistArgs{})
         if (c.rng_mode == SRLHIP_RNG_PHILOX) { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, true); else SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, false); }
         else { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_MT19937, true); else SRL_TREE_SPEC(SRLHIP_RNG_MT19937, false); }     // (the reference's own streams: HipVecEnv's default)
 #undef SRL_TREE_SPEC

@@ -104,7 +104,7 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 // (timeline build of persistent stepping, profiles/probes/persist_timeline.py: -DSRL_PERSIST_PROF; 100 MHz device-wide clock, the stamps of
 //  a workgroup's LAST step, 8 per workgroup, behind the relay / counter words)
 #if defined(SRL_PERSIST_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SRL_PSTAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(pa.relay + 20 * kPersistWordStride)[bid * 8 + (k)] = wall_clock64(); } while (0)
+#define SRL_PSTAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(pa.relay + 28 * kPersistWordStride)[bid * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define SRL_PSTAMP(k) do { } while (0)
 #endif
@@ -416,6 +416,43 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             if (obs_p) obs_p += n * od;
             if (rew_p) rew_p += n;
             if (done_p) done_p += n;
+            if constexpr (GIVEN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                // EARLY COMPLETION SIGNAL of a single-step launch on a host-pointer handle (api.hip host_step_begin arms it: pa.done set):
+                // the host does not wait for the kernel to END (exit stores of ~40 state planes, the completion signal, the stream
+                // synchronisation's wake-up) — the step's outputs are plain stores to its mapped planes in this XCD's L2, and the last
+                // wavefront of each eighth of the grid (one XCD — checked per launch, below; otherwise the host is told to wait for the
+                // kernel's end) writes that L2 back and reports, as in persistent stepping.
+                if (pa.done && t == T - 1) {
+                    if (done && lead) {          // Monitor's record: the host reads it right after the step, before the exit stores below
+                        __hip_atomic_store(st.last_return + e, last_ret, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(st.last_length + e, last_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    // (which XCD is immaterial — a second kernel running beside this one shifts the round-robin — as long as the eighth's
+                    //  workgroups all sit on the SAME one: each ORs its XCD's bit into the eighth's tag before it arrives)
+                    const int per = (int)gridDim.x >> 3, grp8 = bid / per;
+                    uint32_t xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    uint32_t *tag = pa.count + grp8 * kPersistWordStride + 1;
+                    if (threadIdx.x == 0) __hip_atomic_fetch_or(tag, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    asm volatile("" ::: "memory");
+                    int real = (p.n + kGroupEnvs - 1) / kGroupEnvs - grp8 * per;
+                    real = real > per ? per : real;
+                    uint32_t last = 0;
+                    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(pa.count + grp8 * kPersistWordStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (uint32_t)real * pa.start_seq;
+                    if (__builtin_amdgcn_readfirstlane(last)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        if (threadIdx.x == 0) {
+                            const uint32_t seen = __hip_atomic_exchange(tag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (reset for the next launch)
+                            // one XCD: the write-back above carried the whole eighth -> the sequence number; several: its complement
+                            // (the host then waits for the kernel's end, where every L2 is written back)
+                            __hip_atomic_store(pa.done + grp8, (seen & (seen - 1u)) ? ~pa.start_seq : pa.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+                }
+#endif
+            }
         }
 #if defined(SRL_TREE_PROF) && defined(__HIP_DEVICE_COMPILE__)
         { using namespace tree; SRL_TSTAMP(11); }     // episode statistics, auto-reset, observation + output stores
