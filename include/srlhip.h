@@ -172,6 +172,9 @@ int srlhip_step(srlhip_handle h, const void *actions, const double *host_noise,
 int srlhip_step_async(srlhip_handle h, const void *actions, const double *host_noise);
 int srlhip_step_wait(srlhip_handle h, void *obs_out, float *reward_out, uint8_t *done_out);
 int srlhip_step_pending(srlhip_handle h);
+/* (Zero-copy steps of the full-model Kuka kernels do not wait for the kernel's END: the kernel reports the step's outputs per
+ * eighth of its grid — one XCD each, checked per launch — after one L2 write-back, and srlhip_step / srlhip_step_wait poll
+ * those words; the stream synchronisation remains the fallback.  SRLHIP_STEP_SIGNAL=0 switches the signal off.) */
 
 /* Persistent stepping (opt-in; host-pointer handles of the one-button Kuka envs — KukaButtonGymEnv, KukaMovingButtonGymEnv, any
  * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
@@ -184,7 +187,7 @@ int srlhip_step_pending(srlhip_handle h);
  * writes the eighth's `done` word; srlhip_step_wait polls those 8 words.  (Where an eighth does not sit on one XCD, or with
  * SRLHIP_PERSIST_STAGED=1, the outputs go through a staging copy in device memory that the eighth's last wavefront copies out.)  What a per-step launch pays every time — the launch itself, the
  * 5.6 KB model table, ~40 state planes, the generators, forward kinematics, the stream synchronisation — is paid once: measured
- * ~10 us less per step at every batch size (HipVecEnv.step 94.5 -> 84.1 us at 4096 envs, 44.9 -> 34.0 at 16).  Same kernel
+ * HipVecEnv.step 82 -> 72 us at 4096 envs, 62 -> 52 at 256, 39 -> 28 at 16 (launching path -> persistent).  Same kernel
  * code, same arithmetic: results are those of the launching path bit for bit (tests/test_gpu_persistent_step.py).
  * The kernel PARKS (writes the state back and exits) when any other entry point touches the handle, and by itself when no step
  * arrived for park_us microseconds (<= 0: 2000) — the next step restarts it, at the cost of a launch.  While it is resident it
