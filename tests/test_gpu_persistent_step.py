@@ -155,3 +155,37 @@ def test_persistent_staged_output_path(monkeypatch):
         if t % 150 == 70:
             assert np.array_equal(a._h.get_state(_lib.F_KUKA_Q), b._h.get_state(_lib.F_KUKA_Q))      # park + restart
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n", [4096, 1030, 5])
+def test_single_step_launches_with_the_early_completion_signal_equal_the_fused_rollout(n):
+    """the default per-step path does not wait for the kernel's end (the step's outputs are reported per XCD after one L2 write-back):
+    1200 single steps — other entry points in between — against ONE fused 1200-step rollout of a twin handle on the same actions
+    (no signal on that path: its planes are device memory), bit for bit, and Monitor's records with them"""
+    T = 1200
+    cfg = _lib.default_config(_lib.ENV_KUKA_BUTTON)
+    cfg.num_envs, cfg.seed0, cfg.rng_mode, cfg.info_bits = n, 21, _lib.RNG_MT19937, 1
+    a, b = _lib.Handle(cfg), _lib.Handle(cfg)
+    assert np.array_equal(a.reset(), b.reset())
+    acts = np.random.RandomState(3).randint(6, size=(T, n)).astype(np.int32)
+    ref = b.rollout(T, actions=acts)
+    out = (a.new_obs(), np.zeros(n, np.float32), np.zeros(n, np.uint8))
+    ret, length = a.episode_records()
+    ends = 0
+    for t in range(T):
+        if t % 2:
+            a.step(acts[t], out=out)
+        else:
+            a.step_async(acts[t]); a.step_wait(out=out)
+        assert np.array_equal(out[0], ref["obs"][t]) and np.array_equal(out[1], ref["reward"][t]) and np.array_equal(out[2], ref["done"][t]), t
+        fin = np.flatnonzero(out[2] & 1)
+        if fin.size:                              # Monitor's record of an episode that ended in this step is there when the step returns
+            ends += fin.size
+            assert (length[fin] > 0).all() and np.isfinite(ret[fin]).all()
+        if t % 211 == 100:
+            a.get_state(_lib.F_KUKA_Q)            # a synchronising entry point between two signalled steps
+    assert ends >= n
+    assert np.array_equal(a.get_state(_lib.F_KUKA_Q), b.get_state(_lib.F_KUKA_Q))
+    sa, sb = a.episode_stats(), b.episode_stats()
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    a.close(); b.close()
