@@ -7,7 +7,7 @@
 namespace srl {
 using namespace kuka;
 
-#define SRL_TREE_RB_GO(MODE, J, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, PersistArgs{})
+#define SRL_TREE_RB_GO(MODE, J, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, G, 1, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, G ? sig : PersistArgs{})
 #define SRL_TREE_RB_MODE(MODE)                                      \
     if (joints && d_actions) SRL_TREE_RB_GO(MODE, true, true);      \
     else if (joints) SRL_TREE_RB_GO(MODE, true, false);             \
@@ -17,6 +17,8 @@ int kuka_tree_rb_launch(Handle *h, const KukaParams &p, int T, const void *d_act
                         uint8_t *d_done, void *d_act_out) {
     dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
+    PersistArgs sig{};                          // the early completion signal of a single-step launch (kuka_tree.hip, api.hip)
+    if (h->step_signal && T == 1 && d_actions) { sig = *h->step_signal; h->step_signal_armed = true; }
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_TREE_RB_MODE(SRLHIP_RNG_PHILOX) break;
         case SRLHIP_RNG_MT19937: SRL_TREE_RB_MODE(SRLHIP_RNG_MT19937) break;
