@@ -172,7 +172,7 @@ int srlhip_step(srlhip_handle h, const void *actions, const double *host_noise,
 int srlhip_step_async(srlhip_handle h, const void *actions, const double *host_noise);
 int srlhip_step_wait(srlhip_handle h, void *obs_out, float *reward_out, uint8_t *done_out);
 int srlhip_step_pending(srlhip_handle h);
-/* (Zero-copy steps of the full-model Kuka kernels do not wait for the kernel's END: the kernel reports the step's outputs per
+/* (Zero-copy steps of the full-model Kuka kernels and of the MobileRobot family do not wait for the kernel's END: the kernel reports the step's outputs per
  * eighth of its grid — one XCD each, checked per launch — after one L2 write-back, and srlhip_step / srlhip_step_wait poll
  * those words; the stream synchronisation remains the fallback.  SRLHIP_STEP_SIGNAL=0 switches the signal off.) */
 

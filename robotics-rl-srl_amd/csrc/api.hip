@@ -493,13 +493,14 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
     void *d_obs = want_obs ? o : nullptr;
     float *d_rew = reinterpret_cast<float *>(o + L.out_rew);
     uint8_t *d_done = o + L.out_done;
-    // Early completion signal (zero-copy steps of the full-model Kuka kernels; SRLHIP_STEP_SIGNAL=0: always wait for the kernel's end):
+    // Early completion signal (zero-copy steps of the full-model Kuka kernels and of the MobileRobot per-step kernel; SRLHIP_STEP_SIGNAL=0:
+    // always wait for the kernel's end):
     // the kernel reports the step's outputs per eighth of its grid (kuka_tree_kernels.hpp), host_step_finish polls those words instead
     // of synchronising the stream — the kernel's exit stores and the completion wake-up leave the step's latency.
     static const bool sig_enabled = [] { const char *v = getenv("SRLHIP_STEP_SIGNAL"); return !v || atoi(v) != 0; }();
     PersistArgs sg{};
     h->signal_wait = false;
-    if (sig_enabled && L.zero_copy && !host_noise && !is_mobile(h->cfg.env_kind) && !ensure_signal_buffers(h)) {
+    if (sig_enabled && L.zero_copy && !host_noise && !ensure_signal_buffers(h)) {
         if (h->signal_seq >= 0xfffffff0u) {               // the arrival counters count in step with the sequence number: restart both
             SRL_HIP_CHECK(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->persist_relay + 20 * kPersistWordStride), 0, 8 * kPersistWordStride, h->stream));
             h->signal_seq = 0;
@@ -562,13 +563,13 @@ int host_step_finish(Handle *h, void *obs_out, float *reward_out, uint8_t *done_
         // XCD than its eighth's) the stream synchronisation below is the answer, as before.
         h->signal_wait = false;
         PersistHost *c = persist_ctl(h);
-        const uint32_t want = h->signal_seq, blocks = ((uint32_t)h->n + 3) / 4, per = (blocks + 7) / 8;
+        const uint32_t want = h->signal_seq;
         bool seen = true;
         uint64_t spins = 0;
         const auto t0 = std::chrono::steady_clock::now();
         bool split = false;                              // an eighth of the grid reported from more than one XCD (~want)
-        for (uint32_t b = 0; seen && b < 8 && b * per < blocks; b++)
-            for (;;) {
+        for (uint32_t b = 0; seen && b < 8; b++)
+            for (; (h->signal_eighths >> b) & 1u;) {
                 const uint32_t v = __atomic_load_n(&c->done[8 + b], __ATOMIC_ACQUIRE);
                 if (v == want) break;
                 if (v == ~want) { split = true; break; }

@@ -168,6 +168,7 @@ struct Handle {
     const PersistArgs *step_signal = nullptr;
     bool step_signal_armed = false, signal_wait = false;
     uint32_t signal_seq = 0, signal_steps = 0, signal_fallbacks = 0;
+    uint32_t signal_eighths = 0;     // which of the 8 `done` words the armed launch will write (set by the launcher)
     int persist_reserved = 0;        // workgroups this handle holds in the per-device residency tally (api.hip)
 
     int fail(int code, const std::string &msg) { err = msg; return code; }

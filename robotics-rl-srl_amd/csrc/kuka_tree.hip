@@ -110,7 +110,12 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
     // a single-step launch with the caller's actions on a handle whose host side armed the early completion signal (api.hip): this
     // kernel reports the step's outputs per eighth of the grid before it ends
     PersistArgs sig{};
-    if (h->step_signal && T == 1 && d_actions) { sig = *h->step_signal; h->step_signal_armed = true; }
+    if (h->step_signal && T == 1 && d_actions) {
+        sig = *h->step_signal; h->step_signal_armed = true;
+        const uint32_t blocks = (uint32_t)(h->n + kGroupEnvs - 1) / kGroupEnvs, per = (blocks + 7) / 8;      // eighth g = the contiguous workgroup range [g, g + 1) * per
+        h->signal_eighths = 0;
+        for (uint32_t g = 0; g < 8 && g * per < blocks; g++) h->signal_eighths |= 1u << g;
+    }
     if (spec) {
 #define SRL_TREE_SPEC(MODE, G) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, G, 1, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, T, d_actions, d_noise, obs, d_rew, d_done, d_act_out, G ? sig : PersistArgs{})
         if (c.rng_mode == SRLHIP_RNG_PHILOX) { if (d_actions) SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, true); else SRL_TREE_SPEC(SRLHIP_RNG_PHILOX, false); }

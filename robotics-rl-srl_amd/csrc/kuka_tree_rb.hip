@@ -18,7 +18,12 @@ int kuka_tree_rb_launch(Handle *h, const KukaParams &p, int T, const void *d_act
     dim3 grid(((h->n + kGroupEnvs - 1) / kGroupEnvs + 7) / 8 * 8), block(kGroupBlock);      // a multiple of 8: the rollout kernel maps blocks to envs XCD by XCD
     const bool joints = !h->cfg.is_discrete && h->cfg.action_joints;
     PersistArgs sig{};                          // the early completion signal of a single-step launch (kuka_tree.hip, api.hip)
-    if (h->step_signal && T == 1 && d_actions) { sig = *h->step_signal; h->step_signal_armed = true; }
+    if (h->step_signal && T == 1 && d_actions) {
+        sig = *h->step_signal; h->step_signal_armed = true;
+        const uint32_t blocks = (uint32_t)(h->n + kGroupEnvs - 1) / kGroupEnvs, per = (blocks + 7) / 8;
+        h->signal_eighths = 0;
+        for (uint32_t g = 0; g < 8 && g * per < blocks; g++) h->signal_eighths |= 1u << g;
+    }
     switch (h->cfg.rng_mode) {
         case SRLHIP_RNG_PHILOX: SRL_TREE_RB_MODE(SRLHIP_RNG_PHILOX) break;
         case SRLHIP_RNG_MT19937: SRL_TREE_RB_MODE(SRLHIP_RNG_MT19937) break;

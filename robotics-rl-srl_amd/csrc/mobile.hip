@@ -282,7 +282,7 @@ template <int MODE, int KIND, int DISC>
 __global__ void __launch_bounds__(kBlock)
 mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, int T, const void *__restrict__ actions,
                  const double *__restrict__ noise, float *__restrict__ obs, float *__restrict__ rew,
-                 uint8_t *__restrict__ done_out, int advance_actr) {
+                 uint8_t *__restrict__ done_out, int advance_actr, PersistArgs sig) {
     int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.n) return;
     if (KIND >= 0) p.kind = KIND;                 // compile-time constants from here on
@@ -337,6 +337,35 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
             }
             if (rew) __builtin_nontemporal_store((float)reward, rew + row);
             if (done_out) __builtin_nontemporal_store((uint8_t)done, done_out + row);
+        }
+    }
+    if (sig.done) {
+        // EARLY COMPLETION SIGNAL of a single-step launch on a host-pointer handle (api.hip host_step_begin; the Kuka kernels'
+        // kuka_tree_kernels.hpp has the long version): the step's outputs are in this XCD's L2; per eighth of the grid (workgroups
+        // b = g mod 8: one XCD, checked through the eighth's XCD tag) the last WAVEFRONT to arrive writes that L2 back and posts the
+        // step's sequence number — the host does not wait for the exit stores below, the kernel's end and the stream synchronisation.
+        if (n_fin != n_fin0) {           // Monitor's record: the host reads it right after the step
+            __hip_atomic_store(st.last_return + e, last_ret, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(st.last_length + e, last_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const int g8 = (int)blockIdx.x & 7, waves = (p.n + 63) / 64;
+        int real = 0;                    // wavefronts with a live lane in the workgroups of this eighth
+        for (int b = g8; b * (kBlock / 64) < waves; b += 8) real += min(kBlock / 64, waves - b * (kBlock / 64));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint32_t *cnt = sig.count + g8 * kPersistWordStride, *tag = cnt + 1;
+        const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0;       // the wavefront's first ACTIVE lane
+        if (first) __hip_atomic_fetch_or(tag, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        uint32_t last = 0;
+        if (first) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (uint32_t)real * sig.start_seq;
+        if (__builtin_amdgcn_readfirstlane(last)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (first) {
+                const uint32_t seen = __hip_atomic_exchange(tag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sig.done + g8, (seen & (seen - 1u)) ? ~sig.start_seq : sig.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     store_env(s, e, m);
@@ -612,9 +641,14 @@ template <int MODE>
 void launch_rollout(Handle *h, const MobileParams &p, int T, const void *d_actions, const double *d_noise, float *d_obs,
                     float *d_rew, uint8_t *d_done, int advance_actr) {
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+    PersistArgs sig{};                          // the early completion signal of a single-step launch with the caller's actions (api.hip)
+    if (h->step_signal && T == 1 && d_actions && !advance_actr) {
+        sig = *h->step_signal; h->step_signal_armed = true;
+        h->signal_eighths = grid.x >= 8 ? 0xffu : (1u << grid.x) - 1u;      // eighth g = the workgroups b = g mod 8
+    }
 #define SRL_GO(KIND, DISC)                                                                                              \
     hipLaunchKernelGGL((mobile_rollout_k<MODE, KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats, T, \
-                       d_actions, d_noise, d_obs, d_rew, d_done, advance_actr)
+                       d_actions, d_noise, d_obs, d_rew, d_done, advance_actr, sig)
 #define SRL_KIND(KIND) { if (p.is_discrete) SRL_GO(KIND, 1); else SRL_GO(KIND, 0); }
     switch (p.kind) {
         case SRLHIP_ENV_MOBILE: SRL_KIND(SRLHIP_ENV_MOBILE) break;
@@ -757,7 +791,7 @@ int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *
     MobileParams p = params_of(h);
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, -1, -1>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
-                       1, d_actions, d_noise, d_obs, d_rew, d_done, 0);
+                       1, d_actions, d_noise, d_obs, d_rew, d_done, 0, PersistArgs{});
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }
