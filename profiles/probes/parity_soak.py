@@ -6,7 +6,8 @@ Runs on the GPU box (the oracle leg uses the host's cores: ~2 minutes per base):
     python profiles/probes/parity_soak.py [bases=3] [n=4096] [T=1001] [mode=given] > gpurun_out/r05_parity_soak.json
     python profiles/probes/parity_soak.py 4 4096 2048 philox > gpurun_out/r05_parity_soak_philox.json
 mode philox = the launch bench.py times: Philox env streams, actions sampled on the device by the synthetic agent (compared too).
-mode perstep = the per-step API (srlhip_step, host numpy buffers: what HipVecEnv / rl_baselines.train drive), one launch per step.
+mode perstep = the per-step API (srlhip_step, host numpy buffers: what HipVecEnv / rl_baselines.train drive), one launch per step
+(round 6: reported by the kernel's early completion signal); mode persistent = the same calls under srlhip_set_persistent.
 mode continuous | joints = KukaButton with 3-D Cartesian / 7-D joint-space Box actions (uniform in [-1, 1]).
 mode moving | two | rand = the env variants at the BASELINE size (KukaMovingButton with shape_reward, Kuka2Button, KukaRandButton with
 random_target; MT19937 streams, given actions): the test suite compares them at 128 envs.
@@ -54,7 +55,9 @@ for b in range(1, bases + 1):
         cfg.random_target = 1
     h = _lib.Handle(cfg)
     obs0 = h.reset()
-    if mode == "perstep":
+    if mode in ("perstep", "persistent"):
+        if mode == "persistent":
+            h.set_persistent(True)                       # round 6: no launch per step (srlhip_set_persistent)
         od = obs0.shape[1]
         out = {"obs": np.zeros((T, n, od), np.float32), "reward": np.zeros((T, n), np.float32), "done": np.zeros((T, n), np.uint8), "actions": actions}
         for t in range(T):
