@@ -508,7 +508,7 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
         void *dctl = nullptr;
         SRL_HIP_CHECK(h, hipHostGetDevicePointer(&dctl, h->persist_host, 0));
         uint32_t *w = static_cast<uint32_t *>(dctl);
-        sg.done = w + 16 + 8; sg.count = h->persist_relay + 20 * kPersistWordStride; sg.relay = h->persist_relay;
+        sg.done = w + 16 + 8; sg.count = h->persist_relay + 20 * kPersistWordStride;       // (done[8..15]; counter + XCD tag per eighth)
         sg.start_seq = h->signal_seq + 1;
         h->step_signal = &sg; h->step_signal_armed = false;
     }

@@ -98,9 +98,11 @@ __device__ __forceinline__ void tstore_body(const KukaState &s, int64_t n, int e
 // this configuration, kuka_tree.hip: spec_config_of).
 // PERSIST = 1 (srlhip_set_persistent; GIVEN actions): the loop does not count to T — before every step the wavefront waits for the host's
 // next sequence number (PersistArgs: workgroup 0 polls the mapped word, the others its relay in device memory), reads its actions from
-// the SAME mapped row every step, writes its outputs to a staging copy of the output planes (the last wavefront of its eighth of the
-// grid copies them to the host and reports), publishes Monitor's record of an episode that ended right away; it leaves the loop (and
-// writes the state back like any rollout) when workgroup 0 relays the park token.
+// the SAME mapped row every step, writes its outputs straight to the host's mapped planes (they stay in its XCD's L2; the last wavefront
+// of its eighth of the grid — one XCD, verified behind a start barrier — writes that L2 back and reports; on any other placement the
+// outputs go through a staging copy that this wavefront copies out), publishes Monitor's record of an episode that ended right away;
+// it leaves the loop (and writes the state back like any rollout) when workgroup 0 relays the park token.  While it waits it already
+// runs the action-independent half of the next step (tree::tphysics_pre).
 // (timeline build of persistent stepping, profiles/probes/persist_timeline.py: -DSRL_PERSIST_PROF; 100 MHz device-wide clock, the stamps of
 //  a workgroup's LAST step, 8 per workgroup, behind the relay / counter words)
 #if defined(SRL_PERSIST_PROF) && defined(__HIP_DEVICE_COMPILE__)
