@@ -135,7 +135,7 @@ int mobile_oracle_rollout(int kind, int is_discrete, int random_target, int shap
     mrng *r = (mrng *)malloc(sizeof(mrng));
     if (!r) return -12;
     for (e = 0; e < n; e++) {
-        menv m; philox_t act;
+        menv m; philox_t act; uint64_t act_i = 0;
         double ep_ret = 0.0, last_ret = 0.0; int ep_len = 0, last_len = 0, n_fin = 0;
         memset(&m, 0, sizeof m);
         r->mode = rng_mode;
@@ -152,7 +152,14 @@ int mobile_oracle_rollout(int kind, int is_discrete, int random_target, int shap
                 if (is_discrete) a = ((const int32_t *)actions)[row];
                 else { af[0] = ((const float *)actions)[2 * row]; af[1] = ((const float *)actions)[2 * row + 1]; }
             } else {
-                if (is_discrete) a = (int)philox_bounded(&act, kind == MOBILE_1D ? 1u : 3u);
+                if (is_discrete) {
+                    /* synthetic agent, discrete: action i of the env is word i % 4 of block i / 4 of its action stream (multiply-shift
+                     * into [0, m]) — four actions per Philox block (round 6; before: one block per action, word 0) */
+                    uint32_t o[4]; const uint32_t m = kind == MOBILE_1D ? 1u : 3u;
+                    act.ctr = act_i >> 2; philox_block(&act, o);
+                    a = (int)(uint32_t)(((uint64_t)o[act_i & 3] * ((uint64_t)m + 1)) >> 32);
+                    act_i++;
+                }
                 else {
                     uint32_t o[4]; philox_block(&act, o);
                     af[0] = (float)(-1.0 + 2.0 * philox_to_double(o[0], o[1]));

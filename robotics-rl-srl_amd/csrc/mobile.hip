@@ -237,38 +237,63 @@ mobile_reset_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, cons
     }
 }
 
-// Synthetic random-agent action (rl_baselines/random_agent.py:36): Philox stream 1, block `actr` of the env.
+// Synthetic random-agent action (rl_baselines/random_agent.py:36) from Philox stream 1 of the env.  Discrete: action i is word i % 4 of
+// block i / 4 (multiply-shift into [0, m]) — FOUR actions per Philox block (round 6: the sampler's 131 072 blocks per 4096 x 2048
+// rollout were 27 us of the whole chip beside a 25 us recurrence; oracle/mobile_oracle.c draws the same way); continuous: one block per
+// action (two float64 uniforms).  `actr` counts ACTIONS.
+__device__ __forceinline__ int discrete_from_word(const MobileParams &p, uint32_t w) {
+    const uint32_t m = p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u;
+    return (int)(uint32_t)(((uint64_t)w * ((uint64_t)m + 1)) >> 32);
+}
 __device__ __forceinline__ void sample_action(const MobileParams &p, uint32_t k0, uint32_t k1, uint64_t actr,
                                               int &a, float &a0, float &a1) {
-    Philox ph; ph.k0 = k0; ph.k1 = k1; ph.ctr = actr; ph.stream = 1;
+    Philox ph; ph.k0 = k0; ph.k1 = k1; ph.stream = 1;
+    uint32_t o[4];
     if (p.is_discrete) {
-        a = (int)ph.bounded(p.kind == SRLHIP_ENV_MOBILE_1D ? 1u : 3u);      // masks 1 / 3: never rejects -> exactly one block
+        ph.ctr = actr >> 2; ph.block(o);
+        a = discrete_from_word(p, o[actr & 3]);
     } else {
-        uint32_t o[4]; ph.block(o);
+        ph.ctr = actr; ph.block(o);
         a0 = (float)(-1.0 + 2.0 * Philox::to_double(o[0], o[1]));
         a1 = (float)(-1.0 + 2.0 * Philox::to_double(o[2], o[3]));
     }
 }
 
-// All T x N synthetic actions of a rollout at once: thread (t, e) draws block act_ctr[e] + t of env e's action stream.
-// entry t * N + e of a [T][N] action plane whose first row is block base[e] + offset of env e's action stream.
-// The plane is covered by T rows of `bpr` workgroups; workgroup `sb` finds its row without an integer division (a 64-bit i / n and
-// i % n per entry cost three times the Philox block they index): t = trunc(sb * (1 / bpr)) in float64, off by at most one, corrected.
+// All T x N synthetic actions of a rollout at once, into a [T][N] action plane whose row 0 is action base[e] + offset of env e's stream.
+// The plane is covered by `plane_rows` rows of `bpr` workgroups — continuous actions: row t, one block per entry; discrete actions: row q
+// is the q-th Philox BLOCK the env's T actions touch (they start anywhere inside their first block: T / 4 + 1 blocks at most), the thread
+// writes the up to four entries it yields.  Workgroup `sb` finds its row without an integer division (a 64-bit i / n and i % n per entry
+// cost three times the Philox block they index): row = trunc(sb * (1 / bpr)) in float64, off by at most one, corrected.
 struct PlaneMap { uint32_t bpr; double inv_bpr; };
 inline PlaneMap plane_map(int64_t n) { PlaneMap m; m.bpr = (uint32_t)((n + kBlock - 1) / kBlock); m.inv_bpr = 1.0 / (double)m.bpr; return m; }
+inline int64_t plane_rows(const MobileParams &p, int T) { return p.is_discrete ? (int64_t)(T + 3) / 4 + 1 : (int64_t)T; }
 __device__ __forceinline__ void sample_plane_entry(const MobileParams &p, const uint32_t *key, const uint64_t *base, uint64_t offset, uint32_t sb,
                                                    const PlaneMap &pm, int T, void *__restrict__ act) {
     int32_t t = (int32_t)((double)sb * pm.inv_bpr);
     int32_t r = (int32_t)sb - t * (int32_t)pm.bpr;
     if (r < 0) { t -= 1; r += (int32_t)pm.bpr; } else if (r >= (int32_t)pm.bpr) { t += 1; r -= (int32_t)pm.bpr; }
     const int64_t e64 = (int64_t)r * kBlock + threadIdx.x;
-    if (t >= T || e64 >= p.n) return;
+    if (e64 >= p.n) return;
     const int e = (int)e64;
+    if (p.is_discrete) {
+        if (t > (T + 3) / 4) return;
+        const uint64_t first = base[e] + offset;                    // the env's action index of plane row 0
+        Philox ph; ph.k0 = key[e]; ph.k1 = key[p.n + e]; ph.stream = 1; ph.ctr = (first >> 2) + (uint64_t)t;
+        const int64_t row0 = (int64_t)(ph.ctr * 4 - first);         // plane row of the block's word 0 (-3 .. T + 3)
+        if (row0 >= T) return;
+        uint32_t o[4]; ph.block(o);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int64_t row = row0 + w;
+            if (row >= 0 && row < T) static_cast<int32_t *>(act)[row * p.n + e] = discrete_from_word(p, o[w]);
+        }
+        return;
+    }
+    if (t >= T) return;
     const int64_t i = (int64_t)t * p.n + e;
     int a = 0; float a0 = 0.f, a1 = 0.f;
     sample_action(p, key[e], key[p.n + e], base[e] + offset + (uint64_t)t, a, a0, a1);
-    if (p.is_discrete) static_cast<int32_t *>(act)[i] = a;
-    else static_cast<float2 *>(act)[i] = make_float2(a0, a1);
+    static_cast<float2 *>(act)[i] = make_float2(a0, a1);
 }
 __global__ void __launch_bounds__(kBlock)
 mobile_sample_actions_k(MobileParams p, RngState rs, int T, PlaneMap pm, void *__restrict__ act) {
@@ -690,7 +715,7 @@ int launch_rollout_ep(Handle *h, const MobileParams &p, int T, const void *d_act
     const int64_t lanes = (int64_t)smax * h->n;
     const int ep_blocks = (int)((lanes + kBlock - 1) / kBlock);
     const PlaneMap pm = plane_map(h->n);
-    const int64_t extra = next_plane ? (int64_t)T * pm.bpr : 0;
+    const int64_t extra = next_plane ? plane_rows(p, T) * pm.bpr : 0;
     const NextPlane next{next_plane, in_actr, ep_blocks, pm};
     dim3 grid((unsigned)(ep_blocks + extra)), block(kBlock);
     const int draws = mobile_reset_rand_count(h->cfg);
@@ -742,7 +767,7 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
             if (h->prefetch_valid && h->prefetch_T == T) cur = h->prefetch_buf;
             else {
                 const PlaneMap pm = plane_map(h->n);
-                hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((int64_t)T * pm.bpr)), dim3(kBlock), 0, h->stream,
+                hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)(plane_rows(p, T) * pm.bpr)), dim3(kBlock), 0, h->stream,
                                    p, h->rng, T, pm, h->act_plane[0]);
                 SRL_HIP_CHECK(h, hipGetLastError());
             }
@@ -768,7 +793,7 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
             plane = h->st_noise;
         }
         const PlaneMap pm = plane_map(h->n);
-        hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)((int64_t)T * pm.bpr)), dim3(kBlock), 0, h->stream,
+        hipLaunchKernelGGL(mobile_sample_actions_k, dim3((unsigned)(plane_rows(p, T) * pm.bpr)), dim3(kBlock), 0, h->stream,
                            p, h->rng, T, pm, plane);
         SRL_HIP_CHECK(h, hipGetLastError());
         d_actions = plane;
