@@ -176,7 +176,7 @@ int srlhip_step_pending(srlhip_handle h);
  * eighth of its grid — one XCD each, checked per launch — after one L2 write-back, and srlhip_step / srlhip_step_wait poll
  * those words; the stream synchronisation remains the fallback.  SRLHIP_STEP_SIGNAL=0 switches the signal off.) */
 
-/* Persistent stepping (opt-in; host-pointer handles of the one-button Kuka envs — KukaButtonGymEnv, KukaMovingButtonGymEnv, any
+/* Persistent stepping (opt-in; host-pointer handles of KukaButtonGymEnv, KukaMovingButtonGymEnv and Kuka2ButtonGymEnv — any
  * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
  * 4096 envs on an MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
  * the device with every env's state in registers.  srlhip_step_async writes the actions and a sequence number into mapped

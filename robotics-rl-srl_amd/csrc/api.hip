@@ -647,7 +647,7 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
     int capacity = 0;
     const int blocks = kuka_persist_blocks(h, &capacity);
     if (blocks <= 0 || !step_layout(h).zero_copy)
-        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs a one-button Kuka env (KukaButtonGymEnv, KukaMovingButtonGymEnv) on a device RNG mode, non-pixel "
+        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs KukaButtonGymEnv, KukaMovingButtonGymEnv or Kuka2ButtonGymEnv (full model) on a device RNG mode, non-pixel "
                                        "observations, zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
     if ((rc = ensure_signal_buffers(h))) return rc;
     if (!h->persist_stage) {

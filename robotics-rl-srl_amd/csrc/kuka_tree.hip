@@ -134,16 +134,17 @@ int kuka_tree_launch(Handle *h, const KukaParams &p, int T, const void *d_action
 }
 
 // ---- persistent stepping (internal.hpp PersistArgs; srlhip_set_persistent) ---------------------------------------------------------
-// Persistent instantiations exist for the one-button envs (KukaButtonGymEnv, KukaMovingButtonGymEnv) on a device RNG mode: the
+// Persistent instantiations exist for KukaButtonGymEnv, KukaMovingButtonGymEnv and Kuka2ButtonGymEnv on a device RNG mode: the
 // configuration-specialised kernel where kuka_tree_launch would pick it (reference ctor defaults, default solver details), the generic
 // one otherwise (random_target, shaped reward, continuous Cartesian or joint-space actions, the joints observation modes, other
 // solver details).  The grid must be CO-RESIDENT: a workgroup that waits for the host in a loop never makes room for one that has not
 // started.
-static int persist_kind(const Handle *h) {          // 0: none, 1: SPEC, 2: generic Cartesian, 3: generic joint-space actions
+static int persist_kind(const Handle *h) {          // 0: none, 1: SPEC, 2: generic Cartesian, 3: generic joint-space actions, 4: Kuka2Button
     const srlhip_config &c = h->cfg;
-    if (!h->kuka || c.kuka_model != SRLHIP_KUKA_MODEL_FULL || !(c.env_kind == SRLHIP_ENV_KUKA_BUTTON || c.env_kind == SRLHIP_ENV_KUKA_MOVING) ||
+    if (!h->kuka || c.kuka_model != SRLHIP_KUKA_MODEL_FULL || c.env_kind == SRLHIP_ENV_KUKA_RAND ||      // (KukaRandButton: kuka_tree_rb.hip, kinds 5, 6)
         !(c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) || c.obs_mode == SRLHIP_OBS_RAW_PIXELS)
         return 0;
+    if (c.env_kind == SRLHIP_ENV_KUKA_2BUTTON) return c.is_discrete ? 4 : 0;          // (Kuka2ButtonGymEnv takes discrete actions only)
     const bool spec = reinterpret_cast<const TreeModel *>(h->kuka_tmodel_host)->solver_detail == 0.0 && c.env_kind == SRLHIP_ENV_KUKA_BUTTON && c.is_discrete &&
                       !c.action_joints && !c.random_target && c.force_down && !c.shape_reward && c.action_repeat == 1 && c.auto_reset && c.obs_mode == SRLHIP_OBS_GROUND_TRUTH;
     if (spec) return 1;
@@ -155,6 +156,7 @@ static const void *persist_fn(const Handle *h, int kind) {
         case 1: return ph ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 1, 1>) : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 1, 0, 1, 1>);
         case 2: return ph ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 1, 0, 0, 1>) : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 1, 0, 0, 1>);
         case 3: return ph ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, true, true, 1, 0, 0, 1>) : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, true, true, 1, 0, 0, 1>);
+        case 4: return ph ? reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_PHILOX, false, true, 2, 0, 0, 1>) : reinterpret_cast<const void *>(kuka_tree_rollout_k<SRLHIP_RNG_MT19937, false, true, 2, 0, 0, 1>);
     }
     return nullptr;
 }
@@ -176,13 +178,16 @@ int kuka_tree_persist_launch(Handle *h, const KukaParams &p, const void *d_actio
     void *no_act = nullptr;
     const bool ph = h->cfg.rng_mode == SRLHIP_RNG_PHILOX;
 #define SRL_TREE_PERSIST(MODE, J, SPEC) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, J, true, 1, 0, SPEC, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, 0, d_actions, no_noise, obs, d_rew, d_done, no_act, pa)
+#define SRL_TREE_PERSIST2(MODE) hipLaunchKernelGGL((kuka_tree_rollout_k<MODE, false, true, 2, 0, 0, 1>), grid, block, 0, h->stream, p, *h->kuka, h->rng, h->stats, 0, d_actions, no_noise, obs, d_rew, d_done, no_act, pa)
     switch (persist_kind(h)) {
         case 1: if (ph) SRL_TREE_PERSIST(SRLHIP_RNG_PHILOX, false, 1); else SRL_TREE_PERSIST(SRLHIP_RNG_MT19937, false, 1); break;
         case 2: if (ph) SRL_TREE_PERSIST(SRLHIP_RNG_PHILOX, false, 0); else SRL_TREE_PERSIST(SRLHIP_RNG_MT19937, false, 0); break;
         case 3: if (ph) SRL_TREE_PERSIST(SRLHIP_RNG_PHILOX, true, 0); else SRL_TREE_PERSIST(SRLHIP_RNG_MT19937, true, 0); break;
+        case 4: if (ph) SRL_TREE_PERSIST2(SRLHIP_RNG_PHILOX); else SRL_TREE_PERSIST2(SRLHIP_RNG_MT19937); break;
         default: return h->fail(SRLHIP_ENOTSUP, "persistent stepping: no instantiation for this configuration");
     }
 #undef SRL_TREE_PERSIST
+#undef SRL_TREE_PERSIST2
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }

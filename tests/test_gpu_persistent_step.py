@@ -54,7 +54,7 @@ def test_persistent_env_is_the_launching_env_bit_for_bit(n, rng_mode, tmp_path):
 
 def test_persistent_is_refused_where_it_cannot_work():
     for kind, tweak in ((_lib.ENV_MOBILE, {}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}), (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}),
-                        (_lib.ENV_KUKA_2BUTTON, {}), (_lib.ENV_KUKA_RAND, {})):
+                        (_lib.ENV_KUKA_RAND, {})):
         cfg = _lib.default_config(kind)
         cfg.num_envs, cfg.rng_mode = 64, _lib.RNG_PHILOX
         for k, v in tweak.items():
@@ -117,10 +117,13 @@ def test_persistent_shards_on_one_device_share_its_residency():
     ("KukaButtonGymEnv-v0", {"srl_model": "joints_position", "is_discrete": False, "action_joints": True}, "mt19937"),
     ("KukaButtonGymEnv-v0", {"srl_model": "joints", "action_repeat": 2}, "philox"),
     ("KukaMovingButtonGymEnv-v0", {"srl_model": "ground_truth"}, "mt19937"),
+    ("Kuka2ButtonGymEnv-v0", {"srl_model": "ground_truth"}, "mt19937"),
+    ("Kuka2ButtonGymEnv-v0", {"srl_model": "joints_position"}, "philox"),
 ])
 def test_persistent_generic_instantiations(env_id, kw, rng_mode):
     """the one-button configurations the configuration-specialised kernel does not cover run the generic persistent instantiations:
-    random targets, continuous Cartesian and joint-space actions, the joints observation modes, action repeat, the moving button"""
+    random targets, continuous Cartesian and joint-space actions, the joints observation modes, action repeat, the moving button, the
+    two-button env"""
     n = 520
     a = HipVecEnv(env_id, n, seed=11, env_kwargs=kw, rng_mode=rng_mode)
     b = HipVecEnv(env_id, n, seed=11, env_kwargs=kw, rng_mode=rng_mode, persistent=True)
