@@ -174,7 +174,10 @@ int srlhip_step_wait(srlhip_handle h, void *obs_out, float *reward_out, uint8_t 
 int srlhip_step_pending(srlhip_handle h);
 /* (Zero-copy steps of the full-model Kuka kernels and of the MobileRobot family do not wait for the kernel's END: the kernel reports the step's outputs per
  * eighth of its grid — one XCD each, checked per launch — after one L2 write-back, and srlhip_step / srlhip_step_wait poll
- * those words; the stream synchronisation remains the fallback.  SRLHIP_STEP_SIGNAL=0 switches the signal off.) */
+ * those words; the stream synchronisation remains the fallback.  SRLHIP_STEP_SIGNAL=0 switches the signal off.  What the call
+ * returns — observations, rewards, dones, Monitor's records — is complete; the kernel's exit stores of the STATE planes may still be
+ * in flight on the handle's stream: every entry point of this library is ordered behind them, a caller that reads
+ * srlhip_device_ptr() planes of a host-pointer handle from a stream of its own calls srlhip_sync() first.) */
 
 /* Persistent stepping (opt-in; host-pointer handles of KukaButtonGymEnv, KukaMovingButtonGymEnv and Kuka2ButtonGymEnv — any
  * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
