@@ -192,3 +192,56 @@ def test_single_step_launches_with_the_early_completion_signal_equal_the_fused_r
     sa, sb = a.episode_stats(), b.episode_stats()
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     a.close(); b.close()
+
+
+def test_random_call_sequences_on_the_three_per_step_paths():
+    """fuzz: random batch sizes, env variants, RNG modes and random interleavings of step / step_async + step_wait / masked reset /
+    re-seed / state reads on three twin handles — single-step launches with the early completion signal, persistent stepping, and
+    srlhip_rollout(T = 1) (no signal, no residency: staged copies and a stream synchronisation) — must agree bit for bit"""
+    rs = np.random.RandomState(12345)
+    kinds = [(_lib.ENV_KUKA_BUTTON, {}), (_lib.ENV_KUKA_BUTTON, {"random_target": 1}), (_lib.ENV_KUKA_MOVING, {"shape_reward": 1}),
+             (_lib.ENV_KUKA_2BUTTON, {}), (_lib.ENV_KUKA_BUTTON, {"obs_mode": _lib.OBS_JOINTS})]
+    for trial in range(30):
+        kind, tweak = kinds[trial % len(kinds)]
+        n = int(rs.choice([1, 3, 64, 257, 1000, 2048, 4096]))
+        cfg = _lib.default_config(kind)
+        cfg.num_envs, cfg.seed0, cfg.info_bits = n, 1000 * trial, 1
+        cfg.rng_mode = _lib.RNG_PHILOX if trial % 2 else _lib.RNG_MT19937
+        for k, v in tweak.items():
+            setattr(cfg, k, v)
+        hs = [_lib.Handle(cfg) for _ in range(3)]
+        hs[1].set_persistent(True, 500)
+        na = hs[0].num_actions
+        obs = [h.reset() for h in hs]
+        assert np.array_equal(obs[0], obs[1]) and np.array_equal(obs[0], obs[2])
+        outs = [(h.new_obs(), np.zeros(n, np.float32), np.zeros(n, np.uint8)) for h in hs[:2]]
+        for t in range(200):
+            op = rs.rand()
+            if op < 0.08:
+                mask = (rs.rand(n) < 0.3).astype(np.uint8)
+                r = [h.reset(mask=mask) for h in hs]
+                assert np.array_equal(r[0], r[1]) and np.array_equal(r[0], r[2]), (trial, t)
+                continue
+            if op < 0.12:
+                seeds = rs.randint(0, 2 ** 31, size=n).astype(np.int64)
+                for h in hs:
+                    h.seed(seeds)
+                    h.reset()
+                continue
+            if op < 0.2:
+                q = [h.get_state(_lib.F_KUKA_Q) for h in hs]
+                assert np.array_equal(q[0], q[1]) and np.array_equal(q[0], q[2]), (trial, t)
+                continue
+            a = rs.randint(-1, na, size=n).astype(np.int32)            # (-1: the reference's `None` action)
+            for h, o in zip(hs[:2], outs):
+                if rs.rand() < 0.5:
+                    h.step(a, out=o)
+                else:
+                    h.step_async(a); h.step_wait(out=o)
+            ref = hs[2].rollout(1, actions=a[None])
+            for o in outs:
+                assert np.array_equal(o[0], ref["obs"][0]) and np.array_equal(o[1], ref["reward"][0]) and np.array_equal(o[2], ref["done"][0]), (trial, t, n)
+        st = [h.episode_stats() for h in hs]
+        assert all(np.array_equal(x, y) for x, y in zip(st[0], st[1])) and all(np.array_equal(x, y) for x, y in zip(st[0], st[2]))
+        for h in hs:
+            h.close()
