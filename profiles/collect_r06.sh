@@ -38,6 +38,8 @@ timeout 300 python profiles/probes/vecenv_latency.py > $OUT/vecenv_latency.txt 2
 timeout 300 python bench.py --per-step > $OUT/bench_per_step.json 2>/dev/null
 timeout 300 python bench.py --per-step --envs-per-gpu 2048 --device-ids 0,0 > $OUT/bench_per_step_2x2048_one_device.json 2>/dev/null
 timeout 300 python bench.py --per-step --envs-per-gpu 1024 --device-ids 0,0,0,0 > $OUT/bench_per_step_4x1024_one_device.json 2>/dev/null
+rm -rf /tmp/prof_ps
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ps -o ps -- python $R/bench.py --per-step > /dev/null 2>&1; cp $(find /tmp/prof_ps -name "*kernel_stats.csv" | head -1) $OUT/per_step_kernel_stats.csv)
 timeout 300 python bench.py --per-step --persistent > $OUT/bench_per_step_persistent.json 2>/dev/null
 timeout 300 python bench.py --per-step --persistent --envs-per-gpu 256 > $OUT/bench_per_step_persistent_256.json 2>/dev/null
 [ -f robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so ] && SRLHIP_LIB=$R/robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so timeout 200 python profiles/probes/persist_timeline.py 4096 2>&1 | grep -v libdrm > $OUT/persist_timeline.txt
