@@ -1081,8 +1081,12 @@ static_assert(NJ * GL <= kNArows * GL && SM_COUNT2 * GL <= 2 * kNB * GL, "stash 
 struct GenOut { double u, acc_b, dvb_b; double u2, dvb_b2; bool bodies_done; double dvo[3]; };   // + KukaRandButton: the own body's velocity change when its rows were swept here   // own bank-A value; sum_s nAB_s lambda_s; sum_s jb_s lambda_s / m of the bank-B rows (per glider)
 // DET >= 0: the table's solver_detail as a compile-time constant (the configuration-specialised rollout instantiation: the host checks
 // the installed table), -1: read from the lane table
-template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1>
-SRL_G GenOut general_path(const GenIn &in) {
+// PART (the persistent kernels' early setup, tphysics_pre2 / tphysics_post2): 0 = the whole path; 1 = the setup only — row
+// definitions, couplings in LDS, the own bank-B row: everything in front of the sweeps, and all of it independent of the step's
+// action —, its per-lane result handed out in `ctx`; 2 = the sweeps and the outputs on a setup a PART = 1 call left behind.
+struct GenCtx { BRow b; int nlim_w, ngen_w; bool on_lim, on_con; };
+template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, int PART = 0>
+SRL_G GenOut general_path(const GenIn &in, GenCtx *ctx = nullptr) {
     static_assert(!OCC || (NB == 1 && RB == 0), "the two-wavefronts-per-SIMD variant covers the one-button envs");
     // Written for a SMALL register footprint, not for speed (the path is rare): every loop over joints / slots is rolled and works
     // on LDS-resident data, so that the common path's long-lived values are not pushed into scratch by this code's pressure.
@@ -1108,6 +1112,8 @@ SRL_G GenOut general_path(const GenIn &in) {
     b.obj = -1; b.Jo[0] = 0.0; b.Jo[1] = 0.0; b.Jo[2] = 0.0; b.jo2m = 0.0;
     int nlim = 0, ngen = 0, nlim_w = 0, ngen_w = 0;
     bool on_lim = false, on_con = false;           // the own bank-B row belongs to the limit phase / the contact phase of the sweep
+    if constexpr (PART == 2) { b = ctx->b; nlim_w = ctx->nlim_w; ngen_w = ctx->ngen_w; on_lim = ctx->on_lim; on_con = ctx->on_con; }
+    if constexpr (PART != 2) {
     {
         // ---- the parked inputs of this lane (the MISC plane is reused for the NAB couplings below)
         double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30, pen_lo, pen_hi;
@@ -1320,6 +1326,12 @@ SRL_G GenOut general_path(const GenIn &in) {
     }
     sync_scratch();
     SRL_TSTAMP(14);                         // the own bank-B row: diagonal, right-hand side, couplings
+    }       // PART != 2
+    if constexpr (PART == 1) {
+        ctx->b = b; ctx->nlim_w = nlim_w; ctx->ngen_w = ngen_w; ctx->on_lim = on_lim; ctx->on_con = on_con;
+        GenOut none = {};
+        return none;
+    }
     // ---- Bullet's row order: motors 0..11, button motor, [joint limits], button stops, [contact normals], [frictions].
     // Every impulse starts at 0, i.e. u_k = -lo_k / S_k = 1/2 on the symmetric bank-A rows (motors, button motor: all swept before
     // any bank-B row): row l starts with what the bank-A rows BEHIND it contribute at that value.
@@ -1870,6 +1882,269 @@ SRL_G void tphysics_step(Env &e, GState &g, const double *tab, const Cfg &cfg, d
     SRL_TSTAMP(9);                          // velocity update, integration, sin / cos, forward kinematics
 }
 
+// ---- the persistent kernel of the reference's default configuration (SPEC instantiation: one button, no free bodies, one wavefront per
+// SIMD) splits the physics step at the ACTION: tphysics_pre2 runs everything that depends on the state only — joint axes, dynamics,
+// collision detection, the bank-A rows up to their right-hand sides, and on a step with generic rows the general path's whole SETUP
+// (general_path<..., PART = 1>: 16 k cycles of the contact step that sets a 4096-env step's latency) — while the wavefront waits for
+// the host; tphysics_post2 takes the action: IK, motor targets, right-hand sides, the sweeps, integration.  The same operations on
+// the same operands as tphysics_step (the blocks are its own, in another order); `e` is not modified before the action is there (a
+// park in between stores the state as it was).
+struct PreStep {
+    double S[6], W[NJ], tau, qd, qd_new, bqd_g, bound_bm, rhs_b, off, inv;
+    TRows r;                      // everything but cs
+    int contact_table, contact_button;
+    bool live, any_generic;
+    GenCtx ctx;
+};
+template <int DET>
+SRL_G void tphysics_pre2(const Env &e, const GState &g, const double *tab, double *scratch, PreStep &P) {
+    const double dt = kDt, inv_dt = 1.0 / kDt;
+    const TL L = lane_view(tab);
+    // step_command switches the button's motor on in front of the physics step — unless the action is `None` (kuka_env.hpp): the one
+    // thing the rows take from the action besides the IK target.  Assumed on here; tenv_step falls back to tphysics_step for a
+    // wavefront in which it is not (an env's `None` action right after its reset).
+    constexpr int motor_on = 1;
+    double *S = P.S, *W = P.W;
+    tjoint_axis(L, g, S);
+    if (L.jnt) {                            // parked for the (rare) general path, see GenIn
+#pragma unroll
+        for (int k = 0; k < 6; k++) (scratch + SC_S)[L.l * 6 + k] = S[k];
+    }
+    // ---- collision detection at the current poses: every lane owns one sphere of the model
+    double cc[3], n_cap[3] = {0, 0, 1}, n_base[3] = {0, 0, 1}, d_cap = 1e30, d_base = 1e30;
+    const bool sphere = L.slink() >= 0;
+    {
+        double Rs[9], ps[3];
+        link_frame(g, sphere ? L.slink() : 0, Rs, ps);
+        const double sph3[3] = {L.sph(0), L.sph(1), L.sph(2)};
+        frame_point(Rs, ps, sph3, cc);
+    }
+    const double cap_z0 = e.bz + kGliderOriginZ + e.bq;
+    {
+        const double reach = L.sph(3) + kContactThreshold + 1e-9, dx = cc[0] - e.bx, dy = cc[1] - e.by, rho2 = dx * dx + dy * dy;
+        const double rmax = kBaseRadius + reach;
+        const double top = fmax(cap_z0 + kCapHeight, e.bz + kBaseHeight), bottom = fmin(cap_z0, e.bz);
+        const bool far = cc[2] - top >= reach || bottom - cc[2] >= reach || rho2 >= rmax * rmax;
+        if (wany(sphere && !far)) {
+            if (sphere) {
+                d_cap = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kCapRadius, cap_z0, cap_z0 + kCapHeight, n_cap);
+                d_base = sphere_cylinder(cc, L.sph(3), e.bx, e.by, kBaseRadius, e.bz, e.bz + kBaseHeight, n_base);
+            }
+        }
+    }
+    const bool c_cap = sphere && d_cap < kContactThreshold, c_base = sphere && d_base < kContactThreshold;
+    {
+        double *m = scratch + SC_STASH_MISC + L.l;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m[(SM_CC + k) * GL] = cc[k]; m[(SM_NCAP + k) * GL] = n_cap[k]; m[(SM_NBASE + k) * GL] = n_base[k]; }
+        m[SM_DCAP * GL] = d_cap; m[SM_DBASE * GL] = d_base;
+    }
+    P.contact_table = gany(sphere && (cc[2] - L.sph(3) - L.table_z() < kContactThreshold)) ? 1 : 0;
+    P.contact_button = gany(c_cap) ? 1 : 0;
+    const double qd = g.qd * L.jm;
+    P.qd = qd;
+    tdynamics(L, g, S, qd, W, P.tau);
+#pragma unroll
+    for (int k = 0; k < NJ; k++) (scratch + SC_STASH_W)[k * GL + L.l] = W[k];
+    double qdd = 0.0;
+    rdot_step<0, NJ>(qdd, W, P.tau);
+    const double qd_new = fma(dt, qdd, qd);
+    P.qd_new = qd_new;
+    const double bqd_g = e.bqd + dt * kGravityZ;
+    P.bqd_g = bqd_g;
+    // ---- bank-A rows (impulse space, A = J W J^T): motor row per joint lane, the button's three scalar rows
+    const double wb = 1.0 / kCapMass, blim = kLimitMaxImpulse;
+    const double bound_bm = motor_on ? kButtonMaxForce * dt : kDefaultMotorImpulse;
+    const bool is_bm = L.l == kBM, is_blo = L.l == kBLo, is_bhi = L.l == kBHi;
+    const double lerp = L.limit_erp();
+    TRows &r = P.r;
+    double rhs = 0.0, off = 0.0;
+#pragma unroll
+    for (int k = 0; k < GL; k++) r.n[k] = 0.0;
+    r.lo = 0.0; r.S = 0.0; r.jb = 0.0; r.diag = 0.0;
+    // bounds of every bank-A row are known on every lane without communication: motor row k has lo = -bound_k, S = 2 bound_k (the
+    // lane table), the button motor -+bound_bm, the button stops [0, blim]
+    auto S_of = [&](int k) -> double { return k < NJ ? 2.0 * tab[LT_BOUND * GL + k] : k == kBM ? 2.0 * bound_bm : k < GL - 1 ? blim : 0.0; };
+    auto lo_of = [&](int k) -> double { return k < NJ ? -tab[LT_BOUND * GL + k] : k == kBM ? -bound_bm : 0.0; };
+    // unscaled coupling of the own bank-A row to bank-A row k
+    auto a_of = [&](int k) -> double {
+        if (k < NJ) return L.jnt ? W[k] * (1.0 - L.e(k)) : 0.0;
+        if (k == kBM) return is_blo ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBLo) return is_bm ? wb : is_bhi ? -wb : 0.0;
+        if (k == kBHi) return (is_bm || is_blo) ? -wb : 0.0;
+        return 0.0;
+    };
+    if (L.jnt) {
+#pragma unroll
+        for (int k = 0; k < NJ; k++) r.diag = fma(L.e(k), W[k], r.diag);
+        r.lo = -L.bound(); r.S = 2.0 * L.bound();       // (rhs = target - qd_new: tphysics_post2, behind the IK)
+    } else if (is_bm) {
+        rhs = (motor_on ? kButtonKp * (kButtonTarget - e.bq) * inv_dt : 0.0) - bqd_g;
+        r.lo = -bound_bm; r.S = 2.0 * bound_bm; r.jb = 1.0; r.diag = wb;
+    } else if (is_blo) {
+        const double pen = e.bq - kGliderLower;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) - bqd_g) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt);
+        r.S = blim; r.jb = 1.0; r.diag = wb;
+    } else if (is_bhi) {
+        const double pen = kGliderUpper - e.bq;
+        rhs = ((pen > 0 ? -pen * inv_dt : 0.0) + bqd_g) + (pen > 0 ? 0.0 : -pen * lerp * inv_dt);
+        r.S = blim; r.jb = -1.0; r.diag = wb;
+    }
+#pragma unroll
+    for (int k = 0; k < kNArows; k++) off = fma(a_of(k), lo_of(k), off);
+    P.bound_bm = bound_bm; P.rhs_b = rhs; P.off = off;
+    // ---- generic rows: joint-limit candidates of the own joint, contact candidates of the own sphere
+    const bool has_lim = L.jnt && L.jlo() <= L.jhi();
+    const double pen_lo = g.q - L.jlo(), pen_hi = L.jhi() - g.q;
+    const bool lim_lo = has_lim && pen_lo <= kLimitActivationVel * dt, lim_hi = has_lim && pen_hi <= kLimitActivationVel * dt;
+    { scratch[SC_STASH_MISC + SM_PENLO * GL + L.l] = pen_lo; scratch[SC_STASH_MISC + SM_PENHI * GL + L.l] = pen_hi; }
+    const bool any_generic = wany(lim_lo || lim_hi || c_cap || c_base);
+    P.any_generic = any_generic;
+    // ---- scale the bank-A rows to u in [0, 1]:  x_r = cs_r + sum_k n_rk u_k  (cs_r: tphysics_post2)
+    {
+        const bool live = r.S > 0.0 && r.diag > 0.0;
+        const double inv = live ? rcp(r.diag * r.S) : 0.0;
+        P.live = live; P.inv = inv;
+#pragma unroll
+        for (int k = 0; k < kNArows; k++) r.n[k] = -(a_of(k) * S_of(k)) * inv;
+        r.acc0 = 0.0;
+        if (L.jnt) {
+#pragma unroll
+            for (int k = 0; k < NJ; k++) r.acc0 = fma(r.n[k] * (k > L.l ? 1.0 : 0.0), 0.5, r.acc0);
+        }
+    }
+    if (any_generic) {
+        GenIn in;
+        in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = bqd_g; in.bound_bm = bound_bm;
+        in.r2.cs = 0.0; in.r2.n[0] = 0.0; in.r2.n[1] = 0.0; in.r2.n[2] = 0.0; in.r2.lo = 0.0; in.r2.S = 0.0; in.r2.jb = 0.0;
+        in.bqd2 = 0.0; in.rb = nullptr; in.park = nullptr; in.g = &g; in.e = &e;
+        (void)general_path<1, 0, 0, DET, 1>(in, &P.ctx);
+    }
+}
+template <int DET>
+SRL_G void tphysics_post2(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, const double motor[3], bool joint_mode, double jt_own,
+                          double finger_angle, PreStep &P) {
+    const double dt = kDt, inv_dt = 1.0 / kDt;
+    const TL L = lane_view(tab);
+    const double *S = P.S;
+    e.contact_table = P.contact_table; e.contact_button = P.contact_button;
+    // ---- IK target accumulate + clip (kuka.py:134-139), one damped-least-squares step on the arm block (kuka.py:144-156)
+    double qdes = L.arm ? jt_own : L.tsel() * finger_angle;
+    if (!joint_mode) {
+        const int b = (cfg.random_target || cfg.two) ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double v = e.ee[k] + motor[k];
+            v = v < kEeBox[b][0][k] ? kEeBox[b][0][k] : v;
+            v = v > kEeBox[b][1][k] ? kEeBox[b][1][k] : v;
+            e.ee[k] = v;
+        }
+        double Rt[9], pt[3], ee[3], dS[6], J[6];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rt[k] = bcast<NA - 1>(g.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pt[k] = bcast<NA - 1>(g.p[k]);
+        const double eept[3] = {L.eept(0), L.eept(1), L.eept(2)};
+        frame_point(Rt, pt, eept, ee);
+        {
+            double d[3], Sa[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { d[k] = ee[k] - g.p[k]; Sa[k] = S[k] * L.am; }
+            cross3(Sa, d, J);
+#pragma unroll
+            for (int k = 0; k < 3; k++) J[3 + k] = Sa[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) dS[k] = e.ee[k] - ee[k];
+        {   // orientation error towards quat(euler(0, -pi, 0)), replicated (same construction as kuka_group.hpp)
+            const double *R = Rt;
+            double qx, qy, qz, qw;
+            const double m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+            const double tr = m00 + m11 + m22;
+            if (tr > 0) { double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
+            else if (m00 > m11 && m00 > m22) { double s = sqrt(1.0 + m00 - m11 - m22) * 2; qw = (m21 - m12) / s; qx = 0.25 * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
+            else if (m11 > m22) { double s = sqrt(1.0 + m11 - m00 - m22) * 2; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25 * s; qz = (m12 + m21) / s; }
+            else { double s = sqrt(1.0 + m22 - m00 - m11) * 2; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25 * s; }
+            const double tx = 0.0, ty = -1.0, tz = 0.0, tw = 6.123233995736766e-17;
+            const double ix = -qx, iy = -qy, iz = -qz, iw = qw;
+            const double dw = tw * iw - tx * ix - ty * iy - tz * iz;
+            const double dx = tw * ix + tx * iw + ty * iz - tz * iy;
+            const double dy = tw * iy - tx * iz + ty * iw + tz * ix;
+            const double dz = tw * iz + tx * iy - ty * ix + tz * iw;
+            const double sv = sqrt(dx * dx + dy * dy + dz * dz);
+            double angle = 2.0 * atan2(sv, dw), ax, ay, az;
+            if (sv * sv < 10.0 * 2.2204460492503131e-16) { ax = 1; ay = 0; az = 0; }
+            else { ax = dx / sv; ay = dy / sv; az = dz / sv; }
+            if (angle > kPi) angle -= 2 * kPi;
+            dS[3] = angle * ax; dS[4] = angle * ay; dS[5] = angle * az;
+        }
+        double A[NA], bb = 0.0;
+        dot6_step<0, NA>(J, J, A);
+        const double damping = cfg.two ? kIkDampingDefault : kIkDamping;
+#pragma unroll
+        for (int k = 0; k < NA; k++) A[k] = fma(damping, L.e(k), A[k]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb = fma(J[c], dS[c], bb);
+        double det = 1.0;
+        gj_step<0, NA, false>(L, A, bb, &det);
+        if (det < kIkCrossDet) e.ikx |= 1;      // sticky until the episode's reset (kuka_core.hpp kIkCrossDet)
+        bb *= L.am;
+        double all[NA], maxabs = 0.0;
+        ball_step<0, NA>(bb, all);
+#pragma unroll
+        for (int k = 0; k < NA; k++) maxabs = fmax(maxabs, fabs(all[k]));
+        if (L.arm) qdes = g.q + bb;
+        if (wany(maxabs > kIkMaxAngle)) {
+            const double scale = kIkMaxAngle / maxabs;
+            if (maxabs > kIkMaxAngle && L.arm) qdes = g.q + bb * scale;
+        }
+    }
+    double target = L.kp() * (qdes - g.q) * inv_dt;
+    target = target > L.maxvel() ? L.maxvel() : target;
+    target = target < -L.maxvel() ? -L.maxvel() : target;
+    const double qd_new = P.qd_new, wb = 1.0 / kCapMass;
+    e.bqd = P.bqd_g;
+    TRows &r = P.r;
+    const bool is_bm = L.l == kBM;
+    {
+        const double rhs = L.jnt ? target - qd_new : P.rhs_b, off = P.off, inv = P.inv;
+        const bool live = P.live;
+        r.cs = live ? (rhs - off) * inv + ((L.jnt || is_bm) ? 0.5 : 0.0) : 0.0;
+    }
+    static_assert(DET == 0, "the early setup exists for the default solver details (the configuration-specialised kernel)");
+    double u, acc_b = 0.0, dvb_b = 0.0;
+    if (!P.any_generic) u = sweeps_free<1>(r);
+    else {
+        GenIn in;
+        in.tab = tab; in.scratch = scratch; in.r = r; in.qd_new = qd_new; in.bqd = e.bqd; in.bound_bm = P.bound_bm;
+        in.r2.cs = 0.0; in.r2.n[0] = 0.0; in.r2.n[1] = 0.0; in.r2.n[2] = 0.0; in.r2.lo = 0.0; in.r2.S = 0.0; in.r2.jb = 0.0;
+        in.bqd2 = 0.0; in.rb = nullptr; in.park = nullptr; in.g = &g; in.e = &e;
+        const GenOut out = general_path<1, 0, 0, DET, 2>(in, &P.ctx);
+        u = out.u; acc_b = out.acc_b; dvb_b = out.dvb_b;
+    }
+    const double lam = r.lo + r.S * u;
+    SRL_GDBG(5, lane_id(), lam);
+    // ---- velocity change: joint lane i gets sum_r a_ir lambda_r, the glider sum_r jb_r lambda_r / m
+    double dv = 0.0, dvb = 0.0;
+    {
+        const double v = r.S > 0.0 ? lam / r.S : 0.0, pb = r.jb * lam * wb;
+        double acc = 0.0;
+#define SRL_ACC(K) fmac_bcast<K>(acc, v, r.n[K]);
+        SRL_ACC(0) SRL_ACC(1) SRL_ACC(2) SRL_ACC(3) SRL_ACC(4) SRL_ACC(5) SRL_ACC(6) SRL_ACC(7) SRL_ACC(8) SRL_ACC(9) SRL_ACC(10) SRL_ACC(11)
+#undef SRL_ACC
+        dvb = bcast<kBM>(pb) + bcast<kBLo>(pb) + bcast<kBHi>(pb);
+        acc += acc_b; dvb += dvb_b;
+        dv = r.diag * (lam - r.S * acc);
+    }
+    // ---- semi-implicit Euler, refresh sin/cos, frames and the gripper position (a fresh copy of the lane constants: the one loaded
+    //      at the top of the step is not kept live across the solver loop)
+    if (lane_id() < NJ) { g.qd = qd_new + dv; g.q += dt * g.qd; }
+    e.bqd += dvb;
+    e.bq += dt * e.bqd;
+    const TL L3 = lane_view(tab);
+    trefresh(L3, g, e);
+}
+
 // ------------------------------------------------------------------ env level (mirrors kuka_group.hpp / kuka_env.hpp)
 // packed start state: q12 qd12 sq12 cq12 ee3 bq bqd grip3
 SRL_G void tunpack_start(Env &e, GState &g, const double *o) {
@@ -1953,10 +2228,11 @@ SRL_G void tenv_reset(Env &e, GState &g, const double *tab, const Cfg &cfg, doub
 
 // KukaButtonGymEnv.step + step2 for one lane group.  ca3: the Cartesian action (replicated), ca_own: the own arm joint's action.
 // finger_angle = 0.0 (kuka_button_gym_env.py:312,335: "Close the gripper"; joints mode appends [0, 0]).
-// EARLY = 1 (persistent kernels): `pre` holds the action-independent half of the FIRST physics step (tphysics_pre on the state this call starts from)
+// EARLY = 1 (persistent kernels): `pre` holds the action-independent half of the FIRST physics step (tphysics_pre on the state this call
+// starts from); EARLY = 2 (the configuration-specialised persistent kernel): `pre2` holds everything in front of the action (tphysics_pre2)
 template <int NB = 1, int RB = 0, int OCC = 0, int DET = -1, int EARLY = 0, class R>
 SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, double *scratch, R &rng, int action, const float *ca3, float ca_own, bool *done,
-                       RBody *rb = nullptr, double *park = nullptr, const PreDyn *pre = nullptr) {
+                       RBody *rb = nullptr, double *park = nullptr, const PreDyn *pre = nullptr, PreStep *pre2 = nullptr) {
     if constexpr (RB) {
         // kuka_rand_button_gym_env.py:111-123: at env step 10 the ball is kicked (applyExternalForce: it acts on the next stepSimulation)
         const double kx = shfl(rb->ox, 9), ky = shfl(rb->oy, 9);
@@ -1973,7 +2249,10 @@ SRL_G double tenv_step(Env &e, GState &g, const double *tab, const Cfg &cfg, dou
     const double jt = joint_target(c, ca_own, tab[LT_Q0 * GL + lane_id()]);
     SRL_TSTAMP(21);                         // noise draw + action mapping (step_command)
     for (int rep = 0; rep < cfg.action_repeat; rep++) {
-        if constexpr (EARLY) {
+        if constexpr (EARLY == 2) {
+            if (rep == 0 && !wany(e.motor_on != 1)) tphysics_post2<DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, *pre2);
+            else tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
+        } else if constexpr (EARLY) {
             if (rep == 0) tphysics_step<NB, RB, OCC, DET, 1>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park, pre);
             else tphysics_step<NB, RB, OCC, DET>(e, g, tab, cfg, scratch, c.motor, c.joint_mode, jt, 0.0, rb, park);
         } else {

@@ -269,7 +269,13 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     }
     for (int t = 0; (PERSIST && !park_now) || (!PERSIST && t < T); t++) {
         tree::PreDyn pre;
-        if constexpr (PERSIST) {
+        tree::PreStep pre2;
+        if constexpr (PERSIST && SPEC == 1) {
+            // everything of the step that depends on the state only — dynamics, collision detection, the rows up to their right-hand
+            // sides and, on a contact step, the general path's whole setup (16 k cycles of the step that sets the batch's latency) —
+            // runs BEFORE the wait for the host's action
+            tree::tphysics_pre2<0>(v, g, tab, scratch, pre2);
+        } else if constexpr (PERSIST) {
             // the action-independent half of the step's (first) physics step — joint axes, bias forces, the mass matrix and its inverse:
             // 8 k of a free step's 53 k cycles — runs BEFORE the wait for the host's action: off the step's latency
             tree::tphysics_pre(g, tab, pre);
@@ -343,7 +349,8 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #endif
         bool done;
         double reward;
-        if constexpr (PERSIST) reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1, 1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, &pre);
+        if constexpr (PERSIST && SPEC == 1) reward = tree::tenv_step<NB, RB, 0, 0, 2>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, nullptr, &pre2);
+        else if constexpr (PERSIST) reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1, 1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, &pre);
         else reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
         ep_ret += reward; ep_len += 1; last_reward = reward;
         const int info = cfg.info_bits ? (v.ikx & 1) << 1 : 0;      // srlhip_config.info_bits: the IK conditioning flag this step ran under (before the auto-reset clears it)
