@@ -270,6 +270,16 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
     for (int t = 0; (PERSIST && !park_now) || (!PERSIST && t < T); t++) {
         tree::PreDyn pre;
         tree::PreStep pre2;
+        // (the launching kernel of the default configuration with the caller's actions — the per-step path of HipVecEnv — takes the same
+        //  split: its action is REQUESTED first, from mapped host memory on a single-step launch, and everything in front of the action
+        //  runs under that PCIe round trip)
+        constexpr bool kLaunchSplit = GIVEN && !PERSIST && SPEC == 1;
+        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
+        if constexpr (kLaunchSplit) {
+            a = *reinterpret_cast<const int32_t *>(given_p);
+            given_p += act_stride;
+            tree::tphysics_pre2<0>(v, g, tab, scratch, pre2);
+        }
         if constexpr (PERSIST && SPEC == 1) {
             // everything of the step that depends on the state only — dynamics, collision detection, the rows up to their right-hand
             // sides and, on a contact step, the general path's whole setup (16 k cycles of the step that sets the batch's latency) —
@@ -315,9 +325,9 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
             asm volatile("" ::: "memory");                       // the action reads below stay behind the token (they are system-scope loads)
 #endif
         }
-        int a = 0; float ca[7] = {0, 0, 0, 0, 0, 0, 0};
         if constexpr (GIVEN) {
-            if constexpr (PERSIST) {           // the same mapped row every step: re-read, never cached in a register
+            if constexpr (kLaunchSplit) {
+            } else if constexpr (PERSIST) {           // the same mapped row every step: re-read, never cached in a register
                 if (cfg.is_discrete) a = __hip_atomic_load(reinterpret_cast<const int32_t *>(given_p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 else for (int j = 0; j < adim; j++) ca[j] = __hip_atomic_load(reinterpret_cast<const float *>(given_p) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
@@ -349,7 +359,7 @@ kuka_tree_rollout_k(KukaParams p, KukaState s, RngState rs, EpisodeStats st, int
 #endif
         bool done;
         double reward;
-        if constexpr (PERSIST && SPEC == 1) reward = tree::tenv_step<NB, RB, 0, 0, 2>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, nullptr, &pre2);
+        if constexpr ((PERSIST || kLaunchSplit) && SPEC == 1) reward = tree::tenv_step<NB, RB, 0, 0, 2>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, nullptr, &pre2);
         else if constexpr (PERSIST) reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1, 1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body, nullptr, &pre);
         else reward = tree::tenv_step<NB, RB, 0, SPEC ? 0 : -1>(v, g, tab, cfg, scratch, rng0, a, ca, ca_own, &done, &body);
         ep_ret += reward; ep_len += 1; last_reward = reward;
