@@ -183,14 +183,14 @@ int srlhip_step_pending(srlhip_handle h);
  * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
  * 4096 envs on an MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
  * the device with every env's state in registers.  srlhip_step_async writes the actions and a sequence number into mapped
- * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront has already run the
- * action-independent half of the step (bias forces, mass matrix and its inverse) while it waited, finishes the step and writes its
+ * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront has already run everything
+ * in front of the action (dynamics, collision detection, on a contact step the solver's setup) while it waited, finishes the step and writes its
  * outputs to the host's mapped planes with plain stores — they stay in its XCD's L2; the last wavefront of each eighth of the
  * grid (= one XCD, verified at launch through HW_REG_XCC_ID) to finish writes that L2 back with ONE system-scope release and
  * writes the eighth's `done` word; srlhip_step_wait polls those 8 words.  (Where an eighth does not sit on one XCD, or with
  * SRLHIP_PERSIST_STAGED=1, the outputs go through a staging copy in device memory that the eighth's last wavefront copies out.)  What a per-step launch pays every time — the launch itself, the
  * 5.6 KB model table, ~40 state planes, the generators, forward kinematics, the stream synchronisation — is paid once: measured
- * HipVecEnv.step 82 -> 72 us at 4096 envs, 62 -> 52 at 256, 39 -> 28 at 16 (launching path -> persistent).  Same kernel
+ * HipVecEnv.step 82 -> 62 us at 4096 envs, 61 -> 45 at 256, 38 -> 27 at 16 (launching path -> persistent).  Same kernel
  * code, same arithmetic: results are those of the launching path bit for bit (tests/test_gpu_persistent_step.py).
  * The kernel PARKS (writes the state back and exits) when any other entry point touches the handle, and by itself when no step
  * arrived for park_us microseconds (<= 0: 2000) — the next step restarts it, at the cost of a launch.  While it is resident it
