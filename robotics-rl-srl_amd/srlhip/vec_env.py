@@ -172,7 +172,6 @@ class HipVecEnv(object):
         # The dicts of envs with something to report are fresh per step, like SubprocVecEnv's.)
         self._no_info = {}
         self._quiet_infos = (self._no_info,) * self.num_envs
-        self._n_finished = np.zeros(self.num_envs, np.int32)
         # per-step fast path of the host-pointer handles (ground-truth observation modes, raw pixels): GLOBAL action / obs / reward /
         # done arrays; every shard's two foreign calls are bound ONCE to its slice of them (a step costs one srlhip_step_async and
         # one srlhip_step_wait per shard, no per-step ctypes marshalling, no concatenation); Monitor's (r, l) are read from the
@@ -414,7 +413,7 @@ class HipVecEnv(object):
         idx = hot
         if hot.size and self._info_bits:
             bits = done[hot]
-            if bits.max() > 1:
+            if max(bits.tolist()) > 1:                       # (a handful of entries: a Python max beats a numpy reduction)
                 # (include/srlhip.h SRLHIP_F_KUKA_IK_CROSSED: behind this flag the reference's own DLS controller amplifies rounding, parity
                 #  with PyBullet is not claimed; rare — random agents never raise it, saturating policies do)
                 infos = [self._no_info] * self.num_envs
@@ -435,11 +434,9 @@ class HipVecEnv(object):
                         if b > a:
                             loc = idx[a:b] - sh.lo
                             ret[a:b], length[a:b] = sh.ret[loc], sh.len[loc]
-                self._n_finished[idx] += 1
             else:
                 stats = [sh.h.episode_stats() for sh in self._shards]
                 ret, length = np.concatenate([s[0] for s in stats])[idx], np.concatenate([s[1] for s in stats])[idx]
-                self._n_finished = np.concatenate([s[2] for s in stats])
             now = time.time()
             t = round(now - self._t_start, 6)
             if infos is self._quiet_infos:
