@@ -135,7 +135,7 @@ int persist_launch(Handle *h, uint32_t start_seq) {
     pa.seq = w; pa.stop = w + 1; pa.parked = w + 2; pa.done = w + 16; pa.relay = h->persist_relay; pa.count = h->persist_relay + 8 * kPersistWordStride; pa.ctrl = h->persist_relay + 16 * kPersistWordStride;
     pa.start_seq = start_seq;
     { const char *v = getenv("SRLHIP_PERSIST_STAGED"); pa.force_staged = v && atoi(v) != 0; }
-    pa.spin_limit = h->persist_park_us / 2 + 1;        // one poll of workgroup 0: two PCIe reads + s_sleep 16, ~2 us
+    pa.spin_limit = h->persist_park_us / 2 + 1;        // one poll of workgroup 0: one 8-byte PCIe read + s_sleep 8, ~2 us
     const size_t n = (size_t)h->n, ob = obs_bytes_per_env(h) * n, out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * n;
     pa.stage = static_cast<const uint32_t *>(h->persist_stage); pa.host_out = static_cast<uint32_t *>(dout);
     pa.rew_dw = (uint32_t)(out_rew / 4); pa.done_dw = (uint32_t)(out_done / 4);
