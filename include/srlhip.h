@@ -179,8 +179,8 @@ int srlhip_step_pending(srlhip_handle h);
  * in flight on the handle's stream: every entry point of this library is ordered behind them, a caller that reads
  * srlhip_device_ptr() planes of a host-pointer handle from a stream of its own calls srlhip_sync() first.) */
 
-/* Persistent stepping (opt-in; host-pointer handles of KukaButtonGymEnv, KukaMovingButtonGymEnv and Kuka2ButtonGymEnv — any
- * action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
+/* Persistent stepping (opt-in; host-pointer handles of the MobileRobot family, KukaButtonGymEnv, KukaMovingButtonGymEnv and
+ * Kuka2ButtonGymEnv — any action mode and any observation mode but raw pixels — on a device RNG mode, whose wavefronts are all resident at once: up to
  * 4096 envs on an MI355X; SRLHIP_ENOTSUP otherwise): the step pair WITHOUT a kernel launch per step.  One launch of the rollout kernel stays on
  * the device with every env's state in registers.  srlhip_step_async writes the actions and a sequence number into mapped
  * memory; workgroup 0 polls that word over PCIe and relays it through device memory; every wavefront has already run everything
@@ -190,7 +190,8 @@ int srlhip_step_pending(srlhip_handle h);
  * writes the eighth's `done` word; srlhip_step_wait polls those 8 words.  (Where an eighth does not sit on one XCD, or with
  * SRLHIP_PERSIST_STAGED=1, the outputs go through a staging copy in device memory that the eighth's last wavefront copies out.)  What a per-step launch pays every time — the launch itself, the
  * 5.6 KB model table, ~40 state planes, the generators, forward kinematics, the stream synchronisation — is paid once: measured
- * HipVecEnv.step 80 -> 60 us at 4096 envs, 60 -> 44 at 256, 39 -> 28 at 16 (launching path -> persistent).  Same kernel
+ * HipVecEnv.step 80 -> 60 us at 4096 envs, 60 -> 44 at 256, 39 -> 28 at 16 (launching path -> persistent; MobileRobot: 19 -> 13 us
+ * and 13 -> 6 us at 16 envs).  Same kernel
  * code, same arithmetic: results are those of the launching path bit for bit (tests/test_gpu_persistent_step.py).
  * The kernel PARKS (writes the state back and exits) when any other entry point touches the handle, and by itself when no step
  * arrived for park_us microseconds (<= 0: 2000) — the next step restarts it, at the cost of a launch.  While it is resident it

@@ -139,8 +139,10 @@ int persist_launch(Handle *h, uint32_t start_seq) {
     const size_t n = (size_t)h->n, ob = obs_bytes_per_env(h) * n, out_rew = (ob + 15) & ~(size_t)15, out_done = out_rew + 4 * n;
     pa.stage = static_cast<const uint32_t *>(h->persist_stage); pa.host_out = static_cast<uint32_t *>(dout);
     pa.rew_dw = (uint32_t)(out_rew / 4); pa.done_dw = (uint32_t)(out_done / 4);
-    uint8_t *o = static_cast<uint8_t *>(h->persist_stage);
-    int rc = kuka_persist_start(h, din, reinterpret_cast<float *>(o), reinterpret_cast<float *>(o + out_rew), o + out_done, pa);
+    uint8_t *o = static_cast<uint8_t *>(h->persist_stage), *ho = static_cast<uint8_t *>(dout);
+    // (the Kuka kernels take the staging copy and switch to the host's planes themselves; the MobileRobot kernel writes the host's planes)
+    int rc = is_mobile(h->cfg.env_kind) ? mobile_persist_start(h, din, reinterpret_cast<float *>(ho), reinterpret_cast<float *>(ho + out_rew), ho + out_done, pa)
+                                        : kuka_persist_start(h, din, reinterpret_cast<float *>(o), reinterpret_cast<float *>(o + out_rew), o + out_done, pa);
     if (rc) return rc;
     h->persist_running = true;
     return 0;
@@ -479,7 +481,7 @@ int host_step_begin(Handle *h, const void *actions, const double *host_noise, bo
         din = static_cast<uint8_t *>(h->st_actions);
         o = static_cast<uint8_t *>(h->st_obs);
     }
-    if (h->persist_on && L.zero_copy && !host_noise && !is_mobile(h->cfg.env_kind)) {
+    if (h->persist_on && L.zero_copy && !host_noise) {
         // persistent stepping: no launch — (re)start the resident kernel if it is parked, then hand it the step's sequence number
         PersistHost *c = persist_ctl(h);
         if (h->persist_running && c->parked) { if ((rc = persist_park(h))) return rc; }
@@ -537,10 +539,9 @@ int host_step_finish(Handle *h, void *obs_out, float *reward_out, uint8_t *done_
         h->persist_step = false;
         uint64_t spins = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        // (persist_blocks real workgroups in a grid rounded up to a multiple of 8: eighth g reports iff it holds a real workgroup)
-        const uint32_t per = (h->persist_blocks + 7) / 8;
-        for (uint32_t b = 0; b < 8 && b * per < h->persist_blocks; b++) {
-            while (__atomic_load_n(&c->done[b], __ATOMIC_ACQUIRE) != want) {
+        // (eighth g reports iff it holds a real workgroup: persist_eighths, set with the mode)
+        for (uint32_t b = 0; b < 8; b++) {
+            while (((h->persist_eighths >> b) & 1u) && __atomic_load_n(&c->done[b], __ATOMIC_ACQUIRE) != want) {
                 if ((++spins & 1023u) != 0) continue;
                 if (c->parked) {
                     int rc = persist_park(h);
@@ -643,11 +644,17 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
     int rc = set_device(h);                            // (parks a resident kernel)
     if (rc) return rc;
     if (!on) { h->persist_on = false; persist_release(h); return 0; }
-    if (h->cfg.io_device || is_mobile(h->cfg.env_kind)) return h->fail(SRLHIP_ENOTSUP, "set_persistent: host-pointer Kuka handles only");
+    if (h->cfg.io_device) return h->fail(SRLHIP_ENOTSUP, "set_persistent: host-pointer handles only");
     int capacity = 0;
-    const int blocks = kuka_persist_blocks(h, &capacity);
+    uint32_t eighths = 0;
+    const bool mobile = is_mobile(h->cfg.env_kind);
+    const int blocks = mobile ? mobile_persist_blocks(h, &capacity, &eighths) : kuka_persist_blocks(h, &capacity);
+    if (!mobile) {                  // eighth g = the contiguous workgroup range [g, g + 1) * ceil(blocks / 8) (kuka_tree_kernels.hpp)
+        const uint32_t per = ((uint32_t)(blocks > 0 ? blocks : 0) + 7) / 8;
+        for (uint32_t g = 0; g < 8 && g * per < (uint32_t)(blocks > 0 ? blocks : 0); g++) eighths |= 1u << g;
+    }
     if (blocks <= 0 || !step_layout(h).zero_copy)
-        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs KukaButtonGymEnv, KukaMovingButtonGymEnv or Kuka2ButtonGymEnv (full model) on a device RNG mode, non-pixel "
+        return h->fail(SRLHIP_ENOTSUP, "set_persistent: needs a MobileRobot env, KukaButtonGymEnv, KukaMovingButtonGymEnv or Kuka2ButtonGymEnv (full model) on a device RNG mode, non-pixel "
                                        "observations, zero-copy step buffers, and a batch whose wavefronts are all resident at once (4096 envs on an MI355X)");
     if ((rc = ensure_signal_buffers(h))) return rc;
     if (!h->persist_stage) {
@@ -656,7 +663,7 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
         if (hipMalloc(&h->persist_stage, L.out_total + 16) != hipSuccess) return h->fail(SRLHIP_ENOMEM, "set_persistent: hipMalloc failed");
     }
     if (!h->persist_reserved) {
-        const int grid = (blocks + 7) / 8 * 8;
+        const int grid = mobile ? blocks : (blocks + 7) / 8 * 8;
         std::lock_guard<std::mutex> lk(g_persist_mu);
         if (g_persist_reserved[h->cfg.device_id & 63] + grid > capacity)
             return h->fail(SRLHIP_ENOTSUP, "set_persistent: the resident kernels of the handles already in persistent mode on this device leave no room for this one");
@@ -664,6 +671,7 @@ int srlhip_set_persistent(srlhip_handle hh, int32_t on, int32_t park_us) {
         h->persist_reserved = grid;
     }
     h->persist_blocks = (uint32_t)blocks;
+    h->persist_eighths = eighths;
     h->persist_park_us = park_us > 0 ? (uint32_t)park_us : 2000u;
     h->persist_on = true;
     return 0;

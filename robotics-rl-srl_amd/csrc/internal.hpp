@@ -57,6 +57,8 @@ int mobile_rollout(Handle *h, int T, const void *d_actions, float *d_obs, float 
                    void *d_act_out);
 int mobile_field(Handle *h, int field, void **dptr, size_t *elem, int *count);
 int mobile_reset_rand_count(const srlhip_config &c);
+int mobile_persist_blocks(Handle *h, int *capacity, uint32_t *eighths);      // persistent stepping (mobile.hip)
+int mobile_persist_start(Handle *h, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done, const struct PersistArgs &pa);
 
 // kuka.hip
 int kuka_alloc(Handle *h);
@@ -169,6 +171,7 @@ struct Handle {
     bool step_signal_armed = false, signal_wait = false;
     uint32_t signal_seq = 0, signal_steps = 0, signal_fallbacks = 0;
     uint32_t signal_eighths = 0;     // which of the 8 `done` words the armed launch will write (set by the launcher)
+    uint32_t persist_eighths = 0;    // which of the 8 `done` words the resident kernel writes
     int persist_reserved = 0;        // workgroups this handle holds in the per-device residency tally (api.hip)
 
     int fail(int code, const std::string &msg) { err = msg; return code; }

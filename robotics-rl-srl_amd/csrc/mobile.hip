@@ -401,6 +401,125 @@ mobile_rollout_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, in
     st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
 }
 
+// Persistent stepping (srlhip_set_persistent; the protocol of the Kuka kernels, kuka_tree_kernels.hpp): ONE launch stays resident with every
+// env's state in registers and takes its steps from the host through mapped memory — workgroup 0 polls the host's sequence number and
+// relays it, the others poll the relay; every lane reads its action from the mapped plane, steps, stores its outputs straight to the
+// host's mapped planes (plain stores: they stay in the XCD's L2), and the last wavefront of each eighth of the grid (workgroups b = g mod
+// 8: one XCD, verified behind a start barrier) writes that L2 back and posts the eighth's `done` word.  Where an eighth does not sit on
+// one XCD the outputs are written through instead (system-scope stores: slow, correct).  Same step code as mobile_rollout_k: bit-identical.
+template <int MODE, int KIND, int DISC>
+__global__ void __launch_bounds__(kBlock)
+mobile_persist_k(MobileParams p, MobileState s, RngState rs, EpisodeStats st, const void *actions, float *obs, float *rew, uint8_t *done_out, PersistArgs pa) {
+    __shared__ uint32_t tok_s, verdict_s;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = e < p.n;
+    const int ee = valid ? e : p.n - 1;
+    p.kind = KIND; p.is_discrete = DISC;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(pa.ctrl, 1u + (((xcc & 15u) != (blockIdx.x & 7u)) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typename RngSel<MODE>::type rng;
+    rng_load<MODE>(rng, rs, ee, p.n, nullptr, 0, nullptr);
+    MobileEnv m;
+    load_env(s, ee, m);
+    double ep_ret = st.ep_return[ee], last_ret = 0.0, last_reward = st.last_reward[ee];
+    int32_t ep_len = st.ep_length[ee], last_len = 0, n_fin = st.n_finished[ee];
+    // start barrier: every workgroup has registered -> 1: direct outputs, 2: written-through outputs, 3: told to stop while waiting
+    if (threadIdx.x == 0) {
+        uint32_t verdict = 0;
+        uint32_t *vw = pa.ctrl + kPersistWordStride;
+        if (blockIdx.x == 0) {
+            for (;;) {
+                const uint32_t reg = __hip_atomic_load(pa.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((reg & 0xffffu) == gridDim.x) { verdict = ((reg >> 16) || pa.force_staged) ? 2u : 1u; break; }
+                if (__hip_atomic_load(pa.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { verdict = 3u; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __hip_atomic_store(vw, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (!(verdict = __hip_atomic_load(vw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) __builtin_amdgcn_s_sleep(8);
+        }
+        verdict_s = verdict;
+    }
+    __syncthreads();
+    const uint32_t verdict = verdict_s;
+    const bool direct = verdict == 1u;
+    const int g8 = (int)blockIdx.x & 7, waves = (p.n + 63) / 64;
+    int real = 0;                    // wavefronts with a live lane in the workgroups of this eighth
+    for (int b = g8; b * (kBlock / 64) < waves; b += 8) real += min(kBlock / 64, waves - b * (kBlock / 64));
+    const bool first = valid && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0;     // (lanes of a wavefront are valid from lane 0 up)
+    uint32_t my_seq = pa.start_seq, k = 0;
+    const int od = p.kind == SRLHIP_ENV_MOBILE_1D ? 1 : 2;
+    while (verdict != 3u) {
+        if (threadIdx.x == 0) {
+            uint32_t token;
+            if (blockIdx.x == 0) {
+                uint32_t sq = my_seq, stop = 0, spins = 0;
+                for (;;) {
+                    const uint64_t w = __hip_atomic_load(reinterpret_cast<const uint64_t *>(pa.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    sq = (uint32_t)w; stop = (uint32_t)(w >> 32);
+                    if (sq != my_seq || stop || ++spins >= pa.spin_limit) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                token = sq != my_seq ? sq : kPersistPark;
+                if (token == kPersistPark) __hip_atomic_store(pa.parked, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int x = 0; x < 8; x++) __hip_atomic_store(pa.relay + x * kPersistWordStride, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint32_t *rw = pa.relay + (blockIdx.x & 7) * kPersistWordStride;
+                while ((token = __hip_atomic_load(rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == my_seq) __builtin_amdgcn_s_sleep(8);
+            }
+            tok_s = token;
+        }
+        __syncthreads();
+        const uint32_t token = tok_s;
+        __syncthreads();                                   // everybody has read the token before thread 0 writes the next one
+        if (token == kPersistPark) break;
+        my_seq = token; k += 1;
+        if (valid) {
+            int a = 0; float a0 = 0.f, a1 = 0.f;
+            if (p.is_discrete) a = __hip_atomic_load(static_cast<const int32_t *>(actions) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else {
+                a0 = __hip_atomic_load(static_cast<const float *>(actions) + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                a1 = __hip_atomic_load(static_cast<const float *>(actions) + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            double dv = 0.1 + rng.normal(0.0, 0.0);       // DELTA_POS + N(0, NOISE_STD = 0): drawn, value 0
+            double reward; bool done;
+            step_env<KIND, DISC>(p, m, a, a0, a1, dv, reward, done);
+            ep_ret += reward; ep_len += 1; last_reward = reward;
+            if (done) {
+                last_ret = ep_ret; last_len = ep_len; n_fin += 1; ep_ret = 0.0; ep_len = 0;
+                if (p.auto_reset) reset_env(p, rng, m);
+                __hip_atomic_store(st.last_return + e, last_ret, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // Monitor's record, with the step
+                __hip_atomic_store(st.last_length + e, last_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            float o0, o1;
+            observe(p, m, o0, o1);
+            if (direct) {
+                if (od == 1) obs[e] = o0; else { obs[2 * e] = o0; obs[2 * e + 1] = o1; }
+                rew[e] = (float)reward; done_out[e] = (uint8_t)done;
+            } else {
+                __hip_atomic_store(obs + od * e, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (od == 2) __hip_atomic_store(obs + 2 * e + 1, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(rew + e, (float)reward, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(done_out + e, (uint8_t)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        uint32_t last = 0;
+        if (first) last = __hip_atomic_fetch_add(pa.count + g8 * kPersistWordStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (uint32_t)real * k;
+        if (__builtin_amdgcn_readfirstlane(last)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (first) __hip_atomic_store(pa.done + g8, my_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (!valid) return;
+    store_env(s, e, m);
+    rng_store<MODE>(rng, rs, e);
+    st.ep_return[e] = ep_ret; st.ep_length[e] = ep_len;
+    st.n_finished[e] = n_fin; st.last_reward[e] = last_reward;
+}
+
 // Episode-parallel rollout (Philox mode with auto-reset).  In the MobileRobot family an episode always lasts exactly
 // 251 steps (`done = counter > 250`, `terminated` is never set: mobile_robot_env.py:336-343) and a reset consumes a
 // fixed number of counter-based draws, so the state an env has right after its k-th reset inside a rollout is a pure
@@ -817,6 +936,57 @@ int mobile_step(Handle *h, const void *d_actions, const double *d_noise, float *
     dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL((mobile_rollout_k<SRLHIP_RNG_HOST, -1, -1>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats,
                        1, d_actions, d_noise, d_obs, d_rew, d_done, 0, PersistArgs{});
+    SRL_HIP_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- persistent stepping, host side (api.hip: srlhip_set_persistent) --------------------------------------------------------------------
+template <int MODE> static const void *mobile_persist_fn(const MobileParams &p) {
+#define SRL_FN(KIND, DISC) reinterpret_cast<const void *>(mobile_persist_k<MODE, KIND, DISC>)
+#define SRL_KIND(KIND) (p.is_discrete ? SRL_FN(KIND, 1) : SRL_FN(KIND, 0))
+    switch (p.kind) {
+        case SRLHIP_ENV_MOBILE: return SRL_KIND(SRLHIP_ENV_MOBILE);
+        case SRLHIP_ENV_MOBILE_1D: return SRL_KIND(SRLHIP_ENV_MOBILE_1D);
+        case SRLHIP_ENV_MOBILE_2TARGET: return SRL_KIND(SRLHIP_ENV_MOBILE_2TARGET);
+        default: return SRL_KIND(SRLHIP_ENV_MOBILE_LINE);
+    }
+#undef SRL_KIND
+#undef SRL_FN
+}
+// workgroups of the resident kernel (0: no persistent form for this handle); capacity: how many the device holds at once;
+// eighths: which of the 8 `done` words it writes (eighth g = the workgroups b = g mod 8)
+int mobile_persist_blocks(Handle *h, int *capacity, uint32_t *eighths) {
+    if (capacity) *capacity = 0;
+    const srlhip_config &c = h->cfg;
+    if (!(c.rng_mode == SRLHIP_RNG_PHILOX || c.rng_mode == SRLHIP_RNG_MT19937) || c.obs_mode == SRLHIP_OBS_RAW_PIXELS) return 0;
+    const MobileParams p = params_of(h);
+    const int grid = (h->n + kBlock - 1) / kBlock;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device_id) != hipSuccess) return 0;
+    const void *fn = c.rng_mode == SRLHIP_RNG_PHILOX ? mobile_persist_fn<SRLHIP_RNG_PHILOX>(p) : mobile_persist_fn<SRLHIP_RNG_MT19937>(p);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess) return 0;
+    if (capacity) *capacity = per_cu * prop.multiProcessorCount;
+    if (eighths) *eighths = grid >= 8 ? 0xffu : (1u << grid) - 1u;
+    return (long long)per_cu * prop.multiProcessorCount >= grid ? grid : 0;
+}
+int mobile_persist_start(Handle *h, const void *d_actions, float *d_obs, float *d_rew, uint8_t *d_done, const PersistArgs &pa) {
+    h->snap_valid = false; h->prefetch_valid = false;
+    const MobileParams p = params_of(h);
+    dim3 grid((h->n + kBlock - 1) / kBlock), block(kBlock);
+#define SRL_GO(MODE, KIND, DISC) hipLaunchKernelGGL((mobile_persist_k<MODE, KIND, DISC>), grid, block, 0, h->stream, p, h->mobile, h->rng, h->stats, d_actions, d_obs, d_rew, d_done, pa)
+#define SRL_KIND(MODE, KIND) { if (p.is_discrete) SRL_GO(MODE, KIND, 1); else SRL_GO(MODE, KIND, 0); }
+#define SRL_MODE(MODE)                                                                        \
+    switch (p.kind) {                                                                         \
+        case SRLHIP_ENV_MOBILE: SRL_KIND(MODE, SRLHIP_ENV_MOBILE) break;                       \
+        case SRLHIP_ENV_MOBILE_1D: SRL_KIND(MODE, SRLHIP_ENV_MOBILE_1D) break;                 \
+        case SRLHIP_ENV_MOBILE_2TARGET: SRL_KIND(MODE, SRLHIP_ENV_MOBILE_2TARGET) break;       \
+        default: SRL_KIND(MODE, SRLHIP_ENV_MOBILE_LINE)                                        \
+    }
+    if (h->cfg.rng_mode == SRLHIP_RNG_PHILOX) SRL_MODE(SRLHIP_RNG_PHILOX) else SRL_MODE(SRLHIP_RNG_MT19937)
+#undef SRL_MODE
+#undef SRL_KIND
+#undef SRL_GO
     SRL_HIP_CHECK(h, hipGetLastError());
     return 0;
 }

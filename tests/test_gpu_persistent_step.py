@@ -53,7 +53,7 @@ def test_persistent_env_is_the_launching_env_bit_for_bit(n, rng_mode, tmp_path):
 
 
 def test_persistent_is_refused_where_it_cannot_work():
-    for kind, tweak in ((_lib.ENV_MOBILE, {}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}), (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}),
+    for kind, tweak in ((_lib.ENV_MOBILE, {"io_device": 1}), (_lib.ENV_KUKA_BUTTON, {"io_device": 1}), (_lib.ENV_KUKA_BUTTON, {"num_envs": 8192}),
                         (_lib.ENV_KUKA_RAND, {})):
         cfg = _lib.default_config(kind)
         cfg.num_envs, cfg.rng_mode = 64, _lib.RNG_PHILOX
@@ -64,7 +64,7 @@ def test_persistent_is_refused_where_it_cannot_work():
             h.set_persistent(True)
         h.close()
     with pytest.raises(_lib.SrlHipError):
-        HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "ground_truth"}, persistent=True)
+        HipVecEnv("KukaRandButtonGymEnv-v0", 16, env_kwargs={"srl_model": "ground_truth"}, persistent=True)
     env = HipVecEnv("MobileRobotGymEnv-v0", 16, env_kwargs={"srl_model": "ground_truth"})      # SRLHIP_PERSISTENT unset: plain launches
     assert not env.persistent
     env.close()
@@ -245,3 +245,36 @@ def test_random_call_sequences_on_the_three_per_step_paths():
         assert all(np.array_equal(x, y) for x, y in zip(st[0], st[1])) and all(np.array_equal(x, y) for x, y in zip(st[0], st[2]))
         for h in hs:
             h.close()
+
+
+@pytest.mark.parametrize("env_id, kw, rng_mode, n", [
+    ("MobileRobotGymEnv-v0", {"srl_model": "ground_truth"}, "mt19937", 4096),
+    ("MobileRobotGymEnv-v0", {"srl_model": "ground_truth", "is_discrete": False, "random_target": True}, "philox", 1000),
+    ("MobileRobot1DGymEnv-v0", {"srl_model": "ground_truth"}, "mt19937", 7),
+    ("MobileRobot2TargetGymEnv-v0", {"srl_model": "ground_truth", "shape_reward": True}, "philox", 300),
+    ("MobileRobotLineTargetGymEnv-v0", {"srl_model": "ground_truth", "random_target": True}, "mt19937", 2049),
+])
+def test_persistent_mobile_robot_family(env_id, kw, rng_mode, n, tmp_path, monkeypatch):
+    """the MobileRobot family under persistent stepping (mobile_persist_k): observations, rewards, dones, infos and Monitor files of the
+    launching path bit for bit, across parks; the written-through output form (SRLHIP_PERSIST_STAGED=1) once as well"""
+    if n == 300:
+        monkeypatch.setenv("SRLHIP_PERSIST_STAGED", "1")
+    a = HipVecEnv(env_id, n, seed=4, env_kwargs=kw, rng_mode=rng_mode, log_dir=str(tmp_path / "a"))
+    b = HipVecEnv(env_id, n, seed=4, env_kwargs=kw, rng_mode=rng_mode, log_dir=str(tmp_path / "b"), persistent=True)
+    assert b.persistent
+    assert np.array_equal(a.reset(), b.reset())
+    rs = np.random.RandomState(8)
+    ended = 0
+    for t in range(600):
+        act = rs.randint(a.action_space.n, size=n) if kw.get("is_discrete", True) else rs.uniform(-1, 1, size=(n,) + a.action_space.shape).astype(np.float32)
+        x, y = a.step(act), b.step(act)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), t
+        assert _strip_t(x[3]) == _strip_t(y[3]), t
+        ended += int(x[2].sum())
+        if t % 170 == 60:
+            assert np.array_equal(a._h.get_state(_lib.F_POS_X), b._h.get_state(_lib.F_POS_X))      # park + restart
+    assert ended >= 2 * n
+    a.close(); b.close()
+    for i in (0, n - 1):
+        with open(str(tmp_path / "a" / "{}.monitor.csv".format(i))) as f, open(str(tmp_path / "b" / "{}.monitor.csv".format(i))) as g:
+            assert [r.split(",")[:2] for r in f.read().splitlines()[2:]] == [r.split(",")[:2] for r in g.read().splitlines()[2:]]
