@@ -190,7 +190,7 @@ int srlhip_step_pending(srlhip_handle h);
  * writes the eighth's `done` word; srlhip_step_wait polls those 8 words.  (Where an eighth does not sit on one XCD, or with
  * SRLHIP_PERSIST_STAGED=1, the outputs go through a staging copy in device memory that the eighth's last wavefront copies out.)  What a per-step launch pays every time — the launch itself, the
  * 5.6 KB model table, ~40 state planes, the generators, forward kinematics, the stream synchronisation — is paid once: measured
- * HipVecEnv.step 80 -> 60 us at 4096 envs, 60 -> 44 at 256, 39 -> 28 at 16 (launching path -> persistent; MobileRobot: 19 -> 13 us
+ * HipVecEnv.step 82 -> 62 us at 4096 envs, 61 -> 44 at 256, 39 -> 28 at 16 (launching path -> persistent; MobileRobot: 19 -> 13 us
  * and 13 -> 6 us at 16 envs).  Same kernel
  * code, same arithmetic: results are those of the launching path bit for bit (tests/test_gpu_persistent_step.py).
  * The kernel PARKS (writes the state back and exits) when any other entry point touches the handle, and by itself when no step

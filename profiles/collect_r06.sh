@@ -42,6 +42,8 @@ rm -rf /tmp/prof_ps
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ps -o ps -- python $R/bench.py --per-step > /dev/null 2>&1; cp $(find /tmp/prof_ps -name "*kernel_stats.csv" | head -1) $OUT/per_step_kernel_stats.csv)
 timeout 300 python bench.py --per-step --persistent > $OUT/bench_per_step_persistent.json 2>/dev/null
 timeout 300 python bench.py --per-step --persistent --envs-per-gpu 256 > $OUT/bench_per_step_persistent_256.json 2>/dev/null
+timeout 300 python bench.py --per-step --workload mobile --persistent > $OUT/bench_per_step_mobile_persistent.json 2>/dev/null
+timeout 300 python bench.py --per-step --workload mobile --persistent --envs-per-gpu 16 > $OUT/bench_per_step_mobile_persistent_16.json 2>/dev/null
 [ -f robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so ] && SRLHIP_LIB=$R/robotics-rl-srl_amd/csrc/build/libsrlhip_pprof.so timeout 200 python profiles/probes/persist_timeline.py 4096 2>&1 | grep -v libdrm > $OUT/persist_timeline.txt
 timeout 300 python profiles/encoder_microbench.py > $OUT/encoder_microbench.txt 2>&1
 SRLHIP_ENCODER_L1=f16 timeout 300 python profiles/encoder_microbench.py > $OUT/encoder_microbench_f16_layer1.txt 2>&1
